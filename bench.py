@@ -1,0 +1,219 @@
+"""Training-step throughput of the accelerated audio-tagging path (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+
+One "step" = STFT -> mel -> log -> freq channel -> 2-d CNN forward -> per-sample LSEP -> mean ->
+backward -> (gradient all-reduce over RCCL when N > 1) -> Adam-amsgrad, on one synthetic batch
+already resident in HBM.  Workload = BASELINE.json configs[1]: batch 128 x 10 s @ 44.1 kHz,
+mel_2048_1024_128, 6 blocks base 100 growth 1.5, deep supervision from block 1, dropout 0.7
+(reference README.md:200-214), fp32.  N > 1: one process per GPU (torch.distributed.run), the
+same per-GPU batch on every rank (weak scaling), value = clips of all ranks / max-over-ranks time.
+
+Rank 0 prints one JSON line carrying `roofline` (dominant kernel = the implicit-GEMM conv
+kernel, algorithmic FLOPs over HIP-event time measured inside the timed region) and, at N = 1,
+`cpu_baseline` (the CPU oracle = pure-PyTorch restatement of the reference path, timed on this
+box's host cores on a bounded sample: batch 8 of the same model and clip length).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_F32_MFMA_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md, chip-level parameters
+
+
+class NS(dict):
+    __getattr__ = dict.__getitem__
+
+
+WORKLOADS = {
+    # BASELINE.json configs[1]
+    "cfg2": dict(features="mel_2048_1024_128", blocks=6, base=100, growth=1.5, start=1, dropout=0.7,
+                 batch=128, samples=441000, sr=44100, n_mel=128),
+    # BASELINE.json configs[0] shape (used for quick checks: --workload cfg1)
+    "cfg1": dict(features="mel_1024_512_64", blocks=3, base=32, growth=2, start=1, dropout=0.0,
+                 batch=64, samples=32000, sr=16000, n_mel=64),
+}
+
+
+def make_experiment(w):
+    return NS(config=NS(
+        network=NS(num_conv_blocks=w["blocks"], start_deep_supervision_on=w["start"],
+                   conv_base_depth=w["base"], growth_rate=w["growth"], output_dropout=w["dropout"],
+                   aggregation_type="max"),
+        data=NS(features=w["features"], _input_dim=w["n_mel"], _n_classes=80),
+        train=NS(accumulation_steps=1, optimizer="adam", learning_rate=3e-3, weight_decay=0.0,
+                 scheduler="1cycle_0.0001_0.005", switch_off_augmentations_on=10 ** 9, _save_every=10 ** 9)))
+
+
+def synthetic_batch(w, batch, device, seed):
+    gen = torch.Generator(device=device).manual_seed(seed)
+    signal = 0.1 * torch.randn(batch, w["samples"], 1, device=device, generator=gen)
+    labels = (torch.rand(batch, 80, device=device, generator=gen) < 0.02).float()
+    pos = torch.randint(0, 80, (batch,), device=device, generator=gen)
+    labels[torch.arange(batch, device=device), pos] = 1.0
+    return signal, labels
+
+
+def cpu_baseline(w, steps=3, batch=8):
+    """The oracle (CPU restatement of the reference path) on this box's host cores."""
+    from oracle import ref_torch as oref
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    torch.manual_seed(0)
+    model = oref.TagCNN2d(w["features"], w["blocks"], w["base"], w["growth"], w["start"], 80,
+                          output_dropout=w["dropout"])
+    opt = oref.make_adam(model, 3e-3)
+    signal, labels = synthetic_batch(w, batch, torch.device("cpu"), 99)
+    times = []
+    for i in range(steps + 1):
+        t0 = time.perf_counter()
+        oref.train_step(model, opt, signal, labels)
+        times.append(time.perf_counter() - t0)
+    times = sorted(times[1:])
+    med = times[len(times) // 2]
+    cpu_model = "unknown"
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    cpu_model = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    return dict(value=batch / med, unit="clips/s", cores=cores, kind="port",
+                sample="oracle train step, same model and clip length, batch %d, 1 warm-up + %d timed steps "
+                       "(median), %s" % (batch, steps, cpu_model))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
+    ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (default: the workload's)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timer", action="store_true")
+    ap.add_argument("--kernel-table", action="store_true", help="print per-kernel timing to stderr")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch N > 1 with torch.distributed.run" % (args.gpus, world))
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+
+    from freesound_classification_amd import functional as F
+    from freesound_classification_amd.networks.classifiers import TwoDimensionalCNNClassificationModel
+    from freesound_classification_amd.ops.training import make_step
+
+    w = WORKLOADS[args.workload]
+    batch = args.batch or w["batch"]
+    torch.manual_seed(42)
+    model = TwoDimensionalCNNClassificationModel(make_experiment(w), device=str(device))
+    model.train()
+    model.global_step = 0
+    model.make_optimizer(max_steps=args.steps + args.warmup + 1)
+    signal, labels = synthetic_batch(w, batch, device, 1234 + rank)
+
+    def one_step():
+        model.global_step += 1
+        make_step(model.scheduler, step=model.global_step)
+        return model.training_step(signal, labels)
+
+    for _ in range(args.warmup):
+        one_step()
+    timer = None
+    if not args.no_kernel_timer:
+        timer = F.KernelTimer()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    F.TIMER = timer
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        logits, per, loss = one_step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    F.TIMER = None
+    if world > 1:
+        tmax = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    final_loss = float(loss)
+    if not torch.isfinite(torch.tensor(final_loss)):
+        raise SystemExit("non-finite loss in the benchmark: %r" % final_loss)
+
+    if rank == 0:
+        result = {
+            "metric": "training-step clips/s (STFT->mel->CNN->LSEP)",
+            "value": world * batch * args.steps / elapsed,
+            "unit": "clips/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "%s: batch %d x %.0f s @ %.1f kHz, %s, %d-block 2d CNN base %d growth %g, "
+                                   "LSEP, Adam-amsgrad, dropout %g" % (
+                                       args.workload, batch, w["samples"] / w["sr"], w["sr"] / 1e3, w["features"],
+                                       w["blocks"], w["base"], w["growth"], w["dropout"]),
+                       "global_batch": world * batch, "parallelism": "dp%d" % world},
+            "final_loss": final_loss,
+        }
+        if timer is not None:
+            summ = timer.summary()
+            fam = {}
+            for name, r in summ.items():
+                key = name.split("<")[0]
+                f = fam.setdefault(key, dict(launches=0, flops=0.0, ms=0.0))
+                for k in f:
+                    f[k] += r[k]
+            if args.kernel_table:
+                for name, r in sorted(summ.items(), key=lambda kv: -kv[1]["ms"]):
+                    print("%-36s launches %5d  ms/step %8.3f  TFLOP/s %7.2f" % (
+                        name, r["launches"], r["ms"] / args.steps, r["flops"] / r["ms"] / 1e9), file=sys.stderr)
+            dom_name, dom = max(summ.items(), key=lambda kv: kv[1]["ms"])
+            achieved = dom["flops"] / dom["ms"] / 1e9          # TFLOP/s
+            traffic = None
+            tpath = os.path.join(ROOT, "profiles", "roofline_traffic.json")
+            if os.path.exists(tpath):
+                with open(tpath) as f:
+                    traffic = json.load(f).get(dom_name)
+            result["roofline"] = {
+                "kernel": dom_name, "bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS,
+                "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
+                "launches_per_step": dom["launches"] / args.steps,
+                "avg_launch_ms": dom["ms"] / dom["launches"],
+                "algorithmic_gflop_per_launch": dom["flops"] / dom["launches"] / 1e9,
+                "conv_ms_per_step": {k: v["ms"] / args.steps for k, v in fam.items()},
+                "conv_tflops": {k: v["flops"] / v["ms"] / 1e9 for k, v in fam.items()},
+            }
+        if world == 1 and not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline(w)
+        print(json.dumps(result))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

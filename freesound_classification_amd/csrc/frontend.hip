@@ -1,0 +1,270 @@
+// Fused audio front-end for gfx950: waveform -> reflect-padded Hann frames -> real FFT ->
+// magnitude -> (banded mel projection) -> log -> (frequency-encoding channel).
+// Replaces ops/utils.py:110-127 + networks/classifiers.py:565-582 of the reference, which
+// materialise the complex STFT (226 MB at cfg 2) and its magnitude before the mel conv1d.
+//
+// One workgroup owns FG consecutive frames of one clip.  A frame's n_fft real samples are
+// packed into an n_fft/2-point complex sequence, transformed by an LDS Stockham FFT
+// (radix-4 passes, one radix-2 pass when log2 is odd) whose twiddles are staged in LDS once
+// per workgroup, unpacked to the one-sided spectrum, and reduced to mel bins straight from
+// LDS.  Results are collected in an LDS tile [feature][frame] so the global store writes
+// contiguous runs along the frame axis of the (N, F, frames) output.
+#include "common.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+
+__device__ __forceinline__ float2 cmul(float2 a, float2 b) {
+    return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+
+__global__ void tables_kernel(float* tables, int n_fft) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_fft) return;
+    const double x = (double)i / (double)n_fft;
+    // periodic Hann: 0.5 - 0.5 cos(2 pi i / n_fft)
+    tables[i] = (float)(0.5 - 0.5 * cospi(2.0 * x));
+    double s, c;
+    sincospi(-2.0 * x, &s, &c);
+    tables[n_fft + 2 * i] = (float)c;
+    tables[n_fft + 2 * i + 1] = (float)s;
+}
+
+struct FrontendArgs {
+    const float* wave;
+    long wave_stride;
+    int t;
+    int n_fft, hop, frames;
+    const float* tables;
+    const int* mel_start;
+    const int* mel_len;
+    const float* mel_w;
+    int n_mel;     // number of output features (n_mel in mel mode, n_fft/2+1 in stft mode)
+    float log_eps;
+    int apply_log;
+    float* out;
+    long out_n_stride;
+    int freq_channel;
+    int fg;        // frames per workgroup
+    int tpf;       // threads per frame (power of two, 64..256)
+};
+
+// MEL = true: banded mel projection + log.  MEL = false: (log) magnitude of every bin.
+template <bool MEL>
+__global__ __launch_bounds__(kThreads) void frontend_kernel(FrontendArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int n_fft = a.n_fft, nc = n_fft >> 1, nbins = nc + 1;
+    const int tid = threadIdx.x;
+    const int tpf = a.tpf, fpb = kThreads / tpf;
+    const int sub = tid / tpf, st = tid - sub * tpf;
+    const int clip = blockIdx.y;
+    const int f_base = blockIdx.x * a.fg;
+    const int tile_ld = a.fg + 1;
+
+    float2* tw = reinterpret_cast<float2*>(smem);                 // n_fft entries
+    float2* buf0 = tw + n_fft + (size_t)sub * 2 * nc;             // nc entries
+    float2* buf1 = buf0 + nc;
+    float* tile = smem + 2 * n_fft + (size_t)fpb * 4 * nc;        // n_out x (fg + 1)
+
+    const float* win = a.tables;
+    const float2* tw_g = reinterpret_cast<const float2*>(a.tables + n_fft);
+    for (int i = tid; i < n_fft; i += kThreads) tw[i] = tw_g[i];
+
+    const float* wav = a.wave + (long)clip * a.wave_stride;
+    const int t = a.t;
+    const int iters = (a.fg + fpb - 1) / fpb;
+
+    for (int it = 0; it < iters; ++it) {
+        const int fl = it * fpb + sub;           // frame index inside the group
+        const int f = f_base + fl;
+        const bool live = (fl < a.fg) && (f < a.frames);
+        // ---- load + window + pack (even, odd) -> complex
+        if (live) {
+            const long s0 = (long)f * a.hop - nc;
+            for (int j = st; j < nc; j += tpf) {
+                long i0 = s0 + 2 * j, i1 = i0 + 1;
+                if (i0 < 0) i0 = -i0; else if (i0 >= t) i0 = 2L * (t - 1) - i0;
+                if (i1 < 0) i1 = -i1; else if (i1 >= t) i1 = 2L * (t - 1) - i1;
+                buf0[j] = make_float2(wav[i0] * win[2 * j], wav[i1] * win[2 * j + 1]);
+            }
+        }
+        __syncthreads();
+        // ---- Stockham FFT of nc complex points
+        float2* src = buf0;
+        float2* dst = buf1;
+        int p = 1;
+        const int quarter = nc >> 2;
+        while (p * 4 <= nc) {
+            if (live) {
+                const int tstep = n_fft / (4 * p);
+                for (int b = st; b < quarter; b += tpf) {
+                    const int k = b & (p - 1);
+                    const int j = ((b - k) << 2) + k;
+                    const int m1 = k * tstep;
+                    const float2 u0 = src[b];
+                    const float2 u1 = cmul(src[b + quarter], tw[m1]);
+                    const float2 u2 = cmul(src[b + 2 * quarter], tw[2 * m1]);
+                    const float2 u3 = cmul(src[b + 3 * quarter], tw[3 * m1]);
+                    const float2 v0 = make_float2(u0.x + u2.x, u0.y + u2.y);
+                    const float2 v1 = make_float2(u0.x - u2.x, u0.y - u2.y);
+                    const float2 v2 = make_float2(u1.x + u3.x, u1.y + u3.y);
+                    const float2 v3 = make_float2(u1.y - u3.y, u3.x - u1.x);   // -i (u1 - u3)
+                    dst[j] = make_float2(v0.x + v2.x, v0.y + v2.y);
+                    dst[j + p] = make_float2(v1.x + v3.x, v1.y + v3.y);
+                    dst[j + 2 * p] = make_float2(v0.x - v2.x, v0.y - v2.y);
+                    dst[j + 3 * p] = make_float2(v1.x - v3.x, v1.y - v3.y);
+                }
+            }
+            __syncthreads();
+            float2* tmp = src; src = dst; dst = tmp;
+            p <<= 2;
+        }
+        if (p < nc) {   // one radix-2 pass left (p * 2 == nc)
+            if (live) {
+                const int half = nc >> 1;
+                const int tstep = n_fft / (2 * p);
+                for (int b = st; b < half; b += tpf) {
+                    const int k = b & (p - 1);
+                    const int j = ((b - k) << 1) + k;
+                    const float2 u0 = src[b];
+                    const float2 u1 = cmul(src[b + half], tw[k * tstep]);
+                    dst[j] = make_float2(u0.x + u1.x, u0.y + u1.y);
+                    dst[j + p] = make_float2(u0.x - u1.x, u0.y - u1.y);
+                }
+            }
+            __syncthreads();
+            float2* tmp = src; src = dst; dst = tmp;
+        }
+        // ---- unpack to the one-sided spectrum of the real frame, magnitude -> dst (as floats)
+        float* mag = reinterpret_cast<float*>(dst);
+        if (live) {
+            for (int k = st; k < nbins; k += tpf) {
+                const float2 zk = src[k & (nc - 1)];
+                const float2 zr = src[(nc - k) & (nc - 1)];
+                // even part E = (zk + conj(zr)) / 2, odd part O = (zk - conj(zr)) / (2i)
+                const float2 e = make_float2(0.5f * (zk.x + zr.x), 0.5f * (zk.y - zr.y));
+                const float2 o = make_float2(0.5f * (zk.y + zr.y), -0.5f * (zk.x - zr.x));
+                const float2 wo = cmul(tw[k], o);
+                const float re = e.x + wo.x, im = e.y + wo.y;
+                mag[k] = sqrtf(re * re + im * im);
+            }
+        }
+        __syncthreads();
+        if (live) {
+            if (MEL) {
+                for (int m = st; m < a.n_mel; m += tpf) {
+                    const int s = a.mel_start[m], len = a.mel_len[m];
+                    float acc = 0.f;
+                    for (int j = 0; j < len; ++j) acc = fmaf(a.mel_w[(long)j * a.n_mel + m], mag[s + j], acc);
+                    tile[m * tile_ld + fl] = logf(acc + a.log_eps);
+                }
+            } else {
+                for (int k = st; k < nbins; k += tpf)
+                    tile[k * tile_ld + fl] = a.apply_log ? logf(mag[k] + a.log_eps) : mag[k];
+            }
+        }
+        __syncthreads();
+    }
+    // ---- coalesced store of the tile: rows = features, contiguous along frames
+    const int fvalid = min(a.fg, a.frames - f_base);
+    float* dst_g = a.out + (long)clip * a.out_n_stride;
+    const int total = a.n_mel * fvalid;
+    for (int i = tid; i < total; i += kThreads) {
+        const int row = i / fvalid, fl = i - row * fvalid;
+        dst_g[(long)row * a.frames + f_base + fl] = tile[row * tile_ld + fl];
+    }
+    if (a.freq_channel) {
+        // torch.linspace(-1, 1, h): symmetric evaluation in fp32
+        float* fq = dst_g + (long)a.n_mel * a.frames;
+        const int h = a.n_mel;
+        const float step = 2.0f / (float)(h - 1);
+        for (int i = tid; i < total; i += kThreads) {
+            const int row = i / fvalid, fl = i - row * fvalid;
+            const float v = (row < h / 2) ? (-1.0f + step * (float)row)
+                                          : (1.0f - step * (float)(h - 1 - row));
+            fq[(long)row * a.frames + f_base + fl] = v;
+        }
+    }
+}
+
+bool pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
+
+int launch(const FrontendArgs& base, bool mel, int n, hipStream_t stream) {
+    FrontendArgs a = base;
+    const int nc = a.n_fft / 2;
+    int tpf = nc / 4;
+    if (tpf < 64) tpf = 64;
+    if (tpf > kThreads) tpf = kThreads;
+    a.tpf = tpf;
+    const int fpb = kThreads / tpf;
+    int fg = 32;
+    auto lds_bytes = [&](int g) {
+        return sizeof(float) * ((size_t)2 * a.n_fft + (size_t)fpb * 4 * nc + (size_t)a.n_mel * (g + 1));
+    };
+    while (fg > fpb && lds_bytes(fg) > 64 * 1024) fg >>= 1;
+    if (fg < fpb) fg = fpb;
+    const size_t lds = lds_bytes(fg);
+    FSC_CHECK_ARG(lds <= 160 * 1024, "frontend: LDS tile of %zu bytes does not fit (n_fft=%d, features=%d)",
+                  lds, a.n_fft, a.n_mel);
+    a.fg = fg;
+    dim3 grid(fsc::ceil_div(a.frames, fg), n);
+    if (mel) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&frontend_kernel<true>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(frontend_kernel<true>, grid, dim3(kThreads), lds, stream, a);
+    } else {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&frontend_kernel<false>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(frontend_kernel<false>, grid, dim3(kThreads), lds, stream, a);
+    }
+    FSC_LAUNCH_CHECK("fsc_frontend");
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t fsc_frontend_table_floats(int n_fft) { return (size_t)3 * n_fft; }
+
+int fsc_frontend_tables_init(float* tables, int n_fft, fsc_stream_t stream) {
+    FSC_CHECK_ARG(tables && pow2(n_fft) && n_fft >= 64 && n_fft <= 4096,
+                  "fsc_frontend_tables_init: n_fft=%d must be a power of two in [64, 4096]", n_fft);
+    hipLaunchKernelGGL(tables_kernel, dim3(fsc::ceil_div(n_fft, 256)), dim3(256), 0,
+                       fsc::as_stream(stream), tables, n_fft);
+    FSC_LAUNCH_CHECK("fsc_frontend_tables_init");
+    return 0;
+}
+
+int fsc_frontend_logmel_fwd(const float* wave, int n, int t, long wave_stride, int n_fft, int hop,
+                            const float* tables, const int* mel_start, const int* mel_len,
+                            const float* mel_w, int n_mel, int max_band, float log_eps, float* out,
+                            long out_n_stride, int freq_channel, fsc_stream_t stream) {
+    FSC_CHECK_ARG(wave && tables && mel_start && mel_len && mel_w && out, "fsc_frontend_logmel_fwd: null pointer");
+    FSC_CHECK_ARG(pow2(n_fft) && n_fft >= 64 && n_fft <= 4096, "fsc_frontend_logmel_fwd: bad n_fft %d", n_fft);
+    FSC_CHECK_ARG(hop > 0 && n > 0 && n_mel > 0 && max_band >= 0, "fsc_frontend_logmel_fwd: bad sizes");
+    FSC_CHECK_ARG(t > n_fft / 2, "fsc_frontend_logmel_fwd: reflect padding needs T (%d) > n_fft/2 (%d)", t, n_fft / 2);
+    FrontendArgs a{};
+    a.wave = wave; a.wave_stride = wave_stride; a.t = t; a.n_fft = n_fft; a.hop = hop;
+    a.frames = 1 + t / hop; a.tables = tables; a.mel_start = mel_start; a.mel_len = mel_len;
+    a.mel_w = mel_w; a.n_mel = n_mel; a.log_eps = log_eps; a.apply_log = 1; a.out = out;
+    a.out_n_stride = out_n_stride; a.freq_channel = freq_channel;
+    return launch(a, true, n, fsc::as_stream(stream));
+}
+
+int fsc_frontend_stft_fwd(const float* wave, int n, int t, long wave_stride, int n_fft, int hop,
+                          const float* tables, int apply_log, float log_eps, float* out,
+                          long out_n_stride, int freq_channel, fsc_stream_t stream) {
+    FSC_CHECK_ARG(wave && tables && out, "fsc_frontend_stft_fwd: null pointer");
+    FSC_CHECK_ARG(pow2(n_fft) && n_fft >= 64 && n_fft <= 4096, "fsc_frontend_stft_fwd: bad n_fft %d", n_fft);
+    FSC_CHECK_ARG(hop > 0 && n > 0, "fsc_frontend_stft_fwd: bad sizes");
+    FSC_CHECK_ARG(t > n_fft / 2, "fsc_frontend_stft_fwd: reflect padding needs T (%d) > n_fft/2 (%d)", t, n_fft / 2);
+    FrontendArgs a{};
+    a.wave = wave; a.wave_stride = wave_stride; a.t = t; a.n_fft = n_fft; a.hop = hop;
+    a.frames = 1 + t / hop; a.tables = tables; a.n_mel = n_fft / 2 + 1; a.log_eps = log_eps;
+    a.apply_log = apply_log; a.out = out; a.out_n_stride = out_n_stride; a.freq_channel = freq_channel;
+    return launch(a, false, n, fsc::as_stream(stream));
+}
+
+}  // extern "C"

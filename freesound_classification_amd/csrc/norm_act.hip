@@ -1,0 +1,447 @@
+// Batch normalisation (train + eval) fused with the per-channel PReLU and residual add that
+// follow it in the reference's blocks (networks/classifiers.py:524,533-534, 37-104, 543-546).
+// All kernels are HBM-bound streaming passes over (N, C, HW) fp32 activations:
+//   stats    : 1 read of x                       -> per-channel mean / invstd / scale / shift
+//   fwd      : 1 read of x (+ residual), 1 write -> y = prelu(x*scale + shift + residual)
+//   bwd      : reduce pass (reads dy, x, residual) + apply pass (reads the same, writes dx,
+//              dresidual); the pre-activation is recomputed instead of stored.
+// Per-channel reductions: fp32 per-thread partials on pivot-shifted data, fp64 across threads,
+// blocks and splits (deterministic two-stage reduce, no atomics on the statistics).
+#include "common.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kMaxSplit = 64;
+
+// workspace layout (doubles): partial[c][split][4], then coef[c][4] floats
+struct Partials {
+    double* part;   // c * kMaxSplit * 4
+    float* coef;    // c * 4
+};
+
+__host__ __device__ inline size_t part_doubles(int c) { return (size_t)c * kMaxSplit * 4; }
+
+inline Partials carve(void* ws, int c) {
+    Partials p;
+    p.part = reinterpret_cast<double*>(ws);
+    p.coef = reinterpret_cast<float*>(p.part + part_doubles(c));
+    return p;
+}
+
+// ---------------------------------------------------------------- statistics
+__global__ __launch_bounds__(kThreads) void stats_partial_kernel(
+    const float* __restrict__ x, int n, int c, long hw, int nsplit, double* __restrict__ part) {
+    __shared__ double scratch[kThreads / 64];
+    const int ch = blockIdx.x, sp = blockIdx.y;
+    const float pivot = x[(long)ch * hw];
+    float s1 = 0.f, s2 = 0.f;
+    const bool vec = (hw & 3) == 0;
+    for (int b = sp; b < n; b += nsplit) {
+        const float* p = x + ((long)b * c + ch) * hw;
+        if (vec) {
+            const float4* p4 = reinterpret_cast<const float4*>(p);
+            const long n4 = hw >> 2;
+            for (long i = threadIdx.x; i < n4; i += kThreads) {
+                const float4 v = p4[i];
+                const float a0 = v.x - pivot, a1 = v.y - pivot, a2 = v.z - pivot, a3 = v.w - pivot;
+                s1 += (a0 + a1) + (a2 + a3);
+                s2 += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
+            }
+        } else {
+            for (long i = threadIdx.x; i < hw; i += kThreads) {
+                const float a0 = p[i] - pivot;
+                s1 += a0;
+                s2 += a0 * a0;
+            }
+        }
+    }
+    const double t1 = fsc::block_sum<double, kThreads / 64>((double)s1, scratch);
+    const double t2 = fsc::block_sum<double, kThreads / 64>((double)s2, scratch);
+    if (threadIdx.x == 0) {
+        double* o = part + ((size_t)ch * kMaxSplit + sp) * 4;
+        o[0] = t1;
+        o[1] = t2;
+    }
+}
+
+// HW == 1: x is (N, C); one thread per channel, coalesced across channels.
+__global__ void stats_rows_kernel(const float* __restrict__ x, int n, int c, double* __restrict__ part) {
+    const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ch >= c) return;
+    const float pivot = x[ch];
+    double s1 = 0.0, s2 = 0.0;
+    for (int b = 0; b < n; ++b) {
+        const double a = (double)(x[(long)b * c + ch] - pivot);
+        s1 += a;
+        s2 += a * a;
+    }
+    double* o = part + (size_t)ch * kMaxSplit * 4;
+    o[0] = s1;
+    o[1] = s2;
+}
+
+__global__ void stats_finalize_kernel(const float* __restrict__ x, int c, long hw, double count, int nsplit,
+                                      const double* __restrict__ part, const float* __restrict__ gamma,
+                                      const float* __restrict__ beta, float eps, float momentum,
+                                      float* running_mean, float* running_var, float* save_mean,
+                                      float* save_invstd, float* scale, float* shift) {
+    const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ch >= c) return;
+    double s1 = 0.0, s2 = 0.0;
+    for (int s = 0; s < nsplit; ++s) {
+        s1 += part[((size_t)ch * kMaxSplit + s) * 4];
+        s2 += part[((size_t)ch * kMaxSplit + s) * 4 + 1];
+    }
+    const double pivot = (double)x[(long)ch * hw];
+    const double m1 = s1 / count;
+    const double mean = pivot + m1;
+    double var = s2 / count - m1 * m1;
+    if (var < 0.0) var = 0.0;
+    const double invstd = 1.0 / sqrt(var + (double)eps);
+    if (running_mean) {
+        const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+        running_mean[ch] = (float)((1.0 - momentum) * running_mean[ch] + momentum * mean);
+        running_var[ch] = (float)((1.0 - momentum) * running_var[ch] + momentum * unbiased);
+    }
+    save_mean[ch] = (float)mean;
+    save_invstd[ch] = (float)invstd;
+    const float g = gamma ? gamma[ch] : 1.f, b = beta ? beta[ch] : 0.f;
+    const float sc = g * (float)invstd;
+    scale[ch] = sc;
+    shift[ch] = b - (float)mean * sc;
+}
+
+__global__ void eval_prepare_kernel(int c, const float* gamma, const float* beta, const float* rm,
+                                    const float* rv, float eps, float* scale, float* shift) {
+    const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ch >= c) return;
+    const float invstd = 1.0f / sqrtf(rv[ch] + eps);
+    const float sc = (gamma ? gamma[ch] : 1.f) * invstd;
+    scale[ch] = sc;
+    shift[ch] = (beta ? beta[ch] : 0.f) - rm[ch] * sc;
+}
+
+// ---------------------------------------------------------------- forward apply
+__device__ __forceinline__ float act(float z, float alpha, bool has_alpha) {
+    return (has_alpha && !(z > 0.f)) ? alpha * z : z;
+}
+
+// one (n, c) plane per blockIdx.x, blockIdx.y strides over the plane
+__global__ __launch_bounds__(kThreads) void fwd_plane_kernel(
+    const float* __restrict__ x, const float* __restrict__ res, const float* __restrict__ scale,
+    const float* __restrict__ shift, const float* __restrict__ alpha, float* __restrict__ y, int c, long hw) {
+    const long plane = blockIdx.x;
+    const int ch = (int)(plane % c);
+    const float sc = scale[ch], sh = shift[ch];
+    const bool has_alpha = alpha != nullptr;
+    const float al = has_alpha ? alpha[ch] : 0.f;
+    const float* px = x + plane * hw;
+    const float* pr = res ? res + plane * hw : nullptr;
+    float* py = y + plane * hw;
+    if ((hw & 3) == 0) {
+        const long n4 = hw >> 2;
+        for (long i = (long)blockIdx.y * kThreads + threadIdx.x; i < n4; i += (long)gridDim.y * kThreads) {
+            float4 v = reinterpret_cast<const float4*>(px)[i];
+            float4 z = make_float4(fmaf(v.x, sc, sh), fmaf(v.y, sc, sh), fmaf(v.z, sc, sh), fmaf(v.w, sc, sh));
+            if (pr) {
+                const float4 r = reinterpret_cast<const float4*>(pr)[i];
+                z.x += r.x; z.y += r.y; z.z += r.z; z.w += r.w;
+            }
+            z.x = act(z.x, al, has_alpha); z.y = act(z.y, al, has_alpha);
+            z.z = act(z.z, al, has_alpha); z.w = act(z.w, al, has_alpha);
+            reinterpret_cast<float4*>(py)[i] = z;
+        }
+    } else {
+        for (long i = (long)blockIdx.y * kThreads + threadIdx.x; i < hw; i += (long)gridDim.y * kThreads) {
+            float z = fmaf(px[i], sc, sh);
+            if (pr) z += pr[i];
+            py[i] = act(z, al, has_alpha);
+        }
+    }
+}
+
+// small planes: flat indexing
+__global__ void fwd_flat_kernel(const float* __restrict__ x, const float* __restrict__ res,
+                                const float* __restrict__ scale, const float* __restrict__ shift,
+                                const float* __restrict__ alpha, float* __restrict__ y, int c, long hw, long total) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int ch = (int)((i / hw) % c);
+        float z = fmaf(x[i], scale[ch], shift[ch]);
+        if (res) z += res[i];
+        y[i] = (alpha && !(z > 0.f)) ? alpha[ch] * z : z;
+    }
+}
+
+// ---------------------------------------------------------------- backward
+struct BwdArgs {
+    const float* dy;        // may be null (treated as zero)
+    const float* gmax_dy;   // (N*C) gradient of a global-max-pool head on the output, may be null
+    const int* gmax_idx;    // (N*C) argmax inside the plane
+    const float* x;
+    const float* res;
+    const float* mean;
+    const float* invstd;
+    const float* gamma;
+    const float* beta;
+    const float* alpha;
+    int n, c;
+    long hw;
+};
+
+__device__ __forceinline__ float upstream(const BwdArgs& a, const float* pdy, long i, float gval, long gpos) {
+    float g = pdy ? pdy[i] : 0.f;
+    if (i == gpos) g += gval;
+    return g;
+}
+
+// partial sums per (channel, split): [0]=sum dz, [1]=sum dz*xhat, [2]=sum dy*min(z,0)
+__global__ __launch_bounds__(kThreads) void bwd_partial_kernel(BwdArgs a, int nsplit, double* __restrict__ part) {
+    __shared__ double scratch[kThreads / 64];
+    const int ch = blockIdx.x, sp = blockIdx.y;
+    const float mean = a.mean[ch], invstd = a.invstd[ch];
+    const float g = a.gamma ? a.gamma[ch] : 1.f, b = a.beta ? a.beta[ch] : 0.f;
+    const bool has_alpha = a.alpha != nullptr;
+    const float al = has_alpha ? a.alpha[ch] : 1.f;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+    for (int nb = sp; nb < a.n; nb += nsplit) {
+        const long plane = (long)nb * a.c + ch;
+        const float* px = a.x + plane * a.hw;
+        const float* pr = a.res ? a.res + plane * a.hw : nullptr;
+        const float* pdy = a.dy ? a.dy + plane * a.hw : nullptr;
+        const float gval = a.gmax_dy ? a.gmax_dy[plane] : 0.f;
+        const long gpos = a.gmax_dy ? (long)a.gmax_idx[plane] : -1;
+        for (long i = threadIdx.x; i < a.hw; i += kThreads) {
+            const float xh = (px[i] - mean) * invstd;
+            float z = fmaf(xh, g, b);
+            if (pr) z += pr[i];
+            const float up = upstream(a, pdy, i, gval, gpos);
+            const bool neg = has_alpha && !(z > 0.f);
+            const float dz = neg ? al * up : up;
+            s0 += dz;
+            s1 += dz * xh;
+            if (neg) s2 += up * z;
+        }
+    }
+    const double t0 = fsc::block_sum<double, kThreads / 64>((double)s0, scratch);
+    const double t1 = fsc::block_sum<double, kThreads / 64>((double)s1, scratch);
+    const double t2 = fsc::block_sum<double, kThreads / 64>((double)s2, scratch);
+    if (threadIdx.x == 0) {
+        double* o = part + ((size_t)ch * kMaxSplit + sp) * 4;
+        o[0] = t0; o[1] = t1; o[2] = t2;
+    }
+}
+
+// HW == 1 version: thread per channel
+__global__ void bwd_rows_kernel(BwdArgs a, double* __restrict__ part) {
+    const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ch >= a.c) return;
+    const float mean = a.mean[ch], invstd = a.invstd[ch];
+    const float g = a.gamma ? a.gamma[ch] : 1.f, b = a.beta ? a.beta[ch] : 0.f;
+    const bool has_alpha = a.alpha != nullptr;
+    const float al = has_alpha ? a.alpha[ch] : 1.f;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+    for (int nb = 0; nb < a.n; ++nb) {
+        const long i = (long)nb * a.c + ch;
+        const float xh = (a.x[i] - mean) * invstd;
+        float z = fmaf(xh, g, b);
+        if (a.res) z += a.res[i];
+        const float up = a.dy ? a.dy[i] : 0.f;
+        const bool neg = has_alpha && !(z > 0.f);
+        const float dz = neg ? al * up : up;
+        s0 += dz; s1 += (double)dz * xh;
+        if (neg) s2 += (double)up * z;
+    }
+    double* o = part + (size_t)ch * kMaxSplit * 4;
+    o[0] = s0; o[1] = s1; o[2] = s2;
+}
+
+__global__ void bwd_finalize_kernel(int c, double count, int nsplit, const double* __restrict__ part,
+                                    float* dgamma, float* dbeta, float* dalpha, float* coef, float* dx_chan_sum) {
+    const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ch >= c) return;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+    for (int s = 0; s < nsplit; ++s) {
+        const double* p = part + ((size_t)ch * kMaxSplit + s) * 4;
+        s0 += p[0]; s1 += p[1]; s2 += p[2];
+    }
+    if (dbeta) dbeta[ch] = (float)s0;
+    if (dgamma) dgamma[ch] = (float)s1;
+    if (dalpha) dalpha[ch] = (float)s2;
+    coef[ch * 2] = (float)(s0 / count);
+    coef[ch * 2 + 1] = (float)(s1 / count);
+    if (dx_chan_sum) dx_chan_sum[ch] = 0.f;
+}
+
+__global__ __launch_bounds__(kThreads) void bwd_apply_plane_kernel(BwdArgs a, const float* __restrict__ coef,
+                                                                    float* __restrict__ dx, float* __restrict__ dres,
+                                                                    float* dx_chan_sum) {
+    __shared__ float scratch[kThreads / 64];
+    const long plane = blockIdx.x;
+    const int ch = (int)(plane % a.c);
+    const float mean = a.mean[ch], invstd = a.invstd[ch];
+    const float g = a.gamma ? a.gamma[ch] : 1.f, b = a.beta ? a.beta[ch] : 0.f;
+    const bool has_alpha = a.alpha != nullptr;
+    const float al = has_alpha ? a.alpha[ch] : 1.f;
+    const float c1 = coef[ch * 2], c2 = coef[ch * 2 + 1];
+    const float k = g * invstd;
+    const float* px = a.x + plane * a.hw;
+    const float* pr = a.res ? a.res + plane * a.hw : nullptr;
+    const float* pdy = a.dy ? a.dy + plane * a.hw : nullptr;
+    const float gval = a.gmax_dy ? a.gmax_dy[plane] : 0.f;
+    const long gpos = a.gmax_dy ? (long)a.gmax_idx[plane] : -1;
+    float* pdx = dx + plane * a.hw;
+    float* pdr = dres ? dres + plane * a.hw : nullptr;
+    float acc = 0.f;
+    for (long i = (long)blockIdx.y * kThreads + threadIdx.x; i < a.hw; i += (long)gridDim.y * kThreads) {
+        const float xh = (px[i] - mean) * invstd;
+        float z = fmaf(xh, g, b);
+        if (pr) z += pr[i];
+        const float up = upstream(a, pdy, i, gval, gpos);
+        const float dz = (has_alpha && !(z > 0.f)) ? al * up : up;
+        const float d = k * (dz - c1 - xh * c2);
+        pdx[i] = d;
+        if (pdr) pdr[i] = dz;
+        acc += d;
+    }
+    if (dx_chan_sum) {
+        const float t = fsc::block_sum<float, kThreads / 64>(acc, scratch);
+        if (threadIdx.x == 0) atomicAdd(dx_chan_sum + ch, t);
+    }
+}
+
+__global__ void bwd_apply_flat_kernel(BwdArgs a, const float* __restrict__ coef, float* __restrict__ dx,
+                                      float* __restrict__ dres, float* dx_chan_sum, long total) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long plane = i / a.hw;
+        const int ch = (int)(plane % a.c);
+        const float invstd = a.invstd[ch];
+        const float g = a.gamma ? a.gamma[ch] : 1.f, b = a.beta ? a.beta[ch] : 0.f;
+        const float xh = (a.x[i] - a.mean[ch]) * invstd;
+        float z = fmaf(xh, g, b);
+        if (a.res) z += a.res[i];
+        float up = a.dy ? a.dy[i] : 0.f;
+        if (a.gmax_dy && (i - plane * a.hw) == (long)a.gmax_idx[plane]) up += a.gmax_dy[plane];
+        const float dz = (a.alpha && !(z > 0.f)) ? a.alpha[ch] * up : up;
+        const float d = g * invstd * (dz - coef[ch * 2] - xh * coef[ch * 2 + 1]);
+        dx[i] = d;
+        if (dres) dres[i] = dz;
+        if (dx_chan_sum) atomicAdd(dx_chan_sum + ch, d);
+    }
+}
+
+int pick_split(int n, int c, long hw) {
+    // enough blocks to fill 256 CUs a few times over, bounded by the batch and the workspace
+    long want = (256L * 8 + c - 1) / c;
+    long by_work = ((long)n * hw + 16383) / 16384;   // >= 16K elements per block
+    long s = want < by_work ? want : by_work;
+    if (s > n) s = n;
+    if (s > kMaxSplit) s = kMaxSplit;
+    if (s < 1) s = 1;
+    return (int)s;
+}
+
+int plane_grid_y(long hw) {
+    long per = (hw & 3) == 0 ? hw / 4 : hw;
+    long gy = (per + kThreads * 4 - 1) / (kThreads * 4);
+    if (gy < 1) gy = 1;
+    if (gy > 64) gy = 64;
+    return (int)gy;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t fsc_bn_workspace_bytes(int c) {
+    return part_doubles(c) * sizeof(double) + (size_t)c * 4 * sizeof(float);
+}
+
+int fsc_bn_train_stats(const float* x, int n, int c, long hw, const float* gamma, const float* beta, float eps,
+                       float momentum, float* running_mean, float* running_var, float* save_mean,
+                       float* save_invstd, float* scale, float* shift, void* workspace, fsc_stream_t stream) {
+    FSC_CHECK_ARG(x && save_mean && save_invstd && scale && shift && workspace, "fsc_bn_train_stats: null pointer");
+    FSC_CHECK_ARG(n > 0 && c > 0 && hw > 0, "fsc_bn_train_stats: bad shape (%d, %d, %ld)", n, c, hw);
+    FSC_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr), "fsc_bn_train_stats: running stats must come in pairs");
+    hipStream_t st = fsc::as_stream(stream);
+    Partials p = carve(workspace, c);
+    int nsplit = 1;
+    if (hw == 1) {
+        hipLaunchKernelGGL(stats_rows_kernel, dim3(fsc::ceil_div(c, 128)), dim3(128), 0, st, x, n, c, p.part);
+    } else {
+        nsplit = pick_split(n, c, hw);
+        hipLaunchKernelGGL(stats_partial_kernel, dim3(c, nsplit), dim3(kThreads), 0, st, x, n, c, hw, nsplit, p.part);
+    }
+    hipLaunchKernelGGL(stats_finalize_kernel, dim3(fsc::ceil_div(c, 128)), dim3(128), 0, st, x, c, hw,
+                       (double)n * (double)hw, nsplit, p.part, gamma, beta, eps, momentum, running_mean,
+                       running_var, save_mean, save_invstd, scale, shift);
+    FSC_LAUNCH_CHECK("fsc_bn_train_stats");
+    return 0;
+}
+
+int fsc_bn_eval_prepare(int c, const float* gamma, const float* beta, const float* running_mean,
+                        const float* running_var, float eps, float* scale, float* shift, fsc_stream_t stream) {
+    FSC_CHECK_ARG(running_mean && running_var && scale && shift && c > 0, "fsc_bn_eval_prepare: bad arguments");
+    hipLaunchKernelGGL(eval_prepare_kernel, dim3(fsc::ceil_div(c, 128)), dim3(128), 0, fsc::as_stream(stream), c,
+                       gamma, beta, running_mean, running_var, eps, scale, shift);
+    FSC_LAUNCH_CHECK("fsc_bn_eval_prepare");
+    return 0;
+}
+
+int fsc_bn_act_fwd(const float* x, const float* residual, const float* scale, const float* shift,
+                   const float* alpha, float* y, int n, int c, long hw, fsc_stream_t stream) {
+    FSC_CHECK_ARG(x && scale && shift && y, "fsc_bn_act_fwd: null pointer");
+    FSC_CHECK_ARG(n > 0 && c > 0 && hw > 0, "fsc_bn_act_fwd: bad shape (%d, %d, %ld)", n, c, hw);
+    hipStream_t st = fsc::as_stream(stream);
+    const long total = (long)n * c * hw;
+    if (hw >= 512) {
+        hipLaunchKernelGGL(fwd_plane_kernel, dim3((unsigned)((long)n * c), plane_grid_y(hw)), dim3(kThreads), 0, st, x,
+                           residual, scale, shift, alpha, y, c, hw);
+    } else {
+        long blocks = (total + 255) / 256;
+        if (blocks > 8192) blocks = 8192;
+        hipLaunchKernelGGL(fwd_flat_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, residual, scale, shift,
+                           alpha, y, c, hw, total);
+    }
+    FSC_LAUNCH_CHECK("fsc_bn_act_fwd");
+    return 0;
+}
+
+int fsc_bn_act_bwd(const float* dy, const float* gmax_dy, const int* gmax_idx, const float* x,
+                   const float* residual, const float* save_mean, const float* save_invstd,
+                   const float* gamma, const float* beta, const float* alpha, float* dx, float* dresidual,
+                   float* dgamma, float* dbeta, float* dalpha, float* dx_chan_sum, int n, int c, long hw,
+                   void* workspace, fsc_stream_t stream) {
+    FSC_CHECK_ARG(x && save_mean && save_invstd && dx && workspace, "fsc_bn_act_bwd: null pointer");
+    FSC_CHECK_ARG(dy || gmax_dy, "fsc_bn_act_bwd: no upstream gradient");
+    FSC_CHECK_ARG((gmax_dy == nullptr) == (gmax_idx == nullptr), "fsc_bn_act_bwd: gmax_dy / gmax_idx must come in pairs");
+    FSC_CHECK_ARG(n > 0 && c > 0 && hw > 0, "fsc_bn_act_bwd: bad shape (%d, %d, %ld)", n, c, hw);
+    FSC_CHECK_ARG((alpha == nullptr) == (dalpha == nullptr) || dalpha == nullptr, "fsc_bn_act_bwd: dalpha without alpha");
+    hipStream_t st = fsc::as_stream(stream);
+    Partials p = carve(workspace, c);
+    BwdArgs a{dy, gmax_dy, gmax_idx, x, residual, save_mean, save_invstd, gamma, beta, alpha, n, c, hw};
+    int nsplit = 1;
+    if (hw == 1) {
+        FSC_CHECK_ARG(gmax_dy == nullptr, "fsc_bn_act_bwd: global-max gradient needs hw > 1");
+        hipLaunchKernelGGL(bwd_rows_kernel, dim3(fsc::ceil_div(c, 128)), dim3(128), 0, st, a, p.part);
+    } else {
+        nsplit = pick_split(n, c, hw);
+        hipLaunchKernelGGL(bwd_partial_kernel, dim3(c, nsplit), dim3(kThreads), 0, st, a, nsplit, p.part);
+    }
+    hipLaunchKernelGGL(bwd_finalize_kernel, dim3(fsc::ceil_div(c, 128)), dim3(128), 0, st, c, (double)n * (double)hw,
+                       nsplit, p.part, dgamma, dbeta, dalpha, p.coef, dx_chan_sum);
+    const long total = (long)n * c * hw;
+    if (hw >= 512) {
+        hipLaunchKernelGGL(bwd_apply_plane_kernel, dim3((unsigned)((long)n * c), plane_grid_y(hw)), dim3(kThreads), 0,
+                           st, a, p.coef, dx, dresidual, dx_chan_sum);
+    } else {
+        long blocks = (total + 255) / 256;
+        if (blocks > 8192) blocks = 8192;
+        hipLaunchKernelGGL(bwd_apply_flat_kernel, dim3((unsigned)blocks), dim3(256), 0, st, a, p.coef, dx, dresidual,
+                           dx_chan_sum, total);
+    }
+    FSC_LAUNCH_CHECK("fsc_bn_act_bwd");
+    return 0;
+}
+
+}  // extern "C"

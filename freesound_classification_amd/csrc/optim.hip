@@ -1,0 +1,116 @@
+// Multi-tensor optimizer steps (HBM-bound: Adam-amsgrad streams 5 reads + 4 writes per
+// parameter).  Reference ops/training.py:9-12 builds torch.optim.Adam(amsgrad=True) and
+// torch.optim.SGD(momentum=0.9, nesterov=True); the arithmetic below follows torch's
+// single-tensor update rules (weight decay folded into the gradient, lerp-style first moment).
+// Tensor tables travel in kernel arguments, kBatch tensors per launch, so nothing has to stay
+// alive on the host and no device-side table is allocated.
+#include "common.h"
+
+namespace {
+
+constexpr int kBatch = 24;
+constexpr int kChunk = 16384;    // elements per workgroup
+constexpr int kThreads = 256;
+
+struct Table {
+    fsc_opt_tensor t[kBatch];
+    int chunk_start[kBatch + 1];
+    int n;
+};
+
+struct AdamHyper {
+    float beta1, beta2, eps, weight_decay, step_size, inv_bc2_sqrt, grad_scale;
+};
+
+struct SgdHyper {
+    float lr, momentum, weight_decay, grad_scale;
+    int first_step;
+};
+
+__device__ __forceinline__ int find_tensor(const Table& tb, int chunk) {
+    int i = 0;
+    while (i + 1 < tb.n && chunk >= tb.chunk_start[i + 1]) ++i;
+    return i;
+}
+
+__global__ __launch_bounds__(kThreads) void adam_kernel(Table tb, AdamHyper h) {
+    const int ti = find_tensor(tb, blockIdx.x);
+    const fsc_opt_tensor t = tb.t[ti];
+    const long base = (long)(blockIdx.x - tb.chunk_start[ti]) * kChunk;
+    const long end = base + kChunk < t.count ? base + kChunk : t.count;
+    for (long i = base + threadIdx.x; i < end; i += kThreads) {
+        const float p = t.param[i];
+        float g = t.grad[i] * h.grad_scale;
+        if (h.weight_decay != 0.f) g = fmaf(h.weight_decay, p, g);
+        float m = t.state0[i];
+        m = m + (1.f - h.beta1) * (g - m);
+        float v = t.state1[i];
+        v = fmaf(v, h.beta2, (1.f - h.beta2) * g * g);
+        const float vmax = fmaxf(t.state2[i], v);
+        const float denom = sqrtf(vmax) * h.inv_bc2_sqrt + h.eps;
+        t.state0[i] = m;
+        t.state1[i] = v;
+        t.state2[i] = vmax;
+        t.param[i] = p - h.step_size * (m / denom);
+    }
+}
+
+__global__ __launch_bounds__(kThreads) void sgd_kernel(Table tb, SgdHyper h) {
+    const int ti = find_tensor(tb, blockIdx.x);
+    const fsc_opt_tensor t = tb.t[ti];
+    const long base = (long)(blockIdx.x - tb.chunk_start[ti]) * kChunk;
+    const long end = base + kChunk < t.count ? base + kChunk : t.count;
+    for (long i = base + threadIdx.x; i < end; i += kThreads) {
+        const float p = t.param[i];
+        float g = t.grad[i] * h.grad_scale;
+        if (h.weight_decay != 0.f) g = fmaf(h.weight_decay, p, g);
+        const float buf = h.first_step ? g : fmaf(t.state0[i], h.momentum, g);
+        t.state0[i] = buf;
+        g = fmaf(h.momentum, buf, g);
+        t.param[i] = p - h.lr * g;
+    }
+}
+
+template <typename Hyper, typename Kernel>
+int run(const fsc_opt_tensor* tensors, int n_tensors, const Hyper& h, Kernel kernel, bool need_all_state,
+        hipStream_t st, const char* name) {
+    for (int first = 0; first < n_tensors; first += kBatch) {
+        Table tb{};
+        tb.n = n_tensors - first < kBatch ? n_tensors - first : kBatch;
+        int chunks = 0;
+        for (int i = 0; i < tb.n; ++i) {
+            const fsc_opt_tensor& t = tensors[first + i];
+            FSC_CHECK_ARG(t.param && t.grad && t.state0 && t.count > 0, "%s: tensor %d has null pointers or zero size", name, first + i);
+            FSC_CHECK_ARG(!need_all_state || (t.state1 && t.state2), "%s: tensor %d misses optimizer state", name, first + i);
+            tb.t[i] = t;
+            tb.chunk_start[i] = chunks;
+            chunks += fsc::ceil_div(t.count, kChunk);
+        }
+        tb.chunk_start[tb.n] = chunks;
+        hipLaunchKernelGGL(kernel, dim3(chunks), dim3(kThreads), 0, st, tb, h);
+        FSC_LAUNCH_CHECK(name);
+    }
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int fsc_adam_amsgrad_step(const fsc_opt_tensor* tensors_host, int n_tensors, float lr, float beta1, float beta2,
+                          float eps, float weight_decay, int step, float grad_scale, fsc_stream_t stream) {
+    FSC_CHECK_ARG(tensors_host && n_tensors > 0 && step >= 1, "fsc_adam_amsgrad_step: bad arguments");
+    const double bc1 = 1.0 - pow((double)beta1, (double)step);
+    const double bc2 = 1.0 - pow((double)beta2, (double)step);
+    AdamHyper h{beta1, beta2, eps, weight_decay, (float)((double)lr / bc1), (float)(1.0 / sqrt(bc2)), grad_scale};
+    return run(tensors_host, n_tensors, h, adam_kernel, true, fsc::as_stream(stream), "fsc_adam_amsgrad_step");
+}
+
+int fsc_sgd_nesterov_step(const fsc_opt_tensor* tensors_host, int n_tensors, float lr, float momentum,
+                          float weight_decay, int first_step, float grad_scale, fsc_stream_t stream) {
+    FSC_CHECK_ARG(tensors_host && n_tensors > 0, "fsc_sgd_nesterov_step: bad arguments");
+    SgdHyper h{lr, momentum, weight_decay, grad_scale, first_step};
+    return run(tensors_host, n_tensors, h, sgd_kernel, false, fsc::as_stream(stream), "fsc_sgd_nesterov_step");
+}
+
+}  // extern "C"

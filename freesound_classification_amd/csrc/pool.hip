@@ -1,0 +1,165 @@
+// Max-pooling kernels (HBM-bound streaming).
+//   fsc_maxpool_*        : nn.MaxPool2d(2,2) / nn.MaxPool1d(2,2), floor mode
+//                          (reference networks/classifiers.py:532, :155)
+//   fsc_global_maxpool_* : nn.AdaptiveMaxPool2d(1) / 1d(1) deep-supervision heads
+//                          (reference networks/classifiers.py:540,591 and :163,201)
+// Tie-breaking follows ATen: the first maximum in row-major window order wins; NaN wins.
+#include "common.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+
+__global__ __launch_bounds__(kThreads) void maxpool_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                               uint8_t* __restrict__ idx, long planes, int h,
+                                                               int w, int ph, int oh, int ow) {
+    const long total = planes * oh * ow;
+    for (long i = (long)blockIdx.x * kThreads + threadIdx.x; i < total; i += (long)gridDim.x * kThreads) {
+        const int ox = (int)(i % ow);
+        const long r = i / ow;
+        const int oy = (int)(r % oh);
+        const long pl = r / oh;
+        const float* p = x + (pl * h + (long)oy * ph) * w + 2 * ox;
+        float best = p[0];
+        int bi = 0;
+        float v = p[1];
+        if (v > best || v != v) { best = v; bi = 1; }
+        if (ph == 2) {
+            v = p[w];
+            if ((v > best || v != v) && best == best) { best = v; bi = 2; }
+            v = p[w + 1];
+            if ((v > best || v != v) && best == best) { best = v; bi = 3; }
+        }
+        y[i] = best;
+        idx[i] = (uint8_t)bi;
+    }
+}
+
+// gather form: every input element is written exactly once
+__global__ __launch_bounds__(kThreads) void maxpool_bwd_kernel(const float* __restrict__ dy,
+                                                               const uint8_t* __restrict__ idx,
+                                                               float* __restrict__ dx, long planes, int h, int w,
+                                                               int ph, int oh, int ow) {
+    const long total = planes * h * w;
+    for (long i = (long)blockIdx.x * kThreads + threadIdx.x; i < total; i += (long)gridDim.x * kThreads) {
+        const int xx = (int)(i % w);
+        const long r = i / w;
+        const int yy = (int)(r % h);
+        const long pl = r / h;
+        const int ox = xx >> 1, oy = ph == 2 ? (yy >> 1) : yy;
+        float g = 0.f;
+        if (ox < ow && oy < oh) {
+            const long o = (pl * oh + oy) * ow + ox;
+            const int pos = (ph == 2 ? ((yy & 1) << 1) : 0) | (xx & 1);
+            if (idx[o] == pos) g = dy[o];
+        }
+        dx[i] = g;
+    }
+}
+
+// one wave per plane when planes are small, one block per plane otherwise
+__global__ __launch_bounds__(kThreads) void gmax_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                            int* __restrict__ idx, long planes, long hw) {
+    __shared__ float sv[kThreads / 64];
+    __shared__ int si[kThreads / 64];
+    __shared__ int sn[kThreads / 64];
+    for (long pl = blockIdx.x; pl < planes; pl += gridDim.x) {
+        const float* p = x + pl * hw;
+        // candidate = (isnan, value, index); NaN beats numbers, larger value wins, ties -> smaller index
+        float key = -INFINITY;
+        int ii = 0x7fffffff;
+        int kn = 0;
+        for (long i = threadIdx.x; i < hw; i += kThreads) {
+            const float v = p[i];
+            const int vn = v != v ? 1 : 0;
+            const bool take = (vn > kn) || (vn == kn && !vn && (v > key || (v == key && (int)i < ii)));
+            if (take) { key = v; ii = (int)i; kn = vn; }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ok = __shfl_xor(key, o, 64);
+            const int oi = __shfl_xor(ii, o, 64);
+            const int on = __shfl_xor(kn, o, 64);
+            const bool take = (on > kn) || (on == kn && (on ? oi < ii : (ok > key || (ok == key && oi < ii))));
+            if (take) { key = ok; ii = oi; kn = on; }
+        }
+        const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+        __syncthreads();
+        if (lane == 0) { sv[wid] = key; si[wid] = ii; sn[wid] = kn; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            for (int k = 1; k < kThreads / 64; ++k) {
+                const float ok = sv[k];
+                const int oi = si[k], on = sn[k];
+                const bool take = (on > kn) || (on == kn && (on ? oi < ii : (ok > key || (ok == key && oi < ii))));
+                if (take) { key = ok; ii = oi; kn = on; }
+            }
+            if (ii == 0x7fffffff) ii = 0;
+            y[pl] = p[ii];
+            idx[pl] = ii;
+        }
+    }
+}
+
+__global__ __launch_bounds__(kThreads) void gmax_bwd_kernel(const float* __restrict__ dy, const int* __restrict__ idx,
+                                                            const float* __restrict__ dx_in, float* __restrict__ dx,
+                                                            long planes, long hw) {
+    const long total = planes * hw;
+    for (long i = (long)blockIdx.x * kThreads + threadIdx.x; i < total; i += (long)gridDim.x * kThreads) {
+        const long pl = i / hw;
+        float g = dx_in ? dx_in[i] : 0.f;
+        if (i - pl * hw == (long)idx[pl]) g += dy[pl];
+        dx[i] = g;
+    }
+}
+
+unsigned stream_grid(long total) {
+    long b = (total + kThreads - 1) / kThreads;
+    if (b > 256L * 16) b = 256L * 16;
+    if (b < 1) b = 1;
+    return (unsigned)b;
+}
+
+}  // namespace
+
+extern "C" {
+
+int fsc_maxpool_fwd(const float* x, float* y, uint8_t* idx, int nc, int h, int w, int ph, fsc_stream_t stream) {
+    FSC_CHECK_ARG(x && y && idx, "fsc_maxpool_fwd: null pointer");
+    FSC_CHECK_ARG((ph == 1 || ph == 2) && nc > 0 && h >= ph && w >= 2, "fsc_maxpool_fwd: bad shape nc=%d h=%d w=%d ph=%d", nc, h, w, ph);
+    const int oh = h / ph, ow = w / 2;
+    hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(stream_grid((long)nc * oh * ow)), dim3(kThreads), 0,
+                       fsc::as_stream(stream), x, y, idx, (long)nc, h, w, ph, oh, ow);
+    FSC_LAUNCH_CHECK("fsc_maxpool_fwd");
+    return 0;
+}
+
+int fsc_maxpool_bwd(const float* dy, const uint8_t* idx, float* dx, int nc, int h, int w, int ph, fsc_stream_t stream) {
+    FSC_CHECK_ARG(dy && dx && idx, "fsc_maxpool_bwd: null pointer");
+    FSC_CHECK_ARG((ph == 1 || ph == 2) && nc > 0 && h >= ph && w >= 2, "fsc_maxpool_bwd: bad shape");
+    const int oh = h / ph, ow = w / 2;
+    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(stream_grid((long)nc * h * w)), dim3(kThreads), 0,
+                       fsc::as_stream(stream), dy, idx, dx, (long)nc, h, w, ph, oh, ow);
+    FSC_LAUNCH_CHECK("fsc_maxpool_bwd");
+    return 0;
+}
+
+int fsc_global_maxpool_fwd(const float* x, float* y, int* idx, int nc, long hw, fsc_stream_t stream) {
+    FSC_CHECK_ARG(x && y && idx && nc > 0 && hw > 0, "fsc_global_maxpool_fwd: bad arguments");
+    long blocks = nc < 256L * 16 ? nc : 256L * 16;
+    hipLaunchKernelGGL(gmax_fwd_kernel, dim3((unsigned)blocks), dim3(kThreads), 0, fsc::as_stream(stream), x, y, idx,
+                       (long)nc, hw);
+    FSC_LAUNCH_CHECK("fsc_global_maxpool_fwd");
+    return 0;
+}
+
+int fsc_global_maxpool_bwd(const float* dy, const int* idx, const float* dx_in, float* dx, int nc, long hw,
+                           fsc_stream_t stream) {
+    FSC_CHECK_ARG(dy && idx && dx && nc > 0 && hw > 0, "fsc_global_maxpool_bwd: bad arguments");
+    hipLaunchKernelGGL(gmax_bwd_kernel, dim3(stream_grid((long)nc * hw)), dim3(kThreads), 0, fsc::as_stream(stream),
+                       dy, idx, dx_in, dx, (long)nc, hw);
+    FSC_LAUNCH_CHECK("fsc_global_maxpool_bwd");
+    return 0;
+}
+
+}  // extern "C"

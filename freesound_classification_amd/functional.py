@@ -1,0 +1,630 @@
+"""Device ops of the accelerated path: thin wrappers over the libfsc_hip.so C ABI plus the
+``torch.autograd.Function``s that give them gradients.  PyTorch is plumbing here (device
+memory, streams, the autograd tape); every number is produced by a hand-written HIP kernel.
+
+Layout: activations are NCHW fp32 like the reference; the 1-d model runs with H == 1.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import ConvDesc, call, ptr, stream_ptr
+
+BN_EPS = 1e-5
+LOG_EPS = 1e-4
+
+
+def _empty(shape, like, dtype=torch.float32):
+    return torch.empty(shape, device=like.device, dtype=dtype)
+
+
+def _need_cuda(t, what):
+    if not t.is_cuda:
+        raise _lib.FscError("%s: expected a device tensor, got %s (no CPU fallback)" % (what, t.device))
+
+
+# ------------------------------------------------------------------------------ front-end
+_TABLES = {}
+
+
+def _frontend_tables(n_fft, device):
+    key = (n_fft, str(device))
+    if key not in _TABLES:
+        n = _lib.load().fsc_frontend_table_floats(n_fft)
+        t = torch.empty(n, device=device, dtype=torch.float32)
+        call("fsc_frontend_tables_init", ptr(t), n_fft, stream_ptr())
+        _TABLES[key] = t
+    return _TABLES[key]
+
+
+class MelBands:
+    """Banded view of a dense (n_mel, n_bins) filterbank: per row the first non-zero bin, the
+    band length, and the weights stored [j][m] so lanes that own consecutive mel rows read
+    consecutive addresses.  Host-side index work only."""
+
+    def __init__(self, filterbank, device):
+        fb = np.asarray(filterbank, dtype=np.float32)
+        n_mel = fb.shape[0]
+        start = np.zeros(n_mel, np.int32)
+        length = np.zeros(n_mel, np.int32)
+        for m in range(n_mel):
+            nz = np.flatnonzero(fb[m])
+            if nz.size:
+                start[m] = nz[0]
+                length[m] = nz[-1] - nz[0] + 1
+        max_band = int(length.max()) if n_mel else 0
+        w = np.zeros((max(max_band, 1), n_mel), np.float32)
+        for m in range(n_mel):
+            w[:length[m], m] = fb[m, start[m]:start[m] + length[m]]
+        self.n_mel = n_mel
+        self.n_bins = fb.shape[1]
+        self.max_band = max_band
+        self.start = torch.from_numpy(start).to(device)
+        self.length = torch.from_numpy(length).to(device)
+        self.weights = torch.from_numpy(w).to(device)
+
+
+def frontend_logmel(wave, n_fft, hop, bands, freq_channel):
+    """(N, T) waveform -> (N, 1|2, n_mel, frames) log-mel (+ frequency-encoding channel)."""
+    _need_cuda(wave, "frontend_logmel")
+    wave = wave.contiguous()
+    n, t = wave.shape
+    frames = 1 + t // hop
+    planes = 2 if freq_channel else 1
+    out = _empty((n, planes, bands.n_mel, frames), wave)
+    call("fsc_frontend_logmel_fwd", ptr(wave), n, t, t, n_fft, hop,
+         ptr(_frontend_tables(n_fft, wave.device)), ptr(bands.start), ptr(bands.length),
+         ptr(bands.weights), bands.n_mel, bands.max_band, LOG_EPS, ptr(out),
+         planes * bands.n_mel * frames, 1 if freq_channel else 0, stream_ptr())
+    return out
+
+
+def frontend_stft(wave, n_fft, hop, apply_log, freq_channel=False):
+    """(N, T) waveform -> (N, [1|2,] n_fft/2+1, frames) magnitude or log-magnitude."""
+    _need_cuda(wave, "frontend_stft")
+    wave = wave.contiguous()
+    n, t = wave.shape
+    frames = 1 + t // hop
+    bins = n_fft // 2 + 1
+    if freq_channel:
+        out = _empty((n, 2, bins, frames), wave)
+        stride = 2 * bins * frames
+    else:
+        out = _empty((n, bins, frames), wave)
+        stride = bins * frames
+    call("fsc_frontend_stft_fwd", ptr(wave), n, t, t, n_fft, hop,
+         ptr(_frontend_tables(n_fft, wave.device)), 1 if apply_log else 0, LOG_EPS, ptr(out),
+         stride, 1 if freq_channel else 0, stream_ptr())
+    return out
+
+
+# ------------------------------------------------------------------------------ convolution
+def _desc(n, c_in, c_out, h, w, kh, kw):
+    return ConvDesc(n, c_in, c_out, h, w, kh, kw)
+
+
+class KernelTimer:
+    """Optional per-launch timing of the conv kernels with HIP events recorded on the stream
+    the kernels are launched on (bench.py uses it for the roofline numbers).  Off by default."""
+
+    def __init__(self):
+        self.records = []      # (kernel name, algorithmic flops, start event, end event)
+
+    def summary(self):
+        """name -> dict(launches, flops, ms); call after a device synchronise."""
+        out = {}
+        for name, flops, e0, e1 in self.records:
+            r = out.setdefault(name, dict(launches=0, flops=0.0, ms=0.0))
+            r["launches"] += 1
+            r["flops"] += flops
+            r["ms"] += e0.elapsed_time(e1)
+        return out
+
+
+TIMER = None
+
+
+def plan_name(desc, mode):
+    buf = C.create_string_buffer(256)
+    call("fsc_conv_plan_describe", C.byref(desc), mode, buf, 256)
+    return buf.value.decode().split(" ")[0]
+
+
+class _timed:
+    def __init__(self, desc, mode):
+        self.on = TIMER is not None
+        if self.on:
+            self.name = plan_name(desc, mode)
+            self.flops = 2.0 * desc.n * desc.h * desc.w * desc.c_in * desc.c_out * desc.kh * desc.kw
+
+    def __enter__(self):
+        if self.on:
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e1 = torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+
+    def __exit__(self, *exc):
+        if self.on:
+            self.e1.record()
+            TIMER.records.append((self.name, self.flops, self.e0, self.e1))
+
+
+def conv_pack(desc, weight, dgrad):
+    lib = _lib.load()
+    n = lib.fsc_conv_packed_floats(C.byref(desc), dgrad)
+    if n == 0:
+        raise _lib.FscError("conv: unsupported shape %s" % [getattr(desc, f) for f, _ in desc._fields_])
+    packed = _empty((n,), weight)
+    call("fsc_conv_pack_weights", C.byref(desc), ptr(weight), dgrad, ptr(packed), stream_ptr())
+    return packed
+
+
+def conv_forward(x, weight, bias):
+    """x (N, Cin, H, W), weight (Cout, Cin, kh, kw) -> (N, Cout, H, W); stride 1, same pad."""
+    n, c_in, h, w = x.shape
+    c_out, _, kh, kw = weight.shape
+    d = _desc(n, c_in, c_out, h, w, kh, kw)
+    packed = conv_pack(d, weight, 0)
+    out = _empty((n, c_out, h, w), x)
+    with _timed(d, 0):
+        call("fsc_conv_fwd", C.byref(d), ptr(x), ptr(packed), ptr(bias), 0, 0, ptr(out), stream_ptr())
+    return out
+
+
+def conv_dgrad(dout, weight, x_shape, accumulate_into=None):
+    """Gradient w.r.t. the conv input.  With `accumulate_into` the result is added in place."""
+    n, c_in, h, w = x_shape
+    c_out, _, kh, kw = weight.shape
+    d = _desc(n, c_in, c_out, h, w, kh, kw)
+    packed = conv_pack(d, weight, 1)
+    if accumulate_into is None:
+        dx = _empty((n, c_in, h, w), dout)
+        acc = 0
+    else:
+        dx = accumulate_into
+        acc = 1
+    with _timed(d, 1):
+        call("fsc_conv_fwd", C.byref(d), ptr(dout), ptr(packed), None, 1, acc, ptr(dx), stream_ptr())
+    return dx
+
+
+def conv_wgrad(x, dout, weight_shape):
+    n, c_in, h, w = x.shape
+    c_out, _, kh, kw = weight_shape
+    d = _desc(n, c_in, c_out, h, w, kh, kw)
+    nbytes = _lib.load().fsc_conv_wgrad_workspace_bytes(C.byref(d))
+    if nbytes == 0:
+        raise _lib.FscError("conv wgrad: unsupported shape")
+    ws = torch.empty(nbytes // 4, device=x.device, dtype=torch.float32)
+    dw = _empty(tuple(weight_shape), x)
+    with _timed(d, 2):
+        call("fsc_conv_wgrad", C.byref(d), ptr(x), ptr(dout), ptr(dw), ptr(ws), stream_ptr())
+    return dw
+
+
+# ------------------------------------------------------------------------------ BN + PReLU
+def _bn_ws(c, like):
+    nbytes = _lib.load().fsc_bn_workspace_bytes(c)
+    return torch.empty((nbytes + 7) // 8, device=like.device, dtype=torch.float64)
+
+
+class BNState:
+    """What one fused BN(+residual)(+PReLU) unit keeps between forward and backward."""
+    __slots__ = ("mean", "invstd", "scale", "shift")
+
+
+def bn_prepare(x, bn, training):
+    """Batch statistics (training; also updates the running stats, once) or running statistics
+    (eval) -> per-channel scale/shift."""
+    n, c = x.shape[0], x.shape[1]
+    hw = x.numel() // (n * c)
+    st = BNState()
+    st.scale = _empty((c,), x)
+    st.shift = _empty((c,), x)
+    gamma, beta = bn.weight, bn.bias
+    if training or bn.running_mean is None:
+        st.mean = _empty((c,), x)
+        st.invstd = _empty((c,), x)
+        track = training and bn.track_running_stats and bn.running_mean is not None
+        momentum = 0.1 if bn.momentum is None else bn.momentum
+        if track:
+            bn.num_batches_tracked.add_(1)
+            if bn.momentum is None:
+                momentum = 1.0 / float(bn.num_batches_tracked)
+        call("fsc_bn_train_stats", ptr(x), n, c, hw, ptr(gamma), ptr(beta), bn.eps, momentum,
+             ptr(bn.running_mean) if track else None, ptr(bn.running_var) if track else None,
+             ptr(st.mean), ptr(st.invstd), ptr(st.scale), ptr(st.shift), ptr(_bn_ws(c, x)), stream_ptr())
+    else:
+        st.mean = None
+        st.invstd = None
+        call("fsc_bn_eval_prepare", c, ptr(gamma), ptr(beta), ptr(bn.running_mean), ptr(bn.running_var),
+             bn.eps, ptr(st.scale), ptr(st.shift), stream_ptr())
+    return st
+
+
+def bn_act_forward(x, st, alpha=None, residual=None):
+    n, c = x.shape[0], x.shape[1]
+    hw = x.numel() // (n * c)
+    y = torch.empty_like(x)
+    call("fsc_bn_act_fwd", ptr(x), ptr(residual), ptr(st.scale), ptr(st.shift), ptr(alpha), ptr(y),
+         n, c, hw, stream_ptr())
+    return y
+
+
+def bn_act_backward(dy, x, st, bn, alpha=None, residual=None, gmax=None, want_dx=True,
+                    want_dres=False, want_chan_sum=False):
+    """Returns (dx, dresidual, dgamma, dbeta, dalpha, dx_chan_sum)."""
+    n, c = x.shape[0], x.shape[1]
+    hw = x.numel() // (n * c)
+    dx = torch.empty_like(x)          # always produced (the apply pass also yields chan sums)
+    dres = torch.empty_like(x) if want_dres else None
+    dgamma = _empty((c,), x)
+    dbeta = _empty((c,), x)
+    dalpha = _empty((c,), x) if alpha is not None else None
+    csum = _empty((c,), x) if want_chan_sum else None
+    gdy, gidx = gmax if gmax is not None else (None, None)
+    call("fsc_bn_act_bwd", ptr(dy), ptr(gdy), ptr(gidx), ptr(x), ptr(residual), ptr(st.mean),
+         ptr(st.invstd), ptr(bn.weight), ptr(bn.bias), ptr(alpha), ptr(dx), ptr(dres), ptr(dgamma),
+         ptr(dbeta), ptr(dalpha), ptr(csum), n, c, hw, ptr(_bn_ws(c, x)), stream_ptr())
+    return dx, dres, dgamma, dbeta, dalpha, csum
+
+
+# ------------------------------------------------------------------------------ pooling
+def maxpool_forward(x, ph):
+    n, c, h, w = x.shape
+    y = _empty((n, c, h // ph, w // 2), x)
+    idx = _empty((n, c, h // ph, w // 2), x, torch.uint8)
+    call("fsc_maxpool_fwd", ptr(x), ptr(y), ptr(idx), n * c, h, w, ph, stream_ptr())
+    return y, idx
+
+
+def maxpool_backward(dy, idx, x_shape, ph):
+    n, c, h, w = x_shape
+    dx = _empty(tuple(x_shape), dy)
+    call("fsc_maxpool_bwd", ptr(dy), ptr(idx), ptr(dx), n * c, h, w, ph, stream_ptr())
+    return dx
+
+
+def global_maxpool_forward(x):
+    n, c = x.shape[0], x.shape[1]
+    hw = x.numel() // (n * c)
+    y = _empty((n, c), x)
+    idx = _empty((n, c), x, torch.int32)
+    call("fsc_global_maxpool_fwd", ptr(x), ptr(y), ptr(idx), n * c, hw, stream_ptr())
+    return y, idx
+
+
+# ------------------------------------------------------------------------------ conv block
+def _conv_params(conv):
+    """(weight as 4-d, bias, kh, kw) for nn.Conv2d / nn.Conv1d parameter holders."""
+    w = conv.weight
+    if w.dim() == 3:
+        w = w.unsqueeze(2)
+    return w, conv.bias
+
+
+class _BlockCtx:
+    pass
+
+
+def _block_forward(x, mods, training, want_head, ph, keep):
+    """BN -> conv3 -> maxpool -> BN+PReLU -> residual unit (-> global max).  `mods` is the
+    reference's nn.Sequential of parameter holders.  Returns (out, feat, ctx)."""
+    bn_a, conv_a, _pool, bn_b, prelu_b, res = mods[0], mods[1], mods[2], mods[3], mods[4], mods[5]
+    k = _BlockCtx()
+    k.x_shape = tuple(x.shape)
+    st_a = bn_prepare(x, bn_a, training)
+    a = bn_act_forward(x, st_a)
+    w_a, b_a = _conv_params(conv_a)
+    c = conv_forward(a, w_a, b_a)
+    p, pidx = maxpool_forward(c, ph)
+    k.c_shape = tuple(c.shape)
+    del c
+    st_b = bn_prepare(p, bn_b, training)
+    b = bn_act_forward(p, st_b, prelu_b.weight)
+    w1, b1 = _conv_params(res.conv1)
+    r1 = conv_forward(b, w1, b1)
+    st1 = bn_prepare(r1, res.bn1, training)
+    s1 = bn_act_forward(r1, st1, res.prelu1.weight)
+    w2, b2 = _conv_params(res.conv2)
+    r2 = conv_forward(s1, w2, b2)
+    st2 = bn_prepare(r2, res.bn2, training)
+    s2 = bn_act_forward(r2, st2, res.prelu2.weight)
+    w3, b3 = _conv_params(res.conv3)
+    r3 = conv_forward(s2, w3, b3)
+    st3 = bn_prepare(r3, res.bn3, training)
+    out = bn_act_forward(r3, st3, res.prelu3.weight, residual=b)
+    feat, fidx = (None, None)
+    if want_head:
+        feat, fidx = global_maxpool_forward(out)
+    if keep:
+        k.x, k.a, k.pidx, k.p, k.b = x, a, pidx, p, b
+        k.r1, k.s1, k.r2, k.s2, k.r3 = r1, s1, r2, s2, r3
+        k.st_a, k.st_b, k.st1, k.st2, k.st3 = st_a, st_b, st1, st2, st3
+        k.fidx = fidx
+    return out, feat, k
+
+
+def _block_params(mods):
+    """Parameters in the order their gradients are returned by ConvBlockFn.backward."""
+    bn_a, conv_a, _pool, bn_b, prelu_b, res = mods[0], mods[1], mods[2], mods[3], mods[4], mods[5]
+    return [bn_a.weight, bn_a.bias, conv_a.weight, conv_a.bias, bn_b.weight, bn_b.bias, prelu_b.weight,
+            res.conv1.weight, res.conv1.bias, res.bn1.weight, res.bn1.bias, res.prelu1.weight,
+            res.conv2.weight, res.conv2.bias, res.bn2.weight, res.bn2.bias, res.prelu2.weight,
+            res.conv3.weight, res.conv3.bias, res.bn3.weight, res.bn3.bias, res.prelu3.weight]
+
+
+class ConvBlockFn(torch.autograd.Function):
+    """One `conv_modules[k]` block of the reference (networks/classifiers.py:524-536 with
+    ResnetBlock2d :72-104, or the 1-d pair :147-161 / :37-69) and its deep-supervision head
+    (:589-591) as a single autograd node with a hand-written backward."""
+
+    @staticmethod
+    def forward(ctx, x, mods, training, want_head, ph, *params):
+        keep = any(ctx.needs_input_grad)
+        out, feat, k = _block_forward(x, mods, training, want_head, ph, keep)
+        ctx.k = k
+        ctx.mods = mods
+        ctx.ph = ph
+        ctx.want_head = want_head
+        ctx.x_needs_grad = ctx.needs_input_grad[0]
+        ctx.set_materialize_grads(False)
+        if want_head:
+            return out, feat
+        dummy = out.new_empty(0)
+        ctx.mark_non_differentiable(dummy)
+        return out, dummy
+
+    @staticmethod
+    def backward(ctx, d_out, d_feat):
+        k, mods, ph = ctx.k, ctx.mods, ctx.ph
+        bn_a, conv_a, _pool, bn_b, prelu_b, res = mods[0], mods[1], mods[2], mods[3], mods[4], mods[5]
+        gmax = None
+        if ctx.want_head and d_feat is not None:
+            gmax = (d_feat.contiguous(), k.fidx)
+        if d_out is not None:
+            d_out = d_out.contiguous()
+        if d_out is None and gmax is None:
+            raise _lib.FscError("ConvBlockFn.backward: no upstream gradient")
+        # ---- out = prelu3(bn3(r3) + b)
+        dr3, db, dg3, dbt3, dal3, dbias3 = bn_act_backward(
+            d_out, k.r3, k.st3, res.bn3, res.prelu3.weight, residual=k.b, gmax=gmax,
+            want_dres=True, want_chan_sum=True)
+        w3, _ = _conv_params(res.conv3)
+        dw3 = conv_wgrad(k.s2, dr3, w3.shape)
+        ds2 = conv_dgrad(dr3, w3, k.s2.shape)
+        del dr3
+        dr2, _, dg2, dbt2, dal2, dbias2 = bn_act_backward(ds2, k.r2, k.st2, res.bn2, res.prelu2.weight,
+                                                          want_chan_sum=True)
+        del ds2
+        w2, _ = _conv_params(res.conv2)
+        dw2 = conv_wgrad(k.s1, dr2, w2.shape)
+        ds1 = conv_dgrad(dr2, w2, k.s1.shape)
+        del dr2
+        dr1, _, dg1, dbt1, dal1, dbias1 = bn_act_backward(ds1, k.r1, k.st1, res.bn1, res.prelu1.weight,
+                                                          want_chan_sum=True)
+        del ds1
+        w1, _ = _conv_params(res.conv1)
+        dw1 = conv_wgrad(k.b, dr1, w1.shape)
+        db = conv_dgrad(dr1, w1, k.b.shape, accumulate_into=db)     # residual + conv1 paths
+        del dr1
+        # ---- b = prelu(bn_b(p))
+        dp, _, dgb, dbtb, dalb, dbias_a = bn_act_backward(db, k.p, k.st_b, bn_b, prelu_b.weight,
+                                                          want_chan_sum=True)
+        del db
+        dc = maxpool_backward(dp, k.pidx, k.c_shape, ph)
+        del dp
+        wa, _ = _conv_params(conv_a)
+        dwa = conv_wgrad(k.a, dc, wa.shape)
+        da = conv_dgrad(dc, wa, k.a.shape)
+        del dc
+        dx, _, dga, dbta, _, _ = bn_act_backward(da, k.x, k.st_a, bn_a)
+        if not ctx.x_needs_grad:
+            dx = None
+
+        def like(param, g):
+            return g.reshape(param.shape) if g is not None else None
+
+        grads = [dga, dbta, like(conv_a.weight, dwa), dbias_a, dgb, dbtb, dalb,
+                 like(res.conv1.weight, dw1), dbias1, dg1, dbt1, dal1,
+                 like(res.conv2.weight, dw2), dbias2, dg2, dbt2, dal2,
+                 like(res.conv3.weight, dw3), dbias3, dg3, dbt3, dal3]
+        ctx.k = None
+        return (dx, None, None, None, None) + tuple(grads)
+
+
+def conv_block(x, mods, training, want_head, ph):
+    """Differentiable block call.  Returns (out, feat or None)."""
+    _need_cuda(x, "conv_block")
+    x = x.contiguous()
+    if torch.is_grad_enabled() and any(p.requires_grad for p in _block_params(mods)):
+        out, feat = ConvBlockFn.apply(x, mods, training, want_head, ph, *_block_params(mods))
+    else:
+        out, feat, _ = _block_forward(x, mods, training, want_head, ph, keep=False)
+    return out, (feat if want_head else None)
+
+
+# ------------------------------------------------------------------------------ head ops
+class BNActFn(torch.autograd.Function):
+    """BatchNorm1d (+ PReLU) on (N, C) features (classifiers.py:543-546)."""
+
+    @staticmethod
+    def forward(ctx, x, bn, prelu, training, gamma, beta, alpha):
+        x = x.contiguous()
+        st = bn_prepare(x, bn, training)
+        y = bn_act_forward(x, st, alpha)
+        ctx.save_for_backward(x)
+        ctx.st, ctx.bn, ctx.prelu = st, bn, prelu
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        st = ctx.st
+        if st.mean is None:
+            raise _lib.FscError("BNActFn.backward in eval mode is not supported")
+        alpha = ctx.prelu.weight if ctx.prelu is not None else None
+        dx, _, dg, db, dal, _ = bn_act_backward(dy.contiguous(), x, st, ctx.bn, alpha)
+        return dx, None, None, None, dg, db, dal
+
+
+def bn_act(x, bn, prelu, training):
+    alpha = prelu.weight if prelu is not None else None
+    return BNActFn.apply(x, bn, prelu, training, bn.weight, bn.bias, alpha)
+
+
+class LinearFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        x = x.contiguous()
+        m, k = x.shape
+        n_out = weight.shape[0]
+        y = _empty((m, n_out), x)
+        call("fsc_linear_fwd", ptr(x), ptr(weight), ptr(bias), ptr(y), m, k, n_out, stream_ptr())
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        dy = dy.contiguous()
+        m, k = x.shape
+        n_out = weight.shape[0]
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        dw = torch.empty_like(weight) if ctx.needs_input_grad[1] else None
+        db = _empty((n_out,), x) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+        call("fsc_linear_bwd", ptr(dy), ptr(x), ptr(weight), ptr(dx), ptr(dw), ptr(db), m, k, n_out,
+             stream_ptr())
+        return dx, dw, db
+
+
+def linear(x, weight, bias):
+    return LinearFn.apply(x, weight, bias)
+
+
+_DROPOUT_OFFSET = [0]
+
+
+class DropoutFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, p, seed):
+        x = x.contiguous()
+        y = torch.empty_like(x)
+        mask = torch.empty(x.shape, device=x.device, dtype=torch.uint8)
+        offset = _DROPOUT_OFFSET[0]
+        _DROPOUT_OFFSET[0] += x.numel()
+        call("fsc_dropout_fwd", ptr(x), ptr(y), ptr(mask), x.numel(), p, seed, offset, stream_ptr())
+        ctx.save_for_backward(mask)
+        ctx.p = p
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (mask,) = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = torch.empty_like(dy)
+        call("fsc_dropout_bwd", ptr(dy), ptr(mask), ptr(dx), dy.numel(), ctx.p, stream_ptr())
+        return dx, None, None
+
+
+def dropout(x, p, training):
+    if not training or p <= 0.0:
+        return x
+    return DropoutFn.apply(x, float(p), int(torch.initial_seed()) & 0xFFFFFFFFFFFFFFFF)
+
+
+# ------------------------------------------------------------------------------ losses
+class LsepFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, targets):
+        logits = logits.contiguous()
+        targets = targets.contiguous().float()
+        n, c = logits.shape
+        loss = _empty((n,), logits)
+        call("fsc_lsep_fwd", ptr(logits), ptr(targets), ptr(loss), n, c, stream_ptr())
+        ctx.save_for_backward(logits, targets)
+        return loss
+
+    @staticmethod
+    def backward(ctx, dloss):
+        logits, targets = ctx.saved_tensors
+        n, c = logits.shape
+        dl = torch.empty_like(logits)
+        call("fsc_lsep_bwd", ptr(logits), ptr(targets), ptr(dloss.contiguous()), ptr(dl), n, c, stream_ptr())
+        return dl, None
+
+
+class MeanFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, scale):
+        x = x.contiguous()
+        y = _empty((), x)
+        call("fsc_mean_fwd", ptr(x), ptr(y), x.numel(), scale, stream_ptr())
+        ctx.shape, ctx.scale = x.shape, scale
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        dx = torch.empty(ctx.shape, device=dy.device, dtype=torch.float32)
+        call("fsc_mean_bwd", ptr(dy.contiguous()), ptr(dx), dx.numel(), ctx.scale, stream_ptr())
+        return dx, None
+
+
+def mean(x, scale=1.0):
+    return MeanFn.apply(x, float(scale))
+
+
+class BceFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, targets):
+        logits = logits.contiguous()
+        targets = targets.contiguous().float()
+        loss = _empty((), logits)
+        ws = torch.empty(1, device=logits.device, dtype=torch.float64)
+        call("fsc_bce_fwd", ptr(logits), ptr(targets), ptr(loss), ptr(ws), logits.numel(), stream_ptr())
+        ctx.save_for_backward(logits, targets)
+        return loss
+
+    @staticmethod
+    def backward(ctx, dloss):
+        logits, targets = ctx.saved_tensors
+        dl = torch.empty_like(logits)
+        call("fsc_bce_bwd", ptr(logits), ptr(targets), ptr(dloss.contiguous()), ptr(dl), logits.numel(),
+             stream_ptr())
+        return dl, None
+
+
+def sigmoid(x):
+    _need_cuda(x, "sigmoid")
+    x = x.detach().contiguous()
+    y = torch.empty_like(x)
+    call("fsc_sigmoid", ptr(x), ptr(y), x.numel(), stream_ptr())
+    return y
+
+
+# ------------------------------------------------------------------------------ MixUp on device
+def mixup_batch(a, b, len_a, len_b, start, alpha, labels_a=None, labels_b=None):
+    """Batched ops/audio.py:32-52.  a (N, Ta), b (N, Tb) zero-padded rows with true lengths
+    len_a / len_b (int32); `alpha` is the fp64 mixing draw per row.  Returns (mixed, labels)."""
+    _need_cuda(a, "mixup_batch")
+    n, ta = a.shape
+    tb = b.shape[1]
+    t_out = max(ta, tb)
+    out = _empty((n, t_out), a)
+    alpha64 = np.asarray(alpha, dtype=np.float64)
+    al = torch.from_numpy(alpha64.astype(np.float32)).to(a.device)
+    om = torch.from_numpy((1.0 - alpha64).astype(np.float32)).to(a.device)
+    dev = lambda v: torch.as_tensor(np.asarray(v, dtype=np.int32)).to(a.device)  # noqa: E731
+    la, lb, st = dev(len_a), dev(len_b), dev(start)
+    lo = None
+    c = 0
+    if labels_a is not None:
+        labels_a, labels_b = labels_a.contiguous().float(), labels_b.contiguous().float()
+        lo = torch.empty_like(labels_a)
+        c = labels_a.shape[1]
+    call("fsc_mixup_batch", ptr(a.contiguous()), ptr(b.contiguous()), ptr(la), ptr(lb), ptr(st), ptr(al),
+         ptr(om), ptr(out), n, ta, tb, t_out, ptr(labels_a), ptr(labels_b), ptr(lo), c, stream_ptr())
+    return out, lo

@@ -1,0 +1,313 @@
+"""Counterpart of the reference's networks/classifiers.py for the accelerated path.
+
+`TwoDimensionalCNNClassificationModel` and `HierarchicalCNNClassificationModel` keep the
+reference's constructor (`experiment`, `device`), methods (forward / fit_validate /
+train_epoch / evaluate / validation / predict / make_optimizer / load_best_model) and --
+because the parameter holders are registered in the same order with the same torch module
+types -- the same state-dict keys, shapes and default initialisation draws
+(networks/classifiers.py:107-217, 483-892).  All device arithmetic runs in libfsc_hip.so.
+
+Additions the reference does not have: `loss` selection ("lsep" | "bce"; cfg 1 of the
+benchmark names BCE although the reference hard-codes LSEP), and data-parallel training when
+`torch.distributed` is initialised (one process per GPU, bucketed RCCL all-reduce of the
+gradients overlapped with backward, see `..parallel`).
+"""
+import os
+from collections import deque
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .. import functional as F
+from .. import parallel
+from ..ops.training import OPTIMIZERS, make_scheduler, make_step
+from ..ops.utils import is_mel, is_stft, lwlrap, make_mel_filterbanks, parse_features
+from .losses import binary_cross_entropy, lsep_loss
+
+try:  # logging only; absent in this image
+    from tensorboardX import SummaryWriter
+except ImportError:  # pragma: no cover
+    class SummaryWriter:
+        def __init__(self, *a, **k):
+            pass
+
+        def add_scalar(self, *a, **k):
+            pass
+
+        add_image = add_histogram = add_scalar
+
+try:
+    from tqdm import tqdm
+except ImportError:  # pragma: no cover
+    tqdm = None
+
+
+class _ResidualHolder(nn.Module):
+    """Parameter holder for the bottleneck unit conv1x1-BN-PReLU-conv3-BN-PReLU-conv1x1-BN-(+x)-PReLU
+    (reference ResnetBlock :37-69 and ResnetBlock2d :72-104).  The arithmetic lives in
+    functional.ConvBlockFn; registration order fixes state-dict keys and init RNG order."""
+
+    def __init__(self, depth, conv, bn):
+        super().__init__()
+        self.conv1 = conv(depth, depth, kernel_size=1)
+        self.bn1 = bn(depth)
+        self.conv2 = conv(depth, depth, kernel_size=3, padding=1)
+        self.bn2 = bn(depth)
+        self.conv3 = conv(depth, depth, kernel_size=1)
+        self.bn3 = bn(depth)
+        self.prelu1 = nn.PReLU(depth)
+        self.prelu2 = nn.PReLU(depth)
+        self.prelu3 = nn.PReLU(depth)
+
+    def forward(self, x):
+        raise RuntimeError("residual units run inside functional.conv_block")
+
+
+class ResnetBlock(_ResidualHolder):
+    def __init__(self, depth):
+        super().__init__(depth, nn.Conv1d, nn.BatchNorm1d)
+
+
+class ResnetBlock2d(_ResidualHolder):
+    def __init__(self, depth):
+        super().__init__(depth, nn.Conv2d, nn.BatchNorm2d)
+
+
+class _TaggingModel(nn.Module):
+    dims = 2
+
+    def __init__(self, experiment, device="cuda", loss="lsep"):
+        super().__init__()
+        self.device = device
+        self.experiment = experiment
+        self.config = experiment.config
+        self.loss_name = loss
+        net, data = self.config.network, self.config.data
+        if getattr(net, "aggregation_type", "max") != "max":
+            raise NotImplementedError("aggregation_type=%r: only the global-max-pool heads are on the "
+                                      "accelerated path" % net.aggregation_type)
+        if torch.device(device).type != "cuda":
+            raise F._lib.FscError("the accelerated model needs device='cuda' (an MI355X under ROCm); "
+                                  "there is no CPU fallback")
+        self._bands = None
+        if is_mel(data.features):
+            self.filterbanks = torch.from_numpy(make_mel_filterbanks(data.features)).to(self.device)
+
+        conv, bn, pool = (nn.Conv2d, nn.BatchNorm2d, nn.MaxPool2d) if self.dims == 2 else \
+                         (nn.Conv1d, nn.BatchNorm1d, nn.MaxPool1d)
+        res = ResnetBlock2d if self.dims == 2 else ResnetBlock
+        self.conv_modules = nn.ModuleList()
+        self.rnns = nn.ModuleList()
+        total_depth = 0
+        depth = None
+        for k in range(net.num_conv_blocks):
+            input_size = (2 if self.dims == 2 else data._input_dim) if not k else depth
+            depth = int(net.growth_rate ** k * net.conv_base_depth)
+            if k >= net.start_deep_supervision_on:
+                total_depth += depth
+            self.conv_modules.append(nn.Sequential(
+                bn(input_size), conv(input_size, depth, kernel_size=3, padding=1),
+                pool(kernel_size=2, stride=2), bn(depth), nn.PReLU(depth), res(depth)))
+        self.output_transform = nn.Sequential(
+            nn.BatchNorm1d(total_depth), nn.Linear(total_depth, total_depth),
+            nn.BatchNorm1d(total_depth), nn.PReLU(total_depth),
+            nn.Dropout(p=net.output_dropout), nn.Linear(total_depth, data._n_classes))
+        self.to(self.device)
+        self._reducer = None
+
+    # ------------------------------------------------------------------ forward
+    def _front_end(self, signal):
+        features = self.config.data.features
+        wave = signal.squeeze(-1)
+        two_d = self.dims == 2
+        if is_mel(features):
+            _, (n_fft, hop, _n_mel) = parse_features(features)
+            if self._bands is None or self._bands.weights.device != wave.device:
+                self._bands = F.MelBands(self.filterbanks.cpu().numpy(), wave.device)
+            x = F.frontend_logmel(wave, n_fft, hop, self._bands, freq_channel=two_d)
+            return x if two_d else x.squeeze(1)
+        if is_stft(features):
+            _, (n_fft, hop) = parse_features(features)
+            return F.frontend_stft(wave, n_fft, hop, apply_log=True, freq_channel=two_d)
+        raise NotImplementedError("features=%r: raw waveforms are not on the accelerated path" % features)
+
+    def forward(self, signal):
+        h = self._front_end(signal)
+        if self.dims == 1:
+            h = h.unsqueeze(2)              # (N, C, 1, L): the 1-d model is the H == 1 case
+        start = self.config.network.start_deep_supervision_on
+        ph = 2 if self.dims == 2 else 1
+        feats = []
+        for k, mods in enumerate(self.conv_modules):
+            h, feat = F.conv_block(h, mods, self.training, k >= start, ph)
+            if feat is not None:
+                feats.append(feat)
+        feats = torch.cat(feats, -1)
+        ot = self.output_transform
+        z = F.bn_act(feats, ot[0], None, self.training)
+        z = F.linear(z, ot[1].weight, ot[1].bias)
+        z = F.bn_act(z, ot[2], ot[3], self.training)
+        z = F.dropout(z, ot[4].p, self.training)
+        logits = F.linear(z, ot[5].weight, ot[5].bias)
+        return dict(class_logits=logits)
+
+    # ------------------------------------------------------------------ summaries
+    def add_scalar_summaries(self, loss, metric, writer, global_step):
+        writer.add_scalar("loss", loss, global_step)
+        writer.add_scalar("metric", metric, global_step)
+
+    def add_histogram_summaries(self, losses, writer, global_step):
+        writer.add_histogram("losses", np.array(losses), global_step=global_step)
+
+    def add_image_summaries(self, signal, global_step, writer, to_plot=8):
+        pass   # the reference plots the raw waveform grid via torchvision; logging only
+
+    # ------------------------------------------------------------------ training
+    def _per_sample_loss(self, class_logits, labels):
+        if self.loss_name == "lsep":
+            return lsep_loss(class_logits, labels, average=False)
+        if self.loss_name == "bce":
+            return binary_cross_entropy(class_logits, labels)
+        raise ValueError("unknown loss %r" % self.loss_name)
+
+    def training_step(self, signal, labels, step_optimizer=True):
+        """Forward, loss, backward, (all-reduce,) optimizer step on one device batch.
+        Returns (class_logits, per-sample losses or scalar loss).  No host synchronisation."""
+        acc = self.config.train.accumulation_steps
+        outputs = self(signal)
+        class_logits = outputs["class_logits"]
+        per = self._per_sample_loss(class_logits, labels)
+        loss = F.mean(per, 1.0 / acc) if per.dim() else F.mean(per.reshape(1), 1.0 / acc)
+        if self._reducer is not None:
+            self._reducer.prepare(sync=step_optimizer)
+        loss.backward()
+        if step_optimizer:
+            if self._reducer is not None:
+                self._reducer.finish()
+            self.optimizer.step()
+            self.optimizer.zero_grad()
+        return class_logits, per, loss
+
+    def train_epoch(self, train_loader, epoch, log_interval, write_summary=True):
+        self.train()
+        print("\n" + " " * 10 + "****** Epoch {epoch} ******\n".format(epoch=epoch))
+        training_losses = []
+        history = deque(maxlen=30)
+        self.optimizer.zero_grad()
+        acc = self.config.train.accumulation_steps
+        pb = tqdm(total=len(train_loader), ncols=80) if tqdm is not None else None
+        for batch_idx, sample in enumerate(train_loader):
+            self.global_step += 1
+            make_step(self.scheduler, step=self.global_step)
+            signal = sample["signal"].to(self.device, non_blocking=True)
+            labels = sample["labels"].to(self.device, non_blocking=True).float()
+            # the reference steps when batch_idx % accumulation_steps == 0 (so also on batch 0)
+            class_logits, per, loss = self.training_step(signal, labels, batch_idx % acc == 0)
+            probs = F.sigmoid(class_logits)
+            # one host synchronisation per step for the running metric (the reference has three)
+            per_host = per.detach().reshape(-1).cpu().numpy() / acc
+            training_losses.extend(per_host)
+            metric = lwlrap(labels.cpu().numpy(), probs.cpu().numpy())
+            history.append(metric)
+            loss_value = float(per_host.mean())
+            if pb is not None:
+                pb.update()
+                pb.set_description("Loss: {:.4f}, Metric: {:.4f}".format(loss_value, np.mean(history)))
+            if write_summary and batch_idx % log_interval == 0:
+                self.add_scalar_summaries(loss_value, metric, self.train_writer, self.global_step)
+        if pb is not None:
+            pb.close()
+        if write_summary:
+            self.add_histogram_summaries(training_losses, self.train_writer, self.global_step)
+
+    def evaluate(self, loader, verbose=False, write_summary=False, epoch=None):
+        self.eval()
+        valid_loss = 0.0
+        all_class_probs, all_labels = [], []
+        with torch.no_grad():
+            for sample in loader:
+                signal = sample["signal"].to(self.device)
+                labels = sample["labels"].to(self.device).float()
+                class_logits = self(signal)["class_logits"]
+                loss = lsep_loss(class_logits, labels).item()
+                valid_loss += loss * len(labels) / len(loader.dataset)
+                all_class_probs.extend(F.sigmoid(class_logits).cpu().numpy())
+                all_labels.extend(labels.cpu().numpy())
+        all_class_probs = np.asarray(all_class_probs)
+        all_labels = np.asarray(all_labels)
+        metric = lwlrap(all_labels, all_class_probs)
+        if write_summary:
+            self.add_scalar_summaries(valid_loss, metric, writer=self.valid_writer, global_step=self.global_step)
+        if verbose:
+            print("\nValidation loss: {:.4f}".format(valid_loss))
+            print("Validation metric: {:.4f}".format(metric))
+        return metric
+
+    def validation(self, valid_loader, epoch):
+        return self.evaluate(valid_loader, verbose=True, write_summary=True, epoch=epoch)
+
+    def predict(self, loader, n_tta=1):
+        self.eval()
+        all_class_probs = []
+        for _ in range(n_tta):
+            tta_probs = []
+            with torch.no_grad():
+                for sample in loader:
+                    signal = sample["signal"].to(self.device)
+                    tta_probs.extend(F.sigmoid(self(signal)["class_logits"]).cpu().numpy())
+            all_class_probs.append(np.array(tta_probs))
+        return np.mean(all_class_probs, 0)
+
+    def fit_validate(self, train_loader, valid_loader, epochs, fold, log_interval=25):
+        self.experiment.register_directory("summaries")
+        fold_dir = "fold_{}".format(fold)
+        self.train_writer = SummaryWriter(log_dir=os.path.join(self.experiment.summaries, fold_dir, "train"))
+        self.valid_writer = SummaryWriter(log_dir=os.path.join(self.experiment.summaries, fold_dir, "valid"))
+        os.makedirs(os.path.join(self.experiment.checkpoints, fold_dir), exist_ok=True)
+        self.global_step = 0
+        self.make_optimizer(max_steps=len(train_loader) * epochs)
+        scores = []
+        best_score = 0
+        for epoch in range(epochs):
+            make_step(self.scheduler, epoch=epoch)
+            if epoch == self.config.train.switch_off_augmentations_on:
+                train_loader.dataset.transform.switch_off_augmentations()
+            self.train_epoch(train_loader, epoch, log_interval, write_summary=True)
+            validation_score = self.validation(valid_loader, epoch)
+            scores.append(validation_score)
+            if parallel.rank() != 0:
+                continue
+            ckpt = os.path.join(self.experiment.checkpoints, fold_dir)
+            if epoch % self.config.train._save_every == 0:
+                print("\nSaving model on epoch", epoch)
+                torch.save(self.state_dict(), os.path.join(ckpt, "model_on_epoch_{}.pth".format(epoch)))
+            if validation_score > best_score:
+                torch.save(self.state_dict(), os.path.join(ckpt, "best_model.pth"))
+                best_score = validation_score
+        return scores
+
+    def make_optimizer(self, max_steps):
+        train = self.config.train
+        self.optimizer = OPTIMIZERS[train.optimizer](
+            self.parameters(), train.learning_rate, weight_decay=train.weight_decay)
+        self.scheduler = make_scheduler(train.scheduler, max_steps=max_steps)(self.optimizer)
+        if parallel.world_size() > 1:
+            parallel.broadcast_module(self)
+            self._reducer = parallel.BucketedGradReducer(list(self.parameters()))
+            self.optimizer.grad_scale = 1.0 / parallel.world_size()
+
+    def load_best_model(self, fold):
+        path = os.path.join(self.experiment.checkpoints, "fold_{}".format(fold), "best_model.pth")
+        self.load_state_dict(torch.load(path, map_location=self.device))
+
+
+class TwoDimensionalCNNClassificationModel(_TaggingModel):
+    """Reference networks/classifiers.py:483-892 (log-mel + frequency channel, 2-d blocks)."""
+    dims = 2
+
+
+class HierarchicalCNNClassificationModel(_TaggingModel):
+    """Reference networks/classifiers.py:107-480 (spectrogram bins as channels, 1-d blocks).
+    Its training loop uses the scalar-mean LSEP on `logits.squeeze()` (:268-275)."""
+    dims = 1

@@ -1,0 +1,171 @@
+"""Counterpart of the reference's ops/training.py: `OPTIMIZERS`, `make_scheduler`, `make_step`,
+`OneCycleScheduler` with the same descriptors ("steplr_{step}_{gamma}", "1cycle_{min}_{max}").
+The optimizers are fused multi-tensor HIP kernels with torch-compatible state dicts.
+"""
+import ctypes as C
+from functools import partial
+
+import torch
+from torch.optim import Optimizer
+from torch.optim.lr_scheduler import StepLR
+
+from .. import _lib
+from .._lib import OptTensor, call, stream_ptr
+
+
+def _table(entries):
+    arr = (OptTensor * len(entries))()
+    for i, (p, g, s0, s1, s2) in enumerate(entries):
+        arr[i] = OptTensor(p.data_ptr(), g.data_ptr(), s0.data_ptr(),
+                           s1.data_ptr() if s1 is not None else None,
+                           s2.data_ptr() if s2 is not None else None, p.numel())
+    return arr
+
+
+def _checked_grad(p):
+    g = p.grad
+    if g.is_sparse:
+        raise RuntimeError("sparse gradients are not supported")
+    if not p.is_cuda:
+        raise _lib.FscError("fused optimizers need device parameters (no CPU fallback)")
+    if not g.is_contiguous():
+        g = g.contiguous()
+        p.grad = g
+    return g
+
+
+class FusedAdam(Optimizer):
+    """torch.optim.Adam semantics (L2 weight decay, optional amsgrad) in one kernel per 24
+    tensors.  State keys match torch (step, exp_avg, exp_avg_sq, max_exp_avg_sq).
+    `grad_scale` multiplies gradients first (1/world_size after a summing all-reduce)."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, amsgrad=False):
+        if not amsgrad:
+            raise NotImplementedError("the accelerated path ships Adam with amsgrad=True only "
+                                      "(reference ops/training.py:10)")
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, amsgrad=amsgrad))
+        self.grad_scale = 1.0
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        for group in self.param_groups:
+            entries = []
+            step = None
+            for p in group["params"]:
+                if p.grad is None:
+                    continue
+                g = _checked_grad(p)
+                st = self.state[p]
+                if not st:
+                    st["step"] = 0
+                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+                    st["max_exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+                st["step"] = int(st["step"]) + 1
+                if step is None:
+                    step = st["step"]
+                if st["step"] != step:       # tensors that joined late get their own launch
+                    self._launch(group, [(p, g, st["exp_avg"], st["exp_avg_sq"], st["max_exp_avg_sq"])], st["step"])
+                    continue
+                entries.append((p, g, st["exp_avg"], st["exp_avg_sq"], st["max_exp_avg_sq"]))
+            if entries:
+                self._launch(group, entries, step)
+        return loss
+
+    def _launch(self, group, entries, step):
+        b1, b2 = group["betas"]
+        tbl = _table(entries)
+        call("fsc_adam_amsgrad_step", tbl, len(entries), float(group["lr"]), b1, b2, group["eps"],
+             group["weight_decay"], int(step), float(self.grad_scale), stream_ptr())
+
+
+class FusedSGD(Optimizer):
+    """torch.optim.SGD(momentum, nesterov=True, dampening=0) semantics with L2 weight decay."""
+
+    def __init__(self, params, lr, momentum=0.9, weight_decay=0.0, nesterov=True):
+        if not nesterov or momentum <= 0:
+            raise NotImplementedError("the accelerated path ships SGD with Nesterov momentum only "
+                                      "(reference ops/training.py:11)")
+        super().__init__(params, dict(lr=lr, momentum=momentum, weight_decay=weight_decay, nesterov=nesterov,
+                                      dampening=0))
+        self.grad_scale = 1.0
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        for group in self.param_groups:
+            fresh, warm = [], []
+            for p in group["params"]:
+                if p.grad is None:
+                    continue
+                g = _checked_grad(p)
+                st = self.state[p]
+                if "momentum_buffer" not in st or st["momentum_buffer"] is None:
+                    st["momentum_buffer"] = torch.empty_like(p, memory_format=torch.contiguous_format)
+                    fresh.append((p, g, st["momentum_buffer"], None, None))
+                else:
+                    warm.append((p, g, st["momentum_buffer"], None, None))
+            for entries, first in ((fresh, 1), (warm, 0)):
+                if entries:
+                    call("fsc_sgd_nesterov_step", _table(entries), len(entries), float(group["lr"]),
+                         group["momentum"], group["weight_decay"], first, float(self.grad_scale), stream_ptr())
+        return loss
+
+
+OPTIMIZERS = {
+    "adam": partial(FusedAdam, amsgrad=True),
+    "momentum": partial(FusedSGD, momentum=0.9, nesterov=True),
+}
+
+
+class OneCycleScheduler:
+    """Linear warm-up from min_lr to max_lr over the first 30 % of `max_steps`, then linear
+    decay to min_lr / 1000 (reference ops/training.py:208-234).  `step()` sets the lr for the
+    upcoming optimizer step."""
+
+    def __init__(self, optimizer, min_lr, max_lr, max_steps):
+        self.optimizer = optimizer
+        self.min_lr = min_lr
+        self.max_lr = max_lr
+        self.max_steps = max_steps
+        self.epoch = -1
+
+    def lr_at(self, index):
+        knee = int(round(self.max_steps * 0.3))
+        if index < knee:
+            return self.min_lr + (index / knee) * (self.max_lr - self.min_lr)
+        frac = (index - knee) / (self.max_steps - knee)
+        return self.max_lr + frac * (self.min_lr / 1e3 - self.max_lr)
+
+    def step(self):
+        self.epoch += 1
+        lr = self.lr_at(self.epoch)
+        for group in self.optimizer.param_groups:
+            group["lr"] = lr
+
+
+def make_scheduler(params, max_steps):
+    """Descriptor -> callable(optimizer) building the scheduler (reference ops/training.py:15-34)."""
+    name, *args = params.split("_")
+    if name == "steplr":
+        step_size, gamma = int(args[0]), float(args[1])
+        return partial(StepLR, step_size=step_size, gamma=gamma)
+    if name == "1cycle":
+        min_lr, max_lr = float(args[0]), float(args[1])
+        return partial(OneCycleScheduler, min_lr=min_lr, max_lr=max_lr, max_steps=max_steps)
+    raise ValueError("unknown scheduler descriptor %r" % params)
+
+
+def make_step(scheduler, epoch=None, step=None, val_score=None):
+    """StepLR advances per epoch, 1cycle per training step (reference ops/training.py:37-43)."""
+    if isinstance(scheduler, StepLR) and epoch is not None:
+        scheduler.step(epoch)
+    elif isinstance(scheduler, OneCycleScheduler) and step is not None:
+        scheduler.step()

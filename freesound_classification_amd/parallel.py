@@ -1,0 +1,135 @@
+"""Data-parallel glue for the training step: one process per GPU, `torch.distributed` with the
+"nccl" backend (= RCCL over xGMI on ROCm), or "gloo" for CPU tests.
+
+The reference is single-process (train_2d_cnn.py:355-362); data parallelism is the one
+exchange step the hot path needs: a sum all-reduce of the 21.5 M fp32
+gradients per step.  Gradients are packed into a few flat buckets in reverse registration
+order (the head and the deepest block finish their backward first, and own the three largest
+tensors), and each bucket's all-reduce is launched from the autograd hook of its last
+gradient on a side stream, so communication overlaps the rest of backward.  xGMI is
+point-to-point (ring collectives are per-link bound), hence few large buckets rather than
+many small ones.  The 1/world factor is folded into the fused optimizer (`grad_scale`).
+"""
+import torch
+import torch.distributed as dist
+
+
+def initialized():
+    return dist.is_available() and dist.is_initialized()
+
+
+def world_size():
+    return dist.get_world_size() if initialized() else 1
+
+
+def rank():
+    return dist.get_rank() if initialized() else 0
+
+
+def broadcast_module(module, src=0):
+    """Make every replica start from rank `src`'s parameters and buffers."""
+    if world_size() == 1:
+        return
+    with torch.no_grad():
+        for t in list(module.parameters()) + list(module.buffers()):
+            dist.broadcast(t.data, src)
+
+
+def shard_range(total, world=None, index=None):
+    """Contiguous [lo, hi) slice of `total` units owned by rank `index`; sizes differ by <= 1."""
+    world = world_size() if world is None else world
+    index = rank() if index is None else index
+    base, extra = divmod(total, world)
+    lo = index * base + min(index, extra)
+    return lo, lo + base + (1 if index < extra else 0)
+
+
+class BucketedGradReducer:
+    """Sum-all-reduce of parameter gradients in flat buckets, overlapped with backward."""
+
+    def __init__(self, params, bucket_bytes=32 << 20, group=None):
+        self.group = group
+        self.params = [p for p in params if p.requires_grad]
+        self.buckets = []          # list of dict(flat, items=[(param, offset, numel)], pending, handle)
+        self._where = {}
+        order = list(reversed(self.params))
+        cur, cur_elems = [], 0
+        limit = max(1, bucket_bytes // 4)
+        for p in order:
+            if cur and cur_elems + p.numel() > limit:
+                self._close(cur)
+                cur, cur_elems = [], 0
+            cur.append(p)
+            cur_elems += p.numel()
+        if cur:
+            self._close(cur)
+        self._sync = False
+        self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params]
+        self._comm_stream = None
+
+    def _close(self, plist):
+        total = sum(p.numel() for p in plist)
+        flat = torch.zeros(total, device=plist[0].device, dtype=plist[0].dtype)
+        items, off = [], 0
+        for p in plist:
+            items.append((p, off, p.numel()))
+            self._where[id(p)] = (len(self.buckets), off)
+            off += p.numel()
+        self.buckets.append(dict(flat=flat, items=items, pending=len(items), handle=None, launched=False))
+
+    def bucket_sizes(self):
+        return [b["flat"].numel() for b in self.buckets]
+
+    def prepare(self, sync=True):
+        """Call before backward.  sync=False (gradient accumulation micro-step): no communication."""
+        self._sync = sync
+        for b in self.buckets:
+            b["pending"] = len(b["items"])
+            b["handle"] = None
+            b["launched"] = False
+
+    def _launch(self, b):
+        flat = b["flat"]
+        if flat.is_cuda:
+            if self._comm_stream is None:
+                self._comm_stream = torch.cuda.Stream(device=flat.device)
+            self._comm_stream.wait_stream(torch.cuda.current_stream(flat.device))
+            with torch.cuda.stream(self._comm_stream):
+                b["handle"] = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        else:
+            b["handle"] = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        b["launched"] = True
+
+    def _on_grad(self, p):
+        if not self._sync:
+            return
+        bi, off = self._where[id(p)]
+        b = self.buckets[bi]
+        b["flat"][off:off + p.numel()].copy_(p.grad.reshape(-1))
+        b["pending"] -= 1
+        if b["pending"] == 0:
+            self._launch(b)
+
+    def finish(self):
+        """Call after backward: waits for every bucket and re-points p.grad at the reduced data."""
+        if not self._sync:
+            return
+        for b in self.buckets:
+            if not b["launched"]:
+                # some parameter received no gradient this step: contribute zeros for it
+                for p, off, n in b["items"]:
+                    if p.grad is None:
+                        b["flat"][off:off + n].zero_()
+                self._launch(b)
+        for b in self.buckets:
+            b["handle"].wait()
+            if b["flat"].is_cuda:
+                torch.cuda.current_stream(b["flat"].device).wait_stream(self._comm_stream)
+            for p, off, n in b["items"]:
+                p.grad = b["flat"][off:off + n].view_as(p)
+        self._sync = False
+
+    def remove(self):
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []

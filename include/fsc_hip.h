@@ -1,0 +1,214 @@
+/*
+ * fsc_hip.h -- C ABI of libfsc_hip.so, the MI355X (gfx950) kernels behind the
+ * freesound-classification audio-tagging hot path.
+ *
+ * The reference (ex4sperans/freesound-classification) is pure Python on stock ATen ops and
+ * has no FFI of its own; each entry point below cites the reference call site whose device
+ * work it replaces (paths relative to the reference root).  INTEGRATION.md shows the ctypes
+ * binding a maintainer adds on the reference side.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer to contiguous fp32 unless the name ends in _host;
+ *   - activations are NCHW (the reference's layout); the 1-d model uses H == 1;
+ *   - all launches are asynchronous on `stream` (a hipStream_t passed as void*);
+ *   - the caller owns every buffer, including workspaces sized by the *_workspace_bytes /
+ *     *_floats queries; no entry point allocates device memory;
+ *   - return value 0 = success; anything else is an error whose text
+ *     fsc_last_error_string() returns.  No entry point synchronises the device.
+ */
+#ifndef FSC_HIP_H
+#define FSC_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* fsc_stream_t; /* hipStream_t */
+
+int fsc_version(void);
+const char* fsc_last_error_string(void);
+
+/* ------------------------------------------------------------------ front-end (K1-K5)
+ * ops/utils.py:110-127 (torch.stft + magnitude), networks/classifiers.py:565-582
+ * (mel conv1d, log(x+1e-4), frequency-encoding channel). */
+
+/* floats needed for the window + twiddle tables of one n_fft (power of two, 64..4096) */
+size_t fsc_frontend_table_floats(int n_fft);
+/* fills tables with the periodic Hann window and exp(-2*pi*i*m/n_fft), computed in fp64 */
+int fsc_frontend_tables_init(float* tables, int n_fft, fsc_stream_t stream);
+
+/* waveform (N, T) [row stride wave_stride] -> log-mel.
+ * out + n*out_n_stride holds clip n's (n_mel, frames) plane; if freq_channel != 0 a second
+ * plane with linspace(-1, 1, n_mel) broadcast over frames follows it (classifiers.py:553-561).
+ * Banded filterbank: row m uses weights mel_w[j*n_mel + m], j < mel_len[m], against
+ * magnitude bins mel_start[m] + j.  frames = 1 + T / hop. */
+int fsc_frontend_logmel_fwd(const float* wave, int n, int t, long wave_stride,
+                            int n_fft, int hop, const float* tables,
+                            const int* mel_start, const int* mel_len, const float* mel_w,
+                            int n_mel, int max_band, float log_eps,
+                            float* out, long out_n_stride, int freq_channel,
+                            fsc_stream_t stream);
+
+/* waveform -> |STFT| (apply_log == 0, compute_torch_stft itself) or log(|STFT| + eps)
+ * (apply_log != 0, classifiers.py:184-185 / :571-572).  out is (N, n_fft/2+1, frames). */
+int fsc_frontend_stft_fwd(const float* wave, int n, int t, long wave_stride,
+                          int n_fft, int hop, const float* tables, int apply_log,
+                          float log_eps, float* out, long out_n_stride, int freq_channel,
+                          fsc_stream_t stream);
+
+/* ------------------------------------------------------------------ convolution (K7, K10)
+ * nn.Conv2d 3x3 pad 1 / 1x1 (classifiers.py:526-531, 77-81) and nn.Conv1d k3 / k1
+ * (classifiers.py:149-154, 42-46; H == 1, kh == 1).  Implicit GEMM on
+ * v_mfma_f32_16x16x4_f32, weights pre-packed per step by fsc_conv_pack_weights. */
+
+typedef struct {
+    int n, c_in, c_out, h, w; /* output spatial size == input spatial size (stride 1, same pad) */
+    int kh, kw;               /* (3,3), (1,1), (1,3) */
+} fsc_conv_desc;
+
+/* floats of packed-weight workspace for one direction (fwd or dgrad) */
+size_t fsc_conv_packed_floats(const fsc_conv_desc* d, int dgrad);
+/* weight (c_out, c_in, kh, kw) -> packed [tap][k][m]; dgrad != 0 packs the flipped transpose */
+int fsc_conv_pack_weights(const fsc_conv_desc* d, const float* weight, int dgrad,
+                          float* packed, fsc_stream_t stream);
+/* out = conv(in) + bias (accumulate == 0) or out += conv(in) + bias (accumulate != 0).
+ * With dgrad != 0: in has c_out channels, out has c_in channels, bias must be NULL, and
+ * `packed` must come from fsc_conv_pack_weights(dgrad=1). */
+int fsc_conv_fwd(const fsc_conv_desc* d, const float* in, const float* packed,
+                 const float* bias, int dgrad, int accumulate, float* out,
+                 fsc_stream_t stream);
+/* human-readable tiling chosen for this shape (mode 0 fwd, 1 dgrad, 2 wgrad): kernel
+ * instantiation, pixel box, grid, LDS bytes.  For logs, DESIGN.md tables and profiles. */
+int fsc_conv_plan_describe(const fsc_conv_desc* d, int mode, char* buf, size_t buf_len);
+/* bytes of split-K workspace for the weight gradient */
+size_t fsc_conv_wgrad_workspace_bytes(const fsc_conv_desc* d);
+/* dweight (c_out, c_in, kh, kw) = sum_pixels dout x in  (overwrites dweight) */
+int fsc_conv_wgrad(const fsc_conv_desc* d, const float* in, const float* dout,
+                   float* dweight, void* workspace, fsc_stream_t stream);
+
+/* ------------------------------------------------------------------ batch norm + PReLU (K6, K9, K11)
+ * nn.BatchNorm2d/1d (train and eval) fused with the following per-channel PReLU and the
+ * residual add of ResnetBlock(2d) (classifiers.py:524,533-534; 37-104; 543-546).
+ * x is (N, C, HW); HW == 1 covers BatchNorm1d on (N, C). */
+
+size_t fsc_bn_workspace_bytes(int c);
+/* train: batch statistics -> scale/shift (scale = gamma*invstd, shift = beta - mean*scale),
+ * save_mean / save_invstd for backward, running stats updated with `momentum`
+ * (running_var gets the unbiased estimate), exactly one update per call. */
+int fsc_bn_train_stats(const float* x, int n, int c, long hw, const float* gamma,
+                       const float* beta, float eps, float momentum, float* running_mean,
+                       float* running_var, float* save_mean, float* save_invstd,
+                       float* scale, float* shift, void* workspace, fsc_stream_t stream);
+/* eval: scale/shift from the running statistics */
+int fsc_bn_eval_prepare(int c, const float* gamma, const float* beta, const float* running_mean,
+                        const float* running_var, float eps, float* scale, float* shift,
+                        fsc_stream_t stream);
+/* y = act(x*scale + shift [+ residual]); act = PReLU(alpha[c]) if alpha != NULL else identity */
+int fsc_bn_act_fwd(const float* x, const float* residual, const float* scale,
+                   const float* shift, const float* alpha, float* y, int n, int c, long hw,
+                   fsc_stream_t stream);
+/* backward of the fused unit.  Upstream gradient = dy (may be NULL) plus, when the output also
+ * feeds a global max-pool head, gmax_dy[n*c] scattered at position gmax_idx[n*c] of each plane
+ * (both NULL otherwise).  Outputs: dx; dresidual (may be NULL; equals the gradient at the
+ * pre-activation); dgamma, dbeta, dalpha (C each; may be NULL); dx_chan_sum (C, may be NULL) =
+ * per-channel sum of dx = bias gradient of the convolution that produced x. */
+int fsc_bn_act_bwd(const float* dy, const float* gmax_dy, const int* gmax_idx, const float* x,
+                   const float* residual, const float* save_mean, const float* save_invstd,
+                   const float* gamma, const float* beta, const float* alpha, float* dx,
+                   float* dresidual, float* dgamma, float* dbeta, float* dalpha,
+                   float* dx_chan_sum, int n, int c, long hw, void* workspace,
+                   fsc_stream_t stream);
+
+/* ------------------------------------------------------------------ pooling (K8, K12)
+ * nn.MaxPool2d(2,2) / nn.MaxPool1d(2,2), floor mode (classifiers.py:532, 155);
+ * nn.AdaptiveMaxPool2d(1) / 1d(1) (classifiers.py:540, 163). ph is 2 (2-d) or 1 (1-d). */
+int fsc_maxpool_fwd(const float* x, float* y, uint8_t* idx, int nc, int h, int w, int ph,
+                    fsc_stream_t stream);
+int fsc_maxpool_bwd(const float* dy, const uint8_t* idx, float* dx, int nc, int h, int w,
+                    int ph, fsc_stream_t stream);
+int fsc_global_maxpool_fwd(const float* x, float* y, int* idx, int nc, long hw,
+                           fsc_stream_t stream);
+/* dx = (dx_in ? dx_in : 0) + scatter(dy at idx) */
+int fsc_global_maxpool_bwd(const float* dy, const int* idx, const float* dx_in, float* dx,
+                           int nc, long hw, fsc_stream_t stream);
+
+/* ------------------------------------------------------------------ classifier head (K13)
+ * nn.Linear (classifiers.py:544,548), nn.Dropout (:547). */
+/* y (m, n_out) = x (m, k) . w (n_out, k)^T + bias */
+int fsc_linear_fwd(const float* x, const float* w, const float* bias, float* y, int m, int k,
+                   int n_out, fsc_stream_t stream);
+/* dx (m,k) = dy . w ; dw (n_out,k) = dy^T . x ; dbias (n_out) = column sums of dy.
+ * Any of dx / dw / dbias may be NULL. */
+int fsc_linear_bwd(const float* dy, const float* x, const float* w, float* dx, float* dw,
+                   float* dbias, int m, int k, int n_out, fsc_stream_t stream);
+/* inverted dropout with a counter-based generator; mask (uint8) is written for backward */
+int fsc_dropout_fwd(const float* x, float* y, uint8_t* mask, long count, float p,
+                    uint64_t seed, uint64_t offset, fsc_stream_t stream);
+int fsc_dropout_bwd(const float* dy, const uint8_t* mask, float* dx, long count, float p,
+                    fsc_stream_t stream);
+
+/* ------------------------------------------------------------------ losses (K14, K15)
+ * networks/losses.py:47-58 (lsep_loss), :19-22 (binary_cross_entropy),
+ * classifiers.py:687 (sigmoid). */
+/* loss[n] = log(1 + sum_{i,j: t[n,j] < t[n,i]} exp(s[n,j] - s[n,i])) */
+int fsc_lsep_fwd(const float* logits, const float* targets, float* loss, int n, int c,
+                 fsc_stream_t stream);
+/* dlogits[n,k] = dloss[n] * d loss[n] / d s[n,k] */
+int fsc_lsep_bwd(const float* logits, const float* targets, const float* dloss,
+                 float* dlogits, int n, int c, fsc_stream_t stream);
+/* mean over all n*c elements of BCE(sigmoid(x), t), log terms clamped at -100 like torch */
+int fsc_bce_fwd(const float* logits, const float* targets, float* loss_scalar,
+                double* workspace /* 1 double */, long count, fsc_stream_t stream);
+int fsc_bce_bwd(const float* logits, const float* targets, const float* dloss_scalar,
+                float* dlogits, long count, fsc_stream_t stream);
+int fsc_sigmoid(const float* x, float* y, long count, fsc_stream_t stream);
+/* y = scale * mean(x) (count elements) and its backward dx = dy * scale / count */
+int fsc_mean_fwd(const float* x, float* y, long count, float scale, fsc_stream_t stream);
+int fsc_mean_bwd(const float* dy, float* dx, long count, float scale, fsc_stream_t stream);
+
+/* ------------------------------------------------------------------ MixUp (a-8)
+ * ops/audio.py:32-52 applied to a batch resident on the device.  For row n:
+ * equal lengths -> (a + b) / 2; otherwise out = longer * f32(alpha) except
+ * [start, start + shorter) which is REPLACED by shorter * f32(1 - alpha) (`=+` at audio.py:50);
+ * samples past the longer length are zero.  labels = clip(la + lb, 0, 1). */
+int fsc_mixup_batch(const float* a, const float* b, const int* len_a, const int* len_b,
+                    const int* start, const float* alpha, const float* one_minus_alpha,
+                    float* out, int n, long t_a, long t_b, long t_out,
+                    const float* labels_a, const float* labels_b, float* labels_out, int c,
+                    fsc_stream_t stream);
+
+/* ------------------------------------------------------------------ optimizers (K16)
+ * ops/training.py:9-12: Adam(amsgrad=True) and SGD(momentum=0.9, nesterov=True), both with
+ * L2 weight decay folded into the gradient (torch semantics). */
+typedef struct {
+    float* param;
+    const float* grad;
+    float* state0; /* adam: exp_avg        | sgd: momentum buffer */
+    float* state1; /* adam: exp_avg_sq     | sgd: unused */
+    float* state2; /* adam: max_exp_avg_sq | sgd: unused */
+    long count;
+} fsc_opt_tensor;
+
+/* tensors_host is a HOST array (copied into kernel arguments, 24 tensors per launch).
+ * step = 1-based step count used for bias correction; grad_scale multiplies every gradient
+ * first (1/world_size after a sum all-reduce). */
+int fsc_adam_amsgrad_step(const fsc_opt_tensor* tensors_host, int n_tensors, float lr,
+                          float beta1, float beta2, float eps, float weight_decay, int step,
+                          float grad_scale, fsc_stream_t stream);
+/* first_step != 0: momentum buffer := gradient (torch's first-step rule) */
+int fsc_sgd_nesterov_step(const fsc_opt_tensor* tensors_host, int n_tensors, float lr,
+                          float momentum, float weight_decay, int first_step,
+                          float grad_scale, fsc_stream_t stream);
+
+/* ------------------------------------------------------------------ misc device helpers */
+int fsc_fill(float* x, float value, long count, fsc_stream_t stream);
+/* y = a*x + y  (used for gradient accumulation / bucket flattening) */
+int fsc_axpy(const float* x, float a, float* y, long count, fsc_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FSC_HIP_H */

@@ -1,0 +1,268 @@
+"""Model-level parity on the GPU: the accelerated classifiers against the golden vectors the
+imported reference produced (tests/golden/make_golden.py) and against the CPU oracle on the
+same seeded inputs.  fp32 tolerance 1e-3 absolute (BASELINE.json north_star); most checks
+run much tighter."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+if not torch.cuda.is_available():
+    pytest.skip("needs an MI355X", allow_module_level=True)
+
+from freesound_classification_amd import functional as F  # noqa: E402
+from freesound_classification_amd.networks.classifiers import (  # noqa: E402
+    HierarchicalCNNClassificationModel, TwoDimensionalCNNClassificationModel)
+from freesound_classification_amd.networks.losses import lsep_loss  # noqa: E402
+from freesound_classification_amd.ops.utils import lwlrap  # noqa: E402
+from oracle import host as ohost  # noqa: E402
+from oracle import ref_torch as oref  # noqa: E402
+
+TOL = 1e-3
+DEV = "cuda:0"
+
+
+class NS(dict):
+    __getattr__ = dict.__getitem__
+
+
+def experiment(features, blocks, base, growth, start, input_dim, dropout=0.0, n_classes=80, optimizer="adam",
+               lr=1e-3, wd=0.0, scheduler="1cycle_0.0001_0.005", acc=1):
+    return NS(config=NS(
+        network=NS(num_conv_blocks=blocks, start_deep_supervision_on=start, conv_base_depth=base,
+                   growth_rate=growth, output_dropout=dropout, aggregation_type="max"),
+        data=NS(features=features, _input_dim=input_dim, _n_classes=n_classes),
+        train=NS(accumulation_steps=acc, optimizer=optimizer, learning_rate=lr, weight_decay=wd,
+                 scheduler=scheduler, switch_off_augmentations_on=1000, _save_every=1000)))
+
+
+def maxdiff(a, b):
+    return float((torch.as_tensor(a).detach().cpu().double() - torch.as_tensor(b).detach().cpu().double()).abs().max())
+
+
+def load_init(model, g, prefix="init."):
+    sd = {k[len(prefix):]: torch.from_numpy(v) for k, v in g.items() if k.startswith(prefix)}
+    model.load_state_dict(sd)
+
+
+def test_state_dict_keys_and_init_match_reference(golden):
+    keys = golden("g3_state_keys.json")
+    torch.manual_seed(3)
+    m = TwoDimensionalCNNClassificationModel(experiment("mel_1024_512_64", 2, 8, 1.5, 1, 64), device=DEV)
+    got = [[k, list(v.shape), str(v.dtype)] for k, v in m.state_dict().items()]
+    assert got == keys
+    g = golden("g3_tiny2d.npz")
+    for k, v in m.state_dict().items():          # same registration order => same init draws
+        np.testing.assert_array_equal(v.cpu().numpy(), g["init." + k])
+    keys1d = golden("g5_state_keys.json")
+    m1 = HierarchicalCNNClassificationModel(experiment("stft_256_128", 3, 12, 1.5, 1, 129), device=DEV)
+    assert [[k, list(v.shape), str(v.dtype)] for k, v in m1.state_dict().items()] == keys1d
+
+
+def test_single_block_golden(golden):
+    g = golden("g4_block.npz")
+    m = TwoDimensionalCNNClassificationModel(experiment("mel_1024_512_64", 2, 12, 1.5, 0, 64), device=DEV)
+    for idx in range(2):
+        p = "blk%d." % idx
+        mods = m.conv_modules[idx]
+        sd = {k[len(p + "state."):]: torch.from_numpy(v) for k, v in g.items() if k.startswith(p + "state.")}
+        # golden state was saved after the forward; reset the BN buffers to their initial values
+        for k in sd:
+            if k.endswith("running_mean"):
+                sd[k] = torch.zeros_like(sd[k])
+            elif k.endswith("running_var"):
+                sd[k] = torch.ones_like(sd[k])
+            elif k.endswith("num_batches_tracked"):
+                sd[k] = torch.zeros_like(sd[k])
+        mods.load_state_dict(sd)
+        mods.train()
+        x = torch.from_numpy(g[p + "x"]).to(DEV).requires_grad_()
+        y, feat = F.conv_block(x, mods, True, True, 2)
+        assert maxdiff(y, g[p + "y"]) < 1e-4
+        assert maxdiff(feat, torch.from_numpy(g[p + "y"]).flatten(2).amax(2)) < 1e-4
+        y.backward(torch.from_numpy(g[p + "gy"]).to(DEV))
+        assert maxdiff(x.grad, g[p + "gx"]) < 2e-4
+        for k, prm in mods.named_parameters():
+            assert maxdiff(prm.grad, g[p + "grad." + k]) < 3e-4, k
+        for k, v in mods.state_dict().items():
+            if "running" in k:
+                assert maxdiff(v, g[p + "state." + k]) < 1e-4, k
+
+
+def _run_model_case(model, g, n_steps, scalar_loss=False):
+    load_init(model, g)
+    signal = torch.from_numpy(g["signal"]).to(DEV)
+    labels = torch.from_numpy(g["labels"]).to(DEV)
+    model.train()
+    model.make_optimizer(max_steps=100)
+    from freesound_classification_amd.ops.training import make_step
+    for step in range(n_steps):
+        make_step(model.scheduler, step=step + 1)
+        assert abs(model.optimizer.param_groups[0]["lr"] - float(g["lr.%d" % step])) < 1e-12
+        model.optimizer.zero_grad()
+        logits = model(signal)["class_logits"]
+        if scalar_loss:
+            loss = lsep_loss(logits, labels)
+            per = loss.reshape(1)
+            loss.backward()
+        else:
+            per = lsep_loss(logits, labels, average=False)
+            F.mean(per).backward()
+        if step == 0:
+            assert maxdiff(logits, g["logits"]) < TOL
+            assert maxdiff(per, g["loss"]) < TOL
+            worst = 0.0
+            for k, p in model.named_parameters():
+                d = maxdiff(p.grad, g["grad." + k])
+                worst = max(worst, d)
+                assert d < TOL, (k, d)
+            print("worst grad diff", worst)
+            for k, v in model.state_dict().items():
+                if "running" in k:
+                    assert maxdiff(v, g["bn1." + k]) < TOL, k
+                if "num_batches" in k:
+                    assert int(v) == int(g["bn1." + k])
+            model.eval()
+            with torch.no_grad():
+                ev = model(signal)["class_logits"]
+            assert maxdiff(ev, g["eval_logits"]) < TOL
+            assert maxdiff(F.sigmoid(ev), g["eval_probs"]) < TOL
+            model.train()
+        model.optimizer.step()
+    total_lr = sum(float(g["lr.%d" % s]) for s in range(n_steps))
+    for k, v in model.state_dict().items():
+        noise = ("grad." + k) in g and np.abs(g["grad." + k]).max() < 1e-5
+        tol = 4.0 * total_lr if noise else TOL
+        if "running_mean" in k:
+            tol = 2e-3
+        assert maxdiff(v, g["final." + k]) < tol, k
+
+
+def test_tiny_2d_model_golden(golden):
+    m = TwoDimensionalCNNClassificationModel(experiment("mel_1024_512_64", 2, 8, 1.5, 1, 64), device=DEV)
+    _run_model_case(m, golden("g3_tiny2d.npz"), 3)
+
+
+def test_three_block_2d_model_golden(golden):
+    m = TwoDimensionalCNNClassificationModel(experiment("mel_1024_512_64", 3, 10, 1.5, 0, 64), device=DEV)
+    _run_model_case(m, golden("g3b_threeblock2d.npz"), 1)
+
+
+def test_tiny_1d_model_golden(golden):
+    m = HierarchicalCNNClassificationModel(experiment("stft_256_128", 3, 12, 1.5, 1, 129), device=DEV)
+    _run_model_case(m, golden("g5_tiny1d.npz"), 2, scalar_loss=True)
+
+
+@pytest.mark.parametrize("loss_name", ["lsep", "bce"])
+def test_cfg1_end_to_end_golden(golden, loss_name):
+    """cfg 1 of BASELINE.json: 64 x 2 s @ 16 kHz, mel_1024_512_64, 3 blocks base 32 growth 2."""
+    g = golden("g11_cfg1.npz")
+    gen = torch.Generator().manual_seed(int(g["signal_seed"]))
+    signal = (0.1 * torch.randn(64, 32000, 1, generator=gen)).to(DEV)
+    labels = torch.from_numpy(g["labels"]).to(DEV)
+    torch.manual_seed(11)
+    m = TwoDimensionalCNNClassificationModel(
+        experiment("mel_1024_512_64", 3, 32, 2, 1, 64), device=DEV, loss=loss_name)
+    assert sum(p.numel() for p in m.parameters()) == 386516
+    m.train()
+    m.make_optimizer(max_steps=10)
+    from freesound_classification_amd.ops.training import make_step
+    for step in range(2):
+        make_step(m.scheduler, step=step + 1)
+        logits, per, loss = m.training_step(signal, labels)
+        assert maxdiff(logits, g["%s.logits%d" % (loss_name, step)]) < TOL
+        assert abs(float(loss) - float(g["%s.loss%d" % (loss_name, step)])) < TOL
+        probs = F.sigmoid(logits).cpu().numpy()
+        assert abs(lwlrap(labels.cpu().numpy(), probs) - float(g["%s.lwlrap%d" % (loss_name, step)])) < TOL
+
+
+def test_against_oracle_odd_shapes():
+    """A config with awkward channel counts (growth 1.5 -> 14, 21, 31) and a zero-padded tail,
+    checked against the CPU oracle built from the same state dict."""
+    torch.manual_seed(21)
+    exp = experiment("mel_1024_512_64", 3, 14, 1.5, 1, 64)
+    m = TwoDimensionalCNNClassificationModel(exp, device=DEV)
+    ref = oref.TagCNN2d("mel_1024_512_64", 3, 14, 1.5, 1, 80)
+    ref.load_state_dict({k: v.cpu() for k, v in m.state_dict().items()})
+    signal = 0.1 * torch.randn(6, 30000, 1)
+    signal[-1, 17000:] = 0.0
+    labels = torch.zeros(6, 80)
+    labels[torch.arange(6), torch.randint(0, 80, (6,))] = 1.0
+    ref.train()
+    rl = ref(signal)["class_logits"]
+    oref.lsep(rl, labels, average=False).mean().backward()
+    m.train()
+    ml = m(signal.to(DEV))["class_logits"]
+    F.mean(lsep_loss(ml, labels.to(DEV), average=False)).backward()
+    assert maxdiff(ml, rl) < TOL
+    rgrads = dict(ref.named_parameters())
+    for k, p in m.named_parameters():
+        assert maxdiff(p.grad, rgrads[k].grad) < TOL, k
+    ref.eval()
+    m.eval()
+    with torch.no_grad():
+        assert maxdiff(m(signal.to(DEV))["class_logits"], ref(signal)["class_logits"]) < TOL
+
+
+def test_gradient_accumulation_matches_reference_quirk():
+    """accumulation_steps=2: the reference steps on batch 0 and then every second batch
+    (classifiers.py:682); losses are divided by accumulation_steps."""
+    torch.manual_seed(4)
+    exp = experiment("mel_1024_512_64", 2, 8, 1.5, 1, 64, acc=2)
+    m = TwoDimensionalCNNClassificationModel(exp, device=DEV)
+    ref = oref.TagCNN2d("mel_1024_512_64", 2, 8, 1.5, 1, 80)
+    ref.load_state_dict({k: v.cpu() for k, v in m.state_dict().items()})
+    opt = oref.make_adam(ref, 1e-3)
+    m.train()
+    ref.train()
+    m.make_optimizer(max_steps=10)
+    for grp in m.optimizer.param_groups:
+        grp["lr"] = 1e-3
+    batches = []
+    for b in range(3):
+        x = 0.1 * torch.randn(4, 12000, 1)
+        y = torch.zeros(4, 80)
+        y[torch.arange(4), torch.randint(0, 80, (4,))] = 1.0
+        batches.append((x, y))
+    opt.zero_grad()
+    m.optimizer.zero_grad()
+    for b, (x, y) in enumerate(batches):
+        per = oref.lsep(ref(x)["class_logits"], y, average=False) / 2
+        per.mean().backward()
+        if b % 2 == 0:
+            opt.step()
+            opt.zero_grad()
+        logits, _, _ = m.training_step(x.to(DEV), y.to(DEV), step_optimizer=(b % 2 == 0))
+    rl = ref(batches[0][0])["class_logits"]
+    ml = m(batches[0][0].to(DEV))["class_logits"]
+    assert maxdiff(ml, rl) < 5e-3
+
+
+def test_full_size_properties():
+    """BASELINE cfg-2 sizes (batch 128 x 10 s @ 44.1 kHz): size-independent properties.
+    Front-end: rows are independent (a batch row equals the same clip run alone) and frames
+    inside a zero tail equal log(1e-4).  Conv: linearity in the input at full-resolution shape."""
+    torch.manual_seed(0)
+    n, t = 128, 441000
+    wav = 0.1 * torch.randn(n, t, device=DEV)
+    wav[5, 200000:] = 0.0
+    from freesound_classification_amd.ops.utils import make_mel_filterbanks
+    bands = F.MelBands(make_mel_filterbanks("mel_2048_1024_128"), torch.device(DEV))
+    full = F.frontend_logmel(wav, 2048, 1024, bands, True)
+    assert full.shape == (128, 2, 128, 431)
+    assert torch.isfinite(full).all()
+    for row in (0, 5, 127):
+        alone = F.frontend_logmel(wav[row:row + 1].contiguous(), 2048, 1024, bands, True)
+        assert torch.equal(alone[0], full[row])
+    assert abs(float(full[5, 0, :, 300:].max()) - float(np.log(1e-4))) < 1e-5
+    ref = oref.features_from_signal(wav[:2].cpu()[..., None], "mel_2048_1024_128",
+                                    torch.from_numpy(make_mel_filterbanks("mel_2048_1024_128")))
+    assert maxdiff(full[:2, 0], ref) < TOL
+    x = torch.randn(8, 100, 64, 215, device=DEV)
+    w = torch.randn(100, 100, 3, 3, device=DEV) / 30
+    y1 = F.conv_forward(x, w, None)
+    y2 = F.conv_forward(2.5 * x, w, None)
+    assert maxdiff(y2, 2.5 * y1) < 1e-3
+    shifted = torch.roll(x, 1, dims=0)
+    assert torch.equal(F.conv_forward(shifted, w, None), torch.roll(y1, 1, dims=0))
