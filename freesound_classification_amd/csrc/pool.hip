@@ -57,46 +57,46 @@ __global__ __launch_bounds__(kThreads) void maxpool_bwd_kernel(const float* __re
     }
 }
 
-// one wave per plane when planes are small, one block per plane otherwise
+// (value, index) packed into one sortable 64-bit key: larger value wins, NaN beats every number,
+// equal values -> smaller index (ATen's first-maximum rule).
+__device__ __forceinline__ unsigned long long gmax_key(float v, unsigned idx) {
+    unsigned u;
+    if (v != v) {
+        u = 0xFFFFFFFFu;
+    } else {
+        if (v == 0.f) v = 0.f;              // -0 and +0 compare equal
+        u = __float_as_uint(v);
+        u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+    }
+    return ((unsigned long long)u << 32) | (unsigned long long)(0xFFFFFFFFu - idx);
+}
+
+// one workgroup per (n, c) plane
 __global__ __launch_bounds__(kThreads) void gmax_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
                                                             int* __restrict__ idx, long planes, long hw) {
-    __shared__ float sv[kThreads / 64];
-    __shared__ int si[kThreads / 64];
-    __shared__ int sn[kThreads / 64];
+    __shared__ unsigned long long sk[kThreads / 64];
     for (long pl = blockIdx.x; pl < planes; pl += gridDim.x) {
         const float* p = x + pl * hw;
-        // candidate = (isnan, value, index); NaN beats numbers, larger value wins, ties -> smaller index
-        float key = -INFINITY;
-        int ii = 0x7fffffff;
-        int kn = 0;
+        unsigned long long best = 0ull;     // below every real key (index field of a real key is > 0 only if idx < 2^32-1)
         for (long i = threadIdx.x; i < hw; i += kThreads) {
-            const float v = p[i];
-            const int vn = v != v ? 1 : 0;
-            const bool take = (vn > kn) || (vn == kn && !vn && (v > key || (v == key && (int)i < ii)));
-            if (take) { key = v; ii = (int)i; kn = vn; }
+            const unsigned long long k = gmax_key(p[i], (unsigned)i);
+            best = k > best ? k : best;
         }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
-            const float ok = __shfl_xor(key, o, 64);
-            const int oi = __shfl_xor(ii, o, 64);
-            const int on = __shfl_xor(kn, o, 64);
-            const bool take = (on > kn) || (on == kn && (on ? oi < ii : (ok > key || (ok == key && oi < ii))));
-            if (take) { key = ok; ii = oi; kn = on; }
+            const unsigned long long other = __shfl_xor(best, o, 64);
+            best = other > best ? other : best;
         }
         const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
         __syncthreads();
-        if (lane == 0) { sv[wid] = key; si[wid] = ii; sn[wid] = kn; }
+        if (lane == 0) sk[wid] = best;
         __syncthreads();
         if (threadIdx.x == 0) {
-            for (int k = 1; k < kThreads / 64; ++k) {
-                const float ok = sv[k];
-                const int oi = si[k], on = sn[k];
-                const bool take = (on > kn) || (on == kn && (on ? oi < ii : (ok > key || (ok == key && oi < ii))));
-                if (take) { key = ok; ii = oi; kn = on; }
-            }
-            if (ii == 0x7fffffff) ii = 0;
+#pragma unroll
+            for (int k = 1; k < kThreads / 64; ++k) best = sk[k] > best ? sk[k] : best;
+            const unsigned ii = 0xFFFFFFFFu - (unsigned)(best & 0xFFFFFFFFull);
             y[pl] = p[ii];
-            idx[pl] = ii;
+            idx[pl] = (int)ii;
         }
     }
 }
