@@ -62,10 +62,12 @@ def synthetic_batch(w, batch, device, seed):
     return signal, labels
 
 
-def cpu_baseline(w, steps=3, batch=8):
-    """The oracle (CPU restatement of the reference path) on this box's host cores."""
+def cpu_baseline(w, steps=2, batch=4):
+    """The oracle (CPU restatement of the reference path) on this box's host cores.  Bounded
+    sample: ~10-30 s of CPU work.  Thread count is capped at 32: on a 256-thread host the
+    intra-op pool oversubscribes badly on these shapes (measured 0.07 clips/s at 256 threads)."""
     from oracle import ref_torch as oref
-    cores = os.cpu_count() or 1
+    cores = min(32, os.cpu_count() or 1)
     torch.set_num_threads(cores)
     torch.manual_seed(0)
     model = oref.TagCNN2d(w["features"], w["blocks"], w["base"], w["growth"], w["start"], 80,

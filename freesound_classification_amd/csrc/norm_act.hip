@@ -30,26 +30,30 @@ inline Partials carve(void* ws, int c) {
 }
 
 // ---------------------------------------------------------------- statistics
+// Threads are split into (image lane tn, pixel lane ti) with `hwp` = power of two >= min(hw, 256)
+// pixel lanes, so planes smaller than the block still keep every lane busy.
 __global__ __launch_bounds__(kThreads) void stats_partial_kernel(
-    const float* __restrict__ x, int n, int c, long hw, int nsplit, double* __restrict__ part) {
+    const float* __restrict__ x, int n, int c, long hw, int nsplit, int hwp_log2, double* __restrict__ part) {
     __shared__ double scratch[kThreads / 64];
     const int ch = blockIdx.x, sp = blockIdx.y;
     const float pivot = x[(long)ch * hw];
+    const int hwp = 1 << hwp_log2, groups = kThreads >> hwp_log2;
+    const int tn = threadIdx.x >> hwp_log2, ti = threadIdx.x & (hwp - 1);
     float s1 = 0.f, s2 = 0.f;
-    const bool vec = (hw & 3) == 0;
-    for (int b = sp; b < n; b += nsplit) {
+    const bool vec = (hw & 3) == 0 && hwp == kThreads;
+    for (int b = sp * groups + tn; b < n; b += nsplit * groups) {
         const float* p = x + ((long)b * c + ch) * hw;
         if (vec) {
             const float4* p4 = reinterpret_cast<const float4*>(p);
             const long n4 = hw >> 2;
-            for (long i = threadIdx.x; i < n4; i += kThreads) {
+            for (long i = ti; i < n4; i += kThreads) {
                 const float4 v = p4[i];
                 const float a0 = v.x - pivot, a1 = v.y - pivot, a2 = v.z - pivot, a3 = v.w - pivot;
                 s1 += (a0 + a1) + (a2 + a3);
                 s2 += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
             }
         } else {
-            for (long i = threadIdx.x; i < hw; i += kThreads) {
+            for (long i = ti; i < hw; i += hwp) {
                 const float a0 = p[i] - pivot;
                 s1 += a0;
                 s2 += a0 * a0;
@@ -161,7 +165,27 @@ __global__ __launch_bounds__(kThreads) void fwd_plane_kernel(
     }
 }
 
-// small planes: flat indexing
+// planes of 2..511 pixels: one wavefront per (n, c) plane, four planes per workgroup
+__global__ __launch_bounds__(kThreads) void fwd_wave_kernel(
+    const float* __restrict__ x, const float* __restrict__ res, const float* __restrict__ scale,
+    const float* __restrict__ shift, const float* __restrict__ alpha, float* __restrict__ y, int c, long hw,
+    long planes) {
+    const long plane = (long)blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6);
+    if (plane >= planes) return;
+    const int lane = threadIdx.x & 63;
+    const int ch = (int)(plane % c);
+    const float sc = scale[ch], sh = shift[ch];
+    const bool has_alpha = alpha != nullptr;
+    const float al = has_alpha ? alpha[ch] : 0.f;
+    const long base = plane * hw;
+    for (long i = lane; i < hw; i += 64) {
+        float z = fmaf(x[base + i], sc, sh);
+        if (res) z += res[base + i];
+        y[base + i] = act(z, al, has_alpha);
+    }
+}
+
+// hw == 1 (BatchNorm1d on (N, C)): flat indexing
 __global__ void fwd_flat_kernel(const float* __restrict__ x, const float* __restrict__ res,
                                 const float* __restrict__ scale, const float* __restrict__ shift,
                                 const float* __restrict__ alpha, float* __restrict__ y, int c, long hw, long total) {
@@ -196,22 +220,25 @@ __device__ __forceinline__ float upstream(const BwdArgs& a, const float* pdy, lo
 }
 
 // partial sums per (channel, split): [0]=sum dz, [1]=sum dz*xhat, [2]=sum dy*min(z,0)
-__global__ __launch_bounds__(kThreads) void bwd_partial_kernel(BwdArgs a, int nsplit, double* __restrict__ part) {
+__global__ __launch_bounds__(kThreads) void bwd_partial_kernel(BwdArgs a, int nsplit, int hwp_log2,
+                                                               double* __restrict__ part) {
     __shared__ double scratch[kThreads / 64];
     const int ch = blockIdx.x, sp = blockIdx.y;
     const float mean = a.mean[ch], invstd = a.invstd[ch];
     const float g = a.gamma ? a.gamma[ch] : 1.f, b = a.beta ? a.beta[ch] : 0.f;
     const bool has_alpha = a.alpha != nullptr;
     const float al = has_alpha ? a.alpha[ch] : 1.f;
+    const int hwp = 1 << hwp_log2, groups = kThreads >> hwp_log2;
+    const int tn = threadIdx.x >> hwp_log2, ti = threadIdx.x & (hwp - 1);
     float s0 = 0.f, s1 = 0.f, s2 = 0.f;
-    for (int nb = sp; nb < a.n; nb += nsplit) {
+    for (int nb = sp * groups + tn; nb < a.n; nb += nsplit * groups) {
         const long plane = (long)nb * a.c + ch;
         const float* px = a.x + plane * a.hw;
         const float* pr = a.res ? a.res + plane * a.hw : nullptr;
         const float* pdy = a.dy ? a.dy + plane * a.hw : nullptr;
         const float gval = a.gmax_dy ? a.gmax_dy[plane] : 0.f;
         const long gpos = a.gmax_dy ? (long)a.gmax_idx[plane] : -1;
-        for (long i = threadIdx.x; i < a.hw; i += kThreads) {
+        for (long i = ti; i < a.hw; i += hwp) {
             const float xh = (px[i] - mean) * invstd;
             float z = fmaf(xh, g, b);
             if (pr) z += pr[i];
@@ -310,6 +337,43 @@ __global__ __launch_bounds__(kThreads) void bwd_apply_plane_kernel(BwdArgs a, co
     }
 }
 
+// planes of 2..511 pixels: one wavefront per plane; the per-channel sum of dx leaves the wave as
+// ONE atomic (the flat kernel below issued one per element and serialised on C addresses)
+__global__ __launch_bounds__(kThreads) void bwd_apply_wave_kernel(BwdArgs a, const float* __restrict__ coef,
+                                                                   float* __restrict__ dx, float* __restrict__ dres,
+                                                                   float* dx_chan_sum, long planes) {
+    const long plane = (long)blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6);
+    if (plane >= planes) return;
+    const int lane = threadIdx.x & 63;
+    const int ch = (int)(plane % a.c);
+    const float mean = a.mean[ch], invstd = a.invstd[ch];
+    const float g = a.gamma ? a.gamma[ch] : 1.f, b = a.beta ? a.beta[ch] : 0.f;
+    const bool has_alpha = a.alpha != nullptr;
+    const float al = has_alpha ? a.alpha[ch] : 1.f;
+    const float c1 = coef[ch * 2], c2 = coef[ch * 2 + 1];
+    const float k = g * invstd;
+    const long base = plane * a.hw;
+    const float gval = a.gmax_dy ? a.gmax_dy[plane] : 0.f;
+    const long gpos = a.gmax_dy ? (long)a.gmax_idx[plane] : -1;
+    float acc = 0.f;
+    for (long i = lane; i < a.hw; i += 64) {
+        const float xh = (a.x[base + i] - mean) * invstd;
+        float z = fmaf(xh, g, b);
+        if (a.res) z += a.res[base + i];
+        float up = a.dy ? a.dy[base + i] : 0.f;
+        if (i == gpos) up += gval;
+        const float dz = (has_alpha && !(z > 0.f)) ? al * up : up;
+        const float d = k * (dz - c1 - xh * c2);
+        dx[base + i] = d;
+        if (dres) dres[base + i] = dz;
+        acc += d;
+    }
+    if (dx_chan_sum) {
+        acc = fsc::wave_sum(acc);
+        if (lane == 0) atomicAdd(dx_chan_sum + ch, acc);
+    }
+}
+
 __global__ void bwd_apply_flat_kernel(BwdArgs a, const float* __restrict__ coef, float* __restrict__ dx,
                                       float* __restrict__ dres, float* dx_chan_sum, long total) {
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -341,6 +405,12 @@ int pick_split(int n, int c, long hw) {
     return (int)s;
 }
 
+int hwp_log2_for(long hw) {
+    int l = 0;
+    while ((1L << l) < hw && l < 8) ++l;      // 2^l >= min(hw, 256)
+    return l;
+}
+
 int plane_grid_y(long hw) {
     long per = (hw & 3) == 0 ? hw / 4 : hw;
     long gy = (per + kThreads * 4 - 1) / (kThreads * 4);
@@ -370,7 +440,8 @@ int fsc_bn_train_stats(const float* x, int n, int c, long hw, const float* gamma
         hipLaunchKernelGGL(stats_rows_kernel, dim3(fsc::ceil_div(c, 128)), dim3(128), 0, st, x, n, c, p.part);
     } else {
         nsplit = pick_split(n, c, hw);
-        hipLaunchKernelGGL(stats_partial_kernel, dim3(c, nsplit), dim3(kThreads), 0, st, x, n, c, hw, nsplit, p.part);
+        hipLaunchKernelGGL(stats_partial_kernel, dim3(c, nsplit), dim3(kThreads), 0, st, x, n, c, hw, nsplit,
+                           hwp_log2_for(hw), p.part);
     }
     hipLaunchKernelGGL(stats_finalize_kernel, dim3(fsc::ceil_div(c, 128)), dim3(128), 0, st, x, c, hw,
                        (double)n * (double)hw, nsplit, p.part, gamma, beta, eps, momentum, running_mean,
@@ -397,6 +468,10 @@ int fsc_bn_act_fwd(const float* x, const float* residual, const float* scale, co
     if (hw >= 512) {
         hipLaunchKernelGGL(fwd_plane_kernel, dim3((unsigned)((long)n * c), plane_grid_y(hw)), dim3(kThreads), 0, st, x,
                            residual, scale, shift, alpha, y, c, hw);
+    } else if (hw > 1) {
+        const long planes = (long)n * c;
+        hipLaunchKernelGGL(fwd_wave_kernel, dim3((unsigned)((planes + 3) / 4)), dim3(kThreads), 0, st, x, residual,
+                           scale, shift, alpha, y, c, hw, planes);
     } else {
         long blocks = (total + 255) / 256;
         if (blocks > 8192) blocks = 8192;
@@ -426,7 +501,7 @@ int fsc_bn_act_bwd(const float* dy, const float* gmax_dy, const int* gmax_idx, c
         hipLaunchKernelGGL(bwd_rows_kernel, dim3(fsc::ceil_div(c, 128)), dim3(128), 0, st, a, p.part);
     } else {
         nsplit = pick_split(n, c, hw);
-        hipLaunchKernelGGL(bwd_partial_kernel, dim3(c, nsplit), dim3(kThreads), 0, st, a, nsplit, p.part);
+        hipLaunchKernelGGL(bwd_partial_kernel, dim3(c, nsplit), dim3(kThreads), 0, st, a, nsplit, hwp_log2_for(hw), p.part);
     }
     hipLaunchKernelGGL(bwd_finalize_kernel, dim3(fsc::ceil_div(c, 128)), dim3(128), 0, st, c, (double)n * (double)hw,
                        nsplit, p.part, dgamma, dbeta, dalpha, p.coef, dx_chan_sum);
@@ -434,6 +509,10 @@ int fsc_bn_act_bwd(const float* dy, const float* gmax_dy, const int* gmax_idx, c
     if (hw >= 512) {
         hipLaunchKernelGGL(bwd_apply_plane_kernel, dim3((unsigned)((long)n * c), plane_grid_y(hw)), dim3(kThreads), 0,
                            st, a, p.coef, dx, dresidual, dx_chan_sum);
+    } else if (hw > 1) {
+        const long planes = (long)n * c;
+        hipLaunchKernelGGL(bwd_apply_wave_kernel, dim3((unsigned)((planes + 3) / 4)), dim3(kThreads), 0, st, a, p.coef,
+                           dx, dresidual, dx_chan_sum, planes);
     } else {
         long blocks = (total + 255) / 256;
         if (blocks > 8192) blocks = 8192;
