@@ -45,8 +45,22 @@ template <int KH, int KW>
 struct FwdCfg {
     static constexpr int TAPS = KH * KW;
     static constexpr int KC = TAPS == 1 ? 32 : 8;                 // input channels per chunk
-    static constexpr int MAXE = TAPS == 1 ? 16 : 8;               // staged input elements per thread
 };
+
+// 16 bytes of zeros: the source of every lane whose element lies outside the image / channel range
+__device__ __attribute__((aligned(16))) float g_zero16[4] = {0.f, 0.f, 0.f, 0.f};
+
+typedef __attribute__((address_space(3))) void* lds_ptr;
+typedef __attribute__((address_space(1))) const void* glb_ptr;
+
+// LDS-DMA: each lane copies 16 / 4 bytes from its own global address to (wave-uniform LDS base +
+// lane * size).  No VGPR staging; completion is tracked by vmcnt (hipcc drains it at __syncthreads).
+__device__ __forceinline__ void glds16(const float* src, float* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((glb_ptr)src, (lds_ptr)lds_wave_base, 16, 0, 0);
+}
+__device__ __forceinline__ void glds4(const float* src, float* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((glb_ptr)src, (lds_ptr)lds_wave_base, 4, 0, 0);
+}
 
 // -------------------------------------------------------------------------------------------
 template <int KH, int KW, int COT, int PT>
@@ -55,19 +69,21 @@ __global__ __launch_bounds__(kThreads) void conv_fwd_kernel(Geom g, const float*
                                                             const float* __restrict__ bias,
                                                             float* __restrict__ out, int accumulate) {
     using C = FwdCfg<KH, KW>;
-    constexpr int TAPS = C::TAPS, KC = C::KC, MAXE = C::MAXE;
+    constexpr int TAPS = C::TAPS, KC = C::KC;
     constexpr int CO_BLK = COT * 16;
     constexpr int COS = CO_BLK + ((CO_BLK % 32 == 16) ? 0 : 16);   // == 16 (mod 32)
-    constexpr int W4_PER_ROW = CO_BLK / 4;
-    constexpr int W4_TOTAL = TAPS * KC * W4_PER_ROW;
-    constexpr int NW4 = (W4_TOTAL + kThreads - 1) / kThreads;
+    constexpr int WROW4 = COS / 4;                                  // float4 slots per LDS weight row
+    constexpr int W4_TOTAL = TAPS * KC * WROW4;
+    constexpr int NWI = (W4_TOTAL + kThreads - 1) / kThreads;       // weight DMA instructions per wave
+    constexpr int WL_FLOATS = TAPS * KC * COS;
     constexpr int PADH = KH / 2, PADW = KW / 2;
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* wl = smem;                       // [TAPS*KC][COS]
-    float* il = smem + TAPS * KC * COS;     // [KC][plane]
+    const int il_floats = KC * g.plane;
+    const int buf_floats = WL_FLOATS + ((il_floats + 3) & ~3);      // one stage: weights then input box
 
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lm = lane & 15, kq = lane >> 4;
 
     // ---- which box
@@ -79,37 +95,50 @@ __global__ __launch_bounds__(kThreads) void conv_fwd_kernel(Geom g, const float*
     const long p0 = (long)blockIdx.x * g.npix;          // flat mode
     const int co0 = blockIdx.y * CO_BLK;
 
-    // ---- per-thread staging plan for the input box (chunk-invariant)
-    int e_goff[MAXE];     // offset inside the input tensor relative to channel ci0 of image 0, or -1
-    int e_lk[MAXE];       // (k << 20) | lds offset
-    const int n_elems = KC * g.npos;
+    // ---- per-lane DMA plan (chunk-invariant).  Weight slab: LDS image [TAPS*KC][COS] is filled
+    //      linearly, 16 B per lane; instruction iq = q*4 + wid covers float4 slots [iq*64, iq*64+64).
+    int w_off[NWI];       // source offset (floats) relative to packed + ci0*m_pad + co0; -1 = skip (row padding)
 #pragma unroll
-    for (int q = 0; q < MAXE; ++q) {
-        const int e = tid + q * kThreads;
-        e_goff[q] = -1;
-        e_lk[q] = -1;
-        if (e < n_elems) {
-            const int k = e / g.npos, pos = e - k * g.npos;
-            long goff = -1;
-            int loff;
-            if (g.flat) {
-                const long pg = p0 + pos;
-                loff = pos;
-                if (pos < g.npix && pg < g.flat_total) {
-                    const long img = pg / g.hw, i = pg - img * g.hw;
-                    goff = (img * g.cin + k) * g.hw + i;
+    for (int q = 0; q < NWI; ++q) {
+        const int f4 = (q * 4 + wid) * 64 + lane;
+        w_off[q] = -1;
+        if (f4 < W4_TOTAL) {
+            const int row = f4 / WROW4, c4 = f4 - row * WROW4;
+            const int tap = row / KC, k = row - tap * KC;
+            if (c4 * 4 < CO_BLK) w_off[q] = (tap * g.k_pad + k) * g.m_pad + c4 * 4;
+        }
+    }
+    //      Input box: LDS image [KC][plane], 4 B per lane; instruction iq covers floats [iq*64, iq*64+64).
+    constexpr int NXI_MAX = TAPS == 1 ? 20 : 9;
+    const int nxi = (il_floats + kThreads - 1) / kThreads;          // <= NXI_MAX (checked on the host)
+    int x_off[NXI_MAX];   // offset inside the input tensor relative to channel ci0; -1 = zero fill; -2 = skip
+    int x_k[NXI_MAX];
+#pragma unroll
+    for (int q = 0; q < NXI_MAX; ++q) {
+        const int f = (q * 4 + wid) * 64 + lane;
+        x_off[q] = -2;
+        x_k[q] = 0;
+        if (q < nxi && f < il_floats) {
+            const int k = f / g.plane, pos = f - k * g.plane;
+            x_k[q] = k;
+            if (pos < g.npos) {
+                long goff = -1;
+                if (g.flat) {
+                    const long pg = p0 + pos;
+                    if (pos < g.npix && pg < g.flat_total) {
+                        const unsigned img = (unsigned)pg / (unsigned)g.hw, i = (unsigned)pg - img * (unsigned)g.hw;
+                        goff = ((long)img * g.cin + k) * g.hw + i;
+                    }
+                } else {
+                    const int per = g.rows * g.cols;
+                    const int b = pos / per, rem = pos - b * per;
+                    const int rr = rem / g.cols, cc = rem - rr * g.cols;
+                    const int gh = h0 + rr - PADH, gw = w0 + cc - PADW;
+                    if (n0 + b < g.n && gh >= 0 && gh < g.h && gw >= 0 && gw < g.w)
+                        goff = ((long)(n0 + b) * g.cin + k) * g.hw + (long)gh * g.w + gw;
                 }
-            } else {
-                const int per = g.rows * g.cols;
-                const int b = pos / per, rem = pos - b * per;
-                const int rr = rem / g.cols, cc = rem - rr * g.cols;
-                const int gh = h0 + rr - PADH, gw = w0 + cc - PADW;
-                loff = pos;
-                if (n0 + b < g.n && gh >= 0 && gh < g.h && gw >= 0 && gw < g.w)
-                    goff = ((long)(n0 + b) * g.cin + k) * g.hw + (long)gh * g.w + gw;
+                x_off[q] = (int)goff;      // tensors on this path stay below 2^31 elements (checked on host)
             }
-            e_goff[q] = (int)goff;      // tensors on this path stay below 2^31 elements (checked on host)
-            e_lk[q] = (k << 20) | (k * g.plane + loff);
         }
     }
 
@@ -126,8 +155,8 @@ __global__ __launch_bounds__(kThreads) void conv_fwd_kernel(Geom g, const float*
                 const long pg = p0 + p;
                 pix_l[pt] = p;
                 if (pg < g.flat_total) {
-                    const long img = pg / g.hw, i = pg - img * g.hw;
-                    pix_g[pt] = img * g.cout * g.hw + i;
+                    const unsigned img = (unsigned)pg / (unsigned)g.hw, i = (unsigned)pg - img * (unsigned)g.hw;
+                    pix_g[pt] = (long)img * g.cout * g.hw + i;
                 }
             } else {
                 const int per = g.th * g.tw;
@@ -146,72 +175,79 @@ __global__ __launch_bounds__(kThreads) void conv_fwd_kernel(Geom g, const float*
 #pragma unroll
         for (int j = 0; j < PT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    float4 sw[NW4];
-    float sx[MAXE];
-
-    auto load_chunk = [&](int ci0) {
+    const float* zero = g_zero16;
+    auto issue_chunk = [&](int ci0, float* buf) {
+        const float* wsrc = packed + (long)ci0 * g.m_pad + co0;
 #pragma unroll
-        for (int q = 0; q < NW4; ++q) {
-            const int idx = tid + q * kThreads;
-            sw[q] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (idx < W4_TOTAL) {
-                const int row = idx / W4_PER_ROW, c4 = idx - row * W4_PER_ROW;
-                const int tap = row / KC, k = row - tap * KC;
-                sw[q] = *reinterpret_cast<const float4*>(packed + ((long)tap * g.k_pad + ci0 + k) * g.m_pad + co0 + c4 * 4);
+        for (int q = 0; q < NWI; ++q) {
+            if (w_off[q] >= 0) glds16(wsrc + w_off[q], buf + (q * 4 + wid) * 256);
+        }
+        const float* xsrc = in + (long)ci0 * g.hw;
+        float* il = buf + WL_FLOATS;
+#pragma unroll
+        for (int q = 0; q < NXI_MAX; ++q) {
+            if (x_off[q] != -2) {
+                const bool live = x_off[q] >= 0 && ci0 + x_k[q] < g.cin;
+                glds4(live ? xsrc + x_off[q] : zero, il + (q * 4 + wid) * 64);
             }
         }
-        const long cbase = (long)ci0 * g.hw;
-#pragma unroll
-        for (int q = 0; q < MAXE; ++q) {
-            float v = 0.f;
-            if (e_goff[q] >= 0 && ci0 + (e_lk[q] >> 20) < g.cin) v = in[cbase + e_goff[q]];
-            sx[q] = v;
-        }
-    };
-    auto store_chunk = [&]() {
-#pragma unroll
-        for (int q = 0; q < NW4; ++q) {
-            const int idx = tid + q * kThreads;
-            if (idx < W4_TOTAL) {
-                const int row = idx / W4_PER_ROW, c4 = idx - row * W4_PER_ROW;
-                *reinterpret_cast<float4*>(wl + row * COS + c4 * 4) = sw[q];
-            }
-        }
-#pragma unroll
-        for (int q = 0; q < MAXE; ++q)
-            if (e_lk[q] >= 0) il[e_lk[q] & 0xFFFFF] = sx[q];
     };
 
     const int nchunks = g.k_pad / KC;
-    load_chunk(0);
-    store_chunk();
-    __syncthreads();
+    const int k_live = (g.cin + 3) & ~3;       // k-steps beyond the real channels are skipped
+    constexpr int NSTEP = TAPS * (KC / 4);
+
+    // one MFMA k-step: 4 input channels (kq picks this lane's) of one tap
+    auto load_ab = [&](const float* wl, const float* il, int step, float (&a)[COT], float (&b)[PT]) {
+        const int tap = step / (KC / 4), ks = step - tap * (KC / 4);
+        const int tapoff = (tap / KW) * g.cols + (tap % KW);
+        const float* wrow = wl + (tap * KC + ks * 4 + kq) * COS + lm;
+#pragma unroll
+        for (int i = 0; i < COT; ++i) a[i] = wrow[i * 16];
+        const float* irow = il + (ks * 4 + kq) * g.plane + tapoff;
+#pragma unroll
+        for (int j = 0; j < PT; ++j) b[j] = irow[pix_l[j]];
+    };
+    auto mfma_all = [&](const float (&a)[COT], const float (&b)[PT]) {
+#pragma unroll
+        for (int i = 0; i < COT; ++i)
+#pragma unroll
+            for (int j = 0; j < PT; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
+    };
+
+    issue_chunk(0, smem);
     for (int c = 0; c < nchunks; ++c) {
-        const bool more = c + 1 < nchunks;
-        if (more) load_chunk((c + 1) * KC);
-#pragma unroll
-        for (int tap = 0; tap < TAPS; ++tap) {
-            const int tapoff = (tap / KW) * g.cols + (tap % KW);
-#pragma unroll
-            for (int ks = 0; ks < KC / 4; ++ks) {
-                float a[COT], b[PT];
-                const float* wrow = wl + (tap * KC + ks * 4 + kq) * COS + lm;
-#pragma unroll
-                for (int i = 0; i < COT; ++i) a[i] = wrow[i * 16];
-                const float* irow = il + (ks * 4 + kq) * g.plane + tapoff;
-#pragma unroll
-                for (int j = 0; j < PT; ++j) b[j] = irow[pix_l[j]];
-#pragma unroll
-                for (int i = 0; i < COT; ++i)
-#pragma unroll
-                    for (int j = 0; j < PT; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
-            }
-        }
+        // the DMA of chunk c has landed (vmcnt drained at the barrier) and every wave has finished
+        // reading the other stage, which chunk c+1 now overwrites while this chunk is multiplied
         __syncthreads();
-        if (more) {
-            store_chunk();
-            __syncthreads();
+        float* cur = smem + (c & 1) * buf_floats;
+        if (c + 1 < nchunks) issue_chunk((c + 1) * KC, smem + ((c + 1) & 1) * buf_floats);
+        const float* wl = cur;
+        const float* il = cur + WL_FLOATS;
+        const int ks_live = (k_live - c * KC) >> 2;          // >= 1
+        if (ks_live >= KC / 4) {
+            // full chunk: branch-free, operands of step s+1 are fetched from LDS while the MFMAs
+            // of step s run (register double buffer)
+            float a[2][COT], b[2][PT];
+            load_ab(wl, il, 0, a[0], b[0]);
+#pragma unroll
+            for (int s = 0; s < NSTEP; ++s) {
+                if (s + 1 < NSTEP) load_ab(wl, il, s + 1, a[(s + 1) & 1], b[(s + 1) & 1]);
+                __builtin_amdgcn_sched_barrier(0);      // keep the prefetch ahead of this step's MFMAs
+                mfma_all(a[s & 1], b[s & 1]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
+            // channel tail (c_in not a multiple of KC): only the live k-steps of every tap
+#pragma unroll
+            for (int tap = 0; tap < TAPS; ++tap) {
+                for (int ks = 0; ks < ks_live; ++ks) {
+                    float a[COT], b[PT];
+                    load_ab(wl, il, tap * (KC / 4) + ks, a, b);
+                    mfma_all(a, b);
+                }
+            }
         }
     }
 
@@ -261,11 +297,12 @@ __global__ void pack_kernel(const float* __restrict__ w, float* __restrict__ pac
 template <int KH, int KW>
 struct WgCfg {
     static constexpr int TAPS = KH * KW;
-    static constexpr int WAVES = TAPS == 1 ? 4 : 6;
-    static constexpr int NPW = TAPS == 9 ? 3 : 2;                 // (ci-tile, tap) pairs per wave
-    static constexpr int CIT = WAVES * NPW / TAPS;                // ci tiles (16 channels) per workgroup
-    static constexpr int PIXC = 64;                               // pixels per chunk (K of the GEMM)
-    static constexpr int MAXPOS = TAPS == 1 ? 1 : (TAPS == 3 ? 2 : 3);   // staged positions per lane (x 64)
+    static constexpr int WAVES = 4;                               // one wave per SIMD: two workgroups keep a CU balanced
+    static constexpr int CIT = TAPS == 9 ? 2 : (TAPS == 3 ? 4 : 8);   // ci tiles (16 channels) per workgroup
+    static constexpr int NT = CIT * TAPS;                         // (ci-tile, tap) pairs per workgroup
+    static constexpr int NPW = (NT + WAVES - 1) / WAVES;          // pairs per wave (3x3: 5,5,4,4)
+    static constexpr int PIXC = 64;                               // pixels per unit (K of the GEMM) = one wave
+    static constexpr int MAXPOS64 = TAPS == 1 ? 1 : (TAPS == 3 ? 2 : 3);   // staged positions per lane (x 64)
 };
 
 struct WgGeom {
@@ -274,7 +311,7 @@ struct WgGeom {
     int nb, th, tw, tiles_n, tiles_h, tiles_w;
     int rows, cols, plane, npos, npix;
     int ci_pad, co_pad;
-    int units;            // pixel tiles in total
+    int units;            // pixel boxes in total
     int nsplit;
     int ci_blocks;
 };
@@ -282,16 +319,23 @@ struct WgGeom {
 template <int KH, int KW>
 constexpr int wg_threads() { return WgCfg<KH, KW>::WAVES * 64; }
 
+// One workgroup owns a (co block, ci block) pair and walks the pixel boxes split, split+nsplit, ...
+// Per box ("unit" = up to 64 pixels) the dOut tile [CO_BLK][66] and the halo'd input tile
+// [CI_BLK][plane] are copied by LDS-DMA (lane = pixel / staged position, so the per-lane source
+// offset is computed once per unit; each DMA instruction is one channel row).  No VGPR staging:
+// the kernel fits two workgroups (12 waves, 3 per SIMD) on a CU, which a 6-wave workgroup needs
+// to keep all four SIMDs evenly loaded.  Row strides are == 2 (mod 32) so the 16-row x 2-pixel
+// operand reads of an MFMA hit 32 distinct banks.
 template <int KH, int KW, int MT>
 __global__ __launch_bounds__((wg_threads<KH, KW>())) void conv_wgrad_kernel(WgGeom g, const float* __restrict__ in,
-                                                                               const float* __restrict__ dout,
-                                                                               float* __restrict__ part) {
+                                                                           const float* __restrict__ dout,
+                                                                           float* __restrict__ part) {
     using C = WgCfg<KH, KW>;
-    constexpr int TAPS = C::TAPS, WAVES = C::WAVES, NPW = C::NPW, CIT = C::CIT, PIXC = C::PIXC, MAXPOS = C::MAXPOS;
+    constexpr int TAPS = C::TAPS, WAVES = C::WAVES, NPW = C::NPW, CIT = C::CIT, PIXC = C::PIXC, NT = C::NT;
+    constexpr int MAXPOS64 = C::MAXPOS64;
     constexpr int CO_BLK = MT * 16, CI_BLK = CIT * 16;
     constexpr int DS = PIXC + 2;                                   // == 2 (mod 32)
-    constexpr int ND = (CO_BLK + WAVES - 1) / WAVES;               // dout rows staged per wave
-    constexpr int NI = (CI_BLK + WAVES - 1) / WAVES;               // input channels staged per wave
+    constexpr int NKS = PIXC / 4;
     constexpr int PADH = KH / 2, PADW = KW / 2;
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -299,27 +343,26 @@ __global__ __launch_bounds__((wg_threads<KH, KW>())) void conv_wgrad_kernel(WgGe
     float* il = smem + CO_BLK * DS;                // [CI_BLK][plane]
     int* ptab = reinterpret_cast<int*>(il + CI_BLK * g.plane);   // [PIXC] LDS offset of pixel p inside a staged channel
 
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lm = lane & 15, kq = lane >> 4;
     const int co0 = (blockIdx.x / g.ci_blocks) * CO_BLK;
     const int ci0 = (blockIdx.x % g.ci_blocks) * CI_BLK;
     const int split = blockIdx.y;
 
-    // chunk-invariant decode of this lane's pixel (for dout) and staged positions (for in)
-    const int per_pix = g.th * g.tw;
-    int pb = 0, pr = 0, pc = 0;
-    const bool pix_live = lane < g.npix;
-    if (pix_live) {
+    // ---- unit-invariant decode: lane = pixel (dOut) and lane + 64 j = staged position (input)
+    const int per_pix = g.th * g.tw, per_pos = g.rows * g.cols;
+    int pb = -1, pr = 0, pc = 0;
+    if (lane < g.npix) {
         pb = lane / per_pix;
         const int rem = lane - pb * per_pix;
         pr = rem / g.tw;
         pc = rem - pr * g.tw;
     }
-    if (tid < PIXC) ptab[tid] = pix_live ? (pb * g.rows + pr) * g.cols + pc : 0;
-    int qb[MAXPOS], qr[MAXPOS], qc[MAXPOS];
-    const int per_pos = g.rows * g.cols;
+    if (tid < PIXC) ptab[tid] = pb >= 0 ? (pb * g.rows + pr) * g.cols + pc : 0;
+    int qb[MAXPOS64], qr[MAXPOS64], qc[MAXPOS64];
 #pragma unroll
-    for (int j = 0; j < MAXPOS; ++j) {
+    for (int j = 0; j < MAXPOS64; ++j) {
         const int pos = lane + 64 * j;
         qb[j] = -1; qr[j] = 0; qc[j] = 0;
         if (pos < g.npos) {
@@ -336,96 +379,81 @@ __global__ __launch_bounds__((wg_threads<KH, KW>())) void conv_wgrad_kernel(WgGe
 #pragma unroll
         for (int i = 0; i < MT; ++i) acc[s][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    float sd[ND];
-    float sx[NI][MAXPOS];
-
-    auto load_unit = [&](int u) {
+    const float* zero = g_zero16;
+    // The DMA loops stay rolled on purpose: unrolled, hipcc hoists dozens of registers of
+    // unit-invariant 64-bit row offsets out of the unit loop and occupancy drops to one workgroup.
+    auto issue_unit = [&](int u) {
         int t = u;
         const int twi = t % g.tiles_w; t /= g.tiles_w;
         const int thi = t % g.tiles_h; t /= g.tiles_h;
         const int n0 = t * g.nb, h0 = thi * g.th, w0 = twi * g.tw;
-        long dgo = -1;
-        if (pix_live && n0 + pb < g.n && h0 + pr < g.h && w0 + pc < g.w)
-            dgo = (long)(n0 + pb) * g.cout * g.hw + (long)(h0 + pr) * g.w + (w0 + pc);
-#pragma unroll
-        for (int i = 0; i < ND; ++i) {
-            const int col = wid + i * WAVES;
-            float v = 0.f;
-            if (col < CO_BLK && co0 + col < g.cout && dgo >= 0) v = dout[dgo + (long)(co0 + col) * g.hw];
-            sd[i] = v;
+        long po = -1;
+        if (pb >= 0 && n0 + pb < g.n && h0 + pr < g.h && w0 + pc < g.w)
+            po = (long)(n0 + pb) * g.cout * g.hw + (long)(h0 + pr) * g.w + (w0 + pc);
+#pragma unroll 1
+        for (int row = wid; row < CO_BLK; row += WAVES) {
+            const bool live = po >= 0 && co0 + row < g.cout;
+            glds4(live ? dout + po + (long)(co0 + row) * g.hw : zero, dl + row * DS);
         }
-        long xgo[MAXPOS];
 #pragma unroll
-        for (int j = 0; j < MAXPOS; ++j) {
-            xgo[j] = -1;
-            if (qb[j] >= 0) {
+        for (int j = 0; j < MAXPOS64; ++j) {
+            if (j * 64 < g.npos) {                       // uniform
+                long xo = -1;
                 const int gh = h0 + qr[j] - PADH, gw = w0 + qc[j] - PADW;
-                if (n0 + qb[j] < g.n && gh >= 0 && gh < g.h && gw >= 0 && gw < g.w)
-                    xgo[j] = (long)(n0 + qb[j]) * g.cin * g.hw + (long)gh * g.w + gw;
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < NI; ++i) {
-            const int cl = wid + i * WAVES;
-            const bool chan_ok = cl < CI_BLK && ci0 + cl < g.cin;
-#pragma unroll
-            for (int j = 0; j < MAXPOS; ++j) {
-                float v = 0.f;
-                if (chan_ok && xgo[j] >= 0) v = in[xgo[j] + (long)(ci0 + cl) * g.hw];
-                sx[i][j] = v;
-            }
-        }
-    };
-    auto store_unit = [&]() {
-#pragma unroll
-        for (int i = 0; i < ND; ++i) {
-            const int col = wid + i * WAVES;
-            if (col < CO_BLK) dl[col * DS + lane] = sd[i];
-        }
-#pragma unroll
-        for (int i = 0; i < NI; ++i) {
-            const int cl = wid + i * WAVES;
-            if (cl < CI_BLK) {
-#pragma unroll
-                for (int j = 0; j < MAXPOS; ++j)
-                    if (qb[j] >= 0) il[cl * g.plane + lane + 64 * j] = sx[i][j];
+                if (qb[j] >= 0 && n0 + qb[j] < g.n && gh >= 0 && gh < g.h && gw >= 0 && gw < g.w)
+                    xo = (long)(n0 + qb[j]) * g.cin * g.hw + (long)gh * g.w + gw;
+                if (qb[j] >= 0) {                        // lanes past npos stay out of the DMA
+#pragma unroll 1
+                    for (int cl = wid; cl < CI_BLK; cl += WAVES) {
+                        const bool live = xo >= 0 && ci0 + cl < g.cin;
+                        glds4(live ? in + xo + (long)(ci0 + cl) * g.hw : zero, il + cl * g.plane + j * 64);
+                    }
+                }
             }
         }
     };
 
-    int u = split;
-    if (u < g.units) {
-        load_unit(u);
-        store_unit();
-    }
-    __syncthreads();
-    for (; u < g.units; u += g.nsplit) {
-        const int un = u + g.nsplit;
-        const bool more = un < g.units;
-        if (more) load_unit(un);
-#pragma unroll 4
-        for (int ks = 0; ks < PIXC / 4; ++ks) {
-            const int p = ks * 4 + kq;
-            float a[MT], b[NPW];
-            const int poff = ptab[p];
+    // this wave's (ci tile, tap) pairs; pairs whose ci tile lies wholly beyond c_in are skipped
+    int b_base[NPW];
+    bool pair_live[NPW];
 #pragma unroll
-            for (int i = 0; i < MT; ++i) a[i] = dl[(i * 16 + lm) * DS + p];
+    for (int s = 0; s < NPW; ++s) {
+        const int nt = wid * NPW + s;
+        const int cit = nt / TAPS, tap = nt - cit * TAPS;
+        b_base[s] = (cit * 16 + lm) * g.plane + (tap / KW) * g.cols + (tap % KW);
+        pair_live[s] = nt < NT && ci0 + cit * 16 < g.cin;
+        if (nt >= NT) b_base[s] = 0;
+    }
+    const int a_base = lm * DS + kq;
+
+    auto load_ab = [&](int ks, float (&a)[MT], float (&b)[NPW]) {
+        const float* arow = dl + a_base + ks * 4;
+#pragma unroll
+        for (int i = 0; i < MT; ++i) a[i] = arow[i * 16 * DS];
+        const int pk = ptab[ks * 4 + kq];
+#pragma unroll
+        for (int s = 0; s < NPW; ++s) b[s] = il[b_base[s] + pk];
+    };
+
+    for (int u = split; u < g.units; u += g.nsplit) {
+        __syncthreads();              // every wave is done reading the previous unit (and ptab is visible)
+        issue_unit(u);
+        __syncthreads();              // hipcc drains vmcnt here: the unit has landed in LDS
+        float a[2][MT], b[2][NPW];
+        load_ab(0, a[0], b[0]);
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+            if (ks + 1 < NKS) load_ab(ks + 1, a[(ks + 1) & 1], b[(ks + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int s = 0; s < NPW; ++s) {
-                const int nt = wid * NPW + s;
-                const int cit = nt / TAPS, tap = nt - cit * TAPS;
-                b[s] = il[(cit * 16 + lm) * g.plane + poff + (tap / KW) * g.cols + (tap % KW)];
+                if (pair_live[s]) {
+#pragma unroll
+                    for (int i = 0; i < MT; ++i)
+                        acc[s][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ks & 1][i], b[ks & 1][s], acc[s][i], 0, 0, 0);
+                }
             }
-#pragma unroll
-            for (int s = 0; s < NPW; ++s)
-#pragma unroll
-                for (int i = 0; i < MT; ++i)
-                    acc[s][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[s], acc[s][i], 0, 0, 0);
-        }
-        __syncthreads();
-        if (more) {
-            store_unit();
-            __syncthreads();
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
 
@@ -433,8 +461,8 @@ __global__ __launch_bounds__((wg_threads<KH, KW>())) void conv_wgrad_kernel(WgGe
 #pragma unroll
     for (int s = 0; s < NPW; ++s) {
         const int nt = wid * NPW + s;
+        if (nt >= NT) continue;
         const int cit = nt / TAPS, tap = nt - cit * TAPS;
-        if (cit >= CIT) continue;
         const long row = ((long)split * TAPS + tap) * g.ci_pad + ci0 + cit * 16 + lm;
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
@@ -509,7 +537,7 @@ bool plan_fwd(const fsc_conv_desc& d, int dgrad, FwdPlan* out) {
     g.cin = dgrad ? d.c_out : d.c_in;
     g.cout = dgrad ? d.c_in : d.c_out;
     const int kc = taps == 1 ? 32 : 8;
-    const int maxe = taps == 1 ? 16 : 8;
+    const int nxi_max = taps == 1 ? 20 : 9;          // input DMA instructions per wave (kernel NXI_MAX)
     p.kc = kc;
     // channel tiling: minimise padded tiles, prefer fewer blocks
     const int tiles = fsc::ceil_div(g.cout, 16);
@@ -536,7 +564,7 @@ bool plan_fwd(const fsc_conv_desc& d, int dgrad, FwdPlan* out) {
         g.tiles_w = (int)p.grid_x;      // so the box decode in the kernel stays in range
     } else {
         g.flat = 0;
-        const int cap_pos = 256 * maxe / kc;
+        const int cap_pos = 256 * nxi_max / kc - 32;      // staged positions incl. plane padding
         long best_cost = -1;
         int bnb = 1, bth = 1, btw = 1;
         for (int tw = 1; tw <= d.w && tw <= kPixCap; ++tw) {
@@ -567,7 +595,8 @@ bool plan_fwd(const fsc_conv_desc& d, int dgrad, FwdPlan* out) {
     g.plane = pad_plane(g.npos, 16);
     const int co_blk = p.cot * 16;
     const int cos = co_blk + ((co_blk % 32 == 16) ? 0 : 16);
-    p.lds_bytes = sizeof(float) * ((size_t)taps * kc * cos + (size_t)kc * g.plane);
+    if ((kc * g.plane + 255) / 256 > nxi_max) return false;
+    p.lds_bytes = 2 * sizeof(float) * ((size_t)taps * kc * cos + (size_t)((kc * g.plane + 3) & ~3));
     *out = p;
     return true;
 }
@@ -623,10 +652,9 @@ bool plan_wgrad(const fsc_conv_desc& d_in, WgPlan* out) {
     WgPlan p{};
     WgGeom& g = p.g;
     const int taps = d.kh * d.kw;
-    const int waves = taps == 1 ? 4 : 6;
-    const int npw = taps == 9 ? 3 : 2;
-    const int cit = waves * npw / taps;
-    const int pixc = 64, maxpos = taps == 1 ? 1 : (taps == 3 ? 2 : 3);
+    const int waves = 4;
+    const int cit = taps == 9 ? 2 : (taps == 3 ? 4 : 8);
+    const int pixc = 64, maxpos_total = 64 * (taps == 1 ? 1 : (taps == 3 ? 2 : 3));
     g.n = d.n; g.cin = d.c_in; g.cout = d.c_out; g.h = d.h; g.w = d.w; g.hw = (long)d.h * d.w;
     const int tiles = fsc::ceil_div(d.c_out, 16);
     int best_mt = 1, best_blocks = tiles;
@@ -654,9 +682,9 @@ bool plan_wgrad(const fsc_conv_desc& d_in, WgPlan* out) {
             if (nb > d.n) nb = d.n;
             if (nb < 1) nb = 1;
         }
-        while (nb > 1 && nb * (th + d.kh - 1) * (tw + d.kw - 1) > maxpos * 64) --nb;
-        while (th > 1 && nb * (th + d.kh - 1) * (tw + d.kw - 1) > maxpos * 64) --th;
-        if (nb * (th + d.kh - 1) * (tw + d.kw - 1) > maxpos * 64) continue;
+        while (nb > 1 && nb * (th + d.kh - 1) * (tw + d.kw - 1) > maxpos_total) --nb;
+        while (th > 1 && nb * (th + d.kh - 1) * (tw + d.kw - 1) > maxpos_total) --th;
+        if (nb * (th + d.kh - 1) * (tw + d.kw - 1) > maxpos_total) continue;
         const long tiles = (long)fsc::ceil_div(d.n, nb) * fsc::ceil_div(d.h, th) * fsc::ceil_div(d.w, tw);
         const long cost = tiles * box_penalty(tw, d.w);
         if (best_cost < 0 || cost < best_cost || (cost == best_cost && tw > btw)) {
@@ -680,6 +708,7 @@ bool plan_wgrad(const fsc_conv_desc& d_in, WgPlan* out) {
     g.nsplit = (int)ns;
     p.threads = waves * 64;
     p.lds_bytes = sizeof(float) * ((size_t)p.mt * 16 * (pixc + 2) + (size_t)cit * 16 * g.plane + pixc);
+    if (g.npos > maxpos_total) return false;
     *out = p;
     return true;
 }
