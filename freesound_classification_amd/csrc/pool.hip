@@ -10,50 +10,55 @@ namespace {
 
 constexpr int kThreads = 256;
 
+// Threads are split into (row lane, column lane) with a power-of-two column count, so no
+// per-element division is needed and short rows still fill the block.
 __global__ __launch_bounds__(kThreads) void maxpool_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
-                                                               uint8_t* __restrict__ idx, long planes, int h,
-                                                               int w, int ph, int oh, int ow) {
-    const long total = planes * oh * ow;
-    for (long i = (long)blockIdx.x * kThreads + threadIdx.x; i < total; i += (long)gridDim.x * kThreads) {
-        const int ox = (int)(i % ow);
-        const long r = i / ow;
-        const int oy = (int)(r % oh);
+                                                               uint8_t* __restrict__ idx, long out_rows, int h,
+                                                               int w, int ph, int oh, int ow, int colp_log2) {
+    const int colp = 1 << colp_log2, rows_per_block = kThreads >> colp_log2;
+    const int tr = threadIdx.x >> colp_log2, tc = threadIdx.x & (colp - 1);
+    for (long r = (long)blockIdx.x * rows_per_block + tr; r < out_rows; r += (long)gridDim.x * rows_per_block) {
         const long pl = r / oh;
-        const float* p = x + (pl * h + (long)oy * ph) * w + 2 * ox;
-        float best = p[0];
-        int bi = 0;
-        float v = p[1];
-        if (v > best || v != v) { best = v; bi = 1; }
-        if (ph == 2) {
-            v = p[w];
-            if ((v > best || v != v) && best == best) { best = v; bi = 2; }
-            v = p[w + 1];
-            if ((v > best || v != v) && best == best) { best = v; bi = 3; }
+        const int oy = (int)(r - pl * oh);
+        const float* p0 = x + (pl * h + (long)oy * ph) * w;
+        for (int ox = tc; ox < ow; ox += colp) {
+            const float* p = p0 + 2 * ox;
+            float best = p[0];
+            int bi = 0;
+            float v = p[1];
+            if (v > best || v != v) { best = v; bi = 1; }
+            if (ph == 2) {
+                v = p[w];
+                if ((v > best || v != v) && best == best) { best = v; bi = 2; }
+                v = p[w + 1];
+                if ((v > best || v != v) && best == best) { best = v; bi = 3; }
+            }
+            y[r * ow + ox] = best;
+            idx[r * ow + ox] = (uint8_t)bi;
         }
-        y[i] = best;
-        idx[i] = (uint8_t)bi;
     }
 }
 
 // gather form: every input element is written exactly once
 __global__ __launch_bounds__(kThreads) void maxpool_bwd_kernel(const float* __restrict__ dy,
                                                                const uint8_t* __restrict__ idx,
-                                                               float* __restrict__ dx, long planes, int h, int w,
-                                                               int ph, int oh, int ow) {
-    const long total = planes * h * w;
-    for (long i = (long)blockIdx.x * kThreads + threadIdx.x; i < total; i += (long)gridDim.x * kThreads) {
-        const int xx = (int)(i % w);
-        const long r = i / w;
-        const int yy = (int)(r % h);
+                                                               float* __restrict__ dx, long in_rows, int h, int w,
+                                                               int ph, int oh, int ow, int colp_log2) {
+    const int colp = 1 << colp_log2, rows_per_block = kThreads >> colp_log2;
+    const int tr = threadIdx.x >> colp_log2, tc = threadIdx.x & (colp - 1);
+    for (long r = (long)blockIdx.x * rows_per_block + tr; r < in_rows; r += (long)gridDim.x * rows_per_block) {
         const long pl = r / h;
-        const int ox = xx >> 1, oy = ph == 2 ? (yy >> 1) : yy;
-        float g = 0.f;
-        if (ox < ow && oy < oh) {
-            const long o = (pl * oh + oy) * ow + ox;
-            const int pos = (ph == 2 ? ((yy & 1) << 1) : 0) | (xx & 1);
-            if (idx[o] == pos) g = dy[o];
+        const int yy = (int)(r - pl * h);
+        const int oy = ph == 2 ? (yy >> 1) : yy;
+        const bool row_live = oy < oh;
+        const long orow = (pl * oh + oy) * ow;
+        const int rbit = ph == 2 ? ((yy & 1) << 1) : 0;
+        for (int xx = tc; xx < w; xx += colp) {
+            const int ox = xx >> 1;
+            float g = 0.f;
+            if (row_live && ox < ow && idx[orow + ox] == (rbit | (xx & 1))) g = dy[orow + ox];
+            dx[r * w + xx] = g;
         }
-        dx[i] = g;
     }
 }
 
@@ -113,6 +118,19 @@ __global__ __launch_bounds__(kThreads) void gmax_bwd_kernel(const float* __restr
     }
 }
 
+int col_log2(int cols) {
+    int l = 0;
+    while ((1 << l) < cols && l < 8) ++l;
+    return l;
+}
+
+unsigned row_grid(long rows, int colp_log2) {
+    const long per_block = kThreads >> colp_log2;
+    long b = (rows + per_block - 1) / per_block;
+    if (b > 256L * 32) b = 256L * 32;
+    return (unsigned)(b < 1 ? 1 : b);
+}
+
 unsigned stream_grid(long total) {
     long b = (total + kThreads - 1) / kThreads;
     if (b > 256L * 16) b = 256L * 16;
@@ -128,8 +146,10 @@ int fsc_maxpool_fwd(const float* x, float* y, uint8_t* idx, int nc, int h, int w
     FSC_CHECK_ARG(x && y && idx, "fsc_maxpool_fwd: null pointer");
     FSC_CHECK_ARG((ph == 1 || ph == 2) && nc > 0 && h >= ph && w >= 2, "fsc_maxpool_fwd: bad shape nc=%d h=%d w=%d ph=%d", nc, h, w, ph);
     const int oh = h / ph, ow = w / 2;
-    hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(stream_grid((long)nc * oh * ow)), dim3(kThreads), 0,
-                       fsc::as_stream(stream), x, y, idx, (long)nc, h, w, ph, oh, ow);
+    const int cl = col_log2(ow);
+    const long rows = (long)nc * oh;
+    hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(row_grid(rows, cl)), dim3(kThreads), 0, fsc::as_stream(stream), x, y,
+                       idx, rows, h, w, ph, oh, ow, cl);
     FSC_LAUNCH_CHECK("fsc_maxpool_fwd");
     return 0;
 }
@@ -138,8 +158,10 @@ int fsc_maxpool_bwd(const float* dy, const uint8_t* idx, float* dx, int nc, int 
     FSC_CHECK_ARG(dy && dx && idx, "fsc_maxpool_bwd: null pointer");
     FSC_CHECK_ARG((ph == 1 || ph == 2) && nc > 0 && h >= ph && w >= 2, "fsc_maxpool_bwd: bad shape");
     const int oh = h / ph, ow = w / 2;
-    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(stream_grid((long)nc * h * w)), dim3(kThreads), 0,
-                       fsc::as_stream(stream), dy, idx, dx, (long)nc, h, w, ph, oh, ow);
+    const int cl = col_log2(w);
+    const long rows = (long)nc * h;
+    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(row_grid(rows, cl)), dim3(kThreads), 0, fsc::as_stream(stream), dy,
+                       idx, dx, rows, h, w, ph, oh, ow, cl);
     FSC_LAUNCH_CHECK("fsc_maxpool_bwd");
     return 0;
 }
