@@ -53,6 +53,11 @@ __device__ __attribute__((aligned(16))) float g_zero16[4] = {0.f, 0.f, 0.f, 0.f}
 typedef __attribute__((address_space(3))) void* lds_ptr;
 typedef __attribute__((address_space(1))) const void* glb_ptr;
 
+// x / d for 0 <= x < 2^20 and 1 <= d < 2^20 through the fp32 reciprocal `inv` = 1.0f / d: exact at
+// these sizes ((x + 0.5) / d is never within 2^-21 of an integer), three instructions instead
+// of the ~35 of an integer division.  Used for the per-lane index decodes of the conv prologues.
+__device__ __forceinline__ int fdiv(int x, float inv) { return (int)(((float)x + 0.5f) * inv); }
+
 // LDS-DMA: each lane copies 16 / 4 bytes from its own global address to (wave-uniform LDS base +
 // lane * size).  No VGPR staging; completion is tracked by vmcnt (hipcc drains it at __syncthreads).
 __device__ __forceinline__ void glds16(const float* src, float* lds_wave_base) {
@@ -109,6 +114,11 @@ __global__ __launch_bounds__(kThreads) void conv_fwd_kernel(Geom g, const float*
         }
     }
     //      Input box: LDS image [KC][plane], 4 B per lane; instruction iq covers floats [iq*64, iq*64+64).
+    const float inv_plane = 1.0f / (float)g.plane, inv_per = 1.0f / (float)(g.rows * g.cols);
+    const float inv_cols = 1.0f / (float)g.cols, inv_tw = 1.0f / (float)g.tw, inv_thw = 1.0f / (float)(g.th * g.tw);
+    // flat mode: a box of npix consecutive (n, hw) pixels touches image img0 and possibly the next ones
+    const unsigned img0 = g.flat ? (unsigned)(p0 / g.hw) : 0u;
+    const unsigned rem0 = g.flat ? (unsigned)(p0 - (long)img0 * g.hw) : 0u;
     constexpr int NXI_MAX = TAPS == 1 ? 20 : 9;
     const int nxi = (il_floats + kThreads - 1) / kThreads;          // <= NXI_MAX (checked on the host)
     int x_off[NXI_MAX];   // offset inside the input tensor relative to channel ci0; -1 = zero fill; -2 = skip
@@ -119,20 +129,21 @@ __global__ __launch_bounds__(kThreads) void conv_fwd_kernel(Geom g, const float*
         x_off[q] = -2;
         x_k[q] = 0;
         if (q < nxi && f < il_floats) {
-            const int k = f / g.plane, pos = f - k * g.plane;
+            const int k = fdiv(f, inv_plane), pos = f - k * g.plane;
             x_k[q] = k;
             if (pos < g.npos) {
                 long goff = -1;
                 if (g.flat) {
                     const long pg = p0 + pos;
                     if (pos < g.npix && pg < g.flat_total) {
-                        const unsigned img = (unsigned)pg / (unsigned)g.hw, i = (unsigned)pg - img * (unsigned)g.hw;
+                        unsigned img = img0, i = rem0 + (unsigned)pos;
+                        while (i >= (unsigned)g.hw) { i -= (unsigned)g.hw; ++img; }
                         goff = ((long)img * g.cin + k) * g.hw + i;
                     }
                 } else {
                     const int per = g.rows * g.cols;
-                    const int b = pos / per, rem = pos - b * per;
-                    const int rr = rem / g.cols, cc = rem - rr * g.cols;
+                    const int b = fdiv(pos, inv_per), rem = pos - b * per;
+                    const int rr = fdiv(rem, inv_cols), cc = rem - rr * g.cols;
                     const int gh = h0 + rr - PADH, gw = w0 + cc - PADW;
                     if (n0 + b < g.n && gh >= 0 && gh < g.h && gw >= 0 && gw < g.w)
                         goff = ((long)(n0 + b) * g.cin + k) * g.hw + (long)gh * g.w + gw;
@@ -155,13 +166,14 @@ __global__ __launch_bounds__(kThreads) void conv_fwd_kernel(Geom g, const float*
                 const long pg = p0 + p;
                 pix_l[pt] = p;
                 if (pg < g.flat_total) {
-                    const unsigned img = (unsigned)pg / (unsigned)g.hw, i = (unsigned)pg - img * (unsigned)g.hw;
+                    unsigned img = img0, i = rem0 + (unsigned)p;
+                    while (i >= (unsigned)g.hw) { i -= (unsigned)g.hw; ++img; }
                     pix_g[pt] = (long)img * g.cout * g.hw + i;
                 }
             } else {
                 const int per = g.th * g.tw;
-                const int b = p / per, rem = p - b * per;
-                const int r = rem / g.tw, c = rem - r * g.tw;
+                const int b = fdiv(p, inv_thw), rem = p - b * per;
+                const int r = fdiv(rem, inv_tw), c = rem - r * g.tw;
                 pix_l[pt] = (b * g.rows + r) * g.cols + c;
                 if (n0 + b < g.n && h0 + r < g.h && w0 + c < g.w)
                     pix_g[pt] = (long)(n0 + b) * g.cout * g.hw + (long)(h0 + r) * g.w + (w0 + c);
@@ -326,12 +338,18 @@ constexpr int wg_threads() { return WgCfg<KH, KW>::WAVES * 64; }
 // the kernel fits two workgroups (12 waves, 3 per SIMD) on a CU, which a 6-wave workgroup needs
 // to keep all four SIMDs evenly loaded.  Row strides are == 2 (mod 32) so the 16-row x 2-pixel
 // operand reads of an MFMA hit 32 distinct banks.
-template <int KH, int KW, int MT>
+//
+// PACKED (stem layers, c_in * taps <= 32): the GEMM's N axis enumerates (ci, tap) combinations
+// directly (2 column tiles instead of 18 for c_in = 2), every wave owns all tiles, and the four waves
+// split the unit's k-steps; each wave writes its own split-K slice (split * 4 + wave).
+template <int KH, int KW, int MT, bool PACKED>
 __global__ __launch_bounds__((wg_threads<KH, KW>())) void conv_wgrad_kernel(WgGeom g, const float* __restrict__ in,
                                                                            const float* __restrict__ dout,
                                                                            float* __restrict__ part) {
     using C = WgCfg<KH, KW>;
-    constexpr int TAPS = C::TAPS, WAVES = C::WAVES, NPW = C::NPW, CIT = C::CIT, PIXC = C::PIXC, NT = C::NT;
+    constexpr int TAPS = C::TAPS, WAVES = C::WAVES, CIT = C::CIT, PIXC = C::PIXC;
+    constexpr int NPW = PACKED ? 2 : C::NPW;
+    constexpr int NT = PACKED ? 2 : C::NT;
     constexpr int MAXPOS64 = C::MAXPOS64;
     constexpr int CO_BLK = MT * 16, CI_BLK = CIT * 16;
     constexpr int DS = PIXC + 2;                                   // == 2 (mod 32)
@@ -341,7 +359,8 @@ __global__ __launch_bounds__((wg_threads<KH, KW>())) void conv_wgrad_kernel(WgGe
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* dl = smem;                              // [CO_BLK][DS]
     float* il = smem + CO_BLK * DS;                // [CI_BLK][plane]
-    int* ptab = reinterpret_cast<int*>(il + CI_BLK * g.plane);   // [PIXC] LDS offset of pixel p inside a staged channel
+    constexpr int CI_LDS = PACKED ? 16 : CI_BLK;   // staged input channels (packed stem layers have c_in <= 16)
+    int* ptab = reinterpret_cast<int*>(il + CI_LDS * g.plane);   // [PIXC] LDS offset of pixel p inside a staged channel
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -403,8 +422,9 @@ __global__ __launch_bounds__((wg_threads<KH, KW>())) void conv_wgrad_kernel(WgGe
                 if (qb[j] >= 0 && n0 + qb[j] < g.n && gh >= 0 && gh < g.h && gw >= 0 && gw < g.w)
                     xo = (long)(n0 + qb[j]) * g.cin * g.hw + (long)gh * g.w + gw;
                 if (qb[j] >= 0) {                        // lanes past npos stay out of the DMA
+                    const int ci_stage = PACKED ? g.cin : CI_BLK;
 #pragma unroll 1
-                    for (int cl = wid; cl < CI_BLK; cl += WAVES) {
+                    for (int cl = wid; cl < ci_stage; cl += WAVES) {
                         const bool live = xo >= 0 && ci0 + cl < g.cin;
                         glds4(live ? in + xo + (long)(ci0 + cl) * g.hw : zero, il + cl * g.plane + j * 64);
                     }
@@ -418,11 +438,19 @@ __global__ __launch_bounds__((wg_threads<KH, KW>())) void conv_wgrad_kernel(WgGe
     bool pair_live[NPW];
 #pragma unroll
     for (int s = 0; s < NPW; ++s) {
-        const int nt = wid * NPW + s;
-        const int cit = nt / TAPS, tap = nt - cit * TAPS;
-        b_base[s] = (cit * 16 + lm) * g.plane + (tap / KW) * g.cols + (tap % KW);
-        pair_live[s] = nt < NT && ci0 + cit * 16 < g.cin;
-        if (nt >= NT) b_base[s] = 0;
+        if (PACKED) {
+            const int q = s * 16 + lm;                       // (ci, tap) combination of this lane
+            const int ci = q / TAPS, tap = q - ci * TAPS;
+            const bool ok = q < g.cin * TAPS;
+            b_base[s] = ok ? ci * g.plane + (tap / KW) * g.cols + (tap % KW) : 0;
+            pair_live[s] = s * 16 < g.cin * TAPS;
+        } else {
+            const int nt = wid * NPW + s;
+            const int cit = nt / TAPS, tap = nt - cit * TAPS;
+            b_base[s] = (cit * 16 + lm) * g.plane + (tap / KW) * g.cols + (tap % KW);
+            pair_live[s] = nt < NT && ci0 + cit * 16 < g.cin;
+            if (nt >= NT) b_base[s] = 0;
+        }
     }
     const int a_base = lm * DS + kq;
 
@@ -439,6 +467,21 @@ __global__ __launch_bounds__((wg_threads<KH, KW>())) void conv_wgrad_kernel(WgGe
         __syncthreads();              // every wave is done reading the previous unit (and ptab is visible)
         issue_unit(u);
         __syncthreads();              // hipcc drains vmcnt here: the unit has landed in LDS
+        if (PACKED) {
+#pragma unroll 1
+            for (int ks = wid; ks < NKS; ks += WAVES) {
+                float a1[MT], b1[NPW];
+                load_ab(ks, a1, b1);
+#pragma unroll
+                for (int s = 0; s < NPW; ++s)
+                    if (pair_live[s]) {
+#pragma unroll
+                        for (int i = 0; i < MT; ++i)
+                            acc[s][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[i], b1[s], acc[s][i], 0, 0, 0);
+                    }
+            }
+            continue;
+        }
         float a[2][MT], b[2][NPW];
         load_ab(0, a[0], b[0]);
 #pragma unroll
@@ -457,13 +500,54 @@ __global__ __launch_bounds__((wg_threads<KH, KW>())) void conv_wgrad_kernel(WgGe
         }
     }
 
+    if (PACKED) {
+        // the four waves hold partial sums over disjoint k-steps: tree-reduce them through LDS
+        // (the dOut stage is free now) so the workgroup writes ONE split-K slice
+        f32x4* red = reinterpret_cast<f32x4*>(smem);                 // [2 waves][NPW][MT][64 lanes]
+        __syncthreads();
+        if (wid >= 2) {
+#pragma unroll
+            for (int s = 0; s < NPW; ++s)
+#pragma unroll
+                for (int i = 0; i < MT; ++i) red[(((wid - 2) * NPW + s) * MT + i) * 64 + lane] = acc[s][i];
+        }
+        __syncthreads();
+        if (wid < 2) {
+#pragma unroll
+            for (int s = 0; s < NPW; ++s)
+#pragma unroll
+                for (int i = 0; i < MT; ++i) acc[s][i] += red[((wid * NPW + s) * MT + i) * 64 + lane];
+        }
+        __syncthreads();
+        if (wid == 1) {
+#pragma unroll
+            for (int s = 0; s < NPW; ++s)
+#pragma unroll
+                for (int i = 0; i < MT; ++i) red[(s * MT + i) * 64 + lane] = acc[s][i];
+        }
+        __syncthreads();
+        if (wid != 0) return;
+#pragma unroll
+        for (int s = 0; s < NPW; ++s)
+#pragma unroll
+            for (int i = 0; i < MT; ++i) acc[s][i] += red[(s * MT + i) * 64 + lane];
+    }
+
     // partial[split][tap][ci][co]; D row = co (kq*4 + r), column = ci (lm)
 #pragma unroll
     for (int s = 0; s < NPW; ++s) {
-        const int nt = wid * NPW + s;
-        if (nt >= NT) continue;
-        const int cit = nt / TAPS, tap = nt - cit * TAPS;
-        const long row = ((long)split * TAPS + tap) * g.ci_pad + ci0 + cit * 16 + lm;
+        long row;
+        if (PACKED) {
+            const int q = s * 16 + lm;
+            if (q >= g.cin * TAPS) continue;
+            const int ci = q / TAPS, tap = q - ci * TAPS;
+            row = ((long)split * TAPS + tap) * g.ci_pad + ci;
+        } else {
+            const int nt = wid * NPW + s;
+            if (nt >= NT) continue;
+            const int cit = nt / TAPS, tap = nt - cit * TAPS;
+            row = ((long)split * TAPS + tap) * g.ci_pad + ci0 + cit * 16 + lm;
+        }
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
             float4 v = make_float4(acc[s][i][0], acc[s][i][1], acc[s][i][2], acc[s][i][3]);
@@ -641,6 +725,8 @@ struct WgPlan {
     int mt, co_blocks;
     size_t lds_bytes;
     int threads;
+    int packed;           // stem layers: (ci, tap) packed along N, waves split K
+    int part_splits;      // split-K slices in the partial workspace
 };
 
 bool plan_wgrad(const fsc_conv_desc& d_in, WgPlan* out) {
@@ -706,8 +792,17 @@ bool plan_wgrad(const fsc_conv_desc& d_in, WgPlan* out) {
     while (ns > 1 && ns * part_bytes_per_split > (256L << 20)) --ns;
     if (ns < 1) ns = 1;
     g.nsplit = (int)ns;
+    p.packed = (taps > 1 && d.c_in * taps <= 32 && d.c_in <= 16) ? 1 : 0;
+    if (p.packed) {
+        g.ci_blocks = 1;
+        long want = 256L * 5 / p.co_blocks;           // ~5 resident workgroups per CU (latency-bound units)
+        if (want > g.units / 4) want = g.units / 4;
+        if (want < 1) want = 1;
+        g.nsplit = (int)want;
+    }
+    p.part_splits = g.nsplit;
     p.threads = waves * 64;
-    p.lds_bytes = sizeof(float) * ((size_t)p.mt * 16 * (pixc + 2) + (size_t)cit * 16 * g.plane + pixc);
+    p.lds_bytes = sizeof(float) * ((size_t)p.mt * 16 * (pixc + 2) + (size_t)(p.packed ? 16 : cit * 16) * g.plane + pixc);
     if (g.npos > maxpos_total) return false;
     *out = p;
     return true;
@@ -715,10 +810,16 @@ bool plan_wgrad(const fsc_conv_desc& d_in, WgPlan* out) {
 
 template <int KH, int KW, int MT>
 int launch_wgrad_mt(const WgPlan& p, const float* in, const float* dout, float* part, hipStream_t st) {
-    auto kern = conv_wgrad_kernel<KH, KW, MT>;
-    if (p.lds_bytes > 64 * 1024)
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes);
-    hipLaunchKernelGGL(kern, dim3(p.co_blocks * p.g.ci_blocks, p.g.nsplit), dim3(p.threads), p.lds_bytes, st, p.g, in, dout, part);
+    dim3 grid(p.co_blocks * p.g.ci_blocks, p.g.nsplit);
+    if (p.packed && KH * KW > 1) {
+        auto kern = conv_wgrad_kernel<KH, KW, MT, (KH * KW > 1)>;
+        hipLaunchKernelGGL(kern, grid, dim3(p.threads), p.lds_bytes, st, p.g, in, dout, part);
+    } else {
+        auto kern = conv_wgrad_kernel<KH, KW, MT, false>;
+        if (p.lds_bytes > 64 * 1024)
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes);
+        hipLaunchKernelGGL(kern, grid, dim3(p.threads), p.lds_bytes, st, p.g, in, dout, part);
+    }
     FSC_LAUNCH_CHECK("fsc_conv_wgrad");
     return 0;
 }
@@ -777,9 +878,9 @@ int fsc_conv_plan_describe(const fsc_conv_desc* d, int mode, char* buf, size_t b
     if (mode == 2) {
         WgPlan p;
         FSC_CHECK_ARG(plan_wgrad(*d, &p), "fsc_conv_plan_describe: no tiling for this shape");
-        snprintf(buf, buf_len, "conv_wgrad_kernel<%d,%d,%d> box=%dx%dx%d units=%d split=%d grid=%dx%d lds=%zu",
-                 d->kh, d->kw, p.mt, p.g.nb, p.g.th, p.g.tw, p.g.units, p.g.nsplit, p.co_blocks * p.g.ci_blocks,
-                 p.g.nsplit, p.lds_bytes);
+        snprintf(buf, buf_len, "conv_wgrad_kernel<%d,%d,%d%s> box=%dx%dx%d units=%d split=%d grid=%dx%d lds=%zu",
+                 d->kh, d->kw, p.mt, p.packed ? ",packed" : "", p.g.nb, p.g.th, p.g.tw, p.g.units, p.g.nsplit,
+                 p.co_blocks * p.g.ci_blocks, p.g.nsplit, p.lds_bytes);
     } else {
         FwdPlan p;
         FSC_CHECK_ARG(plan_fwd(*d, mode, &p), "fsc_conv_plan_describe: no tiling for this shape");
@@ -793,7 +894,7 @@ size_t fsc_conv_wgrad_workspace_bytes(const fsc_conv_desc* d) {
     if (!valid_desc(d)) return 0;
     WgPlan p;
     if (!plan_wgrad(*d, &p)) return 0;
-    return (size_t)p.g.nsplit * d->kh * d->kw * p.g.ci_pad * p.g.co_pad * sizeof(float);
+    return (size_t)p.part_splits * d->kh * d->kw * p.g.ci_pad * p.g.co_pad * sizeof(float);
 }
 
 int fsc_conv_wgrad(const fsc_conv_desc* d, const float* in, const float* dout, float* dweight, void* workspace,
@@ -813,7 +914,7 @@ int fsc_conv_wgrad(const fsc_conv_desc* d, const float* in, const float* dout, f
     long blocks = (total + 255) / 256;
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, st, part, dweight, d->c_out, d->c_in,
-                       taps, p.g.ci_pad, p.g.co_pad, p.g.nsplit);
+                       taps, p.g.ci_pad, p.g.co_pad, p.part_splits);
     FSC_LAUNCH_CHECK("fsc_conv_wgrad(reduce)");
     return 0;
 }
