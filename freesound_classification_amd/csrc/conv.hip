@@ -784,13 +784,31 @@ bool plan_wgrad(const fsc_conv_desc& d_in, WgPlan* out) {
     g.tiles_n = fsc::ceil_div(d.n, bnb); g.tiles_h = fsc::ceil_div(d.h, bth); g.tiles_w = fsc::ceil_div(d.w, btw);
     g.units = g.tiles_n * g.tiles_h * g.tiles_w;
     g.plane = pad_plane(g.npos, 2);
-    // split-K: aim for ~4 workgroups per CU, at least 4 units per split, partials <= 256 MB
+    // split-K: all workgroups do the same work, so the grid should fill the 512 resident slots
+    // (256 CUs x 2 workgroups) a whole number of times -- 1030 workgroups would cost three rounds.
+    // Pick the split count (>= 4 units per split, partials <= 256 MB) with the best slot utilisation.
     const long base = (long)p.co_blocks * g.ci_blocks;
-    long ns = (256L * 4 + base - 1) / base;
-    if (ns > g.units / 4) ns = g.units / 4;
     const long part_bytes_per_split = (long)taps * g.ci_pad * g.co_pad * 4;
-    while (ns > 1 && ns * part_bytes_per_split > (256L << 20)) --ns;
-    if (ns < 1) ns = 1;
+    long ns_max = g.units / 4;
+    if (ns_max < 1) ns_max = 1;
+    while (ns_max > 1 && ns_max * part_bytes_per_split > (256L << 20)) --ns_max;
+    // resident workgroups per CU: 4-wave workgroups put one wave on each SIMD, so it is the waves/SIMD
+    // the register file admits (VGPR + AGPR ~ 48 + 20*MT for 3x3, measured) capped by LDS
+    const int npw = (cit * taps + waves - 1) / waves;
+    const int regs = 48 + 4 * npw * p.mt;
+    int per_cu = 512 / (int)fsc::round_up(regs, 8);
+    if (per_cu > 8) per_cu = 8;
+    const size_t lds_est = sizeof(float) * ((size_t)p.mt * 16 * (pixc + 2) + (size_t)cit * 16 * g.plane + pixc);
+    if ((size_t)per_cu * lds_est > 160 * 1024) per_cu = (int)(160 * 1024 / lds_est);
+    if (per_cu < 1) per_cu = 1;
+    const long slots = 256L * per_cu;
+    long ns = 1;
+    double best_util = -1.0;
+    for (long cand = 1; cand <= ns_max && cand * base <= 2 * slots + base; ++cand) {
+        const long wgs = cand * base;
+        const double util = (double)wgs / (double)(((wgs + slots - 1) / slots) * slots);
+        if (util > best_util + 1e-9) { best_util = util; ns = cand; }
+    }
     g.nsplit = (int)ns;
     p.packed = (taps > 1 && d.c_in * taps <= 32 && d.c_in <= 16) ? 1 : 0;
     if (p.packed) {
