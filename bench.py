@@ -37,6 +37,11 @@ WORKLOADS = {
     # BASELINE.json configs[1]
     "cfg2": dict(features="mel_2048_1024_128", blocks=6, base=100, growth=1.5, start=1, dropout=0.7,
                  batch=128, samples=441000, sr=44100, n_mel=128),
+    # BASELINE.json configs[2]: 1-d raw-STFT path (win 256), 10-block hierarchical CNN, LSEP + MixUp.
+    # hop 128 / base 64 / growth 1.25 are SURVEY section 8d's assumptions; computed in fp32 here
+    # (bf16 is not implemented yet, the line says dtype f32).
+    "cfg3": dict(features="stft_256_128", blocks=10, base=64, growth=1.25, start=1, dropout=0.0,
+                 batch=128, samples=441000, sr=44100, n_mel=129, dims=1, mixup=0.5),
     # BASELINE.json configs[0] shape (used for quick checks: --workload cfg1)
     "cfg1": dict(features="mel_1024_512_64", blocks=3, base=32, growth=2, start=1, dropout=0.0,
                  batch=64, samples=32000, sr=16000, n_mel=64),
@@ -119,22 +124,37 @@ def main():
         dist.init_process_group("nccl", device_id=device)
 
     from freesound_classification_amd import functional as F
-    from freesound_classification_amd.networks.classifiers import TwoDimensionalCNNClassificationModel
+    from freesound_classification_amd.networks.classifiers import (
+        HierarchicalCNNClassificationModel, TwoDimensionalCNNClassificationModel)
     from freesound_classification_amd.ops.training import make_step
 
     w = WORKLOADS[args.workload]
     batch = args.batch or w["batch"]
     torch.manual_seed(42)
-    model = TwoDimensionalCNNClassificationModel(make_experiment(w), device=str(device))
+    model_cls = HierarchicalCNNClassificationModel if w.get("dims") == 1 else TwoDimensionalCNNClassificationModel
+    model = model_cls(make_experiment(w), device=str(device))
     model.train()
     model.global_step = 0
     model.make_optimizer(max_steps=args.steps + args.warmup + 1)
     signal, labels = synthetic_batch(w, batch, device, 1234 + rank)
 
+    mix_rng = __import__("numpy").random.RandomState(7 + rank)
+
     def one_step():
         model.global_step += 1
         make_step(model.scheduler, step=model.global_step)
-        return model.training_step(signal, labels)
+        x, y = signal, labels
+        if w.get("mixup"):
+            # on-device MixUp (ops/audio.py:32-52 semantics): partner = a batch permutation, rows are
+            # mixed with probability p; equal lengths -> plain average, labels OR-ed
+            perm = torch.from_numpy(mix_rng.permutation(batch)).to(device)
+            take = torch.from_numpy(mix_rng.uniform(size=batch) < w["mixup"]).to(device)
+            partner = torch.where(take, perm, torch.arange(batch, device=device))
+            t = w["samples"]
+            mixed, y = F.mixup_batch(signal.squeeze(-1), signal.squeeze(-1)[partner].contiguous(), [t] * batch, [t] * batch,
+                                     [0] * batch, mix_rng.uniform(0.4, 0.6, size=batch), labels, labels[partner].contiguous())
+            x = mixed.unsqueeze(-1)
+        return model.training_step(x, y)
 
     for _ in range(args.warmup):
         one_step()
@@ -175,10 +195,10 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": "%s: batch %d x %.0f s @ %.1f kHz, %s, %d-block 2d CNN base %d growth %g, "
+            "config": {"workload": "%s: batch %d x %.0f s @ %.1f kHz, %s, %d-block %dd CNN base %d growth %g, "
                                    "LSEP, Adam-amsgrad, dropout %g" % (
                                        args.workload, batch, w["samples"] / w["sr"], w["sr"] / 1e3, w["features"],
-                                       w["blocks"], w["base"], w["growth"], w["dropout"]),
+                                       w["blocks"], w.get("dims", 2), w["base"], w["growth"], w["dropout"]),
                        "global_batch": world * batch, "parallelism": "dp%d" % world},
             "final_loss": final_loss,
         }

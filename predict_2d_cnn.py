@@ -1,0 +1,168 @@
+"""Inference driver: counterpart of the reference's predict_2d_cnn.py (:72-125) with the
+length-grouped batching its README describes (README.md:37) wired in through `BucketingSampler`
+(ops/padding.py:36-81, defined but never instantiated by the reference's own scripts).
+
+Per fold: rebuild the model, load `checkpoints/fold_{k}/best_model.pth`, predict full-length clips
+(no crop, pad-to-longest inside a batch); fold probabilities are averaged and written as a CSV with
+the class columns of `get_class_names_from_classmap` plus `fname`.  Under `torch.distributed.run`
+the batch list is sharded round-robin over ranks (every GPU holds all fold weights) and the
+probabilities are gathered on rank 0.  Batch composition is the single-process sampler's, because
+padding is not masked downstream.
+"""
+import argparse
+import json
+import os
+import random
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from freesound_classification_amd import parallel
+from freesound_classification_amd.datasets.sound_dataset import SoundDataset
+from freesound_classification_amd.networks.classifiers import (
+    HierarchicalCNNClassificationModel, TwoDimensionalCNNClassificationModel)
+from freesound_classification_amd.ops.padding import BucketingSampler, make_collate_fn
+from freesound_classification_amd.ops.transforms import (
+    AudioFeatures, Compose, DropFields, LoadAudio, SyntheticAudio)
+from freesound_classification_amd.ops.utils import get_class_names_from_classmap, load_json
+
+
+class AttrDict(dict):
+    __getattr__ = dict.__getitem__
+
+
+def to_attr(d):
+    return AttrDict({k: to_attr(v) if isinstance(v, dict) else v for k, v in d.items()})
+
+
+class LoadedExperiment:
+    """Read-only view of an experiment directory written by train_2d_cnn.py (or by `mag`)."""
+
+    def __init__(self, directory):
+        self.directory = directory
+        with open(os.path.join(directory, "config.json")) as f:
+            self.config = to_attr(json.load(f))
+        self.checkpoints = os.path.join(directory, "checkpoints")
+        self.predictions = os.path.join(directory, "predictions")
+
+    def register_directory(self, name):
+        path = os.path.join(self.directory, name)
+        os.makedirs(path, exist_ok=True)
+        setattr(self, name, path)
+
+
+class _WithLengths(SoundDataset):
+    """SoundDataset plus the `lengths` attribute BucketingSampler needs (samples per clip)."""
+
+    def __init__(self, files, lengths, transform):
+        super().__init__(files, transform=transform)
+        self.lengths = np.asarray(lengths)
+
+
+def clip_lengths(files):
+    out = []
+    for f in files:
+        if str(f).startswith("synthetic:"):
+            out.append(int(str(f).split(":")[2]))
+        else:
+            from scipy.io import wavfile
+            sr, data = wavfile.read(f, mmap=True)
+            out.append(int(data.shape[0]))
+    return out
+
+
+def grouped_batches(dataset, bucket_seconds, max_batch_seconds, sr, seed):
+    """Length-grouped batch list (identical on every rank: the sampler draws from `random`)."""
+    random.seed(seed)
+    top = int(np.max(dataset.lengths)) + 1
+    step = int(bucket_seconds * sr)
+    buckets = list(range(0, top + step, step))
+    return [list(map(int, b)) for b in BucketingSampler(dataset, int(max_batch_seconds * sr), buckets)]
+
+
+def predict_folds(experiment, folds, dataset, batches, collate, device, model_cls):
+    """Mean over folds of sigmoid(logits); rows follow the dataset order.  Returns rank 0's array."""
+    world, rank = parallel.world_size(), parallel.rank()
+    mine = batches[rank::world]
+    order = [i for b in mine for i in b]
+    loader = torch.utils.data.DataLoader(dataset, batch_sampler=mine, collate_fn=collate)
+    total = None
+    for fold in folds:
+        model = model_cls(experiment, device=device)
+        model.load_best_model(fold)
+        probs = model.predict(loader) if order else np.zeros((0, experiment.config.data._n_classes), np.float32)
+        total = probs if total is None else total + probs
+    local = (total / len(folds)).astype(np.float32)
+    n_classes = experiment.config.data._n_classes
+    out = np.zeros((len(dataset), n_classes), np.float32)
+    if world == 1:
+        out[order] = local
+        return out
+    gathered = [None] * world
+    dist.all_gather_object(gathered, (order, local))
+    for idx, block in gathered:
+        out[idx] = block
+    return out
+
+
+def main():
+    p = argparse.ArgumentParser(formatter_class=argparse.ArgumentDefaultsHelpFormatter)
+    p.add_argument("--experiment", required=True)
+    p.add_argument("--test_df", type=str)
+    p.add_argument("--test_data_dir", type=str)
+    p.add_argument("--classmap", type=str)
+    p.add_argument("--synthetic", type=int, default=0, help="predict N synthetic clips of random lengths")
+    p.add_argument("--synthetic_sr", type=int, default=44100)
+    p.add_argument("--output_df", required=True)
+    p.add_argument("--device", default="cuda")
+    p.add_argument("--folds", type=int, nargs="+", default=None)
+    p.add_argument("--model", choices=["2d", "1d"], default="2d")
+    p.add_argument("--bucket_seconds", type=float, default=2.0)
+    p.add_argument("--max_batch_seconds", type=float, default=1280.0, help="samples per batch = 128 x 10 s")
+    p.add_argument("--seed", type=int, default=7)
+    args = p.parse_args()
+
+    device = args.device
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        local = int(os.environ.get("LOCAL_RANK", "0"))
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl")
+        device = "cuda:%d" % local
+    experiment = LoadedExperiment(args.experiment)
+    config = experiment.config
+    if args.synthetic:
+        rng = np.random.RandomState(args.seed)
+        class_map = {"class_%02d" % i: i for i in range(config.data._n_classes)}
+        lens = rng.randint(int(0.3 * args.synthetic_sr), int(30 * args.synthetic_sr), size=args.synthetic)
+        files = ["synthetic:%d:%d:%d" % (i, n, args.synthetic_sr) for i, n in enumerate(lens)]
+        loader_tf, sr = SyntheticAudio(), args.synthetic_sr
+    else:
+        import pandas as pd
+        class_map = load_json(args.classmap)
+        df = pd.read_csv(args.test_df)
+        files = [os.path.join(args.test_data_dir, f) for f in df.fname.values]
+        loader_tf, sr = LoadAudio(), 44100
+    features = AudioFeatures(config.data.features, verbose=False)
+    transform = Compose([loader_tf, features, DropFields(("audio", "filename", "sr"))])
+    dataset = _WithLengths(files, clip_lengths(files), transform)
+    batches = grouped_batches(dataset, args.bucket_seconds, args.max_batch_seconds, sr, args.seed)
+    folds = args.folds
+    if folds is None:
+        folds = sorted(int(d.split("_")[1]) for d in os.listdir(experiment.checkpoints) if d.startswith("fold_"))
+    model_cls = TwoDimensionalCNNClassificationModel if args.model == "2d" else HierarchicalCNNClassificationModel
+    probs = predict_folds(experiment, folds, dataset, batches, make_collate_fn({"signal": features.padding_value}),
+                          device, model_cls)
+    if parallel.rank() == 0:
+        import pandas as pd
+        out = pd.DataFrame(probs, columns=get_class_names_from_classmap(class_map))
+        out["fname"] = [os.path.basename(str(f)) for f in files]
+        out.to_csv(args.output_df, index=False)
+        print("wrote %d x %d predictions (%d folds, %d length-grouped batches) to %s" % (
+            probs.shape[0], probs.shape[1], len(folds), len(batches), args.output_df))
+    if dist.is_available() and dist.is_initialized():
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

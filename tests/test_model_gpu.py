@@ -271,3 +271,59 @@ def test_full_size_properties():
     assert maxdiff(y2, 2.5 * y1) < 1e-3
     shifted = torch.roll(x, 1, dims=0)
     assert torch.equal(F.conv_forward(shifted, w, None), torch.roll(y1, 1, dims=0))
+
+
+def test_length_grouped_fold_ensemble_inference(tmp_path):
+    """cfg-5-shaped inference at toy size: 2 fold weight sets, variable-length clips, batches from
+    BucketingSampler, fold-mean probabilities in dataset order -- against the CPU oracle fed the
+    same zero-padded batches (padding is unmasked, so batch composition matters)."""
+    import json
+    import sys
+    sys.path.insert(0, str(__import__("pathlib").Path(__file__).resolve().parents[1]))
+    import predict_2d_cnn as drv
+    from freesound_classification_amd.ops.padding import make_collate_fn
+    from freesound_classification_amd.ops.transforms import AudioFeatures, Compose, DropFields, SyntheticAudio
+
+    exp = experiment("mel_1024_512_64", 2, 8, 1.5, 1, 64)
+    root = tmp_path / "exp"
+    (root / "checkpoints").mkdir(parents=True)
+    cfg = json.loads(json.dumps(exp.config))
+    (root / "config.json").write_text(json.dumps(cfg))
+    refs = []
+    for fold in (0, 1):
+        torch.manual_seed(100 + fold)
+        m = TwoDimensionalCNNClassificationModel(exp, device=DEV)
+        # non-trivial running statistics so eval-mode BN is exercised
+        for mod in m.modules():
+            if isinstance(mod, torch.nn.modules.batchnorm._BatchNorm):
+                mod.running_mean.normal_(0, 0.1)
+                mod.running_var.uniform_(0.5, 1.5)
+        d = root / "checkpoints" / ("fold_%d" % fold)
+        d.mkdir()
+        torch.save(m.state_dict(), d / "best_model.pth")
+        ref = oref.TagCNN2d("mel_1024_512_64", 2, 8, 1.5, 1, 80)
+        ref.load_state_dict({k: v.cpu() for k, v in m.state_dict().items()})
+        refs.append(ref.eval())
+    rng = np.random.RandomState(5)
+    lens = rng.randint(6000, 40000, size=23)
+    files = ["synthetic:%d:%d:16000" % (i, n) for i, n in enumerate(lens)]
+    feats = AudioFeatures("mel_1024_512_64", verbose=False)
+    ds = drv._WithLengths(files, drv.clip_lengths(files),
+                          Compose([SyntheticAudio(), feats, DropFields(("audio", "filename", "sr"))]))
+    assert list(ds.lengths) == list(lens)
+    batches = drv.grouped_batches(ds, bucket_seconds=0.5, max_batch_seconds=4.0, sr=16000, seed=3)
+    assert sorted(i for b in batches for i in b) == list(range(23))
+    assert all(max(lens[b]) - min(lens[b]) < 8000 for b in batches)        # similar lengths share a batch
+    loaded = drv.LoadedExperiment(str(root))
+    collate = make_collate_fn({"signal": 0.0})
+    probs = drv.predict_folds(loaded, [0, 1], ds, batches, collate, DEV, TwoDimensionalCNNClassificationModel)
+    assert probs.shape == (23, 80)
+    want = np.zeros((23, 80), np.float32)
+    with torch.no_grad():
+        for b in batches:
+            sig = collate([ds[i] for i in b])["signal"]
+            acc = sum(torch.sigmoid(r(sig)["class_logits"]) for r in refs) / 2
+            want[b] = acc.numpy()
+    assert np.abs(probs - want).max() < TOL
+    assert abs(lwlrap((want > np.median(want)).astype(np.float32), probs)
+               - ohost.lwlrap((want > np.median(want)).astype(np.float32), want)) < TOL
