@@ -119,8 +119,11 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch N > 1 with torch.distributed.run" % (args.gpus, world))
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    if world > 1 or os.environ.get("FSC_FORCE_DP") == "1":
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=device)
 
     from freesound_classification_amd import functional as F
@@ -233,7 +236,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(w)
         print(json.dumps(result))
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

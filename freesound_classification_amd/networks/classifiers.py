@@ -292,7 +292,8 @@ class _TaggingModel(nn.Module):
         self.optimizer = OPTIMIZERS[train.optimizer](
             self.parameters(), train.learning_rate, weight_decay=train.weight_decay)
         self.scheduler = make_scheduler(train.scheduler, max_steps=max_steps)(self.optimizer)
-        if parallel.world_size() > 1:
+        # FSC_FORCE_DP=1 exercises the data-parallel path in a 1-rank process group (device test)
+        if parallel.world_size() > 1 or (parallel.initialized() and os.environ.get("FSC_FORCE_DP") == "1"):
             parallel.broadcast_module(self)
             self._reducer = parallel.BucketedGradReducer(list(self.parameters()))
             self.optimizer.grad_scale = 1.0 / parallel.world_size()

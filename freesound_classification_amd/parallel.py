@@ -28,7 +28,7 @@ def rank():
 
 def broadcast_module(module, src=0):
     """Make every replica start from rank `src`'s parameters and buffers."""
-    if world_size() == 1:
+    if not initialized():
         return
     with torch.no_grad():
         for t in list(module.parameters()) + list(module.buffers()):

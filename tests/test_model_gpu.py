@@ -327,3 +327,40 @@ def test_length_grouped_fold_ensemble_inference(tmp_path):
     assert np.abs(probs - want).max() < TOL
     assert abs(lwlrap((want > np.median(want)).astype(np.float32), probs)
                - ohost.lwlrap((want > np.median(want)).astype(np.float32), want)) < TOL
+
+
+def test_data_parallel_path_on_device_single_rank():
+    """The bucketed all-reduce path (hooks, side stream, RCCL, grad views, fused optimizer scale) on
+    the GPU in a 1-rank `nccl` group: the step must equal the plain single-process step."""
+    import os
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29544")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(DEV))
+    try:
+        results = []
+        for force in ("0", "1"):
+            os.environ["FSC_FORCE_DP"] = force
+            torch.manual_seed(9)
+            m = TwoDimensionalCNNClassificationModel(experiment("mel_1024_512_64", 2, 8, 1.5, 1, 64), device=DEV)
+            m.train()
+            m.make_optimizer(max_steps=10)
+            assert (m._reducer is not None) == (force == "1")
+            g = torch.Generator().manual_seed(1)
+            x = (0.1 * torch.randn(4, 12000, 1, generator=g)).to(DEV)
+            y = torch.zeros(4, 80, device=DEV)
+            y[torch.arange(4), torch.tensor([1, 5, 9, 70])] = 1.0
+            first = None
+            for _ in range(2):
+                logits, _, _ = m.training_step(x, y)
+                first = logits.detach().clone() if first is None else first
+            torch.cuda.synchronize()
+            results.append((first, {k: v.detach().clone() for k, v in m.state_dict().items()}))
+        assert torch.equal(results[0][0], results[1][0])          # same init, same first forward
+        # after two Adam steps: equal up to the float-atomic ordering noise of the conv-bias gradients
+        # (analytically zero; Adam turns that noise into +-lr moves, SURVEY.md section 8c)
+        for k in results[0][1]:
+            assert maxdiff(results[0][1][k], results[1][1][k]) < 1e-3, k
+    finally:
+        os.environ["FSC_FORCE_DP"] = "0"
+        dist.destroy_process_group()
