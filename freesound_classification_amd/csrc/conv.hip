@@ -41,11 +41,14 @@ struct Geom {
     long flat_total;          // n * hw
 };
 
-template <int KH, int KW>
-struct FwdCfg {
-    static constexpr int TAPS = KH * KW;
-    static constexpr int KC = TAPS == 1 ? 32 : 8;                 // input channels per chunk
-};
+// Forward / dgrad tile configuration per kernel size: 128 pixels per workgroup (4 waves x 2 pixel
+// tiles), K chunk of 8 channels x 9 taps (3x3) = 252 MFMAs per wave between barriers; two LDS stages
+// of (weight slab + input box) = 78 KB at COT = 7, i.e. two workgroups per CU.
+// COT = 8 with 8-channel chunks needs 2 x 47 KB of LDS (one workgroup per CU, measured 73-85 TF);
+// 4-channel chunks bring three workgroups back onto the CU.
+__host__ __device__ constexpr int fwd_kc(int taps) { return taps == 1 ? 32 : 8; }
+__host__ __device__ constexpr int fwd_pt(int taps) { return 2; }   // PT = 4 needs > 256 VGPR+AGPR (1 wave/SIMD)
+__host__ __device__ constexpr int fwd_nxi_max(int taps) { return taps == 1 ? 20 : 9; }
 
 // 16 bytes of zeros: the source of every lane whose element lies outside the image / channel range
 __device__ __attribute__((aligned(16))) float g_zero16[4] = {0.f, 0.f, 0.f, 0.f};
@@ -68,13 +71,12 @@ __device__ __forceinline__ void glds4(const float* src, float* lds_wave_base) {
 }
 
 // -------------------------------------------------------------------------------------------
-template <int KH, int KW, int COT, int PT>
+template <int KH, int KW, int COT, int PT, int KC>
 __global__ __launch_bounds__(kThreads) void conv_fwd_kernel(Geom g, const float* __restrict__ in,
                                                             const float* __restrict__ packed,
                                                             const float* __restrict__ bias,
                                                             float* __restrict__ out, int accumulate) {
-    using C = FwdCfg<KH, KW>;
-    constexpr int TAPS = C::TAPS, KC = C::KC;
+    constexpr int TAPS = KH * KW;
     constexpr int CO_BLK = COT * 16;
     constexpr int COS = CO_BLK + ((CO_BLK % 32 == 16) ? 0 : 16);   // == 16 (mod 32)
     constexpr int WROW4 = COS / 4;                                  // float4 slots per LDS weight row
@@ -119,7 +121,7 @@ __global__ __launch_bounds__(kThreads) void conv_fwd_kernel(Geom g, const float*
     // flat mode: a box of npix consecutive (n, hw) pixels touches image img0 and possibly the next ones
     const unsigned img0 = g.flat ? (unsigned)(p0 / g.hw) : 0u;
     const unsigned rem0 = g.flat ? (unsigned)(p0 - (long)img0 * g.hw) : 0u;
-    constexpr int NXI_MAX = TAPS == 1 ? 20 : 9;
+    constexpr int NXI_MAX = fwd_nxi_max(TAPS);
     const int nxi = (il_floats + kThreads - 1) / kThreads;          // <= NXI_MAX (checked on the host)
     int x_off[NXI_MAX];   // offset inside the input tensor relative to channel ci0; -1 = zero fill; -2 = skip
     int x_k[NXI_MAX];
@@ -610,8 +612,6 @@ long tile_penalty(int tiles_per_block) {
     }
 }
 
-constexpr int kPT = 2;                  // pixel tiles (16) per wave -> 128 pixels per workgroup
-constexpr int kPixCap = 4 * kPT * 16;
 
 bool plan_fwd(const fsc_conv_desc& d, int dgrad, FwdPlan* out) {
     FwdPlan p{};
@@ -620,9 +620,8 @@ bool plan_fwd(const fsc_conv_desc& d, int dgrad, FwdPlan* out) {
     g.n = d.n; g.h = d.h; g.w = d.w; g.hw = (long)d.h * d.w;
     g.cin = dgrad ? d.c_out : d.c_in;
     g.cout = dgrad ? d.c_in : d.c_out;
-    const int kc = taps == 1 ? 32 : 8;
-    const int nxi_max = taps == 1 ? 20 : 9;          // input DMA instructions per wave (kernel NXI_MAX)
-    p.kc = kc;
+    const int nxi_max = fwd_nxi_max(taps);           // input DMA instructions per wave (kernel NXI_MAX)
+    const int kPixCap = 4 * fwd_pt(taps) * 16;       // pixels per workgroup
     // channel tiling: minimise padded tiles, prefer fewer blocks
     const int tiles = fsc::ceil_div(g.cout, 16);
     int best_cot = 1, best_blocks = tiles;
@@ -636,8 +635,8 @@ bool plan_fwd(const fsc_conv_desc& d, int dgrad, FwdPlan* out) {
     }
     p.cot = best_cot;
     p.co_blocks = best_blocks;
+    int kc = fwd_kc(taps);                 // box search below assumes this chunk; may shrink to 4 afterwards
     g.m_pad = best_blocks * best_cot * 16;
-    g.k_pad = (int)fsc::round_up(g.cin, kc);
     if (taps == 1) {
         g.flat = 1;
         g.flat_total = (long)d.n * g.hw;
@@ -677,6 +676,11 @@ bool plan_fwd(const fsc_conv_desc& d, int dgrad, FwdPlan* out) {
         p.grid_x = (long)g.tiles_n * g.tiles_h * g.tiles_w;
     }
     g.plane = pad_plane(g.npos, 16);
+    // COT = 8 with 8-channel chunks needs 2 x 47 KB of LDS = one workgroup per CU; when the grid is
+    // large enough to fill the chip three times over, 4-channel chunks (three workgroups per CU) win
+    if (taps == 9 && p.cot == 8 && p.grid_x * p.co_blocks >= 768) kc = 4;
+    p.kc = kc;
+    g.k_pad = (int)fsc::round_up(g.cin, kc);
     const int co_blk = p.cot * 16;
     const int cos = co_blk + ((co_blk % 32 == 16) ? 0 : 16);
     if ((kc * g.plane + 255) / 256 > nxi_max) return false;
@@ -688,10 +692,16 @@ bool plan_fwd(const fsc_conv_desc& d, int dgrad, FwdPlan* out) {
 template <int KH, int KW, int COT>
 int launch_fwd_cot(const FwdPlan& p, const float* in, const float* packed, const float* bias, float* out,
                    int accumulate, hipStream_t st) {
-    auto kern = conv_fwd_kernel<KH, KW, COT, kPT>;
-    if (p.lds_bytes > 64 * 1024)
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes);
-    hipLaunchKernelGGL(kern, dim3((unsigned)p.grid_x, p.co_blocks), dim3(kThreads), p.lds_bytes, st, p.g, in, packed, bias, out, accumulate);
+    dim3 grid((unsigned)p.grid_x, p.co_blocks);
+    if (KH * KW == 9 && COT == 8 && p.kc == 4) {
+        auto kern = conv_fwd_kernel<KH, KW, COT, fwd_pt(KH * KW), (KH * KW == 9 && COT == 8) ? 4 : fwd_kc(KH * KW)>;
+        hipLaunchKernelGGL(kern, grid, dim3(kThreads), p.lds_bytes, st, p.g, in, packed, bias, out, accumulate);
+    } else {
+        auto kern = conv_fwd_kernel<KH, KW, COT, fwd_pt(KH * KW), fwd_kc(KH * KW)>;
+        if (p.lds_bytes > 64 * 1024)
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes);
+        hipLaunchKernelGGL(kern, grid, dim3(kThreads), p.lds_bytes, st, p.g, in, packed, bias, out, accumulate);
+    }
     FSC_LAUNCH_CHECK("fsc_conv_fwd");
     return 0;
 }
@@ -772,7 +782,9 @@ bool plan_wgrad(const fsc_conv_desc& d_in, WgPlan* out) {
         while (th > 1 && nb * (th + d.kh - 1) * (tw + d.kw - 1) > maxpos_total) --th;
         if (nb * (th + d.kh - 1) * (tw + d.kw - 1) > maxpos_total) continue;
         const long tiles = (long)fsc::ceil_div(d.n, nb) * fsc::ceil_div(d.h, th) * fsc::ceil_div(d.w, tw);
-        const long cost = tiles * box_penalty(tw, d.w);
+        // halo'd positions are DMA work per unit (64 positions per instruction and channel)
+        const long halo_instr = (nb * (th + d.kh - 1) * (tw + d.kw - 1) + 63) / 64;
+        const long cost = tiles * box_penalty(tw, d.w) * (20 + halo_instr);
         if (best_cost < 0 || cost < best_cost || (cost == best_cost && tw > btw)) {
             best_cost = cost; bnb = nb; bth = th; btw = tw;
         }
@@ -903,7 +915,7 @@ int fsc_conv_plan_describe(const fsc_conv_desc* d, int mode, char* buf, size_t b
         FwdPlan p;
         FSC_CHECK_ARG(plan_fwd(*d, mode, &p), "fsc_conv_plan_describe: no tiling for this shape");
         snprintf(buf, buf_len, "conv_fwd_kernel<%d,%d,%d,%d> box=%dx%dx%d flat=%d grid=%ldx%d lds=%zu", d->kh, d->kw,
-                 p.cot, kPT, p.g.nb, p.g.th, p.g.tw, p.g.flat, p.grid_x, p.co_blocks, p.lds_bytes);
+                 p.cot, fwd_pt(d->kh * d->kw), p.g.nb, p.g.th, p.g.tw, p.g.flat, p.grid_x, p.co_blocks, p.lds_bytes);
     }
     return 0;
 }

@@ -360,7 +360,8 @@ def test_data_parallel_path_on_device_single_rank():
         # after two Adam steps: equal up to the float-atomic ordering noise of the conv-bias gradients
         # (analytically zero; Adam turns that noise into +-lr moves)
         for k in results[0][1]:
-            assert maxdiff(results[0][1][k], results[1][1][k]) < 1e-3, k
+            tol = 1e-2 if (k.endswith(".bias") or "running_mean" in k) else 1e-3   # lr sum = 1.8e-3, x4 bound
+            assert maxdiff(results[0][1][k], results[1][1][k]) < tol, k
     finally:
         os.environ["FSC_FORCE_DP"] = "0"
         dist.destroy_process_group()
