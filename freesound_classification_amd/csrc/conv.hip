@@ -46,7 +46,7 @@ struct Geom {
 // of (weight slab + input box) = 78 KB at COT = 7, i.e. two workgroups per CU.
 // COT = 8 with 8-channel chunks needs 2 x 47 KB of LDS (one workgroup per CU, measured 73-85 TF);
 // 4-channel chunks bring three workgroups back onto the CU.
-__host__ __device__ constexpr int fwd_kc(int taps) { return taps == 1 ? 32 : 8; }
+__host__ __device__ constexpr int fwd_kc(int taps) { return taps == 1 ? 32 : 8; }   // 3x3 may also run with 4
 __host__ __device__ constexpr int fwd_pt(int taps) { return 2; }   // PT = 4 needs > 256 VGPR+AGPR (1 wave/SIMD)
 __host__ __device__ constexpr int fwd_nxi_max(int taps) { return taps == 1 ? 20 : 9; }
 
@@ -676,9 +676,11 @@ bool plan_fwd(const fsc_conv_desc& d, int dgrad, FwdPlan* out) {
         p.grid_x = (long)g.tiles_n * g.tiles_h * g.tiles_w;
     }
     g.plane = pad_plane(g.npos, 16);
-    // COT = 8 with 8-channel chunks needs 2 x 47 KB of LDS = one workgroup per CU; when the grid is
-    // large enough to fill the chip three times over, 4-channel chunks (three workgroups per CU) win
-    if (taps == 9 && p.cot == 8 && p.grid_x * p.co_blocks >= 768) kc = 4;
+    // 3x3 K chunk (measured, MI355X): narrow channel blocks (COT <= 6) run faster with 4-channel chunks
+    // (19-29 KB of LDS per workgroup, 3-4 workgroups per CU: +3-5 %), COT = 7 with 8 (2 x 39 KB, two
+    // workgroups), COT = 8 with 4 when the grid fills the chip three times over (8 would need 2 x 47 KB =
+    // one workgroup per CU) and with 8 for the small late layers (fewer barriers per workgroup).
+    if (taps == 9 && (p.cot <= 6 || (p.cot == 8 && p.grid_x * p.co_blocks >= 768))) kc = 4;
     p.kc = kc;
     g.k_pad = (int)fsc::round_up(g.cin, kc);
     const int co_blk = p.cot * 16;
@@ -693,8 +695,8 @@ template <int KH, int KW, int COT>
 int launch_fwd_cot(const FwdPlan& p, const float* in, const float* packed, const float* bias, float* out,
                    int accumulate, hipStream_t st) {
     dim3 grid((unsigned)p.grid_x, p.co_blocks);
-    if (KH * KW == 9 && COT == 8 && p.kc == 4) {
-        auto kern = conv_fwd_kernel<KH, KW, COT, fwd_pt(KH * KW), (KH * KW == 9 && COT == 8) ? 4 : fwd_kc(KH * KW)>;
+    if (KH * KW == 9 && p.kc == 4) {
+        auto kern = conv_fwd_kernel<KH, KW, COT, fwd_pt(KH * KW), (KH * KW == 9) ? 4 : fwd_kc(KH * KW)>;
         hipLaunchKernelGGL(kern, grid, dim3(kThreads), p.lds_bytes, st, p.g, in, packed, bias, out, accumulate);
     } else {
         auto kern = conv_fwd_kernel<KH, KW, COT, fwd_pt(KH * KW), fwd_kc(KH * KW)>;
