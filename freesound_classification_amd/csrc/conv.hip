@@ -39,6 +39,7 @@ struct Geom {
     int k_pad, m_pad;         // packed weight extents
     int flat;                 // 1x1: pixels are a flat (n, hw) range, box = [p0, p0 + npix)
     long flat_total;          // n * hw
+    int ksplit;               // > 1: blockIdx.z owns a slice of the K chunks and adds into a zeroed output
 };
 
 // Forward / dgrad tile configuration per kernel size: 128 pixels per workgroup (4 waves x 2 pixel
@@ -207,7 +208,10 @@ __global__ __launch_bounds__(kThreads) void conv_fwd_kernel(Geom g, const float*
         }
     };
 
-    const int nchunks = g.k_pad / KC;
+    const int nchunks_all = g.k_pad / KC;
+    // split-K (late layers whose pixel grid cannot fill the chip): this workgroup owns chunks [c_lo, c_hi)
+    const int c_lo = (int)((long)nchunks_all * blockIdx.z / g.ksplit);
+    const int c_hi = (int)((long)nchunks_all * (blockIdx.z + 1) / g.ksplit);
     const int k_live = (g.cin + 3) & ~3;       // k-steps beyond the real channels are skipped
     constexpr int NSTEP = TAPS * (KC / 4);
 
@@ -230,13 +234,13 @@ __global__ __launch_bounds__(kThreads) void conv_fwd_kernel(Geom g, const float*
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
     };
 
-    issue_chunk(0, smem);
-    for (int c = 0; c < nchunks; ++c) {
+    if (c_lo < c_hi) issue_chunk(c_lo * KC, smem + (c_lo & 1) * buf_floats);
+    for (int c = c_lo; c < c_hi; ++c) {
         // the DMA of chunk c has landed (vmcnt drained at the barrier) and every wave has finished
         // reading the other stage, which chunk c+1 now overwrites while this chunk is multiplied
         __syncthreads();
         float* cur = smem + (c & 1) * buf_floats;
-        if (c + 1 < nchunks) issue_chunk((c + 1) * KC, smem + ((c + 1) & 1) * buf_floats);
+        if (c + 1 < c_hi) issue_chunk((c + 1) * KC, smem + ((c + 1) & 1) * buf_floats);
         const float* wl = cur;
         const float* il = cur + WL_FLOATS;
         const int ks_live = (k_live - c * KC) >> 2;          // >= 1
@@ -272,13 +276,14 @@ __global__ __launch_bounds__(kThreads) void conv_fwd_kernel(Geom g, const float*
         for (int r = 0; r < 4; ++r) {
             const int co = co0 + i * 16 + kq * 4 + r;
             if (co >= g.cout) continue;
-            const float bv = bias ? bias[co] : 0.f;
+            const float bv = (bias && blockIdx.z == 0) ? bias[co] : 0.f;
 #pragma unroll
             for (int j = 0; j < PT; ++j)
                 if (pix_g[j] >= 0) {
                     float* o = out + pix_g[j] + (long)co * g.hw;
                     const float v = acc[i][j][r] + bv;
-                    *o = accumulate ? *o + v : v;
+                    if (g.ksplit > 1) atomicAdd(o, v);           // output zeroed by the host (or accumulating)
+                    else *o = accumulate ? *o + v : v;
                 }
         }
     }
@@ -683,6 +688,17 @@ bool plan_fwd(const fsc_conv_desc& d, int dgrad, FwdPlan* out) {
     if (taps == 9 && (p.cot <= 6 || (p.cot == 8 && p.grid_x * p.co_blocks >= 768))) kc = 4;
     p.kc = kc;
     g.k_pad = (int)fsc::round_up(g.cin, kc);
+    g.ksplit = 1;
+    {
+        const long wgs = p.grid_x * p.co_blocks;
+        const int nchunks = g.k_pad / kc;
+        if (wgs < 256) {
+            long ks = (512 + wgs - 1) / wgs;
+            if (ks > 8) ks = 8;
+            if (ks > nchunks / 4) ks = nchunks / 4;
+            if (ks > 1) g.ksplit = (int)ks;
+        }
+    }
     const int co_blk = p.cot * 16;
     const int cos = co_blk + ((co_blk % 32 == 16) ? 0 : 16);
     if ((kc * g.plane + 255) / 256 > nxi_max) return false;
@@ -694,7 +710,12 @@ bool plan_fwd(const fsc_conv_desc& d, int dgrad, FwdPlan* out) {
 template <int KH, int KW, int COT>
 int launch_fwd_cot(const FwdPlan& p, const float* in, const float* packed, const float* bias, float* out,
                    int accumulate, hipStream_t st) {
-    dim3 grid((unsigned)p.grid_x, p.co_blocks);
+    dim3 grid((unsigned)p.grid_x, p.co_blocks, p.g.ksplit);
+    if (p.g.ksplit > 1 && !accumulate) {
+        const size_t bytes = sizeof(float) * (size_t)p.g.n * p.g.cout * p.g.hw;
+        hipError_t e = hipMemsetAsync(out, 0, bytes, st);
+        FSC_CHECK_ARG(e == hipSuccess, "fsc_conv_fwd: memset failed: %s", hipGetErrorString(e));
+    }
     if (KH * KW == 9 && p.kc == 4) {
         auto kern = conv_fwd_kernel<KH, KW, COT, fwd_pt(KH * KW), (KH * KW == 9) ? 4 : fwd_kc(KH * KW)>;
         hipLaunchKernelGGL(kern, grid, dim3(kThreads), p.lds_bytes, st, p.g, in, packed, bias, out, accumulate);
@@ -916,8 +937,9 @@ int fsc_conv_plan_describe(const fsc_conv_desc* d, int mode, char* buf, size_t b
     } else {
         FwdPlan p;
         FSC_CHECK_ARG(plan_fwd(*d, mode, &p), "fsc_conv_plan_describe: no tiling for this shape");
-        snprintf(buf, buf_len, "conv_fwd_kernel<%d,%d,%d,%d> box=%dx%dx%d flat=%d grid=%ldx%d lds=%zu", d->kh, d->kw,
-                 p.cot, fwd_pt(d->kh * d->kw), p.g.nb, p.g.th, p.g.tw, p.g.flat, p.grid_x, p.co_blocks, p.lds_bytes);
+        snprintf(buf, buf_len, "conv_fwd_kernel<%d,%d,%d,%d> box=%dx%dx%d flat=%d grid=%ldx%dx%d kc=%d lds=%zu", d->kh,
+                 d->kw, p.cot, fwd_pt(d->kh * d->kw), p.g.nb, p.g.th, p.g.tw, p.g.flat, p.grid_x, p.co_blocks,
+                 p.g.ksplit, p.kc, p.lds_bytes);
     }
     return 0;
 }
