@@ -52,6 +52,7 @@ SIGNATURES = {
     "fsc_bn_eval_prepare": (_I, [_I, _P, _P, _P, _P, _F, _P, _P, _P]),
     "fsc_bn_act_fwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _L, _P]),
     "fsc_bn_act_bwd": (_I, [_P] * 16 + [_I, _I, _L, _P, _P]),
+    "fsc_bn_act_bwd_unpool": (_I, [_P] * 13 + [_I, _I, _I, _I, _I, _P, _P]),
     "fsc_maxpool_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
     "fsc_maxpool_bwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
     "fsc_global_maxpool_fwd": (_I, [_P, _P, _P, _I, _L, _P]),

@@ -563,19 +563,23 @@ __global__ __launch_bounds__((wg_threads<KH, KW>())) void conv_wgrad_kernel(WgGe
     }
 }
 
+// blockIdx.y = (tap, ci) row of the partial slices, threads run along co (coalesced reads); no
+// integer division per element.
 __global__ void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, int c_out, int c_in,
                                     int taps, int ci_pad, int co_pad, int nsplit) {
-    const long total = (long)c_out * c_in * taps;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        // i enumerates (tap, ci, co) with co fastest so the partial reads coalesce
-        const int co = (int)(i % c_out);
-        const long r = i / c_out;
-        const int ci = (int)(r % c_in);
-        const int tap = (int)(r / c_in);
-        float s = 0.f;
-        for (int sp = 0; sp < nsplit; ++sp) s += part[(((long)sp * taps + tap) * ci_pad + ci) * co_pad + co];
-        dw[((long)co * c_in + ci) * taps + tap] = s;
+    const int co = blockIdx.x * blockDim.x + threadIdx.x;
+    if (co >= c_out) return;
+    const int tap = blockIdx.y / c_in, ci = blockIdx.y - tap * c_in;
+    const long slice = (long)taps * ci_pad * co_pad;
+    const float* p = part + ((long)tap * ci_pad + ci) * co_pad + co;
+    float s0 = 0.f, s1 = 0.f;
+    int sp = 0;
+    for (; sp + 1 < nsplit; sp += 2) {
+        s0 += p[(long)sp * slice];
+        s1 += p[(long)(sp + 1) * slice];
     }
+    if (sp < nsplit) s0 += p[(long)sp * slice];
+    dw[((long)co * c_in + ci) * taps + tap] = s0 + s1;
 }
 
 // -------------------------------------------------------------------------------------------
@@ -964,11 +968,9 @@ int fsc_conv_wgrad(const fsc_conv_desc* d, const float* in, const float* dout, f
     else rc = launch_wgrad<1, 1>(p, in, dout, part, st);
     if (rc) return rc;
     const int taps = d->kh * d->kw;
-    const long total = (long)d->c_out * d->c_in * taps;
-    long blocks = (total + 255) / 256;
-    if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, st, part, dweight, d->c_out, d->c_in,
-                       taps, p.g.ci_pad, p.g.co_pad, p.part_splits);
+    const int rthreads = d->c_out >= 128 ? 128 : 64;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(fsc::ceil_div(d->c_out, rthreads), taps * d->c_in), dim3(rthreads), 0, st,
+                       part, dweight, d->c_out, d->c_in, taps, p.g.ci_pad, p.g.co_pad, p.part_splits);
     FSC_LAUNCH_CHECK("fsc_conv_wgrad(reduce)");
     return 0;
 }

@@ -422,6 +422,66 @@ __global__ __launch_bounds__(kThreads) void bwd_apply_wave_kernel(BwdArgs a, con
     }
 }
 
+// BN backward apply fused with the backward of the 2x2 (or 1x2) max-pool that produced x: instead
+// of dx at the pooled resolution, the gradient is scattered to the arg-max position of each window
+// of the full-resolution tensor `dc` (all other positions, and the odd trailing row / column that
+// floor-mode pooling never read, are zero).  Saves the pooled dx round trip and the separate
+// max-pool backward pass.  Grid: blockIdx.x = (n, c) plane, blockIdx.y strides over pooled rows.
+__global__ __launch_bounds__(kThreads) void bwd_apply_unpool_kernel(BwdArgs a, const float* __restrict__ coef,
+                                                                     const uint8_t* __restrict__ pool_idx,
+                                                                     float* __restrict__ dc, float* dx_chan_sum,
+                                                                     int h, int w, int ph, int oh, int ow,
+                                                                     int colp_log2) {
+    __shared__ float scratch[kThreads / 64];
+    const long plane = blockIdx.x;
+    const int ch = (int)(plane % a.c);
+    const float mean = a.mean[ch], invstd = a.invstd[ch];
+    const float g = a.gamma ? a.gamma[ch] : 1.f, b = a.beta ? a.beta[ch] : 0.f;
+    const bool has_alpha = a.alpha != nullptr;
+    const float al = has_alpha ? a.alpha[ch] : 1.f;
+    const float c1 = coef[ch * 2], c2 = coef[ch * 2 + 1];
+    const float k = g * invstd;
+    const float* px = a.x + plane * a.hw;
+    const float* pr = a.res ? a.res + plane * a.hw : nullptr;
+    const float* pdy = a.dy + plane * a.hw;
+    const uint8_t* pi = pool_idx + plane * a.hw;
+    float* pdc = dc + plane * h * w;
+    const int colp = 1 << colp_log2, rows_per_block = kThreads >> colp_log2;
+    const int tr = threadIdx.x >> colp_log2, tc = threadIdx.x & (colp - 1);
+    float acc = 0.f;
+    for (int oy = blockIdx.y * rows_per_block + tr; oy < oh; oy += gridDim.y * rows_per_block) {
+        float* r0 = pdc + (long)oy * ph * w;
+        for (int ox = tc; ox < ow; ox += colp) {
+            const int i = oy * ow + ox;
+            const float xh = (px[i] - mean) * invstd;
+            float z = fmaf(xh, g, b);
+            if (pr) z += pr[i];
+            const float up = pdy[i];
+            const float dz = (has_alpha && !(z > 0.f)) ? al * up : up;
+            const float d = k * (dz - c1 - xh * c2);
+            acc += d;
+            const int pos = pi[i];
+            r0[2 * ox] = pos == 0 ? d : 0.f;
+            r0[2 * ox + 1] = pos == 1 ? d : 0.f;
+            if (ph == 2) {
+                r0[w + 2 * ox] = pos == 2 ? d : 0.f;
+                r0[w + 2 * ox + 1] = pos == 3 ? d : 0.f;
+            }
+        }
+        if ((w & 1) && tc == 0) {                      // column floor-mode pooling never read
+            r0[w - 1] = 0.f;
+            if (ph == 2) r0[2 * w - 1] = 0.f;
+        }
+    }
+    if (ph == 2 && (h & 1) && blockIdx.y == 0) {       // trailing row
+        for (int xx = threadIdx.x; xx < w; xx += kThreads) pdc[(long)(h - 1) * w + xx] = 0.f;
+    }
+    if (dx_chan_sum) {
+        const float t = fsc::block_sum<float, kThreads / 64>(acc, scratch);
+        if (threadIdx.x == 0) atomicAdd(dx_chan_sum + ch, t);
+    }
+}
+
 __global__ void bwd_apply_flat_kernel(BwdArgs a, const float* __restrict__ coef, float* __restrict__ dx,
                                       float* __restrict__ dres, float* dx_chan_sum, long total) {
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -568,6 +628,33 @@ int fsc_bn_act_bwd(const float* dy, const float* gmax_dy, const int* gmax_idx, c
                            dx_chan_sum, total);
     }
     FSC_LAUNCH_CHECK("fsc_bn_act_bwd");
+    return 0;
+}
+
+int fsc_bn_act_bwd_unpool(const float* dy, const float* x, const float* save_mean, const float* save_invstd,
+                          const float* gamma, const float* beta, const float* alpha, const uint8_t* pool_idx,
+                          float* dc, float* dgamma, float* dbeta, float* dalpha, float* dx_chan_sum, int n, int c,
+                          int h, int w, int ph, void* workspace, fsc_stream_t stream) {
+    FSC_CHECK_ARG(dy && x && save_mean && save_invstd && pool_idx && dc && workspace, "fsc_bn_act_bwd_unpool: null pointer");
+    FSC_CHECK_ARG((ph == 1 || ph == 2) && n > 0 && c > 0 && h >= ph && w >= 2, "fsc_bn_act_bwd_unpool: bad shape");
+    const int oh = h / ph, ow = w / 2;
+    const long hw = (long)oh * ow;
+    hipStream_t st = fsc::as_stream(stream);
+    Partials p = carve(workspace, c);
+    BwdArgs a{dy, nullptr, nullptr, x, nullptr, save_mean, save_invstd, gamma, beta, alpha, n, c, hw};
+    const int nsplit = pick_split(n, c, hw);
+    hipLaunchKernelGGL(bwd_partial_kernel, dim3(c, nsplit), dim3(kThreads), 0, st, a, nsplit, hwp_log2_for(hw), p.part);
+    hipLaunchKernelGGL(bwd_finalize_kernel, dim3(fsc::ceil_div(c, 128)), dim3(128), 0, st, c, (double)n * (double)hw,
+                       nsplit, p.part, dgamma, dbeta, dalpha, p.coef, dx_chan_sum);
+    int cl = 0;
+    while ((1 << cl) < ow && cl < 8) ++cl;
+    const int per_block = kThreads >> cl;
+    int gy = (oh + per_block * 4 - 1) / (per_block * 4);
+    if (gy < 1) gy = 1;
+    if (gy > 64) gy = 64;
+    hipLaunchKernelGGL(bwd_apply_unpool_kernel, dim3((unsigned)((long)n * c), gy), dim3(kThreads), 0, st, a, p.coef,
+                       pool_idx, dc, dx_chan_sum, h, w, ph, oh, ow, cl);
+    FSC_LAUNCH_CHECK("fsc_bn_act_bwd_unpool");
     return 0;
 }
 

@@ -10,17 +10,20 @@ namespace {
 
 constexpr int kThreads = 256;
 
-// Threads are split into (row lane, column lane) with a power-of-two column count, so no
-// per-element division is needed and short rows still fill the block.
+// blockIdx.x = (n, c) plane, blockIdx.y strides over row groups; threads are split into (row lane,
+// column lane) with a power-of-two column count: no integer division anywhere, short rows still
+// fill the block.
 __global__ __launch_bounds__(kThreads) void maxpool_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
-                                                               uint8_t* __restrict__ idx, long out_rows, int h,
-                                                               int w, int ph, int oh, int ow, int colp_log2) {
+                                                               uint8_t* __restrict__ idx, int h, int w, int ph,
+                                                               int oh, int ow, int colp_log2) {
     const int colp = 1 << colp_log2, rows_per_block = kThreads >> colp_log2;
     const int tr = threadIdx.x >> colp_log2, tc = threadIdx.x & (colp - 1);
-    for (long r = (long)blockIdx.x * rows_per_block + tr; r < out_rows; r += (long)gridDim.x * rows_per_block) {
-        const long pl = r / oh;
-        const int oy = (int)(r - pl * oh);
-        const float* p0 = x + (pl * h + (long)oy * ph) * w;
+    const long pl = blockIdx.x;
+    const float* px = x + pl * h * w;
+    float* py = y + pl * oh * ow;
+    uint8_t* pi = idx + pl * oh * ow;
+    for (int oy = blockIdx.y * rows_per_block + tr; oy < oh; oy += gridDim.y * rows_per_block) {
+        const float* p0 = px + (long)oy * ph * w;
         for (int ox = tc; ox < ow; ox += colp) {
             const float* p = p0 + 2 * ox;
             float best = p[0];
@@ -33,8 +36,8 @@ __global__ __launch_bounds__(kThreads) void maxpool_fwd_kernel(const float* __re
                 v = p[w + 1];
                 if ((v > best || v != v) && best == best) { best = v; bi = 3; }
             }
-            y[r * ow + ox] = best;
-            idx[r * ow + ox] = (uint8_t)bi;
+            py[oy * ow + ox] = best;
+            pi[oy * ow + ox] = (uint8_t)bi;
         }
     }
 }
@@ -42,22 +45,24 @@ __global__ __launch_bounds__(kThreads) void maxpool_fwd_kernel(const float* __re
 // gather form: every input element is written exactly once
 __global__ __launch_bounds__(kThreads) void maxpool_bwd_kernel(const float* __restrict__ dy,
                                                                const uint8_t* __restrict__ idx,
-                                                               float* __restrict__ dx, long in_rows, int h, int w,
-                                                               int ph, int oh, int ow, int colp_log2) {
+                                                               float* __restrict__ dx, int h, int w, int ph, int oh,
+                                                               int ow, int colp_log2) {
     const int colp = 1 << colp_log2, rows_per_block = kThreads >> colp_log2;
     const int tr = threadIdx.x >> colp_log2, tc = threadIdx.x & (colp - 1);
-    for (long r = (long)blockIdx.x * rows_per_block + tr; r < in_rows; r += (long)gridDim.x * rows_per_block) {
-        const long pl = r / h;
-        const int yy = (int)(r - pl * h);
+    const long pl = blockIdx.x;
+    const float* pdy = dy + pl * oh * ow;
+    const uint8_t* pi = idx + pl * oh * ow;
+    float* pdx = dx + pl * h * w;
+    for (int yy = blockIdx.y * rows_per_block + tr; yy < h; yy += gridDim.y * rows_per_block) {
         const int oy = ph == 2 ? (yy >> 1) : yy;
         const bool row_live = oy < oh;
-        const long orow = (pl * oh + oy) * ow;
+        const int orow = oy * ow;
         const int rbit = ph == 2 ? ((yy & 1) << 1) : 0;
         for (int xx = tc; xx < w; xx += colp) {
             const int ox = xx >> 1;
             float g = 0.f;
-            if (row_live && ox < ow && idx[orow + ox] == (rbit | (xx & 1))) g = dy[orow + ox];
-            dx[r * w + xx] = g;
+            if (row_live && ox < ow && pi[orow + ox] == (rbit | (xx & 1))) g = pdy[orow + ox];
+            pdx[yy * w + xx] = g;
         }
     }
 }
@@ -124,11 +129,13 @@ int col_log2(int cols) {
     return l;
 }
 
-unsigned row_grid(long rows, int colp_log2) {
-    const long per_block = kThreads >> colp_log2;
-    long b = (rows + per_block - 1) / per_block;
-    if (b > 256L * 32) b = 256L * 32;
-    return (unsigned)(b < 1 ? 1 : b);
+unsigned row_grid(int rows, int colp_log2) {
+    // row groups per plane: a few rows per block keep >= 8 iterations of work per thread
+    const int per_block = kThreads >> colp_log2;
+    int b = (rows + per_block * 8 - 1) / (per_block * 8);
+    if (b < 1) b = 1;
+    if (b > 64) b = 64;
+    return (unsigned)b;
 }
 
 unsigned stream_grid(long total) {
@@ -147,9 +154,8 @@ int fsc_maxpool_fwd(const float* x, float* y, uint8_t* idx, int nc, int h, int w
     FSC_CHECK_ARG((ph == 1 || ph == 2) && nc > 0 && h >= ph && w >= 2, "fsc_maxpool_fwd: bad shape nc=%d h=%d w=%d ph=%d", nc, h, w, ph);
     const int oh = h / ph, ow = w / 2;
     const int cl = col_log2(ow);
-    const long rows = (long)nc * oh;
-    hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(row_grid(rows, cl)), dim3(kThreads), 0, fsc::as_stream(stream), x, y,
-                       idx, rows, h, w, ph, oh, ow, cl);
+    hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(nc, row_grid(oh, cl)), dim3(kThreads), 0, fsc::as_stream(stream), x, y,
+                       idx, h, w, ph, oh, ow, cl);
     FSC_LAUNCH_CHECK("fsc_maxpool_fwd");
     return 0;
 }
@@ -159,9 +165,8 @@ int fsc_maxpool_bwd(const float* dy, const uint8_t* idx, float* dx, int nc, int 
     FSC_CHECK_ARG((ph == 1 || ph == 2) && nc > 0 && h >= ph && w >= 2, "fsc_maxpool_bwd: bad shape");
     const int oh = h / ph, ow = w / 2;
     const int cl = col_log2(w);
-    const long rows = (long)nc * h;
-    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(row_grid(rows, cl)), dim3(kThreads), 0, fsc::as_stream(stream), dy,
-                       idx, dx, rows, h, w, ph, oh, ow, cl);
+    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(nc, row_grid(h, cl)), dim3(kThreads), 0, fsc::as_stream(stream), dy,
+                       idx, dx, h, w, ph, oh, ow, cl);
     FSC_LAUNCH_CHECK("fsc_maxpool_bwd");
     return 0;
 }

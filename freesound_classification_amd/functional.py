@@ -310,6 +310,21 @@ def bn_act_backward(dy, x, st, bn, alpha=None, residual=None, gmax=None, want_dx
     return dx, dres, dgamma, dbeta, dalpha, csum
 
 
+def bn_act_backward_unpool(dy, x, st, bn, alpha, pool_idx, c_shape, ph):
+    """Backward of BN+PReLU on a pooled tensor fused with the max-pool backward.
+    Returns (dc at the un-pooled shape, dgamma, dbeta, dalpha, per-channel sum of the gradient)."""
+    n, c, h, w = c_shape
+    dc = _empty(tuple(c_shape), x)
+    dgamma = _empty((c,), x)
+    dbeta = _empty((c,), x)
+    dalpha = _empty((c,), x) if alpha is not None else None
+    csum = _empty((c,), x)
+    call("fsc_bn_act_bwd_unpool", ptr(dy), ptr(x), ptr(st.mean), ptr(st.invstd), ptr(bn.weight), ptr(bn.bias),
+         ptr(alpha), ptr(pool_idx), ptr(dc), ptr(dgamma), ptr(dbeta), ptr(dalpha), ptr(csum), n, c, h, w, ph,
+         ptr(_bn_ws(c, x)), stream_ptr())
+    return dc, dgamma, dbeta, dalpha, csum
+
+
 # ------------------------------------------------------------------------------ pooling
 def maxpool_forward(x, ph):
     n, c, h, w = x.shape
@@ -450,11 +465,9 @@ class ConvBlockFn(torch.autograd.Function):
         db = conv_dgrad(dr1, w1, k.b.shape, accumulate_into=db)     # residual + conv1 paths
         del dr1
         # ---- b = prelu(bn_b(p))
-        dp, _, dgb, dbtb, dalb, dbias_a = bn_act_backward(db, k.p, k.st_b, bn_b, prelu_b.weight,
-                                                          want_chan_sum=True)
+        dc, dgb, dbtb, dalb, dbias_a = bn_act_backward_unpool(db.contiguous(), k.p, k.st_b, bn_b, prelu_b.weight,
+                                                              k.pidx, k.c_shape, ph)
         del db
-        dc = maxpool_backward(dp, k.pidx, k.c_shape, ph)
-        del dp
         wa, _ = _conv_params(conv_a)
         dwa = conv_wgrad(k.a, dc, wa.shape, True)
         da = conv_dgrad(dc, wa, k.a.shape)

@@ -122,6 +122,16 @@ int fsc_bn_act_bwd(const float* dy, const float* gmax_dy, const int* gmax_idx, c
                    float* dx_chan_sum, int n, int c, long hw, void* workspace,
                    fsc_stream_t stream);
 
+/* Same backward for the unit that directly follows a max-pool (BN -> PReLU on the pooled tensor x,
+ * classifiers.py:532-534), fused with the pool's backward: writes dc (N, C, h, w), the gradient of
+ * the UN-pooled tensor -- each window's gradient at its arg-max (pool_idx from fsc_maxpool_fwd),
+ * zeros elsewhere -- instead of dx at the pooled resolution.  ph as in fsc_maxpool_fwd. */
+int fsc_bn_act_bwd_unpool(const float* dy, const float* x, const float* save_mean,
+                          const float* save_invstd, const float* gamma, const float* beta,
+                          const float* alpha, const uint8_t* pool_idx, float* dc, float* dgamma,
+                          float* dbeta, float* dalpha, float* dx_chan_sum, int n, int c, int h,
+                          int w, int ph, void* workspace, fsc_stream_t stream);
+
 /* ------------------------------------------------------------------ pooling (K8, K12)
  * nn.MaxPool2d(2,2) / nn.MaxPool1d(2,2), floor mode (classifiers.py:532, 155);
  * nn.AdaptiveMaxPool2d(1) / 1d(1) (classifiers.py:540, 163). ph is 2 (2-d) or 1 (1-d). */

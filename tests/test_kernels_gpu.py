@@ -322,3 +322,34 @@ def test_optimizers_golden(golden):
         assert maxdiff(w, torch.from_numpy(g["adam.w%d" % (s + 1)])) < 2e-6
     sd = opt.state_dict()["state"][0]
     assert set(sd) == {"step", "exp_avg", "exp_avg_sq", "max_exp_avg_sq"}
+
+
+@pytest.mark.parametrize("shape,ph", [((3, 5, 13, 21), 2), ((2, 4, 8, 6), 2), ((3, 6, 1, 17), 1)])
+def test_bn_act_bwd_fused_with_unpool(shape, ph):
+    """fsc_bn_act_bwd_unpool == max_pool backward of (BN + PReLU backward), incl. odd trailing row/col."""
+    n, c, h, w = shape
+    torch.manual_seed(h * w + c)
+    cfull = torch.randn(shape, requires_grad=True)
+    bn = torch.nn.BatchNorm2d(c)
+    prelu = torch.nn.PReLU(c)
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5)
+        bn.bias.normal_()
+        prelu.weight.uniform_(0.1, 0.4)
+    p = TF.max_pool2d(cfull, (ph, 2), (ph, 2))
+    y = prelu(bn(p))
+    gy = torch.randn_like(y)
+    y.backward(gy)
+    dbn = torch.nn.BatchNorm2d(c).to(DEV)
+    with torch.no_grad():
+        dbn.weight.copy_(bn.weight)
+        dbn.bias.copy_(bn.bias)
+    pd, pidx = F.maxpool_forward(cfull.detach().to(DEV), ph)
+    st = F.bn_prepare(pd, dbn, True)
+    alpha = prelu.weight.detach().to(DEV)
+    dc, dg, db, dal, csum = F.bn_act_backward_unpool(gy.to(DEV), pd, st, dbn, alpha, pidx, shape, ph)
+    assert maxdiff(dc, cfull.grad) < 5e-5
+    assert maxdiff(dg, bn.weight.grad) < 2e-4
+    assert maxdiff(db, bn.bias.grad) < 2e-4
+    assert maxdiff(dal, prelu.weight.grad) < 2e-4
+    assert maxdiff(csum, cfull.grad.sum(dim=(0, 2, 3))) < 2e-4

@@ -172,10 +172,11 @@ def test_cfg1_end_to_end_golden(golden, loss_name):
         make_step(m.scheduler, step=step + 1)
         logits, per, loss = m.training_step(signal, labels)
         # Step 0 is a pure function of the inputs.  Step 1 sees parameters after one Adam step,
-        # where the update is lr * g / (|g| + eps): with the mean-BCE loss most gradients are
-        # 1e-8..1e-6, the same size as eps and as fp32 summation noise, so the updated
-        # parameters (and the next logits) legitimately differ at the 1e-3 level.
-        tol = TOL if (step == 0 or loss_name == "lsep") else 5e-3
+        # where the update is lr * g / (|g| + eps): gradients that are analytically zero (conv
+        # biases under batch-stat BN) or, with the mean-BCE loss, 1e-8..1e-6 small are the same size
+        # as eps and as fp32 summation-order noise, so the updated parameters (and the next logits)
+        # legitimately differ at the 1e-3 level between two correct implementations.
+        tol = TOL if step == 0 else 5e-3
         assert maxdiff(logits, g["%s.logits%d" % (loss_name, step)]) < tol
         assert abs(float(loss) - float(g["%s.loss%d" % (loss_name, step)])) < TOL
         probs = F.sigmoid(logits).cpu().numpy()
