@@ -321,7 +321,7 @@ struct WgCfg {
     static constexpr int NT = CIT * TAPS;                         // (ci-tile, tap) pairs per workgroup
     static constexpr int NPW = (NT + WAVES - 1) / WAVES;          // pairs per wave (3x3: 5,5,4,4)
     static constexpr int PIXC = 64;                               // pixels per unit (K of the GEMM) = one wave
-    static constexpr int MAXPOS64 = TAPS == 1 ? 1 : (TAPS == 3 ? 2 : 3);   // staged positions per lane (x 64)
+    static constexpr int MAXPOS64 = TAPS == 1 ? 1 : (TAPS == 3 ? 2 : 4);   // staged positions per lane (x 64)
 };
 
 struct WgGeom {
@@ -777,7 +777,10 @@ bool plan_wgrad(const fsc_conv_desc& d_in, WgPlan* out) {
     const int taps = d.kh * d.kw;
     const int waves = 4;
     const int cit = taps == 9 ? 2 : (taps == 3 ? 4 : 8);
-    const int pixc = 64, maxpos_total = 64 * (taps == 1 ? 1 : (taps == 3 ? 2 : 3));
+    const int pixc = 64, maxpos_total = 64 * (taps == 1 ? 1 : (taps == 3 ? 2 : 4));
+    // stem layers (packed kernel) are HBM-bound on dOut: PMC showed 3x the tensor fetched with 16-pixel
+    // rows (each 64-byte row segment straddles two sectors), so they use full 64-pixel rows
+    const bool wide_rows = taps > 1 && d.c_in * taps <= 32 && d.c_in <= 16 && d.w >= 64;
     g.n = d.n; g.cin = d.c_in; g.cout = d.c_out; g.h = d.h; g.w = d.w; g.hw = (long)d.h * d.w;
     const int tiles = fsc::ceil_div(d.c_out, 16);
     int best_mt = 1, best_blocks = tiles;
@@ -811,7 +814,8 @@ bool plan_wgrad(const fsc_conv_desc& d_in, WgPlan* out) {
         const long tiles = (long)fsc::ceil_div(d.n, nb) * fsc::ceil_div(d.h, th) * fsc::ceil_div(d.w, tw);
         // halo'd positions are DMA work per unit (64 positions per instruction and channel)
         const long halo_instr = (nb * (th + d.kh - 1) * (tw + d.kw - 1) + 63) / 64;
-        const long cost = tiles * box_penalty(tw, d.w) * (20 + halo_instr);
+        long cost = tiles * box_penalty(tw, d.w) * (20 + halo_instr);
+        if (wide_rows && tw != pixc) cost *= 4;
         if (best_cost < 0 || cost < best_cost || (cost == best_cost && tw > btw)) {
             best_cost = cost; bnb = nb; bth = th; btw = tw;
         }
