@@ -18,6 +18,8 @@
 //   * split-K over pixel tiles; partials [split][tap][ci][co] reduced by a second kernel that
 //     also transposes into the (c_out, c_in, kh, kw) layout of the state dict.
 #include "common.h"
+#include <stdlib.h>
+#include <string.h>
 
 namespace {
 
@@ -40,6 +42,12 @@ struct Geom {
     int flat;                 // 1x1: pixels are a flat (n, hw) range, box = [p0, p0 + npix)
     long flat_total;          // n * hw
     int ksplit;               // > 1: blockIdx.z owns a slice of the K chunks and adds into a zeroed output
+    // split-bf16 kernel (conv_fwd_x3_kernel): K runs over 32-channel chunks, one MFMA step per tap
+    int x_nfull;              // chunks of 32 channels (a remainder of 25..31 channels counts as full, zero-filled)
+    int x_tail_oct;           // 8-channel octets of the remainder chunk (0 = none, else 1..3)
+    int x_tail_steps;         // ceil(taps * x_tail_oct / 4)
+    int x_steps;              // x_nfull * taps + x_tail_steps
+    int x_npt;                // input DMA instructions per staged channel = ceil(plane / 64)
 };
 
 // Forward / dgrad tile configuration per kernel size: 128 pixels per workgroup (4 waves x 2 pixel
@@ -308,6 +316,389 @@ __global__ void pack_kernel(const float* __restrict__ w, float* __restrict__ pac
             v = w[((long)co * c_in + ci) * taps + src_tap];
         }
         packed[i] = v;
+    }
+}
+
+// -------------------------------------------------------------------------------------------
+// Forward / dgrad on the bf16 matrix pipe with fp32 results ("x3" = three bf16 limbs per fp32 operand).
+//
+// gfx950 has no tf32/xf32 MFMA and its fp32 MFMA runs at the vector rate (157 TF), 1/16 of the bf16
+// rate.  An fp32 value splits EXACTLY into three bf16 limbs, x = h + m + l (8 + 8 + 8 significant
+// bits, round-to-nearest at each level, the residuals are exact fp32 subtractions), so
+//     a * b = ah*bh + (ah*bm + am*bh) + (ah*bl + am*bm + al*bh) + (am*bl + al*bm) + al*bl
+// where every limb product is exact in the fp32 accumulator of v_mfma_f32_16x16x32_bf16.  NPROD = 9
+// keeps all terms (the product a*b is then exact before accumulation, i.e. at least as accurate as
+// the fp32 FMA chain of the native kernel); NPROD = 6 drops the last three, whose sum is below
+// 2^-23 |a*b| - the size of one fp32 rounding.  6 (9) bf16 MFMAs of K = 32 replace 8 fp32 MFMAs of
+// K = 4, a 2.7x (1.8x) higher MFMA ceiling (2075 TF bf16 16x16x32 / 6 = 346 TF).
+//
+// Data flow per workgroup (4 waves, one per SIMD; COT*16 channels x PT*64 pixels):
+//   * weights arrive pre-split from pack_x3_kernel as ready-made A fragments (1 KB = 64 lanes x
+//     8 bf16 per (step, channel tile, limb)), streamed by LDS-DMA through a ring of three step slots;
+//   * the fp32 input box of a 32-channel chunk [32][plane] is staged by LDS-DMA in two stages;
+//   * one MFMA step = one tap x 32 channels; lane group kq owns channel octet kq (its 8 k-values);
+//     the B operand (8 channels of one pixel) is read as fp32 from LDS and split in registers
+//     while the MFMAs of the previous step run;
+//   * DMAs stay in flight across the raw s_barrier of every step: each wave counts its own DMA
+//     instructions and waits with s_waitcnt vmcnt(N) only for the slot / stage the next step reads.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kXChunk = 32;        // channels per K chunk
+constexpr int kXNptMax = 6;        // input DMA instructions per staged channel (plane <= 384 floats)
+constexpr int kXWaves = 8;         // two waves per SIMD: one wave's split / LDS / scalar work hides behind the other's MFMAs
+
+__device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {      // v_cvt_pk_bf16_f32 (RNE)
+    return __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){lo, hi}, bf16x2));
+}
+
+// x[0..7] -> three packed bf16x8 limbs with x = h + m + l exactly
+__device__ __forceinline__ void split3(const float (&x)[8], u32x4& h, u32x4& m, u32x4& l) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const float x0 = x[2 * q], x1 = x[2 * q + 1];
+        const unsigned hp = cvt_pk_bf16(x0, x1);
+        const float r0 = x0 - __uint_as_float(hp << 16), r1 = x1 - __uint_as_float(hp & 0xffff0000u);
+        const unsigned mp = cvt_pk_bf16(r0, r1);
+        const float s0 = r0 - __uint_as_float(mp << 16), s1 = r1 - __uint_as_float(mp & 0xffff0000u);
+        h[q] = hp;
+        m[q] = mp;
+        l[q] = cvt_pk_bf16(s0, s1);
+    }
+}
+
+// workgroup barrier that neither drains the DMAs in flight nor lets the compiler move LDS accesses across it
+__device__ __forceinline__ void raw_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+template <int KH, int KW, int COT, int PT, int NPROD>
+__global__ __launch_bounds__(kXWaves * 64) void conv_fwd_x3_kernel(Geom g, const float* __restrict__ in,
+                                                               const float* __restrict__ packed,
+                                                               const float* __restrict__ bias,
+                                                               float* __restrict__ out, int accumulate) {
+    constexpr int TAPS = KH * KW;
+    constexpr int CO_BLK = COT * 16;
+    constexpr int PADH = KH / 2, PADW = KW / 2;
+    constexpr int WUNITS = COT * 3;                 // 1 KB fragment images per step
+    constexpr int WSLOT_F = WUNITS * 256;           // floats per ring slot
+    constexpr int NWQ = (WUNITS + kXWaves - 1) / kXWaves;
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* const wring = smem;                                  // 3 slots
+    float* const ibase = smem + 3 * WSLOT_F;                    // 2 stages of [32][plane]
+    const int istage = kXChunk * g.plane;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lm = lane & 15, kq = lane >> 4;
+
+    int t = blockIdx.x;
+    const int twi = t % g.tiles_w; t /= g.tiles_w;
+    const int thi = t % g.tiles_h; t /= g.tiles_h;
+    const int n0 = t * g.nb;
+    const int h0 = thi * g.th, w0 = twi * g.tw;
+    const int co0 = blockIdx.y * CO_BLK;
+
+    // ---- per-lane input DMA plan: position pos = t*64 + lane of the staged box, the same for every channel
+    const float inv_per = 1.0f / (float)(g.rows * g.cols), inv_cols = 1.0f / (float)g.cols;
+    const float inv_tw = 1.0f / (float)g.tw, inv_thw = 1.0f / (float)(g.th * g.tw);
+    int pos_off[kXNptMax];       // offset inside the input tensor relative to channel 0; -1 = zero fill
+#pragma unroll
+    for (int q = 0; q < kXNptMax; ++q) {
+        const int pos = q * 64 + lane;
+        pos_off[q] = -1;
+        if (pos < g.npos) {
+            const int per = g.rows * g.cols;
+            const int b = fdiv(pos, inv_per), rem = pos - b * per;
+            const int rr = fdiv(rem, inv_cols), cc = rem - rr * g.cols;
+            const int gh = h0 + rr - PADH, gw = w0 + cc - PADW;
+            if (n0 + b < g.n && gh >= 0 && gh < g.h && gw >= 0 && gw < g.w)
+                pos_off[q] = (int)(((long)(n0 + b) * g.cin) * g.hw + (long)gh * g.w + gw);
+        }
+    }
+
+    // ---- this lane's output pixels
+    int pix_l[PT];
+    long pix_g[PT];
+#pragma unroll
+    for (int pt = 0; pt < PT; ++pt) {
+        const int p = (wid * PT + pt) * 16 + lm;
+        pix_l[pt] = 0;
+        pix_g[pt] = -1;
+        if (p < g.npix) {
+            const int per = g.th * g.tw;
+            const int b = fdiv(p, inv_thw), rem = p - b * per;
+            const int r = fdiv(rem, inv_tw), c = rem - r * g.tw;
+            pix_l[pt] = (b * g.rows + r) * g.cols + c;
+            if (n0 + b < g.n && h0 + r < g.h && w0 + c < g.w)
+                pix_g[pt] = (long)(n0 + b) * g.cout * g.hw + (long)(h0 + r) * g.w + (w0 + c);
+        }
+    }
+
+    f32x4 acc[COT][PT];
+#pragma unroll
+    for (int i = 0; i < COT; ++i)
+#pragma unroll
+        for (int j = 0; j < PT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // ---- K range of this workgroup (split-K over chunks through blockIdx.z)
+    const int nchunks = g.x_nfull + (g.x_tail_oct ? 1 : 0);
+    const int c_lo = (int)((long)nchunks * blockIdx.z / g.ksplit);
+    const int c_hi = (int)((long)nchunks * (blockIdx.z + 1) / g.ksplit);
+    const int s_lo = c_lo * TAPS;                                    // chunks below the tail are all full
+    const int s_hi = c_hi == nchunks ? g.x_steps : c_hi * TAPS;
+
+    // ---- DMA issue.  Weights: unit u of a step goes to wave u % 8.  Input: channel kk of a chunk to wave kk % 8.
+    const float* zero = g_zero16;
+    const float* wsrc = packed + ((long)blockIdx.y * g.x_steps + s_lo) * WSLOT_F + lane * 4;    // W(S) of this lane
+    auto issue_w = [&](const float* src, int slot) {
+        float* dst = wring + slot * WSLOT_F;
+#pragma unroll
+        for (int q = 0; q < NWQ; ++q) {
+            const int u = q * kXWaves + wid;
+            if (u < WUNITS) glds16(src + u * 256, dst + u * 256);
+        }
+    };
+    auto issue_i = [&](int c) {
+        const int ci0 = c * kXChunk;
+        const int nch = c < g.x_nfull ? kXChunk : g.x_tail_oct * 8;     // staged channels of this chunk
+        float* dst = ibase + (c & 1) * istage;
+        for (int kk = wid; kk < nch; kk += kXWaves) {
+            const float* src = in + (long)(ci0 + kk) * g.hw;
+            const bool ch_live = ci0 + kk < g.cin;
+#pragma unroll
+            for (int q = 0; q < kXNptMax; ++q) {
+                if (q < g.x_npt) {
+                    if (q * 64 + lane < g.plane) {
+                        const bool live = ch_live && pos_off[q] >= 0;
+                        glds4(live ? src + pos_off[q] : zero, dst + kk * g.plane + q * 64);
+                    }
+                }
+            }
+        }
+    };
+    // Outstanding-DMA bookkeeping: a wave issues >= NWLO weight units per step and exactly 4 * x_npt input
+    // instructions per full chunk.  At the barrier of step S the weights W(S) (issued two steps ago) must have
+    // landed; younger and allowed to stay in flight are W(S+1) and an input box issued in the last two steps that
+    // the coming step does not read yet.  Counting less than what is really in flight only waits longer.
+    constexpr int NWLO = WUNITS / kXWaves;
+    auto wait_weights = [&](bool input_in_flight) {
+#define FSC_VMW(k) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(k) : "memory")
+        if (input_in_flight) {
+            switch (g.x_npt) {
+                case 3: FSC_VMW(NWLO + 12); break;
+                case 4: FSC_VMW(NWLO + 16); break;
+                case 5: FSC_VMW(NWLO + 20); break;
+                case 6: FSC_VMW(NWLO + 24); break;
+                default: FSC_VMW(NWLO); break;
+            }
+        } else {
+            FSC_VMW(NWLO);
+        }
+#undef FSC_VMW
+    };
+
+    // ---- B operand: 8 channels (this lane group's octet) of one pixel at the tap of step s of chunk c.
+    //      b_base is this lane's pointer to (octet, tap) inside the staged box.
+    auto b_base = [&](int c, int s) -> const float* {
+        const float* st = ibase + (c & 1) * istage;
+        if (c < g.x_nfull) {                               // full chunk: step = tap, lane group = octet
+            const int ty = s / KW, tx = s - ty * KW;       // wave-uniform
+            return st + kq * 8 * g.plane + ty * g.cols + tx;
+        }
+        const int noct = g.x_tail_oct;
+        int gi = 4 * s + kq;
+        if (gi >= TAPS * noct) gi = 0;                     // its weights are zero
+        const int tap = noct == 2 ? gi >> 1 : noct == 1 ? gi : fdiv(gi, 1.0f / 3.0f);
+        const int oct = gi - tap * noct;
+        const int ty = fdiv(tap, 1.0f / (float)KW), tx = tap - ty * KW;
+        return st + oct * 8 * g.plane + ty * g.cols + tx;
+    };
+
+    struct Limbs { u32x4 h[PT], m[PT], l[PT]; };
+    Limbs lb0, lb1;
+    if (s_lo < s_hi) {
+        issue_i(c_lo);
+        issue_w(wsrc, 0);
+        if (s_lo + 1 < s_hi) issue_w(wsrc + WSLOT_F, 1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        raw_barrier();
+        const float* il = b_base(c_lo, 0);
+#pragma unroll
+        for (int j = 0; j < PT; ++j) {
+            float raw[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) raw[e] = il[e * g.plane + pix_l[j]];
+            split3(raw, lb0.h[j], lb0.m[j], lb0.l[j]);
+        }
+    }
+
+    // incremental step state (all wave-uniform)
+    int c = c_lo, sc = 0;                                            // chunk of step S and step inside it
+    int nst = c < g.x_nfull ? TAPS : g.x_tail_steps;
+    int slot = 0;                                                    // ring slot of W(S)
+    int input_age = 99;                                              // steps since a full-chunk input box was issued
+
+    // One MFMA step.  `cur` holds the split B operand of step S; the B operand of step S+1 is read from LDS
+    // and split into `nxt` between the MFMAs.  Phase i = the PT*NPROD MFMAs of channel tile i in NPROD groups
+    // of PT independent MFMAs (one limb pair each); the A fragments of tile i+1, the raw B reads and the split
+    // arithmetic are placed between the groups at compile time, and the DMA issue after phase 0, so that the
+    // second wave of the SIMD always finds MFMAs of this wave to overlap with.
+    auto step = [&](int S, const Limbs& cur, Limbs& nxt) {
+        const bool last = S + 1 >= s_hi;
+        int cn = c, sn = sc + 1;                                     // coordinates of step S+1
+        if (sn == nst) { cn = c + 1; sn = 0; }
+        if (last) { cn = c; sn = sc; }
+        if (S > s_lo) {
+            wait_weights(input_age <= 1 && cn == c);
+            raw_barrier();
+        }
+        const float* il = b_base(cn, sn);
+        const u32x4* wl = reinterpret_cast<const u32x4*>(wring + slot * WSLOT_F) + lane;
+        float raw[PT][8];
+        u32x4 a[2][3];
+#pragma unroll
+        for (int p = 0; p < 3; ++p) a[0][p] = wl[p * 64];
+#pragma unroll
+        for (int i = 0; i < COT; ++i) {
+            const bf16x8 ah = __builtin_bit_cast(bf16x8, a[i & 1][0]);
+            const bf16x8 am = __builtin_bit_cast(bf16x8, a[i & 1][1]);
+            const bf16x8 al = __builtin_bit_cast(bf16x8, a[i & 1][2]);
+#pragma unroll
+            for (int gq = 0; gq < NPROD; ++gq) {
+                // ---- the side work of this MFMA group (all compile-time placement)
+                if (gq == 0 && i + 1 < COT) {
+#pragma unroll
+                    for (int p = 0; p < 3; ++p) a[(i + 1) & 1][p] = wl[((i + 1) * 3 + p) * 64];
+                }
+#pragma unroll
+                for (int j = 0; j < PT; ++j) {
+                    const int rp = (j >> 1) < COT - 1 ? (j >> 1) : COT - 1;       // phase that reads raw[j]
+                    int sp = rp + 1 > COT - PT + j ? rp + 1 : COT - PT + j;        // phase that splits it
+                    if (sp > COT - 1) sp = COT - 1;
+                    if (rp == i) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e)
+                            if (((j & 1) * 8 + e) % NPROD == gq && (rp != sp || gq < 2))
+                                raw[j][e] = il[e * g.plane + pix_l[j]];
+                        if (rp == sp && gq == 1) {      // single-phase tiles: read everything up front
+#pragma unroll
+                            for (int e = 0; e < 8; ++e)
+                                if (((j & 1) * 8 + e) % NPROD >= 2) raw[j][e] = il[e * g.plane + pix_l[j]];
+                        }
+                    }
+                    if (sp == i && gq >= 2 && gq < 6) {
+                        const int q = gq - 2;
+                        const float x0 = raw[j][2 * q], x1 = raw[j][2 * q + 1];
+                        unsigned hp = cvt_pk_bf16(x0, x1);
+                        const float r0 = x0 - __uint_as_float(hp << 16), r1 = x1 - __uint_as_float(hp & 0xffff0000u);
+                        unsigned mp = cvt_pk_bf16(r0, r1);
+                        const float s0 = r0 - __uint_as_float(mp << 16), s1 = r1 - __uint_as_float(mp & 0xffff0000u);
+                        unsigned lp = cvt_pk_bf16(s0, s1);
+                        // pin the split to this group (otherwise it is sunk to its first use in the next step)
+                        asm volatile("" : "+v"(hp), "+v"(mp), "+v"(lp));
+                        nxt.h[j][q] = hp;
+                        nxt.m[j][q] = mp;
+                        nxt.l[j][q] = lp;
+                    }
+                }
+                // ---- PT independent MFMAs (one limb pair, every pixel tile)
+                constexpr int kPairA[9] = {1, 0, 2, 0, 1, 0, 2, 1, 2};      // 0 = h, 1 = m, 2 = l
+                constexpr int kPairB[9] = {1, 2, 0, 1, 0, 0, 2, 2, 1};      // x6 uses the first six
+                const int pa = NPROD == 9 ? kPairA[(gq + 6) % 9] : kPairA[gq];
+                const int pb = NPROD == 9 ? kPairB[(gq + 6) % 9] : kPairB[gq];
+                const bf16x8 av = pa == 0 ? ah : pa == 1 ? am : al;
+#pragma unroll
+                for (int j = 0; j < PT; ++j) {
+                    const bf16x8 bv = __builtin_bit_cast(bf16x8, pb == 0 ? cur.h[j] : pb == 1 ? cur.m[j] : cur.l[j]);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, bv, acc[i][j], 0, 0, 0);
+                }
+#pragma unroll
+                for (int k = 0; k < PT; ++k) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);     // one MFMA
+                    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);     // up to two LDS reads
+                    __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);     // up to four VALU
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (i == 0) {
+                // DMA issue for step S+2 (its slot was read during step S-1) and, at the first step of a
+                // chunk, of the next chunk's input box (its stage was last read during the previous step)
+                if (S + 2 < s_hi) issue_w(wsrc + 2 * WSLOT_F, slot == 0 ? 2 : slot - 1);
+                ++input_age;
+                if ((S == s_lo || sc == 0) && c + 1 < c_hi) {
+                    issue_i(c + 1);
+                    if (c + 1 < g.x_nfull) input_age = 0;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        // advance
+        wsrc += WSLOT_F;
+        slot = slot == 2 ? 0 : slot + 1;
+        if (cn != c) nst = cn < g.x_nfull ? TAPS : g.x_tail_steps;
+        c = cn;
+        sc = sn;
+    };
+
+    for (int S = s_lo; S < s_hi; S += 2) {
+        step(S, lb0, lb1);
+        if (S + 1 < s_hi) step(S + 1, lb1, lb0);
+    }
+
+    // ---- epilogue: D row = channel (kq*4 + r), column = pixel (lm)
+#pragma unroll
+    for (int i = 0; i < COT; ++i) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int co = co0 + i * 16 + kq * 4 + r;
+            if (co >= g.cout) continue;
+            const float bv = (bias && blockIdx.z == 0) ? bias[co] : 0.f;
+#pragma unroll
+            for (int j = 0; j < PT; ++j)
+                if (pix_g[j] >= 0) {
+                    float* o = out + pix_g[j] + (long)co * g.hw;
+                    const float v = acc[i][j][r] + bv;
+                    if (g.ksplit > 1) atomicAdd(o, v);
+                    else *o = accumulate ? *o + v : v;
+                }
+        }
+    }
+}
+
+// weight (c_out, c_in, kh, kw) -> A fragments of conv_fwd_x3_kernel:
+// packed[co block][step][channel tile][limb][lane][8 bf16]; lane = (kq, m), its 8 values are the channels
+// of octet `oct` at tap `tap` where (tap, oct) = divmod(4 * step_in_chunk + kq, octets of the chunk)
+__global__ void pack_x3_kernel(const float* __restrict__ w, unsigned short* __restrict__ packed, int c_out, int c_in,
+                               int taps, int cot, int co_blocks, int nfull, int tail_oct, int steps, int dgrad) {
+    const long total = (long)co_blocks * steps * cot * 512;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int e = (int)(idx & 7), lane = (int)((idx >> 3) & 63);
+        long rest = idx >> 9;
+        const int i = (int)(rest % cot); rest /= cot;
+        const int S = (int)(rest % steps);
+        const int cb = (int)(rest / steps);
+        const int c = S < nfull * taps ? S / taps : nfull;
+        const int s = S - c * taps;
+        const int noct = c < nfull ? 4 : tail_oct;
+        const int gi = 4 * s + (lane >> 4);
+        float v = 0.f;
+        if (gi < taps * noct) {
+            const int tap = gi / noct, oct = gi - tap * noct;
+            const int k = c * kXChunk + oct * 8 + e, m = (cb * cot + i) * 16 + (lane & 15);
+            const int co = dgrad ? k : m, ci = dgrad ? m : k;
+            if (co < c_out && ci < c_in) v = w[((long)co * c_in + ci) * taps + (dgrad ? taps - 1 - tap : tap)];
+        }
+        const unsigned hp = cvt_pk_bf16(v, 0.f);
+        const float r = v - __uint_as_float(hp << 16);
+        const unsigned mp = cvt_pk_bf16(r, 0.f);
+        const float r2 = r - __uint_as_float(mp << 16);
+        const unsigned lp = cvt_pk_bf16(r2, 0.f);
+        const long base = ((((long)cb * steps + S) * cot + i) * 3) * 512 + lane * 8 + e;
+        packed[base] = (unsigned short)hp;
+        packed[base + 512] = (unsigned short)mp;
+        packed[base + 1024] = (unsigned short)lp;
     }
 }
 
@@ -591,7 +982,23 @@ struct FwdPlan {
     int kc;
     size_t lds_bytes;
     long grid_x;
+    int x3;           // 0: native fp32 MFMA kernel; 6 / 9: conv_fwd_x3_kernel with that many limb products
+    int pt;           // pixel tiles per wave
 };
+
+// Arithmetic of the 3x3 / k3 forward and dgrad kernels: 0 = native fp32 MFMA everywhere, 6 / 9 = split-bf16
+// kernel (that many limb products) wherever its tiling fits.  FSC_CONV_ARITH=f32|bf16x6|bf16x9 or fsc_conv_set_arith.
+int g_conv_arith = -1;
+int conv_arith() {
+    if (g_conv_arith < 0) {
+        const char* e = getenv("FSC_CONV_ARITH");
+        g_conv_arith = 9;
+        if (e && !strcmp(e, "f32")) g_conv_arith = 0;
+        else if (e && !strcmp(e, "bf16x6")) g_conv_arith = 6;
+        else if (e && !strcmp(e, "bf16x9")) g_conv_arith = 9;
+    }
+    return g_conv_arith;
+}
 
 int pad_plane(int floats, int want) {   // smallest p >= floats with p % 32 == want
     int p = floats;
@@ -622,7 +1029,104 @@ long tile_penalty(int tiles_per_block) {
 }
 
 
+constexpr int kX3PT = 2;
+
+// tiling of conv_fwd_x3_kernel; false when the shape does not suit it (the native kernel takes over)
+bool plan_fwd_x3(const fsc_conv_desc& d, int dgrad, int nprod, FwdPlan* out) {
+    FwdPlan p{};
+    Geom& g = p.g;
+    const int taps = d.kh * d.kw;
+    if (taps == 1) return false;
+    g.n = d.n; g.h = d.h; g.w = d.w; g.hw = (long)d.h * d.w;
+    g.cin = dgrad ? d.c_out : d.c_in;
+    g.cout = dgrad ? d.c_in : d.c_out;
+    if (g.cin < 32 || g.cout < 48) return false;         // stem layers: HBM-bound, K or M too small for 16x16x32 tiles
+    const int tiles = fsc::ceil_div(g.cout, 16);
+    int best_cot = 1, best_blocks = tiles;
+    long best_tile_cost = (long)tiles * tile_penalty(1);
+    for (int cot = 2; cot <= 8; ++cot) {
+        const int blocks = fsc::ceil_div(tiles, cot);
+        const long cost = (long)blocks * cot * tile_penalty(cot);
+        if (cost < best_tile_cost || (cost == best_tile_cost && blocks < best_blocks)) {
+            best_cot = cot; best_blocks = blocks; best_tile_cost = cost;
+        }
+    }
+    p.cot = best_cot;
+    p.co_blocks = best_blocks;
+    p.pt = kX3PT;
+    p.x3 = nprod;
+    g.m_pad = best_blocks * best_cot * 16;
+    g.flat = 0;
+    const int pix_cap = kXWaves * p.pt * 16;
+    const size_t lds_total = 160 * 1024;
+    const size_t ring = (size_t)3 * p.cot * 3 * 1024;
+    int cap_pos = (int)((lds_total - ring) / (2 * kXChunk * sizeof(float))) - 4;
+    if (cap_pos > 64 * kXNptMax - 4) cap_pos = 64 * kXNptMax - 4;
+    long best_cost = -1;
+    int bnb = 1, bth = 1, btw = 1;
+    for (int tw = 1; tw <= d.w && tw <= pix_cap; ++tw) {
+        int th = pix_cap / tw;
+        if (th > d.h) th = d.h;
+        int nb = 1;
+        if (th == d.h && tw == d.w) {
+            nb = pix_cap / (th * tw);
+            if (nb > d.n) nb = d.n;
+            if (nb < 1) nb = 1;
+        }
+        while (nb > 1 && nb * (th + d.kh - 1) * (tw + d.kw - 1) > cap_pos) --nb;
+        while (th > 1 && nb * (th + d.kh - 1) * (tw + d.kw - 1) > cap_pos) --th;
+        if (nb * (th + d.kh - 1) * (tw + d.kw - 1) > cap_pos) continue;
+        const long nt = (long)fsc::ceil_div(d.n, nb) * fsc::ceil_div(d.h, th) * fsc::ceil_div(d.w, tw);
+        const long cost = nt * box_penalty(tw, d.w);
+        if (best_cost < 0 || cost < best_cost || (cost == best_cost && tw > btw)) {
+            best_cost = cost; bnb = nb; bth = th; btw = tw;
+        }
+    }
+    if (best_cost < 0) return false;
+    g.nb = bnb; g.th = bth; g.tw = btw;
+    g.rows = bth + d.kh - 1; g.cols = btw + d.kw - 1;
+    g.npix = bnb * bth * btw; g.npos = bnb * g.rows * g.cols;
+    g.tiles_n = fsc::ceil_div(d.n, bnb); g.tiles_h = fsc::ceil_div(d.h, bth); g.tiles_w = fsc::ceil_div(d.w, btw);
+    p.grid_x = (long)g.tiles_n * g.tiles_h * g.tiles_w;
+    // fewer than ~70 % live MFMA columns: the native kernel's 128-pixel boxes fit such shapes better
+    if ((double)d.n * g.hw < 0.7 * (double)p.grid_x * pix_cap) return false;
+    g.plane = g.npos;
+    while (g.plane % 4 != 2) ++g.plane;              // 8 * plane == 16 (mod 32): lane groups kq, kq+1 on disjoint banks
+    g.x_npt = fsc::ceil_div(g.plane, 64);
+    if (g.x_npt > kXNptMax) return false;
+    const int rem = g.cin % kXChunk;
+    g.x_nfull = g.cin / kXChunk + (rem > 24 ? 1 : 0);
+    g.x_tail_oct = (rem > 0 && rem <= 24) ? fsc::ceil_div(rem, 8) : 0;
+    g.x_tail_steps = fsc::ceil_div(taps * g.x_tail_oct, 4);
+    g.x_steps = g.x_nfull * taps + g.x_tail_steps;
+    g.k_pad = (g.x_nfull + (g.x_tail_oct ? 1 : 0)) * kXChunk;
+    p.kc = kXChunk;
+    g.ksplit = 1;
+    {
+        const long wgs = p.grid_x * p.co_blocks;
+        const int nchunks = g.x_nfull + (g.x_tail_oct ? 1 : 0);
+        if (wgs < 200) {
+            long ks = (384 + wgs - 1) / wgs;
+            if (ks > 8) ks = 8;
+            if (ks > nchunks / 2) ks = nchunks / 2;
+            if (ks > 1) g.ksplit = (int)ks;
+        }
+    }
+    p.lds_bytes = ring + (size_t)2 * kXChunk * g.plane * sizeof(float);
+    if (p.lds_bytes > lds_total) return false;
+    *out = p;
+    return true;
+}
+
+bool plan_fwd_f32(const fsc_conv_desc& d, int dgrad, FwdPlan* out);
+
 bool plan_fwd(const fsc_conv_desc& d, int dgrad, FwdPlan* out) {
+    const int arith = conv_arith();
+    if (arith && plan_fwd_x3(d, dgrad, arith, out)) return true;
+    return plan_fwd_f32(d, dgrad, out);
+}
+
+bool plan_fwd_f32(const fsc_conv_desc& d, int dgrad, FwdPlan* out) {
     FwdPlan p{};
     Geom& g = p.g;
     const int taps = d.kh * d.kw;
@@ -644,6 +1148,7 @@ bool plan_fwd(const fsc_conv_desc& d, int dgrad, FwdPlan* out) {
     }
     p.cot = best_cot;
     p.co_blocks = best_blocks;
+    p.pt = fwd_pt(taps);
     int kc = fwd_kc(taps);                 // box search below assumes this chunk; may shrink to 4 afterwards
     g.m_pad = best_blocks * best_cot * 16;
     if (taps == 1) {
@@ -711,6 +1216,14 @@ bool plan_fwd(const fsc_conv_desc& d, int dgrad, FwdPlan* out) {
     return true;
 }
 
+template <int KH, int KW, int COT, int NPROD>
+void launch_x3(const FwdPlan& p, dim3 grid, const float* in, const float* packed, const float* bias, float* out,
+               int accumulate, hipStream_t st) {
+    auto kern = conv_fwd_x3_kernel<KH, KW, COT, kX3PT, NPROD>;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes);
+    hipLaunchKernelGGL(kern, grid, dim3(kXWaves * 64), p.lds_bytes, st, p.g, in, packed, bias, out, accumulate);
+}
+
 template <int KH, int KW, int COT>
 int launch_fwd_cot(const FwdPlan& p, const float* in, const float* packed, const float* bias, float* out,
                    int accumulate, hipStream_t st) {
@@ -719,6 +1232,14 @@ int launch_fwd_cot(const FwdPlan& p, const float* in, const float* packed, const
         const size_t bytes = sizeof(float) * (size_t)p.g.n * p.g.cout * p.g.hw;
         hipError_t e = hipMemsetAsync(out, 0, bytes, st);
         FSC_CHECK_ARG(e == hipSuccess, "fsc_conv_fwd: memset failed: %s", hipGetErrorString(e));
+    }
+    if constexpr (KH * KW > 1) {
+        if (p.x3) {
+            if (p.x3 == 6) launch_x3<KH, KW, COT, 6>(p, grid, in, packed, bias, out, accumulate, st);
+            else launch_x3<KH, KW, COT, 9>(p, grid, in, packed, bias, out, accumulate, st);
+            FSC_LAUNCH_CHECK("fsc_conv_fwd(x3)");
+            return 0;
+        }
     }
     if (KH * KW == 9 && p.kc == 4) {
         auto kern = conv_fwd_kernel<KH, KW, COT, fwd_pt(KH * KW), (KH * KW == 9) ? 4 : fwd_kc(KH * KW)>;
@@ -906,13 +1427,33 @@ size_t fsc_conv_packed_floats(const fsc_conv_desc* d, int dgrad) {
     if (!valid_desc(d)) return 0;
     FwdPlan p;
     if (!plan_fwd(*d, dgrad, &p)) return 0;
+    if (p.x3) return (size_t)p.co_blocks * p.g.x_steps * p.cot * 3 * 256;
     return (size_t)d->kh * d->kw * p.g.k_pad * p.g.m_pad;
 }
+
+int fsc_conv_set_arith(int mode) {
+    FSC_CHECK_ARG(mode == 0 || mode == 6 || mode == 9, "fsc_conv_set_arith: mode must be 0 (fp32 MFMA), 6 or 9 (split-bf16 products)");
+    g_conv_arith = mode;
+    return 0;
+}
+
+int fsc_conv_get_arith(void) { return conv_arith(); }
+
 
 int fsc_conv_pack_weights(const fsc_conv_desc* d, const float* weight, int dgrad, float* packed, fsc_stream_t stream) {
     FSC_CHECK_ARG(valid_desc(d) && weight && packed, "fsc_conv_pack_weights: bad descriptor or null pointer");
     FwdPlan p;
     FSC_CHECK_ARG(plan_fwd(*d, dgrad, &p), "fsc_conv_pack_weights: no tiling for this shape");
+    if (p.x3) {
+        const long items = (long)p.co_blocks * p.g.x_steps * p.cot * 512;
+        long xb = (items + 255) / 256;
+        if (xb > 8192) xb = 8192;
+        hipLaunchKernelGGL(pack_x3_kernel, dim3((unsigned)xb), dim3(256), 0, fsc::as_stream(stream), weight,
+                           reinterpret_cast<unsigned short*>(packed), d->c_out, d->c_in, d->kh * d->kw, p.cot, p.co_blocks,
+                           p.g.x_nfull, p.g.x_tail_oct, p.g.x_steps, dgrad);
+        FSC_LAUNCH_CHECK("fsc_conv_pack_weights(x3)");
+        return 0;
+    }
     const long total = (long)d->kh * d->kw * p.g.k_pad * p.g.m_pad;
     long blocks = (total + 255) / 256;
     if (blocks > 4096) blocks = 4096;
@@ -945,9 +1486,14 @@ int fsc_conv_plan_describe(const fsc_conv_desc* d, int mode, char* buf, size_t b
     } else {
         FwdPlan p;
         FSC_CHECK_ARG(plan_fwd(*d, mode, &p), "fsc_conv_plan_describe: no tiling for this shape");
-        snprintf(buf, buf_len, "conv_fwd_kernel<%d,%d,%d,%d> box=%dx%dx%d flat=%d grid=%ldx%dx%d kc=%d lds=%zu", d->kh,
-                 d->kw, p.cot, fwd_pt(d->kh * d->kw), p.g.nb, p.g.th, p.g.tw, p.g.flat, p.grid_x, p.co_blocks,
-                 p.g.ksplit, p.kc, p.lds_bytes);
+        if (p.x3)
+            snprintf(buf, buf_len, "conv_fwd_x3_kernel<%d,%d,%d,%d,%d> box=%dx%dx%d grid=%ldx%dx%d steps=%d lds=%zu", d->kh,
+                     d->kw, p.cot, p.pt, p.x3, p.g.nb, p.g.th, p.g.tw, p.grid_x, p.co_blocks, p.g.ksplit, p.g.x_steps,
+                     p.lds_bytes);
+        else
+            snprintf(buf, buf_len, "conv_fwd_kernel<%d,%d,%d,%d> box=%dx%dx%d flat=%d grid=%ldx%dx%d kc=%d lds=%zu", d->kh,
+                     d->kw, p.cot, fwd_pt(d->kh * d->kw), p.g.nb, p.g.th, p.g.tw, p.g.flat, p.grid_x, p.co_blocks,
+                     p.g.ksplit, p.kc, p.lds_bytes);
     }
     return 0;
 }

@@ -151,6 +151,17 @@ class _timed:
             TIMER.records.append((self.name, self.flops, self.e0, self.e1))
 
 
+def set_conv_arith(mode):
+    """0 / "f32": native fp32 MFMA; 6, 9 / "bf16x6", "bf16x9": fp32 via exact three-limb bf16 split
+    with that many limb products (include/fsc_hip.h, fsc_conv_set_arith)."""
+    mode = {"f32": 0, "bf16x6": 6, "bf16x9": 9}.get(mode, mode)
+    call("fsc_conv_set_arith", int(mode))
+
+
+def get_conv_arith():
+    return _lib.load().fsc_conv_get_arith()
+
+
 def conv_pack(desc, weight, dgrad):
     lib = _lib.load()
     n = lib.fsc_conv_packed_floats(C.byref(desc), dgrad)

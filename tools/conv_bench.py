@@ -49,7 +49,10 @@ if __name__ == "__main__":
     ap.add_argument("kind", nargs="?", default="all")
     ap.add_argument("--shape", default=None)
     ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--arith", default=None, help="f32 | bf16x6 | bf16x9")
     a = ap.parse_args()
+    if a.arith:
+        F.set_conv_arith(a.arith)
     kinds = ["fwd", "dgrad", "wgrad"] if a.kind == "all" else [a.kind]
     if a.shape in SHAPES:
         shapes = [SHAPES[a.shape]]
