@@ -992,7 +992,7 @@ int g_conv_arith = -1;
 int conv_arith() {
     if (g_conv_arith < 0) {
         const char* e = getenv("FSC_CONV_ARITH");
-        g_conv_arith = 9;
+        g_conv_arith = 6;
         if (e && !strcmp(e, "f32")) g_conv_arith = 0;
         else if (e && !strcmp(e, "bf16x6")) g_conv_arith = 6;
         else if (e && !strcmp(e, "bf16x9")) g_conv_arith = 9;

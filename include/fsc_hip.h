@@ -87,7 +87,7 @@ int fsc_conv_plan_describe(const fsc_conv_desc* d, int mode, char* buf, size_t b
  * 6 / 9: every fp32 operand is split exactly into three bf16 limbs and the product is formed from 6 / 9
  * limb products on v_mfma_f32_16x16x32_bf16 with fp32 accumulation (9 = all terms: the product is exact
  * before accumulation; 6 drops terms below 2^-23 |a*b|).  Inputs, outputs and accumulators are fp32
- * in every mode.  Default 9, or the environment variable FSC_CONV_ARITH = f32 | bf16x6 | bf16x9.
+ * in every mode.  Default 6, or the environment variable FSC_CONV_ARITH = f32 | bf16x6 | bf16x9.
  * The packed-weight format depends on the mode: re-pack after changing it. */
 int fsc_conv_set_arith(int mode);
 int fsc_conv_get_arith(void);

@@ -109,6 +109,86 @@ def test_conv_fwd_dgrad_wgrad(case):
     assert maxdiff(dw, wr.grad) < 3e-6 * scale + 1e-5
 
 
+# split-bf16 kernel (conv_fwd_x3_kernel): full 32-channel chunks, every remainder-octet count, a 25..31
+# channel remainder, several channel blocks, split-K, the k3 1-d form, boxes spanning several images
+X3_CASES = [
+    (2, 100, 100, 16, 43, 3, 3),
+    (3, 150, 150, 18, 27, 3, 3),
+    (2, 48, 64, 17, 33, 3, 3),
+    (2, 60, 225, 16, 30, 3, 3),
+    (4, 64, 48, 1, 256, 1, 3),
+    (3, 41, 80, 1, 512, 1, 3),
+    (16, 337, 100, 4, 13, 3, 3),
+    (2, 32, 48, 16, 16, 3, 3),
+]
+
+
+@pytest.fixture
+def restore_conv_arith():
+    mode = F.get_conv_arith()
+    yield
+    F.set_conv_arith(mode)
+
+
+@pytest.mark.parametrize("mode", [6, 9])
+@pytest.mark.parametrize("case", X3_CASES)
+def test_conv_split_bf16_is_fp32_accurate(case, mode, restore_conv_arith):
+    """The three-limb bf16 kernels must be as accurate as fp32 arithmetic: their error against an fp64
+    convolution is bounded by a small multiple of the error PyTorch's own fp32 convolution makes."""
+    n, cin, cout, h, w, kh, kw = case
+    torch.manual_seed(sum(case))
+    x = torch.randn(n, cin, h, w)
+    wt = torch.randn(cout, cin, kh, kw) / (cin * kh * kw) ** 0.5
+    b = torch.randn(cout)
+    gy = torch.randn(n, cout, h, w)
+    pad = (kh // 2, kw // 2)
+    y64 = TF.conv2d(x.double(), wt.double(), b.double(), padding=pad)
+    dx64 = torch.nn.grad.conv2d_input(x.shape, wt.double(), gy.double(), padding=pad)
+    y32 = TF.conv2d(x, wt, b, padding=pad)
+    dx32 = torch.nn.grad.conv2d_input(x.shape, wt, gy, padding=pad)
+    e_fwd32 = float((y32.double() - y64).abs().max())
+    e_dx32 = float((dx32.double() - dx64).abs().max())
+    rms_fwd32 = float((y32.double() - y64).pow(2).mean().sqrt())
+
+    F.set_conv_arith(mode)
+    d = F._desc(n, cin, cout, h, w, kh, kw)
+    assert F.plan_name(d, 0).startswith("conv_fwd_x3_kernel"), F.plan_name(d, 0)
+    assert F.plan_name(d, 1).startswith("conv_fwd_x3_kernel"), F.plan_name(d, 1)
+    got = F.conv_forward(x.to(DEV), wt.to(DEV), b.to(DEV)).cpu()
+    dx = F.conv_dgrad(gy.to(DEV), wt.to(DEV), x.shape).cpu()
+    # measured on MI355X: rms error 1.0-1.7x, max error 1.5-2.3x that of the fp32 FMA chain (the bf16 MFMA
+    # adds its 32 products and the accumulator with one rounding of a wider intermediate, not 32 roundings)
+    assert float((got.double() - y64).abs().max()) < 4.0 * e_fwd32 + 1e-7
+    assert float((got.double() - y64).pow(2).mean().sqrt()) < 2.5 * rms_fwd32 + 1e-8
+    # the bf16 MFMA truncates its wide intermediate: a systematic offset of -0.2 .. -0.4 ulp (measured -2e-8
+    # .. -4.5e-8 at unit scale), an order of magnitude below the rms rounding error
+    assert abs(float((got.double() - y64).mean())) < 1e-7
+    assert float((dx.double() - dx64).abs().max()) < 4.0 * e_dx32 + 1e-7
+    base = torch.randn_like(x).to(DEV)
+    acc = F.conv_dgrad(gy.to(DEV), wt.to(DEV), x.shape, accumulate_into=base.clone())
+    assert maxdiff(acc - base, dx) < 1e-5
+
+    # and the native fp32 MFMA kernel on the same inputs agrees to fp32 rounding
+    F.set_conv_arith(0)
+    assert F.plan_name(d, 0).startswith("conv_fwd_kernel")
+    ref = F.conv_forward(x.to(DEV), wt.to(DEV), b.to(DEV)).cpu()
+    assert maxdiff(got, ref) < 4.0 * e_fwd32 + 1e-6
+
+
+def test_conv_split_bf16_exact_on_bf16_representable_inputs(restore_conv_arith):
+    """With inputs that are exactly representable in bf16 (single non-zero limb) and power-of-two
+    friendly sums the split kernel reproduces the integer result exactly."""
+    F.set_conv_arith(6)
+    torch.manual_seed(3)
+    x = torch.randint(-4, 5, (2, 64, 16, 16)).float()
+    wt = torch.randint(-3, 4, (48, 64, 3, 3)).float()
+    d = F._desc(2, 64, 48, 16, 16, 3, 3)
+    assert F.plan_name(d, 0).startswith("conv_fwd_x3_kernel")
+    y = TF.conv2d(x, wt, None, padding=1)
+    got = F.conv_forward(x.to(DEV), wt.to(DEV), None).cpu()
+    assert torch.equal(got, y)
+
+
 def test_conv_no_bias_and_identity_transpose_check():
     # asymmetric weights catch a swapped row/column in the MFMA C-write
     x = torch.zeros(1, 16, 1, 16)
