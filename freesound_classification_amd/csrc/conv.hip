@@ -954,6 +954,232 @@ __global__ __launch_bounds__((wg_threads<KH, KW>())) void conv_wgrad_kernel(WgGe
     }
 }
 
+// -------------------------------------------------------------------------------------------
+// Weight gradient on the bf16 matrix pipe with fp32 results (same three-limb arithmetic as
+// conv_fwd_x3_kernel; here BOTH operands are activations and are split in registers).
+//
+//   dW[co][ci][tap] = sum over pixels  dOut[co][p] * In[ci][p + tap]        K = pixels
+//
+// One MFMA k-step covers 32 pixels: lane group kq owns a run of 8 consecutive pixels of one box row.
+// Workgroup = 8 waves = ng co-groups x nt ci-tiles; a wave owns <= MT co tiles x one ci tile x all taps.
+// Per k-step it splits MT dOut fragments (8 values each) and, per kernel row ty, ONE 10-pixel window
+// of the input row r + ty: the three horizontal taps tx = -1, 0, +1 are the same bf16 values packed
+// in two pairings (odd pairs serve tx = -1 and +1, even pairs tx = 0), so the split costs 67 VALU per
+// three taps instead of 132.  Per k-step: 54 * MT MFMAs for 44 * MT + 201 VALU.
+// The unit of work is a box of 64 pixels (th rows x tw columns, tw in {8,16,32,64}) staged by LDS-DMA:
+// dOut [co][64] in run order and the halo'd input rows [ci][th + 2][tw + 8] with column 0 at a 16-byte
+// aligned offset, so every operand read is an aligned ds_read_b128.  Two stages; partial sums
+// [split][tap][ci][co] go to the same workspace and reduce kernel as the native wgrad.
+constexpr int kWgxWaves = 8;
+constexpr int kWgxDso = 68;        // dOut row stride in floats: == 4 (mod 64), 16 b128 lanes on 64 distinct banks
+
+struct WgxGeom {
+    int n, cin, cout, h, w;
+    long hw;
+    int th, tw, tiles_h, tiles_w;   // 64-pixel box and boxes per image
+    int units, nsplit;
+    int ng, nt;                     // co groups x ci tiles of a workgroup (ng * nt == 8)
+    int tpb, tpg;                   // co tiles per block / per group (tpg <= MT)
+    int co_blocks, ci_blocks, co_pad, ci_pad;
+    int rowp, plane;                // input row pitch (tw + 8) and channel plane in floats
+    int in_instr;                   // input DMA instructions per channel = ceil((th + 2) * rowp / 64)
+};
+
+template <int KH, int KW, int MT, int NPROD>
+__global__ __launch_bounds__(kWgxWaves * 64) void conv_wgrad_x3_kernel(WgxGeom g, const float* __restrict__ in,
+                                                                       const float* __restrict__ dout,
+                                                                       float* __restrict__ part) {
+    constexpr int TAPS = KH * KW;
+    constexpr int PADH = KH / 2;
+    constexpr int DSO = kWgxDso;
+    constexpr int MAXI = 4;                                  // input DMA instructions per channel (<= 256 staged floats)
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int co_rows = g.ng * g.tpg * 16, ci_rows = g.nt * 16;
+    const int stage_floats = co_rows * DSO + ci_rows * g.plane;
+    // stage s: dOut rows at smem + s * stage_floats, input planes behind them
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lm = lane & 15, kq = lane >> 4;
+    const int cog = wid / g.nt, cit = wid - cog * g.nt;                     // this wave's co group and ci tile
+    const int cb = blockIdx.x / g.ci_blocks, ib = blockIdx.x - cb * g.ci_blocks;
+    const int tile0 = cb * g.tpb;                                          // first co tile of the block
+    const int ci0 = ib * g.nt * 16;
+    const int split = blockIdx.y;
+    const int total_tiles = (g.cout + 15) >> 4;
+    // live co tiles of this wave: i < mt_live
+    int mt_live = g.tpg;
+    {
+        const int first = tile0 + cog * g.tpg;
+        int lim = tile0 + g.tpb < total_tiles ? tile0 + g.tpb : total_tiles;
+        if (first + mt_live > lim) mt_live = lim - first;
+        if (mt_live < 0) mt_live = 0;
+        if (ci0 + cit * 16 >= g.cin) mt_live = 0;                          // ci tile wholly beyond c_in
+    }
+
+    // ---- unit-invariant DMA plans.  dOut: lane = pixel of the box in row-major (= run) order.
+    const int pr = lane / g.tw, pc = lane - pr * g.tw;
+    // input: lane + 64 j = offset inside the pitched rows; column = offset - 4
+    int qr[MAXI], qc[MAXI];
+#pragma unroll
+    for (int j = 0; j < MAXI; ++j) {
+        const int o = lane + 64 * j;
+        qr[j] = o / g.rowp;
+        qc[j] = o - qr[j] * g.rowp - 4;
+        if (qr[j] >= g.th + KH - 1 || qc[j] < -1 || qc[j] > g.tw) qr[j] = -1;      // outside the staged window
+    }
+
+    const float* zero = g_zero16;
+    auto issue_unit = [&](int u, int stage) {
+        float* dl = smem + stage * stage_floats;
+        float* il = dl + co_rows * DSO;
+        int t = u;
+        const int twi = t % g.tiles_w; t /= g.tiles_w;
+        const int thi = t % g.tiles_h; t /= g.tiles_h;
+        const int n0 = t, h0 = thi * g.th, w0 = twi * g.tw;
+        long po = -1;
+        if (h0 + pr < g.h && w0 + pc < g.w) po = (long)n0 * g.cout * g.hw + (long)(h0 + pr) * g.w + (w0 + pc);
+#pragma unroll 1
+        for (int row = wid; row < co_rows; row += kWgxWaves) {
+            const int co = tile0 * 16 + row;
+            const bool live = po >= 0 && co < g.cout;
+            glds4(live ? dout + po + (long)co * g.hw : zero, dl + row * DSO);
+        }
+#pragma unroll
+        for (int j = 0; j < MAXI; ++j) {
+            if (j < g.in_instr) {                                           // uniform
+                long xo = -1;
+                const int gh = h0 + qr[j] - PADH, gw = w0 + qc[j];
+                if (qr[j] >= 0 && gh >= 0 && gh < g.h && gw >= 0 && gw < g.w)
+                    xo = (long)n0 * g.cin * g.hw + (long)gh * g.w + gw;
+                if (lane + 64 * j < g.plane) {                              // lanes past the plane stay out of the DMA
+#pragma unroll 1
+                    for (int cl = wid; cl < ci_rows; cl += kWgxWaves) {
+                        const bool live = xo >= 0 && ci0 + cl < g.cin;
+                        glds4(live ? in + xo + (long)(ci0 + cl) * g.hw : zero, il + cl * g.plane + j * 64);
+                    }
+                }
+            }
+        }
+    };
+
+    f32x4 acc[KH][KW][MT];
+#pragma unroll
+    for (int ty = 0; ty < KH; ++ty)
+#pragma unroll
+        for (int tx = 0; tx < KW; ++tx)
+#pragma unroll
+            for (int i = 0; i < MT; ++i) acc[ty][tx][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // this lane's runs in the two k-steps of a unit: run = 4 st + kq -> (row, first column)
+    const int runs_shift = g.tw == 8 ? 0 : g.tw == 16 ? 1 : g.tw == 32 ? 2 : 3;      // log2(runs per box row)
+    const int a_row = ((cog * g.tpg) * 16 + lm) * DSO;
+    const int b_row = (cit * 16 + lm) * g.plane;
+
+    constexpr int kPairA[9] = {1, 0, 2, 0, 1, 0, 2, 1, 2};      // limb pairs, 0 = h, 1 = m, 2 = l; x6 uses the first six
+    constexpr int kPairB[9] = {1, 2, 0, 1, 0, 0, 2, 2, 1};
+
+    int stage = 0;
+    if (split < g.units) issue_unit(split, 0);
+    for (int u = split; u < g.units; u += g.nsplit) {
+        __syncthreads();                      // unit u has landed (vmcnt drained); everyone is done with the other stage
+        if (u + g.nsplit < g.units) issue_unit(u + g.nsplit, stage ^ 1);
+        const float* dl = smem + stage * stage_floats;
+        const float* il = dl + co_rows * DSO;
+        // Every wave runs all of its MT co tiles: tiles beyond c_out read zero-filled dOut rows, tiles beyond
+        // the block are recomputed and not stored.  (A second, predicated code path doubles the accumulator
+        // registers in hipcc's allocation and spills.)
+        if (mt_live > 0) {
+#pragma unroll 1
+            for (int st = 0; st < 2; ++st) {
+                const int run = 4 * st + kq;
+                const int r = run >> runs_shift, c0 = (run - (r << runs_shift)) * 8;
+                const int a_off = a_row + run * 8;
+                const int b_off = b_row + r * g.rowp + c0;                 // floats c0-4 .. c0+11 of row r + ty
+                // ---- A: dOut fragments of the live co tiles, split into limbs
+                u32x4 al[MT][3];
+#pragma unroll
+                for (int i = 0; i < MT; ++i) {
+                    {
+                        const f32x4* src = reinterpret_cast<const f32x4*>(dl + a_off + i * 16 * DSO);
+                        const f32x4 v0 = src[0], v1 = src[1];
+                        const float x[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+                        split3(x, al[i][0], al[i][1], al[i][2]);
+                        __builtin_amdgcn_sched_barrier(0);    // one tile's raw values at a time (register budget)
+                    }
+                }
+#pragma unroll
+                for (int ty = 0; ty < KH; ++ty) {
+                    // ---- B: the 10-pixel window c0-1 .. c0+8 of input row r + ty, split once for the three tx
+                    const f32x4* src = reinterpret_cast<const f32x4*>(il + b_off + ty * g.rowp);
+                    const f32x4 w0 = src[0], w1 = src[1], w2 = src[2], w3 = src[3];
+                    const float e[10] = {w0[3], w1[0], w1[1], w1[2], w1[3], w2[0], w2[1], w2[2], w2[3], w3[0]};   // e[k] = pixel c0-1+k
+                    unsigned P[3][5], Q[3][4];      // [limb][dword]: P_k = (e[2k], e[2k+1]) odd pairing, Q_k = (e[2k+1], e[2k+2])
+                    float res[10];
+#pragma unroll
+                    for (int k = 0; k < 10; ++k) res[k] = e[k];
+#pragma unroll
+                    for (int lv = 0; lv < 3; ++lv) {
+#pragma unroll
+                        for (int k = 0; k < 5; ++k) P[lv][k] = cvt_pk_bf16(res[2 * k], res[2 * k + 1]);
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) Q[lv][k] = cvt_pk_bf16(res[2 * k + 1], res[2 * k + 2]);
+                        if (lv < 2) {
+#pragma unroll
+                            for (int k = 0; k < 5; ++k) {
+                                res[2 * k] -= __uint_as_float(P[lv][k] << 16);
+                                res[2 * k + 1] -= __uint_as_float(P[lv][k] & 0xffff0000u);
+                            }
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int gq = 0; gq < NPROD; ++gq) {
+                        const int pa = NPROD == 9 ? kPairA[(gq + 6) % 9] : kPairA[gq];
+                        const int pb = NPROD == 9 ? kPairB[(gq + 6) % 9] : kPairB[gq];
+#pragma unroll
+                        for (int tx = 0; tx < KW; ++tx) {
+                            // tx = 0: pixels c0-1.. -> P_0..P_3; tx = 1: c0.. -> Q_0..Q_3; tx = 2: c0+1.. -> P_1..P_4
+                            u32x4 bq;
+                            if (KW == 1 || tx == 1) bq = (u32x4){Q[pb][0], Q[pb][1], Q[pb][2], Q[pb][3]};
+                            else if (tx == 0) bq = (u32x4){P[pb][0], P[pb][1], P[pb][2], P[pb][3]};
+                            else bq = (u32x4){P[pb][1], P[pb][2], P[pb][3], P[pb][4]};
+                            const bf16x8 bv = __builtin_bit_cast(bf16x8, bq);
+#pragma unroll
+                            for (int i = 0; i < MT; ++i) {
+                                acc[ty][tx][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                                        __builtin_bit_cast(bf16x8, al[i][pa]), bv, acc[ty][tx][i], 0, 0, 0);
+                            }
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);        // keep the next row's loads and split behind these MFMAs
+                }
+            }
+        }
+        stage ^= 1;
+    }
+
+    // partial[split][tap][ci][co]; D row = co (kq*4 + r), column = ci (lm)
+#pragma unroll
+    for (int ty = 0; ty < KH; ++ty)
+#pragma unroll
+        for (int tx = 0; tx < KW; ++tx) {
+            const int tap = ty * KW + tx;
+            const long row = ((long)split * TAPS + tap) * g.ci_pad + ci0 + cit * 16 + lm;
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                if (i < g.tpg) {
+                    const int tile = tile0 + cog * g.tpg + i;
+                    if (tile * 16 < g.co_pad && cog * g.tpg + i < g.tpb) {
+                        const f32x4 a = acc[ty][tx][i];
+                        *reinterpret_cast<float4*>(part + row * g.co_pad + tile * 16 + kq * 4) = make_float4(a[0], a[1], a[2], a[3]);
+                    }
+                }
+            }
+        }
+}
+
 // blockIdx.y = (tap, ci) row of the partial slices, threads run along co (coalesced reads); no
 // integer division per element.
 __global__ void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, int c_out, int c_in,
@@ -1390,6 +1616,99 @@ bool plan_wgrad(const fsc_conv_desc& d_in, WgPlan* out) {
     return true;
 }
 
+// ---- split-bf16 wgrad planning
+struct WgxPlan {
+    WgxGeom g;
+    int mt;               // kernel template: co tiles per wave
+    int nprod;
+    size_t lds_bytes;
+};
+
+bool plan_wgrad_x3(const fsc_conv_desc& d, int nprod, WgxPlan* out) {
+    const int taps = d.kh * d.kw;
+    if (taps == 1 || d.c_in < 32 || d.c_out < 32 || (long)d.h * d.w < 64) return false;
+    WgxPlan p{};
+    WgxGeom& g = p.g;
+    g.n = d.n; g.cin = d.c_in; g.cout = d.c_out; g.h = d.h; g.w = d.w; g.hw = (long)d.h * d.w;
+    // 64-pixel box: th x tw with tw a multiple of 8 (a run of 8 pixels is one lane's K slice)
+    long best_px = -1;
+    for (int tw = 64; tw >= 8; tw >>= 1) {
+        const int th = 64 / tw;
+        if (d.kh == 1 && th != 1) continue;
+        if ((th + d.kh - 1) * (tw + 8) > 256) continue;
+        const long px = (long)fsc::ceil_div(d.h, th) * fsc::ceil_div(d.w, tw) * 64;
+        if (best_px < 0 || px < best_px) { best_px = px; g.th = th; g.tw = tw; }
+    }
+    if (best_px < 0 || (double)d.h * d.w < 0.75 * (double)best_px) return false;
+    g.tiles_h = fsc::ceil_div(d.h, g.th); g.tiles_w = fsc::ceil_div(d.w, g.tw);
+    g.units = d.n * g.tiles_h * g.tiles_w;
+    g.rowp = g.tw + 8;
+    g.plane = (g.th + d.kh - 1) * g.rowp;
+    while (g.plane % 64 != 4 && g.plane % 64 != 36) ++g.plane;      // channel rows on distinct 16-byte bank slots
+    if (g.plane > 256) g.plane = (g.th + d.kh - 1) * g.rowp;
+    g.in_instr = fsc::ceil_div((g.th + d.kh - 1) * g.rowp, 64);
+    // workgroup shape: ng co groups x nt ci tiles, <= 4 co tiles per wave
+    const int tiles_co = fsc::ceil_div(d.c_out, 16), tiles_ci = fsc::ceil_div(d.c_in, 16);
+    double best_eff = -1.0;
+    for (int nt = 2; nt <= 8; nt *= 2) {
+        const int ng = kWgxWaves / nt;
+        const int ci_blocks = fsc::ceil_div(tiles_ci, nt);
+        const int co_blocks = fsc::ceil_div(tiles_co, ng * 4);
+        const int tpb = fsc::ceil_div(tiles_co, co_blocks);
+        const int tpg = fsc::ceil_div(tpb, ng);
+        const size_t lds = 2 * sizeof(float) * ((size_t)ng * tpg * 16 * kWgxDso + (size_t)nt * 16 * g.plane);
+        if (lds > 160 * 1024) continue;
+        // MFMA share of a wave's issue slots grows with the co tiles it owns (54 MFMAs per 44 + 201/tpg VALU)
+        static const double kTileWeight[5] = {0.0, 0.55, 0.78, 0.92, 1.0};
+        const double eff = (double)tiles_co * tiles_ci / ((double)co_blocks * ng * tpg * ci_blocks * nt) * kTileWeight[tpg];
+        if (eff > best_eff) {
+            best_eff = eff;
+            g.ng = ng; g.nt = nt; g.tpb = tpb; g.tpg = tpg; g.co_blocks = co_blocks; g.ci_blocks = ci_blocks;
+            p.lds_bytes = lds;
+        }
+    }
+    if (best_eff < 0.5) return false;
+    p.mt = g.tpg;
+    p.nprod = nprod;
+    g.co_pad = g.co_blocks * g.tpb * 16;
+    g.ci_pad = g.ci_blocks * g.nt * 16;
+    // split-K: one workgroup per CU; fill 256 slots without a straggler round, >= 4 units per split
+    const long base = (long)g.co_blocks * g.ci_blocks;
+    const long part_bytes_per_split = (long)taps * g.ci_pad * g.co_pad * 4;
+    long ns = base >= 256 ? 1 : 256 / base;
+    if (ns > g.units / 4) ns = g.units / 4;
+    if (ns < 1) ns = 1;
+    while (ns > 1 && ns * part_bytes_per_split > (256L << 20)) --ns;
+    g.nsplit = (int)ns;
+    *out = p;
+    return true;
+}
+
+template <int KH, int KW, int MT, int NPROD>
+void launch_wgrad_x3_k(const WgxPlan& p, const float* in, const float* dout, float* part, hipStream_t st) {
+    auto kern = conv_wgrad_x3_kernel<KH, KW, MT, NPROD>;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes);
+    dim3 grid(p.g.co_blocks * p.g.ci_blocks, p.g.nsplit);
+    hipLaunchKernelGGL(kern, grid, dim3(kWgxWaves * 64), p.lds_bytes, st, p.g, in, dout, part);
+}
+
+template <int KH, int KW>
+int launch_wgrad_x3(const WgxPlan& p, const float* in, const float* dout, float* part, hipStream_t st) {
+#define FSC_WGX(MT_)                                                                         \
+    if (p.nprod == 6) launch_wgrad_x3_k<KH, KW, MT_, 6>(p, in, dout, part, st);               \
+    else launch_wgrad_x3_k<KH, KW, MT_, 9>(p, in, dout, part, st);                            \
+    break;
+    switch (p.mt) {
+        case 1: FSC_WGX(1)
+        case 2: FSC_WGX(2)
+        case 3: FSC_WGX(3)
+        default: FSC_WGX(4)
+    }
+#undef FSC_WGX
+    FSC_LAUNCH_CHECK("fsc_conv_wgrad(x3)");
+    return 0;
+}
+
 template <int KH, int KW, int MT>
 int launch_wgrad_mt(const WgPlan& p, const float* in, const float* dout, float* part, hipStream_t st) {
     dim3 grid(p.co_blocks * p.g.ci_blocks, p.g.nsplit);
@@ -1478,6 +1797,13 @@ int fsc_conv_fwd(const fsc_conv_desc* d, const float* in, const float* packed, c
 int fsc_conv_plan_describe(const fsc_conv_desc* d, int mode, char* buf, size_t buf_len) {
     FSC_CHECK_ARG(valid_desc(d) && buf && buf_len > 0, "fsc_conv_plan_describe: bad arguments");
     if (mode == 2) {
+        WgxPlan px;
+        if (conv_arith() && plan_wgrad_x3(*d, conv_arith(), &px)) {
+            snprintf(buf, buf_len, "conv_wgrad_x3_kernel<%d,%d,%d,%d> box=%dx%d groups=%dx%d tiles/block=%d units=%d split=%d grid=%dx%d lds=%zu",
+                     d->kh, d->kw, px.mt, px.nprod, px.g.th, px.g.tw, px.g.ng, px.g.nt, px.g.tpb, px.g.units, px.g.nsplit,
+                     px.g.co_blocks * px.g.ci_blocks, px.g.nsplit, px.lds_bytes);
+            return 0;
+        }
         WgPlan p;
         FSC_CHECK_ARG(plan_wgrad(*d, &p), "fsc_conv_plan_describe: no tiling for this shape");
         snprintf(buf, buf_len, "conv_wgrad_kernel<%d,%d,%d%s> box=%dx%dx%d units=%d split=%d grid=%dx%d lds=%zu",
@@ -1500,6 +1826,9 @@ int fsc_conv_plan_describe(const fsc_conv_desc* d, int mode, char* buf, size_t b
 
 size_t fsc_conv_wgrad_workspace_bytes(const fsc_conv_desc* d) {
     if (!valid_desc(d)) return 0;
+    WgxPlan px;
+    if (conv_arith() && plan_wgrad_x3(*d, conv_arith(), &px))
+        return (size_t)px.g.nsplit * d->kh * d->kw * px.g.ci_pad * px.g.co_pad * sizeof(float);
     WgPlan p;
     if (!plan_wgrad(*d, &p)) return 0;
     return (size_t)p.part_splits * d->kh * d->kw * p.g.ci_pad * p.g.co_pad * sizeof(float);
@@ -1508,11 +1837,23 @@ size_t fsc_conv_wgrad_workspace_bytes(const fsc_conv_desc* d) {
 int fsc_conv_wgrad(const fsc_conv_desc* d, const float* in, const float* dout, float* dweight, void* workspace,
                    fsc_stream_t stream) {
     FSC_CHECK_ARG(valid_desc(d) && in && dout && dweight && workspace, "fsc_conv_wgrad: bad descriptor or null pointer");
-    WgPlan p;
-    FSC_CHECK_ARG(plan_wgrad(*d, &p), "fsc_conv_wgrad: no tiling for this shape");
     hipStream_t st = fsc::as_stream(stream);
     float* part = reinterpret_cast<float*>(workspace);
     int rc;
+    WgxPlan px;
+    if (conv_arith() && plan_wgrad_x3(*d, conv_arith(), &px)) {
+        if (d->kh == 3) rc = launch_wgrad_x3<3, 3>(px, in, dout, part, st);
+        else rc = launch_wgrad_x3<1, 3>(px, in, dout, part, st);
+        if (rc) return rc;
+        const int taps = d->kh * d->kw;
+        const int rthreads = d->c_out >= 128 ? 128 : 64;
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(fsc::ceil_div(d->c_out, rthreads), taps * d->c_in), dim3(rthreads), 0, st,
+                           part, dweight, d->c_out, d->c_in, taps, px.g.ci_pad, px.g.co_pad, px.g.nsplit);
+        FSC_LAUNCH_CHECK("fsc_conv_wgrad(reduce)");
+        return 0;
+    }
+    WgPlan p;
+    FSC_CHECK_ARG(plan_wgrad(*d, &p), "fsc_conv_wgrad: no tiling for this shape");
     if (d->kh == 3) rc = launch_wgrad<3, 3>(p, in, dout, part, st);
     else if (d->kw == 3) rc = launch_wgrad<1, 3>(p, in, dout, part, st);
     else rc = launch_wgrad<1, 1>(p, in, dout, part, st);

@@ -16,6 +16,9 @@ CASES = [
     (4, 64, 48, 1, 300, 1, 3),
     (16, 337, 100, 4, 13, 3, 3),
     (2, 32, 48, 16, 16, 3, 3),
+    (3, 150, 150, 18, 27, 3, 3),
+    (2, 100, 150, 9, 53, 3, 3),
+    (3, 64, 48, 1, 256, 1, 3),
 ]
 dev = torch.device("cuda")
 for case in CASES:
@@ -35,6 +38,13 @@ for case in CASES:
         name = F.plan_name(d, 0)
         got = F.conv_forward(x.to(dev), wt.to(dev), b.to(dev)).cpu()
         dx = F.conv_dgrad(gy.to(dev), wt.to(dev), x.shape).cpu()
+        dw = F.conv_wgrad(x.to(dev), gy.to(dev), wt.shape).cpu()
+        if mode == 0:
+            dw64 = torch.nn.grad.conv2d_weight(x.double(), wt.shape, gy.double(), padding=(kh // 2, kw // 2))
+            dw32 = torch.nn.grad.conv2d_weight(x, wt.shape, gy, padding=(kh // 2, kw // 2))
+            ew32 = float((dw32.double() - dw64).abs().max())
+        ew = float((dw.double() - dw64).abs().max())
+        print("    wgrad %-40s maxerr %.3e (torch f32 %.3e) scale %.2f" % (F.plan_name(d, 2), ew, ew32, float(dw64.abs().max())))
         ef = float((got.double() - y64).abs().max())
         ed = float((dx.double() - dx64).abs().max())
         rms = float((got.double() - y64).pow(2).mean().sqrt())
