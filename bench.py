@@ -26,7 +26,9 @@ import torch.distributed as dist
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-PEAK_F32_MFMA_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md, chip-level parameters
+# /opt/skills/guides/MI355X_MICROARCH.md, chip-level parameters
+PEAK_F32_MFMA_TFLOPS = 157.3      # v_mfma_f32_16x16x4_f32 (native fp32 kernels)
+PEAK_BF16_MFMA_TFLOPS = 2500.0    # dense bf16 MFMA (split-bf16 kernels execute 6 or 9 bf16 MFMA flops per fp32 flop)
 
 
 class NS(dict):
@@ -196,13 +198,14 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": "f32",       # tensors, accumulators and results are fp32; see roofline.arithmetic for the conv products
             "data": "synthetic",
             "config": {"workload": "%s: batch %d x %.0f s @ %.1f kHz, %s, %d-block %dd CNN base %d growth %g, "
                                    "LSEP, Adam-amsgrad, dropout %g" % (
                                        args.workload, batch, w["samples"] / w["sr"], w["sr"] / 1e3, w["features"],
                                        w["blocks"], w.get("dims", 2), w["base"], w["growth"], w["dropout"]),
-                       "global_batch": world * batch, "parallelism": "dp%d" % world},
+                       "global_batch": world * batch, "parallelism": "dp%d" % world,
+                       "conv_arith": {0: "f32", 6: "bf16x6", 9: "bf16x9"}[F.get_conv_arith()]},
             "final_loss": final_loss,
         }
         if timer is not None:
@@ -224,9 +227,17 @@ def main():
             if os.path.exists(tpath):
                 with open(tpath) as f:
                     traffic = json.load(f).get(dom_name)
+            # split-bf16 kernels (name ..._x3_kernel<..., NPROD>): every algorithmic fp32 flop costs NPROD bf16
+            # MFMA flops, so `achieved` counts EXECUTED bf16 flops and is priced against the dense bf16 peak
+            peak, executed_per_flop, arith = PEAK_F32_MFMA_TFLOPS, 1, "native fp32 MFMA"
+            if "_x3_kernel" in dom_name:
+                executed_per_flop = int(dom_name.rstrip(">").split(",")[-1])
+                peak = PEAK_BF16_MFMA_TFLOPS
+                arith = "fp32 via exact 3-limb bf16 split, %d bf16 MFMA products per fp32 product, fp32 accumulate" % executed_per_flop
             result["roofline"] = {
-                "kernel": dom_name, "bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS,
-                "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
+                "kernel": dom_name, "bound": "mfma", "achieved": achieved * executed_per_flop, "peak": peak,
+                "unit": "TFLOP/s", "frac": achieved * executed_per_flop / peak, "traffic": traffic,
+                "arithmetic": arith, "algorithmic_fp32_tflops": achieved,
                 "launches_per_step": dom["launches"] / args.steps,
                 "avg_launch_ms": dom["ms"] / dom["launches"],
                 "algorithmic_gflop_per_launch": dom["flops"] / dom["launches"] / 1e9,

@@ -1030,7 +1030,18 @@ __global__ __launch_bounds__(kWgxWaves * 64) void conv_wgrad_x3_kernel(WgxGeom g
         if (qr[j] >= g.th + KH - 1 || qc[j] < -1 || qc[j] > g.tw) qr[j] = -1;      // outside the staged window
     }
 
-    const float* zero = g_zero16;
+    // Rows beyond c_out / c_in are never copied: zero them once in both stages.  The copy loops then walk the
+    // live rows only with one pointer increment per instruction (lanes outside the image keep pointing at a
+    // zero word with stride 0), which keeps the per-unit DMA issue at a few instructions per row.
+    const int co_live = min(co_rows, g.cout - tile0 * 16), ci_live = min(ci_rows, g.cin - ci0);
+    for (int st = 0; st < 2; ++st) {
+        float* dl = smem + st * stage_floats;
+        float* il = dl + co_rows * DSO;
+        for (int i = (co_live > 0 ? co_live : 0) * DSO + tid; i < co_rows * DSO; i += kWgxWaves * 64) dl[i] = 0.f;
+        for (int i = (ci_live > 0 ? ci_live : 0) * g.plane + tid; i < ci_rows * g.plane; i += kWgxWaves * 64) il[i] = 0.f;
+    }
+    const char* zero = reinterpret_cast<const char*>(g_zero16);
+    const long row_bytes = 8 * g.hw * (long)sizeof(float);          // this wave copies every 8th row
     auto issue_unit = [&](int u, int stage) {
         float* dl = smem + stage * stage_floats;
         float* il = dl + co_rows * DSO;
@@ -1038,26 +1049,36 @@ __global__ __launch_bounds__(kWgxWaves * 64) void conv_wgrad_x3_kernel(WgxGeom g
         const int twi = t % g.tiles_w; t /= g.tiles_w;
         const int thi = t % g.tiles_h; t /= g.tiles_h;
         const int n0 = t, h0 = thi * g.th, w0 = twi * g.tw;
-        long po = -1;
-        if (h0 + pr < g.h && w0 + pc < g.w) po = (long)n0 * g.cout * g.hw + (long)(h0 + pr) * g.w + (w0 + pc);
+        {
+            const bool live = h0 + pr < g.h && w0 + pc < g.w;
+            const char* src = live ? reinterpret_cast<const char*>(dout + (long)n0 * g.cout * g.hw + (long)(h0 + pr) * g.w +
+                                                                   (w0 + pc) + (long)(tile0 * 16 + wid) * g.hw)
+                                   : zero;
+            const long step = live ? row_bytes : 0;
+            float* dst = dl + wid * DSO;
 #pragma unroll 1
-        for (int row = wid; row < co_rows; row += kWgxWaves) {
-            const int co = tile0 * 16 + row;
-            const bool live = po >= 0 && co < g.cout;
-            glds4(live ? dout + po + (long)co * g.hw : zero, dl + row * DSO);
+            for (int row = wid; row < co_live; row += kWgxWaves) {
+                glds4(reinterpret_cast<const float*>(src), dst);
+                src += step;
+                dst += kWgxWaves * DSO;
+            }
         }
 #pragma unroll
         for (int j = 0; j < MAXI; ++j) {
             if (j < g.in_instr) {                                           // uniform
-                long xo = -1;
                 const int gh = h0 + qr[j] - PADH, gw = w0 + qc[j];
-                if (qr[j] >= 0 && gh >= 0 && gh < g.h && gw >= 0 && gw < g.w)
-                    xo = (long)n0 * g.cin * g.hw + (long)gh * g.w + gw;
+                const bool live = qr[j] >= 0 && gh >= 0 && gh < g.h && gw >= 0 && gw < g.w;
                 if (lane + 64 * j < g.plane) {                              // lanes past the plane stay out of the DMA
+                    const char* src = live ? reinterpret_cast<const char*>(in + (long)n0 * g.cin * g.hw + (long)gh * g.w + gw +
+                                                                           (long)(ci0 + wid) * g.hw)
+                                           : zero;
+                    const long step = live ? row_bytes : 0;
+                    float* dst = il + wid * g.plane + j * 64;
 #pragma unroll 1
-                    for (int cl = wid; cl < ci_rows; cl += kWgxWaves) {
-                        const bool live = xo >= 0 && ci0 + cl < g.cin;
-                        glds4(live ? in + xo + (long)(ci0 + cl) * g.hw : zero, il + cl * g.plane + j * 64);
+                    for (int cl = wid; cl < ci_live; cl += kWgxWaves) {
+                        glds4(reinterpret_cast<const float*>(src), dst);
+                        src += step;
+                        dst += kWgxWaves * g.plane;
                     }
                 }
             }
@@ -1115,24 +1136,35 @@ __global__ __launch_bounds__(kWgxWaves * 64) void conv_wgrad_x3_kernel(WgxGeom g
                     const f32x4* src = reinterpret_cast<const f32x4*>(il + b_off + ty * g.rowp);
                     const f32x4 w0 = src[0], w1 = src[1], w2 = src[2], w3 = src[3];
                     const float e[10] = {w0[3], w1[0], w1[1], w1[2], w1[3], w2[0], w2[1], w2[2], w2[3], w3[0]};   // e[k] = pixel c0-1+k
-                    unsigned P[3][5], Q[3][4];      // [limb][dword]: P_k = (e[2k], e[2k+1]) odd pairing, Q_k = (e[2k+1], e[2k+2])
+                    // B operands as ready register quads: bq[tx][limb]; with e[k] packed in pairs, tx = 0 takes the
+                    // odd pairing P_0..P_3 = (e0,e1)..(e6,e7), tx = 2 its shift P_1..P_4, tx = 1 the even pairing
+                    // Q_0..Q_3 = (e1,e2)..(e7,e8)
+                    u32x4 bq[3][3];
                     float res[10];
 #pragma unroll
                     for (int k = 0; k < 10; ++k) res[k] = e[k];
 #pragma unroll
                     for (int lv = 0; lv < 3; ++lv) {
+                        unsigned P[5];
 #pragma unroll
-                        for (int k = 0; k < 5; ++k) P[lv][k] = cvt_pk_bf16(res[2 * k], res[2 * k + 1]);
+                        for (int k = 0; k < 5; ++k) P[k] = cvt_pk_bf16(res[2 * k], res[2 * k + 1]);
 #pragma unroll
-                        for (int k = 0; k < 4; ++k) Q[lv][k] = cvt_pk_bf16(res[2 * k + 1], res[2 * k + 2]);
+                        for (int k = 0; k < 4; ++k) bq[1][lv][k] = cvt_pk_bf16(res[2 * k + 1], res[2 * k + 2]);
+                        bq[0][lv] = (u32x4){P[0], P[1], P[2], P[3]};
+                        bq[2][lv] = (u32x4){P[1], P[2], P[3], P[4]};
                         if (lv < 2) {
 #pragma unroll
                             for (int k = 0; k < 5; ++k) {
-                                res[2 * k] -= __uint_as_float(P[lv][k] << 16);
-                                res[2 * k + 1] -= __uint_as_float(P[lv][k] & 0xffff0000u);
+                                res[2 * k] -= __uint_as_float(P[k] << 16);
+                                res[2 * k + 1] -= __uint_as_float(P[k] & 0xffff0000u);
                             }
                         }
                     }
+                    // pin the operands here: otherwise the quads are re-assembled in front of every MFMA group
+#pragma unroll
+                    for (int tx = 0; tx < 3; ++tx)
+#pragma unroll
+                        for (int lv = 0; lv < 3; ++lv) asm volatile("" : "+v"(bq[tx][lv]));
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int gq = 0; gq < NPROD; ++gq) {
@@ -1140,16 +1172,11 @@ __global__ __launch_bounds__(kWgxWaves * 64) void conv_wgrad_x3_kernel(WgxGeom g
                         const int pb = NPROD == 9 ? kPairB[(gq + 6) % 9] : kPairB[gq];
 #pragma unroll
                         for (int tx = 0; tx < KW; ++tx) {
-                            // tx = 0: pixels c0-1.. -> P_0..P_3; tx = 1: c0.. -> Q_0..Q_3; tx = 2: c0+1.. -> P_1..P_4
-                            u32x4 bq;
-                            if (KW == 1 || tx == 1) bq = (u32x4){Q[pb][0], Q[pb][1], Q[pb][2], Q[pb][3]};
-                            else if (tx == 0) bq = (u32x4){P[pb][0], P[pb][1], P[pb][2], P[pb][3]};
-                            else bq = (u32x4){P[pb][1], P[pb][2], P[pb][3], P[pb][4]};
-                            const bf16x8 bv = __builtin_bit_cast(bf16x8, bq);
+                            const bf16x8 bv = __builtin_bit_cast(bf16x8, bq[KW == 1 ? 1 : tx][pb]);
 #pragma unroll
                             for (int i = 0; i < MT; ++i) {
                                 acc[ty][tx][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                                        __builtin_bit_cast(bf16x8, al[i][pa]), bv, acc[ty][tx][i], 0, 0, 0);
+                                    __builtin_bit_cast(bf16x8, al[i][pa]), bv, acc[ty][tx][i], 0, 0, 0);
                             }
                         }
                     }
