@@ -354,15 +354,23 @@ __device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {      // v_
     return __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){lo, hi}, bf16x2));
 }
 
+// a - b as one v_sub_f32: hipcc otherwise pairs the residual subtractions into v_pk_add_f32, which costs
+// ~15 cycles beside MFMAs on gfx950 (measured) against ~4 for the plain instruction
+__device__ __forceinline__ float fsub(float a, float b) {
+    float r;
+    asm("v_sub_f32_e32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
 // x[0..7] -> three packed bf16x8 limbs with x = h + m + l exactly
 __device__ __forceinline__ void split3(const float (&x)[8], u32x4& h, u32x4& m, u32x4& l) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const float x0 = x[2 * q], x1 = x[2 * q + 1];
         const unsigned hp = cvt_pk_bf16(x0, x1);
-        const float r0 = x0 - __uint_as_float(hp << 16), r1 = x1 - __uint_as_float(hp & 0xffff0000u);
+        const float r0 = fsub(x0, __uint_as_float(hp << 16)), r1 = fsub(x1, __uint_as_float(hp & 0xffff0000u));
         const unsigned mp = cvt_pk_bf16(r0, r1);
-        const float s0 = r0 - __uint_as_float(mp << 16), s1 = r1 - __uint_as_float(mp & 0xffff0000u);
+        const float s0 = fsub(r0, __uint_as_float(mp << 16)), s1 = fsub(r1, __uint_as_float(mp & 0xffff0000u));
         h[q] = hp;
         m[q] = mp;
         l[q] = cvt_pk_bf16(s0, s1);
@@ -592,9 +600,9 @@ __global__ __launch_bounds__(kXWaves * 64) void conv_fwd_x3_kernel(Geom g, const
                         const int q = gq - 2;
                         const float x0 = raw[j][2 * q], x1 = raw[j][2 * q + 1];
                         unsigned hp = cvt_pk_bf16(x0, x1);
-                        const float r0 = x0 - __uint_as_float(hp << 16), r1 = x1 - __uint_as_float(hp & 0xffff0000u);
+                        const float r0 = fsub(x0, __uint_as_float(hp << 16)), r1 = fsub(x1, __uint_as_float(hp & 0xffff0000u));
                         unsigned mp = cvt_pk_bf16(r0, r1);
-                        const float s0 = r0 - __uint_as_float(mp << 16), s1 = r1 - __uint_as_float(mp & 0xffff0000u);
+                        const float s0 = fsub(r0, __uint_as_float(mp << 16)), s1 = fsub(r1, __uint_as_float(mp & 0xffff0000u));
                         unsigned lp = cvt_pk_bf16(s0, s1);
                         // pin the split to this group (otherwise it is sunk to its first use in the next step)
                         asm volatile("" : "+v"(hp), "+v"(mp), "+v"(lp));
@@ -647,22 +655,53 @@ __global__ __launch_bounds__(kXWaves * 64) void conv_fwd_x3_kernel(Geom g, const
         if (S + 1 < s_hi) step(S + 1, lb1, lb0);
     }
 
-    // ---- epilogue: D row = channel (kq*4 + r), column = pixel (lm)
+    // ---- epilogue: D row = channel (kq*4 + r), column = pixel (lm).  With one workgroup per CU nothing hides
+    //      this code, so the common case (own the whole K range, overwrite) is kept to one address add and one
+    //      store per value: lane mask per pixel tile, channel-bound checks only in the last channel block.
+    const bool add_bias = bias != nullptr && blockIdx.z == 0;
+    float bv[COT][4];
 #pragma unroll
-    for (int i = 0; i < COT; ++i) {
+    for (int i = 0; i < COT; ++i)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int co = co0 + i * 16 + kq * 4 + r;
-            if (co >= g.cout) continue;
-            const float bv = (bias && blockIdx.z == 0) ? bias[co] : 0.f;
+            bv[i][r] = (add_bias && co < g.cout) ? bias[co] : 0.f;
+        }
+    if (g.ksplit == 1 && !accumulate) {
+        const bool full = co0 + CO_BLK <= g.cout;
 #pragma unroll
-            for (int j = 0; j < PT; ++j)
-                if (pix_g[j] >= 0) {
-                    float* o = out + pix_g[j] + (long)co * g.hw;
-                    const float v = acc[i][j][r] + bv;
-                    if (g.ksplit > 1) atomicAdd(o, v);
-                    else *o = accumulate ? *o + v : v;
-                }
+        for (int j = 0; j < PT; ++j) {
+            if (pix_g[j] < 0) continue;
+            float* o = out + pix_g[j] + (long)(co0 + kq * 4) * g.hw;
+            if (full) {
+#pragma unroll
+                for (int i = 0; i < COT; ++i)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o[(long)(i * 16 + r) * g.hw] = acc[i][j][r] + bv[i][r];
+            } else {
+#pragma unroll
+                for (int i = 0; i < COT; ++i)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (co0 + i * 16 + kq * 4 + r < g.cout) o[(long)(i * 16 + r) * g.hw] = acc[i][j][r] + bv[i][r];
+            }
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < COT; ++i) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int co = co0 + i * 16 + kq * 4 + r;
+                if (co >= g.cout) continue;
+#pragma unroll
+                for (int j = 0; j < PT; ++j)
+                    if (pix_g[j] >= 0) {
+                        float* o = out + pix_g[j] + (long)co * g.hw;
+                        const float v = acc[i][j][r] + bv[i][r];
+                        if (g.ksplit > 1) atomicAdd(o, v);
+                        else *o += v;
+                    }
+            }
         }
     }
 }
@@ -1118,24 +1157,30 @@ __global__ __launch_bounds__(kWgxWaves * 64) void conv_wgrad_x3_kernel(WgxGeom g
                 const int r = run >> runs_shift, c0 = (run - (r << runs_shift)) * 8;
                 const int a_off = a_row + run * 8;
                 const int b_off = b_row + r * g.rowp + c0;                 // floats c0-4 .. c0+11 of row r + ty
-                // ---- A: dOut fragments of the live co tiles, split into limbs
+                // ---- issue every LDS read of the k-step first: the first input row's window, then the dOut
+                //      fragments of all co tiles (8 values each); the splits below consume them as they arrive
+                const float* brow = il + b_off;
+                f32x4 w1 = *reinterpret_cast<const f32x4*>(brow + 4), w2 = *reinterpret_cast<const f32x4*>(brow + 8);
+                float wl = brow[3], wr = brow[12];                          // pixels c0-1 and c0+8
+                f32x4 ar[MT][2];
+#pragma unroll
+                for (int i = 0; i < MT; ++i) {
+                    const f32x4* src = reinterpret_cast<const f32x4*>(dl + a_off + i * 16 * DSO);
+                    ar[i][0] = src[0];
+                    ar[i][1] = src[1];
+                }
+                __builtin_amdgcn_sched_barrier(0);
                 u32x4 al[MT][3];
 #pragma unroll
                 for (int i = 0; i < MT; ++i) {
-                    {
-                        const f32x4* src = reinterpret_cast<const f32x4*>(dl + a_off + i * 16 * DSO);
-                        const f32x4 v0 = src[0], v1 = src[1];
-                        const float x[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-                        split3(x, al[i][0], al[i][1], al[i][2]);
-                        __builtin_amdgcn_sched_barrier(0);    // one tile's raw values at a time (register budget)
-                    }
+                    const float x[8] = {ar[i][0][0], ar[i][0][1], ar[i][0][2], ar[i][0][3],
+                                        ar[i][1][0], ar[i][1][1], ar[i][1][2], ar[i][1][3]};
+                    split3(x, al[i][0], al[i][1], al[i][2]);
                 }
 #pragma unroll
                 for (int ty = 0; ty < KH; ++ty) {
                     // ---- B: the 10-pixel window c0-1 .. c0+8 of input row r + ty, split once for the three tx
-                    const f32x4* src = reinterpret_cast<const f32x4*>(il + b_off + ty * g.rowp);
-                    const f32x4 w0 = src[0], w1 = src[1], w2 = src[2], w3 = src[3];
-                    const float e[10] = {w0[3], w1[0], w1[1], w1[2], w1[3], w2[0], w2[1], w2[2], w2[3], w3[0]};   // e[k] = pixel c0-1+k
+                    const float e[10] = {wl, w1[0], w1[1], w1[2], w1[3], w2[0], w2[1], w2[2], w2[3], wr};   // e[k] = pixel c0-1+k
                     // B operands as ready register quads: bq[tx][limb]; with e[k] packed in pairs, tx = 0 takes the
                     // odd pairing P_0..P_3 = (e0,e1)..(e6,e7), tx = 2 its shift P_1..P_4, tx = 1 the even pairing
                     // Q_0..Q_3 = (e1,e2)..(e7,e8)
@@ -1155,8 +1200,8 @@ __global__ __launch_bounds__(kWgxWaves * 64) void conv_wgrad_x3_kernel(WgxGeom g
                         if (lv < 2) {
 #pragma unroll
                             for (int k = 0; k < 5; ++k) {
-                                res[2 * k] -= __uint_as_float(P[k] << 16);
-                                res[2 * k + 1] -= __uint_as_float(P[k] & 0xffff0000u);
+                                res[2 * k] = fsub(res[2 * k], __uint_as_float(P[k] << 16));
+                                res[2 * k + 1] = fsub(res[2 * k + 1], __uint_as_float(P[k] & 0xffff0000u));
                             }
                         }
                     }
@@ -1165,6 +1210,14 @@ __global__ __launch_bounds__(kWgxWaves * 64) void conv_wgrad_x3_kernel(WgxGeom g
                     for (int tx = 0; tx < 3; ++tx)
 #pragma unroll
                         for (int lv = 0; lv < 3; ++lv) asm volatile("" : "+v"(bq[tx][lv]));
+                    // the next row's window is fetched while this row's MFMAs run (its registers are free now)
+                    if (ty + 1 < KH) {
+                        const float* nrow = brow + (ty + 1) * g.rowp;
+                        w1 = *reinterpret_cast<const f32x4*>(nrow + 4);
+                        w2 = *reinterpret_cast<const f32x4*>(nrow + 8);
+                        wl = nrow[3];
+                        wr = nrow[12];
+                    }
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int gq = 0; gq < NPROD; ++gq) {
