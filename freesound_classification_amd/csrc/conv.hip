@@ -388,14 +388,17 @@ __global__ __launch_bounds__(kXWaves * 64) void conv_fwd_x3_kernel(Geom g, const
     constexpr int TAPS = KH * KW;
     constexpr int CO_BLK = COT * 16;
     constexpr int PADH = KH / 2, PADW = KW / 2;
+    constexpr int NCH = TAPS == 1 ? 2 : 1;          // 32-channel groups per K chunk: a chunk must span >= 2 steps
+    constexpr int KCH = kXChunk * NCH;              // channels per chunk
+    constexpr int SPC = TAPS * NCH;                 // steps per full chunk
     constexpr int WUNITS = COT * 3;                 // 1 KB fragment images per step
     constexpr int WSLOT_F = WUNITS * 256;           // floats per ring slot
     constexpr int NWQ = (WUNITS + kXWaves - 1) / kXWaves;
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* const wring = smem;                                  // 3 slots
-    float* const ibase = smem + 3 * WSLOT_F;                    // 2 stages of [32][plane]
-    const int istage = kXChunk * g.plane;
+    float* const ibase = smem + 3 * WSLOT_F;                    // 2 stages of [KCH][plane]
+    const int istage = KCH * g.plane;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -454,8 +457,8 @@ __global__ __launch_bounds__(kXWaves * 64) void conv_fwd_x3_kernel(Geom g, const
     const int nchunks = g.x_nfull + (g.x_tail_oct ? 1 : 0);
     const int c_lo = (int)((long)nchunks * blockIdx.z / g.ksplit);
     const int c_hi = (int)((long)nchunks * (blockIdx.z + 1) / g.ksplit);
-    const int s_lo = c_lo * TAPS;                                    // chunks below the tail are all full
-    const int s_hi = c_hi == nchunks ? g.x_steps : c_hi * TAPS;
+    const int s_lo = c_lo * SPC;                                     // chunks below the tail are all full
+    const int s_hi = c_hi == nchunks ? g.x_steps : c_hi * SPC;
 
     // ---- DMA issue.  Weights: unit u of a step goes to wave u % 8.  Input: channel kk of a chunk to wave kk % 8.
     const float* zero = g_zero16;
@@ -469,8 +472,8 @@ __global__ __launch_bounds__(kXWaves * 64) void conv_fwd_x3_kernel(Geom g, const
         }
     };
     auto issue_i = [&](int c) {
-        const int ci0 = c * kXChunk;
-        const int nch = c < g.x_nfull ? kXChunk : g.x_tail_oct * 8;     // staged channels of this chunk
+        const int ci0 = c * KCH;
+        const int nch = c < g.x_nfull ? KCH : g.x_tail_oct * 8;         // staged channels of this chunk
         float* dst = ibase + (c & 1) * istage;
         for (int kk = wid; kk < nch; kk += kXWaves) {
             const float* src = in + (long)(ci0 + kk) * g.hw;
@@ -486,7 +489,7 @@ __global__ __launch_bounds__(kXWaves * 64) void conv_fwd_x3_kernel(Geom g, const
             }
         }
     };
-    // Outstanding-DMA bookkeeping: a wave issues >= NWLO weight units per step and exactly 4 * x_npt input
+    // Outstanding-DMA bookkeeping: a wave issues >= NWLO weight units per step and exactly (KCH / 8) * x_npt input
     // instructions per full chunk.  At the barrier of step S the weights W(S) (issued two steps ago) must have
     // landed; younger and allowed to stay in flight are W(S+1) and an input box issued in the last two steps that
     // the coming step does not read yet.  Counting less than what is really in flight only waits longer.
@@ -495,10 +498,10 @@ __global__ __launch_bounds__(kXWaves * 64) void conv_fwd_x3_kernel(Geom g, const
 #define FSC_VMW(k) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(k) : "memory")
         if (input_in_flight) {
             switch (g.x_npt) {
-                case 3: FSC_VMW(NWLO + 12); break;
-                case 4: FSC_VMW(NWLO + 16); break;
-                case 5: FSC_VMW(NWLO + 20); break;
-                case 6: FSC_VMW(NWLO + 24); break;
+                case 3: FSC_VMW(NWLO + 3 * (KCH / 8)); break;
+                case 4: FSC_VMW(NWLO + 4 * (KCH / 8)); break;
+                case 5: FSC_VMW(NWLO + 5 * (KCH / 8)); break;
+                case 6: FSC_VMW(NWLO + 6 * (KCH / 8)); break;
                 default: FSC_VMW(NWLO); break;
             }
         } else {
@@ -511,14 +514,15 @@ __global__ __launch_bounds__(kXWaves * 64) void conv_fwd_x3_kernel(Geom g, const
     //      b_base is this lane's pointer to (octet, tap) inside the staged box.
     auto b_base = [&](int c, int s) -> const float* {
         const float* st = ibase + (c & 1) * istage;
-        if (c < g.x_nfull) {                               // full chunk: step = tap, lane group = octet
-            const int ty = s / KW, tx = s - ty * KW;       // wave-uniform
-            return st + kq * 8 * g.plane + ty * g.cols + tx;
+        if (c < g.x_nfull) {                               // full chunk: step = (tap, 32-channel group), lane group = octet
+            const int tap = s / NCH, sub = s - tap * NCH;  // wave-uniform
+            const int ty = tap / KW, tx = tap - ty * KW;
+            return st + (sub * 4 + kq) * 8 * g.plane + ty * g.cols + tx;
         }
         const int noct = g.x_tail_oct;
         int gi = 4 * s + kq;
         if (gi >= TAPS * noct) gi = 0;                     // its weights are zero
-        const int tap = noct == 2 ? gi >> 1 : noct == 1 ? gi : fdiv(gi, 1.0f / 3.0f);
+        const int tap = TAPS == 1 ? 0 : fdiv(gi, 1.0f / (float)noct);
         const int oct = gi - tap * noct;
         const int ty = fdiv(tap, 1.0f / (float)KW), tx = tap - ty * KW;
         return st + oct * 8 * g.plane + ty * g.cols + tx;
@@ -544,7 +548,7 @@ __global__ __launch_bounds__(kXWaves * 64) void conv_fwd_x3_kernel(Geom g, const
 
     // incremental step state (all wave-uniform)
     int c = c_lo, sc = 0;                                            // chunk of step S and step inside it
-    int nst = c < g.x_nfull ? TAPS : g.x_tail_steps;
+    int nst = c < g.x_nfull ? SPC : g.x_tail_steps;
     int slot = 0;                                                    // ring slot of W(S)
     int input_age = 99;                                              // steps since a full-chunk input box was issued
 
@@ -645,7 +649,7 @@ __global__ __launch_bounds__(kXWaves * 64) void conv_fwd_x3_kernel(Geom g, const
         // advance
         wsrc += WSLOT_F;
         slot = slot == 2 ? 0 : slot + 1;
-        if (cn != c) nst = cn < g.x_nfull ? TAPS : g.x_tail_steps;
+        if (cn != c) nst = cn < g.x_nfull ? SPC : g.x_tail_steps;
         c = cn;
         sc = sn;
     };
@@ -710,7 +714,7 @@ __global__ __launch_bounds__(kXWaves * 64) void conv_fwd_x3_kernel(Geom g, const
 // packed[co block][step][channel tile][limb][lane][8 bf16]; lane = (kq, m), its 8 values are the channels
 // of octet `oct` at tap `tap` where (tap, oct) = divmod(4 * step_in_chunk + kq, octets of the chunk)
 __global__ void pack_x3_kernel(const float* __restrict__ w, unsigned short* __restrict__ packed, int c_out, int c_in,
-                               int taps, int cot, int co_blocks, int nfull, int tail_oct, int steps, int dgrad) {
+                               int taps, int cot, int co_blocks, int nfull, int tail_oct, int steps, int nch, int dgrad) {
     const long total = (long)co_blocks * steps * cot * 512;
     for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
         const int e = (int)(idx & 7), lane = (int)((idx >> 3) & 63);
@@ -718,14 +722,15 @@ __global__ void pack_x3_kernel(const float* __restrict__ w, unsigned short* __re
         const int i = (int)(rest % cot); rest /= cot;
         const int S = (int)(rest % steps);
         const int cb = (int)(rest / steps);
-        const int c = S < nfull * taps ? S / taps : nfull;
-        const int s = S - c * taps;
-        const int noct = c < nfull ? 4 : tail_oct;
+        const int spc = taps * nch;                          // steps per full chunk of 32 * nch channels
+        const int c = S < nfull * spc ? S / spc : nfull;
+        const int s = S - c * spc;
+        const int noct = c < nfull ? 4 * nch : tail_oct;
         const int gi = 4 * s + (lane >> 4);
         float v = 0.f;
         if (gi < taps * noct) {
             const int tap = gi / noct, oct = gi - tap * noct;
-            const int k = c * kXChunk + oct * 8 + e, m = (cb * cot + i) * 16 + (lane & 15);
+            const int k = c * kXChunk * nch + oct * 8 + e, m = (cb * cot + i) * 16 + (lane & 15);
             const int co = dgrad ? k : m, ci = dgrad ? m : k;
             if (co < c_out && ci < c_in) v = w[((long)co * c_in + ci) * taps + (dgrad ? taps - 1 - tap : tap)];
         }
@@ -1335,14 +1340,18 @@ long tile_penalty(int tiles_per_block) {
 }
 
 
-constexpr int kX3PT = 2;
-
-// tiling of conv_fwd_x3_kernel; false when the shape does not suit it (the native kernel takes over)
-bool plan_fwd_x3(const fsc_conv_desc& d, int dgrad, int nprod, FwdPlan* out) {
+// tiling of conv_fwd_x3_kernel with PT pixel tiles per wave; false when the shape does not suit it
+bool plan_fwd_x3_pt(const fsc_conv_desc& d_in, int dgrad, int nprod, int pt, FwdPlan* out) {
     FwdPlan p{};
     Geom& g = p.g;
+    fsc_conv_desc d = d_in;
     const int taps = d.kh * d.kw;
-    if (taps == 1) return false;
+    if (taps == 1) {                 // no halo: every (n, c) plane is one row of h*w pixels
+        d.w = d.h * d.w;
+        d.h = 1;
+    }
+    const int nch = taps == 1 ? 2 : 1;                   // 32-channel groups per K chunk (kernel NCH)
+    const int kch = kXChunk * nch;
     g.n = d.n; g.h = d.h; g.w = d.w; g.hw = (long)d.h * d.w;
     g.cin = dgrad ? d.c_out : d.c_in;
     g.cout = dgrad ? d.c_in : d.c_out;
@@ -1359,14 +1368,14 @@ bool plan_fwd_x3(const fsc_conv_desc& d, int dgrad, int nprod, FwdPlan* out) {
     }
     p.cot = best_cot;
     p.co_blocks = best_blocks;
-    p.pt = kX3PT;
+    p.pt = pt;
     p.x3 = nprod;
     g.m_pad = best_blocks * best_cot * 16;
     g.flat = 0;
     const int pix_cap = kXWaves * p.pt * 16;
     const size_t lds_total = 160 * 1024;
     const size_t ring = (size_t)3 * p.cot * 3 * 1024;
-    int cap_pos = (int)((lds_total - ring) / (2 * kXChunk * sizeof(float))) - 4;
+    int cap_pos = (int)((lds_total - ring) / (2 * kch * sizeof(float))) - 4;
     if (cap_pos > 64 * kXNptMax - 4) cap_pos = 64 * kXNptMax - 4;
     long best_cost = -1;
     int bnb = 1, bth = 1, btw = 1;
@@ -1394,19 +1403,19 @@ bool plan_fwd_x3(const fsc_conv_desc& d, int dgrad, int nprod, FwdPlan* out) {
     g.npix = bnb * bth * btw; g.npos = bnb * g.rows * g.cols;
     g.tiles_n = fsc::ceil_div(d.n, bnb); g.tiles_h = fsc::ceil_div(d.h, bth); g.tiles_w = fsc::ceil_div(d.w, btw);
     p.grid_x = (long)g.tiles_n * g.tiles_h * g.tiles_w;
-    // fewer than ~70 % live MFMA columns: the native kernel's 128-pixel boxes fit such shapes better
+    // fewer than ~70 % live MFMA columns: smaller boxes (PT = 1, then the native kernel) fit such shapes better
     if ((double)d.n * g.hw < 0.7 * (double)p.grid_x * pix_cap) return false;
     g.plane = g.npos;
     while (g.plane % 4 != 2) ++g.plane;              // 8 * plane == 16 (mod 32): lane groups kq, kq+1 on disjoint banks
     g.x_npt = fsc::ceil_div(g.plane, 64);
     if (g.x_npt > kXNptMax) return false;
-    const int rem = g.cin % kXChunk;
-    g.x_nfull = g.cin / kXChunk + (rem > 24 ? 1 : 0);
-    g.x_tail_oct = (rem > 0 && rem <= 24) ? fsc::ceil_div(rem, 8) : 0;
+    const int rem = g.cin % kch;
+    g.x_nfull = g.cin / kch + (rem > kch - 8 ? 1 : 0);
+    g.x_tail_oct = (rem > 0 && rem <= kch - 8) ? fsc::ceil_div(rem, 8) : 0;
     g.x_tail_steps = fsc::ceil_div(taps * g.x_tail_oct, 4);
-    g.x_steps = g.x_nfull * taps + g.x_tail_steps;
-    g.k_pad = (g.x_nfull + (g.x_tail_oct ? 1 : 0)) * kXChunk;
-    p.kc = kXChunk;
+    g.x_steps = g.x_nfull * taps * nch + g.x_tail_steps;
+    g.k_pad = (g.x_nfull + (g.x_tail_oct ? 1 : 0)) * kch;
+    p.kc = kch;
     g.ksplit = 1;
     {
         const long wgs = p.grid_x * p.co_blocks;
@@ -1418,10 +1427,17 @@ bool plan_fwd_x3(const fsc_conv_desc& d, int dgrad, int nprod, FwdPlan* out) {
             if (ks > 1) g.ksplit = (int)ks;
         }
     }
-    p.lds_bytes = ring + (size_t)2 * kXChunk * g.plane * sizeof(float);
+    p.lds_bytes = ring + (size_t)2 * kch * g.plane * sizeof(float);
     if (p.lds_bytes > lds_total) return false;
     *out = p;
     return true;
+}
+
+// 256-pixel tiles (two pixel tiles per wave) where they fit, else 128-pixel tiles (1x1 convolutions stage
+// 64-channel chunks and always take the small tile)
+bool plan_fwd_x3(const fsc_conv_desc& d, int dgrad, int nprod, FwdPlan* out) {
+    if (d.kh * d.kw > 1 && plan_fwd_x3_pt(d, dgrad, nprod, 2, out)) return true;
+    return plan_fwd_x3_pt(d, dgrad, nprod, 1, out);
 }
 
 bool plan_fwd_f32(const fsc_conv_desc& d, int dgrad, FwdPlan* out);
@@ -1522,12 +1538,24 @@ bool plan_fwd_f32(const fsc_conv_desc& d, int dgrad, FwdPlan* out) {
     return true;
 }
 
+template <int KH, int KW, int COT, int PT, int NPROD>
+void launch_x3_pt(const FwdPlan& p, dim3 grid, const float* in, const float* packed, const float* bias, float* out,
+                  int accumulate, hipStream_t st) {
+    auto kern = conv_fwd_x3_kernel<KH, KW, COT, PT, NPROD>;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes);
+    hipLaunchKernelGGL(kern, grid, dim3(kXWaves * 64), p.lds_bytes, st, p.g, in, packed, bias, out, accumulate);
+}
+
 template <int KH, int KW, int COT, int NPROD>
 void launch_x3(const FwdPlan& p, dim3 grid, const float* in, const float* packed, const float* bias, float* out,
                int accumulate, hipStream_t st) {
-    auto kern = conv_fwd_x3_kernel<KH, KW, COT, kX3PT, NPROD>;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes);
-    hipLaunchKernelGGL(kern, grid, dim3(kXWaves * 64), p.lds_bytes, st, p.g, in, packed, bias, out, accumulate);
+    if constexpr (KH * KW > 1) {
+        if (p.pt == 2) {
+            launch_x3_pt<KH, KW, COT, 2, NPROD>(p, grid, in, packed, bias, out, accumulate, st);
+            return;
+        }
+    }
+    launch_x3_pt<KH, KW, COT, 1, NPROD>(p, grid, in, packed, bias, out, accumulate, st);
 }
 
 template <int KH, int KW, int COT>
@@ -1539,13 +1567,11 @@ int launch_fwd_cot(const FwdPlan& p, const float* in, const float* packed, const
         hipError_t e = hipMemsetAsync(out, 0, bytes, st);
         FSC_CHECK_ARG(e == hipSuccess, "fsc_conv_fwd: memset failed: %s", hipGetErrorString(e));
     }
-    if constexpr (KH * KW > 1) {
-        if (p.x3) {
-            if (p.x3 == 6) launch_x3<KH, KW, COT, 6>(p, grid, in, packed, bias, out, accumulate, st);
-            else launch_x3<KH, KW, COT, 9>(p, grid, in, packed, bias, out, accumulate, st);
-            FSC_LAUNCH_CHECK("fsc_conv_fwd(x3)");
-            return 0;
-        }
+    if (p.x3) {
+        if (p.x3 == 6) launch_x3<KH, KW, COT, 6>(p, grid, in, packed, bias, out, accumulate, st);
+        else launch_x3<KH, KW, COT, 9>(p, grid, in, packed, bias, out, accumulate, st);
+        FSC_LAUNCH_CHECK("fsc_conv_fwd(x3)");
+        return 0;
     }
     if (KH * KW == 9 && p.kc == 4) {
         auto kern = conv_fwd_kernel<KH, KW, COT, fwd_pt(KH * KW), (KH * KW == 9) ? 4 : fwd_kc(KH * KW)>;
@@ -1849,7 +1875,7 @@ int fsc_conv_pack_weights(const fsc_conv_desc* d, const float* weight, int dgrad
         if (xb > 8192) xb = 8192;
         hipLaunchKernelGGL(pack_x3_kernel, dim3((unsigned)xb), dim3(256), 0, fsc::as_stream(stream), weight,
                            reinterpret_cast<unsigned short*>(packed), d->c_out, d->c_in, d->kh * d->kw, p.cot, p.co_blocks,
-                           p.g.x_nfull, p.g.x_tail_oct, p.g.x_steps, dgrad);
+                           p.g.x_nfull, p.g.x_tail_oct, p.g.x_steps, d->kh * d->kw == 1 ? 2 : 1, dgrad);
         FSC_LAUNCH_CHECK("fsc_conv_pack_weights(x3)");
         return 0;
     }

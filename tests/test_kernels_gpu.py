@@ -120,6 +120,10 @@ X3_CASES = [
     (3, 41, 80, 1, 512, 1, 3),
     (16, 337, 100, 4, 13, 3, 3),
     (2, 32, 48, 16, 16, 3, 3),
+    (1, 64, 64, 8, 16, 3, 3),          # 128-pixel tile (one pixel tile per wave)
+    (2, 100, 100, 16, 43, 1, 1),       # 1x1: 64-channel chunks, remainder 36 channels
+    (2, 200, 150, 9, 30, 1, 1),        # 1x1: remainder of one octet
+    (4, 64, 48, 1, 256, 1, 1),         # 1-d k1
 ]
 
 
