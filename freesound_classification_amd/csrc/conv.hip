@@ -48,6 +48,7 @@ struct Geom {
     int x_tail_steps;         // ceil(taps * x_tail_oct / 4)
     int x_steps;              // x_nfull * taps + x_tail_steps
     int x_npt;                // input DMA instructions per staged channel = ceil(plane / 64)
+    int x_coblk;              // channel blocks (work items = pixel tiles x channel blocks, walked by persistent workgroups)
 };
 
 // Forward / dgrad tile configuration per kernel size: 128 pixels per workgroup (4 waves x 2 pixel
@@ -404,48 +405,100 @@ __global__ __launch_bounds__(kXWaves * 64) void conv_fwd_x3_kernel(Geom g, const
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lm = lane & 15, kq = lane >> 4;
 
-    int t = blockIdx.x;
-    const int twi = t % g.tiles_w; t /= g.tiles_w;
-    const int thi = t % g.tiles_h; t /= g.tiles_h;
-    const int n0 = t * g.nb;
-    const int h0 = thi * g.th, w0 = twi * g.tw;
-    const int co0 = blockIdx.y * CO_BLK;
+    // ---- tile-invariant decode.  The workgroup is persistent: it walks the work items (pixel tile, channel
+    //      block) = divmod(item, co_blocks) for item = blockIdx.x, blockIdx.x + gridDim.x, ... and keeps ONE
+    //      stream of MFMA steps and DMAs running across them (the next item's weights and first input box are
+    //      fetched during the current item's last steps), so only the output stores interrupt the MFMA stream.
+    //      Neighbouring workgroups hold the channel blocks of the same pixel tile at the same time (L2 reuse).
 
-    // ---- per-lane input DMA plan: position pos = t*64 + lane of the staged box, the same for every channel
     const float inv_per = 1.0f / (float)(g.rows * g.cols), inv_cols = 1.0f / (float)g.cols;
     const float inv_tw = 1.0f / (float)g.tw, inv_thw = 1.0f / (float)(g.th * g.tw);
-    int pos_off[kXNptMax];       // offset inside the input tensor relative to channel 0; -1 = zero fill
+    int pos_dec[kXNptMax];       // staged position q*64 + lane as (image << 20 | row << 10 | col); -1 = outside the box
 #pragma unroll
     for (int q = 0; q < kXNptMax; ++q) {
         const int pos = q * 64 + lane;
-        pos_off[q] = -1;
+        pos_dec[q] = -1;
         if (pos < g.npos) {
             const int per = g.rows * g.cols;
             const int b = fdiv(pos, inv_per), rem = pos - b * per;
             const int rr = fdiv(rem, inv_cols), cc = rem - rr * g.cols;
-            const int gh = h0 + rr - PADH, gw = w0 + cc - PADW;
-            if (n0 + b < g.n && gh >= 0 && gh < g.h && gw >= 0 && gw < g.w)
-                pos_off[q] = (int)(((long)(n0 + b) * g.cin) * g.hw + (long)gh * g.w + gw);
+            pos_dec[q] = (b << 20) | (rr << 10) | cc;
         }
     }
-
-    // ---- this lane's output pixels
-    int pix_l[PT];
-    long pix_g[PT];
+    int pix_l[PT], pix_dec[PT];  // LDS offset of this lane's pixels inside a staged channel; (image, row, col) in the box
 #pragma unroll
     for (int pt = 0; pt < PT; ++pt) {
         const int p = (wid * PT + pt) * 16 + lm;
         pix_l[pt] = 0;
-        pix_g[pt] = -1;
+        pix_dec[pt] = -1;
         if (p < g.npix) {
             const int per = g.th * g.tw;
             const int b = fdiv(p, inv_thw), rem = p - b * per;
             const int r = fdiv(rem, inv_tw), c = rem - r * g.tw;
             pix_l[pt] = (b * g.rows + r) * g.cols + c;
-            if (n0 + b < g.n && h0 + r < g.h && w0 + c < g.w)
-                pix_g[pt] = (long)(n0 + b) * g.cout * g.hw + (long)(h0 + r) * g.w + (w0 + c);
+            pix_dec[pt] = (b << 20) | (r << 10) | c;
         }
     }
+    const int ntiles = g.tiles_n * g.tiles_h * g.tiles_w;
+    // per tile: input offsets of the staged positions (relative to channel 0; -1 = zero fill) ...
+    int pos_off[kXNptMax];
+    auto plan_input = [&](int tile) {
+        int t = tile;
+        const int twi = t % g.tiles_w; t /= g.tiles_w;
+        const int thi = t % g.tiles_h; t /= g.tiles_h;
+        const int n0 = t * g.nb, h0 = thi * g.th, w0 = twi * g.tw;
+#pragma unroll
+        for (int q = 0; q < kXNptMax; ++q) {
+            pos_off[q] = -1;
+            if (pos_dec[q] >= 0) {
+                const int b = pos_dec[q] >> 20, rr = (pos_dec[q] >> 10) & 1023, cc = pos_dec[q] & 1023;
+                const int gh = h0 + rr - PADH, gw = w0 + cc - PADW;
+                if (n0 + b < g.n && gh >= 0 && gh < g.h && gw >= 0 && gw < g.w)
+                    pos_off[q] = (int)(((long)(n0 + b) * g.cin) * g.hw + (long)gh * g.w + gw);
+            }
+        }
+    };
+    // ... and the output side.  The epilogue transposes each 16-channel x 16-pixel accumulator tile through a
+    // per-wave LDS scratch so that a lane owns FOUR CONSECUTIVE PIXELS of one channel (box widths are multiples
+    // of 4) and writes them with one 16-byte store: 64 lanes x 4 bytes cost the same 16 address cycles as
+    // 64 lanes x 16 bytes, and the dword version of this epilogue took 18 k cycles per tile.
+    // Lane -> channel (lane >> 2) of the tile, pixels 4 * (lane & 3) .. + 3.
+    constexpr int SCR = 20;                       // scratch row stride in floats (16 pixels + pad, 16-byte rows)
+    float* const scratch = ibase + 2 * istage + wid * (16 * SCR);
+    int quad_dec[PT];                             // (image, row, col) of this lane's first quad pixel; -1 = outside the box
+#pragma unroll
+    for (int pt = 0; pt < PT; ++pt) {
+        const int p = (wid * PT + pt) * 16 + (lane & 3) * 4;
+        quad_dec[pt] = -1;
+        if (p < g.npix) {
+            const int per = g.th * g.tw;
+            const int b = fdiv(p, inv_thw), rem = p - b * per;
+            const int r = fdiv(rem, inv_tw), c = rem - r * g.tw;
+            quad_dec[pt] = (b << 20) | (r << 10) | c;
+        }
+    }
+    long quad_g[PT];                              // offset of the quad's first pixel in the output tensor (channel 0)
+    int quad_ok[PT];                              // bit k: pixel k of the quad lies inside the image
+    auto plan_output = [&](int tile) {
+        int t = tile;
+        const int twi = t % g.tiles_w; t /= g.tiles_w;
+        const int thi = t % g.tiles_h; t /= g.tiles_h;
+        const int n0 = t * g.nb, h0 = thi * g.th, w0 = twi * g.tw;
+#pragma unroll
+        for (int pt = 0; pt < PT; ++pt) {
+            quad_g[pt] = 0;
+            quad_ok[pt] = 0;
+            if (quad_dec[pt] >= 0) {
+                const int b = quad_dec[pt] >> 20, r = (quad_dec[pt] >> 10) & 1023, c = quad_dec[pt] & 1023;
+                if (n0 + b < g.n && h0 + r < g.h) {
+                    quad_g[pt] = (long)(n0 + b) * g.cout * g.hw + (long)(h0 + r) * g.w + (w0 + c);
+                    const int left = g.w - (w0 + c), inbox = g.npix - ((wid * PT + pt) * 16 + (lane & 3) * 4);
+                    const int nv = left < inbox ? left : inbox;       // valid pixels of the quad
+                    quad_ok[pt] = nv >= 4 ? 15 : nv <= 0 ? 0 : (1 << nv) - 1;
+                }
+            }
+        }
+    };
 
     f32x4 acc[COT][PT];
 #pragma unroll
@@ -458,11 +511,14 @@ __global__ __launch_bounds__(kXWaves * 64) void conv_fwd_x3_kernel(Geom g, const
     const int c_lo = (int)((long)nchunks * blockIdx.z / g.ksplit);
     const int c_hi = (int)((long)nchunks * (blockIdx.z + 1) / g.ksplit);
     const int s_lo = c_lo * SPC;                                     // chunks below the tail are all full
-    const int s_hi = c_hi == nchunks ? g.x_steps : c_hi * SPC;
+    const int s_hi = c_hi == nchunks ? g.x_steps : c_hi * SPC;       // >= s_lo + 2 (host)
 
     // ---- DMA issue.  Weights: unit u of a step goes to wave u % 8.  Input: channel kk of a chunk to wave kk % 8.
     const float* zero = g_zero16;
-    const float* wsrc = packed + ((long)blockIdx.y * g.x_steps + s_lo) * WSLOT_F + lane * 4;    // W(S) of this lane
+    const float* const wbase0 = packed + (long)s_lo * WSLOT_F + lane * 4;    // W(s_lo) of channel block 0, this lane
+    const long wblk = (long)g.x_steps * WSLOT_F;                              // stride between channel blocks
+    const float* wsrc = wbase0;                                              // W(S) of the current item
+    const float* wnext = wbase0;                                             // W(s_lo) of the next item
     auto issue_w = [&](const float* src, int slot) {
         float* dst = wring + slot * WSLOT_F;
 #pragma unroll
@@ -471,10 +527,10 @@ __global__ __launch_bounds__(kXWaves * 64) void conv_fwd_x3_kernel(Geom g, const
             if (u < WUNITS) glds16(src + u * 256, dst + u * 256);
         }
     };
-    auto issue_i = [&](int c) {
+    auto issue_i = [&](int stage, int c) {                          // uses the current pos_off[]
         const int ci0 = c * KCH;
         const int nch = c < g.x_nfull ? KCH : g.x_tail_oct * 8;         // staged channels of this chunk
-        float* dst = ibase + (c & 1) * istage;
+        float* dst = ibase + stage * istage;
         for (int kk = wid; kk < nch; kk += kXWaves) {
             const float* src = in + (long)(ci0 + kk) * g.hw;
             const bool ch_live = ci0 + kk < g.cin;
@@ -492,7 +548,8 @@ __global__ __launch_bounds__(kXWaves * 64) void conv_fwd_x3_kernel(Geom g, const
     // Outstanding-DMA bookkeeping: a wave issues >= NWLO weight units per step and exactly (KCH / 8) * x_npt input
     // instructions per full chunk.  At the barrier of step S the weights W(S) (issued two steps ago) must have
     // landed; younger and allowed to stay in flight are W(S+1) and an input box issued in the last two steps that
-    // the coming step does not read yet.  Counting less than what is really in flight only waits longer.
+    // the coming step does not read yet.  Counting less than what is really in flight only waits longer (the
+    // output stores of the previous tile share the counter: the first barriers of a tile also wait for them).
     constexpr int NWLO = WUNITS / kXWaves;
     auto wait_weights = [&](bool input_in_flight) {
 #define FSC_VMW(k) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(k) : "memory")
@@ -511,9 +568,9 @@ __global__ __launch_bounds__(kXWaves * 64) void conv_fwd_x3_kernel(Geom g, const
     };
 
     // ---- B operand: 8 channels (this lane group's octet) of one pixel at the tap of step s of chunk c.
-    //      b_base is this lane's pointer to (octet, tap) inside the staged box.
-    auto b_base = [&](int c, int s) -> const float* {
-        const float* st = ibase + (c & 1) * istage;
+    //      b_base is this lane's pointer to (octet, tap) inside the staged box of `stage`.
+    auto b_base = [&](int stage, int c, int s) -> const float* {
+        const float* st = ibase + stage * istage;
         if (c < g.x_nfull) {                               // full chunk: step = (tap, 32-channel group), lane group = octet
             const int tap = s / NCH, sub = s - tap * NCH;  // wave-uniform
             const int ty = tap / KW, tx = tap - ty * KW;
@@ -530,13 +587,18 @@ __global__ __launch_bounds__(kXWaves * 64) void conv_fwd_x3_kernel(Geom g, const
 
     struct Limbs { u32x4 h[PT], m[PT], l[PT]; };
     Limbs lb0, lb1;
-    if (s_lo < s_hi) {
-        issue_i(c_lo);
+    const int nitems = ntiles * g.x_coblk;
+    int item = blockIdx.x;
+    if (item < nitems) {
+        const int tile = item / g.x_coblk;
+        wsrc = wbase0 + (item - tile * g.x_coblk) * wblk;
+        plan_input(tile);
+        issue_i(0, c_lo);
         issue_w(wsrc, 0);
-        if (s_lo + 1 < s_hi) issue_w(wsrc + WSLOT_F, 1);
+        issue_w(wsrc + WSLOT_F, 1);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         raw_barrier();
-        const float* il = b_base(c_lo, 0);
+        const float* il = b_base(0, c_lo, 0);
 #pragma unroll
         for (int j = 0; j < PT; ++j) {
             float raw[8];
@@ -550,23 +612,36 @@ __global__ __launch_bounds__(kXWaves * 64) void conv_fwd_x3_kernel(Geom g, const
     int c = c_lo, sc = 0;                                            // chunk of step S and step inside it
     int nst = c < g.x_nfull ? SPC : g.x_tail_steps;
     int slot = 0;                                                    // ring slot of W(S)
+    int stg = 0;                                                     // input stage of chunk c
     int input_age = 99;                                              // steps since a full-chunk input box was issued
+    bool first_step = true;                                          // the prologue has already synchronised for it
+    bool has_next = false;                                           // another item follows the current one
+    int tile_next = 0;                                               // its pixel tile
+    bool stores_pending = false;                                     // the previous tile's output stores may be in flight
 
-    // One MFMA step.  `cur` holds the split B operand of step S; the B operand of step S+1 is read from LDS
-    // and split into `nxt` between the MFMAs.  Phase i = the PT*NPROD MFMAs of channel tile i in NPROD groups
-    // of PT independent MFMAs (one limb pair each); the A fragments of tile i+1, the raw B reads and the split
-    // arithmetic are placed between the groups at compile time, and the DMA issue after phase 0, so that the
-    // second wave of the SIMD always finds MFMAs of this wave to overlap with.
+    // One MFMA step.  `cur` holds the split B operand of step S; the B operand of the next step (of the next
+    // tile after a tile's last step) is read from LDS and split into `nxt` between the MFMAs.  Phase i = the
+    // PT*NPROD MFMAs of channel tile i in NPROD groups of PT independent MFMAs (one limb pair each); the A
+    // fragments of tile i+1, the raw B reads and the split arithmetic are placed between the groups at
+    // compile time, and the DMA issue after phase 0, so that the second wave of the SIMD always finds MFMAs
+    // of this wave to overlap with.
     auto step = [&](int S, const Limbs& cur, Limbs& nxt) {
-        const bool last = S + 1 >= s_hi;
-        int cn = c, sn = sc + 1;                                     // coordinates of step S+1
-        if (sn == nst) { cn = c + 1; sn = 0; }
-        if (last) { cn = c; sn = sc; }
-        if (S > s_lo) {
-            wait_weights(input_age <= 1 && cn == c);
+        const bool tile_end = S + 1 >= s_hi;
+        const bool last = tile_end && !has_next;                     // nothing follows: no prefetch
+        int cn = c, sn = sc + 1, stg_n = stg;                        // coordinates of the next step
+        if (sn == nst) { cn = c + 1; sn = 0; stg_n = stg ^ 1; }
+        if (tile_end) { cn = c_lo; sn = 0; stg_n = stg ^ 1; }
+        if (last) { cn = c; sn = sc; stg_n = stg; }
+        if (!first_step) {
+            // stores share the VM counter with the DMAs and may retire out of order with them: the first
+            // barrier after a tile's output stores drains everything
+            if (stores_pending) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else wait_weights(input_age <= 1 && stg_n == stg);
             raw_barrier();
         }
-        const float* il = b_base(cn, sn);
+        first_step = false;
+        stores_pending = false;
+        const float* il = b_base(stg_n, cn, sn);
         const u32x4* wl = reinterpret_cast<const u32x4*>(wring + slot * WSLOT_F) + lane;
         float raw[PT][8];
         u32x4 a[2][3];
@@ -635,78 +710,95 @@ __global__ __launch_bounds__(kXWaves * 64) void conv_fwd_x3_kernel(Geom g, const
                 __builtin_amdgcn_sched_barrier(0);
             }
             if (i == 0) {
-                // DMA issue for step S+2 (its slot was read during step S-1) and, at the first step of a
-                // chunk, of the next chunk's input box (its stage was last read during the previous step)
+                // DMA issue for the step after next (its slot was read during the previous step; the weight
+                // stream wraps around at a tile end) and, at the first step of a chunk, of the next input box:
+                // the next chunk of this tile, or the first chunk of the next tile (its stage was last read
+                // during the previous step)
                 if (S + 2 < s_hi) issue_w(wsrc + 2 * WSLOT_F, slot == 0 ? 2 : slot - 1);
+                else if (has_next) issue_w(wnext + (S + 2 - s_hi) * WSLOT_F, slot == 0 ? 2 : slot - 1);
                 ++input_age;
-                if ((S == s_lo || sc == 0) && c + 1 < c_hi) {
-                    issue_i(c + 1);
-                    if (c + 1 < g.x_nfull) input_age = 0;
+                if (sc == 0) {
+                    if (c + 1 < c_hi) {
+                        issue_i(stg ^ 1, c + 1);
+                        if (c + 1 < g.x_nfull) input_age = 0;
+                    } else if (has_next) {
+                        plan_input(tile_next);
+                        issue_i(stg ^ 1, c_lo);
+                        if (c_lo < g.x_nfull) input_age = 0;
+                    }
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
         // advance
-        wsrc += WSLOT_F;
+        wsrc = tile_end ? wnext : wsrc + WSLOT_F;
         slot = slot == 2 ? 0 : slot + 1;
-        if (cn != c) nst = cn < g.x_nfull ? SPC : g.x_tail_steps;
+        if (cn != c || tile_end) nst = cn < g.x_nfull ? SPC : g.x_tail_steps;
         c = cn;
         sc = sn;
+        stg = stg_n;
     };
 
-    for (int S = s_lo; S < s_hi; S += 2) {
-        step(S, lb0, lb1);
-        if (S + 1 < s_hi) step(S + 1, lb1, lb0);
-    }
-
-    // ---- epilogue: D row = channel (kq*4 + r), column = pixel (lm).  With one workgroup per CU nothing hides
-    //      this code, so the common case (own the whole K range, overwrite) is kept to one address add and one
-    //      store per value: lane mask per pixel tile, channel-bound checks only in the last channel block.
     const bool add_bias = bias != nullptr && blockIdx.z == 0;
-    float bv[COT][4];
-#pragma unroll
-    for (int i = 0; i < COT; ++i)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int co = co0 + i * 16 + kq * 4 + r;
-            bv[i][r] = (add_bias && co < g.cout) ? bias[co] : 0.f;
+    for (; item < nitems; item += gridDim.x) {
+        const int tile = item / g.x_coblk;
+        const int co0 = (item - tile * g.x_coblk) * CO_BLK;
+        has_next = item + (int)gridDim.x < nitems;
+        if (has_next) {
+            const int inext = item + gridDim.x;
+            tile_next = inext / g.x_coblk;
+            wnext = wbase0 + (inext - tile_next * g.x_coblk) * wblk;
         }
-    if (g.ksplit == 1 && !accumulate) {
-        const bool full = co0 + CO_BLK <= g.cout;
-#pragma unroll
-        for (int j = 0; j < PT; ++j) {
-            if (pix_g[j] < 0) continue;
-            float* o = out + pix_g[j] + (long)(co0 + kq * 4) * g.hw;
-            if (full) {
-#pragma unroll
-                for (int i = 0; i < COT; ++i)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) o[(long)(i * 16 + r) * g.hw] = acc[i][j][r] + bv[i][r];
-            } else {
-#pragma unroll
-                for (int i = 0; i < COT; ++i)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        if (co0 + i * 16 + kq * 4 + r < g.cout) o[(long)(i * 16 + r) * g.hw] = acc[i][j][r] + bv[i][r];
-            }
+        plan_output(tile);
+        for (int S = s_lo; S < s_hi; S += 2) {
+            step(S, lb0, lb1);
+            if (S + 1 < s_hi) step(S + 1, lb1, lb0);
+            else lb0 = lb1;                       // odd number of steps: the next tile starts from lb0 again
         }
-    } else {
+
+        // ---- epilogue (see plan_output): D row = channel (kq*4 + r), column = pixel (lm) -> scratch[ch][px] ->
+        //      lane = (channel, pixel quad).  The plane size and the bias pointer are made opaque per item:
+        //      otherwise hipcc hoists the channel offsets and bias values out of the item loop and spills.
+        long hw_t = g.hw;
+        const float* bias_t = bias;
+        asm volatile("" : "+s"(hw_t), "+s"(bias_t));
+        const bool plain = g.ksplit == 1 && !accumulate;
+        const int ch = lane >> 2;
 #pragma unroll
         for (int i = 0; i < COT; ++i) {
+            float bv[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int co = co0 + i * 16 + kq * 4 + r;
-                if (co >= g.cout) continue;
-#pragma unroll
-                for (int j = 0; j < PT; ++j)
-                    if (pix_g[j] >= 0) {
-                        float* o = out + pix_g[j] + (long)co * g.hw;
-                        const float v = acc[i][j][r] + bv[i][r];
-                        if (g.ksplit > 1) atomicAdd(o, v);
-                        else *o += v;
-                    }
+                const int cob = co0 + i * 16 + kq * 4 + r;
+                bv[r] = (add_bias && cob < g.cout) ? bias_t[cob] : 0.f;
             }
+            const int co = co0 + i * 16 + ch;
+#pragma unroll
+            for (int j = 0; j < PT; ++j) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) scratch[(kq * 4 + r) * SCR + lm] = acc[i][j][r] + bv[r];
+                const f32x4 v = *reinterpret_cast<const f32x4*>(scratch + ch * SCR + (lane & 3) * 4);
+                if (co < g.cout && quad_ok[j]) {
+                    float* o = out + quad_g[j] + (long)co * hw_t;
+                    if (plain && quad_ok[j] == 15) {
+                        *reinterpret_cast<f32x4*>(o) = v;            // 4-byte aligned 16-byte store
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k)
+                            if (quad_ok[j] & (1 << k)) {
+                                if (g.ksplit > 1) atomicAdd(o + k, v[k]);
+                                else o[k] = accumulate ? o[k] + v[k] : v[k];
+                            }
+                    }
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
+#pragma unroll
+        for (int i = 0; i < COT; ++i)
+#pragma unroll
+            for (int j = 0; j < PT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        stores_pending = true;
     }
 }
 
@@ -1295,6 +1387,7 @@ struct FwdPlan {
     long grid_x;
     int x3;           // 0: native fp32 MFMA kernel; 6 / 9: conv_fwd_x3_kernel with that many limb products
     int pt;           // pixel tiles per wave
+    long launch_x;    // x3: persistent workgroups per (channel block, K slice)
 };
 
 // Arithmetic of the 3x3 / k3 forward and dgrad kernels: 0 = native fp32 MFMA everywhere, 6 / 9 = split-bf16
@@ -1375,15 +1468,18 @@ bool plan_fwd_x3_pt(const fsc_conv_desc& d_in, int dgrad, int nprod, int pt, Fwd
     const int pix_cap = kXWaves * p.pt * 16;
     const size_t lds_total = 160 * 1024;
     const size_t ring = (size_t)3 * p.cot * 3 * 1024;
-    int cap_pos = (int)((lds_total - ring) / (2 * kch * sizeof(float))) - 4;
+    const size_t scratch = (size_t)kXWaves * 16 * 20 * sizeof(float);      // per-wave epilogue transpose tiles
+    int cap_pos = (int)((lds_total - ring - scratch) / (2 * kch * sizeof(float))) - 4;
     if (cap_pos > 64 * kXNptMax - 4) cap_pos = 64 * kXNptMax - 4;
     long best_cost = -1;
     int bnb = 1, bth = 1, btw = 1;
-    for (int tw = 1; tw <= d.w && tw <= pix_cap; ++tw) {
+    // box widths are multiples of 4: the epilogue stores quads of consecutive pixels (the box may overhang
+    // the image's right edge; several images share a box only when whole images of a multiple-of-4 width fit)
+    for (int tw = 4; tw <= ((d.w + 3) & ~3) && tw <= pix_cap; tw += 4) {
         int th = pix_cap / tw;
         if (th > d.h) th = d.h;
         int nb = 1;
-        if (th == d.h && tw == d.w) {
+        if (th == d.h && tw >= d.w) {
             nb = pix_cap / (th * tw);
             if (nb > d.n) nb = d.n;
             if (nb < 1) nb = 1;
@@ -1404,7 +1500,7 @@ bool plan_fwd_x3_pt(const fsc_conv_desc& d_in, int dgrad, int nprod, int pt, Fwd
     g.tiles_n = fsc::ceil_div(d.n, bnb); g.tiles_h = fsc::ceil_div(d.h, bth); g.tiles_w = fsc::ceil_div(d.w, btw);
     p.grid_x = (long)g.tiles_n * g.tiles_h * g.tiles_w;
     // fewer than ~70 % live MFMA columns: smaller boxes (PT = 1, then the native kernel) fit such shapes better
-    if ((double)d.n * g.hw < 0.7 * (double)p.grid_x * pix_cap) return false;
+    if ((double)d.n * g.hw < (pt == 2 ? 0.7 : 0.55) * (double)p.grid_x * pix_cap) return false;
     g.plane = g.npos;
     while (g.plane % 4 != 2) ++g.plane;              // 8 * plane == 16 (mod 32): lane groups kq, kq+1 on disjoint banks
     g.x_npt = fsc::ceil_div(g.plane, 64);
@@ -1427,8 +1523,24 @@ bool plan_fwd_x3_pt(const fsc_conv_desc& d_in, int dgrad, int nprod, int pt, Fwd
             if (ks > 1) g.ksplit = (int)ks;
         }
     }
-    p.lds_bytes = ring + (size_t)2 * kch * g.plane * sizeof(float);
+    p.lds_bytes = ring + (size_t)2 * kch * g.plane * sizeof(float) + scratch;
     if (p.lds_bytes > lds_total) return false;
+    {
+        // every K slice needs two steps (the weight ring runs two steps ahead, across tiles as well)
+        const int nchunks = g.x_nfull + (g.x_tail_oct ? 1 : 0);
+        for (int z = 0; z < g.ksplit; ++z) {
+            const int c_lo = (int)((long)nchunks * z / g.ksplit), c_hi = (int)((long)nchunks * (z + 1) / g.ksplit);
+            const int s_lo = c_lo * taps * nch, s_hi = c_hi == nchunks ? g.x_steps : c_hi * taps * nch;
+            if (s_hi - s_lo < 2) return false;
+        }
+    }
+    // persistent workgroups: one per CU, each walks the (pixel tile, channel block) items w, w + workers, ...
+    g.x_coblk = p.co_blocks;
+    long workers = 256 / g.ksplit;
+    if (workers < 1) workers = 1;
+    const long items = p.grid_x * p.co_blocks;
+    if (items <= 2 * workers) workers = items;        // small layers: one item per workgroup, the GPU balances them
+    p.launch_x = workers;
     *out = p;
     return true;
 }
@@ -1568,6 +1680,8 @@ int launch_fwd_cot(const FwdPlan& p, const float* in, const float* packed, const
         FSC_CHECK_ARG(e == hipSuccess, "fsc_conv_fwd: memset failed: %s", hipGetErrorString(e));
     }
     if (p.x3) {
+        grid.x = (unsigned)p.launch_x;
+        grid.y = 1;
         if (p.x3 == 6) launch_x3<KH, KW, COT, 6>(p, grid, in, packed, bias, out, accumulate, st);
         else launch_x3<KH, KW, COT, 9>(p, grid, in, packed, bias, out, accumulate, st);
         FSC_LAUNCH_CHECK("fsc_conv_fwd(x3)");
