@@ -839,6 +839,146 @@ __global__ void pack_x3_kernel(const float* __restrict__ w, unsigned short* __re
 }
 
 // -------------------------------------------------------------------------------------------
+// Stem layer (c_in <= 4, 3x3; classifiers.py:526-531 with the 2-channel log-mel + frequency input): direct
+// fp32 convolution on the vector ALUs.  With K = c_in * 9 = 18 the matrix tiles are 8-16x padded and
+// the layer is bound by its 100-channel side (2.8 GB at cfg 2), so these kernels are organised around that
+// tensor: a thread owns four consecutive pixels of a row and streams the wide tensor once with 16-byte
+// accesses, the narrow tensor and the weights (LDS, broadcast reads) are cheap.
+//   forward: out[co][4 px] = bias + sum_{ci,tap} W * in[ci][px + tap]      loop over co, 72 FMAs per store
+//   dgrad:   dx[ci][4 px]  = sum_{co,tap} Wm * dout[co][px + tap]           loop over co, 9 loads per 72 FMAs
+// `packed` is the [tap][k][m] layout of fsc_conv_pack_weights (dgrad: mirrored transpose).
+constexpr int kStemThreads = 256;
+
+template <int CIN>
+__global__ __launch_bounds__(kStemThreads) void conv_stem_fwd_kernel(const float* __restrict__ in, const float* __restrict__ packed,
+                                                                     const float* __restrict__ bias, float* __restrict__ out,
+                                                                     int cout, int h, int w, int k_pad, int m_pad, int accumulate) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];      // [cout][CIN*9 padded to 20 (CIN <= 2) or 36]
+    constexpr int WROW = CIN <= 2 ? 20 : 36;
+    for (int i = threadIdx.x; i < cout * CIN * 9; i += kStemThreads) {
+        const int co = i / (CIN * 9), r = i - co * (CIN * 9);
+        const int ci = r / 9, tap = r - ci * 9;
+        smem[co * WROW + r] = packed[((long)tap * k_pad + ci) * m_pad + co];
+    }
+    __syncthreads();
+    const int qpr = (w + 3) >> 2;                                        // pixel quads per row
+    const int q = blockIdx.x * kStemThreads + threadIdx.x;
+    if (q >= h * qpr) return;
+    const int r = q / qpr, c0 = (q - r * qpr) * 4;
+    const long hw = (long)h * w;
+    const float* xin = in + (long)blockIdx.y * CIN * hw;
+    float x[CIN][3][6];
+#pragma unroll
+    for (int ci = 0; ci < CIN; ++ci)
+#pragma unroll
+        for (int ty = 0; ty < 3; ++ty) {
+            const int rr = r + ty - 1;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) {
+                const int cc = c0 + k - 1;
+                x[ci][ty][k] = (rr >= 0 && rr < h && cc >= 0 && cc < w) ? xin[ci * hw + (long)rr * w + cc] : 0.f;
+            }
+        }
+    float* o = out + (long)blockIdx.y * cout * hw + (long)r * w + c0;
+    const int nv = w - c0;                                               // valid pixels of the quad (>= 1)
+    for (int co = 0; co < cout; ++co) {
+        const float* wr = smem + co * WROW;
+        const float b = bias ? bias[co] : 0.f;
+        float a[4] = {b, b, b, b};
+#pragma unroll
+        for (int ci = 0; ci < CIN; ++ci)
+#pragma unroll
+            for (int ty = 0; ty < 3; ++ty)
+#pragma unroll
+                for (int tx = 0; tx < 3; ++tx) {
+                    const float wv = wr[ci * 9 + ty * 3 + tx];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) a[k] = fmaf(wv, x[ci][ty][tx + k], a[k]);
+                }
+        float* oc = o + (long)co * hw;
+        if (nv >= 4 && !accumulate) {
+            *reinterpret_cast<f32x4*>(oc) = (f32x4){a[0], a[1], a[2], a[3]};
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (k < nv) oc[k] = accumulate ? oc[k] + a[k] : a[k];
+        }
+    }
+}
+
+// dgrad of the stem: COUT = channels written (the conv's c_in), kin = channels read (the conv's c_out)
+template <int COUT>
+__global__ __launch_bounds__(kStemThreads) void conv_stem_dgrad_kernel(const float* __restrict__ dout, const float* __restrict__ packed,
+                                                                       float* __restrict__ dx, int kin, int h, int w, int k_pad,
+                                                                       int m_pad, int accumulate) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];      // [kin][9 taps][COUT] padded to a multiple of 4
+    constexpr int WROW = (9 * COUT + 3) & ~3;
+    for (int i = threadIdx.x; i < kin * 9 * COUT; i += kStemThreads) {
+        const int k = i / (9 * COUT), r = i - k * (9 * COUT);
+        const int tap = r / COUT, ci = r - tap * COUT;
+        smem[k * WROW + r] = packed[((long)tap * k_pad + k) * m_pad + ci];
+    }
+    __syncthreads();
+    // block = 8 rows x 32 quads so that the three input rows a thread reads are shared through L1
+    const int qpr = (w + 3) >> 2;
+    const int bq = blockIdx.x % ((qpr + 31) >> 5), br = blockIdx.x / ((qpr + 31) >> 5);
+    const int r = br * 8 + (threadIdx.x >> 5), qc = bq * 32 + (threadIdx.x & 31);
+    if (r >= h || qc >= qpr) return;
+    const int c0 = qc * 4;
+    const long hw = (long)h * w;
+    const float* src = dout + (long)blockIdx.y * kin * hw;
+    float a[COUT][4];
+#pragma unroll
+    for (int ci = 0; ci < COUT; ++ci)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) a[ci][k] = 0.f;
+    const bool interior = c0 >= 1 && c0 + 5 <= w;                     // the six columns c0-1 .. c0+4 exist
+    for (int k = 0; k < kin; ++k) {
+        const float* wr = smem + k * WROW;
+        const float* pk = src + (long)k * hw;
+#pragma unroll
+        for (int ty = 0; ty < 3; ++ty) {
+            const int rr = r + ty - 1;
+            float v[6];
+            if (rr >= 0 && rr < h) {
+                const float* row = pk + (long)rr * w + c0;
+                if (interior) {
+                    v[0] = row[-1];
+                    const f32x4 m = *reinterpret_cast<const f32x4*>(row);   // 4-byte aligned 16-byte load
+                    v[1] = m[0]; v[2] = m[1]; v[3] = m[2]; v[4] = m[3];
+                    v[5] = row[4];
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 6; ++j) {
+                        const int cc = c0 + j - 1;
+                        v[j] = (cc >= 0 && cc < w) ? row[j - 1] : 0.f;
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 6; ++j) v[j] = 0.f;
+            }
+#pragma unroll
+            for (int tx = 0; tx < 3; ++tx)
+#pragma unroll
+                for (int ci = 0; ci < COUT; ++ci) {
+                    const float wv = wr[(ty * 3 + tx) * COUT + ci];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) a[ci][j] = fmaf(wv, v[tx + j], a[ci][j]);
+                }
+        }
+    }
+    const int nv = w - c0;
+#pragma unroll
+    for (int ci = 0; ci < COUT; ++ci) {
+        float* o = dx + ((long)blockIdx.y * COUT + ci) * hw + (long)r * w + c0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (k < nv) o[k] = accumulate ? o[k] + a[ci][k] : a[ci][k];
+    }
+}
+
+// -------------------------------------------------------------------------------------------
 // weight gradient
 template <int KH, int KW>
 struct WgCfg {
@@ -1715,6 +1855,11 @@ int launch_fwd(const FwdPlan& p, const float* in, const float* packed, const flo
     }
 }
 
+// stem layers take the direct kernels: 3x3, at most 4 input channels, weights fit the LDS table
+bool stem_shape(const fsc_conv_desc& d) {
+    return d.kh == 3 && d.kw == 3 && d.c_in <= 4 && d.c_out <= 1024 && d.w >= 8;
+}
+
 bool valid_desc(const fsc_conv_desc* d) {
     if (!d || d->n <= 0 || d->c_in <= 0 || d->c_out <= 0 || d->h <= 0 || d->w <= 0) return false;
     const bool k33 = d->kh == 3 && d->kw == 3, k11 = d->kh == 1 && d->kw == 1, k13 = d->kh == 1 && d->kw == 3;
@@ -2009,6 +2154,28 @@ int fsc_conv_fwd(const fsc_conv_desc* d, const float* in, const float* packed, c
     FwdPlan p;
     FSC_CHECK_ARG(plan_fwd(*d, dgrad, &p), "fsc_conv_fwd: no tiling for this shape");
     hipStream_t st = fsc::as_stream(stream);
+    if (stem_shape(*d) && !p.x3) {
+        // stem layer: direct kernels organised around the wide tensor (see conv_stem_*_kernel)
+        const int qpr = (d->w + 3) / 4;
+        if (!dgrad) {
+            const int wrow = d->c_in <= 2 ? 20 : 36;
+            dim3 grid(fsc::ceil_div((long)d->h * qpr, kStemThreads), d->n);
+            const size_t lds = sizeof(float) * (size_t)d->c_out * wrow;
+#define FSC_STEM_F(CI_) hipLaunchKernelGGL(conv_stem_fwd_kernel<CI_>, grid, dim3(kStemThreads), lds, st, in, packed, bias, out, \
+                                           d->c_out, d->h, d->w, p.g.k_pad, p.g.m_pad, accumulate)
+            switch (d->c_in) { case 1: FSC_STEM_F(1); break; case 2: FSC_STEM_F(2); break; case 3: FSC_STEM_F(3); break; default: FSC_STEM_F(4); }
+#undef FSC_STEM_F
+        } else {
+            dim3 grid(fsc::ceil_div(qpr, 32) * fsc::ceil_div(d->h, 8), d->n);
+            const size_t lds = sizeof(float) * (size_t)d->c_out * ((9 * d->c_in + 3) & ~3);
+#define FSC_STEM_D(CI_) hipLaunchKernelGGL(conv_stem_dgrad_kernel<CI_>, grid, dim3(kStemThreads), lds, st, in, packed, out, \
+                                           d->c_out, d->h, d->w, p.g.k_pad, p.g.m_pad, accumulate)
+            switch (d->c_in) { case 1: FSC_STEM_D(1); break; case 2: FSC_STEM_D(2); break; case 3: FSC_STEM_D(3); break; default: FSC_STEM_D(4); }
+#undef FSC_STEM_D
+        }
+        FSC_LAUNCH_CHECK("fsc_conv_fwd(stem)");
+        return 0;
+    }
     if (d->kh == 3) return launch_fwd<3, 3>(p, in, packed, bias, out, accumulate, st);
     if (d->kw == 3) return launch_fwd<1, 3>(p, in, packed, bias, out, accumulate, st);
     return launch_fwd<1, 1>(p, in, packed, bias, out, accumulate, st);
@@ -2032,7 +2199,10 @@ int fsc_conv_plan_describe(const fsc_conv_desc* d, int mode, char* buf, size_t b
     } else {
         FwdPlan p;
         FSC_CHECK_ARG(plan_fwd(*d, mode, &p), "fsc_conv_plan_describe: no tiling for this shape");
-        if (p.x3)
+        if (stem_shape(*d) && !p.x3)
+            snprintf(buf, buf_len, "%s<%d> quads=%d", mode ? "conv_stem_dgrad_kernel" : "conv_stem_fwd_kernel", d->c_in,
+                     d->h * ((d->w + 3) / 4));
+        else if (p.x3)
             snprintf(buf, buf_len, "conv_fwd_x3_kernel<%d,%d,%d,%d,%d> box=%dx%dx%d grid=%ldx%dx%d steps=%d lds=%zu", d->kh,
                      d->kw, p.cot, p.pt, p.x3, p.g.nb, p.g.th, p.g.tw, p.grid_x, p.co_blocks, p.g.ksplit, p.g.x_steps,
                      p.lds_bytes);

@@ -70,7 +70,11 @@ def test_frontend_stft_vs_oracle(n_fft, hop, t):
 # ------------------------------------------------------------------------------ convolution
 CONV_CASES = [
     # n, cin, cout, h, w, kh, kw
-    (2, 2, 20, 13, 21, 3, 3),
+    (2, 2, 20, 13, 21, 3, 3),          # stem: direct kernels (c_in <= 4)
+    (3, 2, 100, 16, 43, 3, 3),
+    (2, 1, 24, 9, 12, 3, 3),
+    (2, 4, 33, 8, 10, 3, 3),
+    (1, 3, 16, 5, 9, 3, 3),
     (3, 12, 12, 9, 7, 3, 3),
     (2, 20, 30, 16, 37, 3, 3),
     (5, 33, 17, 4, 13, 3, 3),
