@@ -44,6 +44,8 @@ SIGNATURES = {
     "fsc_conv_packed_floats": (_SZ, [_D, _I]),
     "fsc_conv_pack_weights": (_I, [_D, _P, _I, _P, _P]),
     "fsc_conv_fwd": (_I, [_D, _P, _P, _P, _I, _I, _P, _P]),
+    "fsc_conv_pool_supported": (_I, [_D]),
+    "fsc_conv_pool_fwd": (_I, [_D, _P, _P, _P, _P, _P, _P]),
     "fsc_conv_plan_describe": (_I, [_D, _I, C.c_char_p, _SZ]),
     "fsc_conv_set_arith": (_I, [_I]),
     "fsc_conv_get_arith": (_I, []),

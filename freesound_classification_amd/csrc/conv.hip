@@ -906,6 +906,96 @@ __global__ __launch_bounds__(kStemThreads) void conv_stem_fwd_kernel(const float
     }
 }
 
+// forward fused with the 2x2 max-pool that follows the stem conv (classifiers.py:526-532): the full-resolution
+// conv output (2.8 GB at cfg 2) is never written.  A thread owns four pooled pixels of a row = 2 x 8 conv
+// outputs; tie rule and window index as fsc_maxpool_fwd (first maximum, NaN propagates).
+template <int CIN>
+__global__ __launch_bounds__(kStemThreads) void conv_stem_pool_fwd_kernel(const float* __restrict__ in, const float* __restrict__ packed,
+                                                                          const float* __restrict__ bias, float* __restrict__ pooled,
+                                                                          uint8_t* __restrict__ idx, int cout, int h, int w,
+                                                                          int k_pad, int m_pad) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int WROW = 20;
+    for (int i = threadIdx.x; i < cout * CIN * 9; i += kStemThreads) {
+        const int co = i / (CIN * 9), r = i - co * (CIN * 9);
+        const int ci = r / 9, tap = r - ci * 9;
+        smem[co * WROW + r] = packed[((long)tap * k_pad + ci) * m_pad + co];
+    }
+    __syncthreads();
+    const int oh = h >> 1, ow = w >> 1;
+    const int qpr = (ow + 3) >> 2;
+    const int q = blockIdx.x * kStemThreads + threadIdx.x;
+    if (q >= oh * qpr) return;
+    const int oy = q / qpr, ox0 = (q - oy * qpr) * 4;
+    const long hw = (long)h * w, ohw = (long)oh * ow;
+    const float* xin = in + (long)blockIdx.y * CIN * hw;
+    float x[CIN][4][10];                                   // rows 2oy-1 .. 2oy+2, columns 2ox0-1 .. 2ox0+8
+#pragma unroll
+    for (int ci = 0; ci < CIN; ++ci)
+#pragma unroll
+        for (int ty = 0; ty < 4; ++ty) {
+            const int rr = 2 * oy + ty - 1;
+#pragma unroll
+            for (int k = 0; k < 10; ++k) {
+                const int cc = 2 * ox0 + k - 1;
+                x[ci][ty][k] = (rr >= 0 && rr < h && cc >= 0 && cc < w) ? xin[ci * hw + (long)rr * w + cc] : 0.f;
+            }
+        }
+    const int nv = ow - ox0;                               // valid pooled pixels of the quad (>= 1)
+    const long obase = (long)blockIdx.y * cout * ohw + (long)oy * ow + ox0;
+    for (int co = 0; co < cout; ++co) {
+        const float* wr = smem + co * WROW;
+        const float b = bias ? bias[co] : 0.f;
+        float a[2][8];
+#pragma unroll
+        for (int ry = 0; ry < 2; ++ry)
+#pragma unroll
+            for (int k = 0; k < 8; ++k) a[ry][k] = b;
+#pragma unroll
+        for (int ci = 0; ci < CIN; ++ci)
+#pragma unroll
+            for (int ty = 0; ty < 3; ++ty)
+#pragma unroll
+                for (int tx = 0; tx < 3; ++tx) {
+                    const float wv = wr[ci * 9 + ty * 3 + tx];
+#pragma unroll
+                    for (int ry = 0; ry < 2; ++ry)
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) a[ry][k] = fmaf(wv, x[ci][ty + ry][tx + k], a[ry][k]);
+                }
+        float best[4];
+        unsigned bidx = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float bv = a[0][2 * k];
+            unsigned bi = 0;
+            float v = a[0][2 * k + 1];
+            if (v > bv || v != v) { bv = v; bi = 1; }
+            v = a[1][2 * k];
+            if ((v > bv || v != v) && bv == bv) { bv = v; bi = 2; }
+            v = a[1][2 * k + 1];
+            if ((v > bv || v != v) && bv == bv) { bv = v; bi = 3; }
+            best[k] = bv;
+            bidx |= bi << (8 * k);
+        }
+        float* po = pooled + obase + (long)co * ohw;
+        uint8_t* pi = idx + obase + (long)co * ohw;
+        if (nv >= 4) {
+            *reinterpret_cast<f32x4*>(po) = (f32x4){best[0], best[1], best[2], best[3]};
+            if ((reinterpret_cast<uintptr_t>(pi) & 3) == 0) {
+                *reinterpret_cast<unsigned*>(pi) = bidx;
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) pi[k] = (uint8_t)(bidx >> (8 * k));
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (k < nv) { po[k] = best[k]; pi[k] = (uint8_t)(bidx >> (8 * k)); }
+        }
+    }
+}
+
 // dgrad of the stem: COUT = channels written (the conv's c_in), kin = channels read (the conv's c_out)
 template <int COUT>
 __global__ __launch_bounds__(kStemThreads) void conv_stem_dgrad_kernel(const float* __restrict__ dout, const float* __restrict__ packed,
@@ -2179,6 +2269,30 @@ int fsc_conv_fwd(const fsc_conv_desc* d, const float* in, const float* packed, c
     if (d->kh == 3) return launch_fwd<3, 3>(p, in, packed, bias, out, accumulate, st);
     if (d->kw == 3) return launch_fwd<1, 3>(p, in, packed, bias, out, accumulate, st);
     return launch_fwd<1, 1>(p, in, packed, bias, out, accumulate, st);
+}
+
+int fsc_conv_pool_supported(const fsc_conv_desc* d) {
+    return valid_desc(d) && stem_shape(*d) && d->c_in <= 2 && d->h >= 2 && d->w >= 8 ? 1 : 0;
+}
+
+int fsc_conv_pool_fwd(const fsc_conv_desc* d, const float* in, const float* packed, const float* bias, float* pooled,
+                      uint8_t* idx, fsc_stream_t stream) {
+    FSC_CHECK_ARG(fsc_conv_pool_supported(d) && in && packed && pooled && idx,
+                  "fsc_conv_pool_fwd: only 3x3 stem layers (c_in <= 2) are fused with the 2x2 max-pool");
+    FwdPlan p;
+    FSC_CHECK_ARG(plan_fwd(*d, 0, &p) && !p.x3, "fsc_conv_pool_fwd: no tiling for this shape");
+    const int oh = d->h / 2, ow = d->w / 2, qpr = (ow + 3) / 4;
+    dim3 grid(fsc::ceil_div((long)oh * qpr, kStemThreads), d->n);
+    const size_t lds = sizeof(float) * (size_t)d->c_out * 20;
+    hipStream_t st = fsc::as_stream(stream);
+    if (d->c_in == 1)
+        hipLaunchKernelGGL(conv_stem_pool_fwd_kernel<1>, grid, dim3(kStemThreads), lds, st, in, packed, bias, pooled, idx,
+                           d->c_out, d->h, d->w, p.g.k_pad, p.g.m_pad);
+    else
+        hipLaunchKernelGGL(conv_stem_pool_fwd_kernel<2>, grid, dim3(kStemThreads), lds, st, in, packed, bias, pooled, idx,
+                           d->c_out, d->h, d->w, p.g.k_pad, p.g.m_pad);
+    FSC_LAUNCH_CHECK("fsc_conv_pool_fwd");
+    return 0;
 }
 
 int fsc_conv_plan_describe(const fsc_conv_desc* d, int mode, char* buf, size_t buf_len) {

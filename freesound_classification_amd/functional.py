@@ -184,6 +184,22 @@ def conv_forward(x, weight, bias):
     return out
 
 
+def conv_pool_forward(x, weight, bias):
+    """Stem conv 3x3 fused with MaxPool2d(2) (classifiers.py:526-532): (pooled, window index, conv output
+    shape), or None when the shape is not a stem layer (the caller then runs conv_forward + maxpool_forward)."""
+    n, c_in, h, w = x.shape
+    c_out, _, kh, kw = weight.shape
+    d = _desc(n, c_in, c_out, h, w, kh, kw)
+    if not _lib.load().fsc_conv_pool_supported(C.byref(d)):
+        return None
+    packed = conv_pack(d, weight, 0)
+    y = _empty((n, c_out, h // 2, w // 2), x)
+    idx = _empty((n, c_out, h // 2, w // 2), x, torch.uint8)
+    with _timed(d, 0):
+        call("fsc_conv_pool_fwd", C.byref(d), ptr(x), ptr(packed), ptr(bias), ptr(y), ptr(idx), stream_ptr())
+    return y, idx, (n, c_out, h, w)
+
+
 def conv_dgrad(dout, weight, x_shape, accumulate_into=None):
     """Gradient w.r.t. the conv input.  With `accumulate_into` the result is added in place."""
     n, c_in, h, w = x_shape
@@ -383,10 +399,14 @@ def _block_forward(x, mods, training, want_head, ph, keep):
     st_a = bn_prepare(x, bn_a, training)
     a = bn_act_forward(x, st_a)
     w_a, b_a = _conv_params(conv_a)
-    c = conv_forward(a, w_a, b_a)
-    p, pidx = maxpool_forward(c, ph)
-    k.c_shape = tuple(c.shape)
-    del c
+    fused = conv_pool_forward(a, w_a, b_a) if ph == 2 else None
+    if fused is not None:
+        p, pidx, k.c_shape = fused
+    else:
+        c = conv_forward(a, w_a, b_a)
+        p, pidx = maxpool_forward(c, ph)
+        k.c_shape = tuple(c.shape)
+        del c
     st_b = bn_prepare(p, bn_b, training)
     b = bn_act_forward(p, st_b, prelu_b.weight)
     w1, b1 = _conv_params(res.conv1)

@@ -80,6 +80,13 @@ int fsc_conv_pack_weights(const fsc_conv_desc* d, const float* weight, int dgrad
 int fsc_conv_fwd(const fsc_conv_desc* d, const float* in, const float* packed,
                  const float* bias, int dgrad, int accumulate, float* out,
                  fsc_stream_t stream);
+/* Stem layer (3x3, c_in <= 2) fused with the 2x2 max-pool that follows it (classifiers.py:526-532): writes the
+ * pooled tensor (N, c_out, H/2, W/2) and the uint8 window indices of fsc_maxpool_fwd; the full-resolution conv
+ * output is never materialised.  `packed` from fsc_conv_pack_weights(dgrad = 0).  fsc_conv_pool_supported
+ * returns 1 for the shapes this entry point accepts. */
+int fsc_conv_pool_supported(const fsc_conv_desc* d);
+int fsc_conv_pool_fwd(const fsc_conv_desc* d, const float* in, const float* packed, const float* bias,
+                      float* pooled, uint8_t* idx, fsc_stream_t stream);
 /* human-readable tiling chosen for this shape (mode 0 fwd, 1 dgrad, 2 wgrad): kernel
  * instantiation, pixel box, grid, LDS bytes.  For logs, DESIGN.md tables and profiles. */
 int fsc_conv_plan_describe(const fsc_conv_desc* d, int mode, char* buf, size_t buf_len);

@@ -208,6 +208,27 @@ def test_conv_split_bf16_exact_on_bf16_representable_inputs(restore_conv_arith):
     assert torch.equal(got, y)
 
 
+@pytest.mark.parametrize("case", [(2, 2, 20, 13, 21), (3, 2, 100, 16, 43), (2, 1, 24, 9, 12), (1, 2, 7, 2, 9)])
+def test_stem_conv_fused_with_maxpool(case):
+    """fsc_conv_pool_fwd == conv 3x3 followed by MaxPool2d(2): values and (after the same tie rule) window indices."""
+    n, cin, cout, h, w = case
+    torch.manual_seed(sum(case))
+    x = torch.randn(n, cin, h, w)
+    wt = torch.randn(cout, cin, 3, 3) / (cin * 9) ** 0.5
+    b = torch.randn(cout)
+    fused = F.conv_pool_forward(x.to(DEV), wt.to(DEV), b.to(DEV))
+    assert fused is not None
+    p, pidx, c_shape = fused
+    assert c_shape == (n, cout, h, w)
+    c_dev = F.conv_forward(x.to(DEV), wt.to(DEV), b.to(DEV))
+    p_ref, idx_ref = F.maxpool_forward(c_dev, 2)
+    assert torch.equal(p.cpu(), p_ref.cpu())               # same FMA order in both stem kernels: bit-equal
+    assert torch.equal(pidx.cpu(), idx_ref.cpu())
+    y = TF.max_pool2d(TF.conv2d(x, wt, b, padding=1), 2)
+    assert maxdiff(p, y) < 2e-5
+    assert F.conv_pool_forward(torch.randn(2, 12, 8, 8).to(DEV), torch.randn(12, 12, 3, 3).to(DEV), None) is None
+
+
 def test_conv_no_bias_and_identity_transpose_check():
     # asymmetric weights catch a swapped row/column in the MFMA C-write
     x = torch.zeros(1, 16, 1, 16)
