@@ -625,24 +625,9 @@ __global__ __launch_bounds__(kXWaves * 64) void conv_fwd_x3_kernel(Geom g, const
     // fragments of tile i+1, the raw B reads and the split arithmetic are placed between the groups at
     // compile time, and the DMA issue after phase 0, so that the second wave of the SIMD always finds MFMAs
     // of this wave to overlap with.
-    auto step = [&](int S, const Limbs& cur, Limbs& nxt) {
-        const bool tile_end = S + 1 >= s_hi;
-        const bool last = tile_end && !has_next;                     // nothing follows: no prefetch
-        int cn = c, sn = sc + 1, stg_n = stg;                        // coordinates of the next step
-        if (sn == nst) { cn = c + 1; sn = 0; stg_n = stg ^ 1; }
-        if (tile_end) { cn = c_lo; sn = 0; stg_n = stg ^ 1; }
-        if (last) { cn = c; sn = sc; stg_n = stg; }
-        if (!first_step) {
-            // stores share the VM counter with the DMAs and may retire out of order with them: the first
-            // barrier after a tile's output stores drains everything
-            if (stores_pending) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            else wait_weights(input_age <= 1 && stg_n == stg);
-            raw_barrier();
-        }
-        first_step = false;
-        stores_pending = false;
-        const float* il = b_base(stg_n, cn, sn);
-        const u32x4* wl = reinterpret_cast<const u32x4*>(wring + slot * WSLOT_F) + lane;
+    // The MFMA / side-work body of one step (see `step` below): `il` = this lane's B pointer of the next step,
+    // `wl` = this lane's A fragments of this step; `dma` is called once after phase 0.
+    auto phases = [&](const float* il, const u32x4* wl, const Limbs& cur, Limbs& nxt, auto&& dma) {
         float raw[PT][8];
         u32x4 a[2][3];
 #pragma unroll
@@ -710,6 +695,55 @@ __global__ __launch_bounds__(kXWaves * 64) void conv_fwd_x3_kernel(Geom g, const
                 __builtin_amdgcn_sched_barrier(0);
             }
             if (i == 0) {
+                dma();
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    };
+
+    // One MFMA step.  `cur` holds the split B operand of step S; the B operand of the next step (of the next
+    // item after an item's last step) is read from LDS and split into `nxt` between the MFMAs.  Phase i = the
+    // PT*NPROD MFMAs of channel tile i in NPROD groups of PT independent MFMAs (one limb pair each); the A
+    // fragments of tile i+1, the raw B reads and the split arithmetic are placed between the groups at
+    // compile time, and the DMA issue after phase 0, so that the second wave of the SIMD always finds MFMAs
+    // of this wave to overlap with.
+    // Interior steps of a full chunk (7 of 9 for 3x3) take `step_fast`: no input box to issue, no chunk / item /
+    // ring wrap, so the scalar bookkeeping shrinks to a few instructions (every instruction beside the MFMAs
+    // costs: about two per MFMA are free, measured).
+    auto step_fast = [&](const Limbs& cur, Limbs& nxt) {
+        wait_weights(input_age <= 1);
+        raw_barrier();
+        const int tap = (sc + 1) / NCH, sub = (sc + 1) - tap * NCH;
+        const int ty = tap / KW, tx = tap - ty * KW;
+        const float* il = ibase + stg * istage + (sub * 4 + kq) * 8 * g.plane + ty * g.cols + tx;
+        const u32x4* wl = reinterpret_cast<const u32x4*>(wring + slot * WSLOT_F) + lane;
+        phases(il, wl, cur, nxt, [&] {
+            issue_w(wsrc + 2 * WSLOT_F, slot == 0 ? 2 : slot - 1);
+            ++input_age;
+        });
+        wsrc += WSLOT_F;
+        slot = slot == 2 ? 0 : slot + 1;
+        ++sc;
+    };
+    auto step_slow = [&](int S, const Limbs& cur, Limbs& nxt) {
+        const bool tile_end = S + 1 >= s_hi;
+        const bool last = tile_end && !has_next;                     // nothing follows: no prefetch
+        int cn = c, sn = sc + 1, stg_n = stg;                        // coordinates of the next step
+        if (sn == nst) { cn = c + 1; sn = 0; stg_n = stg ^ 1; }
+        if (tile_end) { cn = c_lo; sn = 0; stg_n = stg ^ 1; }
+        if (last) { cn = c; sn = sc; stg_n = stg; }
+        if (!first_step) {
+            // stores share the VM counter with the DMAs and may retire out of order with them: the first
+            // barrier after a tile's output stores drains everything
+            if (stores_pending) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else wait_weights(input_age <= 1 && stg_n == stg);
+            raw_barrier();
+        }
+        first_step = false;
+        stores_pending = false;
+        const float* il = b_base(stg_n, cn, sn);
+        const u32x4* wl = reinterpret_cast<const u32x4*>(wring + slot * WSLOT_F) + lane;
+        phases(il, wl, cur, nxt, [&] {
                 // DMA issue for the step after next (its slot was read during the previous step; the weight
                 // stream wraps around at a tile end) and, at the first step of a chunk, of the next input box:
                 // the next chunk of this tile, or the first chunk of the next tile (its stage was last read
@@ -727,9 +761,7 @@ __global__ __launch_bounds__(kXWaves * 64) void conv_fwd_x3_kernel(Geom g, const
                         if (c_lo < g.x_nfull) input_age = 0;
                     }
                 }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
+        });
         // advance
         wsrc = tile_end ? wnext : wsrc + WSLOT_F;
         slot = slot == 2 ? 0 : slot + 1;
@@ -737,6 +769,10 @@ __global__ __launch_bounds__(kXWaves * 64) void conv_fwd_x3_kernel(Geom g, const
         c = cn;
         sc = sn;
         stg = stg_n;
+    };
+    auto step = [&](int S, const Limbs& cur, Limbs& nxt) {
+        if (!first_step && !stores_pending && sc >= 1 && sc + 1 < nst && c < g.x_nfull && S + 2 < s_hi) step_fast(cur, nxt);
+        else step_slow(S, cur, nxt);
     };
 
     const bool add_bias = bias != nullptr && blockIdx.z == 0;

@@ -22,7 +22,8 @@ __global__ void k(float* out, int iters) {
 #pragma unroll
             for (int f = 0; f < F; ++f) {
                 if (KIND == 0) asm volatile("v_fma_f32 %0, %0, %0, %0" : "+v"(v[(m * F + f) & 7]));
-                if (KIND == 1) asm volatile("s_add_i32 %0, %0, 1" : "+s"(sacc));
+                if (KIND == 1) asm volatile("s_add_i32 %0, %0, 1" : "+s"(sacc) : : "scc");
+                if (KIND == 5) { asm volatile("v_fma_f32 %0, %0, %0, %0" : "+v"(v[(m * F + f) & 7])); asm volatile("s_add_i32 %0, %0, 1" : "+s"(sacc) : : "scc"); }
                 if (KIND == 2) { float t; asm volatile("ds_read_b32 %0, %1" : "=v"(t) : "v"((threadIdx.x & 63) * 4)); asm volatile("s_waitcnt lgkmcnt(8)"); }
                 if (KIND == 3) asm volatile("v_pk_add_f32 %0, %0, %0" : "+v"(*(double*)&v[((m * F + f) & 3) * 2]));
                 if (KIND == 4) asm volatile("v_cvt_pk_bf16_f32 %0, %0, %0" : "+v"(v[(m * F + f) & 7]));
@@ -59,6 +60,7 @@ int main() {
     for (int th : {256, 512}) {
         run<0, 0>("none", th); run<1, 0>("valu", th); run<2, 0>("valu", th); run<3, 0>("valu", th); run<4, 0>("valu", th); run<6, 0>("valu", th); run<8, 0>("valu", th);
         run<2, 1>("salu", th); run<4, 1>("salu", th); run<8, 1>("salu", th);
+        run<2, 5>("v+s", th); run<3, 5>("v+s", th);
         run<1, 2>("lds", th); run<2, 2>("lds", th);
         run<2, 3>("pkadd", th); run<2, 4>("cvtpk", th); run<4, 4>("cvtpk", th);
     }
