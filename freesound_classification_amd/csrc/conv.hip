@@ -818,6 +818,9 @@ __global__ __launch_bounds__(kXWaves * 64) void conv_fwd_x3_kernel(Geom g, const
                     float* o = out + quad_g[j] + (long)co * hw_t;
                     if (plain && quad_ok[j] == 15) {
                         *reinterpret_cast<f32x4*>(o) = v;            // 4-byte aligned 16-byte store
+                    } else if (g.ksplit == 1 && quad_ok[j] == 15) {  // accumulate: 16-byte read-modify-write
+                        const f32x4 old = *reinterpret_cast<const f32x4*>(o);
+                        *reinterpret_cast<f32x4*>(o) = old + v;
                     } else {
 #pragma unroll
                         for (int k = 0; k < 4; ++k)
