@@ -395,10 +395,12 @@ __global__ __launch_bounds__(kXWaves * 64) void conv_fwd_x3_kernel(Geom g, const
     constexpr int WUNITS = COT * 3;                 // 1 KB fragment images per step
     constexpr int WSLOT_F = WUNITS * 256;           // floats per ring slot
     constexpr int NWQ = (WUNITS + kXWaves - 1) / kXWaves;
+    constexpr int RING = COT > 8 ? 2 : 3;           // weight slots: W runs RING - 1 steps ahead of the MFMAs
+    constexpr int AHEAD = RING - 1;
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* const wring = smem;                                  // 3 slots
-    float* const ibase = smem + 3 * WSLOT_F;                    // 2 stages of [KCH][plane]
+    float* const wring = smem;                                  // RING step slots
+    float* const ibase = smem + RING * WSLOT_F;                 // 2 stages of [KCH][plane]
     const int istage = KCH * g.plane;
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -550,7 +552,7 @@ __global__ __launch_bounds__(kXWaves * 64) void conv_fwd_x3_kernel(Geom g, const
     // landed; younger and allowed to stay in flight are W(S+1) and an input box issued in the last two steps that
     // the coming step does not read yet.  Counting less than what is really in flight only waits longer (the
     // output stores of the previous tile share the counter: the first barriers of a tile also wait for them).
-    constexpr int NWLO = WUNITS / kXWaves;
+    constexpr int NWLO = RING == 3 ? WUNITS / kXWaves : 0;     // two slots: W(S) was issued in step S-1, nothing newer
     auto wait_weights = [&](bool input_in_flight) {
 #define FSC_VMW(k) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(k) : "memory")
         if (input_in_flight) {
@@ -595,7 +597,7 @@ __global__ __launch_bounds__(kXWaves * 64) void conv_fwd_x3_kernel(Geom g, const
         plan_input(tile);
         issue_i(0, c_lo);
         issue_w(wsrc, 0);
-        issue_w(wsrc + WSLOT_F, 1);
+        if (RING == 3) issue_w(wsrc + WSLOT_F, 1);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         raw_barrier();
         const float* il = b_base(0, c_lo, 0);
@@ -711,18 +713,18 @@ __global__ __launch_bounds__(kXWaves * 64) void conv_fwd_x3_kernel(Geom g, const
     // ring wrap, so the scalar bookkeeping shrinks to a few instructions (every instruction beside the MFMAs
     // costs: about two per MFMA are free, measured).
     auto step_fast = [&](const Limbs& cur, Limbs& nxt) {
-        wait_weights(input_age <= 1);
+        wait_weights(input_age <= AHEAD - 1);
         raw_barrier();
         const int tap = (sc + 1) / NCH, sub = (sc + 1) - tap * NCH;
         const int ty = tap / KW, tx = tap - ty * KW;
         const float* il = ibase + stg * istage + (sub * 4 + kq) * 8 * g.plane + ty * g.cols + tx;
         const u32x4* wl = reinterpret_cast<const u32x4*>(wring + slot * WSLOT_F) + lane;
         phases(il, wl, cur, nxt, [&] {
-            issue_w(wsrc + 2 * WSLOT_F, slot == 0 ? 2 : slot - 1);
+            issue_w(wsrc + AHEAD * WSLOT_F, slot == 0 ? RING - 1 : slot - 1);
             ++input_age;
         });
         wsrc += WSLOT_F;
-        slot = slot == 2 ? 0 : slot + 1;
+        slot = slot == RING - 1 ? 0 : slot + 1;
         ++sc;
     };
     auto step_slow = [&](int S, const Limbs& cur, Limbs& nxt) {
@@ -736,7 +738,7 @@ __global__ __launch_bounds__(kXWaves * 64) void conv_fwd_x3_kernel(Geom g, const
             // stores share the VM counter with the DMAs and may retire out of order with them: the first
             // barrier after a tile's output stores drains everything
             if (stores_pending) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            else wait_weights(input_age <= 1 && stg_n == stg);
+            else wait_weights(input_age <= AHEAD - 1 && stg_n == stg);
             raw_barrier();
         }
         first_step = false;
@@ -748,8 +750,8 @@ __global__ __launch_bounds__(kXWaves * 64) void conv_fwd_x3_kernel(Geom g, const
                 // stream wraps around at a tile end) and, at the first step of a chunk, of the next input box:
                 // the next chunk of this tile, or the first chunk of the next tile (its stage was last read
                 // during the previous step)
-                if (S + 2 < s_hi) issue_w(wsrc + 2 * WSLOT_F, slot == 0 ? 2 : slot - 1);
-                else if (has_next) issue_w(wnext + (S + 2 - s_hi) * WSLOT_F, slot == 0 ? 2 : slot - 1);
+                if (S + AHEAD < s_hi) issue_w(wsrc + AHEAD * WSLOT_F, slot == 0 ? RING - 1 : slot - 1);
+                else if (has_next) issue_w(wnext + (S + AHEAD - s_hi) * WSLOT_F, slot == 0 ? RING - 1 : slot - 1);
                 ++input_age;
                 if (sc == 0) {
                     if (c + 1 < c_hi) {
@@ -764,14 +766,14 @@ __global__ __launch_bounds__(kXWaves * 64) void conv_fwd_x3_kernel(Geom g, const
         });
         // advance
         wsrc = tile_end ? wnext : wsrc + WSLOT_F;
-        slot = slot == 2 ? 0 : slot + 1;
+        slot = slot == RING - 1 ? 0 : slot + 1;
         if (cn != c || tile_end) nst = cn < g.x_nfull ? SPC : g.x_tail_steps;
         c = cn;
         sc = sn;
         stg = stg_n;
     };
     auto step = [&](int S, const Limbs& cur, Limbs& nxt) {
-        if (!first_step && !stores_pending && sc >= 1 && sc + 1 < nst && c < g.x_nfull && S + 2 < s_hi) step_fast(cur, nxt);
+        if (!first_step && !stores_pending && sc >= 1 && sc + 1 < nst && c < g.x_nfull && S + AHEAD < s_hi) step_fast(cur, nxt);
         else step_slow(S, cur, nxt);
     };
 
@@ -1703,7 +1705,7 @@ long tile_penalty(int tiles_per_block) {
 
 
 // tiling of conv_fwd_x3_kernel with PT pixel tiles per wave; false when the shape does not suit it
-bool plan_fwd_x3_pt(const fsc_conv_desc& d_in, int dgrad, int nprod, int pt, FwdPlan* out) {
+bool plan_fwd_x3_pt(const fsc_conv_desc& d_in, int dgrad, int nprod, int pt, int max_cot, FwdPlan* out) {
     FwdPlan p{};
     Geom& g = p.g;
     fsc_conv_desc d = d_in;
@@ -1718,13 +1720,15 @@ bool plan_fwd_x3_pt(const fsc_conv_desc& d_in, int dgrad, int nprod, int pt, Fwd
     g.cin = dgrad ? d.c_out : d.c_in;
     g.cout = dgrad ? d.c_in : d.c_out;
     if (g.cin < 32 || g.cout < 48) return false;         // stem layers: HBM-bound, K or M too small for 16x16x32 tiles
+    // channel tiles per workgroup: a step costs its MFMAs (proportional to the tiles) plus the side work of
+    // splitting the activations, about 3.5 tiles' worth (measured); more than 8 tiles use a two-slot weight ring
     const int tiles = fsc::ceil_div(g.cout, 16);
     int best_cot = 1, best_blocks = tiles;
-    long best_tile_cost = (long)tiles * tile_penalty(1);
-    for (int cot = 2; cot <= 8; ++cot) {
+    long best_tile_cost = -1;
+    for (int cot = 1; cot <= max_cot; ++cot) {
         const int blocks = fsc::ceil_div(tiles, cot);
-        const long cost = (long)blocks * cot * tile_penalty(cot);
-        if (cost < best_tile_cost || (cost == best_tile_cost && blocks < best_blocks)) {
+        const long cost = (long)blocks * (2 * cot + 7);
+        if (best_tile_cost < 0 || cost < best_tile_cost || (cost == best_tile_cost && blocks < best_blocks)) {
             best_cot = cot; best_blocks = blocks; best_tile_cost = cost;
         }
     }
@@ -1736,7 +1740,7 @@ bool plan_fwd_x3_pt(const fsc_conv_desc& d_in, int dgrad, int nprod, int pt, Fwd
     g.flat = 0;
     const int pix_cap = kXWaves * p.pt * 16;
     const size_t lds_total = 160 * 1024;
-    const size_t ring = (size_t)3 * p.cot * 3 * 1024;
+    const size_t ring = (size_t)(p.cot > 8 ? 2 : 3) * p.cot * 3 * 1024;
     const size_t scratch = (size_t)kXWaves * 16 * 20 * sizeof(float);      // per-wave epilogue transpose tiles
     int cap_pos = (int)((lds_total - ring - scratch) / (2 * kch * sizeof(float))) - 4;
     if (cap_pos > 64 * kXNptMax - 4) cap_pos = 64 * kXNptMax - 4;
@@ -1817,8 +1821,11 @@ bool plan_fwd_x3_pt(const fsc_conv_desc& d_in, int dgrad, int nprod, int pt, Fwd
 // 256-pixel tiles (two pixel tiles per wave) where they fit, else 128-pixel tiles (1x1 convolutions stage
 // 64-channel chunks and always take the small tile)
 bool plan_fwd_x3(const fsc_conv_desc& d, int dgrad, int nprod, FwdPlan* out) {
-    if (d.kh * d.kw > 1 && plan_fwd_x3_pt(d, dgrad, nprod, 2, out)) return true;
-    return plan_fwd_x3_pt(d, dgrad, nprod, 1, out);
+    if (d.kh * d.kw > 1) {
+        // (9-10 tiles with a two-slot ring compile, but at 256 registers they spill and gain nothing: measured)
+        if (plan_fwd_x3_pt(d, dgrad, nprod, 2, 8, out)) return true;
+    }
+    return plan_fwd_x3_pt(d, dgrad, nprod, 1, 8, out);
 }
 
 bool plan_fwd_f32(const fsc_conv_desc& d, int dgrad, FwdPlan* out);
