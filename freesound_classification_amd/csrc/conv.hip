@@ -389,9 +389,10 @@ __global__ __launch_bounds__(kXWaves * 64) void conv_fwd_x3_kernel(Geom g, const
     constexpr int TAPS = KH * KW;
     constexpr int CO_BLK = COT * 16;
     constexpr int PADH = KH / 2, PADW = KW / 2;
-    constexpr int NCH = TAPS == 1 ? 2 : 1;          // 32-channel groups per K chunk: a chunk must span >= 2 steps
-    constexpr int KCH = kXChunk * NCH;              // channels per chunk
-    constexpr int SPC = TAPS * NCH;                 // steps per full chunk
+    constexpr int KCH = kXChunk;                    // channels per K chunk
+    constexpr int SPC = TAPS;                       // steps per full chunk (one per tap)
+    constexpr int NSTG = TAPS == 1 ? 4 : 2;         // input stages: the input DMA runs NSTG - 1 chunks ahead (a 1x1
+                                                    // chunk is a single step, shorter than the HBM latency)
     constexpr int WUNITS = COT * 3;                 // 1 KB fragment images per step
     constexpr int WSLOT_F = WUNITS * 256;           // floats per ring slot
     constexpr int NWQ = (WUNITS + kXWaves - 1) / kXWaves;
@@ -400,7 +401,7 @@ __global__ __launch_bounds__(kXWaves * 64) void conv_fwd_x3_kernel(Geom g, const
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* const wring = smem;                                  // RING step slots
-    float* const ibase = smem + RING * WSLOT_F;                 // 2 stages of [KCH][plane]
+    float* const ibase = smem + RING * WSLOT_F;                 // NSTG stages of [KCH][plane]
     const int istage = KCH * g.plane;
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -466,7 +467,7 @@ __global__ __launch_bounds__(kXWaves * 64) void conv_fwd_x3_kernel(Geom g, const
     // 64 lanes x 16 bytes, and the dword version of this epilogue took 18 k cycles per tile.
     // Lane -> channel (lane >> 2) of the tile, pixels 4 * (lane & 3) .. + 3.
     constexpr int SCR = 20;                       // scratch row stride in floats (16 pixels + pad, 16-byte rows)
-    float* const scratch = ibase + 2 * istage + wid * (16 * SCR);
+    float* const scratch = ibase + NSTG * istage + wid * (16 * SCR);
     int quad_dec[PT];                             // (image, row, col) of this lane's first quad pixel; -1 = outside the box
 #pragma unroll
     for (int pt = 0; pt < PT; ++pt) {
@@ -574,9 +575,8 @@ __global__ __launch_bounds__(kXWaves * 64) void conv_fwd_x3_kernel(Geom g, const
     auto b_base = [&](int stage, int c, int s) -> const float* {
         const float* st = ibase + stage * istage;
         if (c < g.x_nfull) {                               // full chunk: step = (tap, 32-channel group), lane group = octet
-            const int tap = s / NCH, sub = s - tap * NCH;  // wave-uniform
-            const int ty = tap / KW, tx = tap - ty * KW;
-            return st + (sub * 4 + kq) * 8 * g.plane + ty * g.cols + tx;
+            const int ty = s / KW, tx = s - ty * KW;       // wave-uniform
+            return st + kq * 8 * g.plane + ty * g.cols + tx;
         }
         const int noct = g.x_tail_oct;
         int gi = 4 * s + kq;
@@ -591,11 +591,27 @@ __global__ __launch_bounds__(kXWaves * 64) void conv_fwd_x3_kernel(Geom g, const
     Limbs lb0, lb1;
     const int nitems = ntiles * g.x_coblk;
     int item = blockIdx.x;
+    // Input producer: a cursor (item, chunk, stage) that runs NSTG - 1 chunks ahead of the MFMA steps, across items;
+    // pos_off[] always belongs to the producer's pixel tile.
+    int p_item = blockIdx.x, p_c = c_lo, p_stg = 0;
+    auto produce = [&]() -> bool {                                   // returns: a full 32-channel chunk was issued
+        if (p_item >= nitems) return false;
+        issue_i(p_stg, p_c);
+        const bool full = p_c < g.x_nfull;
+        p_stg = p_stg == NSTG - 1 ? 0 : p_stg + 1;
+        if (++p_c == c_hi) {
+            p_c = c_lo;
+            p_item += gridDim.x;
+            if (p_item < nitems) plan_input(p_item / g.x_coblk);
+        }
+        return full;
+    };
     if (item < nitems) {
         const int tile = item / g.x_coblk;
         wsrc = wbase0 + (item - tile * g.x_coblk) * wblk;
         plan_input(tile);
-        issue_i(0, c_lo);
+#pragma unroll
+        for (int d = 0; d < NSTG - 1; ++d) produce();
         issue_w(wsrc, 0);
         if (RING == 3) issue_w(wsrc + WSLOT_F, 1);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -618,7 +634,6 @@ __global__ __launch_bounds__(kXWaves * 64) void conv_fwd_x3_kernel(Geom g, const
     int input_age = 99;                                              // steps since a full-chunk input box was issued
     bool first_step = true;                                          // the prologue has already synchronised for it
     bool has_next = false;                                           // another item follows the current one
-    int tile_next = 0;                                               // its pixel tile
     bool stores_pending = false;                                     // the previous tile's output stores may be in flight
 
     // One MFMA step.  `cur` holds the split B operand of step S; the B operand of the next step (of the next
@@ -715,9 +730,8 @@ __global__ __launch_bounds__(kXWaves * 64) void conv_fwd_x3_kernel(Geom g, const
     auto step_fast = [&](const Limbs& cur, Limbs& nxt) {
         wait_weights(input_age <= AHEAD - 1);
         raw_barrier();
-        const int tap = (sc + 1) / NCH, sub = (sc + 1) - tap * NCH;
-        const int ty = tap / KW, tx = tap - ty * KW;
-        const float* il = ibase + stg * istage + (sub * 4 + kq) * 8 * g.plane + ty * g.cols + tx;
+        const int ty = (sc + 1) / KW, tx = (sc + 1) - ty * KW;
+        const float* il = ibase + stg * istage + kq * 8 * g.plane + ty * g.cols + tx;
         const u32x4* wl = reinterpret_cast<const u32x4*>(wring + slot * WSLOT_F) + lane;
         phases(il, wl, cur, nxt, [&] {
             issue_w(wsrc + AHEAD * WSLOT_F, slot == 0 ? RING - 1 : slot - 1);
@@ -731,13 +745,16 @@ __global__ __launch_bounds__(kXWaves * 64) void conv_fwd_x3_kernel(Geom g, const
         const bool tile_end = S + 1 >= s_hi;
         const bool last = tile_end && !has_next;                     // nothing follows: no prefetch
         int cn = c, sn = sc + 1, stg_n = stg;                        // coordinates of the next step
-        if (sn == nst) { cn = c + 1; sn = 0; stg_n = stg ^ 1; }
-        if (tile_end) { cn = c_lo; sn = 0; stg_n = stg ^ 1; }
+        const int stg_up = stg == NSTG - 1 ? 0 : stg + 1;
+        if (sn == nst) { cn = c + 1; sn = 0; stg_n = stg_up; }
+        if (tile_end) { cn = c_lo; sn = 0; stg_n = stg_up; }
         if (last) { cn = c; sn = sc; stg_n = stg; }
         if (!first_step) {
             // stores share the VM counter with the DMAs and may retire out of order with them: the first
             // barrier after a tile's output stores drains everything
             if (stores_pending) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else if (TAPS == 1) wait_weights(input_age == 0);         // every step opens a chunk: only the box issued in the
+                                                                      // previous step (younger than the one needed now) may fly
             else wait_weights(input_age <= AHEAD - 1 && stg_n == stg);
             raw_barrier();
         }
@@ -747,22 +764,12 @@ __global__ __launch_bounds__(kXWaves * 64) void conv_fwd_x3_kernel(Geom g, const
         const u32x4* wl = reinterpret_cast<const u32x4*>(wring + slot * WSLOT_F) + lane;
         phases(il, wl, cur, nxt, [&] {
                 // DMA issue for the step after next (its slot was read during the previous step; the weight
-                // stream wraps around at a tile end) and, at the first step of a chunk, of the next input box:
-                // the next chunk of this tile, or the first chunk of the next tile (its stage was last read
-                // during the previous step)
+                // stream wraps around at an item end) and, at the first step of a chunk, of the input box
+                // NSTG - 1 chunks ahead (its stage was last read during the previous step)
                 if (S + AHEAD < s_hi) issue_w(wsrc + AHEAD * WSLOT_F, slot == 0 ? RING - 1 : slot - 1);
                 else if (has_next) issue_w(wnext + (S + AHEAD - s_hi) * WSLOT_F, slot == 0 ? RING - 1 : slot - 1);
                 ++input_age;
-                if (sc == 0) {
-                    if (c + 1 < c_hi) {
-                        issue_i(stg ^ 1, c + 1);
-                        if (c + 1 < g.x_nfull) input_age = 0;
-                    } else if (has_next) {
-                        plan_input(tile_next);
-                        issue_i(stg ^ 1, c_lo);
-                        if (c_lo < g.x_nfull) input_age = 0;
-                    }
-                }
+                if (sc == 0 && produce()) input_age = 0;
         });
         // advance
         wsrc = tile_end ? wnext : wsrc + WSLOT_F;
@@ -784,8 +791,7 @@ __global__ __launch_bounds__(kXWaves * 64) void conv_fwd_x3_kernel(Geom g, const
         has_next = item + (int)gridDim.x < nitems;
         if (has_next) {
             const int inext = item + gridDim.x;
-            tile_next = inext / g.x_coblk;
-            wnext = wbase0 + (inext - tile_next * g.x_coblk) * wblk;
+            wnext = wbase0 + (inext - (inext / g.x_coblk) * g.x_coblk) * wblk;
         }
         plan_output(tile);
         for (int S = s_lo; S < s_hi; S += 2) {
@@ -1714,8 +1720,9 @@ bool plan_fwd_x3_pt(const fsc_conv_desc& d_in, int dgrad, int nprod, int pt, int
         d.w = d.h * d.w;
         d.h = 1;
     }
-    const int nch = taps == 1 ? 2 : 1;                   // 32-channel groups per K chunk (kernel NCH)
-    const int kch = kXChunk * nch;
+    const int nch = 1;
+    const int kch = kXChunk;
+    const int nstg = taps == 1 ? 4 : 2;                  // input stages (kernel NSTG)
     g.n = d.n; g.h = d.h; g.w = d.w; g.hw = (long)d.h * d.w;
     g.cin = dgrad ? d.c_out : d.c_in;
     g.cout = dgrad ? d.c_in : d.c_out;
@@ -1742,7 +1749,7 @@ bool plan_fwd_x3_pt(const fsc_conv_desc& d_in, int dgrad, int nprod, int pt, int
     const size_t lds_total = 160 * 1024;
     const size_t ring = (size_t)(p.cot > 8 ? 2 : 3) * p.cot * 3 * 1024;
     const size_t scratch = (size_t)kXWaves * 16 * 20 * sizeof(float);      // per-wave epilogue transpose tiles
-    int cap_pos = (int)((lds_total - ring - scratch) / (2 * kch * sizeof(float))) - 4;
+    int cap_pos = (int)((lds_total - ring - scratch) / (nstg * kch * sizeof(float))) - 4;
     if (cap_pos > 64 * kXNptMax - 4) cap_pos = 64 * kXNptMax - 4;
     long best_cost = -1;
     int bnb = 1, bth = 1, btw = 1;
@@ -1796,7 +1803,7 @@ bool plan_fwd_x3_pt(const fsc_conv_desc& d_in, int dgrad, int nprod, int pt, int
             if (ks > 1) g.ksplit = (int)ks;
         }
     }
-    p.lds_bytes = ring + (size_t)2 * kch * g.plane * sizeof(float) + scratch;
+    p.lds_bytes = ring + (size_t)nstg * kch * g.plane * sizeof(float) + scratch;
     if (p.lds_bytes > lds_total) return false;
     {
         // every K slice needs two steps (the weight ring runs two steps ahead, across tiles as well)
@@ -2270,7 +2277,7 @@ int fsc_conv_pack_weights(const fsc_conv_desc* d, const float* weight, int dgrad
         if (xb > 8192) xb = 8192;
         hipLaunchKernelGGL(pack_x3_kernel, dim3((unsigned)xb), dim3(256), 0, fsc::as_stream(stream), weight,
                            reinterpret_cast<unsigned short*>(packed), d->c_out, d->c_in, d->kh * d->kw, p.cot, p.co_blocks,
-                           p.g.x_nfull, p.g.x_tail_oct, p.g.x_steps, d->kh * d->kw == 1 ? 2 : 1, dgrad);
+                           p.g.x_nfull, p.g.x_tail_oct, p.g.x_steps, 1, dgrad);
         FSC_LAUNCH_CHECK("fsc_conv_pack_weights(x3)");
         return 0;
     }
