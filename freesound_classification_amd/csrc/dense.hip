@@ -18,6 +18,7 @@ struct GemmArgs {
     float* c; long ldc;              // C(m, n) = c[m*ldc + n]
     const float* bias;               // per-n, may be null
     int m, n, k;
+    int ksplit;       // > 1: blockIdx.z owns a K slice and adds into a zeroed C (few output tiles, long K)
 };
 
 __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
@@ -34,7 +35,10 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
         for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     const bool a_kfast = g.sak == 1, b_kfast = g.sbk == 1;
-    for (int k0 = 0; k0 < g.k; k0 += BK) {
+    const int kchunks = (g.k + BK - 1) / BK;
+    const int k_lo = (int)((long)kchunks * blockIdx.z / g.ksplit) * BK;
+    const int k_hi = (int)((long)kchunks * (blockIdx.z + 1) / g.ksplit) * BK;
+    for (int k0 = k_lo; k0 < k_hi; k0 += BK) {
 #pragma unroll
         for (int e = tid; e < BM * BK; e += 256) {
             int mm, kk;
@@ -72,11 +76,14 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
         for (int j = 0; j < 2; ++j) {
             const int gn = n0 + wn + j * 16 + lm;
             if (gn >= g.n) continue;
-            const float bv = g.bias ? g.bias[gn] : 0.f;
+            const float bv = (g.bias && blockIdx.z == 0) ? g.bias[gn] : 0.f;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int gm = m0 + wm + i * 16 + kq * 4 + r;
-                if (gm < g.m) g.c[(long)gm * g.ldc + gn] = acc[i][j][r] + bv;
+                if (gm < g.m) {
+                    if (g.ksplit > 1) atomicAdd(g.c + (long)gm * g.ldc + gn, acc[i][j][r] + bv);
+                    else g.c[(long)gm * g.ldc + gn] = acc[i][j][r] + bv;
+                }
             }
         }
 }
@@ -113,8 +120,24 @@ __global__ void dropout_bwd_kernel(const float* __restrict__ dy, const uint8_t* 
         dx[i] = mask[i] ? dy[i] * inv_keep : 0.f;
 }
 
-int run_gemm(const GemmArgs& g, hipStream_t st, const char* name) {
+int run_gemm(const GemmArgs& g_in, hipStream_t st, const char* name) {
+    GemmArgs g = g_in;
     dim3 grid(fsc::ceil_div(g.n, BN), fsc::ceil_div(g.m, BM));
+    // the head's 128 x 1977 x 1977 products have 62 output tiles: split K so that the chip is filled
+    g.ksplit = 1;
+    const long tiles = (long)grid.x * grid.y;
+    const int kchunks = (g.k + BK - 1) / BK;
+    if (tiles < 128 && kchunks >= 16 && g.ldc == g.n) {
+        long ks = 256 / tiles;
+        if (ks > kchunks / 4) ks = kchunks / 4;
+        if (ks > 16) ks = 16;
+        if (ks > 1) {
+            g.ksplit = (int)ks;
+            hipError_t e = hipMemsetAsync(g.c, 0, sizeof(float) * (size_t)g.m * g.n, st);
+            FSC_CHECK_ARG(e == hipSuccess, "%s: memset failed: %s", name, hipGetErrorString(e));
+        }
+    }
+    grid.z = g.ksplit;
     hipLaunchKernelGGL(gemm_kernel, grid, dim3(256), 0, st, g);
     FSC_LAUNCH_CHECK(name);
     return 0;
