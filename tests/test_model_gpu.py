@@ -211,6 +211,53 @@ def test_against_oracle_odd_shapes():
         assert maxdiff(m(signal.to(DEV))["class_logits"], ref(signal)["class_logits"]) < TOL
 
 
+@pytest.mark.parametrize("arith", ["bf16x6", "bf16x9", "f32"])
+def test_against_oracle_wide_channels_split_bf16(arith):
+    """Channel counts of the benchmark's order (64, 96, 144) so that the split-bf16 forward / dgrad / wgrad
+    kernels, the 1x1 split kernels and the fused stem + max-pool run inside the full autograd chain;
+    logits, every parameter gradient and eval-mode logits against the CPU oracle, in every arithmetic mode."""
+    mode0 = F.get_conv_arith()
+    try:
+        F.set_conv_arith(arith)
+        torch.manual_seed(5)
+        exp = experiment("mel_1024_512_64", 3, 64, 1.5, 1, 64)
+        m = TwoDimensionalCNNClassificationModel(exp, device=DEV)
+        ref = oref.TagCNN2d("mel_1024_512_64", 3, 64, 1.5, 1, 80)
+        ref.load_state_dict({k: v.cpu() for k, v in m.state_dict().items()})
+        signal = 0.1 * torch.randn(8, 66000, 1)               # 129 frames: 64 x 129 -> 32 x 64 -> 16 x 32 -> 8 x 16
+        labels = torch.zeros(8, 80)
+        labels[torch.arange(8), torch.randint(0, 80, (8,))] = 1.0
+        if arith != "f32":
+            used = set()
+            for (cin, cout, hh, ww, kk) in [(64, 64, 32, 64, 3), (64, 96, 32, 64, 3), (96, 96, 16, 32, 3), (64, 64, 32, 64, 1)]:
+                d = F._desc(8, cin, cout, hh, ww, kk, kk)
+                used.update(F.plan_name(d, mode).split("<")[0] for mode in (0, 1, 2))
+            assert "conv_fwd_x3_kernel" in used and "conv_wgrad_x3_kernel" in used, used
+        ref.train()
+        rl = ref(signal)["class_logits"]
+        oref.lsep(rl, labels, average=False).mean().backward()
+        m.train()
+        ml = m(signal.to(DEV))["class_logits"]
+        F.mean(lsep_loss(ml, labels.to(DEV), average=False)).backward()
+        assert maxdiff(ml, rl) < TOL
+        # Gradients: a 2x2 max-pool window whose two largest values differ by less than fp32 rounding may pick a
+        # different arg-max than the CPU evaluation (measured against an fp64 run of the oracle: the oracle itself,
+        # the native-fp32 mode and the split modes each flip their own rare windows; one flip moves the 576 weight
+        # gradients of one output channel by ~1e-3).  So: every gradient within TOL in rms, and all but a
+        # fraction of a percent of its elements within TOL.
+        rgrads = dict(ref.named_parameters())
+        for k, p in m.named_parameters():
+            d = (p.grad.detach().cpu().double() - rgrads[k].grad.double()).abs()
+            assert float(d.pow(2).mean().sqrt()) < 0.5 * TOL, k
+            assert float((d > TOL).double().mean()) < 0.02, k
+        ref.eval()
+        m.eval()
+        with torch.no_grad():
+            assert maxdiff(m(signal.to(DEV))["class_logits"], ref(signal)["class_logits"]) < TOL
+    finally:
+        F.set_conv_arith(mode0)
+
+
 def test_gradient_accumulation_matches_reference_quirk():
     """accumulation_steps=2: the reference steps on batch 0 and then every second batch
     (classifiers.py:682); losses are divided by accumulation_steps."""
