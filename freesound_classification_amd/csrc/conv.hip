@@ -1547,9 +1547,11 @@ __global__ __launch_bounds__(kWgxWaves * 64) void conv_wgrad_x3_kernel(WgxGeom g
                 u32x4 al[MT][3];
 #pragma unroll
                 for (int i = 0; i < MT; ++i) {
-                    const float x[8] = {ar[i][0][0], ar[i][0][1], ar[i][0][2], ar[i][0][3],
-                                        ar[i][1][0], ar[i][1][1], ar[i][1][2], ar[i][1][3]};
-                    split3(x, al[i][0], al[i][1], al[i][2]);
+                    if (i < mt_live) {
+                        const float x[8] = {ar[i][0][0], ar[i][0][1], ar[i][0][2], ar[i][0][3],
+                                            ar[i][1][0], ar[i][1][1], ar[i][1][2], ar[i][1][3]};
+                        split3(x, al[i][0], al[i][1], al[i][2]);
+                    }
                 }
 #pragma unroll
                 for (int ty = 0; ty < KH; ++ty) {
@@ -1593,17 +1595,20 @@ __global__ __launch_bounds__(kWgxWaves * 64) void conv_wgrad_x3_kernel(WgxGeom g
                         wr = nrow[12];
                     }
                     __builtin_amdgcn_sched_barrier(0);
+                    // channel tile outermost, under ONE uniform branch per tile: a wave whose group holds fewer than MT
+                    // live tiles skips the dead ones (consecutive MFMAs still alternate over the three tx accumulators)
 #pragma unroll
-                    for (int gq = 0; gq < NPROD; ++gq) {
-                        const int pa = NPROD == 9 ? kPairA[(gq + 6) % 9] : kPairA[gq];
-                        const int pb = NPROD == 9 ? kPairB[(gq + 6) % 9] : kPairB[gq];
+                    for (int i = 0; i < MT; ++i) {
+                        if (i < mt_live) {
 #pragma unroll
-                        for (int tx = 0; tx < KW; ++tx) {
-                            const bf16x8 bv = __builtin_bit_cast(bf16x8, bq[KW == 1 ? 1 : tx][pb]);
+                            for (int gq = 0; gq < NPROD; ++gq) {
+                                const int pa = NPROD == 9 ? kPairA[(gq + 6) % 9] : kPairA[gq];
+                                const int pb = NPROD == 9 ? kPairB[(gq + 6) % 9] : kPairB[gq];
 #pragma unroll
-                            for (int i = 0; i < MT; ++i) {
-                                acc[ty][tx][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                                    __builtin_bit_cast(bf16x8, al[i][pa]), bv, acc[ty][tx][i], 0, 0, 0);
+                                for (int tx = 0; tx < KW; ++tx)
+                                    acc[ty][tx][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                                        __builtin_bit_cast(bf16x8, al[i][pa]), __builtin_bit_cast(bf16x8, bq[KW == 1 ? 1 : tx][pb]),
+                                        acc[ty][tx][i], 0, 0, 0);
                             }
                         }
                     }
