@@ -1,4 +1,5 @@
-// Implicit-GEMM convolutions for gfx950 on v_mfma_f32_16x16x4_f32 (exact fp32, 157 TF peak).
+// Convolutions for gfx950: split-bf16 kernels on v_mfma_f32_16x16x32_bf16 (fp32 results, see conv_fwd_x3_kernel /
+// conv_wgrad_x3_kernel below), native fp32 implicit GEMM on v_mfma_f32_16x16x4_f32, direct stem kernels.
 // Replaces nn.Conv2d 3x3/1x1 and nn.Conv1d k3/k1 forward, input-gradient and weight-gradient
 // (reference networks/classifiers.py:526-531, 77-81, 149-154, 42-46), NCHW, stride 1, "same"
 // padding.  These kernels carry ~99 % of the step's FLOPs and are MFMA-bound.
