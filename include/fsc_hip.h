@@ -61,8 +61,10 @@ int fsc_frontend_stft_fwd(const float* wave, int n, int t, long wave_stride,
 
 /* ------------------------------------------------------------------ convolution (K7, K10)
  * nn.Conv2d 3x3 pad 1 / 1x1 (classifiers.py:526-531, 77-81) and nn.Conv1d k3 / k1
- * (classifiers.py:149-154, 42-46; H == 1, kh == 1).  Implicit GEMM on
- * v_mfma_f32_16x16x4_f32, weights pre-packed per step by fsc_conv_pack_weights. */
+ * (classifiers.py:149-154, 42-46; H == 1, kh == 1).  fp32 in, fp32 out, fp32 accumulation; the products run on
+ * v_mfma_f32_16x16x32_bf16 through an exact three-limb bf16 split (default) or on v_mfma_f32_16x16x4_f32
+ * (fsc_conv_set_arith), stem layers (c_in <= 4) on the vector ALUs.  Weights are re-packed per use by
+ * fsc_conv_pack_weights; the packed format is private to the library and depends on shape and arithmetic mode. */
 
 typedef struct {
     int n, c_in, c_out, h, w; /* output spatial size == input spatial size (stride 1, same pad) */
