@@ -392,12 +392,12 @@ __global__ __launch_bounds__(kXWaves * 64) void conv_fwd_x3_kernel(Geom g, const
     constexpr int PADH = KH / 2, PADW = KW / 2;
     constexpr int KCH = kXChunk;                    // channels per K chunk
     constexpr int SPC = TAPS;                       // steps per full chunk (one per tap)
-    constexpr int NSTG = TAPS == 1 ? 4 : 2;         // input stages: the input DMA runs NSTG - 1 chunks ahead (a 1x1
-                                                    // chunk is a single step, shorter than the HBM latency)
+    constexpr int NSTG = TAPS == 1 ? (PT == 2 ? 3 : 4) : 2;   // input stages: the input DMA runs NSTG - 1 chunks ahead
+                                                    // (a 1x1 chunk is a single step)
     constexpr int WUNITS = COT * 3;                 // 1 KB fragment images per step
     constexpr int WSLOT_F = WUNITS * 256;           // floats per ring slot
     constexpr int NWQ = (WUNITS + kXWaves - 1) / kXWaves;
-    constexpr int RING = COT > 8 ? 2 : 3;           // weight slots: W runs RING - 1 steps ahead of the MFMAs
+    constexpr int RING = (COT > 8 || (TAPS == 1 && PT == 2)) ? 2 : 3;   // weight slots: W runs RING - 1 steps ahead
     constexpr int AHEAD = RING - 1;
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -754,8 +754,9 @@ __global__ __launch_bounds__(kXWaves * 64) void conv_fwd_x3_kernel(Geom g, const
             // stores share the VM counter with the DMAs and may retire out of order with them: the first
             // barrier after a tile's output stores drains everything
             if (stores_pending) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            else if (TAPS == 1) wait_weights(input_age == 0);         // every step opens a chunk: only the box issued in the
-                                                                      // previous step (younger than the one needed now) may fly
+            else if (TAPS == 1) wait_weights(NSTG == 4 && input_age == 0);   // every step opens a chunk: with four stages the
+                                                                      // box issued in the previous step (younger than the one
+                                                                      // needed now) may stay in flight
             else wait_weights(input_age <= AHEAD - 1 && stg_n == stg);
             raw_barrier();
         }
@@ -1728,7 +1729,7 @@ bool plan_fwd_x3_pt(const fsc_conv_desc& d_in, int dgrad, int nprod, int pt, int
     }
     const int nch = 1;
     const int kch = kXChunk;
-    const int nstg = taps == 1 ? 4 : 2;                  // input stages (kernel NSTG)
+    const int nstg = taps == 1 ? (pt == 2 ? 3 : 4) : 2;  // input stages (kernel NSTG)
     g.n = d.n; g.h = d.h; g.w = d.w; g.hw = (long)d.h * d.w;
     g.cin = dgrad ? d.c_out : d.c_in;
     g.cout = dgrad ? d.c_in : d.c_out;
@@ -1753,7 +1754,7 @@ bool plan_fwd_x3_pt(const fsc_conv_desc& d_in, int dgrad, int nprod, int pt, int
     g.flat = 0;
     const int pix_cap = kXWaves * p.pt * 16;
     const size_t lds_total = 160 * 1024;
-    const size_t ring = (size_t)(p.cot > 8 ? 2 : 3) * p.cot * 3 * 1024;
+    const size_t ring = (size_t)((p.cot > 8 || (taps == 1 && pt == 2)) ? 2 : 3) * p.cot * 3 * 1024;
     const size_t scratch = (size_t)kXWaves * 16 * 20 * sizeof(float);      // per-wave epilogue transpose tiles
     int cap_pos = (int)((lds_total - ring - scratch) / (nstg * kch * sizeof(float))) - 4;
     if (cap_pos > 64 * kXNptMax - 4) cap_pos = 64 * kXNptMax - 4;
@@ -1834,9 +1835,10 @@ bool plan_fwd_x3_pt(const fsc_conv_desc& d_in, int dgrad, int nprod, int pt, int
 // 256-pixel tiles (two pixel tiles per wave) where they fit, else 128-pixel tiles (1x1 convolutions stage
 // 64-channel chunks and always take the small tile)
 bool plan_fwd_x3(const fsc_conv_desc& d, int dgrad, int nprod, FwdPlan* out) {
-    if (d.kh * d.kw > 1) {
-        // (9-10 tiles with a two-slot ring compile, but at 256 registers they spill and gain nothing: measured)
-        if (plan_fwd_x3_pt(d, dgrad, nprod, 2, 8, out)) return true;
+    // (9-10 tiles with a two-slot ring compile, but at 256 registers they spill and gain nothing: measured)
+    if (plan_fwd_x3_pt(d, dgrad, nprod, 2, 8, out)) {
+        // 1x1 layers with few work items keep the 128-pixel tile (256-pixel tiles halve an already short grid)
+        if (d.kh * d.kw > 1 || out->grid_x * out->co_blocks >= 512) return true;
     }
     return plan_fwd_x3_pt(d, dgrad, nprod, 1, 8, out);
 }
@@ -1950,11 +1952,9 @@ void launch_x3_pt(const FwdPlan& p, dim3 grid, const float* in, const float* pac
 template <int KH, int KW, int COT, int NPROD>
 void launch_x3(const FwdPlan& p, dim3 grid, const float* in, const float* packed, const float* bias, float* out,
                int accumulate, hipStream_t st) {
-    if constexpr (KH * KW > 1) {
-        if (p.pt == 2) {
-            launch_x3_pt<KH, KW, COT, 2, NPROD>(p, grid, in, packed, bias, out, accumulate, st);
-            return;
-        }
+    if (p.pt == 2) {
+        launch_x3_pt<KH, KW, COT, 2, NPROD>(p, grid, in, packed, bias, out, accumulate, st);
+        return;
     }
     launch_x3_pt<KH, KW, COT, 1, NPROD>(p, grid, in, packed, bias, out, accumulate, st);
 }
