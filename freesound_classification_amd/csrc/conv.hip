@@ -1211,35 +1211,51 @@ __global__ __launch_bounds__((wg_threads<KH, KW>())) void conv_wgrad_kernel(WgGe
 #pragma unroll
         for (int i = 0; i < MT; ++i) acc[s][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    const float* zero = g_zero16;
-    // The DMA loops stay rolled on purpose: unrolled, hipcc hoists dozens of registers of
-    // unit-invariant 64-bit row offsets out of the unit loop and occupancy drops to one workgroup.
+    // Rows beyond c_out / c_in are never copied: zero them once.  The copy loops walk the live rows only with one
+    // pointer increment per instruction (lanes outside the image keep pointing at a zero word with stride 0);
+    // the earlier version recomputed a 64-bit row address per instruction: 6 scalar instructions per MFMA (PMC).
+    constexpr int CI_STAGE_MAX = PACKED ? 16 : CI_BLK;
+    const int co_live = min(CO_BLK, g.cout - co0);
+    const int ci_live = PACKED ? g.cin : min(CI_BLK, g.cin - ci0);
+    for (int i = (co_live > 0 ? co_live : 0) * DS + tid; i < CO_BLK * DS; i += WAVES * 64) dl[i] = 0.f;
+    for (int i = (ci_live > 0 ? ci_live : 0) * g.plane + tid; i < CI_STAGE_MAX * g.plane; i += WAVES * 64) il[i] = 0.f;
+    const char* zero = reinterpret_cast<const char*>(g_zero16);
+    const long row_bytes = (long)WAVES * g.hw * (long)sizeof(float);       // this wave copies every WAVES-th row
     auto issue_unit = [&](int u) {
         int t = u;
         const int twi = t % g.tiles_w; t /= g.tiles_w;
         const int thi = t % g.tiles_h; t /= g.tiles_h;
         const int n0 = t * g.nb, h0 = thi * g.th, w0 = twi * g.tw;
-        long po = -1;
-        if (pb >= 0 && n0 + pb < g.n && h0 + pr < g.h && w0 + pc < g.w)
-            po = (long)(n0 + pb) * g.cout * g.hw + (long)(h0 + pr) * g.w + (w0 + pc);
+        {
+            const bool live = pb >= 0 && n0 + pb < g.n && h0 + pr < g.h && w0 + pc < g.w;
+            const char* src = live ? reinterpret_cast<const char*>(dout + (long)(n0 + pb) * g.cout * g.hw + (long)(h0 + pr) * g.w +
+                                                                   (w0 + pc) + (long)(co0 + wid) * g.hw)
+                                   : zero;
+            const long step = live ? row_bytes : 0;
+            float* dst = dl + wid * DS;
 #pragma unroll 1
-        for (int row = wid; row < CO_BLK; row += WAVES) {
-            const bool live = po >= 0 && co0 + row < g.cout;
-            glds4(live ? dout + po + (long)(co0 + row) * g.hw : zero, dl + row * DS);
+            for (int row = wid; row < co_live; row += WAVES) {
+                glds4(reinterpret_cast<const float*>(src), dst);
+                src += step;
+                dst += WAVES * DS;
+            }
         }
 #pragma unroll
         for (int j = 0; j < MAXPOS64; ++j) {
             if (j * 64 < g.npos) {                       // uniform
-                long xo = -1;
                 const int gh = h0 + qr[j] - PADH, gw = w0 + qc[j] - PADW;
-                if (qb[j] >= 0 && n0 + qb[j] < g.n && gh >= 0 && gh < g.h && gw >= 0 && gw < g.w)
-                    xo = (long)(n0 + qb[j]) * g.cin * g.hw + (long)gh * g.w + gw;
+                const bool live = qb[j] >= 0 && n0 + qb[j] < g.n && gh >= 0 && gh < g.h && gw >= 0 && gw < g.w;
                 if (qb[j] >= 0) {                        // lanes past npos stay out of the DMA
-                    const int ci_stage = PACKED ? g.cin : CI_BLK;
+                    const char* src = live ? reinterpret_cast<const char*>(in + (long)(n0 + qb[j]) * g.cin * g.hw + (long)gh * g.w + gw +
+                                                                           (long)(ci0 + wid) * g.hw)
+                                           : zero;
+                    const long step = live ? row_bytes : 0;
+                    float* dst = il + wid * g.plane + j * 64;
 #pragma unroll 1
-                    for (int cl = wid; cl < ci_stage; cl += WAVES) {
-                        const bool live = xo >= 0 && ci0 + cl < g.cin;
-                        glds4(live ? in + xo + (long)(ci0 + cl) * g.hw : zero, il + cl * g.plane + j * 64);
+                    for (int cl = wid; cl < ci_live; cl += WAVES) {
+                        glds4(reinterpret_cast<const float*>(src), dst);
+                        src += step;
+                        dst += WAVES * g.plane;
                     }
                 }
             }
