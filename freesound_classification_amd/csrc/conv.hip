@@ -2156,7 +2156,7 @@ struct WgxPlan {
 
 bool plan_wgrad_x3(const fsc_conv_desc& d, int nprod, WgxPlan* out) {
     const int taps = d.kh * d.kw;
-    if (taps == 1 || d.c_in < 32 || d.c_out < 32 || (long)d.h * d.w < 64) return false;
+    if (taps == 1 || d.c_in < 32 || d.c_out < 32) return false;
     WgxPlan p{};
     WgxGeom& g = p.g;
     g.n = d.n; g.cin = d.c_in; g.cout = d.c_out; g.h = d.h; g.w = d.w; g.hw = (long)d.h * d.w;
