@@ -153,11 +153,24 @@ __global__ __launch_bounds__(kThreads) void frontend_kernel(FrontendArgs a) {
         __syncthreads();
         if (live) {
             if (MEL) {
+                // the band of a high mel bin is ~90 spectrum bins long: four independent partial sums keep four
+                // weight loads (L2) in flight instead of one load-to-use latency per bin
                 for (int m = st; m < a.n_mel; m += tpf) {
                     const int s = a.mel_start[m], len = a.mel_len[m];
-                    float acc = 0.f;
-                    for (int j = 0; j < len; ++j) acc = fmaf(a.mel_w[(long)j * a.n_mel + m], mag[s + j], acc);
-                    tile[m * tile_ld + fl] = logf(acc + a.log_eps);
+                    const float* wcol = a.mel_w + m;
+                    const float* mg = mag + s;
+                    float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
+                    int j = 0;
+                    for (; j + 3 < len; j += 4) {
+                        const float w0 = wcol[(long)j * a.n_mel], w1 = wcol[(long)(j + 1) * a.n_mel];
+                        const float w2 = wcol[(long)(j + 2) * a.n_mel], w3 = wcol[(long)(j + 3) * a.n_mel];
+                        acc0 = fmaf(w0, mg[j], acc0);
+                        acc1 = fmaf(w1, mg[j + 1], acc1);
+                        acc2 = fmaf(w2, mg[j + 2], acc2);
+                        acc3 = fmaf(w3, mg[j + 3], acc3);
+                    }
+                    for (; j < len; ++j) acc0 = fmaf(wcol[(long)j * a.n_mel], mg[j], acc0);
+                    tile[m * tile_ld + fl] = logf((acc0 + acc1) + (acc2 + acc3) + a.log_eps);
                 }
             } else {
                 for (int k = st; k < nbins; k += tpf)
@@ -193,7 +206,7 @@ bool pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
 int launch(const FrontendArgs& base, bool mel, int n, hipStream_t stream) {
     FrontendArgs a = base;
     const int nc = a.n_fft / 2;
-    int tpf = nc / 4;
+    int tpf = nc / 8;            // two butterflies per thread and pass: two frames share the barriers of a workgroup
     if (tpf < 64) tpf = 64;
     if (tpf > kThreads) tpf = kThreads;
     a.tpf = tpf;
