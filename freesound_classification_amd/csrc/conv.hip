@@ -1852,6 +1852,15 @@ bool plan_fwd_x3_pt(const fsc_conv_desc& d_in, int dgrad, int nprod, int pt, int
 // 64-channel chunks and always take the small tile)
 bool plan_fwd_x3(const fsc_conv_desc& d, int dgrad, int nprod, FwdPlan* out) {
     // (9-10 tiles with a two-slot ring compile, but at 256 registers they spill and gain nothing: measured)
+    // 150- and 225-channel layers (10 / 15 tiles): ONE wide block on 128-pixel tiles instead of two 5- or 8-tile blocks
+    // on 256-pixel tiles -- the same MFMAs per wave-step with half the activation splitting, and the input is staged
+    // once (+5 ... +18 % measured; 16-tile blocks for the 506 / 759-channel layers gained nothing)
+    {
+        const int tiles = fsc::ceil_div(dgrad ? d.c_in : d.c_out, 16);
+        if (d.kh * d.kw > 1 && (tiles == 10 || tiles == 15) && plan_fwd_x3_pt(d, dgrad, nprod, 1, tiles, out) && out->cot == tiles)
+            return true;
+
+    }
     if (plan_fwd_x3_pt(d, dgrad, nprod, 2, 8, out)) {
         // 1x1 layers with few work items keep the 128-pixel tile (256-pixel tiles halve an already short grid)
         if (d.kh * d.kw > 1 || out->grid_x * out->co_blocks >= 512) return true;
@@ -2005,9 +2014,32 @@ int launch_fwd_cot(const FwdPlan& p, const float* in, const float* packed, const
     return 0;
 }
 
+template <int KH, int KW, int COT>
+int launch_fwd_wide(const FwdPlan& p, const float* in, const float* packed, const float* bias, float* out, int accumulate,
+                      hipStream_t st) {
+    // 10 / 15 channel tiles: split-bf16 kernel only (3x3 / k3, one pixel tile per wave, two-slot weight ring)
+    if constexpr (KH * KW > 1) {
+        dim3 grid((unsigned)p.launch_x, 1, p.g.ksplit);
+        if (p.g.ksplit > 1 && !accumulate) {
+            const size_t bytes = sizeof(float) * (size_t)p.g.n * p.g.cout * p.g.hw;
+            hipError_t e = hipMemsetAsync(out, 0, bytes, st);
+            FSC_CHECK_ARG(e == hipSuccess, "fsc_conv_fwd: memset failed: %s", hipGetErrorString(e));
+        }
+        if (p.x3 == 6) launch_x3_pt<KH, KW, COT, 1, 6>(p, grid, in, packed, bias, out, accumulate, st);
+        else launch_x3_pt<KH, KW, COT, 1, 9>(p, grid, in, packed, bias, out, accumulate, st);
+        FSC_LAUNCH_CHECK("fsc_conv_fwd(x3)");
+        return 0;
+    } else {
+        fsc::set_error("fsc_conv_fwd: internal: wide channel block for a 1x1 kernel");
+        return 22;
+    }
+}
+
 template <int KH, int KW>
 int launch_fwd(const FwdPlan& p, const float* in, const float* packed, const float* bias, float* out, int accumulate,
                hipStream_t st) {
+    if (p.cot == 10) return launch_fwd_wide<KH, KW, 10>(p, in, packed, bias, out, accumulate, st);
+    if (p.cot == 15) return launch_fwd_wide<KH, KW, 15>(p, in, packed, bias, out, accumulate, st);
     switch (p.cot) {
         case 1: return launch_fwd_cot<KH, KW, 1>(p, in, packed, bias, out, accumulate, st);
         case 2: return launch_fwd_cot<KH, KW, 2>(p, in, packed, bias, out, accumulate, st);
