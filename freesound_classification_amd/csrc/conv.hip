@@ -1416,6 +1416,21 @@ struct WgxGeom {
     int in_instr;                   // input DMA instructions per channel = ceil((th + 2) * rowp / 64)
 };
 
+// The `live` co tiles of a block are spread over its ng groups as evenly as possible; the groups that take one tile
+// more are chosen so that the SIMD pairs (group q and q + ng/2 share the SIMDs) carry equal loads: 10 tiles on
+// 4 groups -> 3, 2, 2, 3 (not 3, 3, 3, 1).  Returns the first tile of group q and its tile count.
+__host__ __device__ inline void wgx_group(int live, int ng, int q, int* start, int* count) {
+    const int base = live / ng, extra = live - base * ng;
+    int st = 0, cnt = 0;
+    for (int k = 0; k <= q; ++k) {
+        const int rank = k < (ng + 1) / 2 ? 2 * k : 2 * (ng - 1 - k) + 1;     // order 0, ng-1, 1, ng-2, ...
+        cnt = base + (rank < extra ? 1 : 0);
+        if (k < q) st += cnt;
+    }
+    *start = st;
+    *count = cnt;
+}
+
 template <int KH, int KW, int MT, int NPROD>
 __global__ __launch_bounds__(kWgxWaves * 64) void conv_wgrad_x3_kernel(WgxGeom g, const float* __restrict__ in,
                                                                        const float* __restrict__ dout,
@@ -1440,12 +1455,10 @@ __global__ __launch_bounds__(kWgxWaves * 64) void conv_wgrad_x3_kernel(WgxGeom g
     const int split = blockIdx.y;
     const int total_tiles = (g.cout + 15) >> 4;
     // live co tiles of this wave: i < mt_live
-    int mt_live = g.tpg;
+    int mt_live, g_start;
     {
-        const int first = tile0 + cog * g.tpg;
-        int lim = tile0 + g.tpb < total_tiles ? tile0 + g.tpb : total_tiles;
-        if (first + mt_live > lim) mt_live = lim - first;
-        if (mt_live < 0) mt_live = 0;
+        const int blk_live = tile0 + g.tpb < total_tiles ? g.tpb : total_tiles - tile0;      // live co tiles of this block
+        wgx_group(blk_live > 0 ? blk_live : 0, g.ng, cog, &g_start, &mt_live);
         if (ci0 + cit * 16 >= g.cin) mt_live = 0;                          // ci tile wholly beyond c_in
     }
 
@@ -1526,7 +1539,7 @@ __global__ __launch_bounds__(kWgxWaves * 64) void conv_wgrad_x3_kernel(WgxGeom g
 
     // this lane's runs in the two k-steps of a unit: run = 4 st + kq -> (row, first column)
     const int runs_shift = g.tw == 8 ? 0 : g.tw == 16 ? 1 : g.tw == 32 ? 2 : 3;      // log2(runs per box row)
-    const int a_row = ((cog * g.tpg) * 16 + lm) * DSO;
+    const int a_row = (g_start * 16 + lm) * DSO;
     const int b_row = (cit * 16 + lm) * g.plane;
 
     constexpr int kPairA[9] = {1, 0, 2, 0, 1, 0, 2, 1, 2};      // limb pairs, 0 = h, 1 = m, 2 = l; x6 uses the first six
@@ -1647,8 +1660,8 @@ __global__ __launch_bounds__(kWgxWaves * 64) void conv_wgrad_x3_kernel(WgxGeom g
 #pragma unroll
             for (int i = 0; i < MT; ++i) {
                 if (i < g.tpg) {
-                    const int tile = tile0 + cog * g.tpg + i;
-                    if (tile * 16 < g.co_pad && cog * g.tpg + i < g.tpb) {
+                    const int tile = tile0 + g_start + i;
+                    if (i < mt_live) {          // (tiles beyond c_out and ci rows beyond c_in are never read by the reduce)
                         const f32x4 a = acc[ty][tx][i];
                         *reinterpret_cast<float4*>(part + row * g.co_pad + tile * 16 + kq * 4) = make_float4(a[0], a[1], a[2], a[3]);
                     }
@@ -2222,7 +2235,27 @@ bool plan_wgrad_x3(const fsc_conv_desc& d, int nprod, WgxPlan* out) {
         if (lds > 160 * 1024) continue;
         // MFMA share of a wave's issue slots grows with the co tiles it owns (54 MFMAs per 44 + 201/tpg VALU)
         static const double kTileWeight[5] = {0.0, 0.55, 0.78, 0.92, 1.0};
-        const double eff = (double)tiles_co * tiles_ci / ((double)co_blocks * ng * tpg * ci_blocks * nt) * kTileWeight[tpg];
+        // Dead tiles are skipped, so a workgroup is as slow as its busiest SIMD (waves s and s + 4 share SIMD s;
+        // wave = (co group wid / nt, ci tile wid % nt)): sum that over all workgroups of the grid
+        long busiest = 0;
+        for (int cb = 0; cb < co_blocks; ++cb)
+            for (int ib = 0; ib < ci_blocks; ++ib) {
+                int worst = 0;
+                for (int sd = 0; sd < 4; ++sd) {
+                    int load = 0;
+                    for (int wv = sd; wv < kWgxWaves; wv += 4) {
+                        const int cog = wv / nt, cit = wv % nt;
+                        const int blk_live = cb * tpb + tpb < tiles_co ? tpb : tiles_co - cb * tpb;
+                        int first, live;
+                        wgx_group(blk_live > 0 ? blk_live : 0, ng, cog, &first, &live);
+                        if (ib * nt + cit >= tiles_ci) live = 0;
+                        load += live;
+                    }
+                    if (load > worst) worst = load;
+                }
+                busiest += worst;
+            }
+        const double eff = (double)tiles_co * tiles_ci / (4.0 * (double)busiest) * kTileWeight[tpg];
         if (eff > best_eff) {
             best_eff = eff;
             g.ng = ng; g.nt = nt; g.tpb = tpb; g.tpg = tpg; g.co_blocks = co_blocks; g.ci_blocks = ci_blocks;
