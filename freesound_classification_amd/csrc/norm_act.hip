@@ -461,12 +461,10 @@ __global__ __launch_bounds__(kThreads) void bwd_apply_unpool_kernel(BwdArgs a, c
             const float d = k * (dz - c1 - xh * c2);
             acc += d;
             const int pos = pi[i];
-            r0[2 * ox] = pos == 0 ? d : 0.f;
-            r0[2 * ox + 1] = pos == 1 ? d : 0.f;
-            if (ph == 2) {
-                r0[w + 2 * ox] = pos == 2 ? d : 0.f;
-                r0[w + 2 * ox + 1] = pos == 3 ? d : 0.f;
-            }
+            // one 8-byte store per window row (4-byte aligned): half the store instructions of the scalar form
+            typedef float f32x2 __attribute__((ext_vector_type(2)));
+            *reinterpret_cast<f32x2*>(r0 + 2 * ox) = (f32x2){pos == 0 ? d : 0.f, pos == 1 ? d : 0.f};
+            if (ph == 2) *reinterpret_cast<f32x2*>(r0 + w + 2 * ox) = (f32x2){pos == 2 ? d : 0.f, pos == 3 ? d : 0.f};
         }
         if ((w & 1) && tc == 0) {                      // column floor-mode pooling never read
             r0[w - 1] = 0.f;
