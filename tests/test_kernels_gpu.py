@@ -194,6 +194,43 @@ def test_conv_split_bf16_is_fp32_accurate(case, mode, restore_conv_arith):
     assert maxdiff(got, ref) < 4.0 * e_fwd32 + 1e-6
 
 
+def test_conv_split_bf16_random_shapes_against_native(restore_conv_arith):
+    """Planner sweep: 60 random shapes (3x3, k3, 1x1; channel counts around every tile / chunk boundary, odd
+    widths, single-row images, batch sizes that do not fill a box) through fwd, dgrad (plain and accumulating)
+    and wgrad in the split arithmetic against the native fp32-MFMA kernels on the same device tensors."""
+    rng = np.random.RandomState(7)
+    chans = [32, 33, 40, 48, 56, 57, 63, 64, 65, 72, 95, 96, 100, 112, 128, 129, 150, 160, 161, 200, 225, 256]
+    seen = set()
+    for trial in range(60):
+        kind = trial % 3
+        kh, kw = [(3, 3), (1, 3), (1, 1)][kind]
+        cin, cout = int(rng.choice(chans)), int(rng.choice(chans))
+        n = int(rng.randint(1, 6))
+        if kh == 3:
+            h, w = int(rng.randint(2, 20)), int(rng.randint(5, 48))
+        else:
+            h, w = 1, int(rng.randint(24, 400))
+        torch.manual_seed(trial)
+        x = torch.randn(n, cin, h, w, device=DEV)
+        wt = torch.randn(cout, cin, kh, kw, device=DEV) / (cin * kh * kw) ** 0.5
+        b = torch.randn(cout, device=DEV)
+        gy = torch.randn(n, cout, h, w, device=DEV)
+        base = torch.randn_like(x)
+        res = {}
+        for mode in (0, 6):
+            F.set_conv_arith(mode)
+            d = F._desc(n, cin, cout, h, w, kh, kw)
+            seen.update(F.plan_name(d, m).split("<")[0] for m in (0, 1, 2))
+            res[mode] = (F.conv_forward(x, wt, b), F.conv_dgrad(gy, wt, x.shape),
+                         F.conv_dgrad(gy, wt, x.shape, accumulate_into=base.clone()), F.conv_wgrad(x, gy, wt.shape))
+        k_red = cin * kh * kw
+        tols = (4e-6 * k_red ** 0.5 + 1e-5, 4e-6 * (cout * kh * kw) ** 0.5 + 1e-5, 4e-6 * (cout * kh * kw) ** 0.5 + 1e-5,
+                4e-6 * (n * h * w) ** 0.5 + 1e-5)
+        for name, a, bb, tol in zip(("fwd", "dgrad", "dgrad+acc", "wgrad"), res[0], res[6], tols):
+            assert maxdiff(a, bb) < tol, (trial, name, (n, cin, cout, h, w, kh, kw), maxdiff(a, bb), tol)
+    assert {"conv_fwd_x3_kernel", "conv_wgrad_x3_kernel", "conv_fwd_kernel", "conv_wgrad_kernel"} <= seen, seen
+
+
 def test_conv_split_bf16_exact_on_bf16_representable_inputs(restore_conv_arith):
     """With inputs that are exactly representable in bf16 (single non-zero limb) and power-of-two
     friendly sums the split kernel reproduces the integer result exactly."""
