@@ -555,9 +555,11 @@ __global__ __launch_bounds__(kXWaves * 64) void conv_fwd_x3_kernel(Geom g, const
     // the coming step does not read yet.  Counting less than what is really in flight only waits longer (the
     // output stores of the previous tile share the counter: the first barriers of a tile also wait for them).
     constexpr int NWLO = RING == 3 ? WUNITS / kXWaves : 0;     // two slots: W(S) was issued in step S-1, nothing newer
-    auto wait_weights = [&](bool input_in_flight) {
+    // `w_young`: the previous step issued weights (W(S+1)); without them (last steps of a K slice with no item to
+    // follow) the youngest outstanding units are W(S) itself and nothing may be left in flight.
+    auto wait_weights = [&](bool w_young, bool input_in_flight) {
 #define FSC_VMW(k) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(k) : "memory")
-        if (input_in_flight) {
+        if (input_in_flight && w_young) {
             switch (g.x_npt) {
                 case 3: FSC_VMW(NWLO + 3 * (KCH / 8)); break;
                 case 4: FSC_VMW(NWLO + 4 * (KCH / 8)); break;
@@ -565,8 +567,18 @@ __global__ __launch_bounds__(kXWaves * 64) void conv_fwd_x3_kernel(Geom g, const
                 case 6: FSC_VMW(NWLO + 6 * (KCH / 8)); break;
                 default: FSC_VMW(NWLO); break;
             }
-        } else {
+        } else if (input_in_flight) {
+            switch (g.x_npt) {
+                case 3: FSC_VMW(3 * (KCH / 8)); break;
+                case 4: FSC_VMW(4 * (KCH / 8)); break;
+                case 5: FSC_VMW(5 * (KCH / 8)); break;
+                case 6: FSC_VMW(6 * (KCH / 8)); break;
+                default: FSC_VMW(0); break;
+            }
+        } else if (w_young) {
             FSC_VMW(NWLO);
+        } else {
+            FSC_VMW(0);
         }
 #undef FSC_VMW
     };
@@ -636,6 +648,7 @@ __global__ __launch_bounds__(kXWaves * 64) void conv_fwd_x3_kernel(Geom g, const
     bool first_step = true;                                          // the prologue has already synchronised for it
     bool has_next = false;                                           // another item follows the current one
     bool stores_pending = false;                                     // the previous tile's output stores may be in flight
+    bool w_prev = false;                                             // the previous step issued weight DMAs
 
     // One MFMA step.  `cur` holds the split B operand of step S; the B operand of the next step (of the next
     // tile after a tile's last step) is read from LDS and split into `nxt` between the MFMAs.  Phase i = the
@@ -729,13 +742,14 @@ __global__ __launch_bounds__(kXWaves * 64) void conv_fwd_x3_kernel(Geom g, const
     // ring wrap, so the scalar bookkeeping shrinks to a few instructions (every instruction beside the MFMAs
     // costs: about two per MFMA are free, measured).
     auto step_fast = [&](const Limbs& cur, Limbs& nxt) {
-        wait_weights(input_age <= AHEAD - 1);
+        wait_weights(true, input_age <= AHEAD - 1);      // (the previous step had S + AHEAD < s_hi as well)
         raw_barrier();
         const int ty = (sc + 1) / KW, tx = (sc + 1) - ty * KW;
         const float* il = ibase + stg * istage + kq * 8 * g.plane + ty * g.cols + tx;
         const u32x4* wl = reinterpret_cast<const u32x4*>(wring + slot * WSLOT_F) + lane;
         phases(il, wl, cur, nxt, [&] {
             issue_w(wsrc + AHEAD * WSLOT_F, slot == 0 ? RING - 1 : slot - 1);
+            w_prev = true;
             ++input_age;
         });
         wsrc += WSLOT_F;
@@ -754,10 +768,10 @@ __global__ __launch_bounds__(kXWaves * 64) void conv_fwd_x3_kernel(Geom g, const
             // stores share the VM counter with the DMAs and may retire out of order with them: the first
             // barrier after a tile's output stores drains everything
             if (stores_pending) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            else if (TAPS == 1) wait_weights(NSTG == 4 && input_age == 0);   // every step opens a chunk: with four stages the
-                                                                      // box issued in the previous step (younger than the one
-                                                                      // needed now) may stay in flight
-            else wait_weights(input_age <= AHEAD - 1 && stg_n == stg);
+            else if (TAPS == 1) wait_weights(w_prev, NSTG == 4 && input_age == 0);   // every step opens a chunk: with four
+                                                                      // stages the box issued in the previous step (younger than
+                                                                      // the one needed now) may stay in flight
+            else wait_weights(w_prev, input_age <= AHEAD - 1 && stg_n == stg);
             raw_barrier();
         }
         first_step = false;
@@ -768,8 +782,10 @@ __global__ __launch_bounds__(kXWaves * 64) void conv_fwd_x3_kernel(Geom g, const
                 // DMA issue for the step after next (its slot was read during the previous step; the weight
                 // stream wraps around at an item end) and, at the first step of a chunk, of the input box
                 // NSTG - 1 chunks ahead (its stage was last read during the previous step)
+                w_prev = true;
                 if (S + AHEAD < s_hi) issue_w(wsrc + AHEAD * WSLOT_F, slot == 0 ? RING - 1 : slot - 1);
                 else if (has_next) issue_w(wnext + (S + AHEAD - s_hi) * WSLOT_F, slot == 0 ? RING - 1 : slot - 1);
+                else w_prev = false;
                 ++input_age;
                 if (sc == 0 && produce()) input_age = 0;
         });
@@ -1832,7 +1848,7 @@ bool plan_fwd_x3_pt(const fsc_conv_desc& d_in, int dgrad, int nprod, int pt, int
     {
         const long wgs = p.grid_x * p.co_blocks;
         const int nchunks = g.x_nfull + (g.x_tail_oct ? 1 : 0);
-        if (wgs < 200) {
+        if (wgs < 200 && !getenv("FSC_DBG_NOKSPLIT")) {
             long ks = (384 + wgs - 1) / wgs;
             if (ks > 8) ks = 8;
             if (ks > nchunks / 2) ks = nchunks / 2;

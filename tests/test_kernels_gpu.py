@@ -195,13 +195,13 @@ def test_conv_split_bf16_is_fp32_accurate(case, mode, restore_conv_arith):
 
 
 def test_conv_split_bf16_random_shapes_against_native(restore_conv_arith):
-    """Planner sweep: 60 random shapes (3x3, k3, 1x1; channel counts around every tile / chunk boundary, odd
+    """Planner sweep: 90 random shapes (3x3, k3, 1x1; channel counts around every tile / chunk boundary, odd
     widths, single-row images, batch sizes that do not fill a box) through fwd, dgrad (plain and accumulating)
     and wgrad in the split arithmetic against the native fp32-MFMA kernels on the same device tensors."""
     rng = np.random.RandomState(7)
-    chans = [32, 33, 40, 48, 56, 57, 63, 64, 65, 72, 95, 96, 100, 112, 128, 129, 150, 160, 161, 200, 225, 256]
+    chans = [32, 33, 40, 48, 56, 57, 63, 64, 65, 72, 95, 96, 100, 112, 128, 129, 150, 160, 161, 200, 225, 256, 257, 280, 299]
     seen = set()
-    for trial in range(60):
+    for trial in range(90):
         kind = trial % 3
         kh, kw = [(3, 3), (1, 3), (1, 1)][kind]
         cin, cout = int(rng.choice(chans)), int(rng.choice(chans))
@@ -209,7 +209,7 @@ def test_conv_split_bf16_random_shapes_against_native(restore_conv_arith):
         if kh == 3:
             h, w = int(rng.randint(2, 20)), int(rng.randint(5, 48))
         else:
-            h, w = 1, int(rng.randint(24, 400))
+            h, w = 1, int(rng.randint(24, 640))      # wide rows with > 256 channels: split-K slices of a few steps
         torch.manual_seed(trial)
         x = torch.randn(n, cin, h, w, device=DEV)
         wt = torch.randn(cout, cin, kh, kw, device=DEV) / (cin * kh * kw) ** 0.5
@@ -225,7 +225,7 @@ def test_conv_split_bf16_random_shapes_against_native(restore_conv_arith):
                          F.conv_dgrad(gy, wt, x.shape, accumulate_into=base.clone()), F.conv_wgrad(x, gy, wt.shape))
         k_red = cin * kh * kw
         tols = (4e-6 * k_red ** 0.5 + 1e-5, 4e-6 * (cout * kh * kw) ** 0.5 + 1e-5, 4e-6 * (cout * kh * kw) ** 0.5 + 1e-5,
-                4e-6 * (n * h * w) ** 0.5 + 1e-5)
+                6e-6 * (n * h * w) ** 0.5 + 2e-5)
         for name, a, bb, tol in zip(("fwd", "dgrad", "dgrad+acc", "wgrad"), res[0], res[6], tols):
             assert maxdiff(a, bb) < tol, (trial, name, (n, cin, cout, h, w, kh, kw), maxdiff(a, bb), tol)
     assert {"conv_fwd_x3_kernel", "conv_wgrad_x3_kernel", "conv_fwd_kernel", "conv_wgrad_kernel"} <= seen, seen
