@@ -528,7 +528,7 @@ __global__ __launch_bounds__(kXWaves * 64) void conv_fwd_x3_kernel(Geom g, const
 #pragma unroll
         for (int q = 0; q < NWQ; ++q) {
             const int u = q * kXWaves + wid;
-            if (u < WUNITS) glds16(src + u * 256, dst + u * 256);
+            if ((q + 1) * kXWaves <= WUNITS || u < WUNITS) glds16(src + u * 256, dst + u * 256);   // only the last round is partial
         }
     };
     auto issue_i = [&](int stage, int c) {                          // uses the current pos_off[]
@@ -797,9 +797,23 @@ __global__ __launch_bounds__(kXWaves * 64) void conv_fwd_x3_kernel(Geom g, const
         sc = sn;
         stg = stg_n;
     };
+    // dispatch: the slow step that opens a full chunk counts the interior steps that may take the lean path
+    int fast_left = 0;
     auto step = [&](int S, const Limbs& cur, Limbs& nxt) {
-        if (!first_step && !stores_pending && sc >= 1 && sc + 1 < nst && c < g.x_nfull && S + AHEAD < s_hi) step_fast(cur, nxt);
-        else step_slow(S, cur, nxt);
+        if (fast_left > 0) {
+            --fast_left;
+            step_fast(cur, nxt);
+        } else {
+            const bool opens_full_chunk = sc == 0 && c < g.x_nfull;
+            step_slow(S, cur, nxt);
+            if (opens_full_chunk) {
+                // steps S+1 .. of this chunk with sc >= 1, sc + 1 < SPC and S' + AHEAD < s_hi
+                int nf = SPC - 2;
+                const int cap = s_hi - AHEAD - (S + 1);
+                if (nf > cap) nf = cap;
+                fast_left = nf > 0 ? nf : 0;
+            }
+        }
     };
 
     const bool add_bias = bias != nullptr && blockIdx.z == 0;
