@@ -9,8 +9,9 @@ mel_2048_1024_128, 6 blocks base 100 growth 1.5, deep supervision from block 1, 
 (reference README.md:200-214), fp32.  N > 1: one process per GPU (torch.distributed.run), the
 same per-GPU batch on every rank (weak scaling), value = clips of all ranks / max-over-ranks time.
 
-Rank 0 prints one JSON line carrying `roofline` (dominant kernel = the implicit-GEMM conv
-kernel, algorithmic FLOPs over HIP-event time measured inside the timed region) and, at N = 1,
+Rank 0 prints one JSON line carrying `roofline` (dominant kernel = the conv kernel with the largest
+total time, FLOPs over HIP-event time measured inside the timed region), at N = 1 `alt_f32` (the same
+workload re-timed with the native fp32-MFMA conv kernels, outside the timed region of `value`) and
 `cpu_baseline` (the CPU oracle = pure-PyTorch restatement of the reference path, timed on this
 box's host cores on a bounded sample: batch 8 of the same model and clip length).
 """
@@ -110,6 +111,7 @@ def main():
     ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
     ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (default: the workload's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-alt", action="store_true", help="skip the extra native-fp32-MFMA measurement (alt_f32)")
     ap.add_argument("--no-kernel-timer", action="store_true")
     ap.add_argument("--kernel-table", action="store_true", help="print per-kernel timing to stderr")
     args = ap.parse_args()
@@ -182,7 +184,24 @@ def main():
         tmax = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
-    final_loss = float(loss)
+    final_loss = float(loss.detach())
+    # The same workload with the native fp32-MFMA conv kernels (FSC_CONV_ARITH=f32), for readers who want the
+    # number without the split-bf16 arithmetic; N = 1 only, outside the timed region of `value`.
+    alt = None
+    if world == 1 and not args.no_alt and F.get_conv_arith() != 0:
+        mode0 = F.get_conv_arith()
+        F.set_conv_arith(0)
+        for _ in range(2):
+            one_step()
+        torch.cuda.synchronize()
+        k_alt = max(2, min(args.steps, 5))
+        t1 = time.perf_counter()
+        for _ in range(k_alt):
+            one_step()
+        torch.cuda.synchronize()
+        e_alt = time.perf_counter() - t1
+        F.set_conv_arith(mode0)
+        alt = {"conv_arith": "f32", "value": batch * k_alt / e_alt, "unit": "clips/s", "steps": k_alt, "ms_per_step": 1e3 * e_alt / k_alt}
     if not torch.isfinite(torch.tensor(final_loss)):
         raise SystemExit("non-finite loss in the benchmark: %r" % final_loss)
 
@@ -244,6 +263,8 @@ def main():
                 "conv_ms_per_step": {k: v["ms"] / args.steps for k, v in fam.items()},
                 "conv_tflops": {k: v["flops"] / v["ms"] / 1e9 for k, v in fam.items()},
             }
+        if alt is not None:
+            result["alt_f32"] = alt
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(w)
         print(json.dumps(result))

@@ -2,7 +2,7 @@
 # One PMC pass over the whole bench step, aggregated per kernel (development tool).  usage: tools/pmc_bench.sh "<counters>" <tag>
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-timeout -k 5 400 rocprofv3 --kernel-trace --pmc $1 --output-format csv -d $R/gpurun_out/$2 -o p -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timer > $R/gpurun_out/$2.log 2>&1
+timeout -k 5 400 rocprofv3 --kernel-trace --pmc $1 --output-format csv -d $R/gpurun_out/$2 -o p -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timer --no-alt > $R/gpurun_out/$2.log 2>&1
 python - <<PY
 import csv, glob, collections, re
 agg = collections.defaultdict(lambda: collections.defaultdict(float))
