@@ -224,7 +224,7 @@ def main():
                                        args.workload, batch, w["samples"] / w["sr"], w["sr"] / 1e3, w["features"],
                                        w["blocks"], w.get("dims", 2), w["base"], w["growth"], w["dropout"]),
                        "global_batch": world * batch, "parallelism": "dp%d" % world,
-                       "conv_arith": {0: "f32", 6: "bf16x6", 9: "bf16x9"}[F.get_conv_arith()]},
+                       "conv_arith": {0: "f32", 3: "f16x3", 6: "bf16x6", 9: "bf16x9"}[F.get_conv_arith()]},
             "final_loss": final_loss,
         }
         if timer is not None:
@@ -253,6 +253,9 @@ def main():
                 executed_per_flop = int(dom_name.rstrip(">").split(",")[-1])
                 peak = PEAK_BF16_MFMA_TFLOPS
                 arith = "fp32 via exact 3-limb bf16 split, %d bf16 MFMA products per fp32 product, fp32 accumulate" % executed_per_flop
+                if executed_per_flop == 3:      # (the dense fp16 and bf16 MFMA peaks are equal)
+                    arith = ("fp32 via 2-limb fp16 split with per-tensor power-of-two scaling, 3 fp16 MFMA products "
+                             "per fp32 product, fp32 accumulate")
             result["roofline"] = {
                 "kernel": dom_name, "bound": "mfma", "achieved": achieved * executed_per_flop, "peak": peak,
                 "unit": "TFLOP/s", "frac": achieved * executed_per_flop / peak, "traffic": traffic,

@@ -47,6 +47,25 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
+// Largest |value| a launch writes, for the operand scaling of the split-fp16 conv kernels.  The buffer has
+// kAmaxFloats non-negative floats (all 0 before the launch) and the result is the maximum over ALL of them:
+// workgroups publish into kAmaxSlots slots on separate 128-byte lines (a single address serialises ~2 ns per
+// access in L2: 100 k waves cost more than the streaming pass they belong to), one access per workgroup, and the
+// atomic is skipped when the slot already holds a larger value.  Every thread of the block must call.
+constexpr int kAmaxSlots = 16, kAmaxStride = 32, kAmaxFloats = kAmaxSlots * kAmaxStride;
+__device__ __forceinline__ void publish_amax(float* out, float m) {
+    __shared__ float amax_s[16];
+    m = wave_max(m);
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    if (lane == 0) amax_s[wid] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int i = 1; i < nw; ++i) m = fmaxf(m, amax_s[i]);
+        float* slot = out + ((blockIdx.x + blockIdx.y * 7) % kAmaxSlots) * kAmaxStride;
+        if (m > *reinterpret_cast<volatile float*>(slot)) atomicMax(reinterpret_cast<unsigned*>(slot), __float_as_uint(m));
+    }
+}
+
 // Sum over a block of NW waves; result valid in every thread.  `scratch` holds NW values.
 template <typename T, int NW>
 __device__ __forceinline__ T block_sum(T v, T* scratch) {

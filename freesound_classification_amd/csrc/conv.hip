@@ -379,6 +379,39 @@ __device__ __forceinline__ void split3(const float (&x)[8], u32x4& h, u32x4& m, 
     }
 }
 
+// fp16 two-limb split with a power-of-two scale: h = rne16(x * s), l = rne16(x * s - h), one v_fma_mix each
+// (the mixed-precision FMA reads the fp32 source and the fp16 half directly and rounds once), so a pair of
+// values costs four VALU instructions including the scaling.  |x * s - h - l| <= 2^-24 |x * s|: the two limbs
+// carry the fp32 value to within half an fp32 ulp (11 + 11 significand bits plus the sign of the residual).
+__device__ __forceinline__ void split2_pair(float x0, float x1, float s, unsigned& h, unsigned& l) {
+    unsigned hp, lp;
+    asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(hp) : "v"(x0), "v"(s));
+    asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(hp) : "v"(x1), "v"(s));
+    asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(lp) : "v"(x0), "v"(s), "v"(hp));
+    asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(lp) : "v"(x1), "v"(s), "v"(hp));
+    h = hp;
+    l = lp;
+}
+
+// Power-of-two scale that brings a tensor of magnitude `amax` to [2^14, 2^15) (fp16 overflows at 65504), as the
+// exponent field of the scale; the inverse has field 254 - f.  Tensors below 2^-111 or above 2^125 are clamped.
+__device__ __forceinline__ int scale_field(float amax) {
+    const int e = (int)((__float_as_uint(amax) >> 23) & 0xffu);
+    int f = 268 - e;
+    f = f < 2 ? 2 : f > 252 ? 252 : f;
+    return f;
+}
+__device__ __forceinline__ float field_to_float(int f) { return __uint_as_float((unsigned)f << 23); }
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+template <bool F16>
+__device__ __forceinline__ f32x4 mfma_k32(u32x4 a, u32x4 b, f32x4 c) {
+    if constexpr (F16)
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    else
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
 // workgroup barrier that neither drains the DMAs in flight nor lets the compiler move LDS accesses across it
 __device__ __forceinline__ void raw_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
@@ -386,15 +419,19 @@ template <int KH, int KW, int COT, int PT, int NPROD>
 __global__ __launch_bounds__(kXWaves * 64) void conv_fwd_x3_kernel(Geom g, const float* __restrict__ in,
                                                                const float* __restrict__ packed,
                                                                const float* __restrict__ bias,
-                                                               float* __restrict__ out, int accumulate) {
+                                                               float* __restrict__ out, int accumulate,
+                                                               const float* __restrict__ in_amax,
+                                                               const float* __restrict__ w_amax) {
     constexpr int TAPS = KH * KW;
     constexpr int CO_BLK = COT * 16;
     constexpr int PADH = KH / 2, PADW = KW / 2;
+    constexpr bool F16 = NPROD == 3;                // two scaled fp16 limbs, 3 products; else three bf16 limbs, 6 / 9
+    constexpr int NL = F16 ? 2 : 3;                 // limbs per value
     constexpr int KCH = kXChunk;                    // channels per K chunk
     constexpr int SPC = TAPS;                       // steps per full chunk (one per tap)
     constexpr int NSTG = TAPS == 1 ? (PT == 2 ? 3 : 4) : 2;   // input stages: the input DMA runs NSTG - 1 chunks ahead
                                                     // (a 1x1 chunk is a single step)
-    constexpr int WUNITS = COT * 3;                 // 1 KB fragment images per step
+    constexpr int WUNITS = COT * NL;                // 1 KB fragment images per step
     constexpr int WSLOT_F = WUNITS * 256;           // floats per ring slot
     constexpr int NWQ = (WUNITS + kXWaves - 1) / kXWaves;
     constexpr int RING = (COT > 8 || (TAPS == 1 && PT == 2)) ? 2 : 3;   // weight slots: W runs RING - 1 steps ahead
@@ -510,6 +547,26 @@ __global__ __launch_bounds__(kXWaves * 64) void conv_fwd_x3_kernel(Geom g, const
 #pragma unroll
         for (int j = 0; j < PT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+    // ---- fp16 limbs: activations are scaled to [2^14, 2^15) by a power of two from the tensor's largest magnitude
+    //      (the weights were scaled the same way when they were packed); the epilogue undoes both exactly
+    float sx = 1.f, inv_x = 1.f, inv_w = 1.f;
+    if constexpr (F16) {
+        static_assert(kXWaves * 64 == fsc::kAmaxFloats, "one amax slot float per thread");
+        float* const red = smem;                       // (before any DMA lands in the weight ring)
+        const float mw = fsc::wave_max(in_amax[tid]);
+        if (lane == 0) red[wid] = mw;
+        __syncthreads();
+        float ax = red[0];
+#pragma unroll
+        for (int i = 1; i < kXWaves; ++i) ax = fmaxf(ax, red[i]);
+        ax = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, ax)));
+        __syncthreads();
+        const int fx = scale_field(ax), fw = scale_field(*w_amax);
+        sx = field_to_float(fx);
+        inv_x = field_to_float(254 - fx);
+        inv_w = field_to_float(254 - fw);
+    }
+
     // ---- K range of this workgroup (split-K over chunks through blockIdx.z)
     const int nchunks = g.x_nfull + (g.x_tail_oct ? 1 : 0);
     const int c_lo = (int)((long)nchunks * blockIdx.z / g.ksplit);
@@ -600,8 +657,21 @@ __global__ __launch_bounds__(kXWaves * 64) void conv_fwd_x3_kernel(Geom g, const
         return st + oct * 8 * g.plane + ty * g.cols + tx;
     };
 
-    struct Limbs { u32x4 h[PT], m[PT], l[PT]; };
+    struct Limbs { u32x4 v[NL][PT]; };            // v[0] = high limb ... v[NL - 1] = low limb
     Limbs lb0, lb1;
+    auto split_all = [&](const float (&x)[8], Limbs& dst, int j) {
+        if constexpr (F16) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                unsigned hp, lp;
+                split2_pair(x[2 * q], x[2 * q + 1], sx, hp, lp);
+                dst.v[0][j][q] = hp;
+                dst.v[1][j][q] = lp;
+            }
+        } else {
+            split3(x, dst.v[0][j], dst.v[1][j], dst.v[2][j]);
+        }
+    };
     const int nitems = ntiles * g.x_coblk;
     int item = blockIdx.x;
     // Input producer: a cursor (item, chunk, stage) that runs NSTG - 1 chunks ahead of the MFMA steps, across items;
@@ -635,7 +705,7 @@ __global__ __launch_bounds__(kXWaves * 64) void conv_fwd_x3_kernel(Geom g, const
             float raw[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) raw[e] = il[e * g.plane + pix_l[j]];
-            split3(raw, lb0.h[j], lb0.m[j], lb0.l[j]);
+            split_all(raw, lb0, j);
         }
     }
 
@@ -660,20 +730,17 @@ __global__ __launch_bounds__(kXWaves * 64) void conv_fwd_x3_kernel(Geom g, const
     // `wl` = this lane's A fragments of this step; `dma` is called once after phase 0.
     auto phases = [&](const float* il, const u32x4* wl, const Limbs& cur, Limbs& nxt, auto&& dma) {
         float raw[PT][8];
-        u32x4 a[2][3];
+        u32x4 a[2][NL];
 #pragma unroll
-        for (int p = 0; p < 3; ++p) a[0][p] = wl[p * 64];
+        for (int p = 0; p < NL; ++p) a[0][p] = wl[p * 64];
 #pragma unroll
         for (int i = 0; i < COT; ++i) {
-            const bf16x8 ah = __builtin_bit_cast(bf16x8, a[i & 1][0]);
-            const bf16x8 am = __builtin_bit_cast(bf16x8, a[i & 1][1]);
-            const bf16x8 al = __builtin_bit_cast(bf16x8, a[i & 1][2]);
 #pragma unroll
             for (int gq = 0; gq < NPROD; ++gq) {
                 // ---- the side work of this MFMA group (all compile-time placement)
                 if (gq == 0 && i + 1 < COT) {
 #pragma unroll
-                    for (int p = 0; p < 3; ++p) a[(i + 1) & 1][p] = wl[((i + 1) * 3 + p) * 64];
+                    for (int p = 0; p < NL; ++p) a[(i + 1) & 1][p] = wl[((i + 1) * NL + p) * 64];
                 }
 #pragma unroll
                 for (int j = 0; j < PT; ++j) {
@@ -691,7 +758,23 @@ __global__ __launch_bounds__(kXWaves * 64) void conv_fwd_x3_kernel(Geom g, const
                                 if (((j & 1) * 8 + e) % NPROD >= 2) raw[j][e] = il[e * g.plane + pix_l[j]];
                         }
                     }
-                    if (sp == i && gq >= 2 && gq < 6) {
+                    if constexpr (F16) {
+                        if (sp == i) {
+                            // four pair splits of four instructions: groups 0, 1, 1, 2 (all in the last group when
+                            // the raw values are read in this same phase)
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                const int gsel = rp == sp ? 2 : (q == 0 ? 0 : q == 3 ? 2 : 1);
+                                if (gsel == gq) {
+                                    unsigned hp, lp;
+                                    split2_pair(raw[j][2 * q], raw[j][2 * q + 1], sx, hp, lp);
+                                    asm volatile("" : "+v"(hp), "+v"(lp));
+                                    nxt.v[0][j][q] = hp;
+                                    nxt.v[1][j][q] = lp;
+                                }
+                            }
+                        }
+                    } else if (sp == i && gq >= 2 && gq < 6) {
                         const int q = gq - 2;
                         const float x0 = raw[j][2 * q], x1 = raw[j][2 * q + 1];
                         unsigned hp = cvt_pk_bf16(x0, x1);
@@ -701,22 +784,20 @@ __global__ __launch_bounds__(kXWaves * 64) void conv_fwd_x3_kernel(Geom g, const
                         unsigned lp = cvt_pk_bf16(s0, s1);
                         // pin the split to this group (otherwise it is sunk to its first use in the next step)
                         asm volatile("" : "+v"(hp), "+v"(mp), "+v"(lp));
-                        nxt.h[j][q] = hp;
-                        nxt.m[j][q] = mp;
-                        nxt.l[j][q] = lp;
+                        nxt.v[0][j][q] = hp;
+                        nxt.v[1][j][q] = mp;
+                        nxt.v[NL - 1][j][q] = lp;
                     }
                 }
-                // ---- PT independent MFMAs (one limb pair, every pixel tile)
-                constexpr int kPairA[9] = {1, 0, 2, 0, 1, 0, 2, 1, 2};      // 0 = h, 1 = m, 2 = l
+                // ---- PT independent MFMAs (one limb pair, every pixel tile), smallest products first
+                constexpr int kPairA[9] = {1, 0, 2, 0, 1, 0, 2, 1, 2};      // bf16: 0 = h, 1 = m, 2 = l
                 constexpr int kPairB[9] = {1, 2, 0, 1, 0, 0, 2, 2, 1};      // x6 uses the first six
-                const int pa = NPROD == 9 ? kPairA[(gq + 6) % 9] : kPairA[gq];
-                const int pb = NPROD == 9 ? kPairB[(gq + 6) % 9] : kPairB[gq];
-                const bf16x8 av = pa == 0 ? ah : pa == 1 ? am : al;
+                constexpr int kPairA2[3] = {1, 0, 0}, kPairB2[3] = {0, 1, 0};   // fp16: 0 = h, 1 = l
+                const int pa = F16 ? kPairA2[gq % 3] : NPROD == 9 ? kPairA[(gq + 6) % 9] : kPairA[gq % 9];
+                const int pb = F16 ? kPairB2[gq % 3] : NPROD == 9 ? kPairB[(gq + 6) % 9] : kPairB[gq % 9];
 #pragma unroll
-                for (int j = 0; j < PT; ++j) {
-                    const bf16x8 bv = __builtin_bit_cast(bf16x8, pb == 0 ? cur.h[j] : pb == 1 ? cur.m[j] : cur.l[j]);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, bv, acc[i][j], 0, 0, 0);
-                }
+                for (int j = 0; j < PT; ++j)
+                    acc[i][j] = mfma_k32<F16>(a[i & 1][pa], cur.v[pb][j], acc[i][j]);
 #pragma unroll
                 for (int k = 0; k < PT; ++k) {
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);     // one MFMA
@@ -852,7 +933,8 @@ __global__ __launch_bounds__(kXWaves * 64) void conv_fwd_x3_kernel(Geom g, const
 #pragma unroll
             for (int j = 0; j < PT; ++j) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) scratch[(kq * 4 + r) * SCR + lm] = acc[i][j][r] + bv[r];
+                for (int r = 0; r < 4; ++r)
+                    scratch[(kq * 4 + r) * SCR + lm] = F16 ? fmaf(acc[i][j][r] * inv_x, inv_w, bv[r]) : acc[i][j][r] + bv[r];
                 const f32x4 v = *reinterpret_cast<const f32x4*>(scratch + ch * SCR + (lane & 3) * 4);
                 if (co < g.cout && quad_ok[j]) {
                     float* o = out + quad_g[j] + (long)co * hw_t;
@@ -881,12 +963,39 @@ __global__ __launch_bounds__(kXWaves * 64) void conv_fwd_x3_kernel(Geom g, const
     }
 }
 
+// max |x| of a tensor as the bit pattern of a non-negative float (ordered like an unsigned integer).
+// `out` must hold 0 before a multi-block launch; with one block (`direct`) the result is stored.
+// `slots` > 1: the fsc::publish_amax buffer format (kAmaxFloats floats, the result is the maximum over all of them).
+__global__ __launch_bounds__(256) void amax_kernel(const float* __restrict__ x, long n, float* __restrict__ out, int direct,
+                                                   int slots) {
+    __shared__ float sm[4];
+    float m = 0.f;
+    const long n4 = n >> 2, stride = (long)gridDim.x * 256;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+        const f32x4 v = reinterpret_cast<const f32x4*>(x)[i];
+        m = fmaxf(fmaxf(m, fabsf(v[0])), fmaxf(fabsf(v[1]), fmaxf(fabsf(v[2]), fabsf(v[3]))));
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) m = fmaxf(m, fabsf(x[(n4 << 2) + threadIdx.x]));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        m = fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3]));
+        if (direct) *out = m;
+        else atomicMax(reinterpret_cast<unsigned*>(out + (blockIdx.x % slots) * fsc::kAmaxStride), __float_as_uint(m));
+    }
+}
+
 // weight (c_out, c_in, kh, kw) -> A fragments of conv_fwd_x3_kernel:
 // packed[co block][step][channel tile][limb][lane][8 bf16]; lane = (kq, m), its 8 values are the channels
 // of octet `oct` at tap `tap` where (tap, oct) = divmod(4 * step_in_chunk + kq, octets of the chunk)
+// `w_amax` != null: two fp16 limbs of the weights scaled by scale_field(*w_amax) instead of three bf16 limbs
 __global__ void pack_x3_kernel(const float* __restrict__ w, unsigned short* __restrict__ packed, int c_out, int c_in,
-                               int taps, int cot, int co_blocks, int nfull, int tail_oct, int steps, int nch, int dgrad) {
+                               int taps, int cot, int co_blocks, int nfull, int tail_oct, int steps, int nch, int dgrad,
+                               const float* __restrict__ w_amax) {
     const long total = (long)co_blocks * steps * cot * 512;
+    const float sw = w_amax ? field_to_float(scale_field(*w_amax)) : 1.f;
     for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
         const int e = (int)(idx & 7), lane = (int)((idx >> 3) & 63);
         long rest = idx >> 9;
@@ -904,6 +1013,14 @@ __global__ void pack_x3_kernel(const float* __restrict__ w, unsigned short* __re
             const int k = c * kXChunk * nch + oct * 8 + e, m = (cb * cot + i) * 16 + (lane & 15);
             const int co = dgrad ? k : m, ci = dgrad ? m : k;
             if (co < c_out && ci < c_in) v = w[((long)co * c_in + ci) * taps + (dgrad ? taps - 1 - tap : tap)];
+        }
+        if (w_amax) {
+            unsigned h2, l2;
+            split2_pair(v, 0.f, sw, h2, l2);
+            const long base2 = ((((long)cb * steps + S) * cot + i) * 2) * 512 + lane * 8 + e;
+            packed[base2] = (unsigned short)h2;
+            packed[base2 + 512] = (unsigned short)l2;
+            continue;
         }
         const unsigned hp = cvt_pk_bf16(v, 0.f);
         const float r = v - __uint_as_float(hp << 16);
@@ -1464,10 +1581,14 @@ __host__ __device__ inline void wgx_group(int live, int ng, int q, int* start, i
 template <int KH, int KW, int MT, int NPROD>
 __global__ __launch_bounds__(kWgxWaves * 64) void conv_wgrad_x3_kernel(WgxGeom g, const float* __restrict__ in,
                                                                        const float* __restrict__ dout,
-                                                                       float* __restrict__ part) {
+                                                                       float* __restrict__ part,
+                                                                       const float* __restrict__ in_amax,
+                                                                       const float* __restrict__ dout_amax) {
     constexpr int TAPS = KH * KW;
     constexpr int PADH = KH / 2;
     constexpr int DSO = kWgxDso;
+    constexpr bool F16 = NPROD == 3;                         // two scaled fp16 limbs, 3 products (see conv_fwd_x3_kernel)
+    constexpr int NL = F16 ? 2 : 3;
     constexpr int MAXI = 4;                                  // input DMA instructions per channel (<= 256 staged floats)
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -1502,6 +1623,24 @@ __global__ __launch_bounds__(kWgxWaves * 64) void conv_wgrad_x3_kernel(WgxGeom g
         qr[j] = o / g.rowp;
         qc[j] = o - qr[j] * g.rowp - 4;
         if (qr[j] >= g.th + KH - 1 || qc[j] < -1 || qc[j] > g.tw) qr[j] = -1;      // outside the staged window
+    }
+
+    // fp16 limbs: both operands are scaled to [2^14, 2^15) by powers of two; the partial sums are unscaled on store
+    float sa = 1.f, sb = 1.f, inv_a = 1.f, inv_b = 1.f;
+    if constexpr (F16) {
+        static_assert(kWgxWaves * 64 == fsc::kAmaxFloats, "one amax slot float per thread");
+        const float ma = fsc::wave_max(dout_amax[tid]), mb = fsc::wave_max(in_amax[tid]);
+        if (lane == 0) { smem[wid] = ma; smem[kWgxWaves + wid] = mb; }
+        __syncthreads();
+        float xa = smem[0], xb = smem[kWgxWaves];
+#pragma unroll
+        for (int i = 1; i < kWgxWaves; ++i) { xa = fmaxf(xa, smem[i]); xb = fmaxf(xb, smem[kWgxWaves + i]); }
+        xa = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, xa)));
+        xb = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, xb)));
+        __syncthreads();
+        const int fa = scale_field(xa), fb = scale_field(xb);
+        sa = field_to_float(fa); inv_a = field_to_float(254 - fa);
+        sb = field_to_float(fb); inv_b = field_to_float(254 - fb);
     }
 
     // Rows beyond c_out / c_in are never copied: zero them once in both stages.  The copy loops then walk the
@@ -1574,6 +1713,7 @@ __global__ __launch_bounds__(kWgxWaves * 64) void conv_wgrad_x3_kernel(WgxGeom g
 
     constexpr int kPairA[9] = {1, 0, 2, 0, 1, 0, 2, 1, 2};      // limb pairs, 0 = h, 1 = m, 2 = l; x6 uses the first six
     constexpr int kPairB[9] = {1, 2, 0, 1, 0, 0, 2, 2, 1};
+    constexpr int kPairA2[3] = {1, 0, 0}, kPairB2[3] = {0, 1, 0};   // fp16: 0 = h, 1 = l
 
     int stage = 0;
     if (split < g.units) issue_unit(split, 0);
@@ -1605,13 +1745,23 @@ __global__ __launch_bounds__(kWgxWaves * 64) void conv_wgrad_x3_kernel(WgxGeom g
                     ar[i][1] = src[1];
                 }
                 __builtin_amdgcn_sched_barrier(0);
-                u32x4 al[MT][3];
+                u32x4 al[MT][NL];
 #pragma unroll
                 for (int i = 0; i < MT; ++i) {
                     if (i < mt_live) {
                         const float x[8] = {ar[i][0][0], ar[i][0][1], ar[i][0][2], ar[i][0][3],
                                             ar[i][1][0], ar[i][1][1], ar[i][1][2], ar[i][1][3]};
-                        split3(x, al[i][0], al[i][1], al[i][2]);
+                        if constexpr (F16) {
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                unsigned hp, lp;
+                                split2_pair(x[2 * q], x[2 * q + 1], sa, hp, lp);
+                                al[i][0][q] = hp;
+                                al[i][1][q] = lp;
+                            }
+                        } else {
+                            split3(x, al[i][0], al[i][1], al[i][NL - 1]);
+                        }
                     }
                 }
 #pragma unroll
@@ -1621,12 +1771,25 @@ __global__ __launch_bounds__(kWgxWaves * 64) void conv_wgrad_x3_kernel(WgxGeom g
                     // B operands as ready register quads: bq[tx][limb]; with e[k] packed in pairs, tx = 0 takes the
                     // odd pairing P_0..P_3 = (e0,e1)..(e6,e7), tx = 2 its shift P_1..P_4, tx = 1 the even pairing
                     // Q_0..Q_3 = (e1,e2)..(e7,e8)
-                    u32x4 bq[3][3];
+                    u32x4 bq[3][NL];
                     float res[10];
 #pragma unroll
                     for (int k = 0; k < 10; ++k) res[k] = e[k];
+                    if constexpr (F16) {
+                        // five pair splits (four instructions each) give P; Q_k = (high half of P_k, low half of P_k+1)
+                        unsigned P[2][5];
 #pragma unroll
-                    for (int lv = 0; lv < 3; ++lv) {
+                        for (int k = 0; k < 5; ++k) split2_pair(res[2 * k], res[2 * k + 1], sb, P[0][k], P[1][k]);
+#pragma unroll
+                        for (int lv = 0; lv < 2; ++lv) {
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) bq[1][lv][k] = __builtin_amdgcn_alignbit(P[lv][k + 1], P[lv][k], 16);
+                            bq[0][lv] = (u32x4){P[lv][0], P[lv][1], P[lv][2], P[lv][3]};
+                            bq[2][lv] = (u32x4){P[lv][1], P[lv][2], P[lv][3], P[lv][4]};
+                        }
+                    }
+#pragma unroll
+                    for (int lv = 0; lv < (F16 ? 0 : 3); ++lv) {
                         unsigned P[5];
 #pragma unroll
                         for (int k = 0; k < 5; ++k) P[k] = cvt_pk_bf16(res[2 * k], res[2 * k + 1]);
@@ -1646,7 +1809,7 @@ __global__ __launch_bounds__(kWgxWaves * 64) void conv_wgrad_x3_kernel(WgxGeom g
 #pragma unroll
                     for (int tx = 0; tx < 3; ++tx)
 #pragma unroll
-                        for (int lv = 0; lv < 3; ++lv) asm volatile("" : "+v"(bq[tx][lv]));
+                        for (int lv = 0; lv < NL; ++lv) asm volatile("" : "+v"(bq[tx][lv]));
                     // the next row's window is fetched while this row's MFMAs run (its registers are free now)
                     if (ty + 1 < KH) {
                         const float* nrow = brow + (ty + 1) * g.rowp;
@@ -1663,13 +1826,11 @@ __global__ __launch_bounds__(kWgxWaves * 64) void conv_wgrad_x3_kernel(WgxGeom g
                         if (i < mt_live) {
 #pragma unroll
                             for (int gq = 0; gq < NPROD; ++gq) {
-                                const int pa = NPROD == 9 ? kPairA[(gq + 6) % 9] : kPairA[gq];
-                                const int pb = NPROD == 9 ? kPairB[(gq + 6) % 9] : kPairB[gq];
+                                const int pa = F16 ? kPairA2[gq % 3] : NPROD == 9 ? kPairA[(gq + 6) % 9] : kPairA[gq % 9];
+                                const int pb = F16 ? kPairB2[gq % 3] : NPROD == 9 ? kPairB[(gq + 6) % 9] : kPairB[gq % 9];
 #pragma unroll
                                 for (int tx = 0; tx < KW; ++tx)
-                                    acc[ty][tx][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                                        __builtin_bit_cast(bf16x8, al[i][pa]), __builtin_bit_cast(bf16x8, bq[KW == 1 ? 1 : tx][pb]),
-                                        acc[ty][tx][i], 0, 0, 0);
+                                    acc[ty][tx][i] = mfma_k32<F16>(al[i][pa], bq[KW == 1 ? 1 : tx][pb], acc[ty][tx][i]);
                             }
                         }
                     }
@@ -1692,7 +1853,8 @@ __global__ __launch_bounds__(kWgxWaves * 64) void conv_wgrad_x3_kernel(WgxGeom g
                 if (i < g.tpg) {
                     const int tile = tile0 + g_start + i;
                     if (i < mt_live) {          // (tiles beyond c_out and ci rows beyond c_in are never read by the reduce)
-                        const f32x4 a = acc[ty][tx][i];
+                        f32x4 a = acc[ty][tx][i];
+                        if constexpr (F16) a = a * inv_a * inv_b;
                         *reinterpret_cast<float4*>(part + row * g.co_pad + tile * 16 + kq * 4) = make_float4(a[0], a[1], a[2], a[3]);
                     }
                 }
@@ -1733,6 +1895,11 @@ struct FwdPlan {
     long launch_x;    // x3: persistent workgroups per (channel block, K slice)
 };
 
+// floats of the packed limb fragments of an x3 plan (fp16 limbs: followed by 4 floats holding the weights' amax)
+size_t x3_limb_floats(const FwdPlan& p) {
+    return (size_t)p.co_blocks * p.g.x_steps * p.cot * (p.x3 == 3 ? 2 : 3) * 256;
+}
+
 // Arithmetic of the 3x3 / k3 forward and dgrad kernels: 0 = native fp32 MFMA everywhere, 6 / 9 = split-bf16
 // kernel (that many limb products) wherever its tiling fits.  FSC_CONV_ARITH=f32|bf16x6|bf16x9 or fsc_conv_set_arith.
 int g_conv_arith = -1;
@@ -1741,6 +1908,7 @@ int conv_arith() {
         const char* e = getenv("FSC_CONV_ARITH");
         g_conv_arith = 6;
         if (e && !strcmp(e, "f32")) g_conv_arith = 0;
+        else if (e && !strcmp(e, "f16x3")) g_conv_arith = 3;
         else if (e && !strcmp(e, "bf16x6")) g_conv_arith = 6;
         else if (e && !strcmp(e, "bf16x9")) g_conv_arith = 9;
     }
@@ -1813,7 +1981,7 @@ bool plan_fwd_x3_pt(const fsc_conv_desc& d_in, int dgrad, int nprod, int pt, int
     g.flat = 0;
     const int pix_cap = kXWaves * p.pt * 16;
     const size_t lds_total = 160 * 1024;
-    const size_t ring = (size_t)((p.cot > 8 || (taps == 1 && pt == 2)) ? 2 : 3) * p.cot * 3 * 1024;
+    const size_t ring = (size_t)((p.cot > 8 || (taps == 1 && pt == 2)) ? 2 : 3) * p.cot * (nprod == 3 ? 2 : 3) * 1024;
     const size_t scratch = (size_t)kXWaves * 16 * 20 * sizeof(float);      // per-wave epilogue transpose tiles
     int cap_pos = (int)((lds_total - ring - scratch) / (nstg * kch * sizeof(float))) - 4;
     if (cap_pos > 64 * kXNptMax - 4) cap_pos = 64 * kXNptMax - 4;
@@ -2011,25 +2179,24 @@ bool plan_fwd_f32(const fsc_conv_desc& d, int dgrad, FwdPlan* out) {
 
 template <int KH, int KW, int COT, int PT, int NPROD>
 void launch_x3_pt(const FwdPlan& p, dim3 grid, const float* in, const float* packed, const float* bias, float* out,
-                  int accumulate, hipStream_t st) {
+                  int accumulate, const float* in_amax, hipStream_t st) {
     auto kern = conv_fwd_x3_kernel<KH, KW, COT, PT, NPROD>;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes);
-    hipLaunchKernelGGL(kern, grid, dim3(kXWaves * 64), p.lds_bytes, st, p.g, in, packed, bias, out, accumulate);
+    const float* w_amax = packed + x3_limb_floats(p);      // fp16 limbs: the weights' largest magnitude follows the fragments
+    hipLaunchKernelGGL(kern, grid, dim3(kXWaves * 64), p.lds_bytes, st, p.g, in, packed, bias, out, accumulate, in_amax, w_amax);
 }
 
-template <int KH, int KW, int COT, int NPROD>
-void launch_x3(const FwdPlan& p, dim3 grid, const float* in, const float* packed, const float* bias, float* out,
-               int accumulate, hipStream_t st) {
-    if (p.pt == 2) {
-        launch_x3_pt<KH, KW, COT, 2, NPROD>(p, grid, in, packed, bias, out, accumulate, st);
-        return;
-    }
-    launch_x3_pt<KH, KW, COT, 1, NPROD>(p, grid, in, packed, bias, out, accumulate, st);
+template <int KH, int KW, int COT, int PT>
+void launch_x3_arith(const FwdPlan& p, dim3 grid, const float* in, const float* packed, const float* bias, float* out,
+                     int accumulate, const float* in_amax, hipStream_t st) {
+    if (p.x3 == 3) launch_x3_pt<KH, KW, COT, PT, 3>(p, grid, in, packed, bias, out, accumulate, in_amax, st);
+    else if (p.x3 == 6) launch_x3_pt<KH, KW, COT, PT, 6>(p, grid, in, packed, bias, out, accumulate, in_amax, st);
+    else launch_x3_pt<KH, KW, COT, PT, 9>(p, grid, in, packed, bias, out, accumulate, in_amax, st);
 }
 
 template <int KH, int KW, int COT>
 int launch_fwd_cot(const FwdPlan& p, const float* in, const float* packed, const float* bias, float* out,
-                   int accumulate, hipStream_t st) {
+                   int accumulate, const float* in_amax, hipStream_t st) {
     dim3 grid((unsigned)p.grid_x, p.co_blocks, p.g.ksplit);
     if (p.g.ksplit > 1 && !accumulate) {
         const size_t bytes = sizeof(float) * (size_t)p.g.n * p.g.cout * p.g.hw;
@@ -2039,8 +2206,8 @@ int launch_fwd_cot(const FwdPlan& p, const float* in, const float* packed, const
     if (p.x3) {
         grid.x = (unsigned)p.launch_x;
         grid.y = 1;
-        if (p.x3 == 6) launch_x3<KH, KW, COT, 6>(p, grid, in, packed, bias, out, accumulate, st);
-        else launch_x3<KH, KW, COT, 9>(p, grid, in, packed, bias, out, accumulate, st);
+        if (p.pt == 2) launch_x3_arith<KH, KW, COT, 2>(p, grid, in, packed, bias, out, accumulate, in_amax, st);
+        else launch_x3_arith<KH, KW, COT, 1>(p, grid, in, packed, bias, out, accumulate, in_amax, st);
         FSC_LAUNCH_CHECK("fsc_conv_fwd(x3)");
         return 0;
     }
@@ -2059,7 +2226,7 @@ int launch_fwd_cot(const FwdPlan& p, const float* in, const float* packed, const
 
 template <int KH, int KW, int COT>
 int launch_fwd_wide(const FwdPlan& p, const float* in, const float* packed, const float* bias, float* out, int accumulate,
-                      hipStream_t st) {
+                    const float* in_amax, hipStream_t st) {
     // 10 / 15 channel tiles: split-bf16 kernel only (3x3 / k3, one pixel tile per wave, two-slot weight ring)
     if constexpr (KH * KW > 1) {
         dim3 grid((unsigned)p.launch_x, 1, p.g.ksplit);
@@ -2068,8 +2235,7 @@ int launch_fwd_wide(const FwdPlan& p, const float* in, const float* packed, cons
             hipError_t e = hipMemsetAsync(out, 0, bytes, st);
             FSC_CHECK_ARG(e == hipSuccess, "fsc_conv_fwd: memset failed: %s", hipGetErrorString(e));
         }
-        if (p.x3 == 6) launch_x3_pt<KH, KW, COT, 1, 6>(p, grid, in, packed, bias, out, accumulate, st);
-        else launch_x3_pt<KH, KW, COT, 1, 9>(p, grid, in, packed, bias, out, accumulate, st);
+        launch_x3_arith<KH, KW, COT, 1>(p, grid, in, packed, bias, out, accumulate, in_amax, st);
         FSC_LAUNCH_CHECK("fsc_conv_fwd(x3)");
         return 0;
     } else {
@@ -2080,20 +2246,38 @@ int launch_fwd_wide(const FwdPlan& p, const float* in, const float* packed, cons
 
 template <int KH, int KW>
 int launch_fwd(const FwdPlan& p, const float* in, const float* packed, const float* bias, float* out, int accumulate,
-               hipStream_t st) {
-    if (p.cot == 10) return launch_fwd_wide<KH, KW, 10>(p, in, packed, bias, out, accumulate, st);
-    if (p.cot == 15) return launch_fwd_wide<KH, KW, 15>(p, in, packed, bias, out, accumulate, st);
+               const float* in_amax, hipStream_t st) {
+    if (p.cot == 10) return launch_fwd_wide<KH, KW, 10>(p, in, packed, bias, out, accumulate, in_amax, st);
+    if (p.cot == 15) return launch_fwd_wide<KH, KW, 15>(p, in, packed, bias, out, accumulate, in_amax, st);
     switch (p.cot) {
-        case 1: return launch_fwd_cot<KH, KW, 1>(p, in, packed, bias, out, accumulate, st);
-        case 2: return launch_fwd_cot<KH, KW, 2>(p, in, packed, bias, out, accumulate, st);
-        case 3: return launch_fwd_cot<KH, KW, 3>(p, in, packed, bias, out, accumulate, st);
-        case 4: return launch_fwd_cot<KH, KW, 4>(p, in, packed, bias, out, accumulate, st);
-        case 5: return launch_fwd_cot<KH, KW, 5>(p, in, packed, bias, out, accumulate, st);
-        case 6: return launch_fwd_cot<KH, KW, 6>(p, in, packed, bias, out, accumulate, st);
-        case 7: return launch_fwd_cot<KH, KW, 7>(p, in, packed, bias, out, accumulate, st);
-        default: return launch_fwd_cot<KH, KW, 8>(p, in, packed, bias, out, accumulate, st);
+        case 1: return launch_fwd_cot<KH, KW, 1>(p, in, packed, bias, out, accumulate, in_amax, st);
+        case 2: return launch_fwd_cot<KH, KW, 2>(p, in, packed, bias, out, accumulate, in_amax, st);
+        case 3: return launch_fwd_cot<KH, KW, 3>(p, in, packed, bias, out, accumulate, in_amax, st);
+        case 4: return launch_fwd_cot<KH, KW, 4>(p, in, packed, bias, out, accumulate, in_amax, st);
+        case 5: return launch_fwd_cot<KH, KW, 5>(p, in, packed, bias, out, accumulate, in_amax, st);
+        case 6: return launch_fwd_cot<KH, KW, 6>(p, in, packed, bias, out, accumulate, in_amax, st);
+        case 7: return launch_fwd_cot<KH, KW, 7>(p, in, packed, bias, out, accumulate, in_amax, st);
+        default: return launch_fwd_cot<KH, KW, 8>(p, in, packed, bias, out, accumulate, in_amax, st);
     }
 }
+
+// slots == 1: a single float (the packed weights' tail); slots == kAmaxSlots: an FSC_AMAX_FLOATS buffer
+int launch_amax(const float* x, long n, float* out, hipStream_t st, int slots) {
+    long blocks = (n / 4 + 256 * 8 - 1) / (256 * 8);
+    if (blocks > 1024) blocks = 1024;
+    if (blocks < 1) blocks = 1;
+    if (blocks == 1 && slots == 1) {
+        hipLaunchKernelGGL(amax_kernel, dim3(1), dim3(256), 0, st, x, n, out, 1, 1);
+    } else {
+        hipError_t e = hipMemsetAsync(out, 0, sizeof(float) * (slots == 1 ? 1 : fsc::kAmaxFloats), st);
+        FSC_CHECK_ARG(e == hipSuccess, "fsc_amax: memset failed: %s", hipGetErrorString(e));
+        hipLaunchKernelGGL(amax_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, n, out, 0, slots);
+    }
+    FSC_LAUNCH_CHECK("fsc_amax");
+    return 0;
+}
+
+int wgrad_arith() { return conv_arith(); }
 
 // stem layers take the direct kernels: 3x3, at most 4 input channels, weights fit the LDS table
 bool stem_shape(const fsc_conv_desc& d) {
@@ -2310,18 +2494,21 @@ bool plan_wgrad_x3(const fsc_conv_desc& d, int nprod, WgxPlan* out) {
 }
 
 template <int KH, int KW, int MT, int NPROD>
-void launch_wgrad_x3_k(const WgxPlan& p, const float* in, const float* dout, float* part, hipStream_t st) {
+void launch_wgrad_x3_k(const WgxPlan& p, const float* in, const float* dout, float* part, const float* in_amax,
+                       const float* dout_amax, hipStream_t st) {
     auto kern = conv_wgrad_x3_kernel<KH, KW, MT, NPROD>;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes);
     dim3 grid(p.g.co_blocks * p.g.ci_blocks, p.g.nsplit);
-    hipLaunchKernelGGL(kern, grid, dim3(kWgxWaves * 64), p.lds_bytes, st, p.g, in, dout, part);
+    hipLaunchKernelGGL(kern, grid, dim3(kWgxWaves * 64), p.lds_bytes, st, p.g, in, dout, part, in_amax, dout_amax);
 }
 
 template <int KH, int KW>
-int launch_wgrad_x3(const WgxPlan& p, const float* in, const float* dout, float* part, hipStream_t st) {
-#define FSC_WGX(MT_)                                                                         \
-    if (p.nprod == 6) launch_wgrad_x3_k<KH, KW, MT_, 6>(p, in, dout, part, st);               \
-    else launch_wgrad_x3_k<KH, KW, MT_, 9>(p, in, dout, part, st);                            \
+int launch_wgrad_x3(const WgxPlan& p, const float* in, const float* dout, float* part, const float* in_amax,
+                    const float* dout_amax, hipStream_t st) {
+#define FSC_WGX(MT_)                                                                                          \
+    if (p.nprod == 3) launch_wgrad_x3_k<KH, KW, MT_, 3>(p, in, dout, part, in_amax, dout_amax, st);          \
+    else if (p.nprod == 6) launch_wgrad_x3_k<KH, KW, MT_, 6>(p, in, dout, part, in_amax, dout_amax, st);     \
+    else launch_wgrad_x3_k<KH, KW, MT_, 9>(p, in, dout, part, in_amax, dout_amax, st);                       \
     break;
     switch (p.mt) {
         case 1: FSC_WGX(1)
@@ -2371,12 +2558,13 @@ size_t fsc_conv_packed_floats(const fsc_conv_desc* d, int dgrad) {
     if (!valid_desc(d)) return 0;
     FwdPlan p;
     if (!plan_fwd(*d, dgrad, &p)) return 0;
-    if (p.x3) return (size_t)p.co_blocks * p.g.x_steps * p.cot * 3 * 256;
+    if (p.x3) return x3_limb_floats(p) + (p.x3 == 3 ? 4 : 0);
     return (size_t)d->kh * d->kw * p.g.k_pad * p.g.m_pad;
 }
 
 int fsc_conv_set_arith(int mode) {
-    FSC_CHECK_ARG(mode == 0 || mode == 6 || mode == 9, "fsc_conv_set_arith: mode must be 0 (fp32 MFMA), 6 or 9 (split-bf16 products)");
+    FSC_CHECK_ARG(mode == 0 || mode == 3 || mode == 6 || mode == 9,
+                  "fsc_conv_set_arith: mode must be 0 (fp32 MFMA), 3 (scaled split-fp16), 6 or 9 (split-bf16 products)");
     g_conv_arith = mode;
     return 0;
 }
@@ -2392,9 +2580,15 @@ int fsc_conv_pack_weights(const fsc_conv_desc* d, const float* weight, int dgrad
         const long items = (long)p.co_blocks * p.g.x_steps * p.cot * 512;
         long xb = (items + 255) / 256;
         if (xb > 8192) xb = 8192;
+        float* w_amax = nullptr;
+        if (p.x3 == 3) {
+            w_amax = packed + x3_limb_floats(p);
+            const int rc = launch_amax(weight, (long)d->c_out * d->c_in * d->kh * d->kw, w_amax, fsc::as_stream(stream), 1);
+            if (rc) return rc;
+        }
         hipLaunchKernelGGL(pack_x3_kernel, dim3((unsigned)xb), dim3(256), 0, fsc::as_stream(stream), weight,
                            reinterpret_cast<unsigned short*>(packed), d->c_out, d->c_in, d->kh * d->kw, p.cot, p.co_blocks,
-                           p.g.x_nfull, p.g.x_tail_oct, p.g.x_steps, 1, dgrad);
+                           p.g.x_nfull, p.g.x_tail_oct, p.g.x_steps, 1, dgrad, w_amax);
         FSC_LAUNCH_CHECK("fsc_conv_pack_weights(x3)");
         return 0;
     }
@@ -2408,11 +2602,12 @@ int fsc_conv_pack_weights(const fsc_conv_desc* d, const float* weight, int dgrad
 }
 
 int fsc_conv_fwd(const fsc_conv_desc* d, const float* in, const float* packed, const float* bias, int dgrad,
-                 int accumulate, float* out, fsc_stream_t stream) {
+                 int accumulate, float* out, const float* in_amax, fsc_stream_t stream) {
     FSC_CHECK_ARG(valid_desc(d) && in && packed && out, "fsc_conv_fwd: bad descriptor or null pointer");
     FSC_CHECK_ARG(!(dgrad && bias), "fsc_conv_fwd: dgrad takes no bias");
     FwdPlan p;
     FSC_CHECK_ARG(plan_fwd(*d, dgrad, &p), "fsc_conv_fwd: no tiling for this shape");
+    FSC_CHECK_ARG(p.x3 != 3 || in_amax, "fsc_conv_fwd: the split-fp16 kernels need in_amax (fsc_amax of `in`)");
     hipStream_t st = fsc::as_stream(stream);
     if (stem_shape(*d) && !p.x3) {
         // stem layer: direct kernels organised around the wide tensor (see conv_stem_*_kernel)
@@ -2436,9 +2631,14 @@ int fsc_conv_fwd(const fsc_conv_desc* d, const float* in, const float* packed, c
         FSC_LAUNCH_CHECK("fsc_conv_fwd(stem)");
         return 0;
     }
-    if (d->kh == 3) return launch_fwd<3, 3>(p, in, packed, bias, out, accumulate, st);
-    if (d->kw == 3) return launch_fwd<1, 3>(p, in, packed, bias, out, accumulate, st);
-    return launch_fwd<1, 1>(p, in, packed, bias, out, accumulate, st);
+    if (d->kh == 3) return launch_fwd<3, 3>(p, in, packed, bias, out, accumulate, in_amax, st);
+    if (d->kw == 3) return launch_fwd<1, 3>(p, in, packed, bias, out, accumulate, in_amax, st);
+    return launch_fwd<1, 1>(p, in, packed, bias, out, accumulate, in_amax, st);
+}
+
+int fsc_amax(const float* x, long n, float* out, fsc_stream_t stream) {
+    FSC_CHECK_ARG(x && out && n > 0, "fsc_amax: bad arguments");
+    return launch_amax(x, n, out, fsc::as_stream(stream), fsc::kAmaxSlots);
 }
 
 int fsc_conv_pool_supported(const fsc_conv_desc* d) {
@@ -2469,7 +2669,7 @@ int fsc_conv_plan_describe(const fsc_conv_desc* d, int mode, char* buf, size_t b
     FSC_CHECK_ARG(valid_desc(d) && buf && buf_len > 0, "fsc_conv_plan_describe: bad arguments");
     if (mode == 2) {
         WgxPlan px;
-        if (conv_arith() && plan_wgrad_x3(*d, conv_arith(), &px)) {
+        if (wgrad_arith() && plan_wgrad_x3(*d, wgrad_arith(), &px)) {
             snprintf(buf, buf_len, "conv_wgrad_x3_kernel<%d,%d,%d,%d> box=%dx%d groups=%dx%d tiles/block=%d units=%d split=%d grid=%dx%d lds=%zu",
                      d->kh, d->kw, px.mt, px.nprod, px.g.th, px.g.tw, px.g.ng, px.g.nt, px.g.tpb, px.g.units, px.g.nsplit,
                      px.g.co_blocks * px.g.ci_blocks, px.g.nsplit, px.lds_bytes);
@@ -2501,7 +2701,7 @@ int fsc_conv_plan_describe(const fsc_conv_desc* d, int mode, char* buf, size_t b
 size_t fsc_conv_wgrad_workspace_bytes(const fsc_conv_desc* d) {
     if (!valid_desc(d)) return 0;
     WgxPlan px;
-    if (conv_arith() && plan_wgrad_x3(*d, conv_arith(), &px))
+    if (wgrad_arith() && plan_wgrad_x3(*d, wgrad_arith(), &px))
         return (size_t)px.g.nsplit * d->kh * d->kw * px.g.ci_pad * px.g.co_pad * sizeof(float);
     WgPlan p;
     if (!plan_wgrad(*d, &p)) return 0;
@@ -2509,15 +2709,17 @@ size_t fsc_conv_wgrad_workspace_bytes(const fsc_conv_desc* d) {
 }
 
 int fsc_conv_wgrad(const fsc_conv_desc* d, const float* in, const float* dout, float* dweight, void* workspace,
-                   fsc_stream_t stream) {
+                   const float* in_amax, const float* dout_amax, fsc_stream_t stream) {
     FSC_CHECK_ARG(valid_desc(d) && in && dout && dweight && workspace, "fsc_conv_wgrad: bad descriptor or null pointer");
     hipStream_t st = fsc::as_stream(stream);
     float* part = reinterpret_cast<float*>(workspace);
     int rc;
     WgxPlan px;
-    if (conv_arith() && plan_wgrad_x3(*d, conv_arith(), &px)) {
-        if (d->kh == 3) rc = launch_wgrad_x3<3, 3>(px, in, dout, part, st);
-        else rc = launch_wgrad_x3<1, 3>(px, in, dout, part, st);
+    if (wgrad_arith() && plan_wgrad_x3(*d, wgrad_arith(), &px)) {
+        FSC_CHECK_ARG(px.nprod != 3 || (in_amax && dout_amax),
+                      "fsc_conv_wgrad: the split-fp16 kernels need in_amax and dout_amax (fsc_amax of the operands)");
+        if (d->kh == 3) rc = launch_wgrad_x3<3, 3>(px, in, dout, part, in_amax, dout_amax, st);
+        else rc = launch_wgrad_x3<1, 3>(px, in, dout, part, in_amax, dout_amax, st);
         if (rc) return rc;
         const int taps = d->kh * d->kw;
         const int rthreads = d->c_out >= 128 ? 128 : 64;

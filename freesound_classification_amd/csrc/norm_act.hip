@@ -134,8 +134,10 @@ __device__ __forceinline__ float act(float z, float alpha, bool has_alpha) {
 // one (n, c) plane per blockIdx.x, blockIdx.y strides over the plane
 __global__ __launch_bounds__(kThreads) void fwd_plane_kernel(
     const float* __restrict__ x, const float* __restrict__ res, const float* __restrict__ scale,
-    const float* __restrict__ shift, const float* __restrict__ alpha, float* __restrict__ y, int c, long hw) {
+    const float* __restrict__ shift, const float* __restrict__ alpha, float* __restrict__ y, int c, long hw,
+    float* y_amax) {
     const long plane = blockIdx.x;
+    float mx = 0.f;
     const int ch = (int)(plane % c);
     const float sc = scale[ch], sh = shift[ch];
     const bool has_alpha = alpha != nullptr;
@@ -155,46 +157,60 @@ __global__ __launch_bounds__(kThreads) void fwd_plane_kernel(
             z.x = act(z.x, al, has_alpha); z.y = act(z.y, al, has_alpha);
             z.z = act(z.z, al, has_alpha); z.w = act(z.w, al, has_alpha);
             reinterpret_cast<float4*>(py)[i] = z;
+            mx = fmaxf(fmaxf(mx, fabsf(z.x)), fmaxf(fabsf(z.y), fmaxf(fabsf(z.z), fabsf(z.w))));
         }
     } else {
         for (long i = (long)blockIdx.y * kThreads + threadIdx.x; i < hw; i += (long)gridDim.y * kThreads) {
             float z = fmaf(px[i], sc, sh);
             if (pr) z += pr[i];
-            py[i] = act(z, al, has_alpha);
+            z = act(z, al, has_alpha);
+            py[i] = z;
+            mx = fmaxf(mx, fabsf(z));
         }
     }
+    if (y_amax) fsc::publish_amax(y_amax, mx);
 }
 
 // planes of 2..511 pixels: one wavefront per (n, c) plane, four planes per workgroup
 __global__ __launch_bounds__(kThreads) void fwd_wave_kernel(
     const float* __restrict__ x, const float* __restrict__ res, const float* __restrict__ scale,
     const float* __restrict__ shift, const float* __restrict__ alpha, float* __restrict__ y, int c, long hw,
-    long planes) {
-    const long plane = (long)blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6);
-    if (plane >= planes) return;
+    long planes, float* y_amax) {
+    long plane = (long)blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6);
+    const long hw_live = plane < planes ? hw : 0;        // (no early exit: publish_amax synchronises the block)
+    if (plane >= planes) plane = planes - 1;
     const int lane = threadIdx.x & 63;
     const int ch = (int)(plane % c);
     const float sc = scale[ch], sh = shift[ch];
     const bool has_alpha = alpha != nullptr;
     const float al = has_alpha ? alpha[ch] : 0.f;
     const long base = plane * hw;
-    for (long i = lane; i < hw; i += 64) {
+    float mx = 0.f;
+    for (long i = lane; i < hw_live; i += 64) {
         float z = fmaf(x[base + i], sc, sh);
         if (res) z += res[base + i];
-        y[base + i] = act(z, al, has_alpha);
+        z = act(z, al, has_alpha);
+        y[base + i] = z;
+        mx = fmaxf(mx, fabsf(z));
     }
+    if (y_amax) fsc::publish_amax(y_amax, mx);
 }
 
 // hw == 1 (BatchNorm1d on (N, C)): flat indexing
 __global__ void fwd_flat_kernel(const float* __restrict__ x, const float* __restrict__ res,
                                 const float* __restrict__ scale, const float* __restrict__ shift,
-                                const float* __restrict__ alpha, float* __restrict__ y, int c, long hw, long total) {
+                                const float* __restrict__ alpha, float* __restrict__ y, int c, long hw, long total,
+                                float* y_amax) {
+    float mx = 0.f;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int ch = (int)((i / hw) % c);
         float z = fmaf(x[i], scale[ch], shift[ch]);
         if (res) z += res[i];
-        y[i] = (alpha && !(z > 0.f)) ? alpha[ch] * z : z;
+        z = (alpha && !(z > 0.f)) ? alpha[ch] * z : z;
+        y[i] = z;
+        mx = fmaxf(mx, fabsf(z));
     }
+    if (y_amax) fsc::publish_amax(y_amax, mx);
 }
 
 // ---------------------------------------------------------------- backward
@@ -308,8 +324,11 @@ __global__ void bwd_rows_kernel(BwdArgs a, double* __restrict__ part) {
 }
 
 __global__ void bwd_finalize_kernel(int c, double count, int nsplit, const double* __restrict__ part,
-                                    float* dgamma, float* dbeta, float* dalpha, float* coef, float* dx_chan_sum) {
+                                    float* dgamma, float* dbeta, float* dalpha, float* coef, float* dx_chan_sum,
+                                    float* dx_amax) {
     const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+    if (dx_amax)
+        for (int i = ch; i < fsc::kAmaxFloats; i += gridDim.x * blockDim.x) dx_amax[i] = 0.f;
     if (ch >= c) return;
     double s0 = 0.0, s1 = 0.0, s2 = 0.0;
     for (int s = 0; s < nsplit; ++s) {
@@ -326,9 +345,10 @@ __global__ void bwd_finalize_kernel(int c, double count, int nsplit, const doubl
 
 __global__ __launch_bounds__(kThreads) void bwd_apply_plane_kernel(BwdArgs a, const float* __restrict__ coef,
                                                                     float* __restrict__ dx, float* __restrict__ dres,
-                                                                    float* dx_chan_sum) {
+                                                                    float* dx_chan_sum, float* dx_amax) {
     __shared__ float scratch[kThreads / 64];
     const long plane = blockIdx.x;
+    float mx = 0.f;
     const int ch = (int)(plane % a.c);
     const float mean = a.mean[ch], invstd = a.invstd[ch];
     const float g = a.gamma ? a.gamma[ch] : 1.f, b = a.beta ? a.beta[ch] : 0.f;
@@ -362,6 +382,7 @@ __global__ __launch_bounds__(kThreads) void bwd_apply_plane_kernel(BwdArgs a, co
                 zv[e] = (has_alpha && !(z > 0.f)) ? al * us[e] : us[e];
                 dv[e] = k * (zv[e] - c1 - xh * c2);
                 acc += dv[e];
+                mx = fmaxf(mx, fabsf(dv[e]));
             }
             reinterpret_cast<float4*>(pdx)[i4] = make_float4(dv[0], dv[1], dv[2], dv[3]);
             if (pdr) reinterpret_cast<float4*>(pdr)[i4] = make_float4(zv[0], zv[1], zv[2], zv[3]);
@@ -377,21 +398,24 @@ __global__ __launch_bounds__(kThreads) void bwd_apply_plane_kernel(BwdArgs a, co
             pdx[i] = d;
             if (pdr) pdr[i] = dz;
             acc += d;
+            mx = fmaxf(mx, fabsf(d));
         }
     }
     if (dx_chan_sum) {
         const float t = fsc::block_sum<float, kThreads / 64>(acc, scratch);
         if (threadIdx.x == 0) atomicAdd(dx_chan_sum + ch, t);
     }
+    if (dx_amax) fsc::publish_amax(dx_amax, mx);
 }
 
 // planes of 2..511 pixels: one wavefront per plane; the per-channel sum of dx leaves the wave as
 // ONE atomic (the flat kernel below issued one per element and serialised on C addresses)
 __global__ __launch_bounds__(kThreads) void bwd_apply_wave_kernel(BwdArgs a, const float* __restrict__ coef,
                                                                    float* __restrict__ dx, float* __restrict__ dres,
-                                                                   float* dx_chan_sum, long planes) {
-    const long plane = (long)blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6);
-    if (plane >= planes) return;
+                                                                   float* dx_chan_sum, long planes, float* dx_amax) {
+    long plane = (long)blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6);
+    const long hw_live = plane < planes ? a.hw : 0;      // (no early exit: publish_amax synchronises the block)
+    if (plane >= planes) plane = planes - 1;
     const int lane = threadIdx.x & 63;
     const int ch = (int)(plane % a.c);
     const float mean = a.mean[ch], invstd = a.invstd[ch];
@@ -403,8 +427,8 @@ __global__ __launch_bounds__(kThreads) void bwd_apply_wave_kernel(BwdArgs a, con
     const long base = plane * a.hw;
     const float gval = a.gmax_dy ? a.gmax_dy[plane] : 0.f;
     const long gpos = a.gmax_dy ? (long)a.gmax_idx[plane] : -1;
-    float acc = 0.f;
-    for (long i = lane; i < a.hw; i += 64) {
+    float acc = 0.f, mx = 0.f;
+    for (long i = lane; i < hw_live; i += 64) {
         const float xh = (a.x[base + i] - mean) * invstd;
         float z = fmaf(xh, g, b);
         if (a.res) z += a.res[base + i];
@@ -415,11 +439,13 @@ __global__ __launch_bounds__(kThreads) void bwd_apply_wave_kernel(BwdArgs a, con
         dx[base + i] = d;
         if (dres) dres[base + i] = dz;
         acc += d;
+        mx = fmaxf(mx, fabsf(d));
     }
     if (dx_chan_sum) {
         acc = fsc::wave_sum(acc);
-        if (lane == 0) atomicAdd(dx_chan_sum + ch, acc);
+        if (lane == 0 && hw_live) atomicAdd(dx_chan_sum + ch, acc);
     }
+    if (dx_amax) fsc::publish_amax(dx_amax, mx);
 }
 
 // BN backward apply fused with the backward of the 2x2 (or 1x2) max-pool that produced x: instead
@@ -431,7 +457,7 @@ __global__ __launch_bounds__(kThreads) void bwd_apply_unpool_kernel(BwdArgs a, c
                                                                      const uint8_t* __restrict__ pool_idx,
                                                                      float* __restrict__ dc, float* dx_chan_sum,
                                                                      int h, int w, int ph, int oh, int ow,
-                                                                     int colp_log2) {
+                                                                     int colp_log2, float* dc_amax) {
     __shared__ float scratch[kThreads / 64];
     const long plane = blockIdx.x;
     const int ch = (int)(plane % a.c);
@@ -448,7 +474,7 @@ __global__ __launch_bounds__(kThreads) void bwd_apply_unpool_kernel(BwdArgs a, c
     float* pdc = dc + plane * h * w;
     const int colp = 1 << colp_log2, rows_per_block = kThreads >> colp_log2;
     const int tr = threadIdx.x >> colp_log2, tc = threadIdx.x & (colp - 1);
-    float acc = 0.f;
+    float acc = 0.f, mx = 0.f;
     for (int oy = blockIdx.y * rows_per_block + tr; oy < oh; oy += gridDim.y * rows_per_block) {
         float* r0 = pdc + (long)oy * ph * w;
         for (int ox = tc; ox < ow; ox += colp) {
@@ -460,6 +486,7 @@ __global__ __launch_bounds__(kThreads) void bwd_apply_unpool_kernel(BwdArgs a, c
             const float dz = (has_alpha && !(z > 0.f)) ? al * up : up;
             const float d = k * (dz - c1 - xh * c2);
             acc += d;
+            mx = fmaxf(mx, fabsf(d));
             const int pos = pi[i];
             // one 8-byte store per window row (4-byte aligned): half the store instructions of the scalar form
             typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -478,10 +505,12 @@ __global__ __launch_bounds__(kThreads) void bwd_apply_unpool_kernel(BwdArgs a, c
         const float t = fsc::block_sum<float, kThreads / 64>(acc, scratch);
         if (threadIdx.x == 0) atomicAdd(dx_chan_sum + ch, t);
     }
+    if (dc_amax) fsc::publish_amax(dc_amax, mx);
 }
 
 __global__ void bwd_apply_flat_kernel(BwdArgs a, const float* __restrict__ coef, float* __restrict__ dx,
-                                      float* __restrict__ dres, float* dx_chan_sum, long total) {
+                                      float* __restrict__ dres, float* dx_chan_sum, long total, float* dx_amax) {
+    float mx = 0.f;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const long plane = i / a.hw;
         const int ch = (int)(plane % a.c);
@@ -497,7 +526,9 @@ __global__ void bwd_apply_flat_kernel(BwdArgs a, const float* __restrict__ coef,
         dx[i] = d;
         if (dres) dres[i] = dz;
         if (dx_chan_sum) atomicAdd(dx_chan_sum + ch, d);
+        mx = fmaxf(mx, fabsf(d));
     }
+    if (dx_amax) fsc::publish_amax(dx_amax, mx);
 }
 
 int pick_split(int n, int c, long hw) {
@@ -566,23 +597,27 @@ int fsc_bn_eval_prepare(int c, const float* gamma, const float* beta, const floa
 }
 
 int fsc_bn_act_fwd(const float* x, const float* residual, const float* scale, const float* shift,
-                   const float* alpha, float* y, int n, int c, long hw, fsc_stream_t stream) {
+                   const float* alpha, float* y, int n, int c, long hw, float* y_amax, fsc_stream_t stream) {
     FSC_CHECK_ARG(x && scale && shift && y, "fsc_bn_act_fwd: null pointer");
     FSC_CHECK_ARG(n > 0 && c > 0 && hw > 0, "fsc_bn_act_fwd: bad shape (%d, %d, %ld)", n, c, hw);
     hipStream_t st = fsc::as_stream(stream);
+    if (y_amax) {
+        hipError_t e = hipMemsetAsync(y_amax, 0, fsc::kAmaxFloats * sizeof(float), st);
+        FSC_CHECK_ARG(e == hipSuccess, "fsc_bn_act_fwd: memset failed: %s", hipGetErrorString(e));
+    }
     const long total = (long)n * c * hw;
     if (hw >= 512) {
         hipLaunchKernelGGL(fwd_plane_kernel, dim3((unsigned)((long)n * c), plane_grid_y(hw)), dim3(kThreads), 0, st, x,
-                           residual, scale, shift, alpha, y, c, hw);
+                           residual, scale, shift, alpha, y, c, hw, y_amax);
     } else if (hw > 1) {
         const long planes = (long)n * c;
         hipLaunchKernelGGL(fwd_wave_kernel, dim3((unsigned)((planes + 3) / 4)), dim3(kThreads), 0, st, x, residual,
-                           scale, shift, alpha, y, c, hw, planes);
+                           scale, shift, alpha, y, c, hw, planes, y_amax);
     } else {
         long blocks = (total + 255) / 256;
         if (blocks > 8192) blocks = 8192;
         hipLaunchKernelGGL(fwd_flat_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, residual, scale, shift,
-                           alpha, y, c, hw, total);
+                           alpha, y, c, hw, total, y_amax);
     }
     FSC_LAUNCH_CHECK("fsc_bn_act_fwd");
     return 0;
@@ -592,7 +627,7 @@ int fsc_bn_act_bwd(const float* dy, const float* gmax_dy, const int* gmax_idx, c
                    const float* residual, const float* save_mean, const float* save_invstd,
                    const float* gamma, const float* beta, const float* alpha, float* dx, float* dresidual,
                    float* dgamma, float* dbeta, float* dalpha, float* dx_chan_sum, int n, int c, long hw,
-                   void* workspace, fsc_stream_t stream) {
+                   void* workspace, float* dx_amax, fsc_stream_t stream) {
     FSC_CHECK_ARG(x && save_mean && save_invstd && dx && workspace, "fsc_bn_act_bwd: null pointer");
     FSC_CHECK_ARG(dy || gmax_dy, "fsc_bn_act_bwd: no upstream gradient");
     FSC_CHECK_ARG((gmax_dy == nullptr) == (gmax_idx == nullptr), "fsc_bn_act_bwd: gmax_dy / gmax_idx must come in pairs");
@@ -610,20 +645,20 @@ int fsc_bn_act_bwd(const float* dy, const float* gmax_dy, const int* gmax_idx, c
         hipLaunchKernelGGL(bwd_partial_kernel, dim3(c, nsplit), dim3(kThreads), 0, st, a, nsplit, hwp_log2_for(hw), p.part);
     }
     hipLaunchKernelGGL(bwd_finalize_kernel, dim3(fsc::ceil_div(c, 128)), dim3(128), 0, st, c, (double)n * (double)hw,
-                       nsplit, p.part, dgamma, dbeta, dalpha, p.coef, dx_chan_sum);
+                       nsplit, p.part, dgamma, dbeta, dalpha, p.coef, dx_chan_sum, dx_amax);
     const long total = (long)n * c * hw;
     if (hw >= 512) {
         hipLaunchKernelGGL(bwd_apply_plane_kernel, dim3((unsigned)((long)n * c), plane_grid_y(hw)), dim3(kThreads), 0,
-                           st, a, p.coef, dx, dresidual, dx_chan_sum);
+                           st, a, p.coef, dx, dresidual, dx_chan_sum, dx_amax);
     } else if (hw > 1) {
         const long planes = (long)n * c;
         hipLaunchKernelGGL(bwd_apply_wave_kernel, dim3((unsigned)((planes + 3) / 4)), dim3(kThreads), 0, st, a, p.coef,
-                           dx, dresidual, dx_chan_sum, planes);
+                           dx, dresidual, dx_chan_sum, planes, dx_amax);
     } else {
         long blocks = (total + 255) / 256;
         if (blocks > 8192) blocks = 8192;
         hipLaunchKernelGGL(bwd_apply_flat_kernel, dim3((unsigned)blocks), dim3(256), 0, st, a, p.coef, dx, dresidual,
-                           dx_chan_sum, total);
+                           dx_chan_sum, total, dx_amax);
     }
     FSC_LAUNCH_CHECK("fsc_bn_act_bwd");
     return 0;
@@ -632,7 +667,7 @@ int fsc_bn_act_bwd(const float* dy, const float* gmax_dy, const int* gmax_idx, c
 int fsc_bn_act_bwd_unpool(const float* dy, const float* x, const float* save_mean, const float* save_invstd,
                           const float* gamma, const float* beta, const float* alpha, const uint8_t* pool_idx,
                           float* dc, float* dgamma, float* dbeta, float* dalpha, float* dx_chan_sum, int n, int c,
-                          int h, int w, int ph, void* workspace, fsc_stream_t stream) {
+                          int h, int w, int ph, void* workspace, float* dc_amax, fsc_stream_t stream) {
     FSC_CHECK_ARG(dy && x && save_mean && save_invstd && pool_idx && dc && workspace, "fsc_bn_act_bwd_unpool: null pointer");
     FSC_CHECK_ARG((ph == 1 || ph == 2) && n > 0 && c > 0 && h >= ph && w >= 2, "fsc_bn_act_bwd_unpool: bad shape");
     const int oh = h / ph, ow = w / 2;
@@ -643,7 +678,7 @@ int fsc_bn_act_bwd_unpool(const float* dy, const float* x, const float* save_mea
     const int nsplit = pick_split(n, c, hw);
     hipLaunchKernelGGL(bwd_partial_kernel, dim3(c, nsplit), dim3(kThreads), 0, st, a, nsplit, hwp_log2_for(hw), p.part);
     hipLaunchKernelGGL(bwd_finalize_kernel, dim3(fsc::ceil_div(c, 128)), dim3(128), 0, st, c, (double)n * (double)hw,
-                       nsplit, p.part, dgamma, dbeta, dalpha, p.coef, dx_chan_sum);
+                       nsplit, p.part, dgamma, dbeta, dalpha, p.coef, dx_chan_sum, dc_amax);
     int cl = 0;
     while ((1 << cl) < ow && cl < 8) ++cl;
     const int per_block = kThreads >> cl;
@@ -651,7 +686,7 @@ int fsc_bn_act_bwd_unpool(const float* dy, const float* x, const float* save_mea
     if (gy < 1) gy = 1;
     if (gy > 64) gy = 64;
     hipLaunchKernelGGL(bwd_apply_unpool_kernel, dim3((unsigned)((long)n * c), gy), dim3(kThreads), 0, st, a, p.coef,
-                       pool_idx, dc, dx_chan_sum, h, w, ph, oh, ow, cl);
+                       pool_idx, dc, dx_chan_sum, h, w, ph, oh, ow, cl, dc_amax);
     FSC_LAUNCH_CHECK("fsc_bn_act_bwd_unpool");
     return 0;
 }

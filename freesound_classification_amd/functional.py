@@ -154,12 +154,30 @@ class _timed:
 def set_conv_arith(mode):
     """0 / "f32": native fp32 MFMA; 6, 9 / "bf16x6", "bf16x9": fp32 via exact three-limb bf16 split
     with that many limb products (include/fsc_hip.h, fsc_conv_set_arith)."""
-    mode = {"f32": 0, "bf16x6": 6, "bf16x9": 9}.get(mode, mode)
+    mode = {"f32": 0, "f16x3": 3, "bf16x6": 6, "bf16x9": 9}.get(mode, mode)
     call("fsc_conv_set_arith", int(mode))
 
 
 def get_conv_arith():
     return _lib.load().fsc_conv_get_arith()
+
+
+AMAX_FLOATS = 512          # include/fsc_hip.h FSC_AMAX_FLOATS
+
+
+def amax(x):
+    """max |x| as an FSC_AMAX_FLOATS slot buffer (fsc_amax; the value is the maximum over the buffer)."""
+    out = _empty((AMAX_FLOATS,), x)
+    call("fsc_amax", ptr(x), x.numel(), ptr(out), stream_ptr())
+    return out
+
+
+def _operand_amax(x, given):
+    """The split-fp16 conv kernels scale their operands by the tensor's largest magnitude; producers that
+    know it pass it along, otherwise it costs one read of the tensor."""
+    if given is not None or get_conv_arith() != 3:
+        return given
+    return amax(x)
 
 
 def conv_pack(desc, weight, dgrad):
@@ -172,15 +190,16 @@ def conv_pack(desc, weight, dgrad):
     return packed
 
 
-def conv_forward(x, weight, bias):
+def conv_forward(x, weight, bias, x_amax=None):
     """x (N, Cin, H, W), weight (Cout, Cin, kh, kw) -> (N, Cout, H, W); stride 1, same pad."""
     n, c_in, h, w = x.shape
     c_out, _, kh, kw = weight.shape
     d = _desc(n, c_in, c_out, h, w, kh, kw)
     packed = conv_pack(d, weight, 0)
     out = _empty((n, c_out, h, w), x)
+    x_amax = _operand_amax(x, x_amax)
     with _timed(d, 0):
-        call("fsc_conv_fwd", C.byref(d), ptr(x), ptr(packed), ptr(bias), 0, 0, ptr(out), stream_ptr())
+        call("fsc_conv_fwd", C.byref(d), ptr(x), ptr(packed), ptr(bias), 0, 0, ptr(out), ptr(x_amax), stream_ptr())
     return out
 
 
@@ -200,7 +219,7 @@ def conv_pool_forward(x, weight, bias):
     return y, idx, (n, c_out, h, w)
 
 
-def conv_dgrad(dout, weight, x_shape, accumulate_into=None):
+def conv_dgrad(dout, weight, x_shape, accumulate_into=None, dout_amax=None):
     """Gradient w.r.t. the conv input.  With `accumulate_into` the result is added in place."""
     n, c_in, h, w = x_shape
     c_out, _, kh, kw = weight.shape
@@ -212,8 +231,9 @@ def conv_dgrad(dout, weight, x_shape, accumulate_into=None):
     else:
         dx = accumulate_into
         acc = 1
+    dout_amax = _operand_amax(dout, dout_amax)
     with _timed(d, 1):
-        call("fsc_conv_fwd", C.byref(d), ptr(dout), ptr(packed), None, 1, acc, ptr(dx), stream_ptr())
+        call("fsc_conv_fwd", C.byref(d), ptr(dout), ptr(packed), None, 1, acc, ptr(dx), ptr(dout_amax), stream_ptr())
     return dx
 
 
@@ -240,7 +260,7 @@ def join_side_stream(device):
         torch.cuda.current_stream(device).wait_stream(_SIDE[str(device)])
 
 
-def conv_wgrad(x, dout, weight_shape, on_side_stream=False):
+def conv_wgrad(x, dout, weight_shape, on_side_stream=False, x_amax=None, dout_amax=None):
     """Weight gradient.  With on_side_stream the kernel is launched on the side stream and the caller
     must `join_side_stream` before the result is consumed (ConvBlockFn does)."""
     n, c_in, h, w = x.shape
@@ -253,8 +273,9 @@ def conv_wgrad(x, dout, weight_shape, on_side_stream=False):
     def run():
         ws = torch.empty(nbytes // 4, device=x.device, dtype=torch.float32)
         dw = _empty(tuple(weight_shape), x)
+        xa, da = _operand_amax(x, x_amax), _operand_amax(dout, dout_amax)
         with _timed(d, 2):
-            call("fsc_conv_wgrad", C.byref(d), ptr(x), ptr(dout), ptr(dw), ptr(ws), stream_ptr())
+            call("fsc_conv_wgrad", C.byref(d), ptr(x), ptr(dout), ptr(dw), ptr(ws), ptr(xa), ptr(da), stream_ptr())
         return dw
 
     if not (ASYNC_WGRAD and on_side_stream):
@@ -310,18 +331,25 @@ def bn_prepare(x, bn, training):
     return st
 
 
-def bn_act_forward(x, st, alpha=None, residual=None):
+def _want_amax():
+    return get_conv_arith() == 3
+
+
+def bn_act_forward(x, st, alpha=None, residual=None, with_amax=False):
+    """y = act(bn(x) [+ residual]).  with_amax: returns (y, max |y| as a device scalar or None) -- the scale
+    of the split-fp16 conv kernels, reported by the kernel that writes y."""
     n, c = x.shape[0], x.shape[1]
     hw = x.numel() // (n * c)
     y = torch.empty_like(x)
+    y_amax = _empty((AMAX_FLOATS,), x) if with_amax and _want_amax() else None
     call("fsc_bn_act_fwd", ptr(x), ptr(residual), ptr(st.scale), ptr(st.shift), ptr(alpha), ptr(y),
-         n, c, hw, stream_ptr())
-    return y
+         n, c, hw, ptr(y_amax), stream_ptr())
+    return (y, y_amax) if with_amax else y
 
 
 def bn_act_backward(dy, x, st, bn, alpha=None, residual=None, gmax=None, want_dx=True,
-                    want_dres=False, want_chan_sum=False):
-    """Returns (dx, dresidual, dgamma, dbeta, dalpha, dx_chan_sum)."""
+                    want_dres=False, want_chan_sum=False, with_amax=False):
+    """Returns (dx, dresidual, dgamma, dbeta, dalpha, dx_chan_sum) [+ (max |dx|,) with with_amax]."""
     n, c = x.shape[0], x.shape[1]
     hw = x.numel() // (n * c)
     dx = torch.empty_like(x)          # always produced (the apply pass also yields chan sums)
@@ -331,25 +359,29 @@ def bn_act_backward(dy, x, st, bn, alpha=None, residual=None, gmax=None, want_dx
     dalpha = _empty((c,), x) if alpha is not None else None
     csum = _empty((c,), x) if want_chan_sum else None
     gdy, gidx = gmax if gmax is not None else (None, None)
+    dx_amax = _empty((AMAX_FLOATS,), x) if with_amax and _want_amax() else None
     call("fsc_bn_act_bwd", ptr(dy), ptr(gdy), ptr(gidx), ptr(x), ptr(residual), ptr(st.mean),
          ptr(st.invstd), ptr(bn.weight), ptr(bn.bias), ptr(alpha), ptr(dx), ptr(dres), ptr(dgamma),
-         ptr(dbeta), ptr(dalpha), ptr(csum), n, c, hw, ptr(_bn_ws(c, x)), stream_ptr())
+         ptr(dbeta), ptr(dalpha), ptr(csum), n, c, hw, ptr(_bn_ws(c, x)), ptr(dx_amax), stream_ptr())
+    if with_amax:
+        return dx, dres, dgamma, dbeta, dalpha, csum, dx_amax
     return dx, dres, dgamma, dbeta, dalpha, csum
 
 
 def bn_act_backward_unpool(dy, x, st, bn, alpha, pool_idx, c_shape, ph):
     """Backward of BN+PReLU on a pooled tensor fused with the max-pool backward.
-    Returns (dc at the un-pooled shape, dgamma, dbeta, dalpha, per-channel sum of the gradient)."""
+    Returns (dc at the un-pooled shape, dgamma, dbeta, dalpha, per-channel sum of the gradient, max |dc| or None)."""
     n, c, h, w = c_shape
     dc = _empty(tuple(c_shape), x)
     dgamma = _empty((c,), x)
     dbeta = _empty((c,), x)
     dalpha = _empty((c,), x) if alpha is not None else None
     csum = _empty((c,), x)
+    dc_amax = _empty((AMAX_FLOATS,), x) if _want_amax() else None
     call("fsc_bn_act_bwd_unpool", ptr(dy), ptr(x), ptr(st.mean), ptr(st.invstd), ptr(bn.weight), ptr(bn.bias),
          ptr(alpha), ptr(pool_idx), ptr(dc), ptr(dgamma), ptr(dbeta), ptr(dalpha), ptr(csum), n, c, h, w, ph,
-         ptr(_bn_ws(c, x)), stream_ptr())
-    return dc, dgamma, dbeta, dalpha, csum
+         ptr(_bn_ws(c, x)), ptr(dc_amax), stream_ptr())
+    return dc, dgamma, dbeta, dalpha, csum, dc_amax
 
 
 # ------------------------------------------------------------------------------ pooling
@@ -397,28 +429,28 @@ def _block_forward(x, mods, training, want_head, ph, keep):
     k = _BlockCtx()
     k.x_shape = tuple(x.shape)
     st_a = bn_prepare(x, bn_a, training)
-    a = bn_act_forward(x, st_a)
+    a, a_max = bn_act_forward(x, st_a, with_amax=True)
     w_a, b_a = _conv_params(conv_a)
     fused = conv_pool_forward(a, w_a, b_a) if ph == 2 else None
     if fused is not None:
         p, pidx, k.c_shape = fused
     else:
-        c = conv_forward(a, w_a, b_a)
+        c = conv_forward(a, w_a, b_a, x_amax=a_max)
         p, pidx = maxpool_forward(c, ph)
         k.c_shape = tuple(c.shape)
         del c
     st_b = bn_prepare(p, bn_b, training)
-    b = bn_act_forward(p, st_b, prelu_b.weight)
+    b, b_max = bn_act_forward(p, st_b, prelu_b.weight, with_amax=True)
     w1, b1 = _conv_params(res.conv1)
-    r1 = conv_forward(b, w1, b1)
+    r1 = conv_forward(b, w1, b1, x_amax=b_max)
     st1 = bn_prepare(r1, res.bn1, training)
-    s1 = bn_act_forward(r1, st1, res.prelu1.weight)
+    s1, s1_max = bn_act_forward(r1, st1, res.prelu1.weight, with_amax=True)
     w2, b2 = _conv_params(res.conv2)
-    r2 = conv_forward(s1, w2, b2)
+    r2 = conv_forward(s1, w2, b2, x_amax=s1_max)
     st2 = bn_prepare(r2, res.bn2, training)
-    s2 = bn_act_forward(r2, st2, res.prelu2.weight)
+    s2, s2_max = bn_act_forward(r2, st2, res.prelu2.weight, with_amax=True)
     w3, b3 = _conv_params(res.conv3)
-    r3 = conv_forward(s2, w3, b3)
+    r3 = conv_forward(s2, w3, b3, x_amax=s2_max)
     st3 = bn_prepare(r3, res.bn3, training)
     out = bn_act_forward(r3, st3, res.prelu3.weight, residual=b)
     feat, fidx = (None, None)
@@ -429,6 +461,7 @@ def _block_forward(x, mods, training, want_head, ph, keep):
         k.r1, k.s1, k.r2, k.s2, k.r3 = r1, s1, r2, s2, r3
         k.st_a, k.st_b, k.st1, k.st2, k.st3 = st_a, st_b, st1, st2, st3
         k.fidx = fidx
+        k.amax = (a_max, b_max, s1_max, s2_max)
     return out, feat, k
 
 
@@ -474,34 +507,35 @@ class ConvBlockFn(torch.autograd.Function):
         if d_out is None and gmax is None:
             raise _lib.FscError("ConvBlockFn.backward: no upstream gradient")
         # ---- out = prelu3(bn3(r3) + b)
-        dr3, db, dg3, dbt3, dal3, dbias3 = bn_act_backward(
+        a_max, b_max, s1_max, s2_max = k.amax
+        dr3, db, dg3, dbt3, dal3, dbias3, dr3_max = bn_act_backward(
             d_out, k.r3, k.st3, res.bn3, res.prelu3.weight, residual=k.b, gmax=gmax,
-            want_dres=True, want_chan_sum=True)
+            want_dres=True, want_chan_sum=True, with_amax=True)
         w3, _ = _conv_params(res.conv3)
-        dw3 = conv_wgrad(k.s2, dr3, w3.shape, True)
-        ds2 = conv_dgrad(dr3, w3, k.s2.shape)
+        dw3 = conv_wgrad(k.s2, dr3, w3.shape, True, x_amax=s2_max, dout_amax=dr3_max)
+        ds2 = conv_dgrad(dr3, w3, k.s2.shape, dout_amax=dr3_max)
         del dr3
-        dr2, _, dg2, dbt2, dal2, dbias2 = bn_act_backward(ds2, k.r2, k.st2, res.bn2, res.prelu2.weight,
-                                                          want_chan_sum=True)
+        dr2, _, dg2, dbt2, dal2, dbias2, dr2_max = bn_act_backward(ds2, k.r2, k.st2, res.bn2, res.prelu2.weight,
+                                                                   want_chan_sum=True, with_amax=True)
         del ds2
         w2, _ = _conv_params(res.conv2)
-        dw2 = conv_wgrad(k.s1, dr2, w2.shape, True)
-        ds1 = conv_dgrad(dr2, w2, k.s1.shape)
+        dw2 = conv_wgrad(k.s1, dr2, w2.shape, True, x_amax=s1_max, dout_amax=dr2_max)
+        ds1 = conv_dgrad(dr2, w2, k.s1.shape, dout_amax=dr2_max)
         del dr2
-        dr1, _, dg1, dbt1, dal1, dbias1 = bn_act_backward(ds1, k.r1, k.st1, res.bn1, res.prelu1.weight,
-                                                          want_chan_sum=True)
+        dr1, _, dg1, dbt1, dal1, dbias1, dr1_max = bn_act_backward(ds1, k.r1, k.st1, res.bn1, res.prelu1.weight,
+                                                                   want_chan_sum=True, with_amax=True)
         del ds1
         w1, _ = _conv_params(res.conv1)
-        dw1 = conv_wgrad(k.b, dr1, w1.shape, True)
-        db = conv_dgrad(dr1, w1, k.b.shape, accumulate_into=db)     # residual + conv1 paths
+        dw1 = conv_wgrad(k.b, dr1, w1.shape, True, x_amax=b_max, dout_amax=dr1_max)
+        db = conv_dgrad(dr1, w1, k.b.shape, accumulate_into=db, dout_amax=dr1_max)     # residual + conv1 paths
         del dr1
         # ---- b = prelu(bn_b(p))
-        dc, dgb, dbtb, dalb, dbias_a = bn_act_backward_unpool(db.contiguous(), k.p, k.st_b, bn_b, prelu_b.weight,
-                                                              k.pidx, k.c_shape, ph)
+        dc, dgb, dbtb, dalb, dbias_a, dc_max = bn_act_backward_unpool(db.contiguous(), k.p, k.st_b, bn_b, prelu_b.weight,
+                                                                      k.pidx, k.c_shape, ph)
         del db
         wa, _ = _conv_params(conv_a)
-        dwa = conv_wgrad(k.a, dc, wa.shape, True)
-        da = conv_dgrad(dc, wa, k.a.shape)
+        dwa = conv_wgrad(k.a, dc, wa.shape, True, x_amax=a_max, dout_amax=dc_max)
+        da = conv_dgrad(dc, wa, k.a.shape, dout_amax=dc_max)
         del dc
         dx, _, dga, dbta, _, _ = bn_act_backward(da, k.x, k.st_a, bn_a)
         if not ctx.x_needs_grad:

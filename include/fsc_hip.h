@@ -81,7 +81,15 @@ int fsc_conv_pack_weights(const fsc_conv_desc* d, const float* weight, int dgrad
  * `packed` must come from fsc_conv_pack_weights(dgrad=1). */
 int fsc_conv_fwd(const fsc_conv_desc* d, const float* in, const float* packed,
                  const float* bias, int dgrad, int accumulate, float* out,
-                 fsc_stream_t stream);
+                 const float* in_amax, fsc_stream_t stream);
+/* Largest magnitude of a tensor.  The scaled split-fp16 arithmetic (fsc_conv_set_arith(3)) takes max |x| of each
+ * activation / gradient operand as an `*_amax` device buffer of FSC_AMAX_FLOATS non-negative floats whose
+ * maximum is the value (many slots so that the thousands of workgroups of a producer do not serialise on one
+ * address): from this function, or from the producers that report it for free while they write the tensor
+ * (fsc_bn_act_fwd / fsc_bn_act_bwd `*_amax` outputs).  A value larger than the true maximum is safe (it costs
+ * low-order bits); a smaller one may overflow fp16.  `*_amax` may be NULL in the other arithmetic modes. */
+#define FSC_AMAX_FLOATS 512
+int fsc_amax(const float* x, long n, float* out, fsc_stream_t stream);
 /* Stem layer (3x3, c_in <= 2) fused with the 2x2 max-pool that follows it (classifiers.py:526-532): writes the
  * pooled tensor (N, c_out, H/2, W/2) and the uint8 window indices of fsc_maxpool_fwd; the full-resolution conv
  * output is never materialised.  `packed` from fsc_conv_pack_weights(dgrad = 0).  fsc_conv_pool_supported
@@ -104,7 +112,8 @@ int fsc_conv_get_arith(void);
 size_t fsc_conv_wgrad_workspace_bytes(const fsc_conv_desc* d);
 /* dweight (c_out, c_in, kh, kw) = sum_pixels dout x in  (overwrites dweight) */
 int fsc_conv_wgrad(const fsc_conv_desc* d, const float* in, const float* dout,
-                   float* dweight, void* workspace, fsc_stream_t stream);
+                   float* dweight, void* workspace, const float* in_amax, const float* dout_amax,
+                   fsc_stream_t stream);
 
 /* ------------------------------------------------------------------ batch norm + PReLU (K6, K9, K11)
  * nn.BatchNorm2d/1d (train and eval) fused with the following per-channel PReLU and the
@@ -123,21 +132,23 @@ int fsc_bn_train_stats(const float* x, int n, int c, long hw, const float* gamma
 int fsc_bn_eval_prepare(int c, const float* gamma, const float* beta, const float* running_mean,
                         const float* running_var, float eps, float* scale, float* shift,
                         fsc_stream_t stream);
-/* y = act(x*scale + shift [+ residual]); act = PReLU(alpha[c]) if alpha != NULL else identity */
+/* y = act(x*scale + shift [+ residual]); act = PReLU(alpha[c]) if alpha != NULL else identity.
+ * y_amax (FSC_AMAX_FLOATS floats, may be NULL) receives max |y| -- the operand scale of the split-fp16 conv kernels. */
 int fsc_bn_act_fwd(const float* x, const float* residual, const float* scale,
                    const float* shift, const float* alpha, float* y, int n, int c, long hw,
-                   fsc_stream_t stream);
+                   float* y_amax, fsc_stream_t stream);
 /* backward of the fused unit.  Upstream gradient = dy (may be NULL) plus, when the output also
  * feeds a global max-pool head, gmax_dy[n*c] scattered at position gmax_idx[n*c] of each plane
  * (both NULL otherwise).  Outputs: dx; dresidual (may be NULL; equals the gradient at the
  * pre-activation); dgamma, dbeta, dalpha (C each; may be NULL); dx_chan_sum (C, may be NULL) =
- * per-channel sum of dx = bias gradient of the convolution that produced x. */
+ * per-channel sum of dx = bias gradient of the convolution that produced x; dx_amax (FSC_AMAX_FLOATS floats, may be
+ * NULL) = max |dx|. */
 int fsc_bn_act_bwd(const float* dy, const float* gmax_dy, const int* gmax_idx, const float* x,
                    const float* residual, const float* save_mean, const float* save_invstd,
                    const float* gamma, const float* beta, const float* alpha, float* dx,
                    float* dresidual, float* dgamma, float* dbeta, float* dalpha,
                    float* dx_chan_sum, int n, int c, long hw, void* workspace,
-                   fsc_stream_t stream);
+                   float* dx_amax, fsc_stream_t stream);
 
 /* Same backward for the unit that directly follows a max-pool (BN -> PReLU on the pooled tensor x,
  * classifiers.py:532-534), fused with the pool's backward: writes dc (N, C, h, w), the gradient of
@@ -147,7 +158,7 @@ int fsc_bn_act_bwd_unpool(const float* dy, const float* x, const float* save_mea
                           const float* save_invstd, const float* gamma, const float* beta,
                           const float* alpha, const uint8_t* pool_idx, float* dc, float* dgamma,
                           float* dbeta, float* dalpha, float* dx_chan_sum, int n, int c, int h,
-                          int w, int ph, void* workspace, fsc_stream_t stream);
+                          int w, int ph, void* workspace, float* dc_amax, fsc_stream_t stream);
 
 /* ------------------------------------------------------------------ pooling (K8, K12)
  * nn.MaxPool2d(2,2) / nn.MaxPool1d(2,2), floor mode (classifiers.py:532, 155);

@@ -504,7 +504,7 @@ def test_bn_act_bwd_fused_with_unpool(shape, ph):
     pd, pidx = F.maxpool_forward(cfull.detach().to(DEV), ph)
     st = F.bn_prepare(pd, dbn, True)
     alpha = prelu.weight.detach().to(DEV)
-    dc, dg, db, dal, csum = F.bn_act_backward_unpool(gy.to(DEV), pd, st, dbn, alpha, pidx, shape, ph)
+    dc, dg, db, dal, csum, _ = F.bn_act_backward_unpool(gy.to(DEV), pd, st, dbn, alpha, pidx, shape, ph)
     assert maxdiff(dc, cfull.grad) < 5e-5
     assert maxdiff(dg, bn.weight.grad) < 2e-4
     assert maxdiff(db, bn.bias.grad) < 2e-4

@@ -26,8 +26,10 @@ def run(kind, shape, iters):
     x = torch.randn(n, cin, h, w, device=dev)
     wt = torch.randn(cout, cin, k, k, device=dev) / (cin * k * k) ** 0.5
     gy = torch.randn(n, cout, h, w, device=dev)
-    fn = {"fwd": lambda: F.conv_forward(x, wt, None), "dgrad": lambda: F.conv_dgrad(gy, wt, x.shape),
-          "wgrad": lambda: F.conv_wgrad(x, gy, wt.shape)}[kind]
+    xa = F.amax(x) if F.get_conv_arith() == 3 else None      # producers report it in the model path
+    ga = F.amax(gy) if F.get_conv_arith() == 3 else None
+    fn = {"fwd": lambda: F.conv_forward(x, wt, None, x_amax=xa), "dgrad": lambda: F.conv_dgrad(gy, wt, x.shape, dout_amax=ga),
+          "wgrad": lambda: F.conv_wgrad(x, gy, wt.shape, x_amax=xa, dout_amax=ga)}[kind]
     fn()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -49,7 +51,7 @@ if __name__ == "__main__":
     ap.add_argument("kind", nargs="?", default="all")
     ap.add_argument("--shape", default=None)
     ap.add_argument("--iters", type=int, default=20)
-    ap.add_argument("--arith", default=None, help="f32 | bf16x6 | bf16x9")
+    ap.add_argument("--arith", default=None, help="f32 | f16x3 | bf16x6 | bf16x9")
     a = ap.parse_args()
     if a.arith:
         F.set_conv_arith(a.arith)
