@@ -1900,13 +1900,14 @@ size_t x3_limb_floats(const FwdPlan& p) {
     return (size_t)p.co_blocks * p.g.x_steps * p.cot * (p.x3 == 3 ? 2 : 3) * 256;
 }
 
-// Arithmetic of the 3x3 / k3 forward and dgrad kernels: 0 = native fp32 MFMA everywhere, 6 / 9 = split-bf16
-// kernel (that many limb products) wherever its tiling fits.  FSC_CONV_ARITH=f32|bf16x6|bf16x9 or fsc_conv_set_arith.
+// Arithmetic of the conv kernels: 0 = native fp32 MFMA everywhere; 3 = scaled split-fp16 (two limbs, three
+// products; the default), 6 / 9 = split-bf16 (three limbs, that many products) wherever the x3 tilings fit.
+// FSC_CONV_ARITH=f32|f16x3|bf16x6|bf16x9 or fsc_conv_set_arith.
 int g_conv_arith = -1;
 int conv_arith() {
     if (g_conv_arith < 0) {
         const char* e = getenv("FSC_CONV_ARITH");
-        g_conv_arith = 6;
+        g_conv_arith = 3;
         if (e && !strcmp(e, "f32")) g_conv_arith = 0;
         else if (e && !strcmp(e, "f16x3")) g_conv_arith = 3;
         else if (e && !strcmp(e, "bf16x6")) g_conv_arith = 6;

@@ -141,11 +141,12 @@ def restore_conv_arith():
     F.set_conv_arith(mode)
 
 
-@pytest.mark.parametrize("mode", [6, 9])
+@pytest.mark.parametrize("mode", [3, 6, 9])
 @pytest.mark.parametrize("case", X3_CASES)
 def test_conv_split_bf16_is_fp32_accurate(case, mode, restore_conv_arith):
-    """The three-limb bf16 kernels must be as accurate as fp32 arithmetic: their error against an fp64
-    convolution is bounded by a small multiple of the error PyTorch's own fp32 convolution makes."""
+    """The split-limb kernels (3: two scaled fp16 limbs, 6 / 9: three bf16 limbs) must be as accurate as fp32
+    arithmetic: their error against an fp64 convolution is bounded by a small multiple of the error PyTorch's
+    own fp32 convolution makes."""
     n, cin, cout, h, w, kh, kw = case
     torch.manual_seed(sum(case))
     x = torch.randn(n, cin, h, w)
@@ -217,7 +218,7 @@ def test_conv_split_bf16_random_shapes_against_native(restore_conv_arith):
         gy = torch.randn(n, cout, h, w, device=DEV)
         base = torch.randn_like(x)
         res = {}
-        for mode in (0, 6):
+        for mode in (0, 3, 6):
             F.set_conv_arith(mode)
             d = F._desc(n, cin, cout, h, w, kh, kw)
             seen.update(F.plan_name(d, m).split("<")[0] for m in (0, 1, 2))
@@ -226,15 +227,17 @@ def test_conv_split_bf16_random_shapes_against_native(restore_conv_arith):
         k_red = cin * kh * kw
         tols = (4e-6 * k_red ** 0.5 + 1e-5, 4e-6 * (cout * kh * kw) ** 0.5 + 1e-5, 4e-6 * (cout * kh * kw) ** 0.5 + 1e-5,
                 6e-6 * (n * h * w) ** 0.5 + 2e-5)
-        for name, a, bb, tol in zip(("fwd", "dgrad", "dgrad+acc", "wgrad"), res[0], res[6], tols):
-            assert maxdiff(a, bb) < tol, (trial, name, (n, cin, cout, h, w, kh, kw), maxdiff(a, bb), tol)
+        for mode in (3, 6):
+            for name, a, bb, tol in zip(("fwd", "dgrad", "dgrad+acc", "wgrad"), res[0], res[mode], tols):
+                assert maxdiff(a, bb) < tol, (trial, mode, name, (n, cin, cout, h, w, kh, kw), maxdiff(a, bb), tol)
     assert {"conv_fwd_x3_kernel", "conv_wgrad_x3_kernel", "conv_fwd_kernel", "conv_wgrad_kernel"} <= seen, seen
 
 
-def test_conv_split_bf16_exact_on_bf16_representable_inputs(restore_conv_arith):
-    """With inputs that are exactly representable in bf16 (single non-zero limb) and power-of-two
-    friendly sums the split kernel reproduces the integer result exactly."""
-    F.set_conv_arith(6)
+@pytest.mark.parametrize("mode", [3, 6])
+def test_conv_split_bf16_exact_on_bf16_representable_inputs(mode, restore_conv_arith):
+    """With inputs that are exactly representable in one limb (small integers) and power-of-two
+    friendly sums the split kernels reproduce the integer result exactly."""
+    F.set_conv_arith(mode)
     torch.manual_seed(3)
     x = torch.randint(-4, 5, (2, 64, 16, 16)).float()
     wt = torch.randint(-3, 4, (48, 64, 3, 3)).float()
@@ -243,6 +246,92 @@ def test_conv_split_bf16_exact_on_bf16_representable_inputs(restore_conv_arith):
     y = TF.conv2d(x, wt, None, padding=1)
     got = F.conv_forward(x.to(DEV), wt.to(DEV), None).cpu()
     assert torch.equal(got, y)
+
+
+def _amax_value(buf):
+    assert buf.numel() == F.AMAX_FLOATS
+    return float(buf.max())
+
+
+@pytest.mark.parametrize("numel", [1, 3, 4, 5, 1023, 4096, 100003, 3_000_001])
+def test_amax(numel):
+    """fsc_amax: the maximum over the slot buffer is exactly max |x| (any length, negative extremes)."""
+    torch.manual_seed(numel)
+    x = torch.randn(numel)
+    x[numel // 2] = -7.5 if numel % 2 else 6.25
+    assert _amax_value(F.amax(x.to(DEV))) == float(x.abs().max())
+    assert _amax_value(F.amax(torch.zeros(numel, device=DEV))) == 0.0
+
+
+@pytest.mark.parametrize("case", [(2, 100, 100, 16, 43, 3, 3), (3, 64, 48, 1, 256, 1, 3), (2, 100, 100, 16, 43, 1, 1)])
+def test_conv_split_fp16_power_of_two_scale_invariance(case, restore_conv_arith):
+    """The split-fp16 kernels scale each operand by a power of two taken from its largest magnitude, so multiplying
+    an operand by 2^k changes nothing but the exponent: results are BIT-IDENTICAL up to that factor, from gradients
+    of 1e-18 to activations of 1e12 -- far outside the fp16 range -- and an all-zero operand gives exact zeros."""
+    n, cin, cout, h, w, kh, kw = case
+    F.set_conv_arith(3)
+    torch.manual_seed(11)
+    x = torch.randn(n, cin, h, w, device=DEV)
+    wt = torch.randn(cout, cin, kh, kw, device=DEV) / (cin * kh * kw) ** 0.5
+    gy = torch.randn(n, cout, h, w, device=DEV)
+    d = F._desc(n, cin, cout, h, w, kh, kw)
+    assert F.plan_name(d, 0).startswith("conv_fwd_x3_kernel") and F.plan_name(d, 0).endswith(",3>")
+    y, dx, dw = F.conv_forward(x, wt, None), F.conv_dgrad(gy, wt, x.shape), F.conv_wgrad(x, gy, wt.shape)
+    for k in (-60, -17, 13, 40):
+        f = 2.0 ** k
+        assert torch.equal(F.conv_forward(x * f, wt, None), y * f), k
+        assert torch.equal(F.conv_forward(x, wt * f, None), y * f), k
+        assert torch.equal(F.conv_dgrad(gy * f, wt, x.shape), dx * f), k
+        assert torch.equal(F.conv_wgrad(x * f, gy, wt.shape), dw * f), k
+        assert torch.equal(F.conv_wgrad(x, gy * f, wt.shape), dw * f), k
+    # a declared maximum inside the same binade gives the same scale; a larger one costs low-order bits only
+    am = F.amax(x)
+    assert torch.equal(F.conv_forward(x, wt, None, x_amax=am), y)
+    loose = F.conv_forward(x, wt, None, x_amax=am * 64.0)
+    assert 0 < maxdiff(loose, y) < 1e-4 or torch.equal(loose, y)
+    b = torch.randn(cout, device=DEV)
+    z = F.conv_forward(torch.zeros_like(x), wt, b)
+    assert torch.equal(z, b.view(1, -1, 1, 1).expand_as(z))
+    assert float(F.conv_wgrad(x, torch.zeros_like(gy), wt.shape).abs().max()) == 0.0
+
+
+def test_conv_split_fp16_wide_dynamic_range(restore_conv_arith):
+    """Elements far below the tensor's maximum lose low-limb bits gradually (they fall under fp16's normal range
+    after the per-tensor scaling): with 2^-20 .. 1 magnitudes inside one tensor the result stays within a few
+    fp32 ulps of the LARGEST terms' contribution, i.e. the fp32 error bound of the same sum."""
+    F.set_conv_arith(3)
+    torch.manual_seed(5)
+    n, cin, cout, h, w = 2, 96, 64, 12, 40
+    mag = torch.exp2(-20.0 * torch.rand(n, cin, h, w))
+    x = torch.randn(n, cin, h, w) * mag
+    wt = torch.randn(cout, cin, 3, 3) / (cin * 9) ** 0.5
+    y64 = TF.conv2d(x.double(), wt.double(), None, padding=1)
+    y32 = TF.conv2d(x, wt, None, padding=1)
+    got = F.conv_forward(x.to(DEV), wt.to(DEV), None).cpu()
+    e32 = float((y32.double() - y64).abs().max())
+    assert float((got.double() - y64).abs().max()) < 4.0 * e32 + 1e-9
+
+
+@pytest.mark.parametrize("shape", [(4, 30, 24, 40), (3, 17, 9, 13), (8, 64, 1, 1)])
+def test_bn_kernels_report_amax(shape, restore_conv_arith):
+    """The BN forward / backward kernels report max |output| for the split-fp16 conv kernels that consume it."""
+    F.set_conv_arith(3)
+    n, c, h, w = shape
+    torch.manual_seed(n * c)
+    x = torch.randn(n, c, h, w, device=DEV) * 3.0 + 1.0
+    bn = torch.nn.BatchNorm2d(c).to(DEV)
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 2.0)
+        bn.bias.normal_()
+    alpha = torch.rand(c, device=DEV) * 0.5
+    st = F.bn_prepare(x, bn, True)
+    y, y_max = F.bn_act_forward(x, st, alpha, with_amax=True)
+    assert _amax_value(y_max) == float(y.abs().max())
+    gy = torch.randn_like(x) * 1e-6
+    dx, _, _, _, _, _, dx_max = F.bn_act_backward(gy, x, st, bn, alpha, with_amax=True)
+    assert _amax_value(dx_max) == float(dx.abs().max())
+    F.set_conv_arith(6)
+    assert F.bn_act_forward(x, st, alpha, with_amax=True)[1] is None
 
 
 @pytest.mark.parametrize("case", [(2, 2, 20, 13, 21), (3, 2, 100, 16, 43), (2, 1, 24, 9, 12), (1, 2, 7, 2, 9)])
@@ -504,7 +593,9 @@ def test_bn_act_bwd_fused_with_unpool(shape, ph):
     pd, pidx = F.maxpool_forward(cfull.detach().to(DEV), ph)
     st = F.bn_prepare(pd, dbn, True)
     alpha = prelu.weight.detach().to(DEV)
-    dc, dg, db, dal, csum, _ = F.bn_act_backward_unpool(gy.to(DEV), pd, st, dbn, alpha, pidx, shape, ph)
+    dc, dg, db, dal, csum, dc_max = F.bn_act_backward_unpool(gy.to(DEV), pd, st, dbn, alpha, pidx, shape, ph)
+    if dc_max is not None:          # split-fp16 arithmetic: the kernel reports max |dc|
+        assert float(dc_max.max()) == float(dc.abs().max())
     assert maxdiff(dc, cfull.grad) < 5e-5
     assert maxdiff(dg, bn.weight.grad) < 2e-4
     assert maxdiff(db, bn.bias.grad) < 2e-4

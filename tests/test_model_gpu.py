@@ -211,7 +211,7 @@ def test_against_oracle_odd_shapes():
         assert maxdiff(m(signal.to(DEV))["class_logits"], ref(signal)["class_logits"]) < TOL
 
 
-@pytest.mark.parametrize("arith", ["bf16x6", "bf16x9", "f32"])
+@pytest.mark.parametrize("arith", ["f16x3", "bf16x6", "bf16x9", "f32"])
 def test_against_oracle_wide_channels_split_bf16(arith):
     """Channel counts of the benchmark's order (64, 96, 144) so that the split-bf16 forward / dgrad / wgrad
     kernels, the 1x1 split kernels and the fused stem + max-pool run inside the full autograd chain;
