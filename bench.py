@@ -29,7 +29,7 @@ sys.path.insert(0, ROOT)
 
 # /opt/skills/guides/MI355X_MICROARCH.md, chip-level parameters
 PEAK_F32_MFMA_TFLOPS = 157.3      # v_mfma_f32_16x16x4_f32 (native fp32 kernels)
-PEAK_BF16_MFMA_TFLOPS = 2500.0    # dense bf16 MFMA (split-bf16 kernels execute 6 or 9 bf16 MFMA flops per fp32 flop)
+PEAK_BF16_MFMA_TFLOPS = 2500.0    # dense fp16 = bf16 MFMA (the split kernels execute 3 (fp16 limbs) or 6 / 9 (bf16 limbs) MFMA flops per fp32 flop)
 
 
 class NS(dict):
@@ -186,7 +186,7 @@ def main():
         elapsed = float(tmax.item())
     final_loss = float(loss.detach())
     # The same workload with the native fp32-MFMA conv kernels (FSC_CONV_ARITH=f32), for readers who want the
-    # number without the split-bf16 arithmetic; N = 1 only, outside the timed region of `value`.
+    # number without the split-limb arithmetic; N = 1 only, outside the timed region of `value`.
     alt = None
     if world == 1 and not args.no_alt and F.get_conv_arith() != 0:
         mode0 = F.get_conv_arith()
@@ -246,8 +246,8 @@ def main():
             if os.path.exists(tpath):
                 with open(tpath) as f:
                     traffic = json.load(f).get(dom_name)
-            # split-bf16 kernels (name ..._x3_kernel<..., NPROD>): every algorithmic fp32 flop costs NPROD bf16
-            # MFMA flops, so `achieved` counts EXECUTED bf16 flops and is priced against the dense bf16 peak
+            # split kernels (name ..._x3_kernel<..., NPROD>): every algorithmic fp32 flop costs NPROD 16-bit
+            # MFMA flops, so `achieved` counts EXECUTED 16-bit flops and is priced against the dense fp16 / bf16 peak
             peak, executed_per_flop, arith = PEAK_F32_MFMA_TFLOPS, 1, "native fp32 MFMA"
             if "_x3_kernel" in dom_name:
                 executed_per_flop = int(dom_name.rstrip(">").split(",")[-1])

@@ -2069,6 +2069,11 @@ bool plan_fwd_x3(const fsc_conv_desc& d, int dgrad, int nprod, FwdPlan* out) {
     // once (+5 ... +18 % measured; 16-tile blocks for the 506 / 759-channel layers gained nothing)
     {
         const int tiles = fsc::ceil_div(dgrad ? d.c_in : d.c_out, 16);
+        // (two fp16 limbs leave registers for 10 tiles x 2 pixel tiles: half the weight-fragment reads per MFMA,
+        //  +13 % measured; 15 x 2 spills and runs at half speed)
+        if (d.kh * d.kw > 1 && tiles == 10 && nprod == 3 &&
+            plan_fwd_x3_pt(d, dgrad, nprod, 2, tiles, out) && out->cot == tiles)
+            return true;
         if (d.kh * d.kw > 1 && (tiles == 10 || tiles == 15) && plan_fwd_x3_pt(d, dgrad, nprod, 1, tiles, out) && out->cot == tiles)
             return true;
 
@@ -2235,6 +2240,13 @@ int launch_fwd_wide(const FwdPlan& p, const float* in, const float* packed, cons
             const size_t bytes = sizeof(float) * (size_t)p.g.n * p.g.cout * p.g.hw;
             hipError_t e = hipMemsetAsync(out, 0, bytes, st);
             FSC_CHECK_ARG(e == hipSuccess, "fsc_conv_fwd: memset failed: %s", hipGetErrorString(e));
+        }
+        if constexpr (COT == 10) {
+            if (p.pt == 2) {
+                launch_x3_pt<KH, KW, COT, 2, 3>(p, grid, in, packed, bias, out, accumulate, in_amax, st);
+                FSC_LAUNCH_CHECK("fsc_conv_fwd(x3)");
+                return 0;
+            }
         }
         launch_x3_arith<KH, KW, COT, 1>(p, grid, in, packed, bias, out, accumulate, in_amax, st);
         FSC_LAUNCH_CHECK("fsc_conv_fwd(x3)");

@@ -62,7 +62,8 @@ int fsc_frontend_stft_fwd(const float* wave, int n, int t, long wave_stride,
 /* ------------------------------------------------------------------ convolution (K7, K10)
  * nn.Conv2d 3x3 pad 1 / 1x1 (classifiers.py:526-531, 77-81) and nn.Conv1d k3 / k1
  * (classifiers.py:149-154, 42-46; H == 1, kh == 1).  fp32 in, fp32 out, fp32 accumulation; the products run on
- * v_mfma_f32_16x16x32_bf16 through an exact three-limb bf16 split (default) or on v_mfma_f32_16x16x4_f32
+ * v_mfma_f32_16x16x32_f16 through a two-limb fp16 split with exact power-of-two operand scaling (default), on
+ * v_mfma_f32_16x16x32_bf16 through an exact three-limb bf16 split, or on v_mfma_f32_16x16x4_f32
  * (fsc_conv_set_arith), stem layers (c_in <= 4) on the vector ALUs.  Weights are re-packed per use by
  * fsc_conv_pack_weights; the packed format is private to the library and depends on shape and arithmetic mode. */
 
@@ -100,11 +101,14 @@ int fsc_conv_pool_fwd(const fsc_conv_desc* d, const float* in, const float* pack
 /* human-readable tiling chosen for this shape (mode 0 fwd, 1 dgrad, 2 wgrad): kernel
  * instantiation, pixel box, grid, LDS bytes.  For logs, DESIGN.md tables and profiles. */
 int fsc_conv_plan_describe(const fsc_conv_desc* d, int mode, char* buf, size_t buf_len);
-/* Arithmetic of the 3x3 / k3 forward and dgrad kernels.  0: native fp32 MFMA (v_mfma_f32_16x16x4_f32).
+/* Arithmetic of the convolution kernels.  0: native fp32 MFMA (v_mfma_f32_16x16x4_f32).
+ * 3: every fp32 operand x is scaled by a power of two s (from the tensor's largest magnitude, see fsc_amax) and
+ * split into two fp16 limbs h = rne(x*s), l = rne(x*s - h) (|x*s - h - l| <= 2^-24 |x*s|); the product is formed
+ * from the 3 limb products hh + hl + lh on v_mfma_f32_16x16x32_f16 with fp32 accumulation and unscaled exactly.
  * 6 / 9: every fp32 operand is split exactly into three bf16 limbs and the product is formed from 6 / 9
  * limb products on v_mfma_f32_16x16x32_bf16 with fp32 accumulation (9 = all terms: the product is exact
  * before accumulation; 6 drops terms below 2^-23 |a*b|).  Inputs, outputs and accumulators are fp32
- * in every mode.  Default 6, or the environment variable FSC_CONV_ARITH = f32 | bf16x6 | bf16x9.
+ * in every mode.  Default 3, or the environment variable FSC_CONV_ARITH = f32 | f16x3 | bf16x6 | bf16x9.
  * The packed-weight format depends on the mode: re-pack after changing it. */
 int fsc_conv_set_arith(int mode);
 int fsc_conv_get_arith(void);
