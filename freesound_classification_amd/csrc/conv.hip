@@ -825,8 +825,13 @@ __global__ __launch_bounds__(kXWaves * 64) void conv_fwd_x3_kernel(Geom g, const
     auto step_fast = [&](const Limbs& cur, Limbs& nxt) {
         wait_weights(true, input_age <= AHEAD - 1);      // (the previous step had S + AHEAD < s_hi as well)
         raw_barrier();
-        const int ty = (sc + 1) / KW, tx = (sc + 1) - ty * KW;
-        const float* il = ibase + stg * istage + kq * 8 * g.plane + ty * g.cols + tx;
+        // the next step: the next tap of this chunk, or tap 0 of the next (full) chunk in the next stage -- its box
+        // was issued at this chunk's first step, SPC - 1 >= AHEAD steps ago, so the wait above covered it
+        const bool wrap = sc + 1 == SPC;
+        const int scn = wrap ? 0 : sc + 1;
+        const int stgn = wrap ? (stg == NSTG - 1 ? 0 : stg + 1) : stg;
+        const int ty = scn / KW, tx = scn - ty * KW;
+        const float* il = ibase + stgn * istage + kq * 8 * g.plane + ty * g.cols + tx;
         const u32x4* wl = reinterpret_cast<const u32x4*>(wring + slot * WSLOT_F) + lane;
         phases(il, wl, cur, nxt, [&] {
             issue_w(wsrc + AHEAD * WSLOT_F, slot == 0 ? RING - 1 : slot - 1);
@@ -835,7 +840,9 @@ __global__ __launch_bounds__(kXWaves * 64) void conv_fwd_x3_kernel(Geom g, const
         });
         wsrc += WSLOT_F;
         slot = slot == RING - 1 ? 0 : slot + 1;
-        ++sc;
+        sc = scn;
+        stg = stgn;
+        c += wrap ? 1 : 0;
     };
     auto step_slow = [&](int S, const Limbs& cur, Limbs& nxt) {
         const bool tile_end = S + 1 >= s_hi;
@@ -888,8 +895,9 @@ __global__ __launch_bounds__(kXWaves * 64) void conv_fwd_x3_kernel(Geom g, const
             const bool opens_full_chunk = sc == 0 && c < g.x_nfull;
             step_slow(S, cur, nxt);
             if (opens_full_chunk) {
-                // steps S+1 .. of this chunk with sc >= 1, sc + 1 < SPC and S' + AHEAD < s_hi
-                int nf = SPC - 2;
+                // steps S+1 .. of this chunk with sc >= 1 and S' + AHEAD < s_hi: the interior ones (sc + 1 < SPC) and,
+                // when another full chunk of this K slice follows, the last one
+                int nf = SPC - 2 + ((SPC > 1 && c + 1 < g.x_nfull && c + 1 < c_hi) ? 1 : 0);
                 const int cap = s_hi - AHEAD - (S + 1);
                 if (nf > cap) nf = cap;
                 fast_left = nf > 0 ? nf : 0;
