@@ -823,11 +823,11 @@ __global__ __launch_bounds__(kXWaves * 64) void conv_fwd_x3_kernel(Geom g, const
     // ring wrap, so the scalar bookkeeping shrinks to a few instructions (every instruction beside the MFMAs
     // costs: about two per MFMA are free, measured).
     auto step_fast = [&](const Limbs& cur, Limbs& nxt) {
-        wait_weights(true, input_age <= AHEAD - 1);      // (the previous step had S + AHEAD < s_hi as well)
-        raw_barrier();
-        // the next step: the next tap of this chunk, or tap 0 of the next (full) chunk in the next stage -- its box
-        // was issued at this chunk's first step, SPC - 1 >= AHEAD steps ago, so the wait above covered it
+        // the next step: the next tap of this chunk, or tap 0 of the next (full) chunk in the next stage -- then its
+        // box (issued at this chunk's first step, possibly only AHEAD steps ago: k3 kernels) must have landed too
         const bool wrap = sc + 1 == SPC;
+        wait_weights(true, input_age <= AHEAD - 1 && !wrap);      // (the previous step had S + AHEAD < s_hi as well)
+        raw_barrier();
         const int scn = wrap ? 0 : sc + 1;
         const int stgn = wrap ? (stg == NSTG - 1 ? 0 : stg + 1) : stg;
         const int ty = scn / KW, tx = scn - ty * KW;
@@ -2043,6 +2043,10 @@ bool plan_fwd_x3_pt(const fsc_conv_desc& d_in, int dgrad, int nprod, int pt, int
             long ks = (384 + wgs - 1) / wgs;
             if (ks > 8) ks = 8;
             if (ks > nchunks / 2) ks = nchunks / 2;
+            // a K slice pays a scalar-atomic epilogue (and the output is cleared first): worth it only with enough
+            // MFMA steps behind every output element -- the short-K layers of the 1-d model ran 2-4x slower split
+            // (cfg 3: 6746 -> 7654 clips/s; thresholds of 16 - 64 steps per slice measure the same)
+            if (ks > g.x_steps / 16) ks = g.x_steps / 16;
             if (ks > 1) g.ksplit = (int)ks;
         }
     }
