@@ -235,6 +235,28 @@ def test_conv_split_bf16_random_shapes_against_native(restore_conv_arith):
     assert {"conv_fwd_x3_kernel", "conv_wgrad_x3_kernel", "conv_fwd_kernel", "conv_wgrad_kernel"} <= seen, seen
 
 
+@pytest.mark.parametrize("case", [(6, 793, 412, 1, 525, 1, 3), (8, 593, 795, 1, 509, 1, 3), (5, 379, 738, 1, 536, 1, 3),
+                                  (8, 774, 684, 1, 345, 1, 3)])
+def test_conv_split_k3_long_reduction_against_native(case, restore_conv_arith):
+    """1-d k3 layers with many channels: K slices of several 3-step chunks, where a chunk's last step prefetches
+    its operand from the NEXT chunk's input box only two steps after that box was issued (a missing wait there
+    produced O(1) errors on exactly these shapes; found by tools/conv_sweep.py)."""
+    n, cin, cout, h, w, kh, kw = case
+    torch.manual_seed(sum(case))
+    x = torch.randn(n, cin, h, w, device=DEV)
+    wt = torch.randn(cout, cin, kh, kw, device=DEV) / (cin * kh * kw) ** 0.5
+    b = torch.randn(cout, device=DEV)
+    gy = torch.randn(n, cout, h, w, device=DEV)
+    res = {}
+    for mode in (0, 3, 6):
+        F.set_conv_arith(mode)
+        res[mode] = [(F.conv_forward(x, wt, b), F.conv_dgrad(gy, wt, x.shape)) for _ in range(3)]
+    for mode in (3, 6):
+        for rep in range(3):
+            assert maxdiff(res[mode][rep][0], res[0][0][0]) < 4e-6 * (cin * 3) ** 0.5 + 1e-5, (mode, rep, "fwd")
+            assert maxdiff(res[mode][rep][1], res[0][0][1]) < 4e-6 * (cout * 3) ** 0.5 + 1e-5, (mode, rep, "dgrad")
+
+
 @pytest.mark.parametrize("mode", [3, 6])
 def test_conv_split_bf16_exact_on_bf16_representable_inputs(mode, restore_conv_arith):
     """With inputs that are exactly representable in one limb (small integers) and power-of-two
