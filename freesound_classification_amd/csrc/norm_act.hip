@@ -46,12 +46,42 @@ __global__ __launch_bounds__(kThreads) void stats_partial_kernel(
         if (vec) {
             const float4* p4 = reinterpret_cast<const float4*>(p);
             const long n4 = hw >> 2;
-            for (long i = ti; i < n4; i += kThreads) {
+            long i = ti;
+            // four 16-byte loads in flight per thread (one reached 4.1 TB/s on the 704 MB tensors, short of the
+            // ~5.5 TB/s of the apply passes)
+            float t1[3] = {0.f, 0.f, 0.f}, t2[3] = {0.f, 0.f, 0.f};
+            for (; i + 3 * kThreads < n4; i += 4 * kThreads) {
+                const float4 v = p4[i];
+                float4 u[3];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) u[k] = p4[i + (k + 1) * kThreads];
+                const float a0 = v.x - pivot, a1 = v.y - pivot, a2 = v.z - pivot, a3 = v.w - pivot;
+                s1 += (a0 + a1) + (a2 + a3);
+                s2 += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const float b0 = u[k].x - pivot, b1 = u[k].y - pivot, b2 = u[k].z - pivot, b3 = u[k].w - pivot;
+                    t1[k] += (b0 + b1) + (b2 + b3);
+                    t2[k] += (b0 * b0 + b1 * b1) + (b2 * b2 + b3 * b3);
+                }
+            }
+            for (; i + kThreads < n4; i += 2 * kThreads) {
+                const float4 v = p4[i], u0 = p4[i + kThreads];
+                const float a0 = v.x - pivot, a1 = v.y - pivot, a2 = v.z - pivot, a3 = v.w - pivot;
+                const float b0 = u0.x - pivot, b1 = u0.y - pivot, b2 = u0.z - pivot, b3 = u0.w - pivot;
+                s1 += (a0 + a1) + (a2 + a3);
+                s2 += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
+                t1[0] += (b0 + b1) + (b2 + b3);
+                t2[0] += (b0 * b0 + b1 * b1) + (b2 * b2 + b3 * b3);
+            }
+            for (; i < n4; i += kThreads) {
                 const float4 v = p4[i];
                 const float a0 = v.x - pivot, a1 = v.y - pivot, a2 = v.z - pivot, a3 = v.w - pivot;
                 s1 += (a0 + a1) + (a2 + a3);
                 s2 += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
             }
+            s1 += (t1[0] + t1[1]) + t1[2];
+            s2 += (t2[0] + t2[1]) + t2[2];
         } else {
             for (long i = ti; i < hw; i += hwp) {
                 const float a0 = p[i] - pivot;
