@@ -483,6 +483,16 @@ __global__ __launch_bounds__(kXWaves * 64) void conv_fwd_x3_kernel(Geom g, const
     const int ntiles = g.tiles_n * g.tiles_h * g.tiles_w;
     // per tile: input offsets of the staged positions (relative to channel 0; -1 = zero fill) ...
     int pos_off[kXNptMax];
+    // ... 1x1 kernels (every step opens a chunk, so the copy issue is on the critical path of every step) keep running
+    // source pointers instead: this lane's pointer for each staged position at the NEXT channel this wave copies
+    // (channels wid, wid + 8, ... of chunk after chunk), advanced by `istep` after every copy; positions outside the
+    // image point at a zero word with step 0, so a copy costs one 64-bit increment and no selects (+8 % on the
+    // 100-channel layer; on the 3x3 kernels the extra registers cost more than the instructions saved)
+    constexpr bool RUNPTR = TAPS == 1;
+    const char* iptr[RUNPTR ? kXNptMax : 1];
+    int istep[RUNPTR ? kXNptMax : 1];
+    const int c_lo_first = (int)((long)(g.x_nfull + (g.x_tail_oct ? 1 : 0)) * blockIdx.z / g.ksplit) * KCH + wid;
+    const int chan_step = (int)(8 * g.hw * (long)sizeof(float));          // (host: hw < 2^26)
     auto plan_input = [&](int tile) {
         int t = tile;
         const int twi = t % g.tiles_w; t /= g.tiles_w;
@@ -496,6 +506,11 @@ __global__ __launch_bounds__(kXWaves * 64) void conv_fwd_x3_kernel(Geom g, const
                 const int gh = h0 + rr - PADH, gw = w0 + cc - PADW;
                 if (n0 + b < g.n && gh >= 0 && gh < g.h && gw >= 0 && gw < g.w)
                     pos_off[q] = (int)(((long)(n0 + b) * g.cin) * g.hw + (long)gh * g.w + gw);
+            }
+            if constexpr (RUNPTR) {
+                iptr[q] = pos_off[q] >= 0 ? reinterpret_cast<const char*>(in + pos_off[q] + (long)c_lo_first * g.hw)
+                                          : reinterpret_cast<const char*>(g_zero16);
+                istep[q] = pos_off[q] >= 0 ? chan_step : 0;
             }
         }
     };
@@ -592,6 +607,26 @@ __global__ __launch_bounds__(kXWaves * 64) void conv_fwd_x3_kernel(Geom g, const
         const int ci0 = c * KCH;
         const int nch = c < g.x_nfull ? KCH : g.x_tail_oct * 8;         // staged channels of this chunk
         float* dst = ibase + stage * istage;
+        if constexpr (RUNPTR) {
+            float* dw = dst + wid * g.plane;
+#pragma unroll 1
+            for (int kk = wid; kk < nch; kk += kXWaves) {
+                if (ci0 + kk < g.cin) {                                 // (wave-uniform)
+#pragma unroll
+                    for (int q = 0; q < kXNptMax; ++q)
+                        if (q < g.x_npt && q * 64 + lane < g.plane) {
+                            glds4(reinterpret_cast<const float*>(iptr[q]), dw + q * 64);
+                            iptr[q] += istep[q];
+                        }
+                } else {                                                // channels beyond c_in (last chunk only): zeros
+#pragma unroll
+                    for (int q = 0; q < kXNptMax; ++q)
+                        if (q < g.x_npt && q * 64 + lane < g.plane) glds4(zero, dw + q * 64);
+                }
+                dw += kXWaves * g.plane;
+            }
+            return;
+        }
         for (int kk = wid; kk < nch; kk += kXWaves) {
             const float* src = in + (long)(ci0 + kk) * g.hw;
             const bool ch_live = ci0 + kk < g.cin;
@@ -1970,6 +2005,7 @@ bool plan_fwd_x3_pt(const fsc_conv_desc& d_in, int dgrad, int nprod, int pt, int
     g.cin = dgrad ? d.c_out : d.c_in;
     g.cout = dgrad ? d.c_in : d.c_out;
     if (g.cin < 32 || g.cout < 48) return false;         // stem layers: HBM-bound, K or M too small for 16x16x32 tiles
+    if (g.hw >= (1L << 26)) return false;                // the 1x1 input copies step their pointers by 8 planes in 32 bits
     // channel tiles per workgroup: a step costs its MFMAs (proportional to the tiles) plus the side work of
     // splitting the activations, about 3.5 tiles' worth (measured); more than 8 tiles use a two-slot weight ring
     const int tiles = fsc::ceil_div(g.cout, 16);
