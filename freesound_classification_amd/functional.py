@@ -152,8 +152,9 @@ class _timed:
 
 
 def set_conv_arith(mode):
-    """0 / "f32": native fp32 MFMA; 6, 9 / "bf16x6", "bf16x9": fp32 via exact three-limb bf16 split
-    with that many limb products (include/fsc_hip.h, fsc_conv_set_arith)."""
+    """0 / "f32": native fp32 MFMA; 3 / "f16x3" (the default): fp32 via two fp16 limbs with exact power-of-two
+    operand scaling, three limb products; 6, 9 / "bf16x6", "bf16x9": fp32 via exact three-limb bf16 split with
+    that many limb products (include/fsc_hip.h, fsc_conv_set_arith)."""
     mode = {"f32": 0, "f16x3": 3, "bf16x6": 6, "bf16x9": 9}.get(mode, mode)
     call("fsc_conv_set_arith", int(mode))
 
