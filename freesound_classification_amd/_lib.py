@@ -21,7 +21,10 @@ class FscError(RuntimeError):
 
 class ConvDesc(C.Structure):
     _fields_ = [("n", C.c_int), ("c_in", C.c_int), ("c_out", C.c_int), ("h", C.c_int),
-                ("w", C.c_int), ("kh", C.c_int), ("kw", C.c_int)]
+                ("w", C.c_int), ("kh", C.c_int), ("kw", C.c_int), ("arith", C.c_int)]
+
+    def __init__(self, n, c_in, c_out, h, w, kh, kw, arith=-1):      # -1 = FSC_ARITH_DEFAULT
+        super().__init__(n, c_in, c_out, h, w, kh, kw, arith)
 
 
 class OptTensor(C.Structure):
@@ -48,8 +51,7 @@ SIGNATURES = {
     "fsc_conv_pool_supported": (_I, [_D]),
     "fsc_conv_pool_fwd": (_I, [_D, _P, _P, _P, _P, _P, _P]),
     "fsc_conv_plan_describe": (_I, [_D, _I, C.c_char_p, _SZ]),
-    "fsc_conv_set_arith": (_I, [_I]),
-    "fsc_conv_get_arith": (_I, []),
+    "fsc_conv_default_arith": (_I, []),
     "fsc_conv_wgrad_workspace_bytes": (_SZ, [_D]),
     "fsc_conv_wgrad": (_I, [_D, _P, _P, _P, _P, _P, _P, _P]),
     "fsc_bn_workspace_bytes": (_SZ, [_I]),

@@ -402,6 +402,12 @@ __device__ __forceinline__ int scale_field(float amax) {
     return f;
 }
 __device__ __forceinline__ float field_to_float(int f) { return __uint_as_float((unsigned)f << 23); }
+// Inverse of the scale for the epilogue.  A declared maximum of +Inf (an operand holding an infinity; NaNs never
+// enter the maximum, they travel through the limbs on their own) leaves no usable scale for the finite elements:
+// the inverse is NaN then, so EVERY output of the launch is non-finite instead of silently losing the finite part.
+__device__ __forceinline__ float inv_scale(int f, float amax) {
+    return ((__float_as_uint(amax) >> 23) & 0xffu) == 0xffu ? __uint_as_float(0x7fc00000u) : field_to_float(254 - f);
+}
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 template <bool F16>
@@ -576,10 +582,11 @@ __global__ __launch_bounds__(kXWaves * 64) void conv_fwd_x3_kernel(Geom g, const
         for (int i = 1; i < kXWaves; ++i) ax = fmaxf(ax, red[i]);
         ax = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, ax)));
         __syncthreads();
-        const int fx = scale_field(ax), fw = scale_field(*w_amax);
+        const float aw = *w_amax;
+        const int fx = scale_field(ax), fw = scale_field(aw);
         sx = field_to_float(fx);
-        inv_x = field_to_float(254 - fx);
-        inv_w = field_to_float(254 - fw);
+        inv_x = inv_scale(fx, ax);
+        inv_w = inv_scale(fw, aw);
     }
 
     // ---- K range of this workgroup (split-K over chunks through blockIdx.z)
@@ -1682,8 +1689,8 @@ __global__ __launch_bounds__(kWgxWaves * 64) void conv_wgrad_x3_kernel(WgxGeom g
         xb = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, xb)));
         __syncthreads();
         const int fa = scale_field(xa), fb = scale_field(xb);
-        sa = field_to_float(fa); inv_a = field_to_float(254 - fa);
-        sb = field_to_float(fb); inv_b = field_to_float(254 - fb);
+        sa = field_to_float(fa); inv_a = inv_scale(fa, xa);
+        sb = field_to_float(fb); inv_b = inv_scale(fb, xb);
     }
 
     // Rows beyond c_out / c_in are never copied: zero them once in both stages.  The copy loops then walk the
@@ -1945,19 +1952,19 @@ size_t x3_limb_floats(const FwdPlan& p) {
 
 // Arithmetic of the conv kernels: 0 = native fp32 MFMA everywhere; 3 = scaled split-fp16 (two limbs, three
 // products; the default), 6 / 9 = split-bf16 (three limbs, that many products) wherever the x3 tilings fit.
-// FSC_CONV_ARITH=f32|f16x3|bf16x6|bf16x9 or fsc_conv_set_arith.
-int g_conv_arith = -1;
-int conv_arith() {
-    if (g_conv_arith < 0) {
+// A PER-CALL property: fsc_conv_desc.arith; FSC_ARITH_DEFAULT (-1) there means the process default, which is
+// read once from the environment (FSC_CONV_ARITH=f32|f16x3|bf16x6|bf16x9, else 3) and never changes afterwards.
+int default_arith() {
+    static const int mode = [] {
         const char* e = getenv("FSC_CONV_ARITH");
-        g_conv_arith = 3;
-        if (e && !strcmp(e, "f32")) g_conv_arith = 0;
-        else if (e && !strcmp(e, "f16x3")) g_conv_arith = 3;
-        else if (e && !strcmp(e, "bf16x6")) g_conv_arith = 6;
-        else if (e && !strcmp(e, "bf16x9")) g_conv_arith = 9;
-    }
-    return g_conv_arith;
+        if (e && !strcmp(e, "f32")) return 0;
+        if (e && !strcmp(e, "bf16x6")) return 6;
+        if (e && !strcmp(e, "bf16x9")) return 9;
+        return 3;
+    }();
+    return mode;
 }
+int arith_of(const fsc_conv_desc& d) { return d.arith < 0 ? default_arith() : d.arith; }
 
 int pad_plane(int floats, int want) {   // smallest p >= floats with p % 32 == want
     int p = floats;
@@ -2136,7 +2143,7 @@ bool plan_fwd_x3(const fsc_conv_desc& d, int dgrad, int nprod, FwdPlan* out) {
 bool plan_fwd_f32(const fsc_conv_desc& d, int dgrad, FwdPlan* out);
 
 bool plan_fwd(const fsc_conv_desc& d, int dgrad, FwdPlan* out) {
-    const int arith = conv_arith();
+    const int arith = arith_of(d);
     if (arith && plan_fwd_x3(d, dgrad, arith, out)) return true;
     return plan_fwd_f32(d, dgrad, out);
 }
@@ -2338,7 +2345,6 @@ int launch_amax(const float* x, long n, float* out, hipStream_t st, int slots) {
     return 0;
 }
 
-int wgrad_arith() { return conv_arith(); }
 
 // stem layers take the direct kernels: 3x3, at most 4 input channels, weights fit the LDS table
 bool stem_shape(const fsc_conv_desc& d) {
@@ -2347,6 +2353,7 @@ bool stem_shape(const fsc_conv_desc& d) {
 
 bool valid_desc(const fsc_conv_desc* d) {
     if (!d || d->n <= 0 || d->c_in <= 0 || d->c_out <= 0 || d->h <= 0 || d->w <= 0) return false;
+    if (!(d->arith == FSC_ARITH_DEFAULT || d->arith == 0 || d->arith == 3 || d->arith == 6 || d->arith == 9)) return false;
     const bool k33 = d->kh == 3 && d->kw == 3, k11 = d->kh == 1 && d->kw == 1, k13 = d->kh == 1 && d->kw == 3;
     if (!(k33 || k11 || k13)) return false;
     const long big = 1L << 31;
@@ -2623,14 +2630,7 @@ size_t fsc_conv_packed_floats(const fsc_conv_desc* d, int dgrad) {
     return (size_t)d->kh * d->kw * p.g.k_pad * p.g.m_pad;
 }
 
-int fsc_conv_set_arith(int mode) {
-    FSC_CHECK_ARG(mode == 0 || mode == 3 || mode == 6 || mode == 9,
-                  "fsc_conv_set_arith: mode must be 0 (fp32 MFMA), 3 (scaled split-fp16), 6 or 9 (split-bf16 products)");
-    g_conv_arith = mode;
-    return 0;
-}
-
-int fsc_conv_get_arith(void) { return conv_arith(); }
+int fsc_conv_default_arith(void) { return default_arith(); }
 
 
 int fsc_conv_pack_weights(const fsc_conv_desc* d, const float* weight, int dgrad, float* packed, fsc_stream_t stream) {
@@ -2730,7 +2730,7 @@ int fsc_conv_plan_describe(const fsc_conv_desc* d, int mode, char* buf, size_t b
     FSC_CHECK_ARG(valid_desc(d) && buf && buf_len > 0, "fsc_conv_plan_describe: bad arguments");
     if (mode == 2) {
         WgxPlan px;
-        if (wgrad_arith() && plan_wgrad_x3(*d, wgrad_arith(), &px)) {
+        if (arith_of(*d) && plan_wgrad_x3(*d, arith_of(*d), &px)) {
             snprintf(buf, buf_len, "conv_wgrad_x3_kernel<%d,%d,%d,%d> box=%dx%d groups=%dx%d tiles/block=%d units=%d split=%d grid=%dx%d lds=%zu",
                      d->kh, d->kw, px.mt, px.nprod, px.g.th, px.g.tw, px.g.ng, px.g.nt, px.g.tpb, px.g.units, px.g.nsplit,
                      px.g.co_blocks * px.g.ci_blocks, px.g.nsplit, px.lds_bytes);
@@ -2762,7 +2762,7 @@ int fsc_conv_plan_describe(const fsc_conv_desc* d, int mode, char* buf, size_t b
 size_t fsc_conv_wgrad_workspace_bytes(const fsc_conv_desc* d) {
     if (!valid_desc(d)) return 0;
     WgxPlan px;
-    if (wgrad_arith() && plan_wgrad_x3(*d, wgrad_arith(), &px))
+    if (arith_of(*d) && plan_wgrad_x3(*d, arith_of(*d), &px))
         return (size_t)px.g.nsplit * d->kh * d->kw * px.g.ci_pad * px.g.co_pad * sizeof(float);
     WgPlan p;
     if (!plan_wgrad(*d, &p)) return 0;
@@ -2776,7 +2776,7 @@ int fsc_conv_wgrad(const fsc_conv_desc* d, const float* in, const float* dout, f
     float* part = reinterpret_cast<float*>(workspace);
     int rc;
     WgxPlan px;
-    if (wgrad_arith() && plan_wgrad_x3(*d, wgrad_arith(), &px)) {
+    if (arith_of(*d) && plan_wgrad_x3(*d, arith_of(*d), &px)) {
         FSC_CHECK_ARG(px.nprod != 3 || (in_amax && dout_amax),
                       "fsc_conv_wgrad: the split-fp16 kernels need in_amax and dout_amax (fsc_amax of the operands)");
         if (d->kh == 3) rc = launch_wgrad_x3<3, 3>(px, in, dout, part, in_amax, dout_amax, st);

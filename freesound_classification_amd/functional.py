@@ -101,8 +101,12 @@ def frontend_stft(wave, n_fft, hop, apply_log, freq_channel=False):
 
 
 # ------------------------------------------------------------------------------ convolution
-def _desc(n, c_in, c_out, h, w, kh, kw):
-    return ConvDesc(n, c_in, c_out, h, w, kh, kw)
+_ARITH = None        # host-side default for the descriptors built here (None: the library's FSC_CONV_ARITH default)
+
+
+def _desc(n, c_in, c_out, h, w, kh, kw, arith=None):
+    """fsc_conv_desc; the arithmetic mode is a per-call field of the descriptor (no library state)."""
+    return ConvDesc(n, c_in, c_out, h, w, kh, kw, get_conv_arith() if arith is None else arith)
 
 
 class KernelTimer:
@@ -152,15 +156,20 @@ class _timed:
 
 
 def set_conv_arith(mode):
-    """0 / "f32": native fp32 MFMA; 3 / "f16x3" (the default): fp32 via two fp16 limbs with exact power-of-two
+    """Arithmetic the descriptors built by this module ask for (fsc_conv_desc.arith, include/fsc_hip.h).
+    0 / "f32": native fp32 MFMA; 3 / "f16x3" (the default): fp32 via two fp16 limbs with exact power-of-two
     operand scaling, three limb products; 6, 9 / "bf16x6", "bf16x9": fp32 via exact three-limb bf16 split with
-    that many limb products (include/fsc_hip.h, fsc_conv_set_arith)."""
+    that many limb products; None: back to the library default (FSC_CONV_ARITH or 3).  Host-side convenience only:
+    the C ABI takes the mode per call."""
+    global _ARITH
     mode = {"f32": 0, "f16x3": 3, "bf16x6": 6, "bf16x9": 9}.get(mode, mode)
-    call("fsc_conv_set_arith", int(mode))
+    if mode is not None and int(mode) not in (0, 3, 6, 9):
+        raise _lib.FscError("conv arithmetic must be 0 (f32), 3 (f16x3), 6 (bf16x6) or 9 (bf16x9); got %r" % (mode,))
+    _ARITH = None if mode is None else int(mode)
 
 
 def get_conv_arith():
-    return _lib.load().fsc_conv_get_arith()
+    return _lib.load().fsc_conv_default_arith() if _ARITH is None else _ARITH
 
 
 AMAX_FLOATS = 512          # include/fsc_hip.h FSC_AMAX_FLOATS
@@ -483,6 +492,9 @@ class ConvBlockFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, mods, training, want_head, ph, *params):
         keep = any(ctx.needs_input_grad)
+        if keep and not training:
+            raise _lib.FscError("conv_block: gradients in eval mode (BatchNorm on running statistics) are not on the "
+                                "accelerated path; call model.train() or wrap the forward in torch.no_grad()")
         out, feat, k = _block_forward(x, mods, training, want_head, ph, keep)
         ctx.k = k
         ctx.mods = mods
@@ -499,6 +511,9 @@ class ConvBlockFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, d_out, d_feat):
         k, mods, ph = ctx.k, ctx.mods, ctx.ph
+        if k is None:
+            raise RuntimeError("ConvBlockFn: backward through the block a second time -- its saved activations are "
+                               "freed after the first backward (retain_graph is not supported on this path)")
         bn_a, conv_a, _pool, bn_b, prelu_b, res = mods[0], mods[1], mods[2], mods[3], mods[4], mods[5]
         gmax = None
         if ctx.want_head and d_feat is not None:
@@ -624,17 +639,12 @@ def linear(x, weight, bias):
     return LinearFn.apply(x, weight, bias)
 
 
-_DROPOUT_OFFSET = [0]
-
-
 class DropoutFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, p, seed):
+    def forward(ctx, x, p, seed, offset):
         x = x.contiguous()
         y = torch.empty_like(x)
         mask = torch.empty(x.shape, device=x.device, dtype=torch.uint8)
-        offset = _DROPOUT_OFFSET[0]
-        _DROPOUT_OFFSET[0] += x.numel()
         call("fsc_dropout_fwd", ptr(x), ptr(y), ptr(mask), x.numel(), p, seed, offset, stream_ptr())
         ctx.save_for_backward(mask)
         ctx.p = p
@@ -646,13 +656,27 @@ class DropoutFn(torch.autograd.Function):
         dy = dy.contiguous()
         dx = torch.empty_like(dy)
         call("fsc_dropout_bwd", ptr(dy), ptr(mask), ptr(dx), dy.numel(), ctx.p, stream_ptr())
-        return dx, None, None
+        return dx, None, None, None
 
 
-def dropout(x, p, training):
+class DropoutState:
+    """Position in the counter-based random stream of one dropout site (owned by the caller, e.g. the model:
+    neither the library nor this module keeps it)."""
+
+    def __init__(self):
+        self.offset = 0
+
+
+def dropout(x, p, training, state=None):
+    """nn.Dropout semantics (classifiers.py:547).  `state` advances by x.numel() per call; without one every call
+    draws from the start of the stream of torch.initial_seed()."""
     if not training or p <= 0.0:
         return x
-    return DropoutFn.apply(x, float(p), int(torch.initial_seed()) & 0xFFFFFFFFFFFFFFFF)
+    offset = 0
+    if state is not None:
+        offset = state.offset
+        state.offset += x.numel()
+    return DropoutFn.apply(x, float(p), int(torch.initial_seed()) & 0xFFFFFFFFFFFFFFFF, offset)
 
 
 # ------------------------------------------------------------------------------ losses

@@ -115,6 +115,7 @@ class _TaggingModel(nn.Module):
             nn.Dropout(p=net.output_dropout), nn.Linear(total_depth, data._n_classes))
         self.to(self.device)
         self._reducer = None
+        self._dropout_state = F.DropoutState()
 
     # ------------------------------------------------------------------ forward
     def _front_end(self, signal):
@@ -132,8 +133,27 @@ class _TaggingModel(nn.Module):
             return F.frontend_stft(wave, n_fft, hop, apply_log=True, freq_channel=two_d)
         raise NotImplementedError("features=%r: raw waveforms are not on the accelerated path" % features)
 
+    def _on_device(self):
+        """libfsc_hip launches on the CURRENT HIP device / stream: make it the model's for the duration of a call
+        (a model built with device="cuda:1" in a process whose current device is 0)."""
+        dev = torch.device(self.device)
+        return torch.cuda.device(dev if dev.index is not None else torch.cuda.current_device())
+
     def forward(self, signal):
-        h = self._front_end(signal)
+        with self._on_device():
+            return self._forward(signal)
+
+    def _forward(self, signal):
+        return self.forward_features(self._front_end(signal))
+
+    def features(self, signal):
+        """Front-end only: (N, T, 1) waveforms -> the spectrogram tensor the conv blocks consume.  An ensemble of
+        fold models shares it (same descriptor, same filterbank): see predict_2d_cnn.predict_folds."""
+        with self._on_device():
+            return self._front_end(signal)
+
+    def forward_features(self, h):
+        """Conv blocks + heads + classifier on a precomputed front-end output."""
         if self.dims == 1:
             h = h.unsqueeze(2)              # (N, C, 1, L): the 1-d model is the H == 1 case
         start = self.config.network.start_deep_supervision_on
@@ -148,7 +168,7 @@ class _TaggingModel(nn.Module):
         z = F.bn_act(feats, ot[0], None, self.training)
         z = F.linear(z, ot[1].weight, ot[1].bias)
         z = F.bn_act(z, ot[2], ot[3], self.training)
-        z = F.dropout(z, ot[4].p, self.training)
+        z = F.dropout(z, ot[4].p, self.training, self._dropout_state)
         logits = F.linear(z, ot[5].weight, ot[5].bias)
         return dict(class_logits=logits)
 
@@ -175,18 +195,19 @@ class _TaggingModel(nn.Module):
         """Forward, loss, backward, (all-reduce,) optimizer step on one device batch.
         Returns (class_logits, per-sample losses or scalar loss).  No host synchronisation."""
         acc = self.config.train.accumulation_steps
-        outputs = self(signal)
-        class_logits = outputs["class_logits"]
-        per = self._per_sample_loss(class_logits, labels)
-        loss = F.mean(per, 1.0 / acc) if per.dim() else F.mean(per.reshape(1), 1.0 / acc)
-        if self._reducer is not None:
-            self._reducer.prepare(sync=step_optimizer)
-        loss.backward()
-        if step_optimizer:
+        with self._on_device():
+            outputs = self(signal)
+            class_logits = outputs["class_logits"]
+            per = self._per_sample_loss(class_logits, labels)
+            loss = F.mean(per, 1.0 / acc) if per.dim() else F.mean(per.reshape(1), 1.0 / acc)
             if self._reducer is not None:
-                self._reducer.finish()
-            self.optimizer.step()
-            self.optimizer.zero_grad()
+                self._reducer.prepare(sync=step_optimizer)
+            loss.backward()
+            if step_optimizer:
+                if self._reducer is not None:
+                    self._reducer.finish()
+                self.optimizer.step()
+                self.optimizer.zero_grad()
         return class_logits, per, loss
 
     def train_epoch(self, train_loader, epoch, log_interval, write_summary=True):
@@ -237,6 +258,7 @@ class _TaggingModel(nn.Module):
         all_class_probs = np.asarray(all_class_probs)
         all_labels = np.asarray(all_labels)
         metric = lwlrap(all_labels, all_class_probs)
+        self.last_valid_loss = valid_loss
         if write_summary:
             self.add_scalar_summaries(valid_loss, metric, writer=self.valid_writer, global_step=self.global_step)
         if verbose:

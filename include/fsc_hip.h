@@ -64,12 +64,14 @@ int fsc_frontend_stft_fwd(const float* wave, int n, int t, long wave_stride,
  * (classifiers.py:149-154, 42-46; H == 1, kh == 1).  fp32 in, fp32 out, fp32 accumulation; the products run on
  * v_mfma_f32_16x16x32_f16 through a two-limb fp16 split with exact power-of-two operand scaling (default), on
  * v_mfma_f32_16x16x32_bf16 through an exact three-limb bf16 split, or on v_mfma_f32_16x16x4_f32
- * (fsc_conv_set_arith), stem layers (c_in <= 4) on the vector ALUs.  Weights are re-packed per use by
+ * (fsc_conv_desc.arith), stem layers (c_in <= 4) on the vector ALUs.  Weights are re-packed per use by
  * fsc_conv_pack_weights; the packed format is private to the library and depends on shape and arithmetic mode. */
 
+#define FSC_ARITH_DEFAULT (-1)
 typedef struct {
     int n, c_in, c_out, h, w; /* output spatial size == input spatial size (stride 1, same pad) */
     int kh, kw;               /* (3,3), (1,1), (1,3) */
+    int arith;                /* arithmetic of THIS call: 0, 3, 6, 9 (below) or FSC_ARITH_DEFAULT */
 } fsc_conv_desc;
 
 /* floats of packed-weight workspace for one direction (fwd or dgrad) */
@@ -83,7 +85,7 @@ int fsc_conv_pack_weights(const fsc_conv_desc* d, const float* weight, int dgrad
 int fsc_conv_fwd(const fsc_conv_desc* d, const float* in, const float* packed,
                  const float* bias, int dgrad, int accumulate, float* out,
                  const float* in_amax, fsc_stream_t stream);
-/* Largest magnitude of a tensor.  The scaled split-fp16 arithmetic (fsc_conv_set_arith(3)) takes max |x| of each
+/* Largest magnitude of a tensor.  The scaled split-fp16 arithmetic (arith 3) takes max |x| of each
  * activation / gradient operand as an `*_amax` device buffer of FSC_AMAX_FLOATS non-negative floats whose
  * maximum is the value (many slots so that the thousands of workgroups of a producer do not serialise on one
  * address): from this function, or from the producers that report it for free while they write the tensor
@@ -101,17 +103,20 @@ int fsc_conv_pool_fwd(const fsc_conv_desc* d, const float* in, const float* pack
 /* human-readable tiling chosen for this shape (mode 0 fwd, 1 dgrad, 2 wgrad): kernel
  * instantiation, pixel box, grid, LDS bytes.  For logs, DESIGN.md tables and profiles. */
 int fsc_conv_plan_describe(const fsc_conv_desc* d, int mode, char* buf, size_t buf_len);
-/* Arithmetic of the convolution kernels.  0: native fp32 MFMA (v_mfma_f32_16x16x4_f32).
+/* Arithmetic of the convolution kernels: a per-call property, `fsc_conv_desc.arith` (the library keeps no
+ * mutable mode).  0: native fp32 MFMA (v_mfma_f32_16x16x4_f32).
  * 3: every fp32 operand x is scaled by a power of two s (from the tensor's largest magnitude, see fsc_amax) and
  * split into two fp16 limbs h = rne(x*s), l = rne(x*s - h) (|x*s - h - l| <= 2^-24 |x*s|); the product is formed
- * from the 3 limb products hh + hl + lh on v_mfma_f32_16x16x32_f16 with fp32 accumulation and unscaled exactly.
+ * from the 3 limb products hh + hl + lh on v_mfma_f32_16x16x32_f16 with fp32 accumulation and unscaled exactly
+ * (dropped term ll <= 2^-22 |a*b|).  An operand holding +-Inf (declared maximum Inf) makes every output of the
+ * call non-finite; NaN elements propagate to the outputs they touch.
  * 6 / 9: every fp32 operand is split exactly into three bf16 limbs and the product is formed from 6 / 9
  * limb products on v_mfma_f32_16x16x32_bf16 with fp32 accumulation (9 = all terms: the product is exact
  * before accumulation; 6 drops terms below 2^-23 |a*b|).  Inputs, outputs and accumulators are fp32
- * in every mode.  Default 3, or the environment variable FSC_CONV_ARITH = f32 | f16x3 | bf16x6 | bf16x9.
- * The packed-weight format depends on the mode: re-pack after changing it. */
-int fsc_conv_set_arith(int mode);
-int fsc_conv_get_arith(void);
+ * in every mode.  FSC_ARITH_DEFAULT selects the process default: 3, or the environment variable
+ * FSC_CONV_ARITH = f32 | f16x3 | bf16x6 | bf16x9, read once.  The packed-weight format depends on the mode:
+ * pack with the descriptor (same `arith`) the weights are used with. */
+int fsc_conv_default_arith(void);
 /* bytes of split-K workspace for the weight gradient */
 size_t fsc_conv_wgrad_workspace_bytes(const fsc_conv_desc* d);
 /* dweight (c_out, c_in, kh, kw) = sum_pixels dout x in  (overwrites dweight) */

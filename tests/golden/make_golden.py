@@ -439,6 +439,53 @@ def g11_cfg1():
     save("g11_cfg1.npz", **out)
 
 
+# ---------------------------------------------------------------------------------- G12
+def g12_cfg2_step():
+    """cfg 2 of BASELINE.json at its real widths (6 blocks, base 100, growth 1.5 -> 100/150/225/337/506/759
+    channels, mel_2048_1024_128, 10 s @ 44.1 kHz), batch 4, one training forward/backward of the REFERENCE
+    model.  The 86 MB state dict is not stored: the product registers the same modules in the same order, so
+    `torch.manual_seed(seed)` reproduces the reference's initial parameters bit for bit (checked through the
+    per-parameter checksums stored here).  Stored: logits, per-sample LSEP, eval-mode logits after the one
+    BN update, and per parameter the gradient's l2 norm, sum and 256 elements at seeded positions."""
+    seed = 2024
+    seed_all(seed)
+    exp = experiment("mel_2048_1024_128", blocks=6, base=100, growth=1.5, start=1, input_dim=128)
+    model = TwoDimensionalCNNClassificationModel(exp, device="cpu")
+    gen = torch.Generator().manual_seed(4321)
+    signal = 0.1 * torch.randn(4, 441000, 1, generator=gen)
+    signal[-1, 300000:] = 0.0                                  # collate tail
+    rng = np.random.default_rng(12)
+    labels = torch.from_numpy(labels_multi_hot(4, 80, rng))
+    out = {"seed": np.int64(seed), "signal_seed": np.int64(4321), "labels": labels.numpy(),
+           "zero_tail_from": np.int64(300000)}
+    names = []
+    for k, p in model.named_parameters():
+        names.append(k)
+        v = p.detach().double()
+        out["init_sum." + k] = np.float64(v.sum().item())
+        out["init_abs." + k] = np.float64(v.abs().sum().item())
+    out["n_params"] = np.int64(sum(p.numel() for p in model.parameters()))
+    model.train()
+    logits = model(signal)["class_logits"]
+    per = lsep_loss(logits, labels, average=False)
+    per.mean().backward()
+    out["logits"] = logits.detach().numpy()
+    out["loss"] = per.detach().numpy()
+    pick = np.random.default_rng(99)
+    for k, p in model.named_parameters():
+        g = p.grad.detach().reshape(-1)
+        idx = pick.integers(0, g.numel(), size=min(256, g.numel()))
+        out["grad_idx." + k] = idx.astype(np.int64)
+        out["grad_val." + k] = g[torch.from_numpy(idx)].numpy().copy()
+        out["grad_norm." + k] = np.float64(g.double().norm().item())
+        out["grad_sum." + k] = np.float64(g.double().sum().item())
+        out["grad_absmax." + k] = np.float64(g.abs().max().item())
+    model.eval()
+    with torch.no_grad():
+        out["eval_logits"] = model(signal)["class_logits"].numpy()
+    save("g12_cfg2_step.npz", **out)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
     g1_frontend()
@@ -452,3 +499,4 @@ if __name__ == "__main__":
     g9_schedules()
     g10_lwlrap()
     g11_cfg1()
+    g12_cfg2_step()

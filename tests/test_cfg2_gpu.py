@@ -1,0 +1,321 @@
+"""Parity at the widths the benchmark runs (BASELINE.json configs[1]: 6 blocks, base 100, growth 1.5 ->
+100 / 150 / 225 / 337 / 506 / 759 channels, 128 x 10 s @ 44.1 kHz, mel_2048_1024_128).
+
+* every convolution layer of that model through fwd / dgrad / accumulating dgrad / wgrad, in the default split-fp16
+  arithmetic AND in native fp32, against PyTorch's fp64 convolution on the CPU (never against another HIP kernel),
+  with the kernel instantiation asserted to be the one batch 128 selects;
+* one full training forward / backward of the real 21.5 M-parameter model against the fixture the imported reference
+  produced (tests/golden/g12_cfg2_step.npz) and against the CPU oracle in fp32 and fp64;
+* the split-fp16 arithmetic where it can break: per-sample gradient rows spread over 2^-40, Inf / NaN operands, an
+  LSEP overflow step.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+if not torch.cuda.is_available():
+    pytest.skip("needs an MI355X", allow_module_level=True)
+
+import torch.nn.functional as TF  # noqa: E402
+
+from freesound_classification_amd import functional as F  # noqa: E402
+from freesound_classification_amd.networks.classifiers import TwoDimensionalCNNClassificationModel  # noqa: E402
+from freesound_classification_amd.networks.losses import lsep_loss  # noqa: E402
+from oracle import ref_torch as oref  # noqa: E402
+from test_oracle_cpu import cfg2_golden_inputs, check_cfg2_step_against_golden  # noqa: E402
+
+DEV = torch.device("cuda:0")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REPORT = os.path.join(ROOT, "gpurun_out", "cfg2_layer_parity.txt")
+
+
+def cfg2_layers():
+    """(c_in, c_out, h, w, k) of the 24 convolutions of the cfg-2 model (classifiers.py:524-536, 72-104)."""
+    out = []
+    h, w, c_in = 128, 431, 2
+    for depth in [int(1.5 ** k * 100) for k in range(6)]:
+        out.append((c_in, depth, h, w, 3))
+        h, w = h // 2, w // 2
+        out += [(depth, depth, h, w, 1), (depth, depth, h, w, 3)]        # conv1 == conv3 (1x1), conv2 (3x3)
+        c_in = depth
+    return out
+
+
+LAYERS = cfg2_layers()
+
+
+def _batch_for(layer, arith):
+    """Batch 128 for the planes up to 8 x 26 (cheap enough in fp64); otherwise the smallest batch whose three kernel
+    instantiations (fwd, dgrad, wgrad) are the ones batch 128 selects."""
+    c_in, c_out, h, w, k = layer
+    if h * w <= 8 * 26:
+        return 128
+    full = [F.plan_name(F._desc(128, c_in, c_out, h, w, k, k, arith), m) for m in (0, 1, 2)]
+    for n in (2, 4, 8, 16, 32, 64):
+        if [F.plan_name(F._desc(n, c_in, c_out, h, w, k, k, arith), m) for m in (0, 1, 2)] == full:
+            return n
+    return 128
+
+
+def _report(line):
+    os.makedirs(os.path.dirname(REPORT), exist_ok=True)
+    with open(REPORT, "a") as f:
+        f.write(line + "\n")
+
+
+@pytest.mark.parametrize("arith", [3, 0], ids=["f16x3", "f32"])
+@pytest.mark.parametrize("layer", LAYERS, ids=["%dto%d_%dx%d_k%d" % l for l in LAYERS])
+def test_cfg2_layer_against_fp64(layer, arith):
+    c_in, c_out, h, w, k = layer
+    n = _batch_for(layer, arith)
+    names = [F.plan_name(F._desc(n, c_in, c_out, h, w, k, k, arith), m) for m in (0, 1, 2)]
+    assert names == [F.plan_name(F._desc(128, c_in, c_out, h, w, k, k, arith), m) for m in (0, 1, 2)]
+    if arith == 3 and c_in >= 32:
+        assert names[0].startswith("conv_fwd_x3_kernel") and names[0].endswith(",3>"), names
+    torch.manual_seed(c_in * 7 + c_out + h)
+    pad = k // 2
+    x = torch.randn(n, c_in, h, w)
+    wt = torch.randn(c_out, c_in, k, k) / (c_in * k * k) ** 0.5
+    b = torch.randn(c_out)
+    gy = torch.randn(n, c_out, h, w)
+    y64 = TF.conv2d(x.double(), wt.double(), b.double(), padding=pad)
+    dx64 = torch.nn.grad.conv2d_input(x.shape, wt.double(), gy.double(), padding=pad)
+    dw64 = torch.nn.grad.conv2d_weight(x.double(), wt.shape, gy.double(), padding=pad)
+    # what PyTorch's own fp32 convolution loses against fp64 on the same operands: the yard-stick
+    e_y = float((TF.conv2d(x, wt, b, padding=pad).double() - y64).abs().max())
+    e_dx = float((torch.nn.grad.conv2d_input(x.shape, wt, gy, padding=pad).double() - dx64).abs().max())
+    e_dw = float((torch.nn.grad.conv2d_weight(x, wt.shape, gy, padding=pad).double() - dw64).abs().max())
+
+    mode0 = F.get_conv_arith()
+    try:
+        F.set_conv_arith(arith)
+        xd, wd, bd, gd = x.to(DEV), wt.to(DEV), b.to(DEV), gy.to(DEV)
+        y = F.conv_forward(xd, wd, bd).cpu()
+        dx = F.conv_dgrad(gd, wd, x.shape).cpu()
+        base = torch.randn_like(x)
+        dxa = F.conv_dgrad(gd, wd, x.shape, accumulate_into=base.to(DEV)).cpu()
+        dw = F.conv_wgrad(xd, gd, wt.shape).cpu()
+    finally:
+        F.set_conv_arith(mode0)
+    g_y = float((y.double() - y64).abs().max())
+    g_dx = float((dx.double() - dx64).abs().max())
+    g_dxa = float((dxa.double() - (dx64 + base.double())).abs().max())
+    g_dw = float((dw.double() - dw64).abs().max())
+    _report("%-22s arith %d n %3d  fwd %.2e (torch f32 %.2e, x%.2f) %s | dgrad %.2e (%.2e, x%.2f) %s | wgrad %.2e (%.2e, x%.2f) %s"
+            % ("%dto%d_%dx%d_k%d" % layer, arith, n, g_y, e_y, g_y / e_y, names[0].split(" ")[0], g_dx, e_dx, g_dx / e_dx,
+               names[1].split(" ")[0], g_dw, e_dw, g_dw / e_dw, names[2].split(" ")[0]))
+    # Bound: a small multiple of the error PyTorch's own fp32 convolution makes against fp64 on the same operands
+    # (unit-variance operands and outputs; the measured ratios go to the report: split-fp16 0.3 .. 2.5).
+    assert g_y < 5.0 * e_y + 1e-7, (g_y, e_y)
+    assert g_dx < 5.0 * e_dx + 1e-7, (g_dx, e_dx)
+    assert g_dxa < 5.0 * e_dx + 1e-6, (g_dxa, e_dx)
+    assert g_dw < 5.0 * e_dw + 1e-6, (g_dw, e_dw)
+
+
+# ------------------------------------------------------------------------------ the full cfg-2 model
+class NS(dict):
+    __getattr__ = dict.__getitem__
+
+
+def cfg2_experiment(dropout=0.0):
+    return NS(config=NS(
+        network=NS(num_conv_blocks=6, start_deep_supervision_on=1, conv_base_depth=100, growth_rate=1.5,
+                   output_dropout=dropout, aggregation_type="max"),
+        data=NS(features="mel_2048_1024_128", _input_dim=128, _n_classes=80),
+        train=NS(accumulation_steps=1, optimizer="adam", learning_rate=1e-3, weight_decay=0.0,
+                 scheduler="1cycle_0.0001_0.005", switch_off_augmentations_on=1000, _save_every=1000)))
+
+
+@pytest.fixture(scope="module")
+def cfg2_step(golden):
+    """One training forward / backward + eval forward of the product at cfg-2 width on the fixture's inputs."""
+    g = golden("g12_cfg2_step.npz")
+    torch.manual_seed(int(g["seed"]))
+    m = TwoDimensionalCNNClassificationModel(cfg2_experiment(), device="cuda:0")
+    state = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+    signal, labels = cfg2_golden_inputs(g)
+    m.train()
+    logits = m(signal.to(DEV))["class_logits"]
+    per = lsep_loss(logits, labels.to(DEV), average=False)
+    F.mean(per).backward()
+    grads = {k: p.grad.detach().cpu() for k, p in m.named_parameters()}
+    m.eval()
+    with torch.no_grad():
+        ev = m(signal.to(DEV))["class_logits"].cpu()
+    return dict(g=g, state=state, signal=signal, labels=labels, logits=logits.detach().cpu(), per=per.detach().cpu(),
+                grads=grads, eval_logits=ev, model=m)
+
+
+def test_cfg2_model_step_against_reference_golden(cfg2_step):
+    s = cfg2_step
+    g = s["g"]
+    assert sum(v.numel() for v in s["grads"].values()) == int(g["n_params"]) == 21545583
+    for k, v in s["state"].items():          # same seed, same registration order -> the reference's initial parameters
+        if ("init_sum." + k) in g:
+            assert float(v.double().sum()) == float(g["init_sum." + k]), k
+    worst = check_cfg2_step_against_golden(g, [(k, v.numpy()) for k, v in s["grads"].items()], s["logits"].numpy(),
+                                           s["per"].numpy(), s["eval_logits"].numpy())
+    _report("cfg2 model step vs reference golden: logits %.2e  loss %.2e  eval %.2e  worst scaled grad diff %.2e" % (
+        float(np.abs(s["logits"].numpy() - g["logits"]).max()), float(np.abs(s["per"].numpy() - g["loss"]).max()),
+        float(np.abs(s["eval_logits"].numpy() - g["eval_logits"]).max()), worst))
+
+
+def test_cfg2_model_step_against_oracle_fp32_and_fp64(cfg2_step):
+    """Every element of every gradient against the CPU oracle (fp32), and both against an fp64 run of the oracle:
+    the accelerated step must not be further from fp64 than the fp32 CPU path is (beyond a small factor)."""
+    s = cfg2_step
+    ref = oref.TagCNN2d("mel_2048_1024_128", 6, 100, 1.5, 1, 80)
+    ref.load_state_dict(s["state"])
+    ref.train()
+    rl = ref(s["signal"])["class_logits"]
+    oref.lsep(rl, s["labels"], average=False).mean().backward()
+    r32 = {k: p.grad.detach().clone() for k, p in ref.named_parameters()}
+    ref64 = oref.TagCNN2d("mel_2048_1024_128", 6, 100, 1.5, 1, 80).double()
+    ref64.load_state_dict({k: (v.double() if v.is_floating_point() else v) for k, v in s["state"].items()})
+    ref64.filterbank = ref64.filterbank.double()
+    ref64.train()
+    l64 = ref64(s["signal"].double())["class_logits"]
+    oref.lsep(l64, s["labels"].double(), average=False).mean().backward()
+    r64 = {k: p.grad.detach() for k, p in ref64.named_parameters()}
+    assert float((s["logits"].double() - l64.detach()).abs().max()) < 1e-3
+    assert float((s["logits"] - rl.detach()).abs().max()) < 1e-3
+    tot_p = tot_r = 0.0
+    for k, gp in s["grads"].items():
+        scale = max(1.0, float(r64[k].abs().max()))
+        d32 = (gp.double() - r32[k].double()).abs()
+        assert float(d32.max()) < 2e-3 * scale, (k, float(d32.max()), scale)          # see check_cfg2_step_against_golden
+        assert float(d32.pow(2).mean().sqrt()) < 5e-4 * scale, k
+        ep = float((gp.double() - r64[k]).pow(2).sum())
+        er = float((r32[k].double() - r64[k]).pow(2).sum())
+        tot_p += ep
+        tot_r += er
+    _report("cfg2 model step vs fp64 oracle: sum sq grad error product %.3e, fp32 CPU oracle %.3e" % (tot_p, tot_r))
+    assert tot_p < 9.0 * tot_r + 1e-12, (tot_p, tot_r)          # within 3x in rms of the fp32 CPU path's own error
+
+
+# ------------------------------------------------------------------------------ split-fp16 where it can break
+@pytest.fixture
+def f16x3():
+    mode0 = F.get_conv_arith()
+    F.set_conv_arith(3)
+    yield
+    F.set_conv_arith(mode0)
+
+
+@pytest.mark.parametrize("case", [(16, 100, 150, 16, 43, 3), (16, 150, 150, 8, 26, 1), (41, 64, 48, 1, 300, 3)])
+def test_split_fp16_gradient_rows_spread_over_2_to_minus_40(case, f16x3):
+    """`dout` whose per-sample rows are scaled by 2^0 .. 2^-40 (LSEP gives per-sample gradients of very different
+    size).  One power-of-two scale serves the whole tensor, so the guarantee is ABSOLUTE: error <= a few fp32 ulps of
+    the products of the LARGEST rows (what an fp32 sum over the batch loses anyway, and what the batch-statistics BN
+    backward downstream mixes into every row); rows within 2^-10 of the maximum also keep fp32 RELATIVE accuracy.
+    The per-row relative error is written to the report."""
+    n, c_in, c_out, h, w, k = case
+    kh = 1 if h == 1 else k
+    pad = (kh // 2, k // 2)
+    torch.manual_seed(sum(case))
+    x = torch.randn(n, c_in, h, w)
+    wt = torch.randn(c_out, c_in, kh, k) / (c_in * kh * k) ** 0.5
+    expo = torch.linspace(0, -40, n).round()
+    gy = torch.randn(n, c_out, h, w) * torch.exp2(expo).view(n, 1, 1, 1)
+    dx64 = torch.nn.grad.conv2d_input(x.shape, wt.double(), gy.double(), padding=pad)
+    dw64 = torch.nn.grad.conv2d_weight(x.double(), wt.shape, gy.double(), padding=pad)
+    dx32 = torch.nn.grad.conv2d_input(x.shape, wt, gy, padding=pad)
+    dw32 = torch.nn.grad.conv2d_weight(x, wt.shape, gy, padding=pad)
+    d = F._desc(n, c_in, c_out, h, w, kh, k)
+    assert F.plan_name(d, 1).startswith("conv_fwd_x3_kernel") and F.plan_name(d, 2).startswith("conv_wgrad"), (
+        F.plan_name(d, 1), F.plan_name(d, 2))
+    dx = F.conv_dgrad(gy.to(DEV), wt.to(DEV), x.shape).cpu()
+    dw = F.conv_wgrad(x.to(DEV), gy.to(DEV), wt.shape).cpu()
+    eps = 2.0 ** -23
+    top = float(dx64.abs().max())
+    e_abs = float((dx.double() - dx64).abs().max())
+    assert e_abs < 8 * eps * top, (e_abs, top)
+    rel = []
+    for r in range(n):
+        denom = float(dx64[r].abs().max())
+        rel.append(float((dx[r].double() - dx64[r]).abs().max()) / denom)
+        if expo[r] >= -10:
+            assert rel[-1] < 16 * eps, (r, float(expo[r]), rel[-1])
+    _report("row-scaled dgrad %s: abs err %.2e of max %.2e; per-row rel err at 2^[%s] = [%s]" % (
+        case, e_abs, top, ", ".join("%d" % e for e in expo.tolist()), ", ".join("%.1e" % v for v in rel)))
+    # the weight gradient sums the rows: dominated by the large ones, fp32-accurate in absolute terms
+    e_dw = float((dw.double() - dw64).abs().max())
+    e_dw32 = float((dw32.double() - dw64).abs().max())
+    assert e_dw < 4.0 * e_dw32 + 8 * eps * float(dw64.abs().max()), (e_dw, e_dw32)
+    assert float((dx32.double() - dx64).abs().max()) <= e_abs * 64 + 1.0      # (fp32 reference computed for the report)
+
+
+@pytest.mark.parametrize("bad", [float("inf"), float("-inf"), float("nan")])
+@pytest.mark.parametrize("case", [(2, 100, 100, 16, 43, 3), (2, 100, 100, 16, 43, 1)])
+def test_split_fp16_non_finite_operands_surface(case, bad, f16x3):
+    """An Inf or NaN in an operand must come out non-finite wherever F.conv2d's output is non-finite (never a finite
+    number): NaN elements travel through the limbs; an Inf makes the declared maximum Inf, and the kernels then mark
+    EVERY output of the call non-finite (include/fsc_hip.h)."""
+    n, c_in, c_out, h, w, k = case
+    torch.manual_seed(1)
+    x = torch.randn(n, c_in, h, w)
+    wt = torch.randn(c_out, c_in, k, k) / (c_in * k * k) ** 0.5
+    gy = torch.randn(n, c_out, h, w)
+    xb = x.clone()
+    xb[1, 37, 5, 11] = bad
+    ref = TF.conv2d(xb, wt, None, padding=k // 2)
+    got = F.conv_forward(xb.to(DEV), wt.to(DEV), None).cpu()
+    assert not torch.isfinite(got[~torch.isfinite(ref)]).any()
+    if bad != bad:       # NaN: the rest of the output is untouched and still right
+        ok = torch.isfinite(ref)
+        assert float((got[ok] - ref[ok]).abs().max()) < 1e-4
+    else:
+        assert not torch.isfinite(got).any()
+    gb = gy.clone()
+    gb[0, 3, 2, 2] = bad
+    rdx = torch.nn.grad.conv2d_input(x.shape, wt, gb, padding=k // 2)
+    dx = F.conv_dgrad(gb.to(DEV), wt.to(DEV), x.shape).cpu()
+    assert not torch.isfinite(dx[~torch.isfinite(rdx)]).any()
+    rdw = torch.nn.grad.conv2d_weight(x, wt.shape, gb, padding=k // 2)
+    dw = F.conv_wgrad(x.to(DEV), gb.to(DEV), wt.shape).cpu()
+    assert not torch.isfinite(dw[~torch.isfinite(rdw)]).any()
+    wb = wt.clone()
+    wb[5, 7] = bad
+    rw = TF.conv2d(x, wb, None, padding=k // 2)
+    gw = F.conv_forward(x.to(DEV), wb.to(DEV), None).cpu()
+    assert not torch.isfinite(gw[~torch.isfinite(rw)]).any()
+
+
+def test_lsep_overflow_step_is_loudly_non_finite():
+    """The reference's LSEP exponentiates score gaps unclamped (networks/losses.py:52): a gap above ~88 overflows.
+    The accelerated step must surface that as a non-finite loss and non-finite gradients, exactly like the CPU path --
+    never as finite garbage."""
+    torch.manual_seed(2)
+    exp = NS(config=NS(
+        network=NS(num_conv_blocks=2, start_deep_supervision_on=0, conv_base_depth=64, growth_rate=1.5,
+                   output_dropout=0.0, aggregation_type="max"),
+        data=NS(features="mel_1024_512_64", _input_dim=64, _n_classes=80),
+        train=NS(accumulation_steps=1, optimizer="adam", learning_rate=1e-3, weight_decay=0.0,
+                 scheduler="1cycle_0.0001_0.005")))
+    m = TwoDimensionalCNNClassificationModel(exp, device="cuda:0")
+    ref = oref.TagCNN2d("mel_1024_512_64", 2, 64, 1.5, 0, 80)
+    with torch.no_grad():
+        m.output_transform[5].weight.mul_(400.0)           # logits of several hundred -> exp() overflows in fp32
+    ref.load_state_dict({k: v.cpu() for k, v in m.state_dict().items()})
+    signal = 0.1 * torch.randn(8, 20000, 1)
+    labels = torch.zeros(8, 80)
+    labels[torch.arange(8), torch.randint(0, 80, (8,))] = 1.0
+    ref.train()
+    rl = ref(signal)["class_logits"]
+    rper = oref.lsep(rl, labels, average=False)
+    rper.mean().backward()
+    assert not torch.isfinite(rper).all()                  # the CPU path overflows on this input
+    m.train()
+    m.make_optimizer(max_steps=10)
+    logits, per, loss = m.training_step(signal.to(DEV), labels.to(DEV), step_optimizer=False)
+    assert float((logits.cpu() - rl).abs().max()) < 1e-2 * float(rl.abs().max())
+    assert torch.equal(torch.isfinite(per.cpu()), torch.isfinite(rper))
+    assert not torch.isfinite(loss)
+    rg = dict(ref.named_parameters())
+    for k, p in m.named_parameters():
+        if not torch.isfinite(rg[k].grad).all():
+            assert not torch.isfinite(p.grad).all(), k

@@ -225,3 +225,66 @@ def test_cfg1_end_to_end(golden):
             probs = torch.sigmoid(logits).numpy()
             assert abs(ohost.lwlrap(labels.numpy(), probs)
                        - float(g["%s.lwlrap%d" % (loss_name, step)])) < 1e-3
+
+
+def cfg2_golden_inputs(g):
+    """Inputs of fixture g12 (the cfg-2 model step): seeded waveform batch with a zero tail, labels."""
+    gen = torch.Generator().manual_seed(int(g["signal_seed"]))
+    signal = 0.1 * torch.randn(4, 441000, 1, generator=gen)
+    signal[-1, int(g["zero_tail_from"]):] = 0.0
+    return signal, torch.from_numpy(g["labels"])
+
+
+def check_cfg2_step_against_golden(g, named_grads, logits, per, eval_logits, tol=1e-3):
+    """Shared by the CPU oracle test and the GPU product test (tests/test_cfg2_gpu.py).
+
+    Logits, per-sample LSEP and eval-mode logits: `tol` absolute (north star: 1e-3 fp32).
+    Gradients at this size are O(1..10) sums over up to 5.5 M positions behind 22 M max-pool windows and PReLU
+    kinks: two fp32 evaluations of the SAME model whose log-mel inputs differ by 1e-6 (the reference's conv1d
+    mel product against the oracle's einsum, both on the CPU) pick different winners in a handful of windows and
+    differ by up to 1.0e-3 x max(1, |g|max) on the block-0 parameters, with 0.4 % of the sampled elements beyond
+    1e-3 absolute (measured when this fixture was made).  So: every sampled element within 2 * tol relative to
+    max(1, |g|max of its tensor), at most 2 % of all sampled elements beyond tol absolute, and per tensor the rms
+    difference below tol / 2 on the same scale.  Returns the worst scaled difference."""
+    assert float(np.abs(logits - g["logits"]).max()) < tol
+    assert float(np.abs(per - g["loss"]).max()) < tol
+    assert float(np.abs(eval_logits - g["eval_logits"]).max()) < tol
+    worst, total, beyond = 0.0, 0, 0
+    for k, grad in named_grads:
+        flat = np.asarray(grad).reshape(-1)
+        scale = max(1.0, float(g["grad_absmax." + k]))
+        d = np.abs(flat[g["grad_idx." + k]].astype(np.float64) - g["grad_val." + k])
+        worst = max(worst, float(d.max()) / scale)
+        assert float(d.max()) < 2 * tol * scale, (k, float(d.max()), scale)
+        assert float(np.sqrt((d ** 2).mean())) < 0.5 * tol * scale or d.size < 8, (k, float(np.sqrt((d ** 2).mean())))
+        total += d.size
+        beyond += int((d > tol).sum())
+        norm = float(np.linalg.norm(flat.astype(np.float64)))
+        assert abs(norm - float(g["grad_norm." + k])) < 2 * tol * max(1.0, float(g["grad_norm." + k])), k
+    assert beyond <= 0.02 * total, (beyond, total)
+    return worst
+
+
+def test_cfg2_width_model_step_golden(golden):
+    """Fixture g12: the reference model at the benchmark's real widths (100 ... 759 channels, 21.5 M parameters),
+    one training forward / backward at batch 4.  Same seed -> same init (checksums), then logits, per-sample LSEP,
+    sampled gradients of every parameter and eval-mode logits."""
+    g = golden("g12_cfg2_step.npz")
+    torch.manual_seed(int(g["seed"]))
+    m = oref.TagCNN2d("mel_2048_1024_128", 6, 100, 1.5, 1, 80)
+    assert sum(p.numel() for p in m.parameters()) == int(g["n_params"]) == 21545583
+    for k, p in m.named_parameters():
+        assert float(p.detach().double().sum()) == float(g["init_sum." + k]), k
+        assert float(p.detach().double().abs().sum()) == float(g["init_abs." + k]), k
+    signal, labels = cfg2_golden_inputs(g)
+    m.train()
+    logits = m(signal)["class_logits"]
+    per = oref.lsep(logits, labels, average=False)
+    per.mean().backward()
+    m.eval()
+    with torch.no_grad():
+        ev = m(signal)["class_logits"]
+    check_cfg2_step_against_golden(
+        g, [(k, p.grad.numpy()) for k, p in m.named_parameters()], logits.detach().numpy(), per.detach().numpy(),
+        ev.numpy())
+    assert float(np.abs(logits.detach().numpy() - g["logits"]).max()) < 1e-4       # forward: far inside the tolerance

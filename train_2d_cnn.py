@@ -1,14 +1,16 @@
-"""Training driver for the accelerated 2-d CNN: counterpart of the reference's train_2d_cnn.py
-(CLI flags of train_2d_cnn.py:36-187 that concern the hot path, same config dictionary layout,
-fit_validate -> predictions CSV -> out-of-fold lwlrap).
+"""Training driver for the accelerated 2-d CNN: counterpart of the reference's train_2d_cnn.py -- the same CLI flags
+(train_2d_cnn.py:36-187), the same config dictionary (:194-232), the same per-fold flow (:258-422: stratified
+splits, train / valid loaders, fit_validate, final_model.pth, load_best_model, val_preds_fold_k.csv,
+test_preds_fold_k.csv, optional holdout metric) and the same epilogue (:455-511: out-of-fold lwlrap -> results.json,
+submission.csv = mean of the fold test predictions).
 
-Data: either the reference's CSV layout (`--train_df` with columns fname, labels and
-`--train_data_dir` with WAV files) or `--synthetic N` clips of seeded noise.  Launch under
-`python -m torch.distributed.run --nproc-per-node N` for data-parallel training (one process per GPU).
-`mag` is replaced by a minimal experiment directory object with the same attributes.
+Additions: `--synthetic N` replaces the CSV / WAV inputs by N seeded-noise clips (no dataset is needed to exercise
+the whole call surface), `--loss` (cfg 1 of the benchmark names BCE), and data-parallel training when launched under
+`python -m torch.distributed.run --nproc-per-node N` (one process per GPU; every rank trains on an equally long
+contiguous shard so all ranks take the same number of steps; rank 0 writes files).
+`mag.experiment.Experiment` is replaced by `freesound_classification_amd.experiment.Experiment` (same directory layout).
 """
 import argparse
-import json
 import os
 import random
 
@@ -16,177 +18,295 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
+from freesound_classification_amd import experiment as mag
 from freesound_classification_amd import parallel
 from freesound_classification_amd.datasets.sound_dataset import SoundDataset
-from freesound_classification_amd.networks.classifiers import (
-    HierarchicalCNNClassificationModel, TwoDimensionalCNNClassificationModel)
+from freesound_classification_amd.experiment import Experiment
+from freesound_classification_amd.networks.classifiers import TwoDimensionalCNNClassificationModel
+from freesound_classification_amd.ops.folds import train_validation_data, train_validation_data_stratified
 from freesound_classification_amd.ops.padding import make_collate_fn
 from freesound_classification_amd.ops.transforms import (
-    AudioFeatures, Compose, DropFields, LoadAudio, MapLabels, MixUp, SampleLongAudio, ShuffleAudio,
+    AudioFeatures, Compose, DropFields, Identity, LoadAudio, MapLabels, MixUp, SampleLongAudio, ShuffleAudio,
     SyntheticAudio)
 from freesound_classification_amd.ops.utils import get_class_names_from_classmap, load_json, lwlrap
 
 
-class AttrDict(dict):
-    __getattr__ = dict.__getitem__
-
-
-def to_attr(d):
-    return AttrDict({k: to_attr(v) if isinstance(v, dict) else v for k, v in d.items()})
-
-
-class Experiment:
-    """Directory-backed stand-in for mag.Experiment: config.json, results.json, registered dirs."""
-
-    def __init__(self, config, root="experiments"):
-        self.config = to_attr(config)
-        label = config.get("label") or "run"
-        self.directory = os.path.join(root, label)
-        os.makedirs(self.directory, exist_ok=True)
-        with open(os.path.join(self.directory, "config.json"), "w") as f:
-            json.dump(config, f, indent=2)
-        self._results = {}
-
-    def register_directory(self, name):
-        path = os.path.join(self.directory, name)
-        os.makedirs(path, exist_ok=True)
-        setattr(self, name, path)
-
-    def register_result(self, key, value):
-        self._results[key] = value
-        with open(os.path.join(self.directory, "results.json"), "w") as f:
-            json.dump(self._results, f, indent=2)
-
-    @property
-    def results(self):
-        return AttrDict(to_dict=lambda: dict(self._results))
-
-
-def parse_args():
+def build_parser(default_label="2d_cnn"):
     p = argparse.ArgumentParser(formatter_class=argparse.ArgumentDefaultsHelpFormatter)
-    p.add_argument("--train_df", type=str)
-    p.add_argument("--train_data_dir", type=str)
-    p.add_argument("--classmap", type=str)
-    p.add_argument("--synthetic", type=int, default=0, help="use N synthetic clips instead of files")
+    # --- the reference's flags (train_2d_cnn.py:36-187); the data paths are optional here because of --synthetic
+    p.add_argument("--train_df", type=str, help="path to train dataframe")
+    p.add_argument("--train_data_dir", type=str, help="path to train data")
+    p.add_argument("--noisy_train_df", type=str, help="path to noisy train dataframe (optional)")
+    p.add_argument("--noisy_train_data_dir", type=str, help="path to noisy train data (optional)")
+    p.add_argument("--share_noisy", action="store_true", default=False, help="whether to share noisy files across folds")
+    p.add_argument("--resume", action="store_true", default=False, help="allow resuming even if experiment exists")
+    p.add_argument("--test_data_dir", type=str, help="path to test data")
+    p.add_argument("--sample_submission", type=str, help="path sample submission")
+    p.add_argument("--classmap", type=str, help="path to class map json")
+    p.add_argument("--log_interval", default=10, type=int, help="how frequently to log batch metrics in terms of processed batches")
+    p.add_argument("--batch_size", type=int, default=64, help="minibatch size")
+    p.add_argument("--max_audio_length", type=int, default=10, help="max audio length in seconds. For longer clips are sampled")
+    p.add_argument("--lr", default=0.01, type=float, help="starting learning rate")
+    p.add_argument("--max_samples", type=int, help="maximum number of samples to use")
+    p.add_argument("--holdout_size", type=float, default=0.0, help="size of holdout set")
+    p.add_argument("--epochs", default=100, type=int, help="number of epochs to train")
+    p.add_argument("--scheduler", type=str, default="steplr_1_0.5", help="scheduler type")
+    p.add_argument("--accumulation_steps", type=int, default=1, help="number of gradient accumulation steps")
+    p.add_argument("--save_every", type=int, default=1, help="how frequently to save a model")
+    p.add_argument("--device", type=str, default="cuda", choices=("cuda", "cpu"),
+                   help="the accelerated path runs on an MI355X (\"cuda\" under ROCm); \"cpu\" raises: there is no CPU fallback")
+    p.add_argument("--aggregation_type", type=str, default="max", choices=("max", "rnn"), help="how to aggregate outputs")
+    p.add_argument("--num_conv_blocks", type=int, default=5, help="number of conv blocks")
+    p.add_argument("--start_deep_supervision_on", type=int, default=2,
+                   help="from which layer to start aggregating features for classification")
+    p.add_argument("--conv_base_depth", type=int, default=64, help="base depth for conv layers")
+    p.add_argument("--growth_rate", type=float, default=2, help="how quickly to increase the number of units as a function of layer")
+    p.add_argument("--weight_decay", type=float, default=1e-5, help="weight decay")
+    p.add_argument("--output_dropout", type=float, default=0.0, help="output dropout")
+    p.add_argument("--p_mixup", type=float, default=0.0, help="probability of the mixup augmentation")
+    p.add_argument("--p_aug", type=float, default=0.0, help="probability of audio augmentation (sox; not on the accelerated path)")
+    p.add_argument("--switch_off_augmentations_on", type=int, default=20, help="on which epoch to remove augmentations")
+    p.add_argument("--features", type=str, default="mel_2048_1024_128", help="feature descriptor")
+    p.add_argument("--optimizer", type=str, default="adam", help="which optimizer to use", choices=("adam", "momentum"))
+    p.add_argument("--folds", type=int, default=[0], nargs="+", help="which folds to use")
+    p.add_argument("--n_folds", type=int, default=4, help="number of folds")
+    p.add_argument("--kfold_seed", type=int, default=42, help="kfold seed")
+    p.add_argument("--num_workers", type=int, default=4, help="number of workers for data loader")
+    p.add_argument("--label", type=str, default=default_label, help="optional label")
+    # --- additions
+    p.add_argument("--synthetic", type=int, default=0, help="train on N seeded-noise clips instead of files")
+    p.add_argument("--synthetic_test", type=int, default=None, help="synthetic test clips (default N // 4)")
     p.add_argument("--synthetic_seconds", type=float, default=2.0)
     p.add_argument("--synthetic_sr", type=int, default=16000)
-    p.add_argument("--model", choices=["2d", "1d"], default="2d")
-    p.add_argument("--device", default="cuda", choices=["cuda"])
-    p.add_argument("--features", default="mel_1024_512_64")
-    p.add_argument("--num_conv_blocks", type=int, default=3)
-    p.add_argument("--conv_base_depth", type=int, default=32)
-    p.add_argument("--growth_rate", type=float, default=2.0)
-    p.add_argument("--start_deep_supervision_on", type=int, default=1)
-    p.add_argument("--output_dropout", type=float, default=0.0)
-    p.add_argument("--aggregation_type", default="max")
     p.add_argument("--loss", default="lsep", choices=["lsep", "bce"])
-    p.add_argument("--optimizer", default="adam", choices=["adam", "momentum"])
-    p.add_argument("--lr", type=float, default=1e-3)
-    p.add_argument("--weight_decay", type=float, default=0.0)
-    p.add_argument("--scheduler", default="1cycle_0.0001_0.005")
-    p.add_argument("--batch_size", type=int, default=64)
-    p.add_argument("--epochs", type=int, default=1)
-    p.add_argument("--accumulation_steps", type=int, default=1)
-    p.add_argument("--save_every", type=int, default=10)
-    p.add_argument("--switch_off_augmentations_on", type=int, default=10 ** 6)
-    p.add_argument("--p_mixup", type=float, default=0.0)
-    p.add_argument("--max_audio_length", type=int, default=10)
-    p.add_argument("--n_folds", type=int, default=2)
-    p.add_argument("--folds", type=int, nargs="+", default=[0])
-    p.add_argument("--kfold_seed", type=int, default=42)
-    p.add_argument("--num_workers", type=int, default=0)
-    p.add_argument("--log_interval", type=int, default=25)
-    p.add_argument("--label", default="2d_cnn")
-    return p.parse_args()
+    p.add_argument("--experiments_dir", default="experiments")
+    return p
 
 
-def main():
-    args = parse_args()
-    torch.manual_seed(42)
-    np.random.seed(42)
-    random.seed(42)
-    if int(os.environ.get("WORLD_SIZE", "1")) > 1:
-        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
-        dist.init_process_group("nccl")
-        args.device = "cuda:%d" % int(os.environ.get("LOCAL_RANK", "0"))
+class _Frame:
+    """The two columns the driver reads from the competition CSVs (`fname`, `labels`), file-backed or synthetic."""
 
+    def __init__(self, fname, labels=None):
+        self.fname = np.asarray(fname, dtype=object)
+        self.labels = None if labels is None else np.asarray(labels, dtype=object)
+
+    def __len__(self):
+        return len(self.fname)
+
+    def take(self, idx):
+        return _Frame(self.fname[idx], None if self.labels is None else self.labels[idx])
+
+
+def _read_frames(args):
+    """(train, test, noisy or None, class_map, loader transform, path joiner)."""
     if args.synthetic:
         class_map = {"class_%02d" % i: i for i in range(80)}
         n = int(args.synthetic_seconds * args.synthetic_sr)
         rng = np.random.RandomState(0)
-        files = ["synthetic:%d:%d:%d" % (i, n, args.synthetic_sr) for i in range(args.synthetic)]
-        labels = [["class_%02d" % rng.randint(80)] for _ in files]
-        loader_tf = SyntheticAudio()
-    else:
-        import pandas as pd
-        class_map = load_json(args.classmap)
-        df = pd.read_csv(args.train_df)
-        files = [os.path.join(args.train_data_dir, f) for f in df.fname.values]
-        labels = [item.split(",") for item in df.labels.values]
-        loader_tf = LoadAudio()
 
+        def names(count, base):
+            return ["synthetic:%d:%d:%d" % (base + i, n, args.synthetic_sr) for i in range(count)]
+
+        def lab():
+            picked = {"class_%02d" % rng.randint(80)}
+            if rng.uniform() < 0.3:
+                picked.add("class_%02d" % rng.randint(80))
+            return ",".join(sorted(picked))
+
+        train = _Frame(names(args.synthetic, 0), [lab() for _ in range(args.synthetic)])
+        n_test = args.synthetic // 4 if args.synthetic_test is None else args.synthetic_test
+        test = _Frame(names(max(1, n_test), 10 ** 6))
+        return train, test, None, class_map, SyntheticAudio(), (lambda d, f: f)
+    import pandas as pd
+    for flag in ("train_df", "train_data_dir", "test_data_dir", "sample_submission", "classmap"):
+        if getattr(args, flag) is None:
+            raise SystemExit("--%s is required (or pass --synthetic N)" % flag)
+    class_map = load_json(args.classmap)
+    tr = pd.read_csv(args.train_df)
+    te = pd.read_csv(args.sample_submission)
+    noisy = None
+    if args.noisy_train_df:
+        nz = pd.read_csv(args.noisy_train_df)
+        noisy = _Frame(nz.fname.values, nz.labels.values)
+    return _Frame(tr.fname.values, tr.labels.values), _Frame(te.fname.values), noisy, class_map, LoadAudio(), os.path.join
+
+
+def _split_labels(values):
+    return [item.split(",") for item in values]
+
+
+def main(model_cls=TwoDimensionalCNNClassificationModel, default_label="2d_cnn", argv=None):
+    args = build_parser(default_label).parse_args(argv)
+    torch.manual_seed(42)
+    if torch.cuda.is_available():
+        torch.cuda.manual_seed_all(42)
+    np.random.seed(42)
+    random.seed(42)
+    mag.use_custom_separator("-")
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        local = int(os.environ.get("LOCAL_RANK", "0"))
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        args.device = "cuda:%d" % local
+    if args.p_aug > 0:
+        raise NotImplementedError("--p_aug: the sox AudioAugmentation (pysndfx) is outside the accelerated path")
+    is_main = parallel.rank() == 0
+
+    train_df, test_df, noisy_df, class_map, loader_tf, join = _read_frames(args)
     audio_transform = AudioFeatures(args.features)
-    experiment = Experiment({
+    config = {
         "network": {"num_conv_blocks": args.num_conv_blocks, "start_deep_supervision_on": args.start_deep_supervision_on,
                     "conv_base_depth": args.conv_base_depth, "growth_rate": args.growth_rate,
                     "output_dropout": args.output_dropout, "aggregation_type": args.aggregation_type},
         "data": {"features": args.features, "_n_folds": args.n_folds, "_kfold_seed": args.kfold_seed,
-                 "_input_dim": audio_transform.n_features, "_n_classes": len(class_map), "p_mixup": args.p_mixup,
-                 "max_audio_length": args.max_audio_length},
+                 "_input_dim": audio_transform.n_features, "_n_classes": len(class_map),
+                 "_holdout_size": args.holdout_size, "p_mixup": args.p_mixup, "p_aug": args.p_aug,
+                 "max_audio_length": args.max_audio_length, "noisy": args.noisy_train_df is not None,
+                 "_train_df": args.train_df, "_train_data_dir": args.train_data_dir,
+                 "_noisy_train_df": args.noisy_train_df, "_noisy_train_data_dir": args.noisy_train_data_dir,
+                 "_share_noisy": args.share_noisy},
         "train": {"accumulation_steps": args.accumulation_steps, "batch_size": args.batch_size,
                   "learning_rate": args.lr, "scheduler": args.scheduler, "optimizer": args.optimizer,
                   "epochs": args.epochs, "_save_every": args.save_every, "weight_decay": args.weight_decay,
                   "switch_off_augmentations_on": args.switch_off_augmentations_on},
-        "label": args.label})
-    experiment.register_directory("checkpoints")
-    experiment.register_directory("predictions")
+        "label": args.label}
+    scores_by_fold = {}
+    with Experiment(config, implicit_resuming=args.resume or not is_main, experiments_dir=args.experiments_dir,
+                    write=is_main) as experiment:
+        if parallel.initialized():
+            dist.barrier()                    # the directory exists before the other ranks touch it
+        config = experiment.config
+        print("\n     ////// CONFIG //////")
+        print(experiment.config)
 
-    order = np.random.RandomState(args.kfold_seed).permutation(len(files))
-    fold_of = np.empty(len(files), int)
-    fold_of[order] = np.arange(len(files)) % args.n_folds
-    class_names = get_class_names_from_classmap(class_map)
-    collate = make_collate_fn({"signal": audio_transform.padding_value})
-    model_cls = TwoDimensionalCNNClassificationModel if args.model == "2d" else HierarchicalCNNClassificationModel
-    scores = {}
-    for fold in args.folds:
-        train_idx = np.flatnonzero(fold_of != fold)
-        valid_idx = np.flatnonzero(fold_of == fold)
-        lo, hi = parallel.shard_range(len(train_idx))          # contiguous shard per rank
-        train_idx = train_idx[lo:hi]
+        if args.max_samples:
+            rs = np.random.RandomState(0)
+            train_df = train_df.take(rs.permutation(len(train_df))[:args.max_samples])
+            test_df = test_df.take(rs.permutation(len(test_df))[:min(args.max_samples, len(test_df))])
+        holdout_df = None
+        if args.holdout_size:
+            from sklearn.model_selection import train_test_split
+            keep, holdout = train_test_split(np.arange(len(train_df)), test_size=args.holdout_size,
+                                             random_state=args.kfold_seed)
+            holdout_df, train_df = train_df.take(holdout), train_df.take(keep)
 
-        def subset(idx):
-            return [files[i] for i in idx], [labels[i] for i in idx]
+        splits = list(train_validation_data_stratified(
+            train_df.fname, train_df.labels, class_map, config.data._n_folds, config.data._kfold_seed))
+        noisy_splits = None
+        if noisy_df is not None:
+            noisy_splits = list(train_validation_data(noisy_df.fname, noisy_df.labels, config.data._n_folds,
+                                                      config.data._kfold_seed))
+        class_names = get_class_names_from_classmap(class_map)
+        collate = make_collate_fn({"signal": audio_transform.padding_value})
+        loader_kwargs = {"num_workers": args.num_workers, "pin_memory": True}
+        drop = DropFields(("audio", "filename", "sr"))
 
-        clean = Compose([loader_tf, SampleLongAudio(args.max_audio_length), MapLabels(class_map)])
-        train_tf = Compose([loader_tf, SampleLongAudio(args.max_audio_length), MapLabels(class_map), ShuffleAudio(p=0.5),
-                            MixUp(p=args.p_mixup), audio_transform, DropFields(("audio", "filename", "sr"))])
-        valid_tf = Compose([loader_tf, MapLabels(class_map), audio_transform, DropFields(("audio", "filename", "sr"))])
-        tf_files, tf_labels = subset(train_idx)
-        vf_files, vf_labels = subset(valid_idx)
-        train_loader = torch.utils.data.DataLoader(
-            SoundDataset(tf_files, tf_labels, transform=train_tf, clean_transform=clean),
-            shuffle=True, drop_last=True, batch_size=args.batch_size, collate_fn=collate,
-            num_workers=args.num_workers, pin_memory=True)
-        valid_loader = torch.utils.data.DataLoader(
-            SoundDataset(vf_files, vf_labels, transform=valid_tf), shuffle=False, batch_size=args.batch_size,
-            collate_fn=collate, num_workers=args.num_workers, pin_memory=True)
-        model = model_cls(experiment, device=args.device, loss=args.loss)
-        fold_scores = model.fit_validate(train_loader, valid_loader, epochs=args.epochs, fold=fold,
-                                         log_interval=args.log_interval)
-        scores[fold] = fold_scores
-        if parallel.rank() == 0:
-            experiment.register_result("fold{}.metric".format(fold), max(fold_scores))
-            torch.save(model.state_dict(), os.path.join(experiment.checkpoints, "fold_{}".format(fold), "final_model.pth"))
-            probs = model.predict(valid_loader)
-            truth = np.stack([valid_loader.dataset[i]["labels"] for i in range(len(valid_idx))])
-            print("fold", fold, "validation lwlrap of the final model: %.4f" % lwlrap(truth, probs))
+        def eval_loader(frame, data_dir, with_labels=True):
+            tf = [loader_tf] + ([MapLabels(class_map=class_map)] if with_labels else []) + [audio_transform, drop]
+            return torch.utils.data.DataLoader(
+                SoundDataset(audio_files=[join(data_dir, f) for f in frame.fname],
+                             labels=_split_labels(frame.labels) if with_labels else None, transform=Compose(tf)),
+                shuffle=False, batch_size=config.train.batch_size, collate_fn=collate, **loader_kwargs)
+
+        for fold in args.folds:
+            print("\n\n   -----  Fold {}\n".format(fold))
+            train, valid = splits[fold]
+            experiment.register_directory("checkpoints")
+            experiment.register_directory("predictions")
+            noisy_files, noisy_labels = [], []
+            if noisy_df is not None:
+                _, noisy_valid = noisy_splits[fold]
+                pick = noisy_df if config.data._share_noisy else noisy_df.take(noisy_valid)
+                noisy_files = [join(args.noisy_train_data_dir, f) for f in pick.fname]
+                noisy_labels = _split_labels(pick.labels)
+            # Data parallelism: equally long contiguous shards of the fold's clean training rows, so that every rank
+            # builds the same number of batches (drop_last) and issues the same number of all-reduces per epoch.
+            world = parallel.world_size()
+            if world > 1:
+                per_rank = len(train) // world
+                lo = parallel.rank() * per_rank
+                train = train[lo:lo + per_rank]
+            files = [join(args.train_data_dir, f) for f in train_df.fname[train]] + noisy_files
+            labels = _split_labels(train_df.labels[train]) + noisy_labels
+            clean_tf = [loader_tf, SampleLongAudio(max_length=args.max_audio_length), MapLabels(class_map=class_map)]
+            train_loader = torch.utils.data.DataLoader(
+                SoundDataset(
+                    audio_files=files, labels=labels, is_noisy=[0] * len(train) + [1] * len(noisy_labels),
+                    transform=Compose(clean_tf + [
+                        ShuffleAudio(chunk_length=0.5, p=0.5) if config.network.aggregation_type != "rnn" else Identity(),
+                        MixUp(p=args.p_mixup), audio_transform, drop]),
+                    clean_transform=Compose(list(clean_tf))),
+                shuffle=True, drop_last=True, batch_size=config.train.batch_size, collate_fn=collate, **loader_kwargs)
+            if world > 1:
+                steps = torch.tensor([len(train_loader)], device=args.device)
+                lo_hi = [steps.clone(), steps.clone()]
+                dist.all_reduce(lo_hi[0], op=dist.ReduceOp.MIN)
+                dist.all_reduce(lo_hi[1], op=dist.ReduceOp.MAX)
+                assert int(lo_hi[0]) == int(lo_hi[1]), "ranks disagree on the number of steps per epoch"
+            valid_loader = eval_loader(train_df.take(valid), args.train_data_dir)
+
+            model = model_cls(experiment, device=args.device, loss=args.loss)
+            scores = model.fit_validate(train_loader, valid_loader, epochs=experiment.config.train.epochs, fold=fold,
+                                        log_interval=args.log_interval)
+            scores_by_fold[fold] = scores
+            best_metric = max(scores)
+            fold_dir = os.path.join(experiment.checkpoints, "fold_{}".format(fold))
+            if is_main:
+                experiment.register_result("fold{}.metric".format(fold), best_metric)
+                torch.save(model.state_dict(), os.path.join(fold_dir, "final_model.pth"))
+            if parallel.initialized():
+                dist.barrier()                # best_model.pth is on disk before anyone loads it
+            # predictions (every rank computes them -- the loaders are not sharded -- rank 0 writes)
+            model.load_best_model(fold)
             import pandas as pd
-            out = pd.DataFrame(probs, columns=class_names)
-            out["fname"] = vf_files
-            out.to_csv(os.path.join(experiment.predictions, "val_preds_fold_{}.csv".format(fold)), index=False)
+            val_preds = model.predict(valid_loader)
+            test_preds = model.predict(eval_loader(test_df, args.test_data_dir, with_labels=False))
+            if is_main:
+                out = pd.DataFrame(val_preds, columns=class_names)
+                out["fname"] = train_df.fname[valid]
+                out.to_csv(os.path.join(experiment.predictions, "val_preds_fold_{}.csv".format(fold)), index=False)
+                out = pd.DataFrame(test_preds, columns=class_names)
+                out["fname"] = test_df.fname
+                out.to_csv(os.path.join(experiment.predictions, "test_preds_fold_{}.csv".format(fold)), index=False)
+            if holdout_df is not None:
+                holdout_metric = model.evaluate(eval_loader(holdout_df, args.train_data_dir))
+                if is_main:
+                    experiment.register_result("fold{}.holdout_metric".format(fold), holdout_metric)
+                print("\nHoldout metric: {:.4f}".format(holdout_metric))
+            del model
+            torch.cuda.empty_cache()
+
+        if is_main:
+            import pandas as pd
+            results = experiment.results.to_dict()
+            if all("fold{}".format(k) in results for k in range(config.data._n_folds)):      # global metric
+                frames = [pd.read_csv(os.path.join(experiment.predictions, "val_preds_fold_{}.csv".format(k)))
+                          for k in range(config.data._n_folds)]
+                val_predictions_df = pd.concat(frames).reset_index(drop=True)
+                hot = np.zeros((len(train_df), len(class_map)), np.float32)
+                for row, names in enumerate(_split_labels(train_df.labels)):
+                    for name in names:
+                        hot[row, class_map[name]] = 1.0
+                val_labels_df = pd.DataFrame(hot, columns=class_names)
+                val_labels_df["fname"] = train_df.fname
+                assert set(val_predictions_df.fname) == set(val_labels_df.fname)
+                val_predictions_df.sort_values(by="fname", inplace=True)
+                val_labels_df.sort_values(by="fname", inplace=True)
+                metric = lwlrap(val_labels_df.drop("fname", axis=1).values,
+                                val_predictions_df.drop("fname", axis=1).values)
+                experiment.register_result("metric", metric)
+                print("\nOut-of-fold lwlrap: {:.4f}".format(metric))
+            test_files = [os.path.join(experiment.predictions, "test_preds_fold_{}.csv".format(k))
+                          for k in range(config.data._n_folds)]
+            if all(os.path.isfile(f) for f in test_files):                                 # submission
+                test_dfs = [pd.read_csv(f) for f in test_files]
+                submission_df = pd.DataFrame({"fname": test_dfs[0].fname.values})
+                for c in class_names:
+                    submission_df[c] = np.mean([d[c].values for d in test_dfs], axis=0)
+                submission_df.to_csv(os.path.join(experiment.predictions, "submission.csv"), index=False)
     if dist.is_available() and dist.is_initialized():
         dist.destroy_process_group()
-    return scores
+    return experiment, scores_by_fold
 
 
 if __name__ == "__main__":
