@@ -115,19 +115,36 @@ __global__ void stats_rows_kernel(const float* __restrict__ x, int n, int c, dou
     o[1] = s2;
 }
 
+// Cross-replica statistics (SyncBN): `sync` holds per channel [sum x, sum x^2, count, -] about ZERO in
+// fp64.  phase 1 stops after writing the local moments there; the caller sum-all-reduces the buffer; phase 2
+// finalises from it.  phase 0 is the single-replica path (local pivot-shifted sums, no detour through `sync`).
 __global__ void stats_finalize_kernel(const float* __restrict__ x, int c, long hw, double count, int nsplit,
                                       const double* __restrict__ part, const float* __restrict__ gamma,
                                       const float* __restrict__ beta, float eps, float momentum,
                                       float* running_mean, float* running_var, float* save_mean,
-                                      float* save_invstd, float* scale, float* shift) {
+                                      float* save_invstd, float* scale, float* shift, double* __restrict__ sync,
+                                      int phase) {
     const int ch = blockIdx.x * blockDim.x + threadIdx.x;
     if (ch >= c) return;
-    double s1 = 0.0, s2 = 0.0;
-    for (int s = 0; s < nsplit; ++s) {
-        s1 += part[((size_t)ch * kMaxSplit + s) * 4];
-        s2 += part[((size_t)ch * kMaxSplit + s) * 4 + 1];
+    double s1 = 0.0, s2 = 0.0, pivot = 0.0;
+    if (phase == 2) {
+        s1 = sync[ch * 4];
+        s2 = sync[ch * 4 + 1];
+        count = sync[ch * 4 + 2];
+    } else {
+        for (int s = 0; s < nsplit; ++s) {
+            s1 += part[((size_t)ch * kMaxSplit + s) * 4];
+            s2 += part[((size_t)ch * kMaxSplit + s) * 4 + 1];
+        }
+        pivot = (double)x[(long)ch * hw];
+        if (phase == 1) {                                  // moments about zero: sum (a + p) and sum (a + p)^2
+            sync[ch * 4] = s1 + count * pivot;
+            sync[ch * 4 + 1] = s2 + 2.0 * pivot * s1 + count * pivot * pivot;
+            sync[ch * 4 + 2] = count;
+            sync[ch * 4 + 3] = 0.0;
+            return;
+        }
     }
-    const double pivot = (double)x[(long)ch * hw];
     const double m1 = s1 / count;
     const double mean = pivot + m1;
     double var = s2 / count - m1 * m1;
@@ -303,7 +320,7 @@ __global__ __launch_bounds__(kThreads) void bwd_partial_kernel(BwdArgs a, int ns
                     const float dz = neg ? al * us[e] : us[e];
                     s0 += dz;
                     s1 += dz * xh;
-                    if (neg) s2 += us[e] * z;
+                    s2 += us[e] * (neg ? z : 0.f);
                 }
             }
             continue;
@@ -317,7 +334,7 @@ __global__ __launch_bounds__(kThreads) void bwd_partial_kernel(BwdArgs a, int ns
             const float dz = neg ? al * up : up;
             s0 += dz;
             s1 += dz * xh;
-            if (neg) s2 += up * z;
+            s2 += up * (neg ? z : 0.f);
         }
     }
     const double t0 = fsc::block_sum<double, kThreads / 64>((double)s0, scratch);
@@ -347,27 +364,43 @@ __global__ void bwd_rows_kernel(BwdArgs a, double* __restrict__ part) {
         const bool neg = has_alpha && !(z > 0.f);
         const float dz = neg ? al * up : up;
         s0 += dz; s1 += (double)dz * xh;
-        if (neg) s2 += (double)up * z;
+        s2 += (double)up * (neg ? z : 0.f);
     }
     double* o = part + (size_t)ch * kMaxSplit * 4;
     o[0] = s0; o[1] = s1; o[2] = s2;
 }
 
+// SyncBN: phase 1 writes the parameter gradients (LOCAL sums: the gradient all-reduce adds the replicas later) and
+// [sum dz, sum dz*xhat, count, -] into `sync`, then stops; phase 2 takes the all-reduced `sync` for the two means
+// the input gradient needs.  phase 0: single replica.
 __global__ void bwd_finalize_kernel(int c, double count, int nsplit, const double* __restrict__ part,
                                     float* dgamma, float* dbeta, float* dalpha, float* coef, float* dx_chan_sum,
-                                    float* dx_amax) {
+                                    float* dx_amax, double* __restrict__ sync, int phase) {
     const int ch = blockIdx.x * blockDim.x + threadIdx.x;
-    if (dx_amax)
+    if (dx_amax && phase != 1)
         for (int i = ch; i < fsc::kAmaxFloats; i += gridDim.x * blockDim.x) dx_amax[i] = 0.f;
     if (ch >= c) return;
     double s0 = 0.0, s1 = 0.0, s2 = 0.0;
-    for (int s = 0; s < nsplit; ++s) {
-        const double* p = part + ((size_t)ch * kMaxSplit + s) * 4;
-        s0 += p[0]; s1 += p[1]; s2 += p[2];
+    if (phase == 2) {
+        s0 = sync[ch * 4];
+        s1 = sync[ch * 4 + 1];
+        count = sync[ch * 4 + 2];
+    } else {
+        for (int s = 0; s < nsplit; ++s) {
+            const double* p = part + ((size_t)ch * kMaxSplit + s) * 4;
+            s0 += p[0]; s1 += p[1]; s2 += p[2];
+        }
+        if (dbeta) dbeta[ch] = (float)s0;
+        if (dgamma) dgamma[ch] = (float)s1;
+        if (dalpha) dalpha[ch] = (float)s2;
+        if (phase == 1) {
+            sync[ch * 4] = s0;
+            sync[ch * 4 + 1] = s1;
+            sync[ch * 4 + 2] = count;
+            sync[ch * 4 + 3] = 0.0;
+            return;
+        }
     }
-    if (dbeta) dbeta[ch] = (float)s0;
-    if (dgamma) dgamma[ch] = (float)s1;
-    if (dalpha) dalpha[ch] = (float)s2;
     coef[ch * 2] = (float)(s0 / count);
     coef[ch * 2 + 1] = (float)(s1 / count);
     if (dx_chan_sum) dx_chan_sum[ch] = 0.f;
@@ -596,23 +629,27 @@ size_t fsc_bn_workspace_bytes(int c) {
 
 int fsc_bn_train_stats(const float* x, int n, int c, long hw, const float* gamma, const float* beta, float eps,
                        float momentum, float* running_mean, float* running_var, float* save_mean,
-                       float* save_invstd, float* scale, float* shift, void* workspace, fsc_stream_t stream) {
+                       float* save_invstd, float* scale, float* shift, void* workspace, double* sync, int phase,
+                       fsc_stream_t stream) {
     FSC_CHECK_ARG(x && save_mean && save_invstd && scale && shift && workspace, "fsc_bn_train_stats: null pointer");
+    FSC_CHECK_ARG(phase == 0 || ((phase == 1 || phase == 2) && sync), "fsc_bn_train_stats: phase 1 / 2 need `sync`");
     FSC_CHECK_ARG(n > 0 && c > 0 && hw > 0, "fsc_bn_train_stats: bad shape (%d, %d, %ld)", n, c, hw);
     FSC_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr), "fsc_bn_train_stats: running stats must come in pairs");
     hipStream_t st = fsc::as_stream(stream);
     Partials p = carve(workspace, c);
     int nsplit = 1;
-    if (hw == 1) {
-        hipLaunchKernelGGL(stats_rows_kernel, dim3(fsc::ceil_div(c, 128)), dim3(128), 0, st, x, n, c, p.part);
-    } else {
-        nsplit = pick_split(n, c, hw);
-        hipLaunchKernelGGL(stats_partial_kernel, dim3(c, nsplit), dim3(kThreads), 0, st, x, n, c, hw, nsplit,
-                           hwp_log2_for(hw), p.part);
+    if (phase != 2) {
+        if (hw == 1) {
+            hipLaunchKernelGGL(stats_rows_kernel, dim3(fsc::ceil_div(c, 128)), dim3(128), 0, st, x, n, c, p.part);
+        } else {
+            nsplit = pick_split(n, c, hw);
+            hipLaunchKernelGGL(stats_partial_kernel, dim3(c, nsplit), dim3(kThreads), 0, st, x, n, c, hw, nsplit,
+                               hwp_log2_for(hw), p.part);
+        }
     }
     hipLaunchKernelGGL(stats_finalize_kernel, dim3(fsc::ceil_div(c, 128)), dim3(128), 0, st, x, c, hw,
                        (double)n * (double)hw, nsplit, p.part, gamma, beta, eps, momentum, running_mean,
-                       running_var, save_mean, save_invstd, scale, shift);
+                       running_var, save_mean, save_invstd, scale, shift, sync, phase);
     FSC_LAUNCH_CHECK("fsc_bn_train_stats");
     return 0;
 }
@@ -657,8 +694,9 @@ int fsc_bn_act_bwd(const float* dy, const float* gmax_dy, const int* gmax_idx, c
                    const float* residual, const float* save_mean, const float* save_invstd,
                    const float* gamma, const float* beta, const float* alpha, float* dx, float* dresidual,
                    float* dgamma, float* dbeta, float* dalpha, float* dx_chan_sum, int n, int c, long hw,
-                   void* workspace, float* dx_amax, fsc_stream_t stream) {
+                   void* workspace, float* dx_amax, double* sync, int phase, fsc_stream_t stream) {
     FSC_CHECK_ARG(x && save_mean && save_invstd && dx && workspace, "fsc_bn_act_bwd: null pointer");
+    FSC_CHECK_ARG(phase == 0 || ((phase == 1 || phase == 2) && sync), "fsc_bn_act_bwd: phase 1 / 2 need `sync`");
     FSC_CHECK_ARG(dy || gmax_dy, "fsc_bn_act_bwd: no upstream gradient");
     FSC_CHECK_ARG((gmax_dy == nullptr) == (gmax_idx == nullptr), "fsc_bn_act_bwd: gmax_dy / gmax_idx must come in pairs");
     FSC_CHECK_ARG(n > 0 && c > 0 && hw > 0, "fsc_bn_act_bwd: bad shape (%d, %d, %ld)", n, c, hw);
@@ -667,15 +705,21 @@ int fsc_bn_act_bwd(const float* dy, const float* gmax_dy, const int* gmax_idx, c
     Partials p = carve(workspace, c);
     BwdArgs a{dy, gmax_dy, gmax_idx, x, residual, save_mean, save_invstd, gamma, beta, alpha, n, c, hw};
     int nsplit = 1;
-    if (hw == 1) {
-        FSC_CHECK_ARG(gmax_dy == nullptr, "fsc_bn_act_bwd: global-max gradient needs hw > 1");
-        hipLaunchKernelGGL(bwd_rows_kernel, dim3(fsc::ceil_div(c, 128)), dim3(128), 0, st, a, p.part);
-    } else {
-        nsplit = pick_split(n, c, hw);
-        hipLaunchKernelGGL(bwd_partial_kernel, dim3(c, nsplit), dim3(kThreads), 0, st, a, nsplit, hwp_log2_for(hw), p.part);
+    if (phase != 2) {
+        if (hw == 1) {
+            FSC_CHECK_ARG(gmax_dy == nullptr, "fsc_bn_act_bwd: global-max gradient needs hw > 1");
+            hipLaunchKernelGGL(bwd_rows_kernel, dim3(fsc::ceil_div(c, 128)), dim3(128), 0, st, a, p.part);
+        } else {
+            nsplit = pick_split(n, c, hw);
+            hipLaunchKernelGGL(bwd_partial_kernel, dim3(c, nsplit), dim3(kThreads), 0, st, a, nsplit, hwp_log2_for(hw), p.part);
+        }
     }
     hipLaunchKernelGGL(bwd_finalize_kernel, dim3(fsc::ceil_div(c, 128)), dim3(128), 0, st, c, (double)n * (double)hw,
-                       nsplit, p.part, dgamma, dbeta, dalpha, p.coef, dx_chan_sum, dx_amax);
+                       nsplit, p.part, dgamma, dbeta, dalpha, p.coef, dx_chan_sum, dx_amax, sync, phase);
+    if (phase == 1) {
+        FSC_LAUNCH_CHECK("fsc_bn_act_bwd");
+        return 0;
+    }
     const long total = (long)n * c * hw;
     if (hw >= 512) {
         hipLaunchKernelGGL(bwd_apply_plane_kernel, dim3((unsigned)((long)n * c), plane_grid_y(hw)), dim3(kThreads), 0,
@@ -697,8 +741,10 @@ int fsc_bn_act_bwd(const float* dy, const float* gmax_dy, const int* gmax_idx, c
 int fsc_bn_act_bwd_unpool(const float* dy, const float* x, const float* save_mean, const float* save_invstd,
                           const float* gamma, const float* beta, const float* alpha, const uint8_t* pool_idx,
                           float* dc, float* dgamma, float* dbeta, float* dalpha, float* dx_chan_sum, int n, int c,
-                          int h, int w, int ph, void* workspace, float* dc_amax, fsc_stream_t stream) {
+                          int h, int w, int ph, void* workspace, float* dc_amax, double* sync, int phase,
+                          fsc_stream_t stream) {
     FSC_CHECK_ARG(dy && x && save_mean && save_invstd && pool_idx && dc && workspace, "fsc_bn_act_bwd_unpool: null pointer");
+    FSC_CHECK_ARG(phase == 0 || ((phase == 1 || phase == 2) && sync), "fsc_bn_act_bwd_unpool: phase 1 / 2 need `sync`");
     FSC_CHECK_ARG((ph == 1 || ph == 2) && n > 0 && c > 0 && h >= ph && w >= 2, "fsc_bn_act_bwd_unpool: bad shape");
     const int oh = h / ph, ow = w / 2;
     const long hw = (long)oh * ow;
@@ -706,9 +752,14 @@ int fsc_bn_act_bwd_unpool(const float* dy, const float* x, const float* save_mea
     Partials p = carve(workspace, c);
     BwdArgs a{dy, nullptr, nullptr, x, nullptr, save_mean, save_invstd, gamma, beta, alpha, n, c, hw};
     const int nsplit = pick_split(n, c, hw);
-    hipLaunchKernelGGL(bwd_partial_kernel, dim3(c, nsplit), dim3(kThreads), 0, st, a, nsplit, hwp_log2_for(hw), p.part);
+    if (phase != 2)
+        hipLaunchKernelGGL(bwd_partial_kernel, dim3(c, nsplit), dim3(kThreads), 0, st, a, nsplit, hwp_log2_for(hw), p.part);
     hipLaunchKernelGGL(bwd_finalize_kernel, dim3(fsc::ceil_div(c, 128)), dim3(128), 0, st, c, (double)n * (double)hw,
-                       nsplit, p.part, dgamma, dbeta, dalpha, p.coef, dx_chan_sum, dc_amax);
+                       nsplit, p.part, dgamma, dbeta, dalpha, p.coef, dx_chan_sum, dc_amax, sync, phase);
+    if (phase == 1) {
+        FSC_LAUNCH_CHECK("fsc_bn_act_bwd_unpool");
+        return 0;
+    }
     int cl = 0;
     while ((1 << cl) < ow && cl < 8) ++cl;
     const int per_block = kThreads >> cl;

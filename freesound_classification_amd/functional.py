@@ -312,9 +312,14 @@ class BNState:
     __slots__ = ("mean", "invstd", "scale", "shift")
 
 
-def bn_prepare(x, bn, training):
+def _sync_buffer(c, like):
+    return torch.empty(4 * c, device=like.device, dtype=torch.float64)      # FSC_BN_SYNC_DOUBLES(c)
+
+
+def bn_prepare(x, bn, training, sync=None):
     """Batch statistics (training; also updates the running stats, once) or running statistics
-    (eval) -> per-channel scale/shift."""
+    (eval) -> per-channel scale/shift.  `sync` (a callable that sum-all-reduces a device tensor in place over the
+    data-parallel replicas, see parallel.SyncBN) turns the batch statistics into cross-replica statistics."""
     n, c = x.shape[0], x.shape[1]
     hw = x.numel() // (n * c)
     st = BNState()
@@ -330,9 +335,16 @@ def bn_prepare(x, bn, training):
             bn.num_batches_tracked.add_(1)
             if bn.momentum is None:
                 momentum = 1.0 / float(bn.num_batches_tracked)
-        call("fsc_bn_train_stats", ptr(x), n, c, hw, ptr(gamma), ptr(beta), bn.eps, momentum,
-             ptr(bn.running_mean) if track else None, ptr(bn.running_var) if track else None,
-             ptr(st.mean), ptr(st.invstd), ptr(st.scale), ptr(st.shift), ptr(_bn_ws(c, x)), stream_ptr())
+        args = (ptr(x), n, c, hw, ptr(gamma), ptr(beta), bn.eps, momentum,
+                ptr(bn.running_mean) if track else None, ptr(bn.running_var) if track else None,
+                ptr(st.mean), ptr(st.invstd), ptr(st.scale), ptr(st.shift), ptr(_bn_ws(c, x)))
+        if sync is None:
+            call("fsc_bn_train_stats", *args, None, 0, stream_ptr())
+        else:
+            moments = _sync_buffer(c, x)                   # [sum x, sum x^2, count, 0] per channel, fp64
+            call("fsc_bn_train_stats", *args, ptr(moments), 1, stream_ptr())
+            sync(moments)
+            call("fsc_bn_train_stats", *args, ptr(moments), 2, stream_ptr())
     else:
         st.mean = None
         st.invstd = None
@@ -358,7 +370,7 @@ def bn_act_forward(x, st, alpha=None, residual=None, with_amax=False):
 
 
 def bn_act_backward(dy, x, st, bn, alpha=None, residual=None, gmax=None, want_dx=True,
-                    want_dres=False, want_chan_sum=False, with_amax=False):
+                    want_dres=False, want_chan_sum=False, with_amax=False, sync=None):
     """Returns (dx, dresidual, dgamma, dbeta, dalpha, dx_chan_sum) [+ (max |dx|,) with with_amax]."""
     n, c = x.shape[0], x.shape[1]
     hw = x.numel() // (n * c)
@@ -370,15 +382,22 @@ def bn_act_backward(dy, x, st, bn, alpha=None, residual=None, gmax=None, want_dx
     csum = _empty((c,), x) if want_chan_sum else None
     gdy, gidx = gmax if gmax is not None else (None, None)
     dx_amax = _empty((AMAX_FLOATS,), x) if with_amax and _want_amax() else None
-    call("fsc_bn_act_bwd", ptr(dy), ptr(gdy), ptr(gidx), ptr(x), ptr(residual), ptr(st.mean),
-         ptr(st.invstd), ptr(bn.weight), ptr(bn.bias), ptr(alpha), ptr(dx), ptr(dres), ptr(dgamma),
-         ptr(dbeta), ptr(dalpha), ptr(csum), n, c, hw, ptr(_bn_ws(c, x)), ptr(dx_amax), stream_ptr())
+    args = (ptr(dy), ptr(gdy), ptr(gidx), ptr(x), ptr(residual), ptr(st.mean),
+            ptr(st.invstd), ptr(bn.weight), ptr(bn.bias), ptr(alpha), ptr(dx), ptr(dres), ptr(dgamma),
+            ptr(dbeta), ptr(dalpha), ptr(csum), n, c, hw, ptr(_bn_ws(c, x)), ptr(dx_amax))
+    if sync is None:
+        call("fsc_bn_act_bwd", *args, None, 0, stream_ptr())
+    else:
+        sums = _sync_buffer(c, x)                          # [sum dz, sum dz * xhat, count, 0] per channel
+        call("fsc_bn_act_bwd", *args, ptr(sums), 1, stream_ptr())
+        sync(sums)
+        call("fsc_bn_act_bwd", *args, ptr(sums), 2, stream_ptr())
     if with_amax:
         return dx, dres, dgamma, dbeta, dalpha, csum, dx_amax
     return dx, dres, dgamma, dbeta, dalpha, csum
 
 
-def bn_act_backward_unpool(dy, x, st, bn, alpha, pool_idx, c_shape, ph):
+def bn_act_backward_unpool(dy, x, st, bn, alpha, pool_idx, c_shape, ph, sync=None):
     """Backward of BN+PReLU on a pooled tensor fused with the max-pool backward.
     Returns (dc at the un-pooled shape, dgamma, dbeta, dalpha, per-channel sum of the gradient, max |dc| or None)."""
     n, c, h, w = c_shape
@@ -388,9 +407,16 @@ def bn_act_backward_unpool(dy, x, st, bn, alpha, pool_idx, c_shape, ph):
     dalpha = _empty((c,), x) if alpha is not None else None
     csum = _empty((c,), x)
     dc_amax = _empty((AMAX_FLOATS,), x) if _want_amax() else None
-    call("fsc_bn_act_bwd_unpool", ptr(dy), ptr(x), ptr(st.mean), ptr(st.invstd), ptr(bn.weight), ptr(bn.bias),
-         ptr(alpha), ptr(pool_idx), ptr(dc), ptr(dgamma), ptr(dbeta), ptr(dalpha), ptr(csum), n, c, h, w, ph,
-         ptr(_bn_ws(c, x)), ptr(dc_amax), stream_ptr())
+    args = (ptr(dy), ptr(x), ptr(st.mean), ptr(st.invstd), ptr(bn.weight), ptr(bn.bias),
+            ptr(alpha), ptr(pool_idx), ptr(dc), ptr(dgamma), ptr(dbeta), ptr(dalpha), ptr(csum), n, c, h, w, ph,
+            ptr(_bn_ws(c, x)), ptr(dc_amax))
+    if sync is None:
+        call("fsc_bn_act_bwd_unpool", *args, None, 0, stream_ptr())
+    else:
+        sums = _sync_buffer(c, x)
+        call("fsc_bn_act_bwd_unpool", *args, ptr(sums), 1, stream_ptr())
+        sync(sums)
+        call("fsc_bn_act_bwd_unpool", *args, ptr(sums), 2, stream_ptr())
     return dc, dgamma, dbeta, dalpha, csum, dc_amax
 
 
@@ -432,13 +458,13 @@ class _BlockCtx:
     pass
 
 
-def _block_forward(x, mods, training, want_head, ph, keep):
+def _block_forward(x, mods, training, want_head, ph, keep, sync=None):
     """BN -> conv3 -> maxpool -> BN+PReLU -> residual unit (-> global max).  `mods` is the
     reference's nn.Sequential of parameter holders.  Returns (out, feat, ctx)."""
     bn_a, conv_a, _pool, bn_b, prelu_b, res = mods[0], mods[1], mods[2], mods[3], mods[4], mods[5]
     k = _BlockCtx()
     k.x_shape = tuple(x.shape)
-    st_a = bn_prepare(x, bn_a, training)
+    st_a = bn_prepare(x, bn_a, training, sync)
     a, a_max = bn_act_forward(x, st_a, with_amax=True)
     w_a, b_a = _conv_params(conv_a)
     fused = conv_pool_forward(a, w_a, b_a) if ph == 2 else None
@@ -449,19 +475,19 @@ def _block_forward(x, mods, training, want_head, ph, keep):
         p, pidx = maxpool_forward(c, ph)
         k.c_shape = tuple(c.shape)
         del c
-    st_b = bn_prepare(p, bn_b, training)
+    st_b = bn_prepare(p, bn_b, training, sync)
     b, b_max = bn_act_forward(p, st_b, prelu_b.weight, with_amax=True)
     w1, b1 = _conv_params(res.conv1)
     r1 = conv_forward(b, w1, b1, x_amax=b_max)
-    st1 = bn_prepare(r1, res.bn1, training)
+    st1 = bn_prepare(r1, res.bn1, training, sync)
     s1, s1_max = bn_act_forward(r1, st1, res.prelu1.weight, with_amax=True)
     w2, b2 = _conv_params(res.conv2)
     r2 = conv_forward(s1, w2, b2, x_amax=s1_max)
-    st2 = bn_prepare(r2, res.bn2, training)
+    st2 = bn_prepare(r2, res.bn2, training, sync)
     s2, s2_max = bn_act_forward(r2, st2, res.prelu2.weight, with_amax=True)
     w3, b3 = _conv_params(res.conv3)
     r3 = conv_forward(s2, w3, b3, x_amax=s2_max)
-    st3 = bn_prepare(r3, res.bn3, training)
+    st3 = bn_prepare(r3, res.bn3, training, sync)
     out = bn_act_forward(r3, st3, res.prelu3.weight, residual=b)
     feat, fidx = (None, None)
     if want_head:
@@ -490,13 +516,14 @@ class ConvBlockFn(torch.autograd.Function):
     (:589-591) as a single autograd node with a hand-written backward."""
 
     @staticmethod
-    def forward(ctx, x, mods, training, want_head, ph, *params):
+    def forward(ctx, x, mods, training, want_head, ph, sync, *params):
         keep = any(ctx.needs_input_grad)
         if keep and not training:
             raise _lib.FscError("conv_block: gradients in eval mode (BatchNorm on running statistics) are not on the "
                                 "accelerated path; call model.train() or wrap the forward in torch.no_grad()")
-        out, feat, k = _block_forward(x, mods, training, want_head, ph, keep)
+        out, feat, k = _block_forward(x, mods, training, want_head, ph, keep, sync)
         ctx.k = k
+        ctx.sync = sync
         ctx.mods = mods
         ctx.ph = ph
         ctx.want_head = want_head
@@ -510,7 +537,7 @@ class ConvBlockFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, d_out, d_feat):
-        k, mods, ph = ctx.k, ctx.mods, ctx.ph
+        k, mods, ph, sync = ctx.k, ctx.mods, ctx.ph, ctx.sync
         if k is None:
             raise RuntimeError("ConvBlockFn: backward through the block a second time -- its saved activations are "
                                "freed after the first backward (retain_graph is not supported on this path)")
@@ -526,20 +553,20 @@ class ConvBlockFn(torch.autograd.Function):
         a_max, b_max, s1_max, s2_max = k.amax
         dr3, db, dg3, dbt3, dal3, dbias3, dr3_max = bn_act_backward(
             d_out, k.r3, k.st3, res.bn3, res.prelu3.weight, residual=k.b, gmax=gmax,
-            want_dres=True, want_chan_sum=True, with_amax=True)
+            want_dres=True, want_chan_sum=True, with_amax=True, sync=sync)
         w3, _ = _conv_params(res.conv3)
         dw3 = conv_wgrad(k.s2, dr3, w3.shape, True, x_amax=s2_max, dout_amax=dr3_max)
         ds2 = conv_dgrad(dr3, w3, k.s2.shape, dout_amax=dr3_max)
         del dr3
         dr2, _, dg2, dbt2, dal2, dbias2, dr2_max = bn_act_backward(ds2, k.r2, k.st2, res.bn2, res.prelu2.weight,
-                                                                   want_chan_sum=True, with_amax=True)
+                                                                   want_chan_sum=True, with_amax=True, sync=sync)
         del ds2
         w2, _ = _conv_params(res.conv2)
         dw2 = conv_wgrad(k.s1, dr2, w2.shape, True, x_amax=s1_max, dout_amax=dr2_max)
         ds1 = conv_dgrad(dr2, w2, k.s1.shape, dout_amax=dr2_max)
         del dr2
         dr1, _, dg1, dbt1, dal1, dbias1, dr1_max = bn_act_backward(ds1, k.r1, k.st1, res.bn1, res.prelu1.weight,
-                                                                   want_chan_sum=True, with_amax=True)
+                                                                   want_chan_sum=True, with_amax=True, sync=sync)
         del ds1
         w1, _ = _conv_params(res.conv1)
         dw1 = conv_wgrad(k.b, dr1, w1.shape, True, x_amax=b_max, dout_amax=dr1_max)
@@ -547,13 +574,13 @@ class ConvBlockFn(torch.autograd.Function):
         del dr1
         # ---- b = prelu(bn_b(p))
         dc, dgb, dbtb, dalb, dbias_a, dc_max = bn_act_backward_unpool(db.contiguous(), k.p, k.st_b, bn_b, prelu_b.weight,
-                                                                      k.pidx, k.c_shape, ph)
+                                                                      k.pidx, k.c_shape, ph, sync=sync)
         del db
         wa, _ = _conv_params(conv_a)
         dwa = conv_wgrad(k.a, dc, wa.shape, True, x_amax=a_max, dout_amax=dc_max)
         da = conv_dgrad(dc, wa, k.a.shape, dout_amax=dc_max)
         del dc
-        dx, _, dga, dbta, _, _ = bn_act_backward(da, k.x, k.st_a, bn_a)
+        dx, _, dga, dbta, _, _ = bn_act_backward(da, k.x, k.st_a, bn_a, sync=sync)
         if not ctx.x_needs_grad:
             dx = None
 
@@ -566,17 +593,19 @@ class ConvBlockFn(torch.autograd.Function):
                  like(res.conv2.weight, dw2), dbias2, dg2, dbt2, dal2,
                  like(res.conv3.weight, dw3), dbias3, dg3, dbt3, dal3]
         ctx.k = None
-        return (dx, None, None, None, None) + tuple(grads)
+        return (dx, None, None, None, None, None) + tuple(grads)
 
 
-def conv_block(x, mods, training, want_head, ph):
-    """Differentiable block call.  Returns (out, feat or None)."""
+def conv_block(x, mods, training, want_head, ph, sync=None):
+    """Differentiable block call.  Returns (out, feat or None).  `sync`: cross-replica BN statistics (bn_prepare)."""
     _need_cuda(x, "conv_block")
     x = x.contiguous()
+    if not training:
+        sync = None
     if torch.is_grad_enabled() and any(p.requires_grad for p in _block_params(mods)):
-        out, feat = ConvBlockFn.apply(x, mods, training, want_head, ph, *_block_params(mods))
+        out, feat = ConvBlockFn.apply(x, mods, training, want_head, ph, sync, *_block_params(mods))
     else:
-        out, feat, _ = _block_forward(x, mods, training, want_head, ph, keep=False)
+        out, feat, _ = _block_forward(x, mods, training, want_head, ph, keep=False, sync=sync)
     return out, (feat if want_head else None)
 
 
@@ -585,12 +614,12 @@ class BNActFn(torch.autograd.Function):
     """BatchNorm1d (+ PReLU) on (N, C) features (classifiers.py:543-546)."""
 
     @staticmethod
-    def forward(ctx, x, bn, prelu, training, gamma, beta, alpha):
+    def forward(ctx, x, bn, prelu, training, sync, gamma, beta, alpha):
         x = x.contiguous()
-        st = bn_prepare(x, bn, training)
+        st = bn_prepare(x, bn, training, sync if training else None)
         y = bn_act_forward(x, st, alpha)
         ctx.save_for_backward(x)
-        ctx.st, ctx.bn, ctx.prelu = st, bn, prelu
+        ctx.st, ctx.bn, ctx.prelu, ctx.sync = st, bn, prelu, (sync if training else None)
         return y
 
     @staticmethod
@@ -600,13 +629,13 @@ class BNActFn(torch.autograd.Function):
         if st.mean is None:
             raise _lib.FscError("BNActFn.backward in eval mode is not supported")
         alpha = ctx.prelu.weight if ctx.prelu is not None else None
-        dx, _, dg, db, dal, _ = bn_act_backward(dy.contiguous(), x, st, ctx.bn, alpha)
-        return dx, None, None, None, dg, db, dal
+        dx, _, dg, db, dal, _ = bn_act_backward(dy.contiguous(), x, st, ctx.bn, alpha, sync=ctx.sync)
+        return dx, None, None, None, None, dg, db, dal
 
 
-def bn_act(x, bn, prelu, training):
+def bn_act(x, bn, prelu, training, sync=None):
     alpha = prelu.weight if prelu is not None else None
-    return BNActFn.apply(x, bn, prelu, training, bn.weight, bn.bias, alpha)
+    return BNActFn.apply(x, bn, prelu, training, sync, bn.weight, bn.bias, alpha)
 
 
 class LinearFn(torch.autograd.Function):

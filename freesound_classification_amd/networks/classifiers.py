@@ -77,7 +77,7 @@ class ResnetBlock2d(_ResidualHolder):
 class _TaggingModel(nn.Module):
     dims = 2
 
-    def __init__(self, experiment, device="cuda", loss="lsep"):
+    def __init__(self, experiment, device="cuda", loss="lsep", sync_bn=None):
         super().__init__()
         self.device = device
         self.experiment = experiment
@@ -115,6 +115,10 @@ class _TaggingModel(nn.Module):
             nn.Dropout(p=net.output_dropout), nn.Linear(total_depth, data._n_classes))
         self.to(self.device)
         self._reducer = None
+        # cross-replica BatchNorm statistics under data parallelism (off: each replica normalises its own shard, like
+        # N independent copies of the reference at the per-GPU batch); `config.train.sync_bn` or the constructor argument
+        self.sync_bn = bool(getattr(self.config.train, "sync_bn", False) if sync_bn is None else sync_bn)
+        self._bn_sync = None
         self._dropout_state = F.DropoutState()
 
     # ------------------------------------------------------------------ forward
@@ -160,14 +164,14 @@ class _TaggingModel(nn.Module):
         ph = 2 if self.dims == 2 else 1
         feats = []
         for k, mods in enumerate(self.conv_modules):
-            h, feat = F.conv_block(h, mods, self.training, k >= start, ph)
+            h, feat = F.conv_block(h, mods, self.training, k >= start, ph, self._bn_sync)
             if feat is not None:
                 feats.append(feat)
         feats = torch.cat(feats, -1)
         ot = self.output_transform
-        z = F.bn_act(feats, ot[0], None, self.training)
+        z = F.bn_act(feats, ot[0], None, self.training, self._bn_sync)
         z = F.linear(z, ot[1].weight, ot[1].bias)
-        z = F.bn_act(z, ot[2], ot[3], self.training)
+        z = F.bn_act(z, ot[2], ot[3], self.training, self._bn_sync)
         z = F.dropout(z, ot[4].p, self.training, self._dropout_state)
         logits = F.linear(z, ot[5].weight, ot[5].bias)
         return dict(class_logits=logits)
@@ -319,6 +323,8 @@ class _TaggingModel(nn.Module):
             parallel.broadcast_module(self)
             self._reducer = parallel.BucketedGradReducer(list(self.parameters()))
             self.optimizer.grad_scale = 1.0 / parallel.world_size()
+            if self.sync_bn:
+                self._bn_sync = parallel.SyncBN()
 
     def load_best_model(self, fold):
         path = os.path.join(self.experiment.checkpoints, "fold_{}".format(fold), "best_model.pth")

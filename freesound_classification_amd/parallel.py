@@ -35,6 +35,41 @@ def broadcast_module(module, src=0):
             dist.broadcast(t.data, src)
 
 
+def _staged(group):
+    """gloo has no device collectives in every build: stage device tensors through the host for it (CPU tests and the
+    two-replicas-on-one-GPU parity test); RCCL ("nccl") reduces device memory directly."""
+    return dist.get_backend(group) == "gloo"
+
+
+def all_reduce_sum(t, group=None, async_op=False):
+    """In-place sum all-reduce of a tensor over the replicas; returns a handle with .wait() when async_op."""
+    if t.is_cuda and _staged(group):
+        host = t.detach().cpu()
+        dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
+        t.copy_(host)
+
+        class _Done:
+            def wait(self):
+                return True
+        return _Done() if async_op else None
+    return dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
+
+
+class SyncBN:
+    """Cross-replica BatchNorm statistics: callable handed to the BN wrappers, which call it between
+    the two phases of fsc_bn_train_stats / fsc_bn_act_bwd* on the per-channel fp64 sums [sum, sum, count, 0].
+    One small sum-all-reduce per BatchNorm layer per direction (32 + 32 per step at cfg 2, <= 4 * 1977 doubles
+    each: latency-bound, on the compute stream because the very next kernel consumes the result)."""
+
+    def __init__(self, group=None):
+        self.group = group
+        self.calls = 0
+
+    def __call__(self, sums):
+        self.calls += 1
+        all_reduce_sum(sums, self.group)
+
+
 def shard_range(total, world=None, index=None):
     """Contiguous [lo, hi) slice of `total` units owned by rank `index`; sizes differ by <= 1."""
     world = world_size() if world is None else world
@@ -95,9 +130,9 @@ class BucketedGradReducer:
                 self._comm_stream = torch.cuda.Stream(device=flat.device)
             self._comm_stream.wait_stream(torch.cuda.current_stream(flat.device))
             with torch.cuda.stream(self._comm_stream):
-                b["handle"] = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                b["handle"] = all_reduce_sum(flat, self.group, async_op=True)
         else:
-            b["handle"] = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            b["handle"] = all_reduce_sum(flat, self.group, async_op=True)
         b["launched"] = True
 
     def _on_grad(self, p):

@@ -130,13 +130,24 @@ int fsc_conv_wgrad(const fsc_conv_desc* d, const float* in, const float* dout,
  * x is (N, C, HW); HW == 1 covers BatchNorm1d on (N, C). */
 
 size_t fsc_bn_workspace_bytes(int c);
+/* Cross-replica batch statistics (SyncBN for data parallelism; the reference is single-process so its
+ * BatchNorm at classifiers.py:524,533,78-82,543,545 always sees the whole batch).  The three training entry points
+ * below take `sync` -- FSC_BN_SYNC_DOUBLES(c) doubles, per channel [sum a, sum b, count, 0] -- and `phase`:
+ *   0  single replica, `sync` unused (may be NULL);
+ *   1  reduce the local batch, write the local sums to `sync`, return (no outputs besides the parameter gradients);
+ *      the CALLER then sum-all-reduces `sync` over the replicas (RCCL; one small message per layer);
+ *   2  finish from the reduced `sync` (statistics / input gradient use the global sums and count).
+ * forward: [sum x, sum x^2, count] about zero; backward: [sum dz, sum dz*xhat, count].  dgamma / dbeta / dalpha are
+ * always LOCAL sums (the gradient all-reduce adds the replicas). */
+#define FSC_BN_SYNC_DOUBLES(c) (4 * (size_t)(c))
 /* train: batch statistics -> scale/shift (scale = gamma*invstd, shift = beta - mean*scale),
  * save_mean / save_invstd for backward, running stats updated with `momentum`
  * (running_var gets the unbiased estimate), exactly one update per call. */
 int fsc_bn_train_stats(const float* x, int n, int c, long hw, const float* gamma,
                        const float* beta, float eps, float momentum, float* running_mean,
                        float* running_var, float* save_mean, float* save_invstd,
-                       float* scale, float* shift, void* workspace, fsc_stream_t stream);
+                       float* scale, float* shift, void* workspace, double* sync, int phase,
+                       fsc_stream_t stream);
 /* eval: scale/shift from the running statistics */
 int fsc_bn_eval_prepare(int c, const float* gamma, const float* beta, const float* running_mean,
                         const float* running_var, float eps, float* scale, float* shift,
@@ -157,7 +168,7 @@ int fsc_bn_act_bwd(const float* dy, const float* gmax_dy, const int* gmax_idx, c
                    const float* gamma, const float* beta, const float* alpha, float* dx,
                    float* dresidual, float* dgamma, float* dbeta, float* dalpha,
                    float* dx_chan_sum, int n, int c, long hw, void* workspace,
-                   float* dx_amax, fsc_stream_t stream);
+                   float* dx_amax, double* sync, int phase, fsc_stream_t stream);
 
 /* Same backward for the unit that directly follows a max-pool (BN -> PReLU on the pooled tensor x,
  * classifiers.py:532-534), fused with the pool's backward: writes dc (N, C, h, w), the gradient of
@@ -167,7 +178,8 @@ int fsc_bn_act_bwd_unpool(const float* dy, const float* x, const float* save_mea
                           const float* save_invstd, const float* gamma, const float* beta,
                           const float* alpha, const uint8_t* pool_idx, float* dc, float* dgamma,
                           float* dbeta, float* dalpha, float* dx_chan_sum, int n, int c, int h,
-                          int w, int ph, void* workspace, float* dc_amax, fsc_stream_t stream);
+                          int w, int ph, void* workspace, float* dc_amax, double* sync, int phase,
+                          fsc_stream_t stream);
 
 /* ------------------------------------------------------------------ pooling (K8, K12)
  * nn.MaxPool2d(2,2) / nn.MaxPool1d(2,2), floor mode (classifiers.py:532, 155);

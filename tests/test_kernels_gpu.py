@@ -192,7 +192,7 @@ def test_conv_split_bf16_is_fp32_accurate(case, mode, restore_conv_arith):
 
     # and the native fp32 MFMA kernel on the same inputs agrees to fp32 rounding
     F.set_conv_arith(0)
-    assert F.plan_name(d, 0).startswith("conv_fwd_kernel")
+    assert F.plan_name(F._desc(n, cin, cout, h, w, kh, kw), 0).startswith("conv_fwd_kernel")
     ref = F.conv_forward(x.to(DEV), wt.to(DEV), b.to(DEV)).cpu()
     assert maxdiff(got, ref) < 4.0 * e_fwd32 + 1e-6
 

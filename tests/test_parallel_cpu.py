@@ -104,3 +104,38 @@ def test_shard_range_partitions_exactly():
             sizes = [hi - lo for lo, hi in spans]
             assert max(sizes) - min(sizes) <= 1
     assert parallel.world_size() == 1 and parallel.rank() == 0
+
+
+def test_bucket_layout_of_the_real_cfg2_model():
+    """The 141 parameter tensors of the cfg-2 model (21 545 583 floats): 32 MB buckets in reverse registration order,
+    so the classifier head and the deepest block -- whose backward finishes first and which own the three largest
+    tensors -- fill the first buckets; every tensor lands in exactly one bucket at a disjoint offset."""
+    from oracle import ref_torch as oref
+    torch.manual_seed(0)
+    model = oref.TagCNN2d("mel_2048_1024_128", 6, 100, 1.5, 1, 80)
+    named = list(model.named_parameters())
+    assert len(named) == 141
+    reducer = parallel.BucketedGradReducer([p for _, p in named])
+    try:
+        sizes = reducer.bucket_sizes()
+        assert sum(sizes) == 21545583 and len(sizes) == 4
+        assert all(s <= (32 << 20) // 4 or len(b["items"]) == 1 for s, b in zip(sizes, reducer.buckets))
+        name_of = {id(p): k for k, p in named}
+        order = [name_of[id(p)] for b in reducer.buckets for p, _, _ in b["items"]]
+        assert order == [k for k, _ in reversed(named)]
+        first = [name_of[id(p)] for p, _, _ in reducer.buckets[0]["items"]]
+        assert first[0] == "output_transform.5.bias" and "output_transform.1.weight" in first
+        assert sizes == [4661543, 5766123, 7933964, 3183953]
+        # bucket 1 opens with the largest tensor (5.18 M), bucket 2 with the third largest: the three largest tensors
+        # are on the wire while blocks 4 .. 0 are still in their backward
+        assert name_of[id(reducer.buckets[1]["items"][0][0])] == "conv_modules.5.5.conv2.weight"
+        assert name_of[id(reducer.buckets[2]["items"][0][0])] == "conv_modules.5.1.weight"
+        big3 = sorted(named, key=lambda kv: -kv[1].numel())[:3]
+        assert {k for k, _ in big3} == {"conv_modules.5.5.conv2.weight", "output_transform.1.weight", "conv_modules.5.1.weight"}
+        # the stem (block 0), last to finish its backward, closes the last bucket
+        assert name_of[id(reducer.buckets[-1]["items"][-1][0])] == "conv_modules.0.0.weight"
+        for b in reducer.buckets:
+            offs = [(off, off + n) for _, off, n in b["items"]]
+            assert offs[0][0] == 0 and all(a[1] == c[0] for a, c in zip(offs, offs[1:])) and offs[-1][1] == b["flat"].numel()
+    finally:
+        reducer.remove()
