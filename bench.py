@@ -13,7 +13,7 @@ Rank 0 prints one JSON line carrying `roofline` (dominant kernel = the conv kern
 total time, FLOPs over HIP-event time measured inside the timed region), at N = 1 `alt_f32` (the same
 workload re-timed with the native fp32-MFMA conv kernels, outside the timed region of `value`) and
 `cpu_baseline` (the CPU oracle = pure-PyTorch restatement of the reference path, timed on this
-box's host cores on a bounded sample: batch 8 of the same model and clip length).
+box's host cores on a bounded sample: batch 8 of the same model and clip length, 1 + 3 steps).
 """
 import argparse
 import json
@@ -48,6 +48,12 @@ WORKLOADS = {
     # BASELINE.json configs[0] shape (used for quick checks: --workload cfg1)
     "cfg1": dict(features="mel_1024_512_64", blocks=3, base=32, growth=2, start=1, dropout=0.0,
                  batch=64, samples=32000, sr=16000, n_mel=64),
+    # BASELINE.json configs[4]: 5-fold ensemble inference on variable-length, length-grouped batches (SURVEY 8d:
+    # 4096 clips, lengths U(0.3 s, 30 s) @ 44.1 kHz seed 7, bucket edges every 2 s, <= 128 x 10 s of samples per
+    # batch; the cfg-2 network).  A "step" is one length-grouped batch through all five resident fold models.
+    "cfg5": dict(features="mel_2048_1024_128", blocks=6, base=100, growth=1.5, start=1, dropout=0.7,
+                 batch=128, samples=441000, sr=44100, n_mel=128, inference=dict(folds=5, clips=4096, seed=7,
+                                                                                 min_s=0.3, max_s=30.0, bucket_s=2.0)),
 }
 
 
@@ -70,12 +76,33 @@ def synthetic_batch(w, batch, device, seed):
     return signal, labels
 
 
-def cpu_baseline(w, steps=2, batch=4):
-    """The oracle (CPU restatement of the reference path) on this box's host cores.  Bounded
-    sample: ~10-30 s of CPU work.  Thread count is capped at 32: on a 256-thread host the
-    intra-op pool oversubscribes badly on these shapes (measured 0.07 clips/s at 256 threads)."""
+def physical_cores():
+    """Physical cores of this host (sockets x cores per socket from /proc/cpuinfo), else the logical count."""
+    try:
+        ids = set()
+        phys = core = None
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("physical id"):
+                    phys = line.split(":")[1].strip()
+                elif line.startswith("core id"):
+                    core = line.split(":")[1].strip()
+                elif not line.strip() and phys is not None and core is not None:
+                    ids.add((phys, core))
+        if ids:
+            return len(ids)
+    except OSError:
+        pass
+    return os.cpu_count() or 1
+
+
+def cpu_baseline(w, steps=3, batch=8):
+    """The oracle (CPU restatement of the reference path) on this box's host cores, as BASELINE.md section 4 plans
+    it: the same model and clip length at batch 8, 1 warm-up + 3 timed steps, median.  Threads = the host's PHYSICAL
+    cores, stated in the line (one intra-op thread per hardware thread oversubscribes these shapes badly: 0.07
+    clips/s at 256 threads on the round-1 box)."""
     from oracle import ref_torch as oref
-    cores = min(32, os.cpu_count() or 1)
+    cores = physical_cores()
     torch.set_num_threads(cores)
     torch.manual_seed(0)
     model = oref.TagCNN2d(w["features"], w["blocks"], w["base"], w["growth"], w["start"], 80,
@@ -101,6 +128,106 @@ def cpu_baseline(w, steps=2, batch=4):
     return dict(value=batch / med, unit="clips/s", cores=cores, kind="port",
                 sample="oracle train step, same model and clip length, batch %d, 1 warm-up + %d timed steps "
                        "(median), %s" % (batch, steps, cpu_model))
+
+
+def run_inference(args, w, device, world, rank):
+    """cfg 5: length-grouped fold-ensemble inference (reference predict_2d_cnn.py:72-125, README.md:37).  All fold
+    weight sets and all padded batches are resident in HBM before the timed region; batches are dealt round-robin to
+    the ranks (no data-path collective; total work is fixed -> strong scaling).  Prints ONE JSON line on rank 0."""
+    import random
+
+    import numpy as np
+
+    import predict_2d_cnn as drv
+    from freesound_classification_amd import functional as F
+    from freesound_classification_amd.networks.classifiers import TwoDimensionalCNNClassificationModel
+    from freesound_classification_amd.ops.padding import BucketingSampler
+
+    inf = w["inference"]
+    rng = np.random.RandomState(inf["seed"])
+    lens = rng.randint(int(inf["min_s"] * w["sr"]), int(inf["max_s"] * w["sr"]), size=inf["clips"])
+
+    class _DS:
+        lengths = lens
+
+    random.seed(inf["seed"])
+    step = int(inf["bucket_s"] * w["sr"])
+    edges = list(range(0, int(lens.max()) + 2 * step, step))
+    batches = [list(map(int, b)) for b in BucketingSampler(_DS, w["batch"] * w["samples"], edges)]
+    mine = batches[rank::world]
+    models = []
+    for fold in range(inf["folds"]):
+        torch.manual_seed(100 + fold)
+        m = TwoDimensionalCNNClassificationModel(make_experiment(w), device=str(device))
+        for mod in m.modules():                              # non-trivial running statistics for eval-mode BN
+            if isinstance(mod, torch.nn.modules.batchnorm._BatchNorm):
+                mod.running_mean.normal_(0, 0.1)
+                mod.running_var.uniform_(0.5, 1.5)
+        models.append(m.eval())
+    gen = torch.Generator(device=device).manual_seed(1234 + rank)
+    padded = []
+    for b in mine:                                           # what the collate + H2D hands over: zero-padded to the longest
+        t = int(lens[b].max())
+        x = torch.zeros(len(b), t, 1, device=device)
+        for row, i in enumerate(b):
+            x[row, :lens[i], 0] = 0.1 * torch.randn(int(lens[i]), device=device, generator=gen)
+        padded.append(x)
+    n_steps = len(padded) if args.steps <= 0 or args.steps > len(padded) else args.steps
+    for x in padded[:max(1, min(args.warmup, len(padded)))]:
+        drv.ensemble_batch(models, x)
+    timer = None if args.no_kernel_timer else F.KernelTimer()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    F.TIMER = timer
+    t0 = time.perf_counter()
+    clips = 0
+    for x in padded[:n_steps]:
+        probs = drv.ensemble_batch(models, x)
+        clips += x.shape[0]
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    F.TIMER = None
+    total = torch.tensor([float(clips), elapsed], device=device, dtype=torch.float64)
+    if world > 1:
+        both = total.clone()
+        dist.all_reduce(both[:1], op=dist.ReduceOp.SUM)
+        dist.all_reduce(total[1:], op=dist.ReduceOp.MAX)
+        total[0] = both[0]
+    if not torch.isfinite(probs).all():
+        raise SystemExit("non-finite probabilities in the inference benchmark")
+    if rank == 0:
+        clips_all, tmax = float(total[0]), float(total[1])
+        seconds = float(lens.sum()) / w["sr"]
+        result = {
+            "metric": "inference clips/s (5-fold ensemble, length-grouped batches, GPU STFT+mel)",
+            "value": clips_all / tmax, "unit": "clips/s", "n_gpus": world, "steps": n_steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * tmax / n_steps, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "cfg5: %d clips of U(%.1f, %.0f) s @ %.1f kHz (%.0f s of audio), %d length-grouped batches "
+                                   "(bucket edges every %.0f s, <= %d x %.0f s of samples), %d resident fold models of the "
+                                   "cfg-2 network, sigmoid mean" % (
+                                       inf["clips"], inf["min_s"], inf["max_s"], w["sr"] / 1e3, seconds, len(batches),
+                                       inf["bucket_s"], w["batch"], w["samples"] / w["sr"], inf["folds"]),
+                       "parallelism": "dp%d (batches round-robin)" % world,
+                       "conv_arith": {0: "f32", 3: "f16x3", 6: "bf16x6", 9: "bf16x9"}[F.get_conv_arith()]},
+            "audio_seconds_per_s": seconds * (clips_all / inf["clips"]) / tmax,
+            "reference_claim": "README.md:37: stage-1 test set, 5 folds, 'only 1 minute' (hardware unspecified)",
+        }
+        if timer is not None:
+            summ = timer.summary()
+            dom_name, dom = max(summ.items(), key=lambda kv: kv[1]["ms"])
+            per = 3 if dom_name.endswith(",3>") else 1
+            peak = PEAK_BF16_MFMA_TFLOPS if per == 3 else PEAK_F32_MFMA_TFLOPS
+            ach = dom["flops"] / dom["ms"] / 1e9
+            result["roofline"] = {"kernel": dom_name, "bound": "mfma", "achieved": ach * per, "peak": peak, "unit": "TFLOP/s",
+                                  "frac": ach * per / peak, "traffic": None, "algorithmic_fp32_tflops": ach,
+                                  "conv_ms_total": sum(v["ms"] for v in summ.values()), "wall_ms": 1e3 * elapsed}
+        print(json.dumps(result))
+    if dist.is_initialized():
+        dist.destroy_process_group()
 
 
 def main():
@@ -136,6 +263,10 @@ def main():
     from freesound_classification_amd.ops.training import make_step
 
     w = WORKLOADS[args.workload]
+    if "inference" in w:
+        if "--steps" not in sys.argv:
+            args.steps = 0                      # one pass over every length-grouped batch
+        return run_inference(args, w, device, world, rank)
     batch = args.batch or w["batch"]
     torch.manual_seed(42)
     model_cls = HierarchicalCNNClassificationModel if w.get("dims") == 1 else TwoDimensionalCNNClassificationModel
@@ -204,6 +335,45 @@ def main():
         F.TIMER = None
         F.set_conv_arith(mode0)
         alt = {"conv_arith": "f32", "value": batch * k_alt / e_alt, "unit": "clips/s", "steps": k_alt, "ms_per_step": 1e3 * e_alt / k_alt}
+    # The same step with the batch arriving from the host: the 4 * T * N bytes (226 MB at cfg 2) are copied from a pinned
+    # staging buffer on a copy stream into one of two device buffers while the previous step computes (double
+    # buffering, as ops/device_pipeline.py does for real loaders).  N = 1 only, outside the timed region of `value`.
+    h2d = None
+    if world == 1 and not args.no_alt and not w.get("mixup"):
+        pinned = signal.cpu().pin_memory()
+        dev_buf = [torch.empty_like(signal), torch.empty_like(signal)]
+        copy_stream = torch.cuda.Stream(device=device)
+        events = [None, None]
+
+        def upload(slot):
+            copy_stream.wait_stream(torch.cuda.current_stream(device))      # the buffer's previous consumer is done
+            with torch.cuda.stream(copy_stream):
+                dev_buf[slot].copy_(pinned, non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record(copy_stream)
+            events[slot] = ev
+
+        def h2d_step(k):
+            slot = k & 1
+            torch.cuda.current_stream(device).wait_event(events[slot])
+            upload(slot ^ 1)                                                # next batch on the wire during this step
+            model.global_step += 1
+            make_step(model.scheduler, step=model.global_step)
+            return model.training_step(dev_buf[slot], labels)
+
+        upload(0)
+        for k in range(2):
+            h2d_step(k)
+        torch.cuda.synchronize()
+        k_h = max(2, min(args.steps, 10))
+        t2 = time.perf_counter()
+        for k in range(k_h):
+            h2d_step(k)
+        torch.cuda.synchronize()
+        e_h = time.perf_counter() - t2
+        h2d = {"value": batch * k_h / e_h, "unit": "clips/s", "steps": k_h, "ms_per_step": 1e3 * e_h / k_h,
+               "h2d_bytes_per_step": pinned.numel() * 4,
+               "note": "host->device copy of the waveform batch inside the timed region (pinned, double-buffered, copy stream)"}
     if not torch.isfinite(torch.tensor(final_loss)):
         raise SystemExit("non-finite loss in the benchmark: %r" % final_loss)
 
@@ -270,6 +440,8 @@ def main():
             }
         if alt is not None:
             result["alt_f32"] = alt
+        if h2d is not None:
+            result["with_h2d"] = h2d
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(w)
         print(json.dumps(result))

@@ -59,6 +59,81 @@ __global__ void mixup_kernel(const float* __restrict__ a, const float* __restric
     }
 }
 
+// Batched index copy for the waveform transforms that are pure index work (reference ops/transforms.py:292-309
+// SampleLongAudio: crop; :256-271 ShuffleAudio -> ops/audio.py:55-67: permute ~0.5 s chunks).  Row n of the output is
+// the concatenation of seg_count[n] segments of row src_row[n] of `src`: segment k copies
+// src[seg_src[n][k] ... + (seg_dst[n][k+1] - seg_dst[n][k])) to out[seg_dst[n][k] ...]; everything past
+// seg_dst[n][count] is the collate padding value (0).  Exact copies: bit-identical to the numpy slicing.
+constexpr int kMaxSeg = 256;
+__global__ __launch_bounds__(256) void segments_gather_kernel(const float* __restrict__ src, long src_stride,
+                                                              const int* __restrict__ src_row,
+                                                              const int* __restrict__ seg_count,
+                                                              const int* __restrict__ seg_src,
+                                                              const int* __restrict__ seg_dst, int max_seg,
+                                                              float* __restrict__ out, long t_out) {
+    __shared__ int s_src[kMaxSeg], s_dst[kMaxSeg + 1];
+    const int n = blockIdx.y;
+    const int cnt = seg_count[n];
+    for (int i = threadIdx.x; i < cnt; i += blockDim.x) s_src[i] = seg_src[(long)n * max_seg + i];
+    for (int i = threadIdx.x; i <= cnt; i += blockDim.x) s_dst[i] = seg_dst[(long)n * (max_seg + 1) + i];
+    __syncthreads();
+    const float* ps = src + (long)src_row[n] * src_stride;
+    float* po = out + (long)n * t_out;
+    const int total = cnt > 0 ? s_dst[cnt] : 0;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < t_out; i += (long)gridDim.x * blockDim.x) {
+        float v = 0.f;
+        if (i < total) {
+            int lo = 0, hi = cnt - 1;                      // last segment with s_dst[k] <= i
+            while (lo < hi) {
+                const int mid = (lo + hi + 1) >> 1;
+                if (s_dst[mid] <= (int)i) lo = mid; else hi = mid - 1;
+            }
+            v = ps[s_src[lo] + ((int)i - s_dst[lo])];
+        }
+        po[i] = v;
+    }
+}
+
+// mixup_kernel with a partner table: row n is mixed with row partner[n] of `b` (lengths len_a[n], len_b[n]), or copied
+// unchanged when partner[n] < 0 (MixUp not drawn for this sample, ops/transforms.py:57).
+__global__ void mixup_rows_kernel(const float* __restrict__ a, const float* __restrict__ b, const int* __restrict__ partner,
+                                  const int* __restrict__ len_a, const int* __restrict__ len_b,
+                                  const int* __restrict__ start, const float* __restrict__ alpha,
+                                  const float* __restrict__ oma, float* __restrict__ out, long t_a, long t_b, long t_out) {
+    const int n = blockIdx.y;
+    const int pr = partner[n];
+    const int la = len_a[n], lb = pr < 0 ? 0 : len_b[n];
+    const float* pa = a + (long)n * t_a;
+    const float* pb = b + (long)(pr < 0 ? 0 : pr) * t_b;
+    float* po = out + (long)n * t_out;
+    const bool a_longer = la > lb;
+    const float* plong = a_longer ? pa : pb;
+    const float* pshort = a_longer ? pb : pa;
+    const int ll = a_longer ? la : lb, ls = a_longer ? lb : la;
+    const int s0 = start[n];
+    const float al = alpha[n], om = oma[n];
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < t_out; i += (long)gridDim.x * blockDim.x) {
+        float v = 0.f;
+        if (pr < 0) {
+            if (i < la) v = pa[i];
+        } else if (la == lb) {
+            if (i < la) v = (pa[i] + pb[i]) / 2.f;
+        } else if (i < ll) {
+            v = (i >= s0 && i < s0 + ls) ? pshort[i - s0] * om : plong[i] * al;
+        }
+        po[i] = v;
+    }
+}
+
+__global__ void or_labels_rows_kernel(const float* __restrict__ la, const float* __restrict__ lb, const int* __restrict__ partner,
+                                      float* __restrict__ lo, int n, int c) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < (long)n * c; i += (long)gridDim.x * blockDim.x) {
+        const int row = (int)(i / c), col = (int)(i - (long)row * c);
+        const int pr = partner[row];
+        lo[i] = pr < 0 ? la[i] : fminf(fmaxf(la[i] + lb[(long)pr * c + col], 0.f), 1.f);
+    }
+}
+
 __global__ void or_labels_kernel(const float* __restrict__ la, const float* __restrict__ lb, float* __restrict__ lo,
                                  long count) {
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (long)gridDim.x * blockDim.x)
@@ -110,6 +185,37 @@ int fsc_mixup_batch(const float* a, const float* b, const int* len_a, const int*
                            labels_out, (long)n * c);
     }
     FSC_LAUNCH_CHECK("fsc_mixup_batch");
+    return 0;
+}
+
+int fsc_segments_gather(const float* src, long src_stride, const int* src_row, const int* seg_count, const int* seg_src,
+                        const int* seg_dst, int max_seg, float* out, int n, long t_out, fsc_stream_t stream) {
+    FSC_CHECK_ARG(src && src_row && seg_count && seg_src && seg_dst && out, "fsc_segments_gather: null pointer");
+    FSC_CHECK_ARG(n > 0 && t_out > 0 && max_seg > 0 && max_seg <= kMaxSeg, "fsc_segments_gather: bad sizes (max_seg <= %d)", kMaxSeg);
+    unsigned gx = grid_for(t_out);
+    if (gx > 64) gx = 64;
+    hipLaunchKernelGGL(segments_gather_kernel, dim3(gx, n), dim3(256), 0, fsc::as_stream(stream), src, src_stride, src_row,
+                       seg_count, seg_src, seg_dst, max_seg, out, t_out);
+    FSC_LAUNCH_CHECK("fsc_segments_gather");
+    return 0;
+}
+
+int fsc_mixup_rows(const float* a, const float* b, const int* partner, const int* len_a, const int* len_b, const int* start,
+                   const float* alpha, const float* one_minus_alpha, float* out, int n, long t_a, long t_b, long t_out,
+                   const float* labels_a, const float* labels_b, float* labels_out, int c, fsc_stream_t stream) {
+    FSC_CHECK_ARG(a && b && partner && len_a && len_b && start && alpha && one_minus_alpha && out, "fsc_mixup_rows: null pointer");
+    FSC_CHECK_ARG(n > 0 && t_a > 0 && t_b > 0 && t_out >= (t_a > t_b ? t_a : t_b), "fsc_mixup_rows: bad sizes");
+    hipStream_t st = fsc::as_stream(stream);
+    unsigned gx = grid_for(t_out);
+    if (gx > 64) gx = 64;
+    hipLaunchKernelGGL(mixup_rows_kernel, dim3(gx, n), dim3(256), 0, st, a, b, partner, len_a, len_b, start, alpha,
+                       one_minus_alpha, out, t_a, t_b, t_out);
+    if (labels_out) {
+        FSC_CHECK_ARG(labels_a && labels_b && c > 0, "fsc_mixup_rows: label pointers");
+        hipLaunchKernelGGL(or_labels_rows_kernel, dim3(grid_for((long)n * c)), dim3(256), 0, st, labels_a, labels_b, partner,
+                           labels_out, n, c);
+    }
+    FSC_LAUNCH_CHECK("fsc_mixup_rows");
     return 0;
 }
 

@@ -117,7 +117,12 @@ class _TaggingModel(nn.Module):
         self._reducer = None
         # cross-replica BatchNorm statistics under data parallelism (off: each replica normalises its own shard, like
         # N independent copies of the reference at the per-GPU batch); `config.train.sync_bn` or the constructor argument
-        self.sync_bn = bool(getattr(self.config.train, "sync_bn", False) if sync_bn is None else sync_bn)
+        if sync_bn is None:
+            try:                                   # (mag configs and plain attr-dicts raise different errors)
+                sync_bn = self.config.train.sync_bn
+            except (AttributeError, KeyError):
+                sync_bn = False
+        self.sync_bn = bool(sync_bn)
         self._bn_sync = None
         self._dropout_state = F.DropoutState()
 

@@ -239,6 +239,25 @@ int fsc_mixup_batch(const float* a, const float* b, const int* len_a, const int*
                     const float* labels_a, const float* labels_b, float* labels_out, int c,
                     fsc_stream_t stream);
 
+/* MixUp with a partner table: row n of `a` is mixed with row partner[n] of `b` (len_b[n] = that partner's length), or
+ * passes through unchanged when partner[n] < 0 (MixUp.p not drawn, ops/transforms.py:57).  labels likewise. */
+int fsc_mixup_rows(const float* a, const float* b, const int* partner, const int* len_a,
+                   const int* len_b, const int* start, const float* alpha,
+                   const float* one_minus_alpha, float* out, int n, long t_a, long t_b, long t_out,
+                   const float* labels_a, const float* labels_b, float* labels_out, int c,
+                   fsc_stream_t stream);
+
+/* ------------------------------------------------------------------ device-side input pipeline (f-2)
+ * The waveform transforms that are pure index work, batched on the device: SampleLongAudio's random crop
+ * (ops/transforms.py:292-309) and ShuffleAudio's chunk permutation (:256-271 -> ops/audio.py:55-67).  The random
+ * draws stay on the host (same generators, same order as the reference's per-sample Compose); the device gets, per
+ * output row n, its source row src_row[n] in `src` (rows of src_stride floats) and seg_count[n] <= max_seg <= 256
+ * segments: segment k copies src[seg_src[n*max_seg + k] ...] to out[seg_dst[n*(max_seg+1) + k] ... seg_dst[.. k+1]).
+ * Output past the last segment is 0 (the collate padding, ops/padding.py:26-28).  Bit-exact copies. */
+int fsc_segments_gather(const float* src, long src_stride, const int* src_row, const int* seg_count,
+                        const int* seg_src, const int* seg_dst, int max_seg, float* out, int n,
+                        long t_out, fsc_stream_t stream);
+
 /* ------------------------------------------------------------------ optimizers (K16)
  * ops/training.py:9-12: Adam(amsgrad=True) and SGD(momentum=0.9, nesterov=True), both with
  * L2 weight decay folded into the gradient (torch semantics). */

@@ -486,6 +486,46 @@ def g12_cfg2_step():
     save("g12_cfg2_step.npz", **out)
 
 
+# ---------------------------------------------------------------------------------- G13
+def g13_input_pipeline():
+    """The reference's per-sample training transforms that the build moves to the device:
+    Compose([loader, SampleLongAudio, MapLabels, ShuffleAudio, MixUp]) through the reference's own SoundDataset
+    (random_clean_sample -> clean_transform), on seeded-noise clips (LoadAudio needs librosa + files, so a loader with
+    the same protocol returns 0.1 * N(0, 1) drawn from the clip's seed).  Stored: clip descriptors, generator seeds,
+    and per sample the resulting waveform and labels, in dataset order."""
+    from datasets.sound_dataset import SoundDataset
+    from ops.transforms import Compose, MapLabels, MixUp, SampleLongAudio, ShuffleAudio
+
+    class SeededNoise:
+        def __call__(self, dataset, **inputs):
+            out = dict(inputs)
+            _, seed, n, sr = str(inputs["filename"]).split(":")
+            out["audio"] = (0.1 * np.random.RandomState(int(seed)).standard_normal(int(n))).astype(np.float32)
+            out["sr"] = int(sr)
+            return out
+
+    sr = 8000
+    rng = np.random.default_rng(13)
+    lengths = rng.integers(int(0.3 * sr), int(3.2 * sr), size=14)
+    lengths[3] = lengths[7]                                   # an equal-length MixUp pair is possible
+    files = ["synthetic:%d:%d:%d" % (100 + i, n, sr) for i, n in enumerate(lengths)]
+    class_map = {"c%02d" % i: i for i in range(80)}
+    labels = [["c%02d" % rng.integers(80)] + (["c%02d" % rng.integers(80)] if i % 3 == 0 else []) for i in range(14)]
+    out = {"files": np.array(files), "labels_csv": np.array([",".join(l) for l in labels]), "sr": np.int64(sr),
+           "max_length": np.int64(1), "chunk_length": np.float64(0.25), "p_shuffle": np.float64(0.6),
+           "p_mixup": np.float64(0.5), "seed": np.int64(131)}
+    clean = Compose([SeededNoise(), SampleLongAudio(max_length=1), MapLabels(class_map=class_map)])
+    tf = Compose([SeededNoise(), SampleLongAudio(max_length=1), MapLabels(class_map=class_map),
+                  ShuffleAudio(chunk_length=0.25, p=0.6), MixUp(p=0.5)])
+    ds = SoundDataset(audio_files=files, labels=labels, transform=tf, clean_transform=clean)
+    seed_all(131)
+    for i in range(len(ds)):
+        s = ds[i]
+        out["audio.%d" % i] = np.asarray(s["audio"], np.float32).copy()
+        out["labels.%d" % i] = np.asarray(s["labels"], np.float32).copy()
+    save("g13_input_pipeline.npz", **out)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
     g1_frontend()
@@ -500,3 +540,4 @@ if __name__ == "__main__":
     g10_lwlrap()
     g11_cfg1()
     g12_cfg2_step()
+    g13_input_pipeline()
