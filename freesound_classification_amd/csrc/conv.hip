@@ -1316,6 +1316,21 @@ __global__ __launch_bounds__(kStemThreads) void conv_stem_dgrad_kernel(const flo
 
 // -------------------------------------------------------------------------------------------
 // weight gradient
+// XCD-aware block order for grids of (blocks, splits): the hardware deals workgroups to the 8 XCDs round-robin in
+// dispatch order (x fastest), so the `blocks` workgroups of one split -- which read the SAME pixels of both operands --
+// would land on different XCDs and each fetch its operands from HBM into its own L2.  Re-index so that every XCD owns
+// a contiguous range of the (split, block) sequence: the blocks of a split then run on one XCD, back to back, and the
+// re-reads hit its L2.  Returns the logical (block, split) of this workgroup; a bijection for any grid size.
+__device__ __forceinline__ void xcd_block_order(int* block, int* split) {
+    const unsigned bx = gridDim.x, total = gridDim.x * gridDim.y;
+    const unsigned id = blockIdx.x + bx * blockIdx.y;
+    const unsigned xcd = id & 7u, slot = id >> 3;
+    const unsigned chunk = total >> 3, rem = total & 7u;
+    const unsigned v = xcd < rem ? xcd * (chunk + 1) + slot : rem * (chunk + 1) + (xcd - rem) * chunk + slot;
+    *split = (int)(v / bx);
+    *block = (int)(v - (unsigned)*split * bx);
+}
+
 template <int KH, int KW>
 struct WgCfg {
     static constexpr int TAPS = KH * KW;
@@ -1375,9 +1390,10 @@ __global__ __launch_bounds__((wg_threads<KH, KW>())) void conv_wgrad_kernel(WgGe
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lm = lane & 15, kq = lane >> 4;
-    const int co0 = (blockIdx.x / g.ci_blocks) * CO_BLK;
-    const int ci0 = (blockIdx.x % g.ci_blocks) * CI_BLK;
-    const int split = blockIdx.y;
+    int blk, split;
+    xcd_block_order(&blk, &split);
+    const int co0 = (blk / g.ci_blocks) * CO_BLK;
+    const int ci0 = (blk % g.ci_blocks) * CI_BLK;
 
     // ---- unit-invariant decode: lane = pixel (dOut) and lane + 64 j = staged position (input)
     const int per_pix = g.th * g.tw, per_pos = g.rows * g.cols;
@@ -1650,10 +1666,11 @@ __global__ __launch_bounds__(kWgxWaves * 64) void conv_wgrad_x3_kernel(WgxGeom g
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lm = lane & 15, kq = lane >> 4;
     const int cog = wid / g.nt, cit = wid - cog * g.nt;                     // this wave's co group and ci tile
-    const int cb = blockIdx.x / g.ci_blocks, ib = blockIdx.x - cb * g.ci_blocks;
+    int blk, split;
+    xcd_block_order(&blk, &split);
+    const int cb = blk / g.ci_blocks, ib = blk - cb * g.ci_blocks;
     const int tile0 = cb * g.tpb;                                          // first co tile of the block
     const int ci0 = ib * g.nt * 16;
-    const int split = blockIdx.y;
     const int total_tiles = (g.cout + 15) >> 4;
     // live co tiles of this wave: i < mt_live
     int mt_live, g_start;

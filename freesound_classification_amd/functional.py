@@ -335,9 +335,10 @@ def bn_prepare(x, bn, training, sync=None):
             bn.num_batches_tracked.add_(1)
             if bn.momentum is None:
                 momentum = 1.0 / float(bn.num_batches_tracked)
+        ws = _bn_ws(c, x)                                  # (kept alive across both phases)
         args = (ptr(x), n, c, hw, ptr(gamma), ptr(beta), bn.eps, momentum,
                 ptr(bn.running_mean) if track else None, ptr(bn.running_var) if track else None,
-                ptr(st.mean), ptr(st.invstd), ptr(st.scale), ptr(st.shift), ptr(_bn_ws(c, x)))
+                ptr(st.mean), ptr(st.invstd), ptr(st.scale), ptr(st.shift), ptr(ws))
         if sync is None:
             call("fsc_bn_train_stats", *args, None, 0, stream_ptr())
         else:
@@ -382,9 +383,10 @@ def bn_act_backward(dy, x, st, bn, alpha=None, residual=None, gmax=None, want_dx
     csum = _empty((c,), x) if want_chan_sum else None
     gdy, gidx = gmax if gmax is not None else (None, None)
     dx_amax = _empty((AMAX_FLOATS,), x) if with_amax and _want_amax() else None
+    ws = _bn_ws(c, x)                                      # (kept alive across both phases)
     args = (ptr(dy), ptr(gdy), ptr(gidx), ptr(x), ptr(residual), ptr(st.mean),
             ptr(st.invstd), ptr(bn.weight), ptr(bn.bias), ptr(alpha), ptr(dx), ptr(dres), ptr(dgamma),
-            ptr(dbeta), ptr(dalpha), ptr(csum), n, c, hw, ptr(_bn_ws(c, x)), ptr(dx_amax))
+            ptr(dbeta), ptr(dalpha), ptr(csum), n, c, hw, ptr(ws), ptr(dx_amax))
     if sync is None:
         call("fsc_bn_act_bwd", *args, None, 0, stream_ptr())
     else:
@@ -407,9 +409,10 @@ def bn_act_backward_unpool(dy, x, st, bn, alpha, pool_idx, c_shape, ph, sync=Non
     dalpha = _empty((c,), x) if alpha is not None else None
     csum = _empty((c,), x)
     dc_amax = _empty((AMAX_FLOATS,), x) if _want_amax() else None
+    ws = _bn_ws(c, x)                                      # (kept alive across both phases)
     args = (ptr(dy), ptr(x), ptr(st.mean), ptr(st.invstd), ptr(bn.weight), ptr(bn.bias),
             ptr(alpha), ptr(pool_idx), ptr(dc), ptr(dgamma), ptr(dbeta), ptr(dalpha), ptr(csum), n, c, h, w, ph,
-            ptr(_bn_ws(c, x)), ptr(dc_amax))
+            ptr(ws), ptr(dc_amax))
     if sync is None:
         call("fsc_bn_act_bwd_unpool", *args, None, 0, stream_ptr())
     else:

@@ -188,10 +188,11 @@ class DeviceInputPipeline:
         f32 = lambda v: torch.from_numpy(np.asarray(v, np.float32)).to(self.device, non_blocking=True)  # noqa: E731
         plabels = torch.from_numpy(np.stack(plan.partner_labels)).to(self.device, non_blocking=True)
         lab_out = torch.empty_like(labels)
-        call("fsc_mixup_rows", ptr(a), ptr(b), ptr(i32(plan.partner)), ptr(i32(plan.lengths)),
-             ptr(i32(plan.partner_len_of_row)), ptr(i32(plan.mix_start)), ptr(f32(alpha64.astype(np.float32))),
-             ptr(f32((1.0 - alpha64).astype(np.float32))), ptr(out), n, t_a, t_b, t_out, ptr(labels), ptr(plabels),
-             ptr(lab_out), labels.shape[1], stream_ptr())
+        # (named, so that every table outlives the launch: a temporary's block would be recycled by the next upload)
+        partner, len_a, len_b, start = i32(plan.partner), i32(plan.lengths), i32(plan.partner_len_of_row), i32(plan.mix_start)
+        al, om = f32(alpha64.astype(np.float32)), f32((1.0 - alpha64).astype(np.float32))
+        call("fsc_mixup_rows", ptr(a), ptr(b), ptr(partner), ptr(len_a), ptr(len_b), ptr(start), ptr(al), ptr(om),
+             ptr(out), n, t_a, t_b, t_out, ptr(labels), ptr(plabels), ptr(lab_out), labels.shape[1], stream_ptr())
         return dict(signal=out.unsqueeze(-1), labels=lab_out)
 
     def batch(self, indices):

@@ -154,7 +154,9 @@ class _TagCNN(nn.Module):
             if collect is not None:
                 collect.append(x)
             if k >= self.start:
-                pooled.append(x.flatten(2).amax(dim=2))
+                # AdaptiveMaxPool2d(1) / 1d(1) (classifiers.py:540,591 / :163,201): ONE arg-max per plane gets the
+                # gradient (amax would split it between ties)
+                pooled.append(F.adaptive_max_pool1d(x.flatten(2), 1).squeeze(-1))
         return torch.cat(pooled, dim=-1)
 
     def forward(self, signal):

@@ -67,15 +67,21 @@ def _report(line):
         f.write(line + "\n")
 
 
+@pytest.mark.parametrize("batch", ["bench", 4], ids=["n128plan", "n4"])
 @pytest.mark.parametrize("arith", [3, 0], ids=["f16x3", "f32"])
 @pytest.mark.parametrize("layer", LAYERS, ids=["%dto%d_%dx%d_k%d" % l for l in LAYERS])
-def test_cfg2_layer_against_fp64(layer, arith):
+def test_cfg2_layer_against_fp64(layer, arith, batch):
+    """batch "bench": the kernel instantiations (and, up to 8 x 26, the exact plans) batch 128 runs.  batch 4: the
+    plans the full-model parity step below runs (split-K, several images per box, partly filled tiles)."""
     c_in, c_out, h, w, k = layer
-    n = _batch_for(layer, arith)
+    if batch == 4 and h * w > 32 * 107:
+        pytest.skip("batch 4 on the large planes is covered by the batch-128 plan at batch 2 .. 64")
+    n = _batch_for(layer, arith) if batch == "bench" else 4
     names = [F.plan_name(F._desc(n, c_in, c_out, h, w, k, k, arith), m) for m in (0, 1, 2)]
-    assert names == [F.plan_name(F._desc(128, c_in, c_out, h, w, k, k, arith), m) for m in (0, 1, 2)]
-    if arith == 3 and c_in >= 32:
-        assert names[0].startswith("conv_fwd_x3_kernel") and names[0].endswith(",3>"), names
+    if batch == "bench":
+        assert names == [F.plan_name(F._desc(128, c_in, c_out, h, w, k, k, arith), m) for m in (0, 1, 2)]
+        if arith == 3 and c_in >= 32:
+            assert names[0].startswith("conv_fwd_x3_kernel") and names[0].endswith(",3>"), names
     torch.manual_seed(c_in * 7 + c_out + h)
     pad = k // 2
     x = torch.randn(n, c_in, h, w)
@@ -159,51 +165,145 @@ def cfg2_step(golden):
                 grads=grads, eval_logits=ev, model=m)
 
 
-def test_cfg2_model_step_against_reference_golden(cfg2_step):
+def test_cfg2_model_forward_against_reference_golden(cfg2_step):
+    """Same seed -> the reference's initial parameters (checksums); then logits, per-sample LSEP and eval-mode logits of
+    the real 21.5 M-parameter model against what the imported reference produced: 1e-3 absolute (measured 5e-5)."""
     s = cfg2_step
     g = s["g"]
     assert sum(v.numel() for v in s["grads"].values()) == int(g["n_params"]) == 21545583
-    for k, v in s["state"].items():          # same seed, same registration order -> the reference's initial parameters
-        if ("init_sum." + k) in g:
-            assert float(v.double().sum()) == float(g["init_sum." + k]), k
-    worst = check_cfg2_step_against_golden(g, [(k, v.numpy()) for k, v in s["grads"].items()], s["logits"].numpy(),
-                                           s["per"].numpy(), s["eval_logits"].numpy())
-    _report("cfg2 model step vs reference golden: logits %.2e  loss %.2e  eval %.2e  worst scaled grad diff %.2e" % (
-        float(np.abs(s["logits"].numpy() - g["logits"]).max()), float(np.abs(s["per"].numpy() - g["loss"]).max()),
-        float(np.abs(s["eval_logits"].numpy() - g["eval_logits"]).max()), worst))
+    for k, v in s["state"].items():
+        if ("init_sum." + k) in g:             # (the fp64 sum depends on the host's thread count in the last bits)
+            assert abs(float(v.double().sum()) - float(g["init_sum." + k])) <= 1e-9 * float(g["init_abs." + k]), k
+            assert abs(float(v.double().abs().sum()) - float(g["init_abs." + k])) <= 1e-9 * float(g["init_abs." + k]), k
+    d_logits = float(np.abs(s["logits"].numpy() - g["logits"]).max())
+    d_loss = float(np.abs(s["per"].numpy() - g["loss"]).max())
+    d_eval = float(np.abs(s["eval_logits"].numpy() - g["eval_logits"]).max())
+    _report("cfg2 model forward vs reference golden: logits %.2e  loss %.2e  eval logits %.2e" % (d_logits, d_loss, d_eval))
+    assert d_logits < 1e-3 and d_loss < 1e-3 and d_eval < 1e-3
 
 
-def test_cfg2_model_step_against_oracle_fp32_and_fp64(cfg2_step):
-    """Every element of every gradient against the CPU oracle (fp32), and both against an fp64 run of the oracle:
-    the accelerated step must not be further from fp64 than the fp32 CPU path is (beyond a small factor)."""
+def _relative_l2(a, b):
+    num = sum(float((a[k].double() - b[k].double()).pow(2).sum()) for k in b)
+    den = sum(float(b[k].double().pow(2).sum()) for k in b)
+    return (num / den) ** 0.5
+
+
+def test_cfg2_model_gradient_end_to_end_within_the_cpu_paths_own_sensitivity(cfg2_step):
+    """End to end, the training gradient of this model is NOT a smooth function at fp32 resolution: 22 M max-pool
+    windows, PReLU kinks and global-max picks sit in front of a head whose two BatchNorm1d layers normalise over the
+    4 samples of this batch.  Measured when this test was written: on the CPU, in fp32, a 1e-6 RELATIVE perturbation of
+    the waveform moves parameter gradients by 3-4 % of their scale; the fp32 CPU path is 0.9 % from its own fp64
+    evaluation; the (exactly matching, see the stage-wise test) head turns the 3e-5 feature differences between two
+    correct forwards into a 6 % difference of the feature gradient.  An element-wise 1e-3 bound is therefore
+    unattainable for ANY two implementations; what is asserted: the accelerated gradient is no further from the CPU
+    oracle's than a few times what the oracle moves under that 1e-6 perturbation (global relative L2 over all 21.5 M
+    elements, and per tensor on its own scale).  The tight statements are the per-layer tests above (every conv at
+    these widths against fp64) and the stage-wise test below (every block and the head on IDENTICAL inputs)."""
+    s = cfg2_step
+
+    def oracle_grads(signal):
+        ref = oref.TagCNN2d("mel_2048_1024_128", 6, 100, 1.5, 1, 80)
+        ref.load_state_dict(s["state"])
+        ref.train()
+        logits = ref(signal)["class_logits"]
+        oref.lsep(logits, s["labels"], average=False).mean().backward()
+        return logits.detach(), {k: p.grad.detach().clone() for k, p in ref.named_parameters()}
+
+    rl, r32 = oracle_grads(s["signal"])
+    gen = torch.Generator().manual_seed(1)
+    _, rpert = oracle_grads(s["signal"] * (1.0 + 1e-6 * torch.randn(s["signal"].shape, generator=gen)))
+    assert float((s["logits"] - rl).abs().max()) < 1e-3
+    yard = _relative_l2(rpert, r32)
+    ours = _relative_l2(s["grads"], r32)
+    worst_y = max(float((rpert[k] - r32[k]).abs().max()) / max(1.0, float(r32[k].abs().max())) for k in r32)
+    worst_o = max(float((s["grads"][k] - r32[k]).abs().max()) / max(1.0, float(r32[k].abs().max())) for k in r32)
+    cos = sum(float((s["grads"][k].double() * r32[k].double()).sum()) for k in r32) / (
+        sum(float(s["grads"][k].double().pow(2).sum()) for k in r32) ** 0.5 * sum(float(r32[k].double().pow(2).sum()) for k in r32) ** 0.5)
+    _report("cfg2 model gradient end to end: relative L2 to the CPU oracle %.3e (oracle under a 1e-6 input perturbation %.3e); "
+            "worst per-tensor scaled diff %.3e (%.3e); cosine %.6f" % (ours, yard, worst_o, worst_y, cos))
+    assert ours < 5.0 * yard + 1e-3, (ours, yard)
+    assert worst_o < 5.0 * worst_y + 1e-3, (worst_o, worst_y)
+    assert cos > 0.99
+
+
+@pytest.mark.parametrize("stage", [0, 1, 2, 3, 4, 5, "head"])
+def test_cfg2_stagewise_gradients_on_identical_inputs(cfg2_step, stage):
+    """Every conv block of the cfg-2 model at its real width and plane (100 ch @ 128 x 431 ... 759 ch @ 4 x 13), and
+    the classifier head (1977 features), forward AND backward on inputs and upstream gradients that are bit-identical
+    for the accelerated block and the CPU oracle's block (the oracle's own activations of the golden batch): output,
+    deep-supervision feature, input gradient and all 22 parameter gradients."""
     s = cfg2_step
     ref = oref.TagCNN2d("mel_2048_1024_128", 6, 100, 1.5, 1, 80)
     ref.load_state_dict(s["state"])
     ref.train()
-    rl = ref(s["signal"])["class_logits"]
-    oref.lsep(rl, s["labels"], average=False).mean().backward()
-    r32 = {k: p.grad.detach().clone() for k, p in ref.named_parameters()}
-    ref64 = oref.TagCNN2d("mel_2048_1024_128", 6, 100, 1.5, 1, 80).double()
-    ref64.load_state_dict({k: (v.double() if v.is_floating_point() else v) for k, v in s["state"].items()})
-    ref64.filterbank = ref64.filterbank.double()
-    ref64.train()
-    l64 = ref64(s["signal"].double())["class_logits"]
-    oref.lsep(l64, s["labels"].double(), average=False).mean().backward()
-    r64 = {k: p.grad.detach() for k, p in ref64.named_parameters()}
-    assert float((s["logits"].double() - l64.detach()).abs().max()) < 1e-3
-    assert float((s["logits"] - rl.detach()).abs().max()) < 1e-3
-    tot_p = tot_r = 0.0
-    for k, gp in s["grads"].items():
-        scale = max(1.0, float(r64[k].abs().max()))
-        d32 = (gp.double() - r32[k].double()).abs()
-        assert float(d32.max()) < 2e-3 * scale, (k, float(d32.max()), scale)          # see check_cfg2_step_against_golden
-        assert float(d32.pow(2).mean().sqrt()) < 5e-4 * scale, k
-        ep = float((gp.double() - r64[k]).pow(2).sum())
-        er = float((r32[k].double() - r64[k]).pow(2).sum())
-        tot_p += ep
-        tot_r += er
-    _report("cfg2 model step vs fp64 oracle: sum sq grad error product %.3e, fp32 CPU oracle %.3e" % (tot_p, tot_r))
-    assert tot_p < 9.0 * tot_r + 1e-12, (tot_p, tot_r)          # within 3x in rms of the fp32 CPU path's own error
+    m = s["model"]
+    m.load_state_dict(s["state"])
+    m.train()
+    for p in m.parameters():
+        p.grad = None                       # (the fixture's full step left its gradients there)
+    gen = torch.Generator().manual_seed(17)
+    with torch.no_grad():
+        x = ref.front_end(s["signal"])
+        feats = []
+        for k, blk in enumerate(ref.conv_modules):
+            if k == stage:
+                break
+            x = blk(x)
+            if k >= 1:
+                feats.append(TF.adaptive_max_pool2d(x, 1).flatten(1))
+    if stage == "head":
+        f_in = torch.cat(feats, -1)
+        fr = f_in.clone().requires_grad_()
+        rl = ref.output_transform(fr)
+        oref.lsep(rl, s["labels"], average=False).mean().backward()
+        fp = f_in.to(DEV).requires_grad_()
+        ot = m.output_transform
+        z = F.bn_act(fp, ot[0], None, True)
+        z = F.linear(z, ot[1].weight, ot[1].bias)
+        z = F.bn_act(z, ot[2], ot[3], True)
+        ml = F.linear(z, ot[5].weight, ot[5].bias)
+        F.mean(lsep_loss(ml, s["labels"].to(DEV), average=False)).backward()
+        pairs = [("logits", ml, rl), ("d feats", fp.grad, fr.grad)]
+        pairs += [("grad " + k, p.grad, dict(ref.output_transform.named_parameters())[k].grad) for k, p in ot.named_parameters()]
+    else:
+        blk, mods = ref.conv_modules[stage], m.conv_modules[stage]
+        xr = x.clone().requires_grad_(stage > 0)
+        out_r = blk(xr)
+        feat_r = TF.adaptive_max_pool2d(out_r, 1).flatten(1)
+        g_out = 1e-3 * torch.randn(out_r.shape, generator=gen)
+        g_feat = 1e-2 * torch.randn(feat_r.shape, generator=gen)
+        want_head = stage >= 1
+        last = stage == 5
+        torch.autograd.backward([out_r] + ([feat_r] if want_head else []), [g_out * (0.0 if last else 1.0)] + ([g_feat] if want_head else []))
+        xp = x.to(DEV).requires_grad_(stage > 0)
+        out_p, feat_p = F.conv_block(xp, mods, True, want_head, 2)
+        if last:
+            torch.autograd.backward([feat_p], [g_feat.to(DEV)])            # the last block only feeds its head
+        else:
+            torch.autograd.backward([out_p] + ([feat_p] if want_head else []), [g_out.to(DEV)] + ([g_feat.to(DEV)] if want_head else []))
+        pairs = [("out", out_p, out_r)]
+        if want_head:
+            pairs.append(("feat", feat_p, feat_r))
+        if stage > 0:
+            pairs.append(("dx", xp.grad, xr.grad))
+        rp = dict(blk.named_parameters())
+        pairs += [("grad " + k, p.grad, rp[k].grad) for k, p in mods.named_parameters()]
+    worst = ("", 0.0)
+    for name, got, want in pairs:
+        got, want = got.detach().cpu().double(), want.detach().double()
+        scale = max(1.0, float(want.abs().max())) if name.startswith("grad") or name.startswith("d") else 1.0
+        d = (got - want).abs() / scale
+        if float(d.max()) > worst[1]:
+            worst = (name, float(d.max()))
+        # inside one block a 2 x 2 pool window (or a global-max pick) whose two largest values differ by less than fp32
+        # rounding may still go the other way: on the large tensors allow a sliver of elements beyond 1e-3, none
+        # beyond 5e-3; every tensor within 1e-3 in rms (the worst are the first BatchNorm's dgamma / dbeta of blocks 0
+        # and 1 -- fp32 sums over 220 k .. 5.5 M positions on both sides -- at 2 .. 5e-4 of their scale)
+        assert float(d.max()) < 5e-3, (stage, name, float(d.max()))
+        if d.numel() > 10000:
+            assert float((d > 1e-3).double().mean()) < 2e-3, (stage, name, float((d > 1e-3).double().mean()))
+        assert float(d.pow(2).mean().sqrt()) < 1e-3, (stage, name, float(d.pow(2).mean().sqrt()))
+    _report("cfg2 stage %s on identical inputs: worst scaled difference %.2e (%s)" % (stage, worst[1], worst[0]))
 
 
 # ------------------------------------------------------------------------------ split-fp16 where it can break

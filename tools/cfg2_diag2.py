@@ -61,3 +61,37 @@ for k in range(5, -1, -1):
     if outs_p[k].grad is not None:
         d = (outs_p[k].grad.cpu().double() - outs_r[k].grad.double())
         print("     per-sample rel:", ["%.1e" % float(d[i].norm() / (outs_r[k].grad[i].double().norm() + 1e-30)) for i in range(4)])
+if os.environ.get("HEAD"):
+    d = (fp.grad.cpu().double() - fr.grad.double()).abs()
+    flat = torch.topk(d.flatten(), 8).indices
+    for idx in flat.tolist():
+        r, c = divmod(idx, d.shape[1])
+        print("row %d feat %4d  grad ours %.5e ref %.5e | feats column (ours) %s (ref) %s" % (
+            r, c, float(fp.grad[r, c]), float(fr.grad[r, c]), fp.detach().cpu()[:, c].tolist(), fr.detach()[:, c].tolist()))
+    print("per-row rel diff of d feats:", [float(d[i].norm() / fr.grad[i].double().norm()) for i in range(4)])
+    cols = d.sum(0)
+    print("columns carrying 90%% of the difference: %d of %d" % (int((torch.cumsum(torch.sort(cols, descending=True).values, 0) < 0.9 * cols.sum()).sum()) + 1, cols.numel()))
+    # stage by stage through the head on the CPU with OUR features and OUR upstream gradient
+    var = fr.detach().var(0, unbiased=False)
+    print("smallest batch variances of the features:", torch.sort(var).values[:6].tolist())
+if os.environ.get("HEAD"):
+    # our head on the ORACLE's features
+    fq = fr.detach().cuda().requires_grad_()
+    for bn in (ot[0], ot[2]):
+        bn.running_mean.zero_(); bn.running_var.fill_(1.0)
+    z = F.bn_act(fq, ot[0], None, True); z = F.linear(z, ot[1].weight, ot[1].bias); z = F.bn_act(z, ot[2], ot[3], True)
+    ml2 = F.linear(z, ot[5].weight, ot[5].bias)
+    F.mean(lsep_loss(ml2, labels.cuda(), average=False)).backward()
+    print("our head on the oracle's features: logits", rel(ml2, rl), " d feats", rel(fq.grad, fr.grad))
+    # the oracle's head on OUR features
+    fo = fp.detach().cpu().requires_grad_()
+    rl2 = ref.output_transform(fo)
+    oref.lsep(rl2, labels, average=False).mean().backward()
+    print("oracle head on our features: d feats vs oracle-on-own", rel(fo.grad, fr.grad), " ours vs oracle-on-ours", rel(fp.grad, fo.grad))
+    # fp64 head on both feature sets
+    import copy
+    h64 = copy.deepcopy(ref.output_transform).double()
+    for src, name in ((fr, "oracle feats"), (fp, "our feats")):
+        f64 = src.detach().cpu().double().requires_grad_()
+        oref.lsep(h64(f64), labels.double(), average=False).mean().backward()
+        print("fp64 head on %s: d feats vs fp32 oracle %s, vs ours %s" % (name, "%.2e %.2e %.2e" % rel(fr.grad, f64.grad), "%.2e %.2e %.2e" % rel(fp.grad, f64.grad)))
