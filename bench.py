@@ -41,10 +41,11 @@ WORKLOADS = {
     "cfg2": dict(features="mel_2048_1024_128", blocks=6, base=100, growth=1.5, start=1, dropout=0.7,
                  batch=128, samples=441000, sr=44100, n_mel=128),
     # BASELINE.json configs[2]: 1-d raw-STFT path (win 256), 10-block hierarchical CNN, LSEP + MixUp.
-    # hop 128 / base 64 / growth 1.25 are SURVEY section 8d's assumptions; computed in fp32 here
-    # (bf16 is not implemented yet, the line says dtype f32).
+    # hop 128 / base 64 / growth 1.25 are SURVEY section 8d's assumptions.  bf16: conv operands rounded to one bf16
+    # value, v_mfma_f32_16x16x32_bf16 with fp32 accumulation; weights / BN statistics / optimizer state fp32 masters
+    # (`--arith f32` or `f16x3` re-times the same workload in fp32).
     "cfg3": dict(features="stft_256_128", blocks=10, base=64, growth=1.25, start=1, dropout=0.0,
-                 batch=128, samples=441000, sr=44100, n_mel=129, dims=1, mixup=0.5),
+                 batch=128, samples=441000, sr=44100, n_mel=129, dims=1, mixup=0.5, arith="bf16"),
     # BASELINE.json configs[0] shape (used for quick checks: --workload cfg1)
     "cfg1": dict(features="mel_1024_512_64", blocks=3, base=32, growth=2, start=1, dropout=0.0,
                  batch=64, samples=32000, sr=16000, n_mel=64),
@@ -212,7 +213,7 @@ def run_inference(args, w, device, world, rank):
                                        inf["clips"], inf["min_s"], inf["max_s"], w["sr"] / 1e3, seconds, len(batches),
                                        inf["bucket_s"], w["batch"], w["samples"] / w["sr"], inf["folds"]),
                        "parallelism": "dp%d (batches round-robin)" % world,
-                       "conv_arith": {0: "f32", 3: "f16x3", 6: "bf16x6", 9: "bf16x9"}[F.get_conv_arith()]},
+                       "conv_arith": {0: "f32", 1: "bf16", 3: "f16x3", 6: "bf16x6", 9: "bf16x9"}[F.get_conv_arith()]},
             "audio_seconds_per_s": seconds * (clips_all / inf["clips"]) / tmax,
             "reference_claim": "README.md:37: stage-1 test set, 5 folds, 'only 1 minute' (hardware unspecified)",
         }
@@ -241,6 +242,8 @@ def main():
     ap.add_argument("--no-alt", action="store_true", help="skip the extra native-fp32-MFMA measurement (alt_f32)")
     ap.add_argument("--no-kernel-timer", action="store_true")
     ap.add_argument("--kernel-table", action="store_true", help="print per-kernel timing to stderr")
+    ap.add_argument("--arith", default=None, choices=["f32", "bf16", "f16x3", "bf16x6", "bf16x9"],
+                    help="conv arithmetic (default: the workload's, else the library default f16x3)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -263,6 +266,8 @@ def main():
     from freesound_classification_amd.ops.training import make_step
 
     w = WORKLOADS[args.workload]
+    if args.arith or w.get("arith"):
+        F.set_conv_arith(args.arith or w["arith"])
     if "inference" in w:
         if "--steps" not in sys.argv:
             args.steps = 0                      # one pass over every length-grouped batch
@@ -319,7 +324,7 @@ def main():
     # The same workload with the native fp32-MFMA conv kernels (FSC_CONV_ARITH=f32), for readers who want the
     # number without the split-limb arithmetic; N = 1 only, outside the timed region of `value`.
     alt = None
-    if world == 1 and not args.no_alt and F.get_conv_arith() != 0:
+    if world == 1 and not args.no_alt and F.get_conv_arith() not in (0, 1):
         mode0 = F.get_conv_arith()
         F.set_conv_arith(0)
         for _ in range(2):
@@ -389,14 +394,16 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32",       # tensors, accumulators and results are fp32; see roofline.arithmetic for the conv products
+            # f32: tensors, accumulators and results are fp32 (see roofline.arithmetic for how the conv products are formed);
+            # bf16: conv operands rounded to bf16, fp32 accumulation / storage / master weights
+            "dtype": "bf16" if F.get_conv_arith() == 1 else "f32",
             "data": "synthetic",
             "config": {"workload": "%s: batch %d x %.0f s @ %.1f kHz, %s, %d-block %dd CNN base %d growth %g, "
                                    "LSEP, Adam-amsgrad, dropout %g" % (
                                        args.workload, batch, w["samples"] / w["sr"], w["sr"] / 1e3, w["features"],
                                        w["blocks"], w.get("dims", 2), w["base"], w["growth"], w["dropout"]),
                        "global_batch": world * batch, "parallelism": "dp%d" % world,
-                       "conv_arith": {0: "f32", 3: "f16x3", 6: "bf16x6", 9: "bf16x9"}[F.get_conv_arith()]},
+                       "conv_arith": {0: "f32", 1: "bf16", 3: "f16x3", 6: "bf16x6", 9: "bf16x9"}[F.get_conv_arith()]},
             "final_loss": final_loss,
         }
         if timer is not None:
@@ -425,6 +432,8 @@ def main():
                 executed_per_flop = int(dom_name.rstrip(">").split(",")[-1])
                 peak = PEAK_BF16_MFMA_TFLOPS
                 arith = "fp32 via exact 3-limb bf16 split, %d bf16 MFMA products per fp32 product, fp32 accumulate" % executed_per_flop
+                if executed_per_flop == 1:
+                    arith = "bf16 operands (one rounding each), bf16 MFMA, fp32 accumulate"
                 if executed_per_flop == 3:      # (the dense fp16 and bf16 MFMA peaks are equal)
                     arith = ("fp32 via 2-limb fp16 split with per-tensor power-of-two scaling, 3 fp16 MFMA products "
                              "per fp32 product, fp32 accumulate")

@@ -78,6 +78,12 @@ SIGNATURES = {
     "fsc_mixup_batch": (_I, [_P] * 8 + [_I, _L, _L, _L, _P, _P, _P, _I, _P]),
     "fsc_mixup_rows": (_I, [_P] * 9 + [_I, _L, _L, _L, _P, _P, _P, _I, _P]),
     "fsc_segments_gather": (_I, [_P, _L, _P, _P, _P, _P, _I, _P, _I, _L, _P]),
+    "fsc_freq_mean_fwd": (_I, [_P, _P, _I, _I, _I, _I, _P]),
+    "fsc_freq_mean_bwd": (_I, [_P, _P, _I, _I, _I, _I, _P]),
+    "fsc_layernorm_fwd": (_I, [_P, _P, _P, _F, _P, _P, _P, _L, _I, _P]),
+    "fsc_layernorm_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _P]),
+    "fsc_gru_step_fwd": (_I, [_P, _L, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P]),
+    "fsc_gru_step_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _L, _P, _P, _I, _I, _P]),
     "fsc_adam_amsgrad_step": (_I, [C.POINTER(OptTensor), _I, _F, _F, _F, _F, _F, _I, _F, _P]),
     "fsc_sgd_nesterov_step": (_I, [C.POINTER(OptTensor), _I, _F, _F, _F, _I, _F, _P]),
     "fsc_fill": (_I, [_P, _F, _L, _P]),

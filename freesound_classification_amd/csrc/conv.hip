@@ -431,8 +431,8 @@ __global__ __launch_bounds__(kXWaves * 64) void conv_fwd_x3_kernel(Geom g, const
     constexpr int TAPS = KH * KW;
     constexpr int CO_BLK = COT * 16;
     constexpr int PADH = KH / 2, PADW = KW / 2;
-    constexpr bool F16 = NPROD == 3;                // two scaled fp16 limbs, 3 products; else three bf16 limbs, 6 / 9
-    constexpr int NL = F16 ? 2 : 3;                 // limbs per value
+    constexpr bool F16 = NPROD == 3;                // two scaled fp16 limbs, 3 products; else three bf16 limbs, 6 / 9 ...
+    constexpr int NL = NPROD == 1 ? 1 : F16 ? 2 : 3;   // ... or ONE bf16 limb, one product: plain bf16 arithmetic (NPROD = 1)
     constexpr int KCH = kXChunk;                    // channels per K chunk
     constexpr int SPC = TAPS;                       // steps per full chunk (one per tap)
     constexpr int NSTG = TAPS == 1 ? (PT == 2 ? 3 : 4) : 2;   // input stages: the input DMA runs NSTG - 1 chunks ahead
@@ -710,6 +710,9 @@ __global__ __launch_bounds__(kXWaves * 64) void conv_fwd_x3_kernel(Geom g, const
                 dst.v[0][j][q] = hp;
                 dst.v[1][j][q] = lp;
             }
+        } else if constexpr (NL == 1) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) dst.v[0][j][q] = cvt_pk_bf16(x[2 * q], x[2 * q + 1]);
         } else {
             split3(x, dst.v[0][j], dst.v[1][j], dst.v[2][j]);
         }
@@ -816,6 +819,15 @@ __global__ __launch_bounds__(kXWaves * 64) void conv_fwd_x3_kernel(Geom g, const
                                 }
                             }
                         }
+                    } else if constexpr (NL == 1) {
+                        if (sp == i) {
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                unsigned hp = cvt_pk_bf16(raw[j][2 * q], raw[j][2 * q + 1]);
+                                asm volatile("" : "+v"(hp));
+                                nxt.v[0][j][q] = hp;
+                            }
+                        }
                     } else if (sp == i && gq >= 2 && gq < 6) {
                         const int q = gq - 2;
                         const float x0 = raw[j][2 * q], x1 = raw[j][2 * q + 1];
@@ -835,8 +847,8 @@ __global__ __launch_bounds__(kXWaves * 64) void conv_fwd_x3_kernel(Geom g, const
                 constexpr int kPairA[9] = {1, 0, 2, 0, 1, 0, 2, 1, 2};      // bf16: 0 = h, 1 = m, 2 = l
                 constexpr int kPairB[9] = {1, 2, 0, 1, 0, 0, 2, 2, 1};      // x6 uses the first six
                 constexpr int kPairA2[3] = {1, 0, 0}, kPairB2[3] = {0, 1, 0};   // fp16: 0 = h, 1 = l
-                const int pa = F16 ? kPairA2[gq % 3] : NPROD == 9 ? kPairA[(gq + 6) % 9] : kPairA[gq % 9];
-                const int pb = F16 ? kPairB2[gq % 3] : NPROD == 9 ? kPairB[(gq + 6) % 9] : kPairB[gq % 9];
+                const int pa = NL == 1 ? 0 : F16 ? kPairA2[gq % 3] : NPROD == 9 ? kPairA[(gq + 6) % 9] : kPairA[gq % 9];
+                const int pb = NL == 1 ? 0 : F16 ? kPairB2[gq % 3] : NPROD == 9 ? kPairB[(gq + 6) % 9] : kPairB[gq % 9];
 #pragma unroll
                 for (int j = 0; j < PT; ++j)
                     acc[i][j] = mfma_k32<F16>(a[i & 1][pa], cur.v[pb][j], acc[i][j]);
@@ -1043,7 +1055,7 @@ __global__ __launch_bounds__(256) void amax_kernel(const float* __restrict__ x, 
 // `w_amax` != null: two fp16 limbs of the weights scaled by scale_field(*w_amax) instead of three bf16 limbs
 __global__ void pack_x3_kernel(const float* __restrict__ w, unsigned short* __restrict__ packed, int c_out, int c_in,
                                int taps, int cot, int co_blocks, int nfull, int tail_oct, int steps, int nch, int dgrad,
-                               const float* __restrict__ w_amax) {
+                               const float* __restrict__ w_amax, int nl) {
     const long total = (long)co_blocks * steps * cot * 512;
     const float sw = w_amax ? field_to_float(scale_field(*w_amax)) : 1.f;
     for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
@@ -1073,12 +1085,13 @@ __global__ void pack_x3_kernel(const float* __restrict__ w, unsigned short* __re
             continue;
         }
         const unsigned hp = cvt_pk_bf16(v, 0.f);
+        const long base = ((((long)cb * steps + S) * cot + i) * nl) * 512 + lane * 8 + e;
+        packed[base] = (unsigned short)hp;
+        if (nl == 1) continue;                               // plain bf16: one limb
         const float r = v - __uint_as_float(hp << 16);
         const unsigned mp = cvt_pk_bf16(r, 0.f);
         const float r2 = r - __uint_as_float(mp << 16);
         const unsigned lp = cvt_pk_bf16(r2, 0.f);
-        const long base = ((((long)cb * steps + S) * cot + i) * 3) * 512 + lane * 8 + e;
-        packed[base] = (unsigned short)hp;
         packed[base + 512] = (unsigned short)mp;
         packed[base + 1024] = (unsigned short)lp;
     }
@@ -1654,7 +1667,7 @@ __global__ __launch_bounds__(kWgxWaves * 64) void conv_wgrad_x3_kernel(WgxGeom g
     constexpr int PADH = KH / 2;
     constexpr int DSO = kWgxDso;
     constexpr bool F16 = NPROD == 3;                         // two scaled fp16 limbs, 3 products (see conv_fwd_x3_kernel)
-    constexpr int NL = F16 ? 2 : 3;
+    constexpr int NL = NPROD == 1 ? 1 : F16 ? 2 : 3;         // NPROD = 1: one bf16 limb (plain bf16 arithmetic)
     constexpr int MAXI = 4;                                  // input DMA instructions per channel (<= 256 staged floats)
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -1826,6 +1839,9 @@ __global__ __launch_bounds__(kWgxWaves * 64) void conv_wgrad_x3_kernel(WgxGeom g
                                 al[i][0][q] = hp;
                                 al[i][1][q] = lp;
                             }
+                        } else if constexpr (NL == 1) {
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) al[i][0][q] = cvt_pk_bf16(x[2 * q], x[2 * q + 1]);
                         } else {
                             split3(x, al[i][0], al[i][1], al[i][NL - 1]);
                         }
@@ -1856,7 +1872,7 @@ __global__ __launch_bounds__(kWgxWaves * 64) void conv_wgrad_x3_kernel(WgxGeom g
                         }
                     }
 #pragma unroll
-                    for (int lv = 0; lv < (F16 ? 0 : 3); ++lv) {
+                    for (int lv = 0; lv < (F16 ? 0 : NL); ++lv) {
                         unsigned P[5];
 #pragma unroll
                         for (int k = 0; k < 5; ++k) P[k] = cvt_pk_bf16(res[2 * k], res[2 * k + 1]);
@@ -1864,7 +1880,7 @@ __global__ __launch_bounds__(kWgxWaves * 64) void conv_wgrad_x3_kernel(WgxGeom g
                         for (int k = 0; k < 4; ++k) bq[1][lv][k] = cvt_pk_bf16(res[2 * k + 1], res[2 * k + 2]);
                         bq[0][lv] = (u32x4){P[0], P[1], P[2], P[3]};
                         bq[2][lv] = (u32x4){P[1], P[2], P[3], P[4]};
-                        if (lv < 2) {
+                        if (lv + 1 < NL) {
 #pragma unroll
                             for (int k = 0; k < 5; ++k) {
                                 res[2 * k] = fsub(res[2 * k], __uint_as_float(P[k] << 16));
@@ -1893,8 +1909,8 @@ __global__ __launch_bounds__(kWgxWaves * 64) void conv_wgrad_x3_kernel(WgxGeom g
                         if (i < mt_live) {
 #pragma unroll
                             for (int gq = 0; gq < NPROD; ++gq) {
-                                const int pa = F16 ? kPairA2[gq % 3] : NPROD == 9 ? kPairA[(gq + 6) % 9] : kPairA[gq % 9];
-                                const int pb = F16 ? kPairB2[gq % 3] : NPROD == 9 ? kPairB[(gq + 6) % 9] : kPairB[gq % 9];
+                                const int pa = NL == 1 ? 0 : F16 ? kPairA2[gq % 3] : NPROD == 9 ? kPairA[(gq + 6) % 9] : kPairA[gq % 9];
+                                const int pb = NL == 1 ? 0 : F16 ? kPairB2[gq % 3] : NPROD == 9 ? kPairB[(gq + 6) % 9] : kPairB[gq % 9];
 #pragma unroll
                                 for (int tx = 0; tx < KW; ++tx)
                                     acc[ty][tx][i] = mfma_k32<F16>(al[i][pa], bq[KW == 1 ? 1 : tx][pb], acc[ty][tx][i]);
@@ -1963,8 +1979,9 @@ struct FwdPlan {
 };
 
 // floats of the packed limb fragments of an x3 plan (fp16 limbs: followed by 4 floats holding the weights' amax)
+int limbs_of(int nprod) { return nprod == 1 ? 1 : nprod == 3 ? 2 : 3; }
 size_t x3_limb_floats(const FwdPlan& p) {
-    return (size_t)p.co_blocks * p.g.x_steps * p.cot * (p.x3 == 3 ? 2 : 3) * 256;
+    return (size_t)p.co_blocks * p.g.x_steps * p.cot * limbs_of(p.x3) * 256;
 }
 
 // Arithmetic of the conv kernels: 0 = native fp32 MFMA everywhere; 3 = scaled split-fp16 (two limbs, three
@@ -1975,6 +1992,7 @@ int default_arith() {
     static const int mode = [] {
         const char* e = getenv("FSC_CONV_ARITH");
         if (e && !strcmp(e, "f32")) return 0;
+        if (e && !strcmp(e, "bf16")) return 1;
         if (e && !strcmp(e, "bf16x6")) return 6;
         if (e && !strcmp(e, "bf16x9")) return 9;
         return 3;
@@ -2050,7 +2068,7 @@ bool plan_fwd_x3_pt(const fsc_conv_desc& d_in, int dgrad, int nprod, int pt, int
     g.flat = 0;
     const int pix_cap = kXWaves * p.pt * 16;
     const size_t lds_total = 160 * 1024;
-    const size_t ring = (size_t)((p.cot > 8 || (taps == 1 && pt == 2)) ? 2 : 3) * p.cot * (nprod == 3 ? 2 : 3) * 1024;
+    const size_t ring = (size_t)((p.cot > 8 || (taps == 1 && pt == 2)) ? 2 : 3) * p.cot * limbs_of(nprod) * 1024;
     const size_t scratch = (size_t)kXWaves * 16 * 20 * sizeof(float);      // per-wave epilogue transpose tiles
     int cap_pos = (int)((lds_total - ring - scratch) / (nstg * kch * sizeof(float))) - 4;
     if (cap_pos > 64 * kXNptMax - 4) cap_pos = 64 * kXNptMax - 4;
@@ -2268,6 +2286,7 @@ template <int KH, int KW, int COT, int PT>
 void launch_x3_arith(const FwdPlan& p, dim3 grid, const float* in, const float* packed, const float* bias, float* out,
                      int accumulate, const float* in_amax, hipStream_t st) {
     if (p.x3 == 3) launch_x3_pt<KH, KW, COT, PT, 3>(p, grid, in, packed, bias, out, accumulate, in_amax, st);
+    else if (p.x3 == 1) launch_x3_pt<KH, KW, COT, PT, 1>(p, grid, in, packed, bias, out, accumulate, in_amax, st);
     else if (p.x3 == 6) launch_x3_pt<KH, KW, COT, PT, 6>(p, grid, in, packed, bias, out, accumulate, in_amax, st);
     else launch_x3_pt<KH, KW, COT, PT, 9>(p, grid, in, packed, bias, out, accumulate, in_amax, st);
 }
@@ -2370,7 +2389,7 @@ bool stem_shape(const fsc_conv_desc& d) {
 
 bool valid_desc(const fsc_conv_desc* d) {
     if (!d || d->n <= 0 || d->c_in <= 0 || d->c_out <= 0 || d->h <= 0 || d->w <= 0) return false;
-    if (!(d->arith == FSC_ARITH_DEFAULT || d->arith == 0 || d->arith == 3 || d->arith == 6 || d->arith == 9)) return false;
+    if (!(d->arith == FSC_ARITH_DEFAULT || d->arith == 0 || d->arith == 1 || d->arith == 3 || d->arith == 6 || d->arith == 9)) return false;
     const bool k33 = d->kh == 3 && d->kw == 3, k11 = d->kh == 1 && d->kw == 1, k13 = d->kh == 1 && d->kw == 3;
     if (!(k33 || k11 || k13)) return false;
     const long big = 1L << 31;
@@ -2592,6 +2611,7 @@ int launch_wgrad_x3(const WgxPlan& p, const float* in, const float* dout, float*
                     const float* dout_amax, hipStream_t st) {
 #define FSC_WGX(MT_)                                                                                          \
     if (p.nprod == 3) launch_wgrad_x3_k<KH, KW, MT_, 3>(p, in, dout, part, in_amax, dout_amax, st);          \
+    else if (p.nprod == 1) launch_wgrad_x3_k<KH, KW, MT_, 1>(p, in, dout, part, in_amax, dout_amax, st);     \
     else if (p.nprod == 6) launch_wgrad_x3_k<KH, KW, MT_, 6>(p, in, dout, part, in_amax, dout_amax, st);     \
     else launch_wgrad_x3_k<KH, KW, MT_, 9>(p, in, dout, part, in_amax, dout_amax, st);                       \
     break;
@@ -2666,7 +2686,7 @@ int fsc_conv_pack_weights(const fsc_conv_desc* d, const float* weight, int dgrad
         }
         hipLaunchKernelGGL(pack_x3_kernel, dim3((unsigned)xb), dim3(256), 0, fsc::as_stream(stream), weight,
                            reinterpret_cast<unsigned short*>(packed), d->c_out, d->c_in, d->kh * d->kw, p.cot, p.co_blocks,
-                           p.g.x_nfull, p.g.x_tail_oct, p.g.x_steps, 1, dgrad, w_amax);
+                           p.g.x_nfull, p.g.x_tail_oct, p.g.x_steps, 1, dgrad, w_amax, limbs_of(p.x3));
         FSC_LAUNCH_CHECK("fsc_conv_pack_weights(x3)");
         return 0;
     }

@@ -155,16 +155,19 @@ class _timed:
             TIMER.records.append((self.name, self.flops, self.e0, self.e1))
 
 
+ARITH_NAMES = {"f32": 0, "bf16": 1, "f16x3": 3, "bf16x6": 6, "bf16x9": 9}
+
+
 def set_conv_arith(mode):
     """Arithmetic the descriptors built by this module ask for (fsc_conv_desc.arith, include/fsc_hip.h).
     0 / "f32": native fp32 MFMA; 3 / "f16x3" (the default): fp32 via two fp16 limbs with exact power-of-two
     operand scaling, three limb products; 6, 9 / "bf16x6", "bf16x9": fp32 via exact three-limb bf16 split with
-    that many limb products; None: back to the library default (FSC_CONV_ARITH or 3).  Host-side convenience only:
+    that many limb products; 1 / "bf16": plain bf16 operands, fp32 accumulation (mixed precision, cfg 3); None: back to the library default (FSC_CONV_ARITH or 3).  Host-side convenience only:
     the C ABI takes the mode per call."""
     global _ARITH
-    mode = {"f32": 0, "f16x3": 3, "bf16x6": 6, "bf16x9": 9}.get(mode, mode)
-    if mode is not None and int(mode) not in (0, 3, 6, 9):
-        raise _lib.FscError("conv arithmetic must be 0 (f32), 3 (f16x3), 6 (bf16x6) or 9 (bf16x9); got %r" % (mode,))
+    mode = ARITH_NAMES.get(mode, mode)
+    if mode is not None and int(mode) not in (0, 1, 3, 6, 9):
+        raise _lib.FscError("conv arithmetic must be 0 (f32), 1 (bf16), 3 (f16x3), 6 (bf16x6) or 9 (bf16x9); got %r" % (mode,))
     _ARITH = None if mode is None else int(mode)
 
 

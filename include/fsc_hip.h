@@ -71,7 +71,7 @@ int fsc_frontend_stft_fwd(const float* wave, int n, int t, long wave_stride,
 typedef struct {
     int n, c_in, c_out, h, w; /* output spatial size == input spatial size (stride 1, same pad) */
     int kh, kw;               /* (3,3), (1,1), (1,3) */
-    int arith;                /* arithmetic of THIS call: 0, 3, 6, 9 (below) or FSC_ARITH_DEFAULT */
+    int arith;                /* arithmetic of THIS call: 0, 1, 3, 6, 9 (below) or FSC_ARITH_DEFAULT */
 } fsc_conv_desc;
 
 /* floats of packed-weight workspace for one direction (fwd or dgrad) */
@@ -110,11 +110,14 @@ int fsc_conv_plan_describe(const fsc_conv_desc* d, int mode, char* buf, size_t b
  * from the 3 limb products hh + hl + lh on v_mfma_f32_16x16x32_f16 with fp32 accumulation and unscaled exactly
  * (dropped term ll <= 2^-22 |a*b|).  An operand holding +-Inf (declared maximum Inf) makes every output of the
  * call non-finite; NaN elements propagate to the outputs they touch.
+ * 1: plain bf16 arithmetic (BASELINE.json configs[2]): every operand is rounded to ONE bf16 value (round to nearest
+ * even), products on v_mfma_f32_16x16x32_bf16 with fp32 accumulation -- the usual mixed-precision recipe with fp32
+ * master weights; relative operand error 2^-9, NOT fp32-accurate.
  * 6 / 9: every fp32 operand is split exactly into three bf16 limbs and the product is formed from 6 / 9
  * limb products on v_mfma_f32_16x16x32_bf16 with fp32 accumulation (9 = all terms: the product is exact
  * before accumulation; 6 drops terms below 2^-23 |a*b|).  Inputs, outputs and accumulators are fp32
  * in every mode.  FSC_ARITH_DEFAULT selects the process default: 3, or the environment variable
- * FSC_CONV_ARITH = f32 | f16x3 | bf16x6 | bf16x9, read once.  The packed-weight format depends on the mode:
+ * FSC_CONV_ARITH = f32 | bf16 | f16x3 | bf16x6 | bf16x9, read once.  The packed-weight format depends on the mode:
  * pack with the descriptor (same `arith`) the weights are used with. */
 int fsc_conv_default_arith(void);
 /* bytes of split-K workspace for the weight gradient */
@@ -257,6 +260,34 @@ int fsc_mixup_rows(const float* a, const float* b, const int* partner, const int
 int fsc_segments_gather(const float* src, long src_stride, const int* src_row, const int* seg_count,
                         const int* seg_src, const int* seg_dst, int max_seg, float* out, int n,
                         long t_out, fsc_stream_t stream);
+
+/* ------------------------------------------------------------------ RNN aggregation head (f-3)
+ * aggregation_type == "rnn" (classifiers.py:514-522, 592-597): rnn_input = mean(h, dim=2).permute(0, 2, 1), then
+ * LayerNorm((C,)) and a bidirectional GRU(C, 128, batch_first=True); the two final hidden states are the block's
+ * features.  The input projections X W_ih^T + b_ih of all time steps and the weight gradients are GEMMs
+ * (fsc_linear_fwd / fsc_linear_bwd); these entry points are the remaining pieces.  Gate order r, z, n; h' = (1 - z) n + z h
+ * (torch.nn.GRU).  All fp32. */
+/* y (N, W, C) = mean over H of x (N, C, H, W); backward writes dx (N, C, H, W) = dy / H broadcast over H */
+int fsc_freq_mean_fwd(const float* x, float* y, int n, int c, int h, int w, fsc_stream_t stream);
+int fsc_freq_mean_bwd(const float* dy, float* dx, int n, int c, int h, int w, fsc_stream_t stream);
+/* LayerNorm over the last dimension of (rows, C): biased variance, eps inside the root; saves mean / rstd per row */
+int fsc_layernorm_fwd(const float* x, const float* gamma, const float* beta, float eps, float* y,
+                      float* mean, float* rstd, long rows, int c, fsc_stream_t stream);
+int fsc_layernorm_bwd(const float* dy, const float* x, const float* mean, const float* rstd,
+                      const float* gamma, float* dx, float* dgamma, float* dbeta, long rows, int c,
+                      fsc_stream_t stream);
+/* One GRU time step for a batch.  gx: rows of 3*hidden input projections [r | z | n] (b_ih included), row stride
+ * gx_stride floats (a time slice of a (N, T, 3*hidden) tensor); w_hh (3*hidden, hidden), b_hh (3*hidden).
+ * r/z/n/ghn_save (batch x hidden each, all NULL in inference) keep what the backward step needs. */
+int fsc_gru_step_fwd(const float* gx, long gx_stride, const float* h_prev, const float* w_hh,
+                     const float* b_hh, float* h_out, float* r_save, float* z_save, float* n_save,
+                     float* ghn_save, int batch, int hidden, fsc_stream_t stream);
+/* Backward of one step: from dh (gradient of h_out) writes dgx (row stride dgx_stride), dgh (batch x 3*hidden: the
+ * gradient of W_hh h + b_hh, input of the W_hh / b_hh gradient GEMM) and dh_prev = dh * z + dgh W_hh. */
+int fsc_gru_step_bwd(const float* dh, const float* r_save, const float* z_save, const float* n_save,
+                     const float* ghn_save, const float* h_prev, const float* w_hh, float* dgx,
+                     long dgx_stride, float* dgh, float* dh_prev, int batch, int hidden,
+                     fsc_stream_t stream);
 
 /* ------------------------------------------------------------------ optimizers (K16)
  * ops/training.py:9-12: Adam(amsgrad=True) and SGD(momentum=0.9, nesterov=True), both with
