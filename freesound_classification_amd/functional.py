@@ -451,6 +451,101 @@ def global_maxpool_forward(x):
     return y, idx
 
 
+# ------------------------------------------------------------------------------ RNN aggregation head
+def _raw_call_ptr(t, offset_floats):
+    """Device address `offset_floats` into a contiguous tensor (a time slice of a (N, T, G) buffer)."""
+    return t.data_ptr() + 4 * offset_floats
+
+
+class RnnHeadFn(torch.autograd.Function):
+    """aggregation_type == "rnn" head of one block (reference networks/classifiers.py:514-522, 592-597; 1-d :137-145,
+    202-207): mean over frequency, LayerNorm((C,)), bidirectional GRU(C, hidden), features = the two final states.
+    Input projections and weight gradients are GEMMs (fsc_linear_*), the recurrence is one fsc_gru_step_* per step."""
+
+    @staticmethod
+    def forward(ctx, out, eps, ln_w, ln_b, w_ih, w_hh, b_ih, b_hh, w_ih_r, w_hh_r, b_ih_r, b_hh_r):
+        out = out.contiguous()
+        n, c, h, w = out.shape
+        hid = w_hh.shape[1]
+        keep = any(ctx.needs_input_grad)
+        xm = _empty((n, w, c), out)
+        call("fsc_freq_mean_fwd", ptr(out), ptr(xm), n, c, h, w, stream_ptr())
+        rows = n * w
+        xl = torch.empty_like(xm)
+        mean, rstd = _empty((rows,), out), _empty((rows,), out)
+        call("fsc_layernorm_fwd", ptr(xm), ptr(ln_w), ptr(ln_b), float(eps), ptr(xl), ptr(mean), ptr(rstd), rows, c, stream_ptr())
+        feats, saved = [], []
+        for rev, (wi, wh, bi, bh) in enumerate(((w_ih, w_hh, b_ih, b_hh), (w_ih_r, w_hh_r, b_ih_r, b_hh_r))):
+            gx = _empty((n, w, 3 * hid), out)
+            call("fsc_linear_fwd", ptr(xl), ptr(wi), ptr(bi), ptr(gx), rows, c, 3 * hid, stream_ptr())
+            hs = _empty((w + 1, n, hid), out)
+            call("fsc_fill", ptr(hs[0]), 0.0, n * hid, stream_ptr())
+            gates = _empty((4, w, n, hid), out) if keep else None
+            for s in range(w):
+                t = w - 1 - s if rev else s
+                g = [ptr(gates[q, s]) for q in range(4)] if keep else [None] * 4
+                call("fsc_gru_step_fwd", _raw_call_ptr(gx, t * 3 * hid), w * 3 * hid, ptr(hs[s]), ptr(wh), ptr(bh),
+                     ptr(hs[s + 1]), g[0], g[1], g[2], g[3], n, hid, stream_ptr())
+            feats.append(hs[w])
+            saved.append((hs, gates))
+        feat = torch.cat(feats, dim=1)
+        if keep:
+            ctx.save_for_backward(xm, xl, mean, rstd, ln_w, w_ih, w_hh, w_ih_r, w_hh_r)
+            ctx.saved_steps = saved
+            ctx.shape = (n, c, h, w, hid)
+        return feat
+
+    @staticmethod
+    def backward(ctx, dfeat):
+        xm, xl, mean, rstd, ln_w, w_ih, w_hh, w_ih_r, w_hh_r = ctx.saved_tensors
+        n, c, h, w, hid = ctx.shape
+        rows = n * w
+        dfeat = dfeat.contiguous()
+        grads = []
+        dxl = None
+        for rev, (wi, wh) in enumerate(((w_ih, w_hh), (w_ih_r, w_hh_r))):
+            hs, gates = ctx.saved_steps[rev]
+            dgx = _empty((n, w, 3 * hid), xm)
+            dgh = _empty((w, n, 3 * hid), xm)
+            dh = dfeat[:, rev * hid:(rev + 1) * hid].contiguous()
+            dh_prev = torch.empty_like(dh)
+            for s in range(w - 1, -1, -1):
+                t = w - 1 - s if rev else s
+                call("fsc_gru_step_bwd", ptr(dh), ptr(gates[0, s]), ptr(gates[1, s]), ptr(gates[2, s]), ptr(gates[3, s]),
+                     ptr(hs[s]), ptr(wh), _raw_call_ptr(dgx, t * 3 * hid), w * 3 * hid, ptr(dgh[s]), ptr(dh_prev), n, hid,
+                     stream_ptr())
+                dh, dh_prev = dh_prev, dh
+            d_wh, d_bh = torch.empty_like(wh), _empty((3 * hid,), xm)
+            call("fsc_linear_bwd", ptr(dgh), ptr(hs[:w]), ptr(wh), None, ptr(d_wh), ptr(d_bh), w * n, hid, 3 * hid, stream_ptr())
+            d_wi, d_bi = torch.empty_like(wi), _empty((3 * hid,), xm)
+            dx_dir = torch.empty_like(xl)
+            call("fsc_linear_bwd", ptr(dgx), ptr(xl), ptr(wi), ptr(dx_dir), ptr(d_wi), ptr(d_bi), rows, c, 3 * hid, stream_ptr())
+            if dxl is None:
+                dxl = dx_dir
+            else:
+                call("fsc_axpy", ptr(dx_dir), 1.0, ptr(dxl), dxl.numel(), stream_ptr())
+            grads += [d_wi, d_wh, d_bi, d_bh]
+        dxm = torch.empty_like(xm)
+        d_lnw, d_lnb = _empty((c,), xm), _empty((c,), xm)
+        call("fsc_layernorm_bwd", ptr(dxl), ptr(xm), ptr(mean), ptr(rstd), ptr(ln_w), ptr(dxm), ptr(d_lnw), ptr(d_lnb), rows, c,
+             stream_ptr())
+        dout = None
+        if ctx.needs_input_grad[0]:
+            dout = _empty((n, c, h, w), xm)
+            call("fsc_freq_mean_bwd", ptr(dxm), ptr(dout), n, c, h, w, stream_ptr())
+        ctx.saved_steps = None
+        return (dout, None, d_lnw, d_lnb) + tuple(grads)
+
+
+def rnn_head(out, rnn):
+    """`rnn` = the reference's nn.Sequential(nn.LayerNorm((C,)), nn.GRU(C, 128, batch_first=True, bidirectional=True))
+    parameter holder; `out` (N, C, H, W) block output (H == 1 for the 1-d model).  Returns (N, 2 * hidden)."""
+    _need_cuda(out, "rnn_head")
+    ln, gru = rnn[0], rnn[1]
+    return RnnHeadFn.apply(out, ln.eps, ln.weight, ln.bias, gru.weight_ih_l0, gru.weight_hh_l0, gru.bias_ih_l0, gru.bias_hh_l0,
+                           gru.weight_ih_l0_reverse, gru.weight_hh_l0_reverse, gru.bias_ih_l0_reverse, gru.bias_hh_l0_reverse)
+
+
 # ------------------------------------------------------------------------------ conv block
 def _conv_params(conv):
     """(weight as 4-d, bias, kh, kw) for nn.Conv2d / nn.Conv1d parameter holders."""

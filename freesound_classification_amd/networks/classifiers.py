@@ -84,9 +84,9 @@ class _TaggingModel(nn.Module):
         self.config = experiment.config
         self.loss_name = loss
         net, data = self.config.network, self.config.data
-        if getattr(net, "aggregation_type", "max") != "max":
-            raise NotImplementedError("aggregation_type=%r: only the global-max-pool heads are on the "
-                                      "accelerated path" % net.aggregation_type)
+        self.aggregation = getattr(net, "aggregation_type", "max")
+        if self.aggregation not in ("max", "rnn"):
+            raise ValueError("aggregation_type must be 'max' or 'rnn', got %r" % (self.aggregation,))
         if torch.device(device).type != "cuda":
             raise F._lib.FscError("the accelerated model needs device='cuda' (an MI355X under ROCm); "
                                   "there is no CPU fallback")
@@ -105,7 +105,13 @@ class _TaggingModel(nn.Module):
             input_size = (2 if self.dims == 2 else data._input_dim) if not k else depth
             depth = int(net.growth_rate ** k * net.conv_base_depth)
             if k >= net.start_deep_supervision_on:
-                total_depth += depth
+                if self.aggregation == "max":
+                    total_depth += depth
+                else:                              # (created BEFORE the block's conv modules, like the reference: :514-522)
+                    rnn_size = 128
+                    total_depth += rnn_size * 2
+                    self.rnns.append(nn.Sequential(
+                        nn.LayerNorm((depth,)), nn.GRU(depth, rnn_size, batch_first=True, bidirectional=True)))
             self.conv_modules.append(nn.Sequential(
                 bn(input_size), conv(input_size, depth, kernel_size=3, padding=1),
                 pool(kernel_size=2, stride=2), bn(depth), nn.PReLU(depth), res(depth)))
@@ -169,7 +175,10 @@ class _TaggingModel(nn.Module):
         ph = 2 if self.dims == 2 else 1
         feats = []
         for k, mods in enumerate(self.conv_modules):
-            h, feat = F.conv_block(h, mods, self.training, k >= start, ph, self._bn_sync)
+            use_max = k >= start and self.aggregation == "max"
+            h, feat = F.conv_block(h, mods, self.training, use_max, ph, self._bn_sync)
+            if k >= start and self.aggregation == "rnn":
+                feat = F.rnn_head(h, self.rnns[k - start])
             if feat is not None:
                 feats.append(feat)
         feats = torch.cat(feats, -1)

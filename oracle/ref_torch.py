@@ -120,10 +120,11 @@ class _TagCNN(nn.Module):
 
     def __init__(self, features, num_conv_blocks, conv_base_depth, growth_rate,
                  start_deep_supervision_on, n_classes, output_dropout=0.0, input_dim=None,
-                 filterbank=None):
+                 filterbank=None, aggregation_type="max"):
         super().__init__()
         self.features = features
         self.start = start_deep_supervision_on
+        self.aggregation = aggregation_type
         self.filterbank = None
         if features.startswith("mel"):
             fb = filterbank if filterbank is not None else _mel.make_mel_filterbanks(features)
@@ -133,10 +134,17 @@ class _TagCNN(nn.Module):
         self.conv_modules = nn.ModuleList()
         self.rnns = nn.ModuleList()
         c_in = first_in
-        for d in depths:
+        total = 0
+        for k, d in enumerate(depths):
+            if k >= self.start:
+                if aggregation_type == "max":
+                    total += d
+                else:     # classifiers.py:514-522 (2-d), :137-145 (1-d): created before the block's conv modules
+                    total += 256
+                    self.rnns.append(nn.Sequential(nn.LayerNorm((d,)),
+                                                   nn.GRU(d, 128, batch_first=True, bidirectional=True)))
             self.conv_modules.append(_block(c_in, d, self.dims))
             c_in = d
-        total = sum(d for k, d in enumerate(depths) if k >= self.start)
         self.output_transform = nn.Sequential(
             nn.BatchNorm1d(total), nn.Linear(total, total), nn.BatchNorm1d(total),
             nn.PReLU(total), nn.Dropout(p=output_dropout), nn.Linear(total, n_classes))
@@ -153,7 +161,12 @@ class _TagCNN(nn.Module):
             x = blk(x)
             if collect is not None:
                 collect.append(x)
-            if k >= self.start:
+            if k >= self.start and self.aggregation == "rnn":
+                # classifiers.py:592-597 (2-d: mean over frequency first), :202-207 (1-d)
+                seq = (torch.mean(x, 2) if self.dims == 2 else x).permute(0, 2, 1)
+                _, state = self.rnns[k - self.start](seq)
+                pooled.append(state.permute(1, 0, 2).contiguous().view(seq.size(0), -1))
+            elif k >= self.start:
                 # AdaptiveMaxPool2d(1) / 1d(1) (classifiers.py:540,591 / :163,201): ONE arg-max per plane gets the
                 # gradient (amax would split it between ties)
                 pooled.append(F.adaptive_max_pool1d(x.flatten(2), 1).squeeze(-1))

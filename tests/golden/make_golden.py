@@ -526,6 +526,48 @@ def g13_input_pipeline():
     save("g13_input_pipeline.npz", **out)
 
 
+# ---------------------------------------------------------------------------------- G14
+def g14_rnn_head():
+    """aggregation_type="rnn" (LayerNorm + bi-GRU(128) on the frequency-averaged block output, classifiers.py:514-522,
+    592-597): tiny 2-d model, 2 blocks, one RNN head; state-dict keys, initial parameters, logits, per-sample LSEP and
+    every parameter gradient of the reference."""
+    seed_all(14)
+    exp = experiment("mel_1024_512_64", blocks=2, base=8, growth=1.5, start=1, input_dim=64)
+    exp.config.network["aggregation_type"] = "rnn"
+    model = TwoDimensionalCNNClassificationModel(exp, device="cpu")
+    rng = np.random.default_rng(14)
+    signal = (0.1 * torch.randn(3, 12000, 1)).float()
+    signal[-1, 7000:] = 0.0
+    labels = torch.from_numpy(labels_multi_hot(3, 80, rng))
+    out = {"signal": signal.numpy(), "labels": labels.numpy(), "seed": np.int64(14)}
+    for k, v in np_state(model).items():        # same seed + same registration order reproduce the parameters: checksums only
+        if v.dtype == np.float32:
+            out["init_sum." + k] = np.float64(v.astype(np.float64).sum())
+            out["init_abs." + k] = np.float64(np.abs(v.astype(np.float64)).sum())
+    model.train()
+    logits = model(signal)["class_logits"]
+    per = lsep_loss(logits, labels, average=False)
+    per.mean().backward()
+    out["logits"] = logits.detach().numpy()
+    out["loss"] = per.detach().numpy()
+    pick = np.random.default_rng(140)
+    for k, p in model.named_parameters():
+        g = p.grad.detach().reshape(-1)
+        if g.numel() <= 4096:
+            out["grad." + k] = g.numpy().copy()
+        else:                                    # the GRU matrices: 4096 seeded elements + norm
+            idx = pick.integers(0, g.numel(), size=4096)
+            out["grad_idx." + k] = idx.astype(np.int64)
+            out["grad." + k] = g[torch.from_numpy(idx)].numpy().copy()
+        out["grad_norm." + k] = np.float64(g.double().norm().item())
+    model.eval()
+    with torch.no_grad():
+        out["eval_logits"] = model(signal)["class_logits"].numpy()
+    save("g14_rnn_head.npz", **out)
+    with open(os.path.join(HERE, "g14_state_keys.json"), "w") as f:
+        json.dump([[k, list(v.shape), str(v.dtype)] for k, v in model.state_dict().items()], f, indent=0)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
     g1_frontend()
@@ -541,3 +583,4 @@ if __name__ == "__main__":
     g11_cfg1()
     g12_cfg2_step()
     g13_input_pipeline()
+    g14_rnn_head()

@@ -288,3 +288,37 @@ def test_cfg2_width_model_step_golden(golden):
         g, [(k, p.grad.numpy()) for k, p in m.named_parameters()], logits.detach().numpy(), per.detach().numpy(),
         ev.numpy())
     assert float(np.abs(logits.detach().numpy() - g["logits"]).max()) < 1e-4       # forward: far inside the tolerance
+
+
+def check_rnn_golden(g, named_grads, logits, per, eval_logits, tol):
+    assert float(np.abs(logits - g["logits"]).max()) < tol
+    assert float(np.abs(per - g["loss"]).max()) < tol
+    assert float(np.abs(eval_logits - g["eval_logits"]).max()) < tol
+    for k, grad in named_grads:
+        flat = np.asarray(grad).reshape(-1)
+        got = flat[g["grad_idx." + k]] if ("grad_idx." + k) in g else flat
+        assert float(np.abs(got - g["grad." + k]).max()) < tol, k
+        assert abs(float(np.linalg.norm(flat.astype(np.float64))) - float(g["grad_norm." + k])) < tol * max(1.0, float(g["grad_norm." + k])), k
+
+
+def test_rnn_aggregation_head_golden(golden):
+    """aggregation_type="rnn" (fixture g14 from the imported reference): state-dict keys, same-seed initial parameters,
+    logits, per-sample LSEP, eval logits and every gradient of the oracle's LayerNorm + bi-GRU head."""
+    g = golden("g14_rnn_head.npz")
+    torch.manual_seed(int(g["seed"]))
+    m = oref.TagCNN2d("mel_1024_512_64", 2, 8, 1.5, 1, 80, aggregation_type="rnn")
+    sig = oref.state_dict_signature(m)
+    assert [[k, list(s), d] for k, (s, d) in sig.items()] == golden("g14_state_keys.json")
+    for k, v in m.state_dict().items():
+        if ("init_sum." + k) in g:
+            assert abs(float(v.double().sum()) - float(g["init_sum." + k])) < 1e-9 * max(1.0, float(g["init_abs." + k])), k
+    signal, labels = torch.from_numpy(g["signal"]), torch.from_numpy(g["labels"])
+    m.train()
+    logits = m(signal)["class_logits"]
+    per = oref.lsep(logits, labels, average=False)
+    per.mean().backward()
+    m.eval()
+    with torch.no_grad():
+        ev = m(signal)["class_logits"]
+    check_rnn_golden(g, [(k, p.grad.numpy()) for k, p in m.named_parameters()], logits.detach().numpy(),
+                     per.detach().numpy(), ev.numpy(), 1e-4)
