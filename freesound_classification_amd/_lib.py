@@ -54,6 +54,14 @@ SIGNATURES = {
     "fsc_conv_default_arith": (_I, []),
     "fsc_conv_wgrad_workspace_bytes": (_SZ, [_D]),
     "fsc_conv_wgrad": (_I, [_D, _P, _P, _P, _P, _P, _P, _P]),
+    "fsc_l16_bytes": (_SZ, [_I, _I, _L]),
+    "fsc_l16_pack": (_I, [_P, _I, _I, _L, _P, _P, _P]),
+    "fsc_l16_unpack": (_I, [_P, _I, _I, _L, _P, _P, _P]),
+    "fsc_conv_l16_supported": (_I, [_D, _I]),
+    "fsc_conv_l16_packed_floats": (_SZ, [_D, _I]),
+    "fsc_conv_l16_pack_weights": (_I, [_D, _P, _I, _P, _P]),
+    "fsc_conv_l16_fwd": (_I, [_D, _P, _P, _P, _P, _I, _I, _P, _P]),
+    "fsc_conv_l16_plan_describe": (_I, [_D, _I, C.c_char_p, _SZ]),
     "fsc_bn_workspace_bytes": (_SZ, [_I]),
     "fsc_bn_train_stats": (_I, [_P, _I, _I, _L, _P, _P, _F, _F, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P]),
     "fsc_bn_eval_prepare": (_I, [_I, _P, _P, _P, _P, _F, _P, _P, _P]),

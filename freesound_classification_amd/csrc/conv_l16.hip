@@ -1,0 +1,802 @@
+// Convolutions on PRE-SPLIT activations ("L16" tensors) for gfx950.
+//
+// conv.hip's split-fp16 kernels read fp32 NCHW activations and split every value into two scaled fp16 limbs
+// beside the MFMAs -- once per TAP, nine times for a 3x3 layer -- which leaves them latency-bound at ~30 % MFMA
+// busy (profiles/r01g_pmc_conv_f16x3.txt).  Here the producer of an activation (the BN / PReLU apply kernels,
+// norm_act.hip, or fsc_l16_pack) writes the limbs ONCE, in the layout the MFMA B operand wants:
+//
+//     L16 tensor of a logical (N, C, H, W) fp32 tensor, OCT = ceil(C / 8):
+//         half[N][OCT][2 limbs][H * W][8 channels]         (16 bytes per (limb, position); pad channels are 0)
+//     with one power-of-two scale per tensor taken from its declared maximum (the FSC_AMAX_FLOATS slot buffer):
+//         h = rne16(x * s), l = rne16(x * s - h)            (same arithmetic as conv.hip split2_pair)
+//
+// 4 bytes per element like fp32.  The conv kernel then
+//   * copies the halo'd box of a 32-channel chunk HBM -> LDS with 16-byte LDS-DMA (a quarter of the copy
+//     instructions of the fp32 kernel), as [octet * 2 + limb][position][8];
+//   * reads a B fragment (8 channels of one pixel, one limb) with ONE ds_read_b128 -- no split, no VALU;
+// everything else (pre-split weight fragments streamed through a ring of step slots, persistent workgroups,
+// counted waits across raw barriers, 16-byte epilogue stores) follows conv_fwd_x3_kernel.  The products and their
+// order are those of the f16x3 arithmetic of conv.hip (hl, lh, hh per k-step), so results are bit-identical to it.
+//
+// Replaces nn.Conv2d 3x3 / 1x1 forward and input gradient (reference networks/classifiers.py:526-531, 77-81).
+#include "common.h"
+#include <stdlib.h>
+#include <string.h>
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef __attribute__((address_space(3))) void* lds_ptr;
+typedef __attribute__((address_space(1))) const void* glb_ptr;
+
+constexpr int kWaves = 8;            // two waves per SIMD
+constexpr int kChunk = 32;           // channels per K chunk = 4 octets
+constexpr int kNptMax = 6;           // input DMA instructions per (octet, limb) plane: plane <= 384 positions
+constexpr int kScr = 20;             // epilogue scratch row stride (floats)
+constexpr int kWmaxBlocks = 64;      // partial maxima of the weights (l16_wmax_kernel)
+
+struct LGeom {
+    int n, cin, cout, h, w;
+    long hw;
+    int oct_in;               // octets of the input tensor
+    int nb, th, tw;           // pixel box: images x rows x cols
+    int tiles_n, tiles_h, tiles_w;
+    int rows, cols;           // staged box incl. halo
+    int plane;                // positions per staged (octet, limb) plane, multiple of 8
+    int npos, npix, npt;
+    int nfull, tail_oct, tail_steps, steps;
+    int coblk;
+    long img_stride;          // 16-byte units between images of the input: oct_in * 2 * hw
+};
+
+__device__ __attribute__((aligned(16))) float g_zero16_l[4] = {0.f, 0.f, 0.f, 0.f};
+
+__device__ __forceinline__ int fdiv(int x, float inv) { return (int)(((float)x + 0.5f) * inv); }
+
+__device__ __forceinline__ void glds16(const void* src, void* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((glb_ptr)src, (lds_ptr)lds_wave_base, 16, 0, 0);
+}
+
+__device__ __forceinline__ void split2_pair(float x0, float x1, float s, unsigned& h, unsigned& l) {
+    unsigned hp, lp;
+    asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(hp) : "v"(x0), "v"(s));
+    asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(hp) : "v"(x1), "v"(s));
+    asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(lp) : "v"(x0), "v"(s), "v"(hp));
+    asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(lp) : "v"(x1), "v"(s), "v"(hp));
+    h = hp;
+    l = lp;
+}
+__device__ __forceinline__ int scale_field(float amax) {
+    const int e = (int)((__float_as_uint(amax) >> 23) & 0xffu);
+    int f = 268 - e;
+    f = f < 2 ? 2 : f > 252 ? 252 : f;
+    return f;
+}
+__device__ __forceinline__ float field_to_float(int f) { return __uint_as_float((unsigned)f << 23); }
+__device__ __forceinline__ float inv_scale(int f, float amax) {
+    return ((__float_as_uint(amax) >> 23) & 0xffu) == 0xffu ? __uint_as_float(0x7fc00000u) : field_to_float(254 - f);
+}
+__device__ __forceinline__ f32x4 mfma16(u32x4 a, u32x4 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ void raw_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// maximum over an FSC_AMAX_FLOATS slot buffer (one float per thread of a 512-thread block), uniform result
+__device__ __forceinline__ float block_amax512(const float* amax, float* red) {
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const float mw = fsc::wave_max(amax[tid]);
+    if (lane == 0) red[wid] = mw;
+    __syncthreads();
+    float ax = red[0];
+#pragma unroll
+    for (int i = 1; i < kWaves; ++i) ax = fmaxf(ax, red[i]);
+    ax = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, ax)));
+    __syncthreads();
+    return ax;
+}
+
+// -------------------------------------------------------------------------------------------
+// fp32 NCHW -> L16 (stand-alone producer: tests, and tensors no fused producer writes).  One thread = one
+// (image, octet, position): reads 8 channel planes (coalesced along positions), writes 16 + 16 bytes.
+__global__ __launch_bounds__(256) void l16_pack_kernel(const float* __restrict__ x, int n, int c, long hw,
+                                                       const float* __restrict__ amax, uint4* __restrict__ out) {
+    __shared__ float red[4];
+    float m = 0.f;
+    for (int i = threadIdx.x; i < fsc::kAmaxFloats; i += 256) m = fmaxf(m, amax[i]);
+    m = fsc::wave_max(m);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    const float s = field_to_float(scale_field(m));
+    const int oct = (c + 7) / 8;
+    const long total = (long)n * oct * hw;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const long p = idx % hw;
+        const long no = idx / hw;
+        const int o = (int)(no % oct);
+        const long img = no / oct;
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int ch = o * 8 + e;
+            v[e] = ch < c ? x[(img * c + ch) * hw + p] : 0.f;
+        }
+        uint4 hi, lo;
+        split2_pair(v[0], v[1], s, hi.x, lo.x);
+        split2_pair(v[2], v[3], s, hi.y, lo.y);
+        split2_pair(v[4], v[5], s, hi.z, lo.z);
+        split2_pair(v[6], v[7], s, hi.w, lo.w);
+        out[(no * 2) * hw + p] = hi;
+        out[(no * 2 + 1) * hw + p] = lo;
+    }
+}
+
+// L16 -> fp32 NCHW: (h + l) / s (exact in fp32 up to the final rounding).  Tests / debugging.
+__global__ __launch_bounds__(256) void l16_unpack_kernel(const uint4* __restrict__ in, int n, int c, long hw,
+                                                         const float* __restrict__ amax, float* __restrict__ x) {
+    __shared__ float red[4];
+    float m = 0.f;
+    for (int i = threadIdx.x; i < fsc::kAmaxFloats; i += 256) m = fmaxf(m, amax[i]);
+    m = fsc::wave_max(m);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    const int f = scale_field(m);
+    const float inv = inv_scale(f, m);
+    const int oct = (c + 7) / 8;
+    const long total = (long)n * oct * hw;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const long p = idx % hw;
+        const long no = idx / hw;
+        const int o = (int)(no % oct);
+        const long img = no / oct;
+        const uint4 hi = in[(no * 2) * hw + p], lo = in[(no * 2 + 1) * hw + p];
+        const unsigned hh[4] = {hi.x, hi.y, hi.z, hi.w}, ll[4] = {lo.x, lo.y, lo.z, lo.w};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int ch = o * 8 + e;
+            if (ch >= c) continue;
+            const unsigned short hb = (unsigned short)(hh[e >> 1] >> ((e & 1) * 16));
+            const unsigned short lb = (unsigned short)(ll[e >> 1] >> ((e & 1) * 16));
+            const float hv = (float)__builtin_bit_cast(_Float16, hb), lv = (float)__builtin_bit_cast(_Float16, lb);
+            x[(img * c + ch) * hw + p] = (hv + lv) * inv;
+        }
+    }
+}
+
+// weight (c_out, c_in, kh, kw) -> A fragments: packed[co block][step][channel tile][limb][lane][8 fp16];
+// lane = (kq, m); its 8 values are the channels of octet `oct` at tap `tap`, (tap, oct) = divmod(4 * step_in_chunk
+// + kq, octets of the chunk).  Scaled by scale_field(*w_amax).  Same format as conv.hip pack_x3_kernel (fp16 limbs).
+__global__ void l16_pack_w_kernel(const float* __restrict__ w, unsigned short* __restrict__ packed, int c_out, int c_in,
+                                  int taps, int cot, int co_blocks, int nfull, int tail_oct, int steps, int dgrad,
+                                  float* __restrict__ w_amax) {
+    const long total = (long)co_blocks * steps * cot * 512;
+    float wm = 0.f;
+    for (int i = 0; i < kWmaxBlocks; ++i) wm = fmaxf(wm, w_amax[4 + i]);      // partial maxima of l16_wmax_kernel
+    if (blockIdx.x == 0 && threadIdx.x == 0) w_amax[0] = wm;
+    const float sw = field_to_float(scale_field(wm));
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int e = (int)(idx & 7), lane = (int)((idx >> 3) & 63);
+        long rest = idx >> 9;
+        const int i = (int)(rest % cot); rest /= cot;
+        const int S = (int)(rest % steps);
+        const int cb = (int)(rest / steps);
+        const int c = S < nfull * taps ? S / taps : nfull;
+        const int s = S - c * taps;
+        const int noct = c < nfull ? 4 : tail_oct;
+        const int gi = 4 * s + (lane >> 4);
+        float v = 0.f;
+        if (gi < taps * noct) {
+            const int tap = gi / noct, oct = gi - tap * noct;
+            const int k = c * kChunk + oct * 8 + e, m = (cb * cot + i) * 16 + (lane & 15);
+            const int co = dgrad ? k : m, ci = dgrad ? m : k;
+            if (co < c_out && ci < c_in) v = w[((long)co * c_in + ci) * taps + (dgrad ? taps - 1 - tap : tap)];
+        }
+        unsigned h2, l2;
+        split2_pair(v, 0.f, sw, h2, l2);
+        const long base2 = ((((long)cb * steps + S) * cot + i) * 2) * 512 + lane * 8 + e;
+        packed[base2] = (unsigned short)h2;
+        packed[base2 + 512] = (unsigned short)l2;
+    }
+}
+
+// max |w| in two stages without a clear: kWmaxBlocks partial maxima behind the fragments, folded by every block of the pack
+// kernel (and published as w_amax[0] for the conv kernel by its first thread)
+__global__ __launch_bounds__(256) void l16_wmax_kernel(const float* __restrict__ x, long n, float* __restrict__ part) {
+    __shared__ float sm[4];
+    float m = 0.f;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) m = fmaxf(m, fabsf(x[i]));
+    m = fsc::wave_max(m);
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.x] = fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3]));
+}
+
+// -------------------------------------------------------------------------------------------
+// Forward / dgrad.  Workgroup = 8 waves, tile = COT*16 output channels x (8 * PT * 16) pixels, persistent over
+// (pixel tile, channel block) items.  One MFMA step = one tap x 32 channels: COT * PT * 3 MFMAs per wave.
+template <int KH, int KW, int COT, int PT>
+__global__ __launch_bounds__(kWaves * 64) void conv_l16_fwd_kernel(LGeom g, const uint4* __restrict__ in,
+                                                                    const float* __restrict__ packed,
+                                                                    const float* __restrict__ bias,
+                                                                    float* __restrict__ out, int accumulate,
+                                                                    const float* __restrict__ in_amax,
+                                                                    const float* __restrict__ w_amax) {
+    constexpr int TAPS = KH * KW;
+    constexpr int CO_BLK = COT * 16;
+    constexpr int PADH = KH / 2, PADW = KW / 2;
+    constexpr int DAHEAD = TAPS == 1 ? 2 : 1;       // the input DMA runs this many chunks ahead
+    constexpr int NSTG = DAHEAD + 1;
+    constexpr int WUNITS = COT * 2;                 // 1 KB fragment images per step
+    constexpr int WSLOT_F = WUNITS * 256;           // floats per ring slot
+    constexpr int NWQ = (WUNITS + kWaves - 1) / kWaves;
+    constexpr int RING = 4;                         // weight slots: W runs three steps ahead
+    constexpr int NWLO = WUNITS / kWaves;           // weight DMAs every wave issues per step (at least)
+    constexpr int NPAIR = (COT + 1) / 2;
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* const wring = smem;
+    uint4* const ibase = reinterpret_cast<uint4*>(smem + RING * WSLOT_F);
+    const int istage = 8 * g.plane;                 // uint4 per stage
+    float* const scratch = reinterpret_cast<float*>(ibase + NSTG * istage) + (threadIdx.x >> 6) * (16 * kScr);
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lm = lane & 15, kq = lane >> 4;
+
+    // ---- operand scales (before any DMA lands in the ring)
+    const float ax = block_amax512(in_amax, smem);
+    const float aw = *w_amax;
+    const int fx = scale_field(ax), fw = scale_field(aw);
+    const float inv_x = inv_scale(fx, ax), inv_w = inv_scale(fw, aw);
+
+    const float inv_per = 1.0f / (float)(g.rows * g.cols), inv_cols = 1.0f / (float)g.cols;
+    const float inv_tw = 1.0f / (float)g.tw, inv_thw = 1.0f / (float)(g.th * g.tw);
+    int pix_b[PT];               // byte offset of this lane's pixel inside a staged plane
+#pragma unroll
+    for (int pt = 0; pt < PT; ++pt) {
+        const int p = (wid * PT + pt) * 16 + lm;
+        int pl = 0;
+        if (p < g.npix) {
+            const int per = g.th * g.tw;
+            const int b = fdiv(p, inv_thw), rem = p - b * per;
+            const int r = fdiv(rem, inv_tw), c = rem - r * g.tw;
+            pl = (b * g.rows + r) * g.cols + c;
+        }
+        pix_b[pt] = pl * 16;
+    }
+    const int ntiles = g.tiles_n * g.tiles_h * g.tiles_w;
+    const int nitems = ntiles * g.coblk;
+    const int nchunks = g.nfull + (g.tail_oct ? 1 : 0);
+
+    int pos_off[kNptMax];        // source offset (16-byte units, relative to unit 0 of image 0) of staged positions; -1 = zeros
+    auto plan_input = [&](int tile) {                       // (once per item: the decode is redone instead of kept in registers)
+        int t = tile;
+        const int twi = t % g.tiles_w; t /= g.tiles_w;
+        const int thi = t % g.tiles_h; t /= g.tiles_h;
+        const int n0 = t * g.nb, h0 = thi * g.th, w0 = twi * g.tw;
+#pragma unroll
+        for (int q = 0; q < kNptMax; ++q) {
+            const int pos = q * 64 + lane;
+            pos_off[q] = -1;
+            if (pos < g.npos) {
+                const int per = g.rows * g.cols;
+                const int b = fdiv(pos, inv_per), rem = pos - b * per;
+                const int rr = fdiv(rem, inv_cols), cc = rem - rr * g.cols;
+                const int gh = h0 + rr - PADH, gw = w0 + cc - PADW;
+                if (n0 + b < g.n && gh >= 0 && gh < g.h && gw >= 0 && gw < g.w)
+                    pos_off[q] = (int)((long)(n0 + b) * g.img_stride + (long)gh * g.w + gw);
+            }
+        }
+    };
+
+    f32x4 acc[COT][PT];
+#pragma unroll
+    for (int i = 0; i < COT; ++i)
+#pragma unroll
+        for (int j = 0; j < PT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // ---- DMA issue
+    const uint4* const zero = reinterpret_cast<const uint4*>(g_zero16_l);
+    auto issue_w = [&](const float* src, int slot) {        // src: this lane's pointer into the step's fragments
+        float* dst = wring + slot * WSLOT_F;
+#pragma unroll
+        for (int q = 0; q < NWQ; ++q) {
+            const int u = q * kWaves + wid;
+            if ((q + 1) * kWaves <= WUNITS || u < WUNITS) glds16(src + u * 256, dst + u * 256);
+        }
+    };
+    // input of chunk c into `stage`: wave wid copies unit wid = (octet wid / 2, limb wid % 2); always g.npt instructions
+    auto issue_i = [&](int stage, int c) {
+        const int oct = c * 4 + (wid >> 1);
+        const bool live_u = oct < g.oct_in;
+        const uint4* src = in + (long)(oct * 2 + (wid & 1)) * g.hw;
+        uint4* dst = ibase + stage * istage + wid * g.plane;
+#pragma unroll
+        for (int q = 0; q < kNptMax; ++q) {
+            if (q < g.npt && q * 64 + lane < g.plane) {         // (lanes past the plane would land in the next unit)
+                const bool live = live_u && pos_off[q] >= 0;
+                glds16(live ? src + pos_off[q] : zero, dst + q * 64);
+            }
+        }
+    };
+
+    // ---- producers: W runs three steps ahead of the MFMA steps, the input DAHEAD chunks, both across items
+    int wp_item = blockIdx.x, wp_left = g.steps, wp_slot = 0;      // wp_left: steps of wp_item not issued yet
+    const float* wp_src = packed + lane * 4;
+    auto wp_set_item = [&]() {
+        if (wp_item < nitems) {
+            const int tile = wp_item / g.coblk;
+            wp_src = packed + (long)(wp_item - tile * g.coblk) * g.steps * WSLOT_F + lane * 4;
+        }
+    };
+    auto produce_w = [&]() -> bool {
+        if (wp_item >= nitems) return false;
+        issue_w(wp_src, wp_slot);
+        wp_src += WSLOT_F;
+        wp_slot = wp_slot == RING - 1 ? 0 : wp_slot + 1;
+        if (--wp_left == 0) {
+            wp_left = g.steps;
+            wp_item += gridDim.x;
+            wp_set_item();
+        }
+        return true;
+    };
+    int ip_item = blockIdx.x, ip_c = 0, ip_stg = 0;
+    auto produce_i = [&]() -> bool {
+        if (ip_item >= nitems) return false;
+        issue_i(ip_stg, ip_c);
+        ip_stg = ip_stg == NSTG - 1 ? 0 : ip_stg + 1;
+        if (++ip_c == nchunks) {
+            ip_c = 0;
+            ip_item += gridDim.x;
+            if (ip_item < nitems) plan_input(ip_item / g.coblk);
+        }
+        return true;
+    };
+
+    // ---- B operand address of (stage, chunk, step) for this lane: byte offset from ibase of its octet's high limb
+    //      at the step's tap (without the pixel).  Full chunks: lane group kq = octet kq, uniform tap.
+    const int limb_b = g.plane * 16;                        // bytes between the limb planes of an octet
+    const int stage_b = 8 * limb_b;
+    const int kq_b = kq * 2 * limb_b;
+    auto b_off_tail = [&](int stage, int s) -> int {        // remainder chunk: (tap, octet) flattened over lane groups
+        const int noct = g.tail_oct;
+        int gi = 4 * s + kq;
+        if (gi >= TAPS * noct) gi = 0;                     // its weights are zero
+        const int tap = TAPS == 1 ? 0 : fdiv(gi, 1.0f / (float)noct);
+        const int oct = gi - tap * noct;
+        const int ty = TAPS == 1 ? 0 : fdiv(tap, 1.0f / (float)KW), tx = tap - ty * KW;
+        return stage * stage_b + oct * 2 * limb_b + (ty * g.cols + tx) * 16;
+    };
+    auto b_off = [&](int stage, int c, int s) -> int {      // (stage, c, s uniform)
+        if (c >= g.nfull) return b_off_tail(stage, s);
+        const int ty = TAPS == 1 ? 0 : (s * 11) >> 5, tx = s - ty * KW;          // s / 3 for s < 10
+        return stage * stage_b + (ty * g.cols + tx) * 16 + kq_b;
+    };
+
+    struct Frag { u32x4 v[2][PT]; };                        // B fragments of a step: [limb][pixel tile]
+    struct AFrag { u32x4 v[2][2]; };                        // A fragments of a pair of channel tiles: [tile][limb]
+    Frag fb0, fb1;
+    AFrag fa0, fa1;
+    const char* const ib = reinterpret_cast<const char*>(ibase);
+    auto read_b = [&](int off, Frag& dst) {
+#pragma unroll
+        for (int j = 0; j < PT; ++j) {
+            dst.v[0][j] = *reinterpret_cast<const u32x4*>(ib + off + pix_b[j]);
+            dst.v[1][j] = *reinterpret_cast<const u32x4*>(ib + off + pix_b[j] + limb_b);
+        }
+    };
+    auto read_a = [&](const u32x4* wl, int pr, AFrag& dst) {      // wl: this lane's fragments of a ring slot
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int l = 0; l < 2; ++l)
+                if (pr * 2 + t < COT) dst.v[t][l] = wl[((pr * 2 + t) * 2 + l) * 64];
+    };
+
+    int item = blockIdx.x;
+    int slot = 0;
+    if (item < nitems) {
+        plan_input(item / g.coblk);
+        wp_set_item();
+#pragma unroll
+        for (int d = 0; d < DAHEAD; ++d) produce_i();
+        produce_w();
+        produce_w();
+        produce_w();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        raw_barrier();
+        read_b(b_off(0, 0, 0), fb0);
+        read_a(reinterpret_cast<const u32x4*>(wring) + lane, 0, fa0);
+    }
+
+    // consumer position (all uniform): chunk c, step sc of nst inside it, input stage stg; wait state
+    int c = 0, sc = 0, nst = g.nfull > 0 ? TAPS : g.tail_steps, stg = 0;
+    bool first_step = true, drain = false, inp_young = false;
+
+    // One MFMA step.  On entry `bcur` / `acur` hold the B fragments and the first pair's A fragments of this step (read
+    // during the previous one); the step reads those of the next step (B at its tap of the staged box, A from the next
+    // ring slot, whose DMAs the barrier at the top has covered) into `bnxt` / `anxt` behind its MFMAs.
+    auto step = [&](const Frag& bcur, Frag& bnxt, const AFrag& acur, AFrag& anxt) {
+        if (!first_step) {
+            // the barrier covers W(S+1) (issued two steps ago); W(S+2) and, in steps 1 and 2 of a chunk (never its last),
+            // the last three copies of the young input box may stay in flight.  Stores share the counter and retire out of
+            // order, and a dry weight producer leaves nothing younger: drain then.
+            if (drain) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else if (TAPS > 1 && inp_young && (sc == 1 || sc == 2) && sc + 1 < nst) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NWLO + 3) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NWLO) : "memory");
+            raw_barrier();
+        }
+        first_step = false;
+        if (TAPS == 1) {
+            produce_i();
+            drain = !produce_w();
+        } else {
+            drain = !produce_w();
+            if (sc == 0) inp_young = produce_i() && g.npt >= 3;
+        }
+        // the next step and the byte offset of its B operand
+        int noff;
+        {
+            int sn = sc + 1;
+            if (sn < nst) {
+                noff = b_off(stg, c, sn);
+            } else {                                        // first step of the next chunk (of the next item at the end)
+                sn = 0;
+                stg = stg == NSTG - 1 ? 0 : stg + 1;
+                c = c + 1 < nchunks ? c + 1 : 0;
+                nst = c < g.nfull ? TAPS : g.tail_steps;
+                noff = b_off(stg, c, 0);
+            }
+            sc = sn;
+        }
+        const u32x4* wl = reinterpret_cast<const u32x4*>(wring + slot * WSLOT_F) + lane;
+        slot = slot == RING - 1 ? 0 : slot + 1;
+        const u32x4* wln = reinterpret_cast<const u32x4*>(wring + slot * WSLOT_F) + lane;
+        AFrag t0, t1;
+        constexpr int kLa[3] = {1, 0, 0}, kLb[3] = {0, 1, 0};     // (A limb, B limb): l*h, h*l, h*h -- smallest first
+#pragma unroll
+        for (int pr = 0; pr < NPAIR; ++pr) {
+            const AFrag& a = pr == 0 ? acur : (pr & 1) ? t1 : t0;
+            AFrag& an = pr + 1 == NPAIR ? anxt : (pr & 1) ? t0 : t1;
+            // reads behind this pair's MFMAs: the next pair's A fragments (the next step's first pair from the next
+            // slot at the end) and, with the first pair, the next step's B fragments
+            if (pr + 1 < NPAIR) read_a(wl, pr + 1, an);
+            else read_a(wln, 0, an);
+            if (pr == 0) read_b(noff, bnxt);
+            const int ntile = pr * 2 + 1 < COT ? 2 : 1;
+#pragma unroll
+            for (int gq = 0; gq < 3; ++gq)
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const int i = pr * 2 + t;
+                    if (i < COT) {
+#pragma unroll
+                        for (int j = 0; j < PT; ++j) acc[i][j] = mfma16(a.v[t][kLa[gq]], bcur.v[kLb[gq]][j], acc[i][j]);
+                    }
+                }
+            // one LDS read behind each of the first MFMAs of the pair
+            const int nrd = (pr + 1 < NPAIR ? (((pr + 1) * 2 + 1 < COT) ? 4 : 2) : (COT > 1 ? 4 : 2)) + (pr == 0 ? 2 * PT : 0);
+#pragma unroll
+            for (int k = 0; k < 3 * ntile * PT; ++k) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                  // one MFMA
+                if (k < nrd) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);     // one LDS read
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+
+    const bool add_bias = bias != nullptr;
+    for (; item < nitems; item += gridDim.x) {
+        const int tile = item / g.coblk;
+        const int co0 = (item - tile * g.coblk) * CO_BLK;
+#pragma unroll 1
+        for (int S = 0; S + 1 < g.steps; S += 2) {
+            step(fb0, fb1, fa0, fa1);
+            step(fb1, fb0, fa1, fa0);
+        }
+        if (g.steps & 1) {                                  // odd number of steps: the next item starts from fb0 / fa0 again
+            step(fb0, fb1, fa0, fa1);
+            fb0 = fb1;
+            fa0 = fa1;
+        }
+
+        // ---- epilogue: D row = channel (kq*4 + r), column = pixel (lm) -> scratch[ch][px] -> lane = (channel, quad).
+        //      This lane's quads (four consecutive pixels of a box row) are decoded here, once per item.
+        long quad_g[PT];
+        int quad_ok[PT];
+        {
+            int t = tile;
+            const int twi = t % g.tiles_w; t /= g.tiles_w;
+            const int thi = t % g.tiles_h; t /= g.tiles_h;
+            const int n0 = t * g.nb, h0 = thi * g.th, w0 = twi * g.tw;
+#pragma unroll
+            for (int pt = 0; pt < PT; ++pt) {
+                const int p = (wid * PT + pt) * 16 + (lane & 3) * 4;
+                quad_g[pt] = 0;
+                quad_ok[pt] = 0;
+                if (p < g.npix) {
+                    const int per = g.th * g.tw;
+                    const int b = fdiv(p, inv_thw), rem = p - b * per;
+                    const int r = fdiv(rem, inv_tw), cq = rem - r * g.tw;
+                    if (n0 + b < g.n && h0 + r < g.h) {
+                        quad_g[pt] = (long)(n0 + b) * g.cout * g.hw + (long)(h0 + r) * g.w + (w0 + cq);
+                        const int left = g.w - (w0 + cq), inbox = g.npix - p;
+                        const int nv = left < inbox ? left : inbox;
+                        quad_ok[pt] = nv >= 4 ? 15 : nv <= 0 ? 0 : (1 << nv) - 1;
+                    }
+                }
+            }
+        }
+        long hw_t = g.hw;
+        const float* bias_t = bias;
+        asm volatile("" : "+s"(hw_t), "+s"(bias_t));
+        const int ch = lane >> 2;
+#pragma unroll
+        for (int i = 0; i < COT; ++i) {
+            float bv[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int cob = co0 + i * 16 + kq * 4 + r;
+                bv[r] = (add_bias && cob < g.cout) ? bias_t[cob] : 0.f;
+            }
+            const int co = co0 + i * 16 + ch;
+#pragma unroll
+            for (int j = 0; j < PT; ++j) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) scratch[(kq * 4 + r) * kScr + lm] = fmaf(acc[i][j][r] * inv_x, inv_w, bv[r]);
+                const f32x4 v = *reinterpret_cast<const f32x4*>(scratch + ch * kScr + (lane & 3) * 4);
+                if (co < g.cout && quad_ok[j]) {
+                    float* o = out + quad_g[j] + (long)co * hw_t;
+                    if (!accumulate && quad_ok[j] == 15) {
+                        *reinterpret_cast<f32x4*>(o) = v;
+                    } else if (quad_ok[j] == 15) {
+                        const f32x4 old = *reinterpret_cast<const f32x4*>(o);
+                        *reinterpret_cast<f32x4*>(o) = old + v;
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k)
+                            if (quad_ok[j] & (1 << k)) o[k] = accumulate ? o[k] + v[k] : v[k];
+                    }
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int i = 0; i < COT; ++i)
+#pragma unroll
+            for (int j = 0; j < PT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        drain = true;                                       // the stores above share the DMA counter
+    }
+}
+
+// -------------------------------------------------------------------------------------------
+// host-side planning
+struct LPlan {
+    LGeom g;
+    int cot, pt, co_blocks;
+    size_t lds_bytes;
+    long tiles, workers;
+};
+
+bool plan_l16_pt(const fsc_conv_desc& d_in, int dgrad, int pt, int max_cot, LPlan* out) {
+    LPlan p{};
+    LGeom& g = p.g;
+    fsc_conv_desc d = d_in;
+    const int taps = d.kh * d.kw;
+    if (!((d.kh == 3 && d.kw == 3) || (d.kh == 1 && d.kw == 1))) return false;
+    if (taps == 1) {
+        d.w = d.h * d.w;
+        d.h = 1;
+    }
+    g.n = d.n; g.h = d.h; g.w = d.w; g.hw = (long)d.h * d.w;
+    g.cin = dgrad ? d.c_out : d.c_in;
+    g.cout = dgrad ? d.c_in : d.c_out;
+    if (g.cin < 32 || g.cout < 48) return false;
+    g.oct_in = (g.cin + 7) / 8;
+    g.img_stride = (long)g.oct_in * 2 * g.hw;
+    if ((long)g.n * g.img_stride >= (1L << 31)) return false;
+    if (g.w >= 1024 && taps > 1) return false;
+    const int nstg = taps == 1 ? 3 : 2;
+    // channel tiles per workgroup: a step costs its MFMAs plus a fixed part (barrier, DMA issue, B reads) worth about
+    // one tile; odd tile counts leave half a pair of the MFMA schedule idle only in the A prefetch, not in MFMAs
+    const int tiles = fsc::ceil_div(g.cout, 16);
+    int best_cot = 1, best_blocks = tiles;
+    long best_cost = -1;
+    for (int cot = 1; cot <= max_cot; ++cot) {
+        const int blocks = fsc::ceil_div(tiles, cot);
+        const long cost = (long)blocks * (cot * 3 + 4);
+        if (best_cost < 0 || cost < best_cost || (cost == best_cost && blocks < best_blocks)) {
+            best_cot = cot; best_blocks = blocks; best_cost = cost;
+        }
+    }
+    p.cot = best_cot;
+    p.co_blocks = best_blocks;
+    p.pt = pt;
+    const int pix_cap = kWaves * pt * 16;
+    const size_t lds_total = 160 * 1024;
+    const size_t ring = (size_t)4 * p.cot * 2 * 1024;
+    const size_t scratch = (size_t)kWaves * 16 * kScr * sizeof(float);
+    if (ring + scratch + (size_t)nstg * 128 * 64 > lds_total) return false;
+    int cap_pos = (int)((lds_total - ring - scratch) / ((size_t)nstg * 128));
+    cap_pos &= ~7;
+    if (cap_pos > 64 * kNptMax) cap_pos = 64 * kNptMax;
+    long bcost = -1;
+    int bnb = 1, bth = 1, btw = 1;
+    for (int tw = 4; tw <= ((d.w + 3) & ~3) && tw <= pix_cap; tw += 4) {
+        int th = pix_cap / tw;
+        if (th > d.h) th = d.h;
+        int nb = 1;
+        if (th == d.h && tw >= d.w) {
+            nb = pix_cap / (th * tw);
+            if (nb > d.n) nb = d.n;
+            if (nb < 1) nb = 1;
+        }
+        while (nb > 1 && nb * (th + d.kh - 1) * (tw + d.kw - 1) > cap_pos) --nb;
+        while (th > 1 && nb * (th + d.kh - 1) * (tw + d.kw - 1) > cap_pos) --th;
+        if (nb * (th + d.kh - 1) * (tw + d.kw - 1) > cap_pos) continue;
+        const long nt = (long)fsc::ceil_div(d.n, nb) * fsc::ceil_div(d.h, th) * fsc::ceil_div(d.w, tw);
+        const long pen = (tw >= 32 || tw >= d.w) ? 100 : tw >= 16 ? 102 : tw >= 8 ? 108 : 125;
+        const long cost = nt * pen;
+        if (bcost < 0 || cost < bcost || (cost == bcost && tw > btw)) {
+            bcost = cost; bnb = nb; bth = th; btw = tw;
+        }
+    }
+    if (bcost < 0) return false;
+    g.nb = bnb; g.th = bth; g.tw = btw;
+    g.rows = bth + d.kh - 1; g.cols = btw + d.kw - 1;
+    g.npix = bnb * bth * btw; g.npos = bnb * g.rows * g.cols;
+    g.tiles_n = fsc::ceil_div(d.n, bnb); g.tiles_h = fsc::ceil_div(d.h, bth); g.tiles_w = fsc::ceil_div(d.w, btw);
+    p.tiles = (long)g.tiles_n * g.tiles_h * g.tiles_w;
+    if ((double)d.n * g.hw < (pt == 2 ? 0.7 : 0.55) * (double)p.tiles * pix_cap) return false;
+    g.plane = (g.npos + 7) & ~7;
+    g.npt = fsc::ceil_div(g.plane, 64);
+    if (g.npt > kNptMax) return false;
+    const int rem = g.cin % kChunk;
+    g.nfull = g.cin / kChunk + (rem > kChunk - 8 ? 1 : 0);
+    g.tail_oct = (rem > 0 && rem <= kChunk - 8) ? fsc::ceil_div(rem, 8) : 0;
+    g.tail_steps = fsc::ceil_div(taps * g.tail_oct, 4);
+    g.steps = g.nfull * taps + g.tail_steps;
+    if (g.steps < 3) return false;
+    g.coblk = p.co_blocks;
+    p.lds_bytes = ring + (size_t)nstg * 128 * g.plane + scratch;
+    if (p.lds_bytes > lds_total) return false;
+    const long items = p.tiles * p.co_blocks;
+    if (items < 128) return false;                  // small late layers: the split-K kernels of conv.hip fill the chip better
+    p.workers = items < 256 ? items : 256;
+    if (items > 256 && items <= 512) p.workers = (items + 1) / 2;     // two items each instead of 256 + a short second wave
+    *out = p;
+    return true;
+}
+
+bool plan_l16(const fsc_conv_desc& d, int dgrad, LPlan* out) {
+    if (d.arith != FSC_ARITH_DEFAULT && d.arith != 3) return false;
+    if (getenv("FSC_NO_L16")) return false;
+    const int taps = d.kh * d.kw;
+    if (plan_l16_pt(d, dgrad, 2, 8, out)) return true;
+    return plan_l16_pt(d, dgrad, 1, taps == 1 ? 8 : 10, out);
+}
+
+size_t l16_limb_floats(const LPlan& p) { return (size_t)p.co_blocks * p.g.steps * p.cot * 2 * 256; }
+
+template <int KH, int KW, int COT, int PT>
+int launch_l16(const LPlan& p, const uint4* in, const float* packed, const float* bias, float* out, int accumulate,
+               const float* in_amax, hipStream_t st) {
+    auto kern = conv_l16_fwd_kernel<KH, KW, COT, PT>;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes);
+    const float* w_amax = packed + l16_limb_floats(p);
+    hipLaunchKernelGGL(kern, dim3((unsigned)p.workers), dim3(kWaves * 64), p.lds_bytes, st, p.g, in, packed, bias, out,
+                       accumulate, in_amax, w_amax);
+    FSC_LAUNCH_CHECK("fsc_conv_l16_fwd");
+    return 0;
+}
+
+template <int KH, int KW, int COT>
+int launch_l16_pt(const LPlan& p, const uint4* in, const float* packed, const float* bias, float* out, int accumulate,
+                  const float* in_amax, hipStream_t st) {
+    if (p.pt == 2) return launch_l16<KH, KW, COT, 2>(p, in, packed, bias, out, accumulate, in_amax, st);
+    return launch_l16<KH, KW, COT, 1>(p, in, packed, bias, out, accumulate, in_amax, st);
+}
+
+template <int KH, int KW>
+int launch_l16_cot(const LPlan& p, const uint4* in, const float* packed, const float* bias, float* out, int accumulate,
+                   const float* in_amax, hipStream_t st) {
+    switch (p.cot) {
+        case 3: return launch_l16_pt<KH, KW, 3>(p, in, packed, bias, out, accumulate, in_amax, st);
+        case 4: return launch_l16_pt<KH, KW, 4>(p, in, packed, bias, out, accumulate, in_amax, st);
+        case 5: return launch_l16_pt<KH, KW, 5>(p, in, packed, bias, out, accumulate, in_amax, st);
+        case 6: return launch_l16_pt<KH, KW, 6>(p, in, packed, bias, out, accumulate, in_amax, st);
+        case 7: return launch_l16_pt<KH, KW, 7>(p, in, packed, bias, out, accumulate, in_amax, st);
+        case 8: return launch_l16_pt<KH, KW, 8>(p, in, packed, bias, out, accumulate, in_amax, st);
+        case 9: if constexpr (KH * KW > 1) return launch_l16_pt<KH, KW, 9>(p, in, packed, bias, out, accumulate, in_amax, st); break;
+        case 10: if constexpr (KH * KW > 1) return launch_l16_pt<KH, KW, 10>(p, in, packed, bias, out, accumulate, in_amax, st); break;
+        default: break;
+    }
+    fsc::set_error("fsc_conv_l16_fwd: internal: no instantiation for %d channel tiles", p.cot);
+    return 22;
+}
+
+bool valid_l16_desc(const fsc_conv_desc* d) {
+    if (!d || d->n <= 0 || d->c_in <= 0 || d->c_out <= 0 || d->h <= 0 || d->w <= 0) return false;
+    const long big = 1L << 31;
+    return (long)d->n * d->c_in * d->h * d->w < big && (long)d->n * d->c_out * d->h * d->w < big;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t fsc_l16_bytes(int n, int c, long hw) { return (size_t)n * ((c + 7) / 8) * 2 * (size_t)hw * 16; }
+
+int fsc_l16_pack(const float* x, int n, int c, long hw, const float* amax, void* out, fsc_stream_t stream) {
+    FSC_CHECK_ARG(x && amax && out && n > 0 && c > 0 && hw > 0, "fsc_l16_pack: bad arguments");
+    const long total = (long)n * ((c + 7) / 8) * hw;
+    long blocks = (total + 255) / 256;
+    if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(l16_pack_kernel, dim3((unsigned)blocks), dim3(256), 0, fsc::as_stream(stream), x, n, c, hw, amax,
+                       reinterpret_cast<uint4*>(out));
+    FSC_LAUNCH_CHECK("fsc_l16_pack");
+    return 0;
+}
+
+int fsc_l16_unpack(const void* in, int n, int c, long hw, const float* amax, float* x, fsc_stream_t stream) {
+    FSC_CHECK_ARG(x && amax && in && n > 0 && c > 0 && hw > 0, "fsc_l16_unpack: bad arguments");
+    const long total = (long)n * ((c + 7) / 8) * hw;
+    long blocks = (total + 255) / 256;
+    if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(l16_unpack_kernel, dim3((unsigned)blocks), dim3(256), 0, fsc::as_stream(stream),
+                       reinterpret_cast<const uint4*>(in), n, c, hw, amax, x);
+    FSC_LAUNCH_CHECK("fsc_l16_unpack");
+    return 0;
+}
+
+int fsc_conv_l16_supported(const fsc_conv_desc* d, int dgrad) {
+    LPlan p;
+    return valid_l16_desc(d) && plan_l16(*d, dgrad, &p) ? 1 : 0;
+}
+
+size_t fsc_conv_l16_packed_floats(const fsc_conv_desc* d, int dgrad) {
+    LPlan p;
+    if (!valid_l16_desc(d) || !plan_l16(*d, dgrad, &p)) return 0;
+    return l16_limb_floats(p) + 4 + kWmaxBlocks;
+}
+
+int fsc_conv_l16_pack_weights(const fsc_conv_desc* d, const float* weight, int dgrad, float* packed, fsc_stream_t stream) {
+    LPlan p;
+    FSC_CHECK_ARG(valid_l16_desc(d) && weight && packed && plan_l16(*d, dgrad, &p), "fsc_conv_l16_pack_weights: unsupported shape");
+    hipStream_t st = fsc::as_stream(stream);
+    float* w_amax = packed + l16_limb_floats(p);
+    hipLaunchKernelGGL(l16_wmax_kernel, dim3(kWmaxBlocks), dim3(256), 0, st, weight, (long)d->c_out * d->c_in * d->kh * d->kw, w_amax + 4);
+    const long items = (long)p.co_blocks * p.g.steps * p.cot * 512;
+    long xb = (items + 255) / 256;
+    if (xb > 8192) xb = 8192;
+    hipLaunchKernelGGL(l16_pack_w_kernel, dim3((unsigned)xb), dim3(256), 0, st, weight, reinterpret_cast<unsigned short*>(packed),
+                       d->c_out, d->c_in, d->kh * d->kw, p.cot, p.co_blocks, p.g.nfull, p.g.tail_oct, p.g.steps, dgrad, w_amax);
+    FSC_LAUNCH_CHECK("fsc_conv_l16_pack_weights");
+    return 0;
+}
+
+int fsc_conv_l16_fwd(const fsc_conv_desc* d, const void* in_l16, const float* in_amax, const float* packed,
+                     const float* bias, int dgrad, int accumulate, float* out, fsc_stream_t stream) {
+    LPlan p;
+    FSC_CHECK_ARG(valid_l16_desc(d) && in_l16 && in_amax && packed && out, "fsc_conv_l16_fwd: bad descriptor or null pointer");
+    FSC_CHECK_ARG(!(dgrad && bias), "fsc_conv_l16_fwd: dgrad takes no bias");
+    FSC_CHECK_ARG(plan_l16(*d, dgrad, &p), "fsc_conv_l16_fwd: unsupported shape (see fsc_conv_l16_supported)");
+    hipStream_t st = fsc::as_stream(stream);
+    const uint4* in = reinterpret_cast<const uint4*>(in_l16);
+    if (d->kh == 3) return launch_l16_cot<3, 3>(p, in, packed, bias, out, accumulate, in_amax, st);
+    return launch_l16_cot<1, 1>(p, in, packed, bias, out, accumulate, in_amax, st);
+}
+
+int fsc_conv_l16_plan_describe(const fsc_conv_desc* d, int dgrad, char* buf, size_t buf_len) {
+    LPlan p;
+    FSC_CHECK_ARG(valid_l16_desc(d) && buf && buf_len > 0 && plan_l16(*d, dgrad, &p), "fsc_conv_l16_plan_describe: unsupported shape");
+    snprintf(buf, buf_len, "conv_l16_fwd_kernel<%d,%d,%d,%d> box=%dx%dx%d items=%ldx%d workers=%ld steps=%d lds=%zu", d->kh, d->kw,
+             p.cot, p.pt, p.g.nb, p.g.th, p.g.tw, p.tiles, p.co_blocks, p.workers, p.g.steps, p.lds_bytes);
+    return 0;
+}
+
+}  // extern "C"

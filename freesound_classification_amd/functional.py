@@ -250,6 +250,84 @@ def conv_dgrad(dout, weight, x_shape, accumulate_into=None, dout_amax=None):
     return dx
 
 
+# ---- pre-split activations (include/fsc_hip.h "L16" tensors)
+class L16:
+    """An activation held as two scaled fp16 limbs in the MFMA operand layout, plus the maximum its scale derives from."""
+    __slots__ = ("data", "amax", "shape")
+
+    def __init__(self, data, amax, shape):
+        self.data, self.amax, self.shape = data, amax, tuple(shape)
+
+
+def l16_empty(shape, like):
+    n, c = shape[0], shape[1]
+    hw = 1
+    for v in shape[2:]:
+        hw *= v
+    nbytes = _lib.load().fsc_l16_bytes(n, c, hw)
+    return torch.empty(nbytes // 4, device=like.device, dtype=torch.int32)
+
+
+def l16_pack(x, x_amax=None):
+    """fp32 (N, C, ...) -> L16 (one read + one write; the fused producers write the format directly)."""
+    x_amax = amax(x) if x_amax is None else x_amax
+    n, c = x.shape[0], x.shape[1]
+    data = l16_empty(x.shape, x)
+    call("fsc_l16_pack", ptr(x), n, c, x.numel() // (n * c), ptr(x_amax), ptr(data), stream_ptr())
+    return L16(data, x_amax, x.shape)
+
+
+def l16_unpack(t):
+    n, c = t.shape[0], t.shape[1]
+    x = torch.empty(t.shape, device=t.data.device, dtype=torch.float32)
+    call("fsc_l16_unpack", ptr(t.data), n, c, x.numel() // (n * c), ptr(t.amax), ptr(x), stream_ptr())
+    return x
+
+
+def conv_l16_supported(desc, dgrad):
+    return bool(_lib.load().fsc_conv_l16_supported(C.byref(desc), dgrad))
+
+
+def l16_plan_name(desc, dgrad):
+    buf = C.create_string_buffer(256)
+    call("fsc_conv_l16_plan_describe", C.byref(desc), dgrad, buf, 256)
+    return buf.value.decode().split(" ")[0]
+
+
+def conv_l16_pack(weight, n, h, w, dgrad):
+    """Packed A fragments of `weight` for fsc_conv_l16_fwd on (n, ., h, w) activations: (descriptor, packed)."""
+    c_out, c_in, kh, kw = weight.shape
+    d = _desc(n, c_in, c_out, h, w, kh, kw, 3)
+    dg = 1 if dgrad else 0
+    nfl = _lib.load().fsc_conv_l16_packed_floats(C.byref(d), dg)
+    if nfl == 0:
+        raise _lib.FscError("conv_l16: unsupported shape %s" % [getattr(d, f) for f, _ in d._fields_])
+    packed = torch.empty(nfl, device=weight.device, dtype=torch.float32)
+    call("fsc_conv_l16_pack_weights", C.byref(d), ptr(weight), dg, ptr(packed), stream_ptr())
+    return d, packed
+
+
+def conv_l16(t, weight, bias, dgrad=False, accumulate_into=None, prepacked=None):
+    """Forward (dgrad False: t = input, (N, Cin, H, W)) or input gradient (dgrad True: t = dout (N, Cout, H, W)) of a
+    stride-1 same-pad convolution on an L16 operand; fp32 NCHW result."""
+    c_out, c_in, kh, kw = weight.shape
+    n, _, h, w = t.shape
+    dg = 1 if dgrad else 0
+    d, packed = prepacked if prepacked is not None else conv_l16_pack(weight, n, h, w, dgrad)
+    if accumulate_into is not None:
+        out, acc = accumulate_into, 1
+    else:
+        out, acc = torch.empty((n, c_in if dgrad else c_out, h, w), device=weight.device, dtype=torch.float32), 0
+    if TIMER is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    call("fsc_conv_l16_fwd", C.byref(d), ptr(t.data), ptr(t.amax), ptr(packed), ptr(bias), dg, acc, ptr(out), stream_ptr())
+    if TIMER is not None:
+        e1.record()
+        TIMER.records.append((l16_plan_name(d, dg), 2.0 * n * h * w * c_in * c_out * kh * kw, e0, e1))
+    return out
+
+
 # Weight gradients are MFMA-bound and nothing in the backward chain depends on them until the
 # optimizer, while the chain itself alternates MFMA-bound dgrads with HBM-bound BN / pooling
 # backward kernels.  Launching wgrad on a second HIP stream lets the two kinds of kernels share the

@@ -127,6 +127,29 @@ int fsc_conv_wgrad(const fsc_conv_desc* d, const float* in, const float* dout,
                    float* dweight, void* workspace, const float* in_amax, const float* dout_amax,
                    fsc_stream_t stream);
 
+/* ---- pre-split activations ("L16" tensors) for the split-fp16 arithmetic (arith 3).
+ * The kernels behind fsc_conv_fwd split every fp32 activation into its two fp16 limbs beside the MFMAs, once per
+ * tap.  An L16 tensor holds the limbs ready-made, in the layout of the MFMA operand: for a logical (N, C, HW) fp32
+ * tensor, half[N][ceil(C/8)][2 limbs][HW][8 channels] (4 bytes per element; pad channels are zero), scaled by the
+ * power of two the kernels derive from the tensor's declared maximum `amax` (an FSC_AMAX_FLOATS buffer; the SAME buffer
+ * must accompany the tensor to its consumers).  Producers: fsc_l16_pack, and the fused BN / PReLU kernels
+ * (fsc_bn_act_fwd_l16 ...).  Consumers: fsc_conv_l16_fwd (forward and input gradient of nn.Conv2d 3x3 / 1x1,
+ * classifiers.py:526-531, 77-81).  Results are bit-identical to fsc_conv_fwd with arith 3 on the fp32 tensor. */
+size_t fsc_l16_bytes(int n, int c, long hw);
+int fsc_l16_pack(const float* x, int n, int c, long hw, const float* amax, void* out_l16, fsc_stream_t stream);
+/* (h + l) / scale back to fp32 NCHW (tests, debugging) */
+int fsc_l16_unpack(const void* in_l16, int n, int c, long hw, const float* amax, float* x, fsc_stream_t stream);
+/* 1 when fsc_conv_l16_fwd has a tiling for this shape and direction (3x3 / 1x1, >= 32 input and >= 48 output
+ * channels, enough work items to fill the chip without split-K; arith 3 or FSC_ARITH_DEFAULT) */
+int fsc_conv_l16_supported(const fsc_conv_desc* d, int dgrad);
+size_t fsc_conv_l16_packed_floats(const fsc_conv_desc* d, int dgrad);
+int fsc_conv_l16_pack_weights(const fsc_conv_desc* d, const float* weight, int dgrad, float* packed,
+                              fsc_stream_t stream);
+/* out (fp32 NCHW) = conv(in) + bias, or += with accumulate; dgrad as in fsc_conv_fwd */
+int fsc_conv_l16_fwd(const fsc_conv_desc* d, const void* in_l16, const float* in_amax, const float* packed,
+                     const float* bias, int dgrad, int accumulate, float* out, fsc_stream_t stream);
+int fsc_conv_l16_plan_describe(const fsc_conv_desc* d, int dgrad, char* buf, size_t buf_len);
+
 /* ------------------------------------------------------------------ batch norm + PReLU (K6, K9, K11)
  * nn.BatchNorm2d/1d (train and eval) fused with the following per-channel PReLU and the
  * residual add of ResnetBlock(2d) (classifiers.py:524,533-534; 37-104; 543-546).
