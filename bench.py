@@ -428,7 +428,12 @@ def main():
             # split kernels (name ..._x3_kernel<..., NPROD>): every algorithmic fp32 flop costs NPROD 16-bit
             # MFMA flops, so `achieved` counts EXECUTED 16-bit flops and is priced against the dense fp16 / bf16 peak
             peak, executed_per_flop, arith = PEAK_F32_MFMA_TFLOPS, 1, "native fp32 MFMA"
-            if "_x3_kernel" in dom_name:
+            if "conv_l16_" in dom_name:        # pre-split (L16) operands: the same 2-limb fp16 arithmetic, 3 products
+                executed_per_flop = 3
+                peak = PEAK_BF16_MFMA_TFLOPS
+                arith = ("fp32 via 2-limb fp16 split with per-tensor power-of-two scaling (operands pre-split by their "
+                         "producers: L16 tensors), 3 fp16 MFMA products per fp32 product, fp32 accumulate")
+            elif "_x3_kernel" in dom_name:
                 executed_per_flop = int(dom_name.rstrip(">").split(",")[-1])
                 peak = PEAK_BF16_MFMA_TFLOPS
                 arith = "fp32 via exact 3-limb bf16 split, %d bf16 MFMA products per fp32 product, fp32 accumulate" % executed_per_flop

@@ -62,12 +62,16 @@ SIGNATURES = {
     "fsc_conv_l16_pack_weights": (_I, [_D, _P, _I, _P, _P]),
     "fsc_conv_l16_fwd": (_I, [_D, _P, _P, _P, _P, _I, _I, _P, _P]),
     "fsc_conv_l16_plan_describe": (_I, [_D, _I, C.c_char_p, _SZ]),
+    "fsc_conv_l16_wgrad_supported": (_I, [_D]),
+    "fsc_conv_l16_wgrad_workspace_bytes": (_SZ, [_D]),
+    "fsc_conv_l16_wgrad": (_I, [_D, _P, _P, _P, _P, _P, _P, _P]),
+    "fsc_conv_l16_wgrad_plan_describe": (_I, [_D, C.c_char_p, _SZ]),
     "fsc_bn_workspace_bytes": (_SZ, [_I]),
-    "fsc_bn_train_stats": (_I, [_P, _I, _I, _L, _P, _P, _F, _F, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P]),
+    "fsc_bn_train_stats": (_I, [_P, _I, _I, _L, _P, _P, _F, _F, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P]),
     "fsc_bn_eval_prepare": (_I, [_I, _P, _P, _P, _P, _F, _P, _P, _P]),
-    "fsc_bn_act_fwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _L, _P, _P]),
-    "fsc_bn_act_bwd": (_I, [_P] * 16 + [_I, _I, _L, _P, _P, _P, _I, _P]),
-    "fsc_bn_act_bwd_unpool": (_I, [_P] * 13 + [_I, _I, _I, _I, _I, _P, _P, _P, _I, _P]),
+    "fsc_bn_act_fwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _L, _P, _P, _P, _P]),
+    "fsc_bn_act_bwd": (_I, [_P] * 16 + [_I, _I, _L, _P, _P, _P, _I, _P, _P]),
+    "fsc_bn_act_bwd_unpool": (_I, [_P] * 13 + [_I, _I, _I, _I, _I, _P, _P, _P, _I, _P, _P]),
     "fsc_maxpool_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
     "fsc_maxpool_bwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
     "fsc_global_maxpool_fwd": (_I, [_P, _P, _P, _I, _L, _P]),

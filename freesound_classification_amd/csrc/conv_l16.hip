@@ -20,6 +20,7 @@
 //
 // Replaces nn.Conv2d 3x3 / 1x1 forward and input gradient (reference networks/classifiers.py:526-531, 77-81).
 #include "common.h"
+#include "l16.h"
 #include <stdlib.h>
 #include <string.h>
 
@@ -59,25 +60,10 @@ __device__ __forceinline__ void glds16(const void* src, void* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((glb_ptr)src, (lds_ptr)lds_wave_base, 16, 0, 0);
 }
 
-__device__ __forceinline__ void split2_pair(float x0, float x1, float s, unsigned& h, unsigned& l) {
-    unsigned hp, lp;
-    asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(hp) : "v"(x0), "v"(s));
-    asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(hp) : "v"(x1), "v"(s));
-    asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(lp) : "v"(x0), "v"(s), "v"(hp));
-    asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(lp) : "v"(x1), "v"(s), "v"(hp));
-    h = hp;
-    l = lp;
-}
-__device__ __forceinline__ int scale_field(float amax) {
-    const int e = (int)((__float_as_uint(amax) >> 23) & 0xffu);
-    int f = 268 - e;
-    f = f < 2 ? 2 : f > 252 ? 252 : f;
-    return f;
-}
-__device__ __forceinline__ float field_to_float(int f) { return __uint_as_float((unsigned)f << 23); }
-__device__ __forceinline__ float inv_scale(int f, float amax) {
-    return ((__float_as_uint(amax) >> 23) & 0xffu) == 0xffu ? __uint_as_float(0x7fc00000u) : field_to_float(254 - f);
-}
+using l16::split2_pair;
+using l16::scale_field;
+using l16::field_to_float;
+using l16::inv_scale;
 __device__ __forceinline__ f32x4 mfma16(u32x4 a, u32x4 b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
 }
@@ -606,7 +592,9 @@ bool plan_l16_pt(const fsc_conv_desc& d_in, int dgrad, int pt, int max_cot, LPla
     const int tiles = fsc::ceil_div(g.cout, 16);
     int best_cot = 1, best_blocks = tiles;
     long best_cost = -1;
+    const char* force_cot = getenv("FSC_L16_COT");          // development: force the channel tiles per workgroup
     for (int cot = 1; cot <= max_cot; ++cot) {
+        if (force_cot && cot != atoi(force_cot)) continue;
         const int blocks = fsc::ceil_div(tiles, cot);
         const long cost = (long)blocks * (cot * 3 + 4);
         if (best_cost < 0 || cost < best_cost || (cost == best_cost && blocks < best_blocks)) {
@@ -676,7 +664,9 @@ bool plan_l16(const fsc_conv_desc& d, int dgrad, LPlan* out) {
     if (d.arith != FSC_ARITH_DEFAULT && d.arith != 3) return false;
     if (getenv("FSC_NO_L16")) return false;
     const int taps = d.kh * d.kw;
-    if (plan_l16_pt(d, dgrad, 2, 8, out)) return true;
+    const char* force_pt = getenv("FSC_L16_PT");            // development: force the pixel tiles per wave
+    if ((!force_pt || atoi(force_pt) == 2) && plan_l16_pt(d, dgrad, 2, taps == 1 ? 8 : 10, out)) return true;
+    if (force_pt && atoi(force_pt) == 2) return false;
     return plan_l16_pt(d, dgrad, 1, taps == 1 ? 8 : 10, out);
 }
 

@@ -1,0 +1,463 @@
+// Weight gradient of nn.Conv2d 3x3 / 1x1 (reference networks/classifiers.py:526-531, 77-81) from PRE-SPLIT operands
+// (L16 tensors, see conv_l16.hip / include/fsc_hip.h):
+//
+//     dW[co][ci][tap] = sum over pixels  dOut[co][p] * In[ci][p + tap]          K = pixels
+//
+// Both operands are activations.  conv.hip's conv_wgrad_x3_kernel reads them as fp32 planes and splits every value into
+// fp16 limbs beside the MFMAs; here they arrive as limbs, 8 channels of a position per 16 bytes.  The MFMA wants the
+// OTHER orientation -- a lane holds 8 consecutive pixels (K) of one channel -- which is exactly what the LDS transpose
+// read of gfx950 delivers: ds_read_b64_tr_b16 hands lane l of a 16-lane group element j = halfword (l & 3) of the 8 bytes
+// lane 4 j + (l >> 2) addressed (measured with tools/probe/tr16_probe.hip).  With lane i = 4 j + c4 addressing
+// [position p0 + j][channels 4 c4 .. 4 c4 + 3] the group receives [channel l][positions p0 .. p0 + 3]: two reads = one
+// 16x16x32 operand, for ANY position offset -- the nine taps of a 3x3 layer are nine address offsets into the one staged
+// box, with no shifting, re-pairing or splitting in registers (the fp32 kernel spends 28 VALU per three taps on that).
+//
+// Workgroup = 8 waves = ng co groups x nt ci groups; a wave owns <= MT co tiles x (3x3: one ci tile x 9 taps | 1x1: CT ci
+// tiles).  Unit of work = a box of 64 pixels (th x tw, tw in {8, 16, 32, 64}) staged by 16-byte LDS-DMA, two stages,
+// split-K over boxes; partial sums [split][tap][ci][co] and the reduce kernel as in conv.hip.  Products and order per
+// k-step are those of the f16x3 arithmetic (lh, hl, hh).
+#include "common.h"
+#include "l16.h"
+#include <stdlib.h>
+#include <type_traits>
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef short v4s __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void* lds_ptr;
+typedef __attribute__((address_space(3))) v4s* lds_v4s;
+typedef __attribute__((address_space(1))) const void* glb_ptr;
+
+constexpr int kWaves = 8;
+constexpr int kMaxXI = 4;          // input DMA instructions per (octet, limb) plane: plane <= 256 positions
+
+struct WGeom {
+    int n, cin, cout, h, w;
+    long hw;
+    int oct_in, oct_out;            // octets of the two L16 tensors
+    int th, tw, tiles_h, tiles_w;   // 64-pixel box and boxes per image
+    int rows, cols, plane;          // staged input window incl. halo; plane = rows * cols
+    int xi;                         // ceil(plane / 64)
+    int units, nsplit;
+    int ng, nt;                     // co groups x ci groups of a workgroup (ng * nt == 8)
+    int tpb, tpg;                   // co tiles per block / per group (tpg <= MT)
+    int co_blocks, ci_blocks, co_pad, ci_pad;
+};
+
+__device__ __attribute__((aligned(16))) float g_zero16_w[4] = {0.f, 0.f, 0.f, 0.f};
+
+__device__ __forceinline__ void glds16(const void* src, void* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((glb_ptr)src, (lds_ptr)lds_wave_base, 16, 0, 0);
+}
+__device__ __forceinline__ f32x4 mfma16(u32x4 a, u32x4 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+// two transpose reads = the 8 K values (positions p .. p + 7) of this lane's channel; `p` = byte address of the lane's piece
+__device__ __forceinline__ u32x4 tr_read8(const char* p) {
+    const u32x2 lo = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s)(p)));
+    const u32x2 hi = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s)(p + 64)));
+    return (u32x4){lo[0], lo[1], hi[0], hi[1]};
+}
+
+// same co-tile spreading as conv.hip wgx_group
+__host__ __device__ inline void w_group(int live, int ng, int q, int* start, int* count) {
+    const int base = live / ng, extra = live - base * ng;
+    int st = 0, cnt = 0;
+    for (int k = 0; k <= q; ++k) {
+        const int rank = k < (ng + 1) / 2 ? 2 * k : 2 * (ng - 1 - k) + 1;
+        cnt = base + (rank < extra ? 1 : 0);
+        if (k < q) st += cnt;
+    }
+    *start = st;
+    *count = cnt;
+}
+
+__device__ __forceinline__ void xcd_block_order(int* block, int* split) {
+    const unsigned bx = gridDim.x, total = gridDim.x * gridDim.y;
+    const unsigned id = blockIdx.x + bx * blockIdx.y;
+    const unsigned xcd = id & 7u, slot = id >> 3;
+    const unsigned chunk = total >> 3, rem = total & 7u;
+    const unsigned v = xcd < rem ? xcd * (chunk + 1) + slot : rem * (chunk + 1) + (xcd - rem) * chunk + slot;
+    *split = (int)(v / bx);
+    *block = (int)(v - (unsigned)*split * bx);
+}
+
+template <int KH, int KW, int MT, int CT>
+__global__ __launch_bounds__(kWaves * 64) void conv_l16_wgrad_kernel(WGeom g, const uint4* __restrict__ in,
+                                                                      const uint4* __restrict__ dout,
+                                                                      float* __restrict__ part,
+                                                                      const float* __restrict__ in_amax,
+                                                                      const float* __restrict__ dout_amax) {
+    constexpr int TAPS = KH * KW;
+    constexpr int PADH = KH / 2, PADW = KW / 2;
+    constexpr int NB = TAPS * CT;                  // B slots of a wave: (ci tile, tap)
+    static_assert(TAPS == 1 || CT == 1, "3x3: one ci tile per wave");
+
+    extern __shared__ __attribute__((aligned(16))) uint4 smem4[];
+    const int co_oct = g.ng * g.tpg * 2, ci_oct = g.nt * CT * 2;             // octets staged per operand
+    const int stage_u4 = co_oct * 2 * 64 + ci_oct * 2 * g.plane;             // uint4 per stage: dOut units, then input units
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int kq = lane >> 4, li = lane & 15, c4 = li & 3, lj = li >> 2;
+    const int lm = li;
+    const int cog = wid / g.nt, cig = wid - cog * g.nt;
+    int blk, split;
+    xcd_block_order(&blk, &split);
+    const int cb = blk / g.ci_blocks, ib = blk - cb * g.ci_blocks;
+    const int tile0 = cb * g.tpb;                                            // first co tile of the block
+    const int cit0 = ib * g.nt * CT;                                         // first ci tile of the block
+    const int total_co_tiles = (g.cout + 15) >> 4, total_ci_tiles = (g.cin + 15) >> 4;
+    int mt_live, g_start;
+    {
+        const int blk_live = tile0 + g.tpb < total_co_tiles ? g.tpb : total_co_tiles - tile0;
+        w_group(blk_live > 0 ? blk_live : 0, g.ng, cog, &g_start, &mt_live);
+        if (cit0 + cig * CT >= total_ci_tiles) mt_live = 0;                  // ci group wholly beyond c_in
+    }
+
+    // ---- operand scales
+    float inv_ab;
+    {
+        float* red = reinterpret_cast<float*>(smem4);
+        const float ma = fsc::wave_max(dout_amax[tid]), mb = fsc::wave_max(in_amax[tid]);
+        if (lane == 0) { red[wid] = ma; red[kWaves + wid] = mb; }
+        __syncthreads();
+        float xa = red[0], xb = red[kWaves];
+#pragma unroll
+        for (int i = 1; i < kWaves; ++i) { xa = fmaxf(xa, red[i]); xb = fmaxf(xb, red[kWaves + i]); }
+        __syncthreads();
+        const int fa = l16::scale_field(xa), fb = l16::scale_field(xb);
+        inv_ab = l16::inv_scale(fa, xa) * l16::inv_scale(fb, xb);
+    }
+
+    // ---- octets of the block beyond the tensors are never copied: zero them once in both stages
+    const int co_oct_live = min(co_oct, g.oct_out - tile0 * 2), ci_oct_live = min(ci_oct, g.oct_in - cit0 * 2);
+    for (int st = 0; st < 2; ++st) {
+        uint4* dl = smem4 + st * stage_u4;
+        uint4* il = dl + co_oct * 2 * 64;
+        const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+        for (int i = (co_oct_live > 0 ? co_oct_live : 0) * 2 * 64 + tid; i < co_oct * 2 * 64; i += kWaves * 64) dl[i] = z;
+        for (int i = (ci_oct_live > 0 ? ci_oct_live : 0) * 2 * g.plane + tid; i < ci_oct * 2 * g.plane; i += kWaves * 64) il[i] = z;
+    }
+
+    // ---- unit-invariant DMA plans.  dOut: lane = pixel of the box in row-major (= run) order; input: lane + 64 j =
+    //      position of the halo'd window
+    const int pr = lane / g.tw, pc = lane - pr * g.tw;
+    int qr[kMaxXI], qc[kMaxXI];
+#pragma unroll
+    for (int j = 0; j < kMaxXI; ++j) {
+        const int o = lane + 64 * j;
+        qr[j] = o / g.cols;
+        qc[j] = o - qr[j] * g.cols;
+        if (o >= g.plane) qr[j] = -1;
+    }
+    const uint4* const zero = reinterpret_cast<const uint4*>(g_zero16_w);
+    const long do_img = (long)g.oct_out * 2 * g.hw, in_img = (long)g.oct_in * 2 * g.hw;
+    auto issue_unit = [&](int u, int stage) {
+        uint4* dl = smem4 + stage * stage_u4;
+        uint4* il = dl + co_oct * 2 * 64;
+        int t = u;
+        const int twi = t % g.tiles_w; t /= g.tiles_w;
+        const int thi = t % g.tiles_h; t /= g.tiles_h;
+        const int n0 = t, h0 = thi * g.th, w0 = twi * g.tw;
+        {
+            const bool live = h0 + pr < g.h && w0 + pc < g.w;
+            const uint4* src = dout + (long)n0 * do_img + (long)(tile0 * 2) * 2 * g.hw + (long)(h0 + pr) * g.w + (w0 + pc);
+#pragma unroll 1
+            for (int un = wid; un < co_oct_live * 2; un += kWaves)            // unit = (octet, limb)
+                glds16(live ? src + (long)un * g.hw : zero, dl + un * 64);
+        }
+#pragma unroll
+        for (int j = 0; j < kMaxXI; ++j) {
+            if (j < g.xi && qr[j] >= 0) {
+                const int gh = h0 + qr[j] - PADH, gw = w0 + qc[j] - PADW;
+                const bool live = gh >= 0 && gh < g.h && gw >= 0 && gw < g.w;
+                const uint4* src = in + (long)n0 * in_img + (long)(cit0 * 2) * 2 * g.hw + (long)gh * g.w + gw;
+#pragma unroll 1
+                for (int un = wid; un < ci_oct_live * 2; un += kWaves)
+                    glds16(live ? src + (long)un * g.hw : zero, il + un * g.plane + j * 64);
+            }
+        }
+    };
+
+    f32x4 acc[NB][MT];
+#pragma unroll
+    for (int s = 0; s < NB; ++s)
+#pragma unroll
+        for (int i = 0; i < MT; ++i) acc[s][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // ---- this lane's transpose-read pieces.  A (dOut) of tile i, limb l, k-step st:
+    //      ((2 (g_start + i) + (c4 >> 1)) * 2 + l) * 64 positions + run * 8 + lj, + (c4 & 1) * 8 bytes;  run = 4 st + kq
+    const int runs_shift = g.tw == 8 ? 0 : g.tw == 16 ? 1 : g.tw == 32 ? 2 : 3;      // log2(runs per box row)
+    const int a_lane = (((2 * g_start + (c4 >> 1)) * 2) * 64 + kq * 8 + lj) * 16 + (c4 & 1) * 8;
+    //      B (input) of slot (ci tile ct, tap), limb l: ((2 (cig * CT + ct) + (c4 >> 1)) * 2 + l) * plane + (r + ty) * cols + c0 + tx + lj
+    int b_lane[2];
+#pragma unroll
+    for (int st = 0; st < 2; ++st) {
+        const int run = 4 * st + kq;
+        const int r = run >> runs_shift, c0 = (run - (r << runs_shift)) * 8;
+        b_lane[st] = (((2 * cig * CT + (c4 >> 1)) * 2) * g.plane + r * g.cols + c0 + lj) * 16 + (c4 & 1) * 8;
+    }
+    const int limb_b = g.plane * 16;
+    constexpr int kLa[3] = {1, 0, 0}, kLb[3] = {0, 1, 0};     // (A limb, B limb): l*h, h*l, h*h
+
+    // The whole unit loop is specialised on the wave's live co tiles (dead tiles of a block's last group are skipped without
+    // a branch per MFMA; a switch INSIDE the loop makes hipcc keep two copies of the accumulators).
+    auto run_units = [&](auto live_c) {
+        constexpr int LIVE = decltype(live_c)::value;
+        int stage = 0;
+        if (split < g.units) issue_unit(split, 0);
+#pragma unroll 1
+        for (int u = split; u < g.units; u += g.nsplit) {
+            __syncthreads();                  // unit u has landed (vmcnt drained); everyone is done with the other stage
+            if (u + g.nsplit < g.units) issue_unit(u + g.nsplit, stage ^ 1);
+            const char* dl = reinterpret_cast<const char*>(smem4 + stage * stage_u4);
+            const char* il = dl + (size_t)co_oct * 2 * 64 * 16;
+            if constexpr (LIVE > 0) {
+#pragma unroll 1
+                for (int st = 0; st < 2; ++st) {
+                    const char* ap = dl + a_lane + st * (4 * 8 * 16);
+                    const char* bp = il + b_lane[st];
+                    u32x4 af[LIVE][2];
+#pragma unroll
+                    for (int i = 0; i < LIVE; ++i)
+#pragma unroll
+                        for (int l = 0; l < 2; ++l) af[i][l] = tr_read8(ap + (i * 4 + l) * 64 * 16);
+                    u32x4 bf[2][2];                                            // [buffer][limb]
+                    auto read_slot = [&](int s, u32x4 (&dst)[2]) {
+                        const int ct = s / TAPS, tap = s - ct * TAPS;
+                        const int ty = tap / KW, tx = tap - ty * KW;
+                        const char* p = bp + ct * 4 * limb_b + (ty * g.cols + tx) * 16;
+                        dst[0] = tr_read8(p);
+                        dst[1] = tr_read8(p + limb_b);
+                    };
+                    read_slot(0, bf[0]);
+#pragma unroll
+                    for (int s = 0; s < NB; ++s) {
+                        if (s + 1 < NB) read_slot(s + 1, bf[(s + 1) & 1]);
+#pragma unroll
+                        for (int gq = 0; gq < 3; ++gq)
+#pragma unroll
+                            for (int i = 0; i < LIVE; ++i) acc[s][i] = mfma16(af[i][kLa[gq]], bf[s & 1][kLb[gq]], acc[s][i]);
+                        // the next slot's four reads go behind the first MFMAs of this one; nothing else moves across slots
+                        // (unpinned, the scheduler hoists every slot's reads to the top of the k-step: +56 registers)
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                            if (s + 1 < NB) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+            }
+            stage ^= 1;
+        }
+    };
+    switch (mt_live) {
+        case 0: run_units(std::integral_constant<int, 0>{}); break;
+        case 1: run_units(std::integral_constant<int, 1>{}); break;
+        case 2: if constexpr (MT >= 2) run_units(std::integral_constant<int, 2>{}); break;
+        case 3: if constexpr (MT >= 3) run_units(std::integral_constant<int, 3>{}); break;
+        default: if constexpr (MT >= 4) run_units(std::integral_constant<int, 4>{}); break;
+    }
+
+    // partial[split][tap][ci][co]; D row = co (kq*4 + r), column = ci (lm)
+#pragma unroll
+    for (int s = 0; s < NB; ++s) {
+        const int ct = s / TAPS, tap = s - ct * TAPS;
+        const long row = ((long)split * TAPS + tap) * g.ci_pad + (cit0 + cig * CT + ct) * 16 + lm;
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            if (i < mt_live && cit0 + cig * CT + ct < total_ci_tiles) {
+                const int tile = tile0 + g_start + i;
+                const f32x4 a = acc[s][i] * inv_ab;
+                *reinterpret_cast<float4*>(part + row * g.co_pad + tile * 16 + kq * 4) = make_float4(a[0], a[1], a[2], a[3]);
+            }
+        }
+    }
+}
+
+// blockIdx.y = (tap, ci) row of the partial slices, threads run along co (coalesced reads)
+__global__ void l16_wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, int c_out, int c_in,
+                                        int taps, int ci_pad, int co_pad, int nsplit) {
+    const int co = blockIdx.x * blockDim.x + threadIdx.x;
+    if (co >= c_out) return;
+    const int tap = blockIdx.y / c_in, ci = blockIdx.y - tap * c_in;
+    const long slice = (long)taps * ci_pad * co_pad;
+    const float* p = part + ((long)tap * ci_pad + ci) * co_pad + co;
+    float s0 = 0.f, s1 = 0.f;
+    int sp = 0;
+    for (; sp + 1 < nsplit; sp += 2) {
+        s0 += p[(long)sp * slice];
+        s1 += p[(long)(sp + 1) * slice];
+    }
+    if (sp < nsplit) s0 += p[(long)sp * slice];
+    dw[((long)co * c_in + ci) * taps + tap] = s0 + s1;
+}
+
+// -------------------------------------------------------------------------------------------
+struct WPlan {
+    WGeom g;
+    int mt, ct;
+    size_t lds_bytes;
+};
+
+bool plan_l16_wgrad(const fsc_conv_desc& d, WPlan* out) {
+    if (d.arith != FSC_ARITH_DEFAULT && d.arith != 3) return false;
+    if (getenv("FSC_NO_L16") || getenv("FSC_NO_L16_WGRAD")) return false;
+    const int taps = d.kh * d.kw;
+    if (!((d.kh == 3 && d.kw == 3) || (d.kh == 1 && d.kw == 1))) return false;
+    if (d.c_in < 32 || d.c_out < 32) return false;
+    WPlan p{};
+    WGeom& g = p.g;
+    int h = d.h, w = d.w;
+    if (taps == 1) {                 // no halo: every (n, octet) plane is one row of h*w positions
+        w = d.h * d.w;
+        h = 1;
+    }
+    g.n = d.n; g.cin = d.c_in; g.cout = d.c_out; g.h = h; g.w = w; g.hw = (long)h * w;
+    g.oct_in = (d.c_in + 7) / 8; g.oct_out = (d.c_out + 7) / 8;
+    if ((long)d.n * g.oct_in * 2 * g.hw >= (1L << 31) || (long)d.n * g.oct_out * 2 * g.hw >= (1L << 31)) return false;
+    long best_px = -1;
+    for (int tw = 64; tw >= 8; tw >>= 1) {
+        const int th = 64 / tw;
+        if (th > 1 && h == 1) continue;
+        if ((th + d.kh - 1) * (tw + d.kw - 1) > 64 * kMaxXI) continue;
+        const long px = (long)fsc::ceil_div(h, th) * fsc::ceil_div(w, tw) * 64;
+        // wider boxes fetch less halo: prefer them unless they waste more than ~6 % of the pixels
+        if (best_px < 0 || px * 100 < best_px * 94) { best_px = px; g.th = th; g.tw = tw; }
+    }
+    if (best_px < 0 || (double)h * w < 0.6 * (double)best_px) return false;
+    g.tiles_h = fsc::ceil_div(h, g.th); g.tiles_w = fsc::ceil_div(w, g.tw);
+    g.units = d.n * g.tiles_h * g.tiles_w;
+    g.rows = g.th + d.kh - 1; g.cols = g.tw + d.kw - 1;
+    g.plane = g.rows * g.cols;
+    g.xi = fsc::ceil_div(g.plane, 64);
+    const int ct = taps == 1 ? 4 : 1;
+    p.ct = ct;
+    const int tiles_co = fsc::ceil_div(d.c_out, 16), tiles_ci = fsc::ceil_div(d.c_in, 16);
+    double best_eff = -1.0;
+    for (int nt = 1; nt <= 8; nt *= 2) {
+        const int ng = kWaves / nt;
+        const int ci_blocks = fsc::ceil_div(tiles_ci, nt * ct);
+        const int co_blocks = fsc::ceil_div(tiles_co, ng * 4);
+        const int tpb = fsc::ceil_div(tiles_co, co_blocks);
+        const int tpg = fsc::ceil_div(tpb, ng);
+        const size_t lds = 2 * 16 * ((size_t)ng * tpg * 2 * 2 * 64 + (size_t)nt * ct * 2 * 2 * g.plane);
+        if (lds > 160 * 1024) continue;
+        static const double kTileWeight[5] = {0.0, 0.6, 0.8, 0.93, 1.0};
+        long busiest = 0;
+        for (int cb = 0; cb < co_blocks; ++cb)
+            for (int ib = 0; ib < ci_blocks; ++ib) {
+                int worst = 0;
+                for (int sd = 0; sd < 4; ++sd) {
+                    int load = 0;
+                    for (int wv = sd; wv < kWaves; wv += 4) {
+                        const int cog = wv / nt, cig = wv % nt;
+                        const int blk_live = cb * tpb + tpb < tiles_co ? tpb : tiles_co - cb * tpb;
+                        int first, live;
+                        w_group(blk_live > 0 ? blk_live : 0, ng, cog, &first, &live);
+                        int ci_live = tiles_ci - (ib * nt + cig) * ct;
+                        ci_live = ci_live < 0 ? 0 : ci_live > ct ? ct : ci_live;
+                        load += live * (ci_live > 0 ? ct : 0);           // (dead ci tiles of a live group still run)
+                    }
+                    if (load > worst) worst = load;
+                }
+                busiest += worst;
+            }
+        const double eff = (double)tiles_co * tiles_ci / (4.0 * (double)busiest) * kTileWeight[tpg];
+        if (eff > best_eff) {
+            best_eff = eff;
+            g.ng = ng; g.nt = nt; g.tpb = tpb; g.tpg = tpg; g.co_blocks = co_blocks; g.ci_blocks = ci_blocks;
+            p.lds_bytes = lds;
+        }
+    }
+    if (best_eff < 0.4) return false;
+    p.mt = g.tpg;
+    g.co_pad = g.co_blocks * g.tpb * 16;
+    g.ci_pad = g.ci_blocks * g.nt * ct * 16;
+    const long base = (long)g.co_blocks * g.ci_blocks;
+    const long part_bytes_per_split = (long)taps * g.ci_pad * g.co_pad * 4;
+    long ns = base >= 256 ? 1 : 256 / base;
+    if (ns > g.units / 4) ns = g.units / 4;
+    if (ns < 1) ns = 1;
+    while (ns > 1 && ns * part_bytes_per_split > (256L << 20)) --ns;
+    g.nsplit = (int)ns;
+    *out = p;
+    return true;
+}
+
+template <int KH, int KW, int MT, int CT>
+void launch_k(const WPlan& p, const uint4* in, const uint4* dout, float* part, const float* in_amax, const float* dout_amax,
+              hipStream_t st) {
+    auto kern = conv_l16_wgrad_kernel<KH, KW, MT, CT>;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes);
+    dim3 grid(p.g.co_blocks * p.g.ci_blocks, p.g.nsplit);
+    hipLaunchKernelGGL(kern, grid, dim3(kWaves * 64), p.lds_bytes, st, p.g, in, dout, part, in_amax, dout_amax);
+}
+
+bool valid_desc(const fsc_conv_desc* d) {
+    if (!d || d->n <= 0 || d->c_in <= 0 || d->c_out <= 0 || d->h <= 0 || d->w <= 0) return false;
+    const long big = 1L << 31;
+    return (long)d->n * d->c_in * d->h * d->w < big && (long)d->n * d->c_out * d->h * d->w < big;
+}
+
+}  // namespace
+
+extern "C" {
+
+int fsc_conv_l16_wgrad_supported(const fsc_conv_desc* d) {
+    WPlan p;
+    return valid_desc(d) && plan_l16_wgrad(*d, &p) ? 1 : 0;
+}
+
+size_t fsc_conv_l16_wgrad_workspace_bytes(const fsc_conv_desc* d) {
+    WPlan p;
+    if (!valid_desc(d) || !plan_l16_wgrad(*d, &p)) return 0;
+    return (size_t)p.g.nsplit * d->kh * d->kw * p.g.ci_pad * p.g.co_pad * sizeof(float);
+}
+
+int fsc_conv_l16_wgrad(const fsc_conv_desc* d, const void* in_l16, const float* in_amax, const void* dout_l16,
+                       const float* dout_amax, float* dweight, void* workspace, fsc_stream_t stream) {
+    WPlan p;
+    FSC_CHECK_ARG(valid_desc(d) && in_l16 && in_amax && dout_l16 && dout_amax && dweight && workspace,
+                  "fsc_conv_l16_wgrad: bad descriptor or null pointer");
+    FSC_CHECK_ARG(plan_l16_wgrad(*d, &p), "fsc_conv_l16_wgrad: unsupported shape (see fsc_conv_l16_wgrad_supported)");
+    hipStream_t st = fsc::as_stream(stream);
+    const uint4* in = reinterpret_cast<const uint4*>(in_l16);
+    const uint4* dout = reinterpret_cast<const uint4*>(dout_l16);
+    float* part = reinterpret_cast<float*>(workspace);
+#define FSC_WL(MT_)                                                                               \
+    if (d->kh == 3) launch_k<3, 3, MT_, 1>(p, in, dout, part, in_amax, dout_amax, st);            \
+    else launch_k<1, 1, MT_, 4>(p, in, dout, part, in_amax, dout_amax, st);                       \
+    break;
+    switch (p.mt) {
+        case 1: FSC_WL(1)
+        case 2: FSC_WL(2)
+        case 3: FSC_WL(3)
+        default: FSC_WL(4)
+    }
+#undef FSC_WL
+    FSC_LAUNCH_CHECK("fsc_conv_l16_wgrad");
+    const int taps = d->kh * d->kw;
+    const int rthreads = d->c_out >= 128 ? 128 : 64;
+    hipLaunchKernelGGL(l16_wgrad_reduce_kernel, dim3(fsc::ceil_div(d->c_out, rthreads), taps * d->c_in), dim3(rthreads), 0, st,
+                       part, dweight, d->c_out, d->c_in, taps, p.g.ci_pad, p.g.co_pad, p.g.nsplit);
+    FSC_LAUNCH_CHECK("fsc_conv_l16_wgrad(reduce)");
+    return 0;
+}
+
+int fsc_conv_l16_wgrad_plan_describe(const fsc_conv_desc* d, char* buf, size_t buf_len) {
+    WPlan p;
+    FSC_CHECK_ARG(valid_desc(d) && buf && buf_len > 0 && plan_l16_wgrad(*d, &p), "fsc_conv_l16_wgrad_plan_describe: unsupported shape");
+    snprintf(buf, buf_len, "conv_l16_wgrad_kernel<%d,%d,%d,%d> box=%dx%d groups=%dx%d tiles/block=%d units=%d split=%d grid=%dx%d lds=%zu",
+             d->kh, d->kw, p.mt, p.ct, p.g.th, p.g.tw, p.g.ng, p.g.nt, p.g.tpb, p.g.units, p.g.nsplit,
+             p.g.co_blocks * p.g.ci_blocks, p.g.nsplit, p.lds_bytes);
+    return 0;
+}
+
+}  // extern "C"

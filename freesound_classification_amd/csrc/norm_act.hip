@@ -8,19 +8,21 @@
 // Per-channel reductions: fp32 per-thread partials on pivot-shifted data, fp64 across threads,
 // blocks and splits (deterministic two-stage reduce, no atomics on the statistics).
 #include "common.h"
+#include "l16.h"
 
 namespace {
 
 constexpr int kThreads = 256;
 constexpr int kMaxSplit = 64;
 
-// workspace layout (doubles): partial[c][split][4], then coef[c][4] floats
+// workspace layout (doubles): partial[c][split][8], then coef[c][4] floats
 struct Partials {
-    double* part;   // c * kMaxSplit * 4
+    double* part;   // c * kMaxSplit * kPartStride
     float* coef;    // c * 4
 };
 
-__host__ __device__ inline size_t part_doubles(int c) { return (size_t)c * kMaxSplit * 4; }
+constexpr int kPartStride = 8;
+__host__ __device__ inline size_t part_doubles(int c) { return (size_t)c * kMaxSplit * kPartStride; }
 
 inline Partials carve(void* ws, int c) {
     Partials p;
@@ -40,6 +42,7 @@ __global__ __launch_bounds__(kThreads) void stats_partial_kernel(
     const int hwp = 1 << hwp_log2, groups = kThreads >> hwp_log2;
     const int tn = threadIdx.x >> hwp_log2, ti = threadIdx.x & (hwp - 1);
     float s1 = 0.f, s2 = 0.f;
+    float mn = pivot, mx = pivot;          // smallest / largest x of the channel (the L16 producers' operand bound)
     const bool vec = (hw & 3) == 0 && hwp == kThreads;
     for (int b = sp * groups + tn; b < n; b += nsplit * groups) {
         const float* p = x + ((long)b * c + ch) * hw;
@@ -58,11 +61,15 @@ __global__ __launch_bounds__(kThreads) void stats_partial_kernel(
                 const float a0 = v.x - pivot, a1 = v.y - pivot, a2 = v.z - pivot, a3 = v.w - pivot;
                 s1 += (a0 + a1) + (a2 + a3);
                 s2 += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
+                mn = fminf(fminf(mn, fminf(v.x, v.y)), fminf(v.z, v.w));
+                mx = fmaxf(fmaxf(mx, fmaxf(v.x, v.y)), fmaxf(v.z, v.w));
 #pragma unroll
                 for (int k = 0; k < 3; ++k) {
                     const float b0 = u[k].x - pivot, b1 = u[k].y - pivot, b2 = u[k].z - pivot, b3 = u[k].w - pivot;
                     t1[k] += (b0 + b1) + (b2 + b3);
                     t2[k] += (b0 * b0 + b1 * b1) + (b2 * b2 + b3 * b3);
+                    mn = fminf(fminf(mn, fminf(u[k].x, u[k].y)), fminf(u[k].z, u[k].w));
+                    mx = fmaxf(fmaxf(mx, fmaxf(u[k].x, u[k].y)), fmaxf(u[k].z, u[k].w));
                 }
             }
             for (; i + kThreads < n4; i += 2 * kThreads) {
@@ -73,12 +80,16 @@ __global__ __launch_bounds__(kThreads) void stats_partial_kernel(
                 s2 += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
                 t1[0] += (b0 + b1) + (b2 + b3);
                 t2[0] += (b0 * b0 + b1 * b1) + (b2 * b2 + b3 * b3);
+                mn = fminf(fminf(fminf(mn, fminf(v.x, v.y)), fminf(v.z, v.w)), fminf(fminf(u0.x, u0.y), fminf(u0.z, u0.w)));
+                mx = fmaxf(fmaxf(fmaxf(mx, fmaxf(v.x, v.y)), fmaxf(v.z, v.w)), fmaxf(fmaxf(u0.x, u0.y), fmaxf(u0.z, u0.w)));
             }
             for (; i < n4; i += kThreads) {
                 const float4 v = p4[i];
                 const float a0 = v.x - pivot, a1 = v.y - pivot, a2 = v.z - pivot, a3 = v.w - pivot;
                 s1 += (a0 + a1) + (a2 + a3);
                 s2 += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
+                mn = fminf(fminf(mn, fminf(v.x, v.y)), fminf(v.z, v.w));
+                mx = fmaxf(fmaxf(mx, fmaxf(v.x, v.y)), fmaxf(v.z, v.w));
             }
             s1 += (t1[0] + t1[1]) + t1[2];
             s2 += (t2[0] + t2[1]) + t2[2];
@@ -87,15 +98,25 @@ __global__ __launch_bounds__(kThreads) void stats_partial_kernel(
                 const float a0 = p[i] - pivot;
                 s1 += a0;
                 s2 += a0 * a0;
+                mn = fminf(mn, p[i]);
+                mx = fmaxf(mx, p[i]);
             }
         }
     }
     const double t1 = fsc::block_sum<double, kThreads / 64>((double)s1, scratch);
     const double t2 = fsc::block_sum<double, kThreads / 64>((double)s2, scratch);
+    mx = fsc::wave_max(mx);
+    mn = -fsc::wave_max(-mn);
+    __shared__ float mm[2][kThreads / 64];
+    if ((threadIdx.x & 63) == 0) { mm[0][threadIdx.x >> 6] = mn; mm[1][threadIdx.x >> 6] = mx; }
+    __syncthreads();
     if (threadIdx.x == 0) {
-        double* o = part + ((size_t)ch * kMaxSplit + sp) * 4;
+        double* o = part + ((size_t)ch * kMaxSplit + sp) * kPartStride;
         o[0] = t1;
         o[1] = t2;
+        for (int i = 1; i < kThreads / 64; ++i) { mn = fminf(mn, mm[0][i]); mx = fmaxf(mx, mm[1][i]); }
+        o[2] = (double)mn;
+        o[3] = (double)mx;
     }
 }
 
@@ -105,14 +126,20 @@ __global__ void stats_rows_kernel(const float* __restrict__ x, int n, int c, dou
     if (ch >= c) return;
     const float pivot = x[ch];
     double s1 = 0.0, s2 = 0.0;
+    float mn = pivot, mx = pivot;
     for (int b = 0; b < n; ++b) {
-        const double a = (double)(x[(long)b * c + ch] - pivot);
+        const float v = x[(long)b * c + ch];
+        const double a = (double)(v - pivot);
         s1 += a;
         s2 += a * a;
+        mn = fminf(mn, v);
+        mx = fmaxf(mx, v);
     }
-    double* o = part + (size_t)ch * kMaxSplit * 4;
+    double* o = part + (size_t)ch * kMaxSplit * kPartStride;
     o[0] = s1;
     o[1] = s2;
+    o[2] = (double)mn;
+    o[3] = (double)mx;
 }
 
 // Cross-replica statistics (SyncBN): `sync` holds per channel [sum x, sum x^2, count, -] about ZERO in
@@ -123,9 +150,18 @@ __global__ void stats_finalize_kernel(const float* __restrict__ x, int c, long h
                                       const float* __restrict__ beta, float eps, float momentum,
                                       float* running_mean, float* running_var, float* save_mean,
                                       float* save_invstd, float* scale, float* shift, double* __restrict__ sync,
-                                      int phase) {
+                                      int phase, float* __restrict__ x_minmax) {
     const int ch = blockIdx.x * blockDim.x + threadIdx.x;
     if (ch >= c) return;
+    if (x_minmax && phase != 2) {          // (phase 2 re-runs on the partials of phase 1: already written)
+        float mn = (float)part[(size_t)ch * kMaxSplit * kPartStride + 2], mx = (float)part[(size_t)ch * kMaxSplit * kPartStride + 3];
+        for (int s = 1; s < nsplit; ++s) {
+            mn = fminf(mn, (float)part[((size_t)ch * kMaxSplit + s) * kPartStride + 2]);
+            mx = fmaxf(mx, (float)part[((size_t)ch * kMaxSplit + s) * kPartStride + 3]);
+        }
+        x_minmax[2 * ch] = mn;
+        x_minmax[2 * ch + 1] = mx;
+    }
     double s1 = 0.0, s2 = 0.0, pivot = 0.0;
     if (phase == 2) {
         s1 = sync[ch * 4];
@@ -133,8 +169,8 @@ __global__ void stats_finalize_kernel(const float* __restrict__ x, int c, long h
         count = sync[ch * 4 + 2];
     } else {
         for (int s = 0; s < nsplit; ++s) {
-            s1 += part[((size_t)ch * kMaxSplit + s) * 4];
-            s2 += part[((size_t)ch * kMaxSplit + s) * 4 + 1];
+            s1 += part[((size_t)ch * kMaxSplit + s) * kPartStride];
+            s2 += part[((size_t)ch * kMaxSplit + s) * kPartStride + 1];
         }
         pivot = (double)x[(long)ch * hw];
         if (phase == 1) {                                  // moments about zero: sum (a + p) and sum (a + p)^2
@@ -260,6 +296,91 @@ __global__ void fwd_flat_kernel(const float* __restrict__ x, const float* __rest
     if (y_amax) fsc::publish_amax(y_amax, mx);
 }
 
+
+// ---------------------------------------------------------------- L16 producers (include/fsc_hip.h "pre-split activations")
+// The conv kernels of conv_l16.hip read activations as two scaled fp16 limbs, 8 channels of a position per 16 bytes.
+// The kernels below write that layout directly: a thread owns VEC consecutive positions x the 8 channels of one
+// (octet, image), reads the 8 fp32 channel planes (coalesced along positions) and stores VEC x 2 x 16 bytes.  The scale
+// needs the tensor's largest magnitude BEFORE the pass: the forward bound comes from the per-channel min / max of x the
+// statistics pass reports (affine + PReLU take their extremes at the ends of the range, so the bound is the exact
+// maximum), the backward bound from per-channel maxima of the reduce pass (see bwd_finalize_kernel).  Every block folds
+// the per-channel bounds itself; block (0, 0) publishes the value as the tensor's FSC_AMAX_FLOATS buffer.
+// UNI: planes of >= 1024 positions, one (octet, image) per block (per-channel constants in scalar registers); otherwise
+// the 256 threads split into (group, position lane) and keep their constants in vector registers.
+__device__ __forceinline__ float block_max256(float m, float* red) {
+    m = fsc::wave_max(m);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    __syncthreads();
+    return m;
+}
+
+template <int VEC, bool UNI>
+__global__ __launch_bounds__(kThreads) void fwd_l16_kernel(
+    const float* __restrict__ x, const float* __restrict__ scale, const float* __restrict__ shift,
+    const float* __restrict__ alpha, const float* __restrict__ x_minmax, float* __restrict__ y,
+    uint4* __restrict__ y16, float* __restrict__ y_amax, int n, int c, long hw, int hwp_log2) {
+    __shared__ float red[kThreads / 64];
+    const bool has_alpha = alpha != nullptr;
+    float m = 0.f;
+    for (int ch = threadIdx.x; ch < c; ch += kThreads) {
+        const float sc = scale[ch], sh = shift[ch], al = has_alpha ? alpha[ch] : 0.f;
+        const float lo = act(fmaf(x_minmax[2 * ch], sc, sh), al, has_alpha), hi = act(fmaf(x_minmax[2 * ch + 1], sc, sh), al, has_alpha);
+        m = fmaxf(m, fmaxf(fabsf(lo), fabsf(hi)));
+    }
+    m = block_max256(m, red);
+    if (blockIdx.x == 0 && blockIdx.y == 0) l16::store_amax(y_amax, m);
+    const float s = l16::field_to_float(l16::scale_field(m));
+    const int oct = (c + 7) >> 3;
+    const int hwp = UNI ? kThreads : 1 << hwp_log2, groups = UNI ? 1 : kThreads >> hwp_log2;
+    const int tn = UNI ? 0 : threadIdx.x >> hwp_log2, ti = UNI ? threadIdx.x : threadIdx.x & (hwp - 1);
+    const long g = (long)blockIdx.x * groups + tn;            // (octet, image), images fastest
+    if (g >= (long)n * oct) return;
+    const int o = (int)(g / n), img = (int)(g - (long)o * n);
+    float sc[8], sh[8], al[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int ch = o * 8 + e;
+        const bool live = ch < c;
+        sc[e] = live ? scale[ch] : 0.f;
+        sh[e] = live ? shift[ch] : 0.f;
+        al[e] = live && has_alpha ? alpha[ch] : 0.f;
+    }
+    const long nq = hw / VEC;
+    const long xbase = ((long)img * c + o * 8) * hw;
+    uint4* const out_hi = y16 + (((long)img * oct + o) * 2) * hw;
+    uint4* const out_lo = out_hi + hw;
+    for (long q = (long)blockIdx.y * hwp + ti; q < nq; q += (long)gridDim.y * hwp) {
+        float z[8][VEC];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const bool live = o * 8 + e < c;
+            if (VEC == 4) {
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (live) v = reinterpret_cast<const float4*>(x + xbase + e * hw)[q];
+                z[e][0] = act(fmaf(v.x, sc[e], sh[e]), al[e], has_alpha);
+                z[e][1 % VEC] = act(fmaf(v.y, sc[e], sh[e]), al[e], has_alpha);
+                z[e][2 % VEC] = act(fmaf(v.z, sc[e], sh[e]), al[e], has_alpha);
+                z[e][3 % VEC] = act(fmaf(v.w, sc[e], sh[e]), al[e], has_alpha);
+                if (y && live) reinterpret_cast<float4*>(y + xbase + e * hw)[q] = make_float4(z[e][0], z[e][1 % VEC], z[e][2 % VEC], z[e][3 % VEC]);
+            } else {
+                const float v = live ? x[xbase + e * hw + q] : 0.f;
+                z[e][0] = act(fmaf(v, sc[e], sh[e]), al[e], has_alpha);
+                if (y && live) y[xbase + e * hw + q] = z[e][0];
+            }
+        }
+#pragma unroll
+        for (int p = 0; p < VEC; ++p) {
+            const float v8[8] = {z[0][p], z[1][p], z[2][p], z[3][p], z[4][p], z[5][p], z[6][p], z[7][p]};
+            uint4 hi, lo;
+            l16::split8(v8, s, hi, lo);
+            out_hi[q * VEC + p] = hi;
+            out_lo[q * VEC + p] = lo;
+        }
+    }
+}
+
 // ---------------------------------------------------------------- backward
 struct BwdArgs {
     const float* dy;        // may be null (treated as zero)
@@ -294,6 +415,7 @@ __global__ __launch_bounds__(kThreads) void bwd_partial_kernel(BwdArgs a, int ns
     const int hwp = 1 << hwp_log2, groups = kThreads >> hwp_log2;
     const int tn = threadIdx.x >> hwp_log2, ti = threadIdx.x & (hwp - 1);
     float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+    float mdz = 0.f, mxh = 0.f;            // max |dz|, max |xhat|: the bound of |dx| for the L16 apply pass
     for (int nb = sp * groups + tn; nb < a.n; nb += nsplit * groups) {
         const long plane = (long)nb * a.c + ch;
         const float* px = a.x + plane * a.hw;
@@ -321,6 +443,8 @@ __global__ __launch_bounds__(kThreads) void bwd_partial_kernel(BwdArgs a, int ns
                     s0 += dz;
                     s1 += dz * xh;
                     s2 += us[e] * (neg ? z : 0.f);
+                    mdz = fmaxf(mdz, fabsf(dz));
+                    mxh = fmaxf(mxh, fabsf(xh));
                 }
             }
             continue;
@@ -335,14 +459,20 @@ __global__ __launch_bounds__(kThreads) void bwd_partial_kernel(BwdArgs a, int ns
             s0 += dz;
             s1 += dz * xh;
             s2 += up * (neg ? z : 0.f);
+            mdz = fmaxf(mdz, fabsf(dz));
+            mxh = fmaxf(mxh, fabsf(xh));
         }
     }
     const double t0 = fsc::block_sum<double, kThreads / 64>((double)s0, scratch);
     const double t1 = fsc::block_sum<double, kThreads / 64>((double)s1, scratch);
     const double t2 = fsc::block_sum<double, kThreads / 64>((double)s2, scratch);
+    __shared__ float mred[kThreads / 64];
+    mdz = block_max256(mdz, mred);
+    mxh = block_max256(mxh, mred);
     if (threadIdx.x == 0) {
-        double* o = part + ((size_t)ch * kMaxSplit + sp) * 4;
+        double* o = part + ((size_t)ch * kMaxSplit + sp) * kPartStride;
         o[0] = t0; o[1] = t1; o[2] = t2;
+        o[3] = (double)mdz; o[4] = (double)mxh;
     }
 }
 
@@ -366,8 +496,8 @@ __global__ void bwd_rows_kernel(BwdArgs a, double* __restrict__ part) {
         s0 += dz; s1 += (double)dz * xh;
         s2 += (double)up * (neg ? z : 0.f);
     }
-    double* o = part + (size_t)ch * kMaxSplit * 4;
-    o[0] = s0; o[1] = s1; o[2] = s2;
+    double* o = part + (size_t)ch * kMaxSplit * kPartStride;
+    o[0] = s0; o[1] = s1; o[2] = s2; o[3] = 0.0; o[4] = 0.0;
 }
 
 // SyncBN: phase 1 writes the parameter gradients (LOCAL sums: the gradient all-reduce adds the replicas later) and
@@ -375,9 +505,10 @@ __global__ void bwd_rows_kernel(BwdArgs a, double* __restrict__ part) {
 // the input gradient needs.  phase 0: single replica.
 __global__ void bwd_finalize_kernel(int c, double count, int nsplit, const double* __restrict__ part,
                                     float* dgamma, float* dbeta, float* dalpha, float* coef, float* dx_chan_sum,
-                                    float* dx_amax, double* __restrict__ sync, int phase) {
+                                    float* dx_amax, double* __restrict__ sync, int phase,
+                                    const float* __restrict__ gamma, const float* __restrict__ invstd, int want_bound) {
     const int ch = blockIdx.x * blockDim.x + threadIdx.x;
-    if (dx_amax && phase != 1)
+    if (dx_amax && phase != 1 && !want_bound)             // (the L16 apply pass stores the bound itself)
         for (int i = ch; i < fsc::kAmaxFloats; i += gridDim.x * blockDim.x) dx_amax[i] = 0.f;
     if (ch >= c) return;
     double s0 = 0.0, s1 = 0.0, s2 = 0.0;
@@ -387,7 +518,7 @@ __global__ void bwd_finalize_kernel(int c, double count, int nsplit, const doubl
         count = sync[ch * 4 + 2];
     } else {
         for (int s = 0; s < nsplit; ++s) {
-            const double* p = part + ((size_t)ch * kMaxSplit + s) * 4;
+            const double* p = part + ((size_t)ch * kMaxSplit + s) * kPartStride;
             s0 += p[0]; s1 += p[1]; s2 += p[2];
         }
         if (dbeta) dbeta[ch] = (float)s0;
@@ -401,9 +532,22 @@ __global__ void bwd_finalize_kernel(int c, double count, int nsplit, const doubl
             return;
         }
     }
-    coef[ch * 2] = (float)(s0 / count);
-    coef[ch * 2 + 1] = (float)(s1 / count);
+    const float c1 = (float)(s0 / count), c2 = (float)(s1 / count);
+    coef[ch * 2] = c1;
+    coef[ch * 2 + 1] = c2;
     if (dx_chan_sum) dx_chan_sum[ch] = 0.f;
+    if (want_bound) {
+        // |dx| = |k (dz - c1 - xhat c2)| <= |k| (max |dz| + |c1| + max |xhat| |c2|): the declared maximum of the L16 tensor
+        // (an over-estimate, by less than 2x for gradients whose means are small against their extremes; safe)
+        float mdz = 0.f, mxh = 0.f;
+        for (int s = 0; s < nsplit; ++s) {
+            const double* p = part + ((size_t)ch * kMaxSplit + s) * kPartStride;
+            mdz = fmaxf(mdz, (float)p[3]);
+            mxh = fmaxf(mxh, (float)p[4]);
+        }
+        const float k = (gamma ? gamma[ch] : 1.f) * invstd[ch];
+        coef[2 * c + ch] = fabsf(k) * (mdz + fabsf(c1) + mxh * fabsf(c2));
+    }
 }
 
 __global__ __launch_bounds__(kThreads) void bwd_apply_plane_kernel(BwdArgs a, const float* __restrict__ coef,
@@ -571,6 +715,214 @@ __global__ __launch_bounds__(kThreads) void bwd_apply_unpool_kernel(BwdArgs a, c
     if (dc_amax) fsc::publish_amax(dc_amax, mx);
 }
 
+// Backward apply pass writing dx as an L16 tensor (and, optionally, as fp32 planes too).  Same arithmetic as
+// bwd_apply_plane_kernel; thread layout of fwd_l16_kernel.  The scale comes from the per-channel bounds coef[2c + ch].
+template <int VEC, bool UNI>
+__global__ __launch_bounds__(kThreads) void bwd_apply_l16_kernel(BwdArgs a, const float* __restrict__ coef,
+                                                                  float* __restrict__ dx, uint4* __restrict__ dx16,
+                                                                  float* __restrict__ dres, float* dx_chan_sum,
+                                                                  float* __restrict__ dx_amax, int hwp_log2) {
+    __shared__ float red[kThreads / 64];
+    float m = 0.f;
+    for (int ch = threadIdx.x; ch < a.c; ch += kThreads) m = fmaxf(m, coef[2 * a.c + ch]);
+    m = block_max256(m, red);
+    if (blockIdx.x == 0 && blockIdx.y == 0) l16::store_amax(dx_amax, m);
+    const float s = l16::field_to_float(l16::scale_field(m));
+    const int c = a.c, oct = (c + 7) >> 3;
+    const long hw = a.hw;
+    const int hwp = UNI ? kThreads : 1 << hwp_log2, groups = UNI ? 1 : kThreads >> hwp_log2;
+    const int tn = UNI ? 0 : threadIdx.x >> hwp_log2, ti = UNI ? threadIdx.x : threadIdx.x & (hwp - 1);
+    const long g = (long)blockIdx.x * groups + tn;            // (octet, image), images fastest
+    const bool g_live = g < (long)a.n * oct;
+    const int o = g_live ? (int)(g / a.n) : 0, img = g_live ? (int)(g - (long)o * a.n) : 0;
+    const bool has_alpha = a.alpha != nullptr;
+    float acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+    const long nq = g_live ? hw / VEC : 0;
+    const long xbase = ((long)img * c + o * 8) * hw;
+    uint4* const out_hi = dx16 + (((long)img * oct + o) * 2) * hw;
+    uint4* const out_lo = out_hi + hw;
+    for (long q = (long)blockIdx.y * hwp + ti; q < nq; q += (long)gridDim.y * hwp) {
+        float d[8][VEC];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int ch = o * 8 + e;
+            if (ch < c) {
+                const float mean = a.mean[ch], invstd = a.invstd[ch];
+                const float gm = a.gamma ? a.gamma[ch] : 1.f, bt = a.beta ? a.beta[ch] : 0.f;
+                const float al = has_alpha ? a.alpha[ch] : 1.f;
+                const float c1 = coef[ch * 2], c2 = coef[ch * 2 + 1];
+                const float k = gm * invstd;
+                const long pb = xbase + e * hw;
+                const long plane = (long)img * c + ch;
+                const float gval = a.gmax_dy ? a.gmax_dy[plane] : 0.f;
+                const long gpos = a.gmax_dy ? (long)a.gmax_idx[plane] : -1;
+                float xs[VEC], rs[VEC], us[VEC], zv[VEC];
+                if (VEC == 4) {
+                    const float4 xv = reinterpret_cast<const float4*>(a.x + pb)[q];
+                    float4 rv = make_float4(0.f, 0.f, 0.f, 0.f), uv = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (a.res) rv = reinterpret_cast<const float4*>(a.res + pb)[q];
+                    if (a.dy) uv = reinterpret_cast<const float4*>(a.dy + pb)[q];
+                    xs[0] = xv.x; xs[1 % VEC] = xv.y; xs[2 % VEC] = xv.z; xs[3 % VEC] = xv.w;
+                    rs[0] = rv.x; rs[1 % VEC] = rv.y; rs[2 % VEC] = rv.z; rs[3 % VEC] = rv.w;
+                    us[0] = uv.x; us[1 % VEC] = uv.y; us[2 % VEC] = uv.z; us[3 % VEC] = uv.w;
+                } else {
+                    xs[0] = a.x[pb + q];
+                    rs[0] = a.res ? a.res[pb + q] : 0.f;
+                    us[0] = a.dy ? a.dy[pb + q] : 0.f;
+                }
+#pragma unroll
+                for (int p = 0; p < VEC; ++p) {
+                    if (q * VEC + p == gpos) us[p] += gval;
+                    const float xh = (xs[p] - mean) * invstd;
+                    const float z = fmaf(xh, gm, bt) + rs[p];
+                    zv[p] = (has_alpha && !(z > 0.f)) ? al * us[p] : us[p];
+                    d[e][p] = k * (zv[p] - c1 - xh * c2);
+                    acc[e] += d[e][p];
+                }
+                if (VEC == 4) {
+                    if (dx) reinterpret_cast<float4*>(dx + pb)[q] = make_float4(d[e][0], d[e][1 % VEC], d[e][2 % VEC], d[e][3 % VEC]);
+                    if (dres) reinterpret_cast<float4*>(dres + pb)[q] = make_float4(zv[0], zv[1 % VEC], zv[2 % VEC], zv[3 % VEC]);
+                } else {
+                    if (dx) dx[pb + q] = d[e][0];
+                    if (dres) dres[pb + q] = zv[0];
+                }
+            } else {
+#pragma unroll
+                for (int p = 0; p < VEC; ++p) d[e][p] = 0.f;
+            }
+        }
+#pragma unroll
+        for (int p = 0; p < VEC; ++p) {
+            const float v8[8] = {d[0][p], d[1][p], d[2][p], d[3][p], d[4][p], d[5][p], d[6][p], d[7][p]};
+            uint4 hi, lo;
+            l16::split8(v8, s, hi, lo);
+            out_hi[q * VEC + p] = hi;
+            out_lo[q * VEC + p] = lo;
+        }
+    }
+    if (dx_chan_sum) {
+        // a wave whose lanes all work on one octet reduces in registers; else every live thread adds its own sums
+        const int o0 = __builtin_amdgcn_readfirstlane(o);
+        const bool same = __all(o == o0);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            if (same) {
+                const float t = fsc::wave_sum(acc[e]);
+                if ((threadIdx.x & 63) == 0 && o0 * 8 + e < c) atomicAdd(dx_chan_sum + o0 * 8 + e, t);
+            } else if (g_live && o * 8 + e < c) {
+                atomicAdd(dx_chan_sum + o * 8 + e, acc[e]);
+            }
+        }
+    }
+}
+
+// L16 form of bwd_apply_unpool_kernel: a thread owns one pooled position x the 8 channels of an (octet, image) and writes the
+// 2 x 2 (or 1 x 2) window of the full-resolution gradient dc -- each channel's gradient at ITS arg-max position, zeros
+// elsewhere -- as 16-byte limb vectors; the odd trailing row / column of dc is zero.
+__global__ __launch_bounds__(kThreads) void bwd_apply_unpool_l16_kernel(BwdArgs a, const float* __restrict__ coef,
+                                                                         const uint8_t* __restrict__ pool_idx,
+                                                                         float* __restrict__ dc, uint4* __restrict__ dc16,
+                                                                         float* dx_chan_sum, int h, int w, int ph, int oh, int ow,
+                                                                         float* __restrict__ dc_amax, int hwp_log2) {
+    __shared__ float red[kThreads / 64];
+    float m = 0.f;
+    for (int ch = threadIdx.x; ch < a.c; ch += kThreads) m = fmaxf(m, coef[2 * a.c + ch]);
+    m = block_max256(m, red);
+    if (blockIdx.x == 0 && blockIdx.y == 0) l16::store_amax(dc_amax, m);
+    const float s = l16::field_to_float(l16::scale_field(m));
+    const int c = a.c, oct = (c + 7) >> 3;
+    const long hw = a.hw, HW = (long)h * w;
+    const int hwp = 1 << hwp_log2, groups = kThreads >> hwp_log2;
+    const int tn = threadIdx.x >> hwp_log2, ti = threadIdx.x & (hwp - 1);
+    const long g = (long)blockIdx.x * groups + tn;
+    const bool g_live = g < (long)a.n * oct;
+    const int o = g_live ? (int)(g / a.n) : 0, img = g_live ? (int)(g - (long)o * a.n) : 0;
+    const bool has_alpha = a.alpha != nullptr;
+    float acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+    const long xbase = ((long)img * c + o * 8) * hw;
+    uint4* const out_hi = dc16 + (((long)img * oct + o) * 2) * HW;
+    uint4* const out_lo = out_hi + HW;
+    const uint4 zero4 = make_uint4(0u, 0u, 0u, 0u);
+    const long nq = g_live ? hw : 0;
+    for (long q = (long)blockIdx.y * hwp + ti; q < nq; q += (long)gridDim.y * hwp) {
+        const int oy = (int)(q / ow), ox = (int)(q - (long)oy * ow);
+        float d[8];
+        int pos[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int ch = o * 8 + e;
+            d[e] = 0.f;
+            pos[e] = 0;
+            if (ch < c) {
+                const float mean = a.mean[ch], invstd = a.invstd[ch];
+                const float gm = a.gamma ? a.gamma[ch] : 1.f, bt = a.beta ? a.beta[ch] : 0.f;
+                const float al = has_alpha ? a.alpha[ch] : 1.f;
+                const float k = gm * invstd;
+                const long i = xbase + e * hw + q;
+                const float xh = (a.x[i] - mean) * invstd;
+                const float z = fmaf(xh, gm, bt);
+                const float up = a.dy[i];
+                const float dz = (has_alpha && !(z > 0.f)) ? al * up : up;
+                d[e] = k * (dz - coef[ch * 2] - xh * coef[ch * 2 + 1]);
+                acc[e] += d[e];
+                pos[e] = pool_idx[i];
+                if (dc) {                                   // fp32 planes as well (bwd_apply_unpool_kernel's stores)
+                    typedef float f32x2 __attribute__((ext_vector_type(2)));
+                    float* r0 = dc + ((long)img * c + ch) * HW + (long)oy * ph * w;
+                    *reinterpret_cast<f32x2*>(r0 + 2 * ox) = (f32x2){pos[e] == 0 ? d[e] : 0.f, pos[e] == 1 ? d[e] : 0.f};
+                    if (ph == 2) *reinterpret_cast<f32x2*>(r0 + w + 2 * ox) = (f32x2){pos[e] == 2 ? d[e] : 0.f, pos[e] == 3 ? d[e] : 0.f};
+                    if ((w & 1) && ox == ow - 1) {
+                        r0[w - 1] = 0.f;
+                        if (ph == 2) r0[2 * w - 1] = 0.f;
+                    }
+                }
+            }
+        }
+        for (int wpos = 0; wpos < 2 * ph; ++wpos) {
+            float v8[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v8[e] = pos[e] == wpos ? d[e] : 0.f;
+            uint4 hi, lo;
+            l16::split8(v8, s, hi, lo);
+            const long dst = (long)(oy * ph + (wpos >> 1)) * w + 2 * ox + (wpos & 1);
+            out_hi[dst] = hi;
+            out_lo[dst] = lo;
+        }
+        if ((w & 1) && ox == ow - 1) {                      // column floor-mode pooling never read
+            for (int r = 0; r < ph; ++r) {
+                out_hi[(long)(oy * ph + r) * w + w - 1] = zero4;
+                out_lo[(long)(oy * ph + r) * w + w - 1] = zero4;
+            }
+        }
+    }
+    if (ph == 2 && (h & 1) && blockIdx.y == 0 && g_live) {  // trailing row
+        for (int xx = ti; xx < w; xx += hwp) {
+            out_hi[(long)(h - 1) * w + xx] = zero4;
+            out_lo[(long)(h - 1) * w + xx] = zero4;
+            if (dc)
+                for (int e = 0; e < 8; ++e)
+                    if (o * 8 + e < c) dc[((long)img * c + o * 8 + e) * HW + (long)(h - 1) * w + xx] = 0.f;
+        }
+    }
+    if (dx_chan_sum) {
+        const int o0 = __builtin_amdgcn_readfirstlane(o);
+        const bool same = __all(o == o0);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            if (same) {
+                const float t = fsc::wave_sum(acc[e]);
+                if ((threadIdx.x & 63) == 0 && o0 * 8 + e < c) atomicAdd(dx_chan_sum + o0 * 8 + e, t);
+            } else if (g_live && o * 8 + e < c) {
+                atomicAdd(dx_chan_sum + o * 8 + e, acc[e]);
+            }
+        }
+    }
+}
+
 __global__ void bwd_apply_flat_kernel(BwdArgs a, const float* __restrict__ coef, float* __restrict__ dx,
                                       float* __restrict__ dres, float* dx_chan_sum, long total, float* dx_amax) {
     float mx = 0.f;
@@ -611,6 +963,26 @@ int hwp_log2_for(long hw) {
     return l;
 }
 
+// launch geometry of the L16 producer kernels: positions per group lane-split, blocks, UNI
+struct L16Grid { int hwp_log2; bool uni; dim3 grid; int vec; };
+L16Grid l16_grid(int n, int c, long hw, bool allow_vec) {
+    L16Grid r;
+    r.vec = (allow_vec && (hw & 3) == 0) ? 4 : 1;
+    const long nq = hw / r.vec;
+    const long groups_total = (long)n * ((c + 7) / 8);
+    r.uni = nq >= kThreads;
+    r.hwp_log2 = 8;
+    if (!r.uni) {
+        r.hwp_log2 = 0;
+        while ((1L << r.hwp_log2) < nq && r.hwp_log2 < 8) ++r.hwp_log2;
+    }
+    const int per_block = r.uni ? 1 : kThreads >> r.hwp_log2;
+    long gy = r.uni ? (nq + kThreads * 4 - 1) / (kThreads * 4) : 1;
+    if (gy > 64) gy = 64;
+    r.grid = dim3((unsigned)((groups_total + per_block - 1) / per_block), (unsigned)gy);
+    return r;
+}
+
 int plane_grid_y(long hw) {
     long per = (hw & 3) == 0 ? hw / 4 : hw;
     long gy = (per + kThreads * 4 - 1) / (kThreads * 4);
@@ -630,7 +1002,7 @@ size_t fsc_bn_workspace_bytes(int c) {
 int fsc_bn_train_stats(const float* x, int n, int c, long hw, const float* gamma, const float* beta, float eps,
                        float momentum, float* running_mean, float* running_var, float* save_mean,
                        float* save_invstd, float* scale, float* shift, void* workspace, double* sync, int phase,
-                       fsc_stream_t stream) {
+                       float* x_minmax, fsc_stream_t stream) {
     FSC_CHECK_ARG(x && save_mean && save_invstd && scale && shift && workspace, "fsc_bn_train_stats: null pointer");
     FSC_CHECK_ARG(phase == 0 || ((phase == 1 || phase == 2) && sync), "fsc_bn_train_stats: phase 1 / 2 need `sync`");
     FSC_CHECK_ARG(n > 0 && c > 0 && hw > 0, "fsc_bn_train_stats: bad shape (%d, %d, %ld)", n, c, hw);
@@ -649,7 +1021,7 @@ int fsc_bn_train_stats(const float* x, int n, int c, long hw, const float* gamma
     }
     hipLaunchKernelGGL(stats_finalize_kernel, dim3(fsc::ceil_div(c, 128)), dim3(128), 0, st, x, c, hw,
                        (double)n * (double)hw, nsplit, p.part, gamma, beta, eps, momentum, running_mean,
-                       running_var, save_mean, save_invstd, scale, shift, sync, phase);
+                       running_var, save_mean, save_invstd, scale, shift, sync, phase, x_minmax);
     FSC_LAUNCH_CHECK("fsc_bn_train_stats");
     return 0;
 }
@@ -664,10 +1036,24 @@ int fsc_bn_eval_prepare(int c, const float* gamma, const float* beta, const floa
 }
 
 int fsc_bn_act_fwd(const float* x, const float* residual, const float* scale, const float* shift,
-                   const float* alpha, float* y, int n, int c, long hw, float* y_amax, fsc_stream_t stream) {
-    FSC_CHECK_ARG(x && scale && shift && y, "fsc_bn_act_fwd: null pointer");
+                   const float* alpha, float* y, int n, int c, long hw, float* y_amax, const float* x_minmax,
+                   void* y_l16, fsc_stream_t stream) {
+    FSC_CHECK_ARG(x && scale && shift && (y || y_l16), "fsc_bn_act_fwd: null pointer");
     FSC_CHECK_ARG(n > 0 && c > 0 && hw > 0, "fsc_bn_act_fwd: bad shape (%d, %d, %ld)", n, c, hw);
     hipStream_t st = fsc::as_stream(stream);
+    if (y_l16) {
+        FSC_CHECK_ARG(x_minmax && y_amax && !residual && hw > 1,
+                      "fsc_bn_act_fwd: the L16 output needs x_minmax (fsc_bn_train_stats) and y_amax, takes no residual, hw > 1");
+        const L16Grid g = l16_grid(n, c, hw, true);
+        uint4* y16 = reinterpret_cast<uint4*>(y_l16);
+#define FSC_FWD_L16(V_, U_) hipLaunchKernelGGL((fwd_l16_kernel<V_, U_>), g.grid, dim3(kThreads), 0, st, x, scale, shift, alpha, \
+                                               x_minmax, y, y16, y_amax, n, c, hw, g.hwp_log2)
+        if (g.vec == 4) { if (g.uni) FSC_FWD_L16(4, true); else FSC_FWD_L16(4, false); }
+        else { if (g.uni) FSC_FWD_L16(1, true); else FSC_FWD_L16(1, false); }
+#undef FSC_FWD_L16
+        FSC_LAUNCH_CHECK("fsc_bn_act_fwd(l16)");
+        return 0;
+    }
     if (y_amax) {
         hipError_t e = hipMemsetAsync(y_amax, 0, fsc::kAmaxFloats * sizeof(float), st);
         FSC_CHECK_ARG(e == hipSuccess, "fsc_bn_act_fwd: memset failed: %s", hipGetErrorString(e));
@@ -694,8 +1080,9 @@ int fsc_bn_act_bwd(const float* dy, const float* gmax_dy, const int* gmax_idx, c
                    const float* residual, const float* save_mean, const float* save_invstd,
                    const float* gamma, const float* beta, const float* alpha, float* dx, float* dresidual,
                    float* dgamma, float* dbeta, float* dalpha, float* dx_chan_sum, int n, int c, long hw,
-                   void* workspace, float* dx_amax, double* sync, int phase, fsc_stream_t stream) {
-    FSC_CHECK_ARG(x && save_mean && save_invstd && dx && workspace, "fsc_bn_act_bwd: null pointer");
+                   void* workspace, float* dx_amax, double* sync, int phase, void* dx_l16, fsc_stream_t stream) {
+    FSC_CHECK_ARG(x && save_mean && save_invstd && (dx || dx_l16) && workspace, "fsc_bn_act_bwd: null pointer");
+    FSC_CHECK_ARG(!dx_l16 || (dx_amax && hw > 1), "fsc_bn_act_bwd: the L16 output needs dx_amax and hw > 1");
     FSC_CHECK_ARG(phase == 0 || ((phase == 1 || phase == 2) && sync), "fsc_bn_act_bwd: phase 1 / 2 need `sync`");
     FSC_CHECK_ARG(dy || gmax_dy, "fsc_bn_act_bwd: no upstream gradient");
     FSC_CHECK_ARG((gmax_dy == nullptr) == (gmax_idx == nullptr), "fsc_bn_act_bwd: gmax_dy / gmax_idx must come in pairs");
@@ -704,20 +1091,31 @@ int fsc_bn_act_bwd(const float* dy, const float* gmax_dy, const int* gmax_idx, c
     hipStream_t st = fsc::as_stream(stream);
     Partials p = carve(workspace, c);
     BwdArgs a{dy, gmax_dy, gmax_idx, x, residual, save_mean, save_invstd, gamma, beta, alpha, n, c, hw};
-    int nsplit = 1;
+    const int nsplit = hw == 1 ? 1 : pick_split(n, c, hw);
     if (phase != 2) {
         if (hw == 1) {
             FSC_CHECK_ARG(gmax_dy == nullptr, "fsc_bn_act_bwd: global-max gradient needs hw > 1");
             hipLaunchKernelGGL(bwd_rows_kernel, dim3(fsc::ceil_div(c, 128)), dim3(128), 0, st, a, p.part);
         } else {
-            nsplit = pick_split(n, c, hw);
             hipLaunchKernelGGL(bwd_partial_kernel, dim3(c, nsplit), dim3(kThreads), 0, st, a, nsplit, hwp_log2_for(hw), p.part);
         }
     }
     hipLaunchKernelGGL(bwd_finalize_kernel, dim3(fsc::ceil_div(c, 128)), dim3(128), 0, st, c, (double)n * (double)hw,
-                       nsplit, p.part, dgamma, dbeta, dalpha, p.coef, dx_chan_sum, dx_amax, sync, phase);
+                       nsplit, p.part, dgamma, dbeta, dalpha, p.coef, dx_chan_sum, dx_amax, sync, phase, gamma, save_invstd,
+                       dx_l16 ? 1 : 0);
     if (phase == 1) {
         FSC_LAUNCH_CHECK("fsc_bn_act_bwd");
+        return 0;
+    }
+    if (dx_l16) {
+        const L16Grid g = l16_grid(n, c, hw, true);
+        uint4* dx16 = reinterpret_cast<uint4*>(dx_l16);
+#define FSC_BWD_L16(V_, U_) hipLaunchKernelGGL((bwd_apply_l16_kernel<V_, U_>), g.grid, dim3(kThreads), 0, st, a, p.coef, dx, dx16, \
+                                               dresidual, dx_chan_sum, dx_amax, g.hwp_log2)
+        if (g.vec == 4) { if (g.uni) FSC_BWD_L16(4, true); else FSC_BWD_L16(4, false); }
+        else { if (g.uni) FSC_BWD_L16(1, true); else FSC_BWD_L16(1, false); }
+#undef FSC_BWD_L16
+        FSC_LAUNCH_CHECK("fsc_bn_act_bwd(l16)");
         return 0;
     }
     const long total = (long)n * c * hw;
@@ -742,8 +1140,9 @@ int fsc_bn_act_bwd_unpool(const float* dy, const float* x, const float* save_mea
                           const float* gamma, const float* beta, const float* alpha, const uint8_t* pool_idx,
                           float* dc, float* dgamma, float* dbeta, float* dalpha, float* dx_chan_sum, int n, int c,
                           int h, int w, int ph, void* workspace, float* dc_amax, double* sync, int phase,
-                          fsc_stream_t stream) {
-    FSC_CHECK_ARG(dy && x && save_mean && save_invstd && pool_idx && dc && workspace, "fsc_bn_act_bwd_unpool: null pointer");
+                          void* dc_l16, fsc_stream_t stream) {
+    FSC_CHECK_ARG(dy && x && save_mean && save_invstd && pool_idx && (dc || dc_l16) && workspace, "fsc_bn_act_bwd_unpool: null pointer");
+    FSC_CHECK_ARG(!dc_l16 || dc_amax, "fsc_bn_act_bwd_unpool: the L16 output needs dc_amax");
     FSC_CHECK_ARG(phase == 0 || ((phase == 1 || phase == 2) && sync), "fsc_bn_act_bwd_unpool: phase 1 / 2 need `sync`");
     FSC_CHECK_ARG((ph == 1 || ph == 2) && n > 0 && c > 0 && h >= ph && w >= 2, "fsc_bn_act_bwd_unpool: bad shape");
     const int oh = h / ph, ow = w / 2;
@@ -755,9 +1154,18 @@ int fsc_bn_act_bwd_unpool(const float* dy, const float* x, const float* save_mea
     if (phase != 2)
         hipLaunchKernelGGL(bwd_partial_kernel, dim3(c, nsplit), dim3(kThreads), 0, st, a, nsplit, hwp_log2_for(hw), p.part);
     hipLaunchKernelGGL(bwd_finalize_kernel, dim3(fsc::ceil_div(c, 128)), dim3(128), 0, st, c, (double)n * (double)hw,
-                       nsplit, p.part, dgamma, dbeta, dalpha, p.coef, dx_chan_sum, dc_amax, sync, phase);
+                       nsplit, p.part, dgamma, dbeta, dalpha, p.coef, dx_chan_sum, dc_amax, sync, phase, gamma, save_invstd,
+                       dc_l16 ? 1 : 0);
     if (phase == 1) {
         FSC_LAUNCH_CHECK("fsc_bn_act_bwd_unpool");
+        return 0;
+    }
+    if (dc_l16) {
+        L16Grid g = l16_grid(n, c, hw, false);
+        if (g.uni) g.hwp_log2 = 8;
+        hipLaunchKernelGGL(bwd_apply_unpool_l16_kernel, g.grid, dim3(kThreads), 0, st, a, p.coef, pool_idx, dc,
+                           reinterpret_cast<uint4*>(dc_l16), dx_chan_sum, h, w, ph, oh, ow, dc_amax, g.hwp_log2);
+        FSC_LAUNCH_CHECK("fsc_bn_act_bwd_unpool(l16)");
         return 0;
     }
     int cl = 0;

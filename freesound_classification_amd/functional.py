@@ -328,6 +328,71 @@ def conv_l16(t, weight, bias, dgrad=False, accumulate_into=None, prepacked=None)
     return out
 
 
+def conv_l16_wgrad_supported(desc):
+    return bool(_lib.load().fsc_conv_l16_wgrad_supported(C.byref(desc)))
+
+
+def l16_wgrad_plan_name(desc):
+    buf = C.create_string_buffer(256)
+    call("fsc_conv_l16_wgrad_plan_describe", C.byref(desc), buf, 256)
+    return buf.value.decode().split(" ")[0]
+
+
+def conv_l16_wgrad(x16, dout16, weight_shape):
+    """Weight gradient from the L16 input and L16 output gradient of a stride-1 same-pad convolution."""
+    c_out, c_in, kh, kw = weight_shape
+    n, _, h, w = x16.shape
+    d = _desc(n, c_in, c_out, h, w, kh, kw, 3)
+    nbytes = _lib.load().fsc_conv_l16_wgrad_workspace_bytes(C.byref(d))
+    if nbytes == 0:
+        raise _lib.FscError("conv_l16_wgrad: unsupported shape %s" % [getattr(d, f) for f, _ in d._fields_])
+    ws = torch.empty(nbytes // 4, device=x16.data.device, dtype=torch.float32)
+    dw = torch.empty(tuple(weight_shape), device=x16.data.device, dtype=torch.float32)
+    if TIMER is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    call("fsc_conv_l16_wgrad", C.byref(d), ptr(x16.data), ptr(x16.amax), ptr(dout16.data), ptr(dout16.amax), ptr(dw), ptr(ws),
+         stream_ptr())
+    if TIMER is not None:
+        e1.record()
+        TIMER.records.append((l16_wgrad_plan_name(d), 2.0 * n * h * w * c_in * c_out * kh * kw, e0, e1))
+    return dw
+
+
+_L16_OK = {}
+USE_L16 = True        # route convolutions through the pre-split (L16) kernels where the library has a tiling for them
+
+
+def l16_ok(n, c_in, c_out, h, w, kh, kw, dgrad):
+    """True when the producer of this convolution's operand should write it as an L16 tensor (split-fp16 arithmetic and
+    fsc_conv_l16_fwd has a tiling for the shape)."""
+    if not USE_L16 or get_conv_arith() != 3:
+        return False
+    key = (n, c_in, c_out, h, w, kh, kw, bool(dgrad))
+    if key not in _L16_OK:
+        _L16_OK[key] = conv_l16_supported(_desc(n, c_in, c_out, h, w, kh, kw, 3), 1 if dgrad else 0)
+    return _L16_OK[key]
+
+
+def _l16_ok_for(x_shape, weight, dgrad):
+    if len(x_shape) != 4:
+        return False
+    c_out, c_in, kh, kw = weight.shape
+    n, h, w = x_shape[0], x_shape[2], x_shape[3]
+    return l16_ok(n, c_in, c_out, h, w, kh, kw, dgrad)
+
+
+def _l16_wgrad_ok_for(x_shape, weight):
+    """True when the weight gradient of this convolution runs on fsc_conv_l16_wgrad (both operands as L16 tensors)."""
+    if len(x_shape) != 4 or not USE_L16 or get_conv_arith() != 3:
+        return False
+    c_out, c_in, kh, kw = weight.shape
+    key = (x_shape[0], c_in, c_out, x_shape[2], x_shape[3], kh, kw, "wgrad")
+    if key not in _L16_OK:
+        _L16_OK[key] = conv_l16_wgrad_supported(_desc(x_shape[0], c_in, c_out, x_shape[2], x_shape[3], kh, kw, 3))
+    return _L16_OK[key]
+
+
 # Weight gradients are MFMA-bound and nothing in the backward chain depends on them until the
 # optimizer, while the chain itself alternates MFMA-bound dgrads with HBM-bound BN / pooling
 # backward kernels.  Launching wgrad on a second HIP stream lets the two kinds of kernels share the
@@ -390,7 +455,7 @@ def _bn_ws(c, like):
 
 class BNState:
     """What one fused BN(+residual)(+PReLU) unit keeps between forward and backward."""
-    __slots__ = ("mean", "invstd", "scale", "shift")
+    __slots__ = ("mean", "invstd", "scale", "shift", "minmax")
 
 
 def _sync_buffer(c, like):
@@ -406,6 +471,7 @@ def bn_prepare(x, bn, training, sync=None):
     st = BNState()
     st.scale = _empty((c,), x)
     st.shift = _empty((c,), x)
+    st.minmax = None
     gamma, beta = bn.weight, bn.bias
     if training or bn.running_mean is None:
         st.mean = _empty((c,), x)
@@ -417,16 +483,17 @@ def bn_prepare(x, bn, training, sync=None):
             if bn.momentum is None:
                 momentum = 1.0 / float(bn.num_batches_tracked)
         ws = _bn_ws(c, x)                                  # (kept alive across both phases)
+        st.minmax = _empty((2 * c,), x)                    # per-channel [min, max] of x: the L16 producers' bound
         args = (ptr(x), n, c, hw, ptr(gamma), ptr(beta), bn.eps, momentum,
                 ptr(bn.running_mean) if track else None, ptr(bn.running_var) if track else None,
                 ptr(st.mean), ptr(st.invstd), ptr(st.scale), ptr(st.shift), ptr(ws))
         if sync is None:
-            call("fsc_bn_train_stats", *args, None, 0, stream_ptr())
+            call("fsc_bn_train_stats", *args, None, 0, ptr(st.minmax), stream_ptr())
         else:
             moments = _sync_buffer(c, x)                   # [sum x, sum x^2, count, 0] per channel, fp64
-            call("fsc_bn_train_stats", *args, ptr(moments), 1, stream_ptr())
+            call("fsc_bn_train_stats", *args, ptr(moments), 1, ptr(st.minmax), stream_ptr())
             sync(moments)
-            call("fsc_bn_train_stats", *args, ptr(moments), 2, stream_ptr())
+            call("fsc_bn_train_stats", *args, ptr(moments), 2, ptr(st.minmax), stream_ptr())
     else:
         st.mean = None
         st.invstd = None
@@ -439,69 +506,87 @@ def _want_amax():
     return get_conv_arith() == 3
 
 
-def bn_act_forward(x, st, alpha=None, residual=None, with_amax=False):
+def bn_act_forward(x, st, alpha=None, residual=None, with_amax=False, l16=False, want_f32=True):
     """y = act(bn(x) [+ residual]).  with_amax: returns (y, max |y| as a device scalar or None) -- the scale
-    of the split-fp16 conv kernels, reported by the kernel that writes y."""
+    of the split-fp16 conv kernels, reported by the kernel that writes y.
+    l16: returns (y or None, L16 or None) instead -- y also (want_f32) or only as a pre-split L16 tensor for
+    conv_l16, when the unit has batch statistics (their min / max bound the output up front) and no residual."""
     n, c = x.shape[0], x.shape[1]
     hw = x.numel() // (n * c)
+    if l16 and st.minmax is not None and residual is None and hw > 1:
+        y = torch.empty_like(x) if want_f32 else None
+        t = L16(l16_empty(x.shape, x), _empty((AMAX_FLOATS,), x), x.shape)
+        call("fsc_bn_act_fwd", ptr(x), None, ptr(st.scale), ptr(st.shift), ptr(alpha), ptr(y),
+             n, c, hw, ptr(t.amax), ptr(st.minmax), ptr(t.data), stream_ptr())
+        return y, t
     y = torch.empty_like(x)
-    y_amax = _empty((AMAX_FLOATS,), x) if with_amax and _want_amax() else None
+    y_amax = _empty((AMAX_FLOATS,), x) if (with_amax or l16) and _want_amax() else None
     call("fsc_bn_act_fwd", ptr(x), ptr(residual), ptr(st.scale), ptr(st.shift), ptr(alpha), ptr(y),
-         n, c, hw, ptr(y_amax), stream_ptr())
+         n, c, hw, ptr(y_amax), None, None, stream_ptr())
+    if l16:
+        return y, None
     return (y, y_amax) if with_amax else y
 
 
 def bn_act_backward(dy, x, st, bn, alpha=None, residual=None, gmax=None, want_dx=True,
-                    want_dres=False, want_chan_sum=False, with_amax=False, sync=None):
-    """Returns (dx, dresidual, dgamma, dbeta, dalpha, dx_chan_sum) [+ (max |dx|,) with with_amax]."""
+                    want_dres=False, want_chan_sum=False, with_amax=False, sync=None, l16=False, want_f32=True):
+    """Returns (dx, dresidual, dgamma, dbeta, dalpha, dx_chan_sum) [+ (max |dx|,) with with_amax].
+    l16 (with with_amax): dx is also (want_f32) or only written as an L16 tensor; the last element of the result is then
+    that L16 (its .amax is the declared bound) instead of the amax buffer."""
     n, c = x.shape[0], x.shape[1]
     hw = x.numel() // (n * c)
-    dx = torch.empty_like(x)          # always produced (the apply pass also yields chan sums)
+    l16 = l16 and with_amax and hw > 1
+    dx = torch.empty_like(x) if (want_f32 or not l16) else None     # (the apply pass also yields chan sums)
     dres = torch.empty_like(x) if want_dres else None
     dgamma = _empty((c,), x)
     dbeta = _empty((c,), x)
     dalpha = _empty((c,), x) if alpha is not None else None
     csum = _empty((c,), x) if want_chan_sum else None
     gdy, gidx = gmax if gmax is not None else (None, None)
-    dx_amax = _empty((AMAX_FLOATS,), x) if with_amax and _want_amax() else None
+    dx_amax = _empty((AMAX_FLOATS,), x) if with_amax and (_want_amax() or l16) else None
+    t = L16(l16_empty(x.shape, x), dx_amax, x.shape) if l16 else None
     ws = _bn_ws(c, x)                                      # (kept alive across both phases)
     args = (ptr(dy), ptr(gdy), ptr(gidx), ptr(x), ptr(residual), ptr(st.mean),
             ptr(st.invstd), ptr(bn.weight), ptr(bn.bias), ptr(alpha), ptr(dx), ptr(dres), ptr(dgamma),
             ptr(dbeta), ptr(dalpha), ptr(csum), n, c, hw, ptr(ws), ptr(dx_amax))
+    t_ptr = ptr(t.data) if l16 else None
     if sync is None:
-        call("fsc_bn_act_bwd", *args, None, 0, stream_ptr())
+        call("fsc_bn_act_bwd", *args, None, 0, t_ptr, stream_ptr())
     else:
         sums = _sync_buffer(c, x)                          # [sum dz, sum dz * xhat, count, 0] per channel
-        call("fsc_bn_act_bwd", *args, ptr(sums), 1, stream_ptr())
+        call("fsc_bn_act_bwd", *args, ptr(sums), 1, t_ptr, stream_ptr())
         sync(sums)
-        call("fsc_bn_act_bwd", *args, ptr(sums), 2, stream_ptr())
+        call("fsc_bn_act_bwd", *args, ptr(sums), 2, t_ptr, stream_ptr())
     if with_amax:
-        return dx, dres, dgamma, dbeta, dalpha, csum, dx_amax
+        return dx, dres, dgamma, dbeta, dalpha, csum, (t if l16 else dx_amax)
     return dx, dres, dgamma, dbeta, dalpha, csum
 
 
-def bn_act_backward_unpool(dy, x, st, bn, alpha, pool_idx, c_shape, ph, sync=None):
+def bn_act_backward_unpool(dy, x, st, bn, alpha, pool_idx, c_shape, ph, sync=None, l16=False, want_f32=True):
     """Backward of BN+PReLU on a pooled tensor fused with the max-pool backward.
-    Returns (dc at the un-pooled shape, dgamma, dbeta, dalpha, per-channel sum of the gradient, max |dc| or None)."""
+    Returns (dc at the un-pooled shape, dgamma, dbeta, dalpha, per-channel sum of the gradient, max |dc| or None); with
+    l16 the last element is dc as an L16 tensor (and dc itself None unless want_f32)."""
     n, c, h, w = c_shape
-    dc = _empty(tuple(c_shape), x)
+    dc = _empty(tuple(c_shape), x) if (want_f32 or not l16) else None
     dgamma = _empty((c,), x)
     dbeta = _empty((c,), x)
     dalpha = _empty((c,), x) if alpha is not None else None
     csum = _empty((c,), x)
-    dc_amax = _empty((AMAX_FLOATS,), x) if _want_amax() else None
+    dc_amax = _empty((AMAX_FLOATS,), x) if (_want_amax() or l16) else None
+    t = L16(l16_empty(c_shape, x), dc_amax, c_shape) if l16 else None
     ws = _bn_ws(c, x)                                      # (kept alive across both phases)
     args = (ptr(dy), ptr(x), ptr(st.mean), ptr(st.invstd), ptr(bn.weight), ptr(bn.bias),
             ptr(alpha), ptr(pool_idx), ptr(dc), ptr(dgamma), ptr(dbeta), ptr(dalpha), ptr(csum), n, c, h, w, ph,
             ptr(ws), ptr(dc_amax))
+    t_ptr = ptr(t.data) if l16 else None
     if sync is None:
-        call("fsc_bn_act_bwd_unpool", *args, None, 0, stream_ptr())
+        call("fsc_bn_act_bwd_unpool", *args, None, 0, t_ptr, stream_ptr())
     else:
         sums = _sync_buffer(c, x)
-        call("fsc_bn_act_bwd_unpool", *args, ptr(sums), 1, stream_ptr())
+        call("fsc_bn_act_bwd_unpool", *args, ptr(sums), 1, t_ptr, stream_ptr())
         sync(sums)
-        call("fsc_bn_act_bwd_unpool", *args, ptr(sums), 2, stream_ptr())
-    return dc, dgamma, dbeta, dalpha, csum, dc_amax
+        call("fsc_bn_act_bwd_unpool", *args, ptr(sums), 2, t_ptr, stream_ptr())
+    return dc, dgamma, dbeta, dalpha, csum, (t if l16 else dc_amax)
 
 
 # ------------------------------------------------------------------------------ pooling
@@ -637,6 +722,53 @@ class _BlockCtx:
     pass
 
 
+def _bn_fwd_for_conv(x, st, alpha, weight, keep_f32=False):
+    """BN (+ PReLU) output that feeds the convolution `weight`: (y fp32 or None, max |y| buffer or None, y as L16 or None).
+    The L16 form is written when the forward convolution or its weight gradient reads it; the fp32 form when one of the two
+    does not (or the caller needs it: keep_f32)."""
+    fw, wg = _l16_ok_for(x.shape, weight, False), _l16_wgrad_ok_for(x.shape, weight)
+    if (fw or wg) and st.minmax is not None:
+        y, t = bn_act_forward(x, st, alpha, l16=True, want_f32=keep_f32 or not (fw and wg))
+        if t is not None:
+            return y, t.amax, t
+    y, y_max = bn_act_forward(x, st, alpha, with_amax=True)
+    return y, y_max, None
+
+
+def _conv_fwd_any(x, x_16, weight, bias, x_amax):
+    if x_16 is not None and _l16_ok_for(x_16.shape, weight, False):
+        return conv_l16(x_16, weight, bias)
+    return conv_forward(x, weight, bias, x_amax=x_amax)
+
+
+def _conv_dgrad_any(dout, dout_16, weight, x_shape, dout_amax, accumulate_into=None):
+    if dout_16 is not None and _l16_ok_for(x_shape, weight, True):
+        return conv_l16(dout_16, weight, None, dgrad=True, accumulate_into=accumulate_into)
+    return conv_dgrad(dout, weight, x_shape, accumulate_into=accumulate_into, dout_amax=dout_amax)
+
+
+def _conv_wgrad_any(x, x_16, x_amax, dout, dout_16, dout_amax, weight):
+    if x_16 is not None and dout_16 is not None and _l16_wgrad_ok_for(x_16.shape, weight):
+        return conv_l16_wgrad(x_16, dout_16, weight.shape)
+    return conv_wgrad(x, dout, weight.shape, True, x_amax=x_amax, dout_amax=dout_amax)
+
+
+def _grad_formats(x_shape, weight):
+    """(write the gradient of this convolution's output as L16, keep its fp32 form): L16 when the input-gradient kernel or
+    the weight-gradient kernel reads it, fp32 when one of them does not."""
+    dg, wg = _l16_ok_for(x_shape, weight, True), _l16_wgrad_ok_for(x_shape, weight)
+    return (dg or wg), not (dg and wg)
+
+
+def _amax_of(m):
+    """The amax buffer inside what the backward BN kernels return as their last element (an L16 or the buffer itself)."""
+    return m.amax if isinstance(m, L16) else m
+
+
+def _l16_of(m):
+    return m if isinstance(m, L16) else None
+
+
 def _block_forward(x, mods, training, want_head, ph, keep, sync=None):
     """BN -> conv3 -> maxpool -> BN+PReLU -> residual unit (-> global max).  `mods` is the
     reference's nn.Sequential of parameter holders.  Returns (out, feat, ctx)."""
@@ -644,28 +776,30 @@ def _block_forward(x, mods, training, want_head, ph, keep, sync=None):
     k = _BlockCtx()
     k.x_shape = tuple(x.shape)
     st_a = bn_prepare(x, bn_a, training, sync)
-    a, a_max = bn_act_forward(x, st_a, with_amax=True)
     w_a, b_a = _conv_params(conv_a)
-    fused = conv_pool_forward(a, w_a, b_a) if ph == 2 else None
+    # Operands of convolutions that have an L16 tiling are written pre-split by the BN / PReLU kernel that produces them
+    # (`*_16`); the fp32 copy stays for the weight gradient (and, for b, the residual).
+    a, a_max, a_16 = _bn_fwd_for_conv(x, st_a, None, w_a)
+    fused = conv_pool_forward(a, w_a, b_a) if (ph == 2 and a is not None) else None
     if fused is not None:
         p, pidx, k.c_shape = fused
     else:
-        c = conv_forward(a, w_a, b_a, x_amax=a_max)
+        c = _conv_fwd_any(a, a_16, w_a, b_a, a_max)
         p, pidx = maxpool_forward(c, ph)
         k.c_shape = tuple(c.shape)
         del c
     st_b = bn_prepare(p, bn_b, training, sync)
-    b, b_max = bn_act_forward(p, st_b, prelu_b.weight, with_amax=True)
     w1, b1 = _conv_params(res.conv1)
-    r1 = conv_forward(b, w1, b1, x_amax=b_max)
+    b, b_max, b_16 = _bn_fwd_for_conv(p, st_b, prelu_b.weight, w1, keep_f32=True)      # (the residual reads it)
+    r1 = _conv_fwd_any(b, b_16, w1, b1, b_max)
     st1 = bn_prepare(r1, res.bn1, training, sync)
-    s1, s1_max = bn_act_forward(r1, st1, res.prelu1.weight, with_amax=True)
     w2, b2 = _conv_params(res.conv2)
-    r2 = conv_forward(s1, w2, b2, x_amax=s1_max)
+    s1, s1_max, s1_16 = _bn_fwd_for_conv(r1, st1, res.prelu1.weight, w2)
+    r2 = _conv_fwd_any(s1, s1_16, w2, b2, s1_max)
     st2 = bn_prepare(r2, res.bn2, training, sync)
-    s2, s2_max = bn_act_forward(r2, st2, res.prelu2.weight, with_amax=True)
     w3, b3 = _conv_params(res.conv3)
-    r3 = conv_forward(s2, w3, b3, x_amax=s2_max)
+    s2, s2_max, s2_16 = _bn_fwd_for_conv(r2, st2, res.prelu2.weight, w3)
+    r3 = _conv_fwd_any(s2, s2_16, w3, b3, s2_max)
     st3 = bn_prepare(r3, res.bn3, training, sync)
     out = bn_act_forward(r3, st3, res.prelu3.weight, residual=b)
     feat, fidx = (None, None)
@@ -677,6 +811,7 @@ def _block_forward(x, mods, training, want_head, ph, keep, sync=None):
         k.st_a, k.st_b, k.st1, k.st2, k.st3 = st_a, st_b, st1, st2, st3
         k.fidx = fidx
         k.amax = (a_max, b_max, s1_max, s2_max)
+        k.l16 = (a_16, b_16, s1_16, s2_16)
     return out, feat, k
 
 
@@ -730,35 +865,46 @@ class ConvBlockFn(torch.autograd.Function):
             raise _lib.FscError("ConvBlockFn.backward: no upstream gradient")
         # ---- out = prelu3(bn3(r3) + b)
         a_max, b_max, s1_max, s2_max = k.amax
-        dr3, db, dg3, dbt3, dal3, dbias3, dr3_max = bn_act_backward(
-            d_out, k.r3, k.st3, res.bn3, res.prelu3.weight, residual=k.b, gmax=gmax,
-            want_dres=True, want_chan_sum=True, with_amax=True, sync=sync)
         w3, _ = _conv_params(res.conv3)
-        dw3 = conv_wgrad(k.s2, dr3, w3.shape, True, x_amax=s2_max, dout_amax=dr3_max)
-        ds2 = conv_dgrad(dr3, w3, k.s2.shape, dout_amax=dr3_max)
-        del dr3
-        dr2, _, dg2, dbt2, dal2, dbias2, dr2_max = bn_act_backward(ds2, k.r2, k.st2, res.bn2, res.prelu2.weight,
-                                                                   want_chan_sum=True, with_amax=True, sync=sync)
-        del ds2
         w2, _ = _conv_params(res.conv2)
-        dw2 = conv_wgrad(k.s1, dr2, w2.shape, True, x_amax=s1_max, dout_amax=dr2_max)
-        ds1 = conv_dgrad(dr2, w2, k.s1.shape, dout_amax=dr2_max)
-        del dr2
-        dr1, _, dg1, dbt1, dal1, dbias1, dr1_max = bn_act_backward(ds1, k.r1, k.st1, res.bn1, res.prelu1.weight,
-                                                                   want_chan_sum=True, with_amax=True, sync=sync)
-        del ds1
         w1, _ = _conv_params(res.conv1)
-        dw1 = conv_wgrad(k.b, dr1, w1.shape, True, x_amax=b_max, dout_amax=dr1_max)
-        db = conv_dgrad(dr1, w1, k.b.shape, accumulate_into=db, dout_amax=dr1_max)     # residual + conv1 paths
-        del dr1
-        # ---- b = prelu(bn_b(p))
-        dc, dgb, dbtb, dalb, dbias_a, dc_max = bn_act_backward_unpool(db.contiguous(), k.p, k.st_b, bn_b, prelu_b.weight,
-                                                                      k.pidx, k.c_shape, ph, sync=sync)
-        del db
         wa, _ = _conv_params(conv_a)
-        dwa = conv_wgrad(k.a, dc, wa.shape, True, x_amax=a_max, dout_amax=dc_max)
-        da = conv_dgrad(dc, wa, k.a.shape, dout_amax=dc_max)
-        del dc
+        a_16, b_16, s1_16, s2_16 = k.l16
+        # gradients whose consumers (input-gradient and weight-gradient kernels) read L16 are written pre-split as well
+        # (`*_m` is then that L16, else the amax buffer), and only as L16 when both consumers do
+        w16, w32 = _grad_formats(k.r2.shape, w3)
+        dr3, db, dg3, dbt3, dal3, dbias3, dr3_m = bn_act_backward(
+            d_out, k.r3, k.st3, res.bn3, res.prelu3.weight, residual=k.b, gmax=gmax,
+            want_dres=True, want_chan_sum=True, with_amax=True, sync=sync, l16=w16, want_f32=w32)
+        s2_shape = k.r2.shape
+        dw3 = _conv_wgrad_any(k.s2, s2_16, s2_max, dr3, _l16_of(dr3_m), _amax_of(dr3_m), w3)
+        ds2 = _conv_dgrad_any(dr3, _l16_of(dr3_m), w3, s2_shape, _amax_of(dr3_m))
+        del dr3, dr3_m
+        w16, w32 = _grad_formats(k.r1.shape, w2)
+        dr2, _, dg2, dbt2, dal2, dbias2, dr2_m = bn_act_backward(ds2, k.r2, k.st2, res.bn2, res.prelu2.weight,
+                                                                 want_chan_sum=True, with_amax=True, sync=sync,
+                                                                 l16=w16, want_f32=w32)
+        del ds2
+        dw2 = _conv_wgrad_any(k.s1, s1_16, s1_max, dr2, _l16_of(dr2_m), _amax_of(dr2_m), w2)
+        ds1 = _conv_dgrad_any(dr2, _l16_of(dr2_m), w2, k.r1.shape, _amax_of(dr2_m))
+        del dr2, dr2_m
+        w16, w32 = _grad_formats(k.b.shape, w1)
+        dr1, _, dg1, dbt1, dal1, dbias1, dr1_m = bn_act_backward(ds1, k.r1, k.st1, res.bn1, res.prelu1.weight,
+                                                                 want_chan_sum=True, with_amax=True, sync=sync,
+                                                                 l16=w16, want_f32=w32)
+        del ds1
+        dw1 = _conv_wgrad_any(k.b, b_16, b_max, dr1, _l16_of(dr1_m), _amax_of(dr1_m), w1)
+        db = _conv_dgrad_any(dr1, _l16_of(dr1_m), w1, k.b.shape, _amax_of(dr1_m), accumulate_into=db)   # residual + conv1 paths
+        del dr1, dr1_m
+        # ---- b = prelu(bn_b(p))
+        a_shape = tuple(k.c_shape[:1]) + (wa.shape[1],) + tuple(k.c_shape[2:])
+        w16, w32 = _grad_formats(a_shape, wa) if len(k.c_shape) == 4 else (False, True)
+        dc, dgb, dbtb, dalb, dbias_a, dc_m = bn_act_backward_unpool(db.contiguous(), k.p, k.st_b, bn_b, prelu_b.weight,
+                                                                    k.pidx, k.c_shape, ph, sync=sync, l16=w16, want_f32=w32)
+        del db
+        dwa = _conv_wgrad_any(k.a, a_16, a_max, dc, _l16_of(dc_m), _amax_of(dc_m), wa)
+        da = _conv_dgrad_any(dc, _l16_of(dc_m), wa, a_shape, _amax_of(dc_m))
+        del dc, dc_m
         dx, _, dga, dbta, _, _ = bn_act_backward(da, k.x, k.st_a, bn_a, sync=sync)
         if not ctx.x_needs_grad:
             dx = None

@@ -149,6 +149,14 @@ int fsc_conv_l16_pack_weights(const fsc_conv_desc* d, const float* weight, int d
 int fsc_conv_l16_fwd(const fsc_conv_desc* d, const void* in_l16, const float* in_amax, const float* packed,
                      const float* bias, int dgrad, int accumulate, float* out, fsc_stream_t stream);
 int fsc_conv_l16_plan_describe(const fsc_conv_desc* d, int dgrad, char* buf, size_t buf_len);
+/* Weight gradient from L16 operands: dweight (c_out, c_in, kh, kw) = sum over pixels dout x in (overwrites dweight), 3x3 and
+ * 1x1, same arithmetic as fsc_conv_wgrad with arith 3.  in_l16 is the (N, c_in, H, W) input of the convolution, dout_l16 the
+ * (N, c_out, H, W) gradient of its output, each with the amax buffer its scale derives from. */
+int fsc_conv_l16_wgrad_supported(const fsc_conv_desc* d);
+size_t fsc_conv_l16_wgrad_workspace_bytes(const fsc_conv_desc* d);
+int fsc_conv_l16_wgrad(const fsc_conv_desc* d, const void* in_l16, const float* in_amax, const void* dout_l16,
+                       const float* dout_amax, float* dweight, void* workspace, fsc_stream_t stream);
+int fsc_conv_l16_wgrad_plan_describe(const fsc_conv_desc* d, char* buf, size_t buf_len);
 
 /* ------------------------------------------------------------------ batch norm + PReLU (K6, K9, K11)
  * nn.BatchNorm2d/1d (train and eval) fused with the following per-channel PReLU and the
@@ -173,39 +181,49 @@ int fsc_bn_train_stats(const float* x, int n, int c, long hw, const float* gamma
                        const float* beta, float eps, float momentum, float* running_mean,
                        float* running_var, float* save_mean, float* save_invstd,
                        float* scale, float* shift, void* workspace, double* sync, int phase,
-                       fsc_stream_t stream);
+                       float* x_minmax, fsc_stream_t stream);
+/* x_minmax (2*C floats, may be NULL): per channel [min x, max x] of the local batch -- what fsc_bn_act_fwd needs to
+ * bound its output before it writes an L16 tensor. */
 /* eval: scale/shift from the running statistics */
 int fsc_bn_eval_prepare(int c, const float* gamma, const float* beta, const float* running_mean,
                         const float* running_var, float eps, float* scale, float* shift,
                         fsc_stream_t stream);
 /* y = act(x*scale + shift [+ residual]); act = PReLU(alpha[c]) if alpha != NULL else identity.
- * y_amax (FSC_AMAX_FLOATS floats, may be NULL) receives max |y| -- the operand scale of the split-fp16 conv kernels. */
+ * y_amax (FSC_AMAX_FLOATS floats, may be NULL) receives max |y| -- the operand scale of the split-fp16 conv kernels.
+ * y_l16 != NULL: y is (also) written as an L16 tensor (fsc_l16_bytes(n, c, hw) bytes) scaled by y_amax, which is
+ * then computed up front from x_minmax (fsc_bn_train_stats; exact: affine + PReLU take their extremes at the ends of
+ * each channel's range); needs x_minmax and y_amax, no residual, hw > 1; the fp32 `y` may be NULL then. */
 int fsc_bn_act_fwd(const float* x, const float* residual, const float* scale,
                    const float* shift, const float* alpha, float* y, int n, int c, long hw,
-                   float* y_amax, fsc_stream_t stream);
+                   float* y_amax, const float* x_minmax, void* y_l16, fsc_stream_t stream);
 /* backward of the fused unit.  Upstream gradient = dy (may be NULL) plus, when the output also
  * feeds a global max-pool head, gmax_dy[n*c] scattered at position gmax_idx[n*c] of each plane
  * (both NULL otherwise).  Outputs: dx; dresidual (may be NULL; equals the gradient at the
  * pre-activation); dgamma, dbeta, dalpha (C each; may be NULL); dx_chan_sum (C, may be NULL) =
  * per-channel sum of dx = bias gradient of the convolution that produced x; dx_amax (FSC_AMAX_FLOATS floats, may be
- * NULL) = max |dx|. */
+ * NULL) = max |dx|.
+ * dx_l16 != NULL: dx is (also) written as an L16 tensor scaled by dx_amax, which then receives an upper bound of
+ * max |dx| derived in the reduce pass (|k| (max |dz| + |mean dz| + max |xhat| |mean dz xhat|) per channel; an
+ * over-estimate is safe); needs dx_amax and hw > 1; the fp32 `dx` may be NULL then. */
 int fsc_bn_act_bwd(const float* dy, const float* gmax_dy, const int* gmax_idx, const float* x,
                    const float* residual, const float* save_mean, const float* save_invstd,
                    const float* gamma, const float* beta, const float* alpha, float* dx,
                    float* dresidual, float* dgamma, float* dbeta, float* dalpha,
                    float* dx_chan_sum, int n, int c, long hw, void* workspace,
-                   float* dx_amax, double* sync, int phase, fsc_stream_t stream);
+                   float* dx_amax, double* sync, int phase, void* dx_l16, fsc_stream_t stream);
 
 /* Same backward for the unit that directly follows a max-pool (BN -> PReLU on the pooled tensor x,
  * classifiers.py:532-534), fused with the pool's backward: writes dc (N, C, h, w), the gradient of
  * the UN-pooled tensor -- each window's gradient at its arg-max (pool_idx from fsc_maxpool_fwd),
- * zeros elsewhere -- instead of dx at the pooled resolution.  ph as in fsc_maxpool_fwd. */
+ * zeros elsewhere -- instead of dx at the pooled resolution.  ph as in fsc_maxpool_fwd.
+ * dc_l16 != NULL: dc is (also) written as an L16 tensor of the un-pooled shape, scaled by the bound dc_amax receives
+ * (as in fsc_bn_act_bwd); the fp32 `dc` may be NULL then. */
 int fsc_bn_act_bwd_unpool(const float* dy, const float* x, const float* save_mean,
                           const float* save_invstd, const float* gamma, const float* beta,
                           const float* alpha, const uint8_t* pool_idx, float* dc, float* dgamma,
                           float* dbeta, float* dalpha, float* dx_chan_sum, int n, int c, int h,
                           int w, int ph, void* workspace, float* dc_amax, double* sync, int phase,
-                          fsc_stream_t stream);
+                          void* dc_l16, fsc_stream_t stream);
 
 /* ------------------------------------------------------------------ pooling (K8, K12)
  * nn.MaxPool2d(2,2) / nn.MaxPool1d(2,2), floor mode (classifiers.py:532, 155);

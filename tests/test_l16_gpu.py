@@ -1,0 +1,223 @@
+"""Pre-split activations (include/fsc_hip.h "L16" tensors): the format round trip, the convolution kernels that read it
+(fsc_conv_l16_fwd, forward and input gradient of nn.Conv2d 3x3 / 1x1 -- reference networks/classifiers.py:526-531, 77-81)
+against PyTorch's fp64 convolution on the CPU and, bit for bit, against the fp32-input split-fp16 kernels, and the fused
+BN / PReLU producers that write the format (forward, backward, backward fused with the max-pool backward) against their
+fp32 outputs.  All through the C ABI.
+"""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+if not torch.cuda.is_available():
+    pytest.skip("needs an MI355X", allow_module_level=True)
+
+import torch.nn as nn  # noqa: E402
+import torch.nn.functional as TF  # noqa: E402
+
+from freesound_classification_amd import functional as F  # noqa: E402
+
+DEV = torch.device("cuda:0")
+
+# (n, c_in, c_out, h, w, k): channel counts around the octet / chunk / tile edges, odd widths, boxes that overhang,
+# several images per box, the cfg-2 shapes at a reduced batch
+CONV_CASES = [
+    (16, 100, 100, 64, 215, 3), (16, 100, 150, 64, 215, 3), (24, 150, 150, 32, 107, 3), (32, 150, 225, 32, 107, 3),
+    (64, 225, 225, 16, 53, 3), (128, 337, 337, 8, 26, 3), (128, 506, 506, 4, 13, 3), (16, 100, 100, 64, 215, 1),
+    (32, 150, 150, 32, 107, 1), (128, 225, 225, 16, 53, 1), (40, 33, 49, 17, 29, 3), (40, 64, 48, 30, 31, 3),
+    (36, 57, 130, 23, 40, 3), (64, 95, 64, 9, 77, 1), (48, 127, 97, 12, 20, 3),
+]
+
+
+def _conv_ref(x, w, b):
+    return TF.conv2d(x.double().cpu(), w.double().cpu(), None if b is None else b.double().cpu(), padding=w.shape[-1] // 2)
+
+
+@pytest.mark.parametrize("case", CONV_CASES, ids=lambda c: "x".join(map(str, c)))
+def test_conv_l16_forward_and_dgrad(case):
+    n, cin, cout, h, w, k = case
+    F.set_conv_arith("f16x3")
+    try:
+        d = F._desc(n, cin, cout, h, w, k, k, 3)
+        torch.manual_seed(sum(case))
+        x = torch.randn(n, cin, h, w, device=DEV) * 3.0
+        wt = torch.randn(cout, cin, k, k, device=DEV) / (cin * k * k) ** 0.5
+        bias = torch.randn(cout, device=DEV)
+        gy = torch.randn(n, cout, h, w, device=DEV) * 1e-3
+        ran = 0
+        if F.conv_l16_supported(d, 0):
+            t = F.l16_pack(x)
+            back = F.l16_unpack(t)
+            assert (back - x).abs().max().item() <= 2.0 ** -22 * x.abs().max().item()
+            got = F.conv_l16(t, wt, bias)
+            same = F.conv_forward(x, wt, bias, x_amax=t.amax)
+            # same limb products in the same order: bit-identical unless the fp32-input kernel splits K over workgroups
+            assert (got - same).abs().max().item() <= 2e-6 * same.abs().max().item()
+            if CONV_CASES.index(case) < 10:
+                assert torch.equal(got, same), "L16 forward differs from the fp32-input f16x3 kernel"
+            ref = _conv_ref(x, wt, bias)
+            err = (got.double().cpu() - ref).abs().max().item()
+            assert err <= 2e-5 * max(1.0, ref.abs().max().item()), err
+            ran += 1
+        if F.conv_l16_supported(d, 1):
+            t = F.l16_pack(gy)
+            got = F.conv_l16(t, wt, None, dgrad=True)
+            same = F.conv_dgrad(gy, wt, x.shape, dout_amax=t.amax)
+            assert (got - same).abs().max().item() <= 2e-6 * same.abs().max().item()
+            if CONV_CASES.index(case) < 10:
+                assert torch.equal(got, same), "L16 dgrad differs from the fp32-input f16x3 kernel"
+            xr = x.double().cpu().requires_grad_(True)
+            TF.conv2d(xr, wt.double().cpu(), None, padding=k // 2).backward(gy.double().cpu())
+            err = (got.double().cpu() - xr.grad).abs().max().item()
+            assert err <= 2e-5 * max(1e-3, xr.grad.abs().max().item()), err
+            # accumulating form
+            base = torch.randn_like(got)
+            acc = F.conv_l16(t, wt, None, dgrad=True, accumulate_into=base.clone())
+            assert (acc - (base + got)).abs().max().item() <= 1e-6 * max(1.0, got.abs().max().item())
+            ran += 1
+        if n * h * w >= 128 * 256 and min(cin, cout) >= 48:
+            assert ran > 0, "no L16 tiling for a benchmark-size layer"
+    finally:
+        F.set_conv_arith(None)
+
+
+def test_l16_pack_scale_and_pad_channels():
+    """Pad channels of the last octet are zero, the scale is the power of two that brings the maximum to [2^14, 2^15)."""
+    x = torch.randn(3, 13, 5, 7, device=DEV) * 1e-7
+    t = F.l16_pack(x)
+    raw = t.data.view(torch.float16).view(3, 2, 2, 35, 8)          # [n][oct][limb][pos][8]
+    assert raw[:, 1, :, :, 5:].abs().max().item() == 0.0
+    hi = raw[:, :, 0].float().abs().max().item()
+    assert 2.0 ** 14 <= hi < 2.0 ** 15
+    # the layout itself: [n][octet][limb][position][8 channels], value = (h + l) / scale
+    scale = 2.0 ** 14 / 2.0 ** torch.floor(torch.log2(x.abs().max())).item()
+    rebuilt = ((raw[:, :, 0].double() + raw[:, :, 1].double()) / scale).permute(0, 1, 3, 2).reshape(3, 16, 5, 7)[:, :13]
+    assert (rebuilt.float() - F.l16_unpack(t)).abs().max().item() <= 1e-6 * x.abs().max().item()
+    assert (F.l16_unpack(t) - x).abs().max().item() <= 2.0 ** -22 * x.abs().max().item()
+
+
+BN_CASES = [(4, 100, 64, 215), (8, 150, 32, 107), (16, 37, 16, 53), (32, 100, 8, 26), (64, 57, 4, 13), (128, 24, 2, 6), (6, 19, 7, 9)]
+
+
+def _bn_units(c):
+    torch.manual_seed(c)
+    bn = nn.BatchNorm2d(c).to(DEV)
+    bn.weight.data.uniform_(0.5, 1.5)
+    bn.bias.data.uniform_(-0.5, 0.5)
+    prelu = nn.PReLU(c).to(DEV)
+    prelu.weight.data.uniform_(-0.2, 0.6)
+    return bn, prelu
+
+
+@pytest.mark.parametrize("case", BN_CASES, ids=lambda c: "x".join(map(str, c)))
+def test_bn_forward_writes_l16(case):
+    n, c, h, w = case
+    bn, prelu = _bn_units(c)
+    x = torch.randn(n, c, h, w, device=DEV) * 2.0 + 0.3
+    st = F.bn_prepare(x, bn, True)
+    for alpha in (None, prelu.weight):
+        y_ref, y_max = F.bn_act_forward(x, st, alpha, with_amax=True)
+        y, t = F.bn_act_forward(x, st, alpha, l16=True)
+        assert t is not None and torch.equal(y, y_ref)
+        true_max = y_ref.abs().max().item()
+        assert t.amax.max().item() == pytest.approx(true_max, rel=1e-6)          # the bound is the exact maximum
+        assert (F.l16_unpack(t) - y_ref).abs().max().item() <= 2.0 ** -21 * true_max
+        _, t_only = F.bn_act_forward(x, st, alpha, l16=True, want_f32=False)
+        assert torch.equal(t_only.data, t.data)
+
+
+@pytest.mark.parametrize("case", BN_CASES, ids=lambda c: "x".join(map(str, c)))
+def test_bn_backward_writes_l16(case):
+    n, c, h, w = case
+    bn, prelu = _bn_units(c)
+    x = torch.randn(n, c, h, w, device=DEV) * 2.0 + 0.3
+    res = torch.randn_like(x)
+    dy = torch.randn_like(x) * 1e-2
+    st = F.bn_prepare(x, bn, True)
+    gdy = torch.randn(n, c, device=DEV)
+    gidx = torch.randint(0, h * w, (n, c), device=DEV, dtype=torch.int32)
+    for kw in (dict(), dict(residual=res, want_dres=True, gmax=(gdy, gidx)), dict(want_chan_sum=True)):
+        ref = F.bn_act_backward(dy, x, st, bn, prelu.weight, with_amax=True, **kw)
+        got = F.bn_act_backward(dy, x, st, bn, prelu.weight, with_amax=True, l16=True, **kw)
+        t = got[-1]
+        assert isinstance(t, F.L16)
+        for a, b in zip(ref[:-1], got[:-1]):
+            if a is None:
+                assert b is None
+            elif a.dim() == 1:            # per-channel sums (the sum of dx is analytically 0): the reduction order differs
+                assert (a - b).abs().max().item() <= max(1e-4 * a.abs().max().item(), 1e-7 * n * h * w * ref[0].abs().max().item())
+            else:                         # (the two kernels contract their multiply-adds differently)
+                assert (a - b).abs().max().item() <= 2e-6 * a.abs().max().item()
+        true_max = ref[0].abs().max().item()
+        bound = t.amax.max().item()
+        assert true_max <= bound <= 8.0 * true_max, (true_max, bound)
+        assert (F.l16_unpack(t) - ref[0]).abs().max().item() <= 2.0 ** -21 * bound
+        only = F.bn_act_backward(dy, x, st, bn, prelu.weight, with_amax=True, l16=True, want_f32=False, **kw)
+        assert only[0] is None and torch.equal(only[-1].data, t.data)
+
+
+@pytest.mark.parametrize("case", [(4, 100, 64, 215, 2), (8, 37, 17, 29, 2), (16, 24, 9, 12, 2), (4, 16, 1, 33, 1), (2, 150, 32, 107, 2)],
+                         ids=lambda c: "x".join(map(str, c)))
+def test_bn_backward_unpool_writes_l16(case):
+    n, c, h, w, ph = case
+    bn, prelu = _bn_units(c)
+    full = torch.randn(n, c, h, w, device=DEV)
+    p, pidx = F.maxpool_forward(full, ph)
+    st = F.bn_prepare(p, bn, True)
+    dy = torch.randn_like(p) * 1e-2
+    ref = F.bn_act_backward_unpool(dy, p, st, bn, prelu.weight, pidx, tuple(full.shape), ph)
+    got = F.bn_act_backward_unpool(dy, p, st, bn, prelu.weight, pidx, tuple(full.shape), ph, l16=True)
+    t = got[-1]
+    assert isinstance(t, F.L16)
+    assert (ref[0] - got[0]).abs().max().item() <= 2e-6 * ref[0].abs().max().item()
+    assert torch.equal(ref[0] == 0, got[0] == 0)              # the same arg-max positions, zeros elsewhere
+    for a, b in zip(ref[1:-1], got[1:-1]):
+        assert (a - b).abs().max().item() <= max(1e-4 * a.abs().max().item(), 1e-7 * n * h * w * ref[0].abs().max().item())
+    true_max = ref[0].abs().max().item()
+    bound = t.amax.max().item()
+    assert true_max <= bound <= 8.0 * true_max
+    assert (F.l16_unpack(t) - ref[0]).abs().max().item() <= 2.0 ** -21 * bound
+    only = F.bn_act_backward_unpool(dy, p, st, bn, prelu.weight, pidx, tuple(full.shape), ph, l16=True, want_f32=False)
+    assert only[0] is None and torch.equal(only[-1].data, t.data)
+
+
+def test_block_with_and_without_l16_agree():
+    """One residual block at a shape whose convolutions take the L16 kernels: outputs and every gradient equal the fp32-input
+    path's within the rounding of the operand scales (the backward bounds over-estimate the maxima)."""
+    from freesound_classification_amd.networks.classifiers import TwoDimensionalCNNClassificationModel
+
+    class NS(dict):
+        __getattr__ = dict.__getitem__
+
+    exp = NS(config=NS(
+        network=NS(num_conv_blocks=2, start_deep_supervision_on=0, conv_base_depth=64, growth_rate=1.5,
+                   output_dropout=0.0, aggregation_type="max"),
+        data=NS(features="mel_1024_512_64", _input_dim=64, _n_classes=80),
+        train=NS(accumulation_steps=1, optimizer="adam", learning_rate=1e-3, weight_decay=0.0,
+                 scheduler="1cycle_0.0001_0.005")))
+    torch.manual_seed(0)
+    model = TwoDimensionalCNNClassificationModel(exp, device="cuda:0")
+    model.train()
+    signal = 0.1 * torch.randn(64, 2 * 44100, 1, device=DEV)
+    labels = torch.zeros(64, 80, device=DEV)
+    labels[torch.arange(64), torch.randint(0, 80, (64,))] = 1.0
+    results = []
+    used = []
+    for use in (False, True):
+        F.USE_L16 = use
+        F._L16_OK.clear()
+        try:
+            for prm in model.parameters():
+                prm.grad = None
+            model.make_optimizer(max_steps=10)
+            logits, per, loss = model.training_step(signal, labels, step_optimizer=False)
+            results.append((logits.detach().clone(), {k: v.grad.detach().clone() for k, v in model.named_parameters() if v.grad is not None}))
+            used.append(any(F._L16_OK.values()))
+        finally:
+            F.USE_L16 = True
+            F._L16_OK.clear()
+    assert used == [False, True], "the test shape must exercise the L16 kernels"
+    (l0, g0), (l1, g1) = results
+    assert (l0 - l1).abs().max().item() <= 1e-4
+    for k in g0:
+        assert (g0[k] - g1[k]).abs().max().item() <= 1e-4 * max(1.0, g0[k].abs().max().item()), k

@@ -30,6 +30,7 @@ def main():
     ap.add_argument("names", nargs="*")
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--n", type=int, default=None)
+    ap.add_argument("--wgrad", action="store_true")
     a = ap.parse_args()
     F.set_conv_arith("f16x3")
     dev = torch.device("cuda")
@@ -43,6 +44,24 @@ def main():
         wt = torch.randn(cout, cin, k, k, device=dev) / (cin * k * k) ** 0.5
         bias = torch.randn(cout, device=dev)
         gy = torch.randn(n, cout, h, w, device=dev)
+        d = F._desc(n, cin, cout, h, w, k, k, 3)
+        if a.wgrad:
+            if not F.conv_l16_wgrad_supported(d):
+                print("%-5s wgrad unsupported" % name, flush=True)
+                continue
+            xa, ga = F.amax(x), F.amax(gy)
+            x16, g16 = F.l16_pack(x, xa), F.l16_pack(gy, ga)
+            ref = F.conv_wgrad(x, gy, wt.shape, x_amax=xa, dout_amax=ga)
+            got = F.conv_l16_wgrad(x16, g16, wt.shape)
+            torch.cuda.synchronize()
+            diff = (ref - got).abs().max().item()
+            ms_old = timeit(lambda: F.conv_wgrad(x, gy, wt.shape, x_amax=xa, dout_amax=ga), a.iters)
+            ms_new = timeit(lambda: F.conv_l16_wgrad(x16, g16, wt.shape), a.iters)
+            fl = 2.0 * n * h * w * cin * cout * k * k
+            print("%-5s wgrad %-34s max|diff| %.3e (max|ref| %.3e) | old %-28s %7.3f ms %6.1f TF | new %7.3f ms %6.1f TF  x%.2f"
+                  % (name, F.l16_wgrad_plan_name(d), diff, ref.abs().max().item(), F.plan_name(d, 2), ms_old, fl / ms_old / 1e9,
+                     ms_new, fl / ms_new / 1e9, ms_old / ms_new), flush=True)
+            continue
         for dgrad in (False, True):
             d = F._desc(n, cin, cout, h, w, k, k, 3)
             if not F.conv_l16_supported(d, int(dgrad)):
