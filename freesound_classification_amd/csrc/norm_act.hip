@@ -9,6 +9,7 @@
 // blocks and splits (deterministic two-stage reduce, no atomics on the statistics).
 #include "common.h"
 #include "l16.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -316,6 +317,29 @@ __device__ __forceinline__ float block_max256(float m, float* red) {
     return m;
 }
 
+// Stores of a thread's VEC = 4 consecutive positions (hi[p], lo[p] = the two 16-byte limb vectors of position 4 q + p).
+// Written directly, a store instruction puts 16 bytes into every fourth 16-byte slot (lane stride 64 bytes): quarter-filled
+// lines, 4x the write requests.  Instead each wave transposes through its own LDS patch (80-byte lane pitch: conflict-free
+// 16-byte writes) so that instruction k stores positions 64 k + lane of the wave's 256 -- 1 KB contiguous.  Needs the wave's
+// lanes on consecutive quads (position lanes >= 64) and EVERY lane of the wave calling (dead lanes pass anything).
+__device__ __forceinline__ void l16_store_quads(uint4* __restrict__ out_hi, uint4* __restrict__ out_lo, long q, long hw,
+                                                const uint4 (&hi)[4], const uint4 (&lo)[4], uint4* wave_patch) {
+    const int lane = threadIdx.x & 63;
+    const long p0 = 4 * (q - lane);                          // first position of the wave's 256
+#pragma unroll
+    for (int limb = 0; limb < 2; ++limb) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) wave_patch[lane * 5 + p] = limb ? lo[p] : hi[p];
+        uint4* out = limb ? out_lo : out_hi;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int pp = k * 64 + lane;
+            const uint4 v = wave_patch[(pp >> 2) * 5 + (pp & 3)];
+            if (p0 + pp < hw) out[p0 + pp] = v;
+        }
+    }
+}
+
 template <int VEC, bool UNI>
 __global__ __launch_bounds__(kThreads) void fwd_l16_kernel(
     const float* __restrict__ x, const float* __restrict__ scale, const float* __restrict__ shift,
@@ -351,11 +375,16 @@ __global__ __launch_bounds__(kThreads) void fwd_l16_kernel(
     const long xbase = ((long)img * c + o * 8) * hw;
     uint4* const out_hi = y16 + (((long)img * oct + o) * 2) * hw;
     uint4* const out_lo = out_hi + hw;
-    for (long q = (long)blockIdx.y * hwp + ti; q < nq; q += (long)gridDim.y * hwp) {
+    __shared__ uint4 patch[kThreads / 64][64 * 5];
+    const bool transpose = VEC == 4 && hwp >= 64;            // (uniform)
+    const int lane = threadIdx.x & 63;
+    // with the transposed stores the loop is wave-uniform: a lane past the plane still takes part in the wave's stores
+    for (long q = (long)blockIdx.y * hwp + ti; transpose ? q - lane < nq : q < nq; q += (long)gridDim.y * hwp) {
+        const bool q_live = q < nq;
         float z[8][VEC];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            const bool live = o * 8 + e < c;
+            const bool live = o * 8 + e < c && q_live;
             if (VEC == 4) {
                 float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (live) v = reinterpret_cast<const float4*>(x + xbase + e * hw)[q];
@@ -370,13 +399,22 @@ __global__ __launch_bounds__(kThreads) void fwd_l16_kernel(
                 if (y && live) y[xbase + e * hw + q] = z[e][0];
             }
         }
+        uint4 hi[VEC], lo[VEC];
 #pragma unroll
         for (int p = 0; p < VEC; ++p) {
             const float v8[8] = {z[0][p], z[1][p], z[2][p], z[3][p], z[4][p], z[5][p], z[6][p], z[7][p]};
-            uint4 hi, lo;
-            l16::split8(v8, s, hi, lo);
-            out_hi[q * VEC + p] = hi;
-            out_lo[q * VEC + p] = lo;
+            l16::split8(v8, s, hi[p], lo[p]);
+        }
+        if constexpr (VEC == 4) {
+            if (transpose) {
+                l16_store_quads(out_hi, out_lo, q, hw, hi, lo, patch[threadIdx.x >> 6]);
+                continue;
+            }
+        }
+#pragma unroll
+        for (int p = 0; p < VEC; ++p) {
+            out_hi[q * VEC + p] = hi[p];
+            out_lo[q * VEC + p] = lo[p];
         }
     }
 }
@@ -715,6 +753,41 @@ __global__ __launch_bounds__(kThreads) void bwd_apply_unpool_kernel(BwdArgs a, c
     if (dc_amax) fsc::publish_amax(dc_amax, mx);
 }
 
+// Per-channel sums of a thread's 8 accumulators into dx_chan_sum.  Same-address float atomics are slow (~250 ns each under
+// contention: 2048 per channel cost the block-0 apply pass +0.5 ms), so a block whose threads all work on one octet
+// reduces through LDS and issues ONE hardware atomic per channel; mixed blocks reduce per wave where the wave is uniform.
+__device__ __forceinline__ void chan_sums_out(const float (&acc)[8], int o, bool g_live, int c, float* dx_chan_sum, bool block_uniform) {
+    __shared__ float cs[kThreads / 64][8];
+    __shared__ int co[kThreads / 64];
+    const int o0 = __builtin_amdgcn_readfirstlane(o);
+    const bool same = __all(o == o0 && g_live);
+    if (!block_uniform) {                       // groups of a block usually share the octet too (images run fastest)
+        if ((threadIdx.x & 63) == 0) co[threadIdx.x >> 6] = same ? o0 : -1 - (int)(threadIdx.x >> 6);
+        __syncthreads();
+        block_uniform = co[0] >= 0 && co[0] == co[1] && co[1] == co[2] && co[2] == co[3];
+    }
+    if (block_uniform) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float t = fsc::wave_sum(g_live ? acc[e] : 0.f);
+            if ((threadIdx.x & 63) == 0) cs[threadIdx.x >> 6][e] = t;
+        }
+        __syncthreads();
+        if (threadIdx.x < 8 && o0 * 8 + threadIdx.x < c)
+            unsafeAtomicAdd(dx_chan_sum + o0 * 8 + threadIdx.x, (cs[0][threadIdx.x] + cs[1][threadIdx.x]) + (cs[2][threadIdx.x] + cs[3][threadIdx.x]));
+        return;
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        if (same) {
+            const float t = fsc::wave_sum(acc[e]);
+            if ((threadIdx.x & 63) == 0 && o0 * 8 + e < c) unsafeAtomicAdd(dx_chan_sum + o0 * 8 + e, t);
+        } else if (g_live && o * 8 + e < c) {
+            unsafeAtomicAdd(dx_chan_sum + o * 8 + e, acc[e]);
+        }
+    }
+}
+
 // Backward apply pass writing dx as an L16 tensor (and, optionally, as fp32 planes too).  Same arithmetic as
 // bwd_apply_plane_kernel; thread layout of fwd_l16_kernel.  The scale comes from the per-channel bounds coef[2c + ch].
 template <int VEC, bool UNI>
@@ -743,12 +816,16 @@ __global__ __launch_bounds__(kThreads) void bwd_apply_l16_kernel(BwdArgs a, cons
     const long xbase = ((long)img * c + o * 8) * hw;
     uint4* const out_hi = dx16 + (((long)img * oct + o) * 2) * hw;
     uint4* const out_lo = out_hi + hw;
-    for (long q = (long)blockIdx.y * hwp + ti; q < nq; q += (long)gridDim.y * hwp) {
+    __shared__ uint4 patch[kThreads / 64][64 * 5];
+    const bool transpose = VEC == 4 && hwp >= 64;            // (uniform; see l16_store_quads)
+    const int lane = threadIdx.x & 63;
+    for (long q = (long)blockIdx.y * hwp + ti; transpose ? q - lane < nq : q < nq; q += (long)gridDim.y * hwp) {
+        const bool q_live = q < nq;
         float d[8][VEC];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const int ch = o * 8 + e;
-            if (ch < c) {
+            if (ch < c && q_live) {
                 const float mean = a.mean[ch], invstd = a.invstd[ch];
                 const float gm = a.gamma ? a.gamma[ch] : 1.f, bt = a.beta ? a.beta[ch] : 0.f;
                 const float al = has_alpha ? a.alpha[ch] : 1.f;
@@ -793,29 +870,25 @@ __global__ __launch_bounds__(kThreads) void bwd_apply_l16_kernel(BwdArgs a, cons
                 for (int p = 0; p < VEC; ++p) d[e][p] = 0.f;
             }
         }
+        uint4 hi[VEC], lo[VEC];
 #pragma unroll
         for (int p = 0; p < VEC; ++p) {
             const float v8[8] = {d[0][p], d[1][p], d[2][p], d[3][p], d[4][p], d[5][p], d[6][p], d[7][p]};
-            uint4 hi, lo;
-            l16::split8(v8, s, hi, lo);
-            out_hi[q * VEC + p] = hi;
-            out_lo[q * VEC + p] = lo;
+            l16::split8(v8, s, hi[p], lo[p]);
         }
-    }
-    if (dx_chan_sum) {
-        // a wave whose lanes all work on one octet reduces in registers; else every live thread adds its own sums
-        const int o0 = __builtin_amdgcn_readfirstlane(o);
-        const bool same = __all(o == o0);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            if (same) {
-                const float t = fsc::wave_sum(acc[e]);
-                if ((threadIdx.x & 63) == 0 && o0 * 8 + e < c) atomicAdd(dx_chan_sum + o0 * 8 + e, t);
-            } else if (g_live && o * 8 + e < c) {
-                atomicAdd(dx_chan_sum + o * 8 + e, acc[e]);
+        if constexpr (VEC == 4) {
+            if (transpose) {
+                l16_store_quads(out_hi, out_lo, q, hw, hi, lo, patch[threadIdx.x >> 6]);
+                continue;
             }
         }
+#pragma unroll
+        for (int p = 0; p < VEC; ++p) {
+            out_hi[q * VEC + p] = hi[p];
+            out_lo[q * VEC + p] = lo[p];
+        }
     }
+    if (dx_chan_sum) chan_sums_out(acc, o, g_live, c, dx_chan_sum, UNI);
 }
 
 // L16 form of bwd_apply_unpool_kernel: a thread owns one pooled position x the 8 channels of an (octet, image) and writes the
@@ -908,19 +981,7 @@ __global__ __launch_bounds__(kThreads) void bwd_apply_unpool_l16_kernel(BwdArgs 
                     if (o * 8 + e < c) dc[((long)img * c + o * 8 + e) * HW + (long)(h - 1) * w + xx] = 0.f;
         }
     }
-    if (dx_chan_sum) {
-        const int o0 = __builtin_amdgcn_readfirstlane(o);
-        const bool same = __all(o == o0);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            if (same) {
-                const float t = fsc::wave_sum(acc[e]);
-                if ((threadIdx.x & 63) == 0 && o0 * 8 + e < c) atomicAdd(dx_chan_sum + o0 * 8 + e, t);
-            } else if (g_live && o * 8 + e < c) {
-                atomicAdd(dx_chan_sum + o * 8 + e, acc[e]);
-            }
-        }
-    }
+    if (dx_chan_sum) chan_sums_out(acc, o, g_live, c, dx_chan_sum, hwp == kThreads);
 }
 
 __global__ void bwd_apply_flat_kernel(BwdArgs a, const float* __restrict__ coef, float* __restrict__ dx,
@@ -967,7 +1028,7 @@ int hwp_log2_for(long hw) {
 struct L16Grid { int hwp_log2; bool uni; dim3 grid; int vec; };
 L16Grid l16_grid(int n, int c, long hw, bool allow_vec) {
     L16Grid r;
-    r.vec = (allow_vec && (hw & 3) == 0) ? 4 : 1;
+    r.vec = (allow_vec && (hw & 3) == 0 && !getenv("FSC_L16_VEC1")) ? 4 : 1;
     const long nq = hw / r.vec;
     const long groups_total = (long)n * ((c + 7) / 8);
     r.uni = nq >= kThreads;
