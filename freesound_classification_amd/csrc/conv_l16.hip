@@ -154,16 +154,27 @@ __global__ __launch_bounds__(256) void l16_unpack_kernel(const uint4* __restrict
 
 // weight (c_out, c_in, kh, kw) -> A fragments: packed[co block][step][channel tile][limb][lane][8 fp16];
 // lane = (kq, m); its 8 values are the channels of octet `oct` at tap `tap`, (tap, oct) = divmod(4 * step_in_chunk
-// + kq, octets of the chunk).  Scaled by scale_field(*w_amax).  Same format as conv.hip pack_x3_kernel (fp16 limbs).
-__global__ void l16_pack_w_kernel(const float* __restrict__ w, unsigned short* __restrict__ packed, int c_out, int c_in,
-                                  int taps, int cot, int co_blocks, int nfull, int tail_oct, int steps, int dgrad,
-                                  float* __restrict__ w_amax) {
-    const long total = (long)co_blocks * steps * cot * 512;
+// + kq, octets of the chunk).  Scaled by scale_field(max |w|).  Same format as conv.hip pack_x3_kernel (fp16 limbs).
+// One launch packs up to two directions (forward and input gradient) of the same weight: blocks [0, a.blocks) write
+// direction a, the rest direction b; both fold the partial maxima of l16_wmax_kernel at `wmax_part`.
+struct PackDir {
+    unsigned short* packed;
+    float* w_amax;           // receives max |w| (read by the conv kernel)
+    int cot, co_blocks, nfull, tail_oct, steps, dgrad;
+    long total;
+    int blocks;
+};
+__global__ void l16_pack_w_kernel(const float* __restrict__ w, int c_out, int c_in, int taps, PackDir a, PackDir b,
+                                  const float* __restrict__ wmax_part) {
+    const bool second = (int)blockIdx.x >= a.blocks;
+    const PackDir& dir = second ? b : a;
+    const int blk = second ? blockIdx.x - a.blocks : blockIdx.x;
     float wm = 0.f;
-    for (int i = 0; i < kWmaxBlocks; ++i) wm = fmaxf(wm, w_amax[4 + i]);      // partial maxima of l16_wmax_kernel
-    if (blockIdx.x == 0 && threadIdx.x == 0) w_amax[0] = wm;
+    for (int i = 0; i < kWmaxBlocks; ++i) wm = fmaxf(wm, wmax_part[i]);
+    if (blk == 0 && threadIdx.x == 0) dir.w_amax[0] = wm;
     const float sw = field_to_float(scale_field(wm));
-    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int cot = dir.cot, steps = dir.steps, nfull = dir.nfull;
+    for (long idx = (long)blk * blockDim.x + threadIdx.x; idx < dir.total; idx += (long)dir.blocks * blockDim.x) {
         const int e = (int)(idx & 7), lane = (int)((idx >> 3) & 63);
         long rest = idx >> 9;
         const int i = (int)(rest % cot); rest /= cot;
@@ -171,20 +182,20 @@ __global__ void l16_pack_w_kernel(const float* __restrict__ w, unsigned short* _
         const int cb = (int)(rest / steps);
         const int c = S < nfull * taps ? S / taps : nfull;
         const int s = S - c * taps;
-        const int noct = c < nfull ? 4 : tail_oct;
+        const int noct = c < nfull ? 4 : dir.tail_oct;
         const int gi = 4 * s + (lane >> 4);
         float v = 0.f;
         if (gi < taps * noct) {
             const int tap = gi / noct, oct = gi - tap * noct;
             const int k = c * kChunk + oct * 8 + e, m = (cb * cot + i) * 16 + (lane & 15);
-            const int co = dgrad ? k : m, ci = dgrad ? m : k;
-            if (co < c_out && ci < c_in) v = w[((long)co * c_in + ci) * taps + (dgrad ? taps - 1 - tap : tap)];
+            const int co = dir.dgrad ? k : m, ci = dir.dgrad ? m : k;
+            if (co < c_out && ci < c_in) v = w[((long)co * c_in + ci) * taps + (dir.dgrad ? taps - 1 - tap : tap)];
         }
         unsigned h2, l2;
         split2_pair(v, 0.f, sw, h2, l2);
         const long base2 = ((((long)cb * steps + S) * cot + i) * 2) * 512 + lane * 8 + e;
-        packed[base2] = (unsigned short)h2;
-        packed[base2 + 512] = (unsigned short)l2;
+        dir.packed[base2] = (unsigned short)h2;
+        dir.packed[base2 + 512] = (unsigned short)l2;
     }
 }
 
@@ -665,7 +676,8 @@ bool plan_l16(const fsc_conv_desc& d, int dgrad, LPlan* out) {
     if (getenv("FSC_NO_L16")) return false;
     const int taps = d.kh * d.kw;
     const char* force_pt = getenv("FSC_L16_PT");            // development: force the pixel tiles per wave
-    if ((!force_pt || atoi(force_pt) == 2) && plan_l16_pt(d, dgrad, 2, taps == 1 ? 8 : 10, out)) return true;
+    // (9 / 10 tiles per block leave too little LDS for a 256-pixel box: 150-channel layers run 7 % faster as 2 x 5 tiles)
+    if ((!force_pt || atoi(force_pt) == 2) && plan_l16_pt(d, dgrad, 2, 8, out)) return true;
     if (force_pt && atoi(force_pt) == 2) return false;
     return plan_l16_pt(d, dgrad, 1, taps == 1 ? 8 : 10, out);
 }
@@ -754,19 +766,40 @@ size_t fsc_conv_l16_packed_floats(const fsc_conv_desc* d, int dgrad) {
     return l16_limb_floats(p) + 4 + kWmaxBlocks;
 }
 
-int fsc_conv_l16_pack_weights(const fsc_conv_desc* d, const float* weight, int dgrad, float* packed, fsc_stream_t stream) {
-    LPlan p;
-    FSC_CHECK_ARG(valid_l16_desc(d) && weight && packed && plan_l16(*d, dgrad, &p), "fsc_conv_l16_pack_weights: unsupported shape");
+static PackDir make_pack_dir(const LPlan& p, float* packed, int dgrad) {
+    PackDir r{};
+    r.packed = reinterpret_cast<unsigned short*>(packed);
+    r.w_amax = packed + l16_limb_floats(p);
+    r.cot = p.cot; r.co_blocks = p.co_blocks; r.nfull = p.g.nfull; r.tail_oct = p.g.tail_oct; r.steps = p.g.steps;
+    r.dgrad = dgrad;
+    r.total = (long)p.co_blocks * p.g.steps * p.cot * 512;
+    long xb = (r.total + 255) / 256;
+    r.blocks = (int)(xb > 4096 ? 4096 : xb);
+    return r;
+}
+
+/* packs the forward (packed_fwd) and / or input-gradient (packed_dgrad) fragments of one weight in two launches total */
+int fsc_conv_l16_pack_weights_pair(const fsc_conv_desc* d, const float* weight, float* packed_fwd, float* packed_dgrad,
+                                   fsc_stream_t stream) {
+    FSC_CHECK_ARG(valid_l16_desc(d) && weight && (packed_fwd || packed_dgrad), "fsc_conv_l16_pack_weights_pair: bad arguments");
+    LPlan pf{}, pd{};
+    FSC_CHECK_ARG(!packed_fwd || plan_l16(*d, 0, &pf), "fsc_conv_l16_pack_weights_pair: no forward tiling for this shape");
+    FSC_CHECK_ARG(!packed_dgrad || plan_l16(*d, 1, &pd), "fsc_conv_l16_pack_weights_pair: no dgrad tiling for this shape");
     hipStream_t st = fsc::as_stream(stream);
-    float* w_amax = packed + l16_limb_floats(p);
-    hipLaunchKernelGGL(l16_wmax_kernel, dim3(kWmaxBlocks), dim3(256), 0, st, weight, (long)d->c_out * d->c_in * d->kh * d->kw, w_amax + 4);
-    const long items = (long)p.co_blocks * p.g.steps * p.cot * 512;
-    long xb = (items + 255) / 256;
-    if (xb > 8192) xb = 8192;
-    hipLaunchKernelGGL(l16_pack_w_kernel, dim3((unsigned)xb), dim3(256), 0, st, weight, reinterpret_cast<unsigned short*>(packed),
-                       d->c_out, d->c_in, d->kh * d->kw, p.cot, p.co_blocks, p.g.nfull, p.g.tail_oct, p.g.steps, dgrad, w_amax);
+    PackDir a{}, b{};
+    if (packed_fwd) a = make_pack_dir(pf, packed_fwd, 0);
+    if (packed_dgrad) b = make_pack_dir(pd, packed_dgrad, 1);
+    if (!packed_fwd) { a = b; b = PackDir{}; }
+    float* part = a.w_amax + 4;                            // partial maxima live behind the first direction's fragments
+    hipLaunchKernelGGL(l16_wmax_kernel, dim3(kWmaxBlocks), dim3(256), 0, st, weight, (long)d->c_out * d->c_in * d->kh * d->kw, part);
+    hipLaunchKernelGGL(l16_pack_w_kernel, dim3((unsigned)(a.blocks + b.blocks)), dim3(256), 0, st, weight, d->c_out, d->c_in,
+                       d->kh * d->kw, a, b, part);
     FSC_LAUNCH_CHECK("fsc_conv_l16_pack_weights");
     return 0;
+}
+
+int fsc_conv_l16_pack_weights(const fsc_conv_desc* d, const float* weight, int dgrad, float* packed, fsc_stream_t stream) {
+    return fsc_conv_l16_pack_weights_pair(d, weight, dgrad ? nullptr : packed, dgrad ? packed : nullptr, stream);
 }
 
 int fsc_conv_l16_fwd(const fsc_conv_desc* d, const void* in_l16, const float* in_amax, const float* packed,

@@ -307,6 +307,21 @@ def conv_l16_pack(weight, n, h, w, dgrad):
     return d, packed
 
 
+def conv_l16_pack_pair(weight, n, h, w):
+    """Forward and input-gradient fragments of one weight in one call: ((desc, packed_fwd) or None, (desc, packed_dgrad) or
+    None), for the directions fsc_conv_l16_fwd has a tiling for."""
+    c_out, c_in, kh, kw = weight.shape
+    d = _desc(n, c_in, c_out, h, w, kh, kw, 3)
+    lib = _lib.load()
+    nf, nd = lib.fsc_conv_l16_packed_floats(C.byref(d), 0), lib.fsc_conv_l16_packed_floats(C.byref(d), 1)
+    if nf == 0 and nd == 0:
+        return None, None
+    pf = torch.empty(nf, device=weight.device, dtype=torch.float32) if nf else None
+    pd = torch.empty(nd, device=weight.device, dtype=torch.float32) if nd else None
+    call("fsc_conv_l16_pack_weights_pair", C.byref(d), ptr(weight), ptr(pf), ptr(pd), stream_ptr())
+    return ((d, pf) if nf else None), ((d, pd) if nd else None)
+
+
 def conv_l16(t, weight, bias, dgrad=False, accumulate_into=None, prepacked=None):
     """Forward (dgrad False: t = input, (N, Cin, H, W)) or input gradient (dgrad True: t = dout (N, Cout, H, W)) of a
     stride-1 same-pad convolution on an L16 operand; fp32 NCHW result."""
@@ -735,15 +750,24 @@ def _bn_fwd_for_conv(x, st, alpha, weight, keep_f32=False):
     return y, y_max, None
 
 
-def _conv_fwd_any(x, x_16, weight, bias, x_amax):
+def _conv_fwd_any(x, x_16, weight, bias, x_amax, packs=None):
+    """`packs` (a list, training only): the input-gradient fragments of this weight are packed in the same call as the
+    forward ones and appended for the backward pass (or None when that direction does not run on the L16 kernels)."""
     if x_16 is not None and _l16_ok_for(x_16.shape, weight, False):
+        if packs is not None:
+            n, _, h, w = x_16.shape
+            pf, pd = conv_l16_pack_pair(weight, n, h, w)
+            packs.append(pd)
+            return conv_l16(x_16, weight, bias, prepacked=pf)
         return conv_l16(x_16, weight, bias)
+    if packs is not None:
+        packs.append(None)
     return conv_forward(x, weight, bias, x_amax=x_amax)
 
 
-def _conv_dgrad_any(dout, dout_16, weight, x_shape, dout_amax, accumulate_into=None):
+def _conv_dgrad_any(dout, dout_16, weight, x_shape, dout_amax, accumulate_into=None, prepacked=None):
     if dout_16 is not None and _l16_ok_for(x_shape, weight, True):
-        return conv_l16(dout_16, weight, None, dgrad=True, accumulate_into=accumulate_into)
+        return conv_l16(dout_16, weight, None, dgrad=True, accumulate_into=accumulate_into, prepacked=prepacked)
     return conv_dgrad(dout, weight, x_shape, accumulate_into=accumulate_into, dout_amax=dout_amax)
 
 
@@ -780,26 +804,29 @@ def _block_forward(x, mods, training, want_head, ph, keep, sync=None):
     # Operands of convolutions that have an L16 tiling are written pre-split by the BN / PReLU kernel that produces them
     # (`*_16`); the fp32 copy stays for the weight gradient (and, for b, the residual).
     a, a_max, a_16 = _bn_fwd_for_conv(x, st_a, None, w_a)
+    packs = [] if keep else None          # input-gradient weight fragments packed along with the forward ones
     fused = conv_pool_forward(a, w_a, b_a) if (ph == 2 and a is not None) else None
     if fused is not None:
         p, pidx, k.c_shape = fused
+        if keep:
+            packs.append(None)
     else:
-        c = _conv_fwd_any(a, a_16, w_a, b_a, a_max)
+        c = _conv_fwd_any(a, a_16, w_a, b_a, a_max, packs)
         p, pidx = maxpool_forward(c, ph)
         k.c_shape = tuple(c.shape)
         del c
     st_b = bn_prepare(p, bn_b, training, sync)
     w1, b1 = _conv_params(res.conv1)
     b, b_max, b_16 = _bn_fwd_for_conv(p, st_b, prelu_b.weight, w1, keep_f32=True)      # (the residual reads it)
-    r1 = _conv_fwd_any(b, b_16, w1, b1, b_max)
+    r1 = _conv_fwd_any(b, b_16, w1, b1, b_max, packs)
     st1 = bn_prepare(r1, res.bn1, training, sync)
     w2, b2 = _conv_params(res.conv2)
     s1, s1_max, s1_16 = _bn_fwd_for_conv(r1, st1, res.prelu1.weight, w2)
-    r2 = _conv_fwd_any(s1, s1_16, w2, b2, s1_max)
+    r2 = _conv_fwd_any(s1, s1_16, w2, b2, s1_max, packs)
     st2 = bn_prepare(r2, res.bn2, training, sync)
     w3, b3 = _conv_params(res.conv3)
     s2, s2_max, s2_16 = _bn_fwd_for_conv(r2, st2, res.prelu2.weight, w3)
-    r3 = _conv_fwd_any(s2, s2_16, w3, b3, s2_max)
+    r3 = _conv_fwd_any(s2, s2_16, w3, b3, s2_max, packs)
     st3 = bn_prepare(r3, res.bn3, training, sync)
     out = bn_act_forward(r3, st3, res.prelu3.weight, residual=b)
     feat, fidx = (None, None)
@@ -812,6 +839,7 @@ def _block_forward(x, mods, training, want_head, ph, keep, sync=None):
         k.fidx = fidx
         k.amax = (a_max, b_max, s1_max, s2_max)
         k.l16 = (a_16, b_16, s1_16, s2_16)
+        k.packs = packs                    # [conv_a, conv1, conv2, conv3]
     return out, feat, k
 
 
@@ -870,6 +898,7 @@ class ConvBlockFn(torch.autograd.Function):
         w1, _ = _conv_params(res.conv1)
         wa, _ = _conv_params(conv_a)
         a_16, b_16, s1_16, s2_16 = k.l16
+        pk_a, pk_1, pk_2, pk_3 = k.packs
         # gradients whose consumers (input-gradient and weight-gradient kernels) read L16 are written pre-split as well
         # (`*_m` is then that L16, else the amax buffer), and only as L16 when both consumers do
         w16, w32 = _grad_formats(k.r2.shape, w3)
@@ -878,7 +907,7 @@ class ConvBlockFn(torch.autograd.Function):
             want_dres=True, want_chan_sum=True, with_amax=True, sync=sync, l16=w16, want_f32=w32)
         s2_shape = k.r2.shape
         dw3 = _conv_wgrad_any(k.s2, s2_16, s2_max, dr3, _l16_of(dr3_m), _amax_of(dr3_m), w3)
-        ds2 = _conv_dgrad_any(dr3, _l16_of(dr3_m), w3, s2_shape, _amax_of(dr3_m))
+        ds2 = _conv_dgrad_any(dr3, _l16_of(dr3_m), w3, s2_shape, _amax_of(dr3_m), prepacked=pk_3)
         del dr3, dr3_m
         w16, w32 = _grad_formats(k.r1.shape, w2)
         dr2, _, dg2, dbt2, dal2, dbias2, dr2_m = bn_act_backward(ds2, k.r2, k.st2, res.bn2, res.prelu2.weight,
@@ -886,7 +915,7 @@ class ConvBlockFn(torch.autograd.Function):
                                                                  l16=w16, want_f32=w32)
         del ds2
         dw2 = _conv_wgrad_any(k.s1, s1_16, s1_max, dr2, _l16_of(dr2_m), _amax_of(dr2_m), w2)
-        ds1 = _conv_dgrad_any(dr2, _l16_of(dr2_m), w2, k.r1.shape, _amax_of(dr2_m))
+        ds1 = _conv_dgrad_any(dr2, _l16_of(dr2_m), w2, k.r1.shape, _amax_of(dr2_m), prepacked=pk_2)
         del dr2, dr2_m
         w16, w32 = _grad_formats(k.b.shape, w1)
         dr1, _, dg1, dbt1, dal1, dbias1, dr1_m = bn_act_backward(ds1, k.r1, k.st1, res.bn1, res.prelu1.weight,
@@ -894,7 +923,7 @@ class ConvBlockFn(torch.autograd.Function):
                                                                  l16=w16, want_f32=w32)
         del ds1
         dw1 = _conv_wgrad_any(k.b, b_16, b_max, dr1, _l16_of(dr1_m), _amax_of(dr1_m), w1)
-        db = _conv_dgrad_any(dr1, _l16_of(dr1_m), w1, k.b.shape, _amax_of(dr1_m), accumulate_into=db)   # residual + conv1 paths
+        db = _conv_dgrad_any(dr1, _l16_of(dr1_m), w1, k.b.shape, _amax_of(dr1_m), accumulate_into=db, prepacked=pk_1)   # residual + conv1 paths
         del dr1, dr1_m
         # ---- b = prelu(bn_b(p))
         a_shape = tuple(k.c_shape[:1]) + (wa.shape[1],) + tuple(k.c_shape[2:])
@@ -903,7 +932,7 @@ class ConvBlockFn(torch.autograd.Function):
                                                                     k.pidx, k.c_shape, ph, sync=sync, l16=w16, want_f32=w32)
         del db
         dwa = _conv_wgrad_any(k.a, a_16, a_max, dc, _l16_of(dc_m), _amax_of(dc_m), wa)
-        da = _conv_dgrad_any(dc, _l16_of(dc_m), wa, a_shape, _amax_of(dc_m))
+        da = _conv_dgrad_any(dc, _l16_of(dc_m), wa, a_shape, _amax_of(dc_m), prepacked=pk_a)
         del dc, dc_m
         dx, _, dga, dbta, _, _ = bn_act_backward(da, k.x, k.st_a, bn_a, sync=sync)
         if not ctx.x_needs_grad:

@@ -145,6 +145,9 @@ int fsc_conv_l16_supported(const fsc_conv_desc* d, int dgrad);
 size_t fsc_conv_l16_packed_floats(const fsc_conv_desc* d, int dgrad);
 int fsc_conv_l16_pack_weights(const fsc_conv_desc* d, const float* weight, int dgrad, float* packed,
                               fsc_stream_t stream);
+/* both directions of one weight in one call (either pointer may be NULL): shares the max |w| pass and the launch */
+int fsc_conv_l16_pack_weights_pair(const fsc_conv_desc* d, const float* weight, float* packed_fwd,
+                                   float* packed_dgrad, fsc_stream_t stream);
 /* out (fp32 NCHW) = conv(in) + bias, or += with accumulate; dgrad as in fsc_conv_fwd */
 int fsc_conv_l16_fwd(const fsc_conv_desc* d, const void* in_l16, const float* in_amax, const float* packed,
                      const float* bias, int dgrad, int accumulate, float* out, fsc_stream_t stream);
