@@ -146,6 +146,30 @@ unsigned grid_for(long count) {
     return (unsigned)(b < 1 ? 1 : b);
 }
 
+// Border sums of (N, C, H, W) planes, per channel: out[c][8] += [first row, last row, first column, last column, and the four
+// corners (0,0), (0,W-1), (H-1,0), (H-1,W-1)] summed over the images (out pre-zeroed).  With them the sums of a gradient over
+// the pixels a convolution tap can reach follow from its total: what ConvBlockFn needs to obtain the first block's
+// input-BN parameter gradients without running the stem input-gradient convolution (functional._stem_bn_grads).
+__global__ __launch_bounds__(256) void border_sums_kernel(const float* __restrict__ x, int c, int h, int w, float* __restrict__ out) {
+    __shared__ float red[4][4];
+    const int ch = blockIdx.x, img = blockIdx.y;
+    const float* p = x + ((long)img * c + ch) * h * w;
+    float r0 = 0.f, rl = 0.f, c0 = 0.f, cl = 0.f;
+    for (int i = threadIdx.x; i < w; i += 256) { r0 += p[i]; rl += p[(long)(h - 1) * w + i]; }
+    for (int i = threadIdx.x; i < h; i += 256) { c0 += p[(long)i * w]; cl += p[(long)i * w + w - 1]; }
+    r0 = fsc::wave_sum(r0); rl = fsc::wave_sum(rl); c0 = fsc::wave_sum(c0); cl = fsc::wave_sum(cl);
+    if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6][0] = r0; red[threadIdx.x >> 6][1] = rl; red[threadIdx.x >> 6][2] = c0; red[threadIdx.x >> 6][3] = cl; }
+    __syncthreads();
+    if (threadIdx.x < 4) {
+        const float v = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+        unsafeAtomicAdd(out + ch * 8 + threadIdx.x, v);
+    } else if (threadIdx.x < 8) {
+        const int k = threadIdx.x - 4;
+        const float v = p[(long)((k >> 1) ? h - 1 : 0) * w + ((k & 1) ? w - 1 : 0)];
+        unsafeAtomicAdd(out + ch * 8 + threadIdx.x, v);
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -216,6 +240,13 @@ int fsc_mixup_rows(const float* a, const float* b, const int* partner, const int
                            labels_out, n, c);
     }
     FSC_LAUNCH_CHECK("fsc_mixup_rows");
+    return 0;
+}
+
+int fsc_plane_border_sums(const float* x, int n, int c, int h, int w, float* out, fsc_stream_t stream) {
+    FSC_CHECK_ARG(x && out && n > 0 && c > 0 && h > 0 && w > 0, "fsc_plane_border_sums: bad arguments");
+    hipLaunchKernelGGL(border_sums_kernel, dim3(c, n), dim3(256), 0, fsc::as_stream(stream), x, c, h, w, out);
+    FSC_LAUNCH_CHECK("fsc_plane_border_sums");
     return 0;
 }
 

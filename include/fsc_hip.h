@@ -357,6 +357,10 @@ int fsc_sgd_nesterov_step(const fsc_opt_tensor* tensors_host, int n_tensors, flo
                           float grad_scale, fsc_stream_t stream);
 
 /* ------------------------------------------------------------------ misc device helpers */
+/* out[c][8] (pre-zeroed) += per channel, over all images of x (N, C, H, W): sums of the first row, last row, first column,
+ * last column and the four corner elements.  Used to obtain the first block's input-BN parameter gradients from the stem
+ * convolution's weight gradient instead of its input gradient (classifiers.py:524-531). */
+int fsc_plane_border_sums(const float* x, int n, int c, int h, int w, float* out, fsc_stream_t stream);
 int fsc_fill(float* x, float value, long count, fsc_stream_t stream);
 /* y = a*x + y  (used for gradient accumulation / bucket flattening) */
 int fsc_axpy(const float* x, float a, float* y, long count, fsc_stream_t stream);

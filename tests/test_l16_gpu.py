@@ -221,3 +221,46 @@ def test_block_with_and_without_l16_agree():
     assert (l0 - l1).abs().max().item() <= 1e-4
     for k in g0:
         assert (g0[k] - g1[k]).abs().max().item() <= 1e-4 * max(1.0, g0[k].abs().max().item()), k
+
+
+def test_first_block_bn_grads_from_weight_gradient():
+    """functional._stem_bn_grads: the input-BN parameter gradients of the first block from the stem convolution's weight
+    gradient and border sums equal those of the explicit route (stem input gradient + BN backward)."""
+    from freesound_classification_amd.networks.classifiers import TwoDimensionalCNNClassificationModel
+
+    class NS(dict):
+        __getattr__ = dict.__getitem__
+
+    exp = NS(config=NS(
+        network=NS(num_conv_blocks=2, start_deep_supervision_on=0, conv_base_depth=24, growth_rate=1.5,
+                   output_dropout=0.0, aggregation_type="max"),
+        data=NS(features="mel_1024_512_64", _input_dim=64, _n_classes=80),
+        train=NS(accumulation_steps=1, optimizer="adam", learning_rate=1e-3, weight_decay=0.0,
+                 scheduler="1cycle_0.0001_0.005")))
+    torch.manual_seed(3)
+    model = TwoDimensionalCNNClassificationModel(exp, device="cuda:0")
+    with torch.no_grad():                     # a BN in front of the stem with non-trivial parameters
+        model.conv_modules[0][0].weight.uniform_(0.5, 1.5)
+        model.conv_modules[0][0].bias.uniform_(-0.5, 0.5)
+    model.train()
+    signal = 0.1 * torch.randn(8, 33333, 1, device=DEV)          # odd frame count: the un-pooled tensor has a trailing column
+    labels = torch.zeros(8, 80, device=DEV)
+    labels[torch.arange(8), torch.randint(0, 80, (8,))] = 1.0
+    grads = []
+    for flag in (False, True):
+        F.STEM_BN_IDENTITY = flag
+        try:
+            for prm in model.parameters():
+                prm.grad = None
+            model.make_optimizer(max_steps=10)
+            model.training_step(signal, labels, step_optimizer=False)
+            grads.append({k: v.grad.detach().clone() for k, v in model.named_parameters() if v.grad is not None})
+        finally:
+            F.STEM_BN_IDENTITY = True
+    g0, g1 = grads
+    for name in ("conv_modules.0.0.weight", "conv_modules.0.0.bias"):
+        scale = max(1e-3, g0[name].abs().max().item())
+        assert (g0[name] - g1[name]).abs().max().item() <= 2e-4 * scale, (name, g0[name], g1[name])
+    for name in g0:                            # everything else is untouched (up to the order of the channel-sum atomics)
+        if not name.startswith("conv_modules.0.0."):
+            assert (g0[name] - g1[name]).abs().max().item() <= 1e-5 * max(1e-3, g0[name].abs().max().item()), name
