@@ -34,13 +34,16 @@ typedef __attribute__((address_space(1))) const void* glb_ptr;
 
 constexpr int kWaves = 8;
 constexpr int kMaxXI = 4;          // input DMA instructions per (octet, limb) plane: plane <= 256 positions
+// Unit pitches (positions) are padded to == 2 (mod 8) where the LDS allows: an octet (two units) is then 64 bytes (mod 256) from
+// the next, and the transpose read's lanes of octet A and octet B hit disjoint bank halves (unpadded: a 2-way conflict on every read).
 
 struct WGeom {
     int n, cin, cout, h, w;
     long hw;
     int oct_in, oct_out;            // octets of the two L16 tensors
     int th, tw, tiles_h, tiles_w;   // 64-pixel box and boxes per image
-    int rows, cols, plane;          // staged input window incl. halo; plane = rows * cols
+    int rows, cols, plane, npos;    // staged input window incl. halo: npos = rows * cols positions, plane = unit pitch (npos padded)
+    int du;                         // dOut unit pitch: 66 (padded) or 64
     int xi;                         // ceil(plane / 64)
     int units, nsplit;
     int ng, nt;                     // co groups x ci groups of a workgroup (ng * nt == 8)
@@ -99,7 +102,7 @@ __global__ __launch_bounds__(kWaves * 64) void conv_l16_wgrad_kernel(WGeom g, co
 
     extern __shared__ __attribute__((aligned(16))) uint4 smem4[];
     const int co_oct = g.ng * g.tpg * 2, ci_oct = g.nt * CT * 2;             // octets staged per operand
-    const int stage_u4 = co_oct * 2 * 64 + ci_oct * 2 * g.plane;             // uint4 per stage: dOut units, then input units
+    const int stage_u4 = co_oct * 2 * g.du + ci_oct * 2 * g.plane;             // uint4 per stage: dOut units, then input units
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -138,9 +141,9 @@ __global__ __launch_bounds__(kWaves * 64) void conv_l16_wgrad_kernel(WGeom g, co
     const int co_oct_live = min(co_oct, g.oct_out - tile0 * 2), ci_oct_live = min(ci_oct, g.oct_in - cit0 * 2);
     for (int st = 0; st < 2; ++st) {
         uint4* dl = smem4 + st * stage_u4;
-        uint4* il = dl + co_oct * 2 * 64;
+        uint4* il = dl + co_oct * 2 * g.du;
         const uint4 z = make_uint4(0u, 0u, 0u, 0u);
-        for (int i = (co_oct_live > 0 ? co_oct_live : 0) * 2 * 64 + tid; i < co_oct * 2 * 64; i += kWaves * 64) dl[i] = z;
+        for (int i = (co_oct_live > 0 ? co_oct_live : 0) * 2 * g.du + tid; i < co_oct * 2 * g.du; i += kWaves * 64) dl[i] = z;
         for (int i = (ci_oct_live > 0 ? ci_oct_live : 0) * 2 * g.plane + tid; i < ci_oct * 2 * g.plane; i += kWaves * 64) il[i] = z;
     }
 
@@ -153,13 +156,13 @@ __global__ __launch_bounds__(kWaves * 64) void conv_l16_wgrad_kernel(WGeom g, co
         const int o = lane + 64 * j;
         qr[j] = o / g.cols;
         qc[j] = o - qr[j] * g.cols;
-        if (o >= g.plane) qr[j] = -1;
+        if (o >= g.npos) qr[j] = -1;
     }
     const uint4* const zero = reinterpret_cast<const uint4*>(g_zero16_w);
     const long do_img = (long)g.oct_out * 2 * g.hw, in_img = (long)g.oct_in * 2 * g.hw;
     auto issue_unit = [&](int u, int stage) {
         uint4* dl = smem4 + stage * stage_u4;
-        uint4* il = dl + co_oct * 2 * 64;
+        uint4* il = dl + co_oct * 2 * g.du;
         int t = u;
         const int twi = t % g.tiles_w; t /= g.tiles_w;
         const int thi = t % g.tiles_h; t /= g.tiles_h;
@@ -169,7 +172,7 @@ __global__ __launch_bounds__(kWaves * 64) void conv_l16_wgrad_kernel(WGeom g, co
             const uint4* src = dout + (long)n0 * do_img + (long)(tile0 * 2) * 2 * g.hw + (long)(h0 + pr) * g.w + (w0 + pc);
 #pragma unroll 1
             for (int un = wid; un < co_oct_live * 2; un += kWaves)            // unit = (octet, limb)
-                glds16(live ? src + (long)un * g.hw : zero, dl + un * 64);
+                glds16(live ? src + (long)un * g.hw : zero, dl + un * g.du);
         }
 #pragma unroll
         for (int j = 0; j < kMaxXI; ++j) {
@@ -193,7 +196,7 @@ __global__ __launch_bounds__(kWaves * 64) void conv_l16_wgrad_kernel(WGeom g, co
     // ---- this lane's transpose-read pieces.  A (dOut) of tile i, limb l, k-step st:
     //      ((2 (g_start + i) + (c4 >> 1)) * 2 + l) * 64 positions + run * 8 + lj, + (c4 & 1) * 8 bytes;  run = 4 st + kq
     const int runs_shift = g.tw == 8 ? 0 : g.tw == 16 ? 1 : g.tw == 32 ? 2 : 3;      // log2(runs per box row)
-    const int a_lane = (((2 * g_start + (c4 >> 1)) * 2) * 64 + kq * 8 + lj) * 16 + (c4 & 1) * 8;
+    const int a_lane = (((2 * g_start + (c4 >> 1)) * 2) * g.du + kq * 8 + lj) * 16 + (c4 & 1) * 8;
     //      B (input) of slot (ci tile ct, tap), limb l: ((2 (cig * CT + ct) + (c4 >> 1)) * 2 + l) * plane + (r + ty) * cols + c0 + tx + lj
     int b_lane[2];
 #pragma unroll
@@ -216,7 +219,7 @@ __global__ __launch_bounds__(kWaves * 64) void conv_l16_wgrad_kernel(WGeom g, co
             __syncthreads();                  // unit u has landed (vmcnt drained); everyone is done with the other stage
             if (u + g.nsplit < g.units) issue_unit(u + g.nsplit, stage ^ 1);
             const char* dl = reinterpret_cast<const char*>(smem4 + stage * stage_u4);
-            const char* il = dl + (size_t)co_oct * 2 * 64 * 16;
+            const char* il = dl + (size_t)co_oct * 2 * g.du * 16;
             if constexpr (LIVE > 0) {
 #pragma unroll 1
                 for (int st = 0; st < 2; ++st) {
@@ -226,7 +229,7 @@ __global__ __launch_bounds__(kWaves * 64) void conv_l16_wgrad_kernel(WGeom g, co
 #pragma unroll
                     for (int i = 0; i < LIVE; ++i)
 #pragma unroll
-                        for (int l = 0; l < 2; ++l) af[i][l] = tr_read8(ap + (i * 4 + l) * 64 * 16);
+                        for (int l = 0; l < 2; ++l) af[i][l] = tr_read8(ap + (i * 4 + l) * g.du * 16);
                     u32x4 bf[2][2];                                            // [buffer][limb]
                     auto read_slot = [&](int s, u32x4 (&dst)[2]) {
                         const int ct = s / TAPS, tap = s - ct * TAPS;
@@ -326,7 +329,7 @@ bool plan_l16_wgrad(const fsc_conv_desc& d, WPlan* out) {
     for (int tw = 64; tw >= 8; tw >>= 1) {
         const int th = 64 / tw;
         if (th > 1 && h == 1) continue;
-        if ((th + d.kh - 1) * (tw + d.kw - 1) > 64 * kMaxXI) continue;
+        if ((th + d.kh - 1) * (tw + d.kw - 1) > 64 * kMaxXI - 8) continue;
         const long px = (long)fsc::ceil_div(h, th) * fsc::ceil_div(w, tw) * 64;
         // wider boxes fetch less halo: prefer them unless they waste more than ~6 % of the pixels
         if (best_px < 0 || px * 100 < best_px * 94) { best_px = px; g.th = th; g.tw = tw; }
@@ -335,45 +338,51 @@ bool plan_l16_wgrad(const fsc_conv_desc& d, WPlan* out) {
     g.tiles_h = fsc::ceil_div(h, g.th); g.tiles_w = fsc::ceil_div(w, g.tw);
     g.units = d.n * g.tiles_h * g.tiles_w;
     g.rows = g.th + d.kh - 1; g.cols = g.tw + d.kw - 1;
-    g.plane = g.rows * g.cols;
-    g.xi = fsc::ceil_div(g.plane, 64);
+    g.npos = g.rows * g.cols;
+    g.xi = fsc::ceil_div(g.npos, 64);
     const int ct = taps == 1 ? 4 : 1;
     p.ct = ct;
     const int tiles_co = fsc::ceil_div(d.c_out, 16), tiles_ci = fsc::ceil_div(d.c_in, 16);
     double best_eff = -1.0;
-    for (int nt = 1; nt <= 8; nt *= 2) {
-        const int ng = kWaves / nt;
-        const int ci_blocks = fsc::ceil_div(tiles_ci, nt * ct);
-        const int co_blocks = fsc::ceil_div(tiles_co, ng * 4);
-        const int tpb = fsc::ceil_div(tiles_co, co_blocks);
-        const int tpg = fsc::ceil_div(tpb, ng);
-        const size_t lds = 2 * 16 * ((size_t)ng * tpg * 2 * 2 * 64 + (size_t)nt * ct * 2 * 2 * g.plane);
-        if (lds > 160 * 1024) continue;
-        static const double kTileWeight[5] = {0.0, 0.6, 0.8, 0.93, 1.0};
-        long busiest = 0;
-        for (int cb = 0; cb < co_blocks; ++cb)
-            for (int ib = 0; ib < ci_blocks; ++ib) {
-                int worst = 0;
-                for (int sd = 0; sd < 4; ++sd) {
-                    int load = 0;
-                    for (int wv = sd; wv < kWaves; wv += 4) {
-                        const int cog = wv / nt, cig = wv % nt;
-                        const int blk_live = cb * tpb + tpb < tiles_co ? tpb : tiles_co - cb * tpb;
-                        int first, live;
-                        w_group(blk_live > 0 ? blk_live : 0, ng, cog, &first, &live);
-                        int ci_live = tiles_ci - (ib * nt + cig) * ct;
-                        ci_live = ci_live < 0 ? 0 : ci_live > ct ? ct : ci_live;
-                        load += live * (ci_live > 0 ? ct : 0);           // (dead ci tiles of a live group still run)
+    for (int pad = 1; pad >= 0 && best_eff < 0.4; --pad) {       // bank-conflict padding first; without it when nothing fits
+        int plane = g.npos;
+        if (pad) while (plane % 8 != 2) ++plane;
+        const int du = pad ? 66 : 64;
+        for (int nt = 1; nt <= 8; nt *= 2) {
+            const int ng = kWaves / nt;
+            const int ci_blocks = fsc::ceil_div(tiles_ci, nt * ct);
+            const int co_blocks = fsc::ceil_div(tiles_co, ng * 4);
+            const int tpb = fsc::ceil_div(tiles_co, co_blocks);
+            const int tpg = fsc::ceil_div(tpb, ng);
+            const size_t lds = 2 * 16 * ((size_t)ng * tpg * 2 * 2 * du + (size_t)nt * ct * 2 * 2 * plane);
+            if (lds > 160 * 1024) continue;
+            static const double kTileWeight[5] = {0.0, 0.6, 0.8, 0.93, 1.0};
+            long busiest = 0;
+            for (int cb = 0; cb < co_blocks; ++cb)
+                for (int ib = 0; ib < ci_blocks; ++ib) {
+                    int worst = 0;
+                    for (int sd = 0; sd < 4; ++sd) {
+                        int load = 0;
+                        for (int wv = sd; wv < kWaves; wv += 4) {
+                            const int cog = wv / nt, cig = wv % nt;
+                            const int blk_live = cb * tpb + tpb < tiles_co ? tpb : tiles_co - cb * tpb;
+                            int first, live;
+                            w_group(blk_live > 0 ? blk_live : 0, ng, cog, &first, &live);
+                            int ci_live = tiles_ci - (ib * nt + cig) * ct;
+                            ci_live = ci_live < 0 ? 0 : ci_live > ct ? ct : ci_live;
+                            load += live * (ci_live > 0 ? ct : 0);           // (dead ci tiles of a live group still run)
+                        }
+                        if (load > worst) worst = load;
                     }
-                    if (load > worst) worst = load;
+                    busiest += worst;
                 }
-                busiest += worst;
+            const double eff = (double)tiles_co * tiles_ci / (4.0 * (double)busiest) * kTileWeight[tpg];
+            if (eff > best_eff) {
+                best_eff = eff;
+                g.ng = ng; g.nt = nt; g.tpb = tpb; g.tpg = tpg; g.co_blocks = co_blocks; g.ci_blocks = ci_blocks;
+                g.plane = plane; g.du = du;
+                p.lds_bytes = lds;
             }
-        const double eff = (double)tiles_co * tiles_ci / (4.0 * (double)busiest) * kTileWeight[tpg];
-        if (eff > best_eff) {
-            best_eff = eff;
-            g.ng = ng; g.nt = nt; g.tpb = tpb; g.tpg = tpg; g.co_blocks = co_blocks; g.ci_blocks = ci_blocks;
-            p.lds_bytes = lds;
         }
     }
     if (best_eff < 0.4) return false;

@@ -1,0 +1,149 @@
+// Weight gradient of the stem convolution (3x3, c_in <= 2; reference networks/classifiers.py:526-532) taken directly from
+// the gradient at the POOLED resolution and the max-pool's arg-max indices:
+//
+//     dW[co][ci][ty][tx] = sum over windows (n, oy, ox)  d[n][co][oy][ox] * a[n][ci][2 oy + ry + ty - 1][2 ox + rx + tx - 1]
+//
+// where (ry, rx) is the window's arg-max position.  The un-pooled gradient dc (2.8 GB at cfg 2) has exactly one non-zero
+// per 2x2 window; materialising it cost a 0.98 ms un-pool pass and a 0.95 ms dense weight-gradient pass.  Here each lane
+// owns pooled columns, gathers its 18 inputs from an LDS tile of the (tiny) conv input and accumulates the 18 sums of one
+// output channel; a wave walks its channels one after the other.  The same pass yields the eight border sums of dc that
+// functional._stem_bn_grads needs (first / last row, first / last column, corners).
+// Output: per (block, channel) 32 floats [18 weight-gradient sums | 8 border sums | pad], summed over blocks by the caller.
+#include "common.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kTileRows = 8;            // pooled rows per block
+
+template <int CIN>
+__global__ __launch_bounds__(kThreads) void stem_wgrad_pooled_kernel(const float* __restrict__ a, const float* __restrict__ dp,
+                                                                      const uint8_t* __restrict__ idx, float* __restrict__ part,
+                                                                      int cout, int h, int w, int oh, int ow, int wp) {
+    extern __shared__ __attribute__((aligned(16))) float atile[];      // [CIN][2 * kTileRows + 2][wp]
+    constexpr int TROWS = 2 * kTileRows + 2;
+    const int n = blockIdx.y, r0 = blockIdx.x * kTileRows;            // first pooled row of the tile
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    // ---- the conv input rows 2 r0 - 1 .. 2 r0 + 2 kTileRows, columns -1 .. w (zero outside the image)
+    for (int i = threadIdx.x; i < CIN * TROWS * wp; i += kThreads) {
+        const int ci = i / (TROWS * wp), rem = i - ci * (TROWS * wp);
+        const int tr = rem / wp, tc = rem - tr * wp;
+        const int y = 2 * r0 - 1 + tr, x = tc - 1;
+        atile[i] = (y >= 0 && y < h && x >= 0 && x < w) ? a[((long)(n * CIN + ci) * h + y) * w + x] : 0.f;
+    }
+    __syncthreads();
+    const int rows = min(kTileRows, oh - r0);
+    for (int co = wv; co < cout; co += kThreads / 64) {
+        float acc[CIN * 9], bs[8];
+#pragma unroll
+        for (int k = 0; k < CIN * 9; ++k) acc[k] = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) bs[k] = 0.f;
+        const long plane = ((long)n * cout + co) * oh;
+        // a pooled row = up to kChunks x 64 columns: all of a row's loads are issued before its arithmetic, and the next
+        // row's loads before this row's (the loop is latency-bound otherwise: two dependent 4-byte loads per 18 FMAs)
+        constexpr int kChunks = 4;
+        float dv[2][kChunks];
+        int pv[2][kChunks];
+        auto load_row = [&](int pr, int buf) {
+            const long rowbase = (plane + r0 + pr) * ow;
+#pragma unroll
+            for (int cch = 0; cch < kChunks; ++cch) {
+                const int ox = cch * 64 + lane;
+                const bool live = pr < rows && ox < ow;
+                dv[buf][cch] = live ? dp[rowbase + ox] : 0.f;
+                pv[buf][cch] = live ? (int)idx[rowbase + ox] : 0;
+            }
+        };
+        auto row_math = [&](int pr, int buf, int cch0) {
+#pragma unroll
+            for (int cch = 0; cch < kChunks; ++cch) {
+                const int ox = (cch0 + cch) * 64 + lane;
+                const float d = dv[buf][cch];                               // (0 for dead lanes: contributes nothing)
+                const int pos = pv[buf][cch];
+                const int ry = pos >> 1, rx = pos & 1;
+                const int y = 2 * pr + ry, x = ox < ow ? 2 * ox + rx : 0;   // tile row of tap ty = 0 / column of tap tx = 0
+                const float* t = atile + y * wp + x;
+#pragma unroll
+                for (int ci = 0; ci < CIN; ++ci)
+#pragma unroll
+                    for (int ty = 0; ty < 3; ++ty)
+#pragma unroll
+                        for (int tx = 0; tx < 3; ++tx)
+                            acc[(ci * 3 + ty) * 3 + tx] = fmaf(d, t[(ci * TROWS + ty) * wp + tx], acc[(ci * 3 + ty) * 3 + tx]);
+                const int gy = 2 * (r0 + pr) + ry;                           // position of the non-zero in the un-pooled gradient
+                const bool top = gy == 0, bot = gy == h - 1, lef = x == 0, rig = x == w - 1;
+                bs[0] += top ? d : 0.f; bs[1] += bot ? d : 0.f; bs[2] += lef ? d : 0.f; bs[3] += rig ? d : 0.f;
+                bs[4] += (top && lef) ? d : 0.f; bs[5] += (top && rig) ? d : 0.f;
+                bs[6] += (bot && lef) ? d : 0.f; bs[7] += (bot && rig) ? d : 0.f;
+            }
+        };
+        if (ow <= kChunks * 64) {
+            load_row(0, 0);
+#pragma unroll 1
+            for (int pr = 0; pr < rows; pr += 2) {
+                load_row(pr + 1, 1);
+                row_math(pr, 0, 0);
+                load_row(pr + 2, 0);
+                if (pr + 1 < rows) row_math(pr + 1, 1, 0);
+            }
+        } else {                                                        // wide images: chunk groups one after the other
+            for (int pr = 0; pr < rows; ++pr)
+                for (int c0 = 0; c0 * 64 < ow; c0 += kChunks) {
+                    const long rowbase = (plane + r0 + pr) * ow;
+#pragma unroll
+                    for (int cch = 0; cch < kChunks; ++cch) {
+                        const int ox = (c0 + cch) * 64 + lane;
+                        dv[0][cch] = ox < ow ? dp[rowbase + ox] : 0.f;
+                        pv[0][cch] = ox < ow ? (int)idx[rowbase + ox] : 0;
+                    }
+                    row_math(pr, 0, c0);
+                }
+        }
+        float* o = part + (((long)blockIdx.y * gridDim.x + blockIdx.x) * cout + co) * 32;
+#pragma unroll
+        for (int k = 0; k < CIN * 9; ++k) {
+            const float v = fsc::wave_sum(acc[k]);
+            if (lane == 0) o[k] = v;
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const float v = fsc::wave_sum(bs[k]);
+            if (lane == 0) o[18 + k] = v;
+        }
+        if (lane < 32 && (lane >= 26 || (lane >= CIN * 9 && lane < 18))) o[lane] = 0.f;
+    }
+}
+
+bool supported(const fsc_conv_desc* d) {
+    return d && d->kh == 3 && d->kw == 3 && d->c_in >= 1 && d->c_in <= 2 && d->h >= 2 && d->w >= 8 && d->n > 0 && d->c_out > 0 &&
+           (size_t)d->c_in * (2 * kTileRows + 2) * (d->w + 2 + 3) * sizeof(float) <= 64 * 1024;
+}
+
+}  // namespace
+
+extern "C" {
+
+/* blocks (= rows of the partial buffer) of fsc_conv_stem_wgrad_pooled for this shape; 0 = unsupported */
+size_t fsc_conv_stem_wgrad_pooled_blocks(const fsc_conv_desc* d) {
+    if (!supported(d)) return 0;
+    return (size_t)fsc::ceil_div(d->h / 2, kTileRows) * d->n;
+}
+
+int fsc_conv_stem_wgrad_pooled(const fsc_conv_desc* d, const float* in, const float* dpooled, const uint8_t* pool_idx,
+                               float* partial, fsc_stream_t stream) {
+    FSC_CHECK_ARG(supported(d) && in && dpooled && pool_idx && partial, "fsc_conv_stem_wgrad_pooled: unsupported shape or null pointer");
+    const int oh = d->h / 2, ow = d->w / 2;
+    const int wp = (d->w + 2 + 3) & ~3;
+    dim3 grid(fsc::ceil_div(oh, kTileRows), d->n);
+    const size_t lds = sizeof(float) * (size_t)d->c_in * (2 * kTileRows + 2) * wp;
+    hipStream_t st = fsc::as_stream(stream);
+    if (d->c_in == 1)
+        hipLaunchKernelGGL(stem_wgrad_pooled_kernel<1>, grid, dim3(kThreads), lds, st, in, dpooled, pool_idx, partial, d->c_out, d->h, d->w, oh, ow, wp);
+    else
+        hipLaunchKernelGGL(stem_wgrad_pooled_kernel<2>, grid, dim3(kThreads), lds, st, in, dpooled, pool_idx, partial, d->c_out, d->h, d->w, oh, ow, wp);
+    FSC_LAUNCH_CHECK("fsc_conv_stem_wgrad_pooled");
+    return 0;
+}
+
+}  // extern "C"

@@ -852,6 +852,28 @@ def _block_params(mods):
             res.conv3.weight, res.conv3.bias, res.bn3.weight, res.bn3.bias, res.prelu3.weight]
 
 
+def stem_wgrad_pooled(a, dp, pidx, weight_shape):
+    """Stem weight gradient straight from the pooled-resolution gradient and the pool indices (fsc_conv_stem_wgrad_pooled):
+    (dW (c_out, c_in, 3, 3), border sums of the never-materialised un-pooled gradient (c_out, 8)), or None when the shape
+    is not a stem layer."""
+    n, c_in, h, w = a.shape
+    c_out = weight_shape[0]
+    d = _desc(n, c_in, c_out, h, w, 3, 3)
+    blocks = _lib.load().fsc_conv_stem_wgrad_pooled_blocks(C.byref(d))
+    if blocks == 0 or tuple(weight_shape[2:]) != (3, 3):
+        return None
+    part = torch.empty(blocks, c_out, 32, device=a.device, dtype=torch.float32)
+    if TIMER is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    call("fsc_conv_stem_wgrad_pooled", C.byref(d), ptr(a), ptr(dp), ptr(pidx), ptr(part), stream_ptr())
+    if TIMER is not None:
+        e1.record()
+        TIMER.records.append(("conv_stem_wgrad_pooled_kernel<%d>" % c_in, 2.0 * n * h * w * c_in * c_out * 9, e0, e1))
+    tot = part.sum(0)
+    return tot[:, :c_in * 9].reshape(c_out, c_in, 3, 3).contiguous(), tot[:, 18:26].contiguous()
+
+
 STEM_BN_IDENTITY = True
 
 
@@ -859,7 +881,7 @@ def h_w_min(t):
     return min(t.shape[2], t.shape[3])
 
 
-def _stem_bn_grads(dc, dc_chan_sum, weight, dweight, bn):
+def _stem_bn_grads(dc, dc_chan_sum, weight, dweight, bn, borders=None):
     """Parameter gradients (dgamma, dbeta) of the BatchNorm in FRONT of a 3x3 convolution, without the convolution's input
     gradient da -- for the first block, whose input (the log-mel image) needs no gradient, so da would only be summed:
         sum_p da[ci][p] a[ci][p] = sum_{co,tap} w[co][ci][tap] dW[co][ci][tap]            (a = the conv input = gamma xhat + beta)
@@ -868,14 +890,17 @@ def _stem_bn_grads(dc, dc_chan_sum, weight, dweight, bn):
     T follows from the channel totals of dc and its border sums (fsc_plane_border_sums).  dbeta = sum da,
     dgamma = sum da xhat = (sum da a - beta sum da) / gamma.  Saves the stem input-gradient kernel (1.36 ms at cfg 2) and the
     BN backward passes over the image; exact in exact arithmetic (same zero padding as the weight gradient)."""
-    n, c, h, w = dc.shape
-    b = torch.zeros(c, 8, device=dc.device, dtype=torch.float32)
-    call("fsc_plane_border_sums", ptr(dc), n, c, h, w, ptr(b), stream_ptr())
+    if borders is None:
+        n, c, h, w = dc.shape
+        b = torch.zeros(c, 8, device=dc.device, dtype=torch.float32)
+        call("fsc_plane_border_sums", ptr(dc), n, c, h, w, ptr(b), stream_ptr())
+    else:
+        b, c = borders, borders.shape[0]           # (the un-pooled gradient itself was never materialised)
     s = dc_chan_sum
     row = [b[:, 0], None, b[:, 1]]           # rows excluded by ty = 0 (first row), 1 (none), 2 (last row)
     col = [b[:, 2], None, b[:, 3]]
     corner = {(0, 0): b[:, 4], (0, 2): b[:, 5], (2, 0): b[:, 6], (2, 2): b[:, 7]}
-    t = torch.empty(c, 3, 3, device=dc.device, dtype=torch.float32)
+    t = torch.empty(c, 3, 3, device=b.device, dtype=torch.float32)
     for ty in range(3):
         for tx in range(3):
             v = s
@@ -968,23 +993,38 @@ class ConvBlockFn(torch.autograd.Function):
         del dr1, dr1_m
         # ---- b = prelu(bn_b(p))
         a_shape = tuple(k.c_shape[:1]) + (wa.shape[1],) + tuple(k.c_shape[2:])
-        w16, w32 = _grad_formats(a_shape, wa) if len(k.c_shape) == 4 else (False, True)
-        dc, dgb, dbtb, dalb, dbias_a, dc_m = bn_act_backward_unpool(db.contiguous(), k.p, k.st_b, bn_b, prelu_b.weight,
-                                                                    k.pidx, k.c_shape, ph, sync=sync, l16=w16, want_f32=w32)
-        del db
-        dwa = _conv_wgrad_any(k.a, a_16, a_max, dc, _l16_of(dc_m), _amax_of(dc_m), wa)
-        if (STEM_BN_IDENTITY and not ctx.x_needs_grad and dc is not None and dc.dim() == 4 and tuple(wa.shape[2:]) == (3, 3)
-                and bn_a.weight is not None and h_w_min(dc) >= 2):
-            # the block input needs no gradient: bn_a's parameter gradients from the weight gradient (no dgrad, no BN backward)
-            dga, dbta = _stem_bn_grads(dc, dbias_a, wa, dwa, bn_a)
+        stem = None
+        if (STEM_BN_IDENTITY and not ctx.x_needs_grad and ph == 2 and k.a is not None and k.a.dim() == 4 and bn_a.weight is not None
+                and _lib.load().fsc_conv_stem_wgrad_pooled_blocks(C.byref(_desc(a_shape[0], a_shape[1], wa.shape[0], a_shape[2], a_shape[3], 3, 3)))):
+            # First block (its input needs no gradient): BN-b backward at the POOLED resolution, the stem weight gradient
+            # straight from that and the pool indices, and bn_a's parameter gradients from the weight gradient --
+            # the un-pooled gradient (2.8 GB at cfg 2), the stem input gradient and bn_a's backward passes never run.
+            dp, _, dgb, dbtb, dalb, dbias_a = bn_act_backward(db.contiguous(), k.p, k.st_b, bn_b, prelu_b.weight,
+                                                              want_chan_sum=True, sync=sync)
+            del db
+            stem = stem_wgrad_pooled(k.a, dp, k.pidx, wa.shape)
+            dwa, borders = stem
+            dga, dbta = _stem_bn_grads(None, dbias_a, wa, dwa, bn_a, borders=borders)
             dx = None
-            del dc, dc_m
-        else:
-            da = _conv_dgrad_any(dc, _l16_of(dc_m), wa, a_shape, _amax_of(dc_m), prepacked=pk_a)
-            del dc, dc_m
-            dx, _, dga, dbta, _, _ = bn_act_backward(da, k.x, k.st_a, bn_a, sync=sync)
-            if not ctx.x_needs_grad:
+            del dp
+        if stem is None:
+            w16, w32 = _grad_formats(a_shape, wa) if len(k.c_shape) == 4 else (False, True)
+            dc, dgb, dbtb, dalb, dbias_a, dc_m = bn_act_backward_unpool(db.contiguous(), k.p, k.st_b, bn_b, prelu_b.weight,
+                                                                        k.pidx, k.c_shape, ph, sync=sync, l16=w16, want_f32=w32)
+            del db
+            dwa = _conv_wgrad_any(k.a, a_16, a_max, dc, _l16_of(dc_m), _amax_of(dc_m), wa)
+            if (STEM_BN_IDENTITY and not ctx.x_needs_grad and dc is not None and dc.dim() == 4 and tuple(wa.shape[2:]) == (3, 3)
+                    and bn_a.weight is not None and h_w_min(dc) >= 2):
+                # the block input needs no gradient: bn_a's parameter gradients from the weight gradient (no dgrad, no BN backward)
+                dga, dbta = _stem_bn_grads(dc, dbias_a, wa, dwa, bn_a)
                 dx = None
+                del dc, dc_m
+            else:
+                da = _conv_dgrad_any(dc, _l16_of(dc_m), wa, a_shape, _amax_of(dc_m), prepacked=pk_a)
+                del dc, dc_m
+                dx, _, dga, dbta, _, _ = bn_act_backward(da, k.x, k.st_a, bn_a, sync=sync)
+                if not ctx.x_needs_grad:
+                    dx = None
 
         def like(param, g):
             return g.reshape(param.shape) if g is not None else None

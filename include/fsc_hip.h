@@ -100,6 +100,14 @@ int fsc_amax(const float* x, long n, float* out, fsc_stream_t stream);
 int fsc_conv_pool_supported(const fsc_conv_desc* d);
 int fsc_conv_pool_fwd(const fsc_conv_desc* d, const float* in, const float* packed, const float* bias,
                       float* pooled, uint8_t* idx, fsc_stream_t stream);
+/* Weight gradient of the stem layer (3x3, c_in <= 2) straight from the gradient at the POOLED resolution `dpooled`
+ * (N, c_out, H/2, W/2) and the window indices of fsc_conv_pool_fwd / fsc_maxpool_fwd -- the un-pooled gradient (one non-zero
+ * per 2x2 window) is never materialised.  partial: fsc_conv_stem_wgrad_pooled_blocks(d) x c_out x 32 floats; per channel
+ * [c_in * 9 weight-gradient sums (ci, ty, tx) | at 18: 8 border sums of the un-pooled gradient in the order of
+ * fsc_plane_border_sums | pad]; the caller sums the blocks. */
+size_t fsc_conv_stem_wgrad_pooled_blocks(const fsc_conv_desc* d);
+int fsc_conv_stem_wgrad_pooled(const fsc_conv_desc* d, const float* in, const float* dpooled, const uint8_t* pool_idx,
+                               float* partial, fsc_stream_t stream);
 /* human-readable tiling chosen for this shape (mode 0 fwd, 1 dgrad, 2 wgrad): kernel
  * instantiation, pixel box, grid, LDS bytes.  For logs, DESIGN.md tables and profiles. */
 int fsc_conv_plan_describe(const fsc_conv_desc* d, int mode, char* buf, size_t buf_len);

@@ -263,4 +263,4 @@ def test_first_block_bn_grads_from_weight_gradient():
         assert (g0[name] - g1[name]).abs().max().item() <= 2e-4 * scale, (name, g0[name], g1[name])
     for name in g0:                            # everything else is untouched (up to the order of the channel-sum atomics)
         if not name.startswith("conv_modules.0.0."):
-            assert (g0[name] - g1[name]).abs().max().item() <= 1e-5 * max(1e-3, g0[name].abs().max().item()), name
+            assert (g0[name] - g1[name]).abs().max().item() <= 1e-5 * max(1e-1, g0[name].abs().max().item()), name
