@@ -84,7 +84,9 @@ def test_two_replicas_with_syncbn_equal_the_single_process_global_batch(tmp_path
     for k in state:                                                    # replicas stay in lock-step
         assert np.array_equal(r0["state." + k], r1["state." + k]), k
     n_bn = sum(1 for k in state if k.endswith("running_mean"))
-    assert int(r0["bn_sync_calls"]) == 2 * n_bn                        # one small all-reduce per BN layer and direction
+    # one small all-reduce per BN layer and direction -- except the backward of the first block's input BN, which does not
+    # run: its parameter gradients come from the stem weight gradient, local sums like every dgamma / dbeta
+    assert int(r0["bn_sync_calls"]) == 2 * n_bn - 1
     assert int(r0["bucket_sizes"].sum()) == sum(v.size for v in grads.values())
 
 
