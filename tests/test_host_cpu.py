@@ -208,3 +208,41 @@ def test_shuffle_audio_is_a_permutation_of_chunks():
     y = paudio.shuffle_audio(x.copy(), 0.25, sr=16000)       # 4 chunks
     assert sorted(y.tolist()) == x.tolist() and not np.array_equal(x, y)
     assert paudio.shuffle_audio(x, 2.0, sr=16000) is x       # fewer than two chunks: untouched
+
+
+def test_l16_plans_cover_the_cfg2_training_layers():
+    """The pre-split (L16) kernels have a tiling for the cfg-2 convolutions that carry the step (planning runs on the host):
+    forward, input gradient and weight gradient of every 3x3 / 1x1 layer from 100 to 506 channels; the stem (2 input
+    channels) and shapes the format cannot serve are declined, not mis-planned."""
+    import ctypes
+
+    lib = _lib.load()
+    buf = ctypes.create_string_buffer(256)
+    layers, hh, ww, cin = [], 128, 431, 2
+    for depth in [int(1.5 ** i * 100) for i in range(6)]:          # classifiers.py:524-536, 72-104 at cfg 2
+        layers.append((cin, depth, hh, ww, 3))
+        hh, ww = hh // 2, ww // 2
+        layers += [(depth, depth, hh, ww, 1), (depth, depth, hh, ww, 3)]
+        cin = depth
+    for (c_in, c_out, h, w, k) in layers:
+        d = _lib.ConvDesc(128, c_in, c_out, h, w, k, k, 3)
+        big = c_in >= 100 and c_out <= 506
+        for dgrad in (0, 1):
+            ok = lib.fsc_conv_l16_supported(ctypes.byref(d), dgrad)
+            if big:
+                assert ok, (c_in, c_out, h, w, k, dgrad)
+            if c_in < 32:
+                assert not ok
+            if ok:
+                assert lib.fsc_conv_l16_packed_floats(ctypes.byref(d), dgrad) > 0
+                assert lib.fsc_conv_l16_plan_describe(ctypes.byref(d), dgrad, buf, 256) == 0
+                assert buf.value.decode().startswith("conv_l16_fwd_kernel<%d,%d," % (k, k))
+        okw = lib.fsc_conv_l16_wgrad_supported(ctypes.byref(d))
+        if c_in >= 100 and c_out <= 337:
+            assert okw, (c_in, c_out, h, w, k)
+        if okw:
+            assert lib.fsc_conv_l16_wgrad_workspace_bytes(ctypes.byref(d)) > 0
+            assert lib.fsc_conv_l16_wgrad_plan_describe(ctypes.byref(d), buf, 256) == 0
+    # a descriptor in another arithmetic is not served by the L16 kernels
+    assert not lib.fsc_conv_l16_supported(ctypes.byref(_lib.ConvDesc(128, 100, 100, 64, 215, 3, 3, 0)), 0)
+    assert lib.fsc_l16_bytes(3, 13, 35) == 3 * 2 * 2 * 35 * 16
