@@ -403,7 +403,7 @@ __global__ __launch_bounds__(kWaves * 64) void conv_l16_fwd_kernel(LGeom g, cons
         for (int d = 0; d < DAHEAD; ++d) produce_i();
         produce_w();
         produce_w();
-        produce_w();
+        if (TAPS == 1) produce_w();                          // (3x3: the first pair's two slots; each lead tap issues the next pair)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         raw_barrier();
         read_b(b_off(0, 0, 0), fb0);
@@ -412,28 +412,39 @@ __global__ __launch_bounds__(kWaves * 64) void conv_l16_fwd_kernel(LGeom g, cons
 
     // consumer position (all uniform): chunk c, step sc of nst inside it, input stage stg; wait state
     int c = 0, sc = 0, nst = g.nfull > 0 ? TAPS : g.tail_steps, stg = 0;
-    bool first_step = true, drain = false, inp_young = false;
+    bool first_step = true, drain = false;
 
-    // One MFMA step.  On entry `bcur` / `acur` hold the B fragments and the first pair's A fragments of this step (read
-    // during the previous one); the step reads those of the next step (B at its tap of the staged box, A from the next
-    // ring slot, whose DMAs the barrier at the top has covered) into `bnxt` / `anxt` behind its MFMAs.
-    auto step = [&](const Frag& bcur, Frag& bnxt, const AFrag& acur, AFrag& anxt) {
-        if (!first_step) {
-            // the barrier covers W(S+1) (issued two steps ago); W(S+2) and, in steps 1 and 2 of a chunk (never its last),
-            // the last three copies of the young input box may stay in flight.  Stores share the counter and retire out of
-            // order, and a dry weight producer leaves nothing younger: drain then.
-            if (drain) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            else if (TAPS > 1 && inp_young && (sc == 1 || sc == 2) && sc + 1 < nst) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NWLO + 3) : "memory");
-            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NWLO) : "memory");
-            raw_barrier();
-        }
-        first_step = false;
-        if (TAPS == 1) {
+    // One MFMA step = one tap x 32 channels.  3x3 kernels synchronise every TWO taps (TWO): the workgroup barrier, the DMA
+    // issue and the wait for the weights cost ~1150 cycles per barrier whatever the number of MFMAs behind it (measured: step
+    // time 2260 cycles at 24 MFMAs per wave, 3090 at 42), so a `lead` tap (barrier, DMA issue for the next pair, its first A
+    // fragments read fresh) is followed by a `follow` tap that runs straight on from registers: its B fragments and first A
+    // fragments were read behind the lead's MFMAs (both weight slots of a pair land before its barrier).  1x1 kernels (every
+    // tap opens a chunk) keep one barrier per tap with counted waits and read the next tap's first A fragments across it.
+    constexpr bool TWO = TAPS > 1;
+    auto step = [&](bool lead, bool has_follow, const Frag& bcur, Frag& bnxt, const AFrag& acur, AFrag& anxt) {
+        if (!TWO) {
+            if (!first_step) {
+                // the barrier covers W(S+1) (issued two steps ago); W(S+2) may stay in flight.  Stores share the counter and
+                // retire out of order, and a dry weight producer leaves nothing younger: drain then.
+                if (drain) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NWLO) : "memory");
+                raw_barrier();
+            }
+            first_step = false;
             produce_i();
             drain = !produce_w();
-        } else {
-            drain = !produce_w();
-            if (sc == 0) inp_young = produce_i() && g.npt >= 3;
+        } else if (lead) {
+            if (!first_step) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // everything issued a pair ago has landed (weights of this
+                raw_barrier();                                       // pair, a young input box, the previous item's stores)
+            }
+            first_step = false;
+            // weights of the NEXT pair into the two slots the previous pair used; the input box DAHEAD chunks ahead when a
+            // chunk opens in either tap of this pair
+            const bool opens = sc == 0 || (has_follow && sc + 1 == nst);
+            produce_w();
+            if (has_follow) produce_w();
+            if (opens) produce_i();
         }
         // the next step and the byte offset of its B operand
         int noff;
@@ -453,16 +464,19 @@ __global__ __launch_bounds__(kWaves * 64) void conv_l16_fwd_kernel(LGeom g, cons
         const u32x4* wl = reinterpret_cast<const u32x4*>(wring + slot * WSLOT_F) + lane;
         slot = slot == RING - 1 ? 0 : slot + 1;
         const u32x4* wln = reinterpret_cast<const u32x4*>(wring + slot * WSLOT_F) + lane;
-        AFrag t0, t1;
+        const bool fresh_a = TWO && lead;                    // (uniform) this tap's first pair is read now, behind the barrier
+        const bool next_a = TWO ? (lead && has_follow) : true;   // the next tap's first pair can be read at the end of this one
+        AFrag t0, t1, af;
+        if (fresh_a) read_a(wl, 0, af);
         constexpr int kLa[3] = {1, 0, 0}, kLb[3] = {0, 1, 0};     // (A limb, B limb): l*h, h*l, h*h -- smallest first
 #pragma unroll
         for (int pr = 0; pr < NPAIR; ++pr) {
-            const AFrag& a = pr == 0 ? acur : (pr & 1) ? t1 : t0;
+            const AFrag& a = pr == 0 ? (fresh_a ? af : acur) : (pr & 1) ? t1 : t0;
             AFrag& an = pr + 1 == NPAIR ? anxt : (pr & 1) ? t0 : t1;
-            // reads behind this pair's MFMAs: the next pair's A fragments (the next step's first pair from the next
-            // slot at the end) and, with the first pair, the next step's B fragments
+            // reads behind this pair's MFMAs: the next pair's A fragments (the next tap's first pair from the next slot at
+            // the end) and, with the first pair, the next tap's B fragments
             if (pr + 1 < NPAIR) read_a(wl, pr + 1, an);
-            else read_a(wln, 0, an);
+            else if (next_a) read_a(wln, 0, an);
             if (pr == 0) read_b(noff, bnxt);
             const int ntile = pr * 2 + 1 < COT ? 2 : 1;
 #pragma unroll
@@ -492,11 +506,11 @@ __global__ __launch_bounds__(kWaves * 64) void conv_l16_fwd_kernel(LGeom g, cons
         const int co0 = (item - tile * g.coblk) * CO_BLK;
 #pragma unroll 1
         for (int S = 0; S + 1 < g.steps; S += 2) {
-            step(fb0, fb1, fa0, fa1);
-            step(fb1, fb0, fa1, fa0);
+            step(true, true, fb0, fb1, fa0, fa1);
+            step(false, false, fb1, fb0, fa1, fa0);
         }
         if (g.steps & 1) {                                  // odd number of steps: the next item starts from fb0 / fa0 again
-            step(fb0, fb1, fa0, fa1);
+            step(true, false, fb0, fb1, fa0, fa1);
             fb0 = fb1;
             fa0 = fa1;
         }
@@ -566,7 +580,7 @@ __global__ __launch_bounds__(kWaves * 64) void conv_l16_fwd_kernel(LGeom g, cons
         for (int i = 0; i < COT; ++i)
 #pragma unroll
             for (int j = 0; j < PT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        drain = true;                                       // the stores above share the DMA counter
+        drain = true;                                       // (1x1) the stores above share the DMA counter
     }
 }
 
