@@ -65,6 +65,8 @@ SIGNATURES = {
     "fsc_conv_l16_pack_weights_pair": (_I, [_D, _P, _P, _P, _P]),
     "fsc_conv_l16_fwd": (_I, [_D, _P, _P, _P, _P, _I, _I, _P, _P]),
     "fsc_conv_l16_plan_describe": (_I, [_D, _I, C.c_char_p, _SZ]),
+    "fsc_conv_l16_pool_supported": (_I, [_D]),
+    "fsc_conv_l16_pool_fwd": (_I, [_D, _P, _P, _P, _P, _P, _P, _P]),
     "fsc_conv_l16_wgrad_supported": (_I, [_D]),
     "fsc_conv_l16_wgrad_workspace_bytes": (_SZ, [_D]),
     "fsc_conv_l16_wgrad": (_I, [_D, _P, _P, _P, _P, _P, _P, _P]),
@@ -143,6 +145,11 @@ def ptr(t):
                        "path has no CPU fallback." % t.device)
     if not t.is_contiguous():
         raise FscError("non-contiguous tensor passed to a libfsc_hip kernel")
+    if t.device.index is not None and t.device.index != torch.cuda.current_device():
+        # kernels are launched on the CURRENT device's stream (stream_ptr): a tensor of another GPU would be read through
+        # peer access or fault.  Callers select the device first (torch.cuda.set_device / `with torch.cuda.device(...)`).
+        raise FscError("tensor on %s passed to a libfsc_hip kernel while the current device is cuda:%d"
+                       % (t.device, torch.cuda.current_device()))
     return t.data_ptr()
 
 

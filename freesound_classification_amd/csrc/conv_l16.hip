@@ -214,13 +214,19 @@ __global__ __launch_bounds__(256) void l16_wmax_kernel(const float* __restrict__
 // -------------------------------------------------------------------------------------------
 // Forward / dgrad.  Workgroup = 8 waves, tile = COT*16 output channels x (8 * PT * 16) pixels, persistent over
 // (pixel tile, channel block) items.  One MFMA step = one tap x 32 channels: COT * PT * 3 MFMAs per wave.
-template <int KH, int KW, int COT, int PT>
+// POOL: forward of a convolution that is followed by MaxPool2d(2) (classifiers.py:526-532 for the blocks after the stem): a
+// wave's 16-pixel tiles are 2 x 8 blocks of the box instead of 16 consecutive pixels, so the four pixels of every pooling window
+// sit in lanes lm, lm + 1, lm + 8, lm + 9 of one MFMA column group -- the epilogue pools with two shuffles per value (same
+// first-maximum / NaN rule as fsc_maxpool_fwd) and writes the pooled tensor and the window indices; the full-resolution output
+// (1 GB at the first such layer of cfg 2) is never written and the separate max-pool pass disappears.  `out` = pooled tensor.
+template <int KH, int KW, int COT, int PT, bool POOL = false>
 __global__ __launch_bounds__(kWaves * 64) void conv_l16_fwd_kernel(LGeom g, const uint4* __restrict__ in,
                                                                     const float* __restrict__ packed,
                                                                     const float* __restrict__ bias,
                                                                     float* __restrict__ out, int accumulate,
                                                                     const float* __restrict__ in_amax,
-                                                                    const float* __restrict__ w_amax) {
+                                                                    const float* __restrict__ w_amax,
+                                                                    uint8_t* __restrict__ pool_idx = nullptr) {
     constexpr int TAPS = KH * KW;
     constexpr int CO_BLK = COT * 16;
     constexpr int PADH = KH / 2, PADW = KW / 2;
@@ -257,10 +263,18 @@ __global__ __launch_bounds__(kWaves * 64) void conv_l16_fwd_kernel(LGeom g, cons
         const int p = (wid * PT + pt) * 16 + lm;
         int pl = 0;
         if (p < g.npix) {
-            const int per = g.th * g.tw;
-            const int b = fdiv(p, inv_thw), rem = p - b * per;
-            const int r = fdiv(rem, inv_tw), c = rem - r * g.tw;
-            pl = (b * g.rows + r) * g.cols + c;
+            if (POOL) {                                  // tile = a 2 x 8 block: (image, row pair, column octet)
+                const int tpr = g.tw >> 3, tpi = (g.th >> 1) * tpr;
+                const int t = wid * PT + pt;
+                const int b = t / tpi, rem = t - b * tpi;
+                const int tr = rem / tpr, tc = rem - tr * tpr;
+                pl = (b * g.rows + 2 * tr + (lm >> 3)) * g.cols + 8 * tc + (lm & 7);
+            } else {
+                const int per = g.th * g.tw;
+                const int b = fdiv(p, inv_thw), rem = p - b * per;
+                const int r = fdiv(rem, inv_tw), c = rem - r * g.tw;
+                pl = (b * g.rows + r) * g.cols + c;
+            }
         }
         pix_b[pt] = pl * 16;
     }
@@ -515,6 +529,75 @@ __global__ __launch_bounds__(kWaves * 64) void conv_l16_fwd_kernel(LGeom g, cons
             fa0 = fa1;
         }
 
+        if constexpr (POOL) {
+            // ---- pooled epilogue.  After the shuffles the four even lanes lm = 0, 2, 4, 6 of a column group hold the pooled
+            //      value and window index of 4 channels x one window; through the scratch tile lane L = (channel L >> 2,
+            //      window L & 3) stores four bytes of four consecutive pooled pixels of a channel.
+            int t = tile;
+            const int twi = t % g.tiles_w; t /= g.tiles_w;
+            const int thi = t % g.tiles_h; t /= g.tiles_h;
+            const int n0 = t * g.nb, h0 = thi * g.th, w0 = twi * g.tw;
+            const int oh = g.h >> 1, ow = g.w >> 1;
+            const int tpr = g.tw >> 3, tpi = (g.th >> 1) * tpr;
+            long pool_g[PT];                                // pooled offset (channel 0) of this lane's window; -1 = outside
+#pragma unroll
+            for (int pt = 0; pt < PT; ++pt) {
+                const int tt = wid * PT + pt;
+                pool_g[pt] = -1;
+                if (tt * 16 < g.npix) {
+                    const int b = tt / tpi, rem = tt - b * tpi;
+                    const int tr = rem / tpr, tc = rem - tr * tpr;
+                    const int pr = (h0 >> 1) + tr, pc = (w0 >> 1) + 4 * tc + (lane & 3);
+                    if (n0 + b < g.n && pr < oh && pc < ow) pool_g[pt] = ((long)(n0 + b) * g.cout * oh + pr) * ow + pc;
+                }
+            }
+            const long ohw = (long)oh * ow;
+            const float* bias_p = bias;
+            asm volatile("" : "+s"(bias_p));
+            const int chp = lane >> 2;
+#pragma unroll
+            for (int i = 0; i < COT; ++i) {
+                float bv[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int cob = co0 + i * 16 + kq * 4 + r;
+                    bv[r] = (bias_p != nullptr && cob < g.cout) ? bias_p[cob] : 0.f;
+                }
+                const int co = co0 + i * 16 + chp;
+#pragma unroll
+                for (int j = 0; j < PT; ++j) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float v0 = fmaf(acc[i][j][r] * inv_x, inv_w, bv[r]);
+                        const float v1 = __shfl_xor(v0, 1);
+                        const float v2 = __shfl_xor(v0, 8);
+                        const float v3 = __shfl_xor(v1, 8);
+                        float best = v0;                     // first maximum in window order, NaN wins (fsc_maxpool_fwd)
+                        int bi = 0;
+                        if (v1 > best || v1 != v1) { best = v1; bi = 1; }
+                        if ((v2 > best || v2 != v2) && best == best) { best = v2; bi = 2; }
+                        if ((v3 > best || v3 != v3) && best == best) { best = v3; bi = 3; }
+                        if ((lm & 9) == 0) {                 // lanes lm = 0, 2, 4, 6: the window's first pixel
+                            scratch[(kq * 4 + r) * kScr + (lm >> 1)] = best;
+                            scratch[(kq * 4 + r) * kScr + 8 + (lm >> 1)] = __int_as_float(bi);
+                        }
+                    }
+                    const float val = scratch[chp * kScr + (lane & 3)];
+                    const int bidx = __float_as_int(scratch[chp * kScr + 8 + (lane & 3)]);
+                    if (co < g.cout && pool_g[j] >= 0) {
+                        out[pool_g[j] + (long)co * ohw] = val;
+                        pool_idx[pool_g[j] + (long)co * ohw] = (uint8_t)bidx;
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int i = 0; i < COT; ++i)
+#pragma unroll
+                for (int j = 0; j < PT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            drain = true;
+            continue;
+        }
         // ---- epilogue: D row = channel (kq*4 + r), column = pixel (lm) -> scratch[ch][px] -> lane = (channel, quad).
         //      This lane's quads (four consecutive pixels of a box row) are decoded here, once per item.
         long quad_g[PT];
@@ -593,7 +676,7 @@ struct LPlan {
     long tiles, workers;
 };
 
-bool plan_l16_pt(const fsc_conv_desc& d_in, int dgrad, int pt, int max_cot, LPlan* out) {
+bool plan_l16_pt(const fsc_conv_desc& d_in, int dgrad, int pt, int max_cot, LPlan* out, bool pool = false) {
     LPlan p{};
     LGeom& g = p.g;
     fsc_conv_desc d = d_in;
@@ -640,16 +723,19 @@ bool plan_l16_pt(const fsc_conv_desc& d_in, int dgrad, int pt, int max_cot, LPla
     long bcost = -1;
     int bnb = 1, bth = 1, btw = 1;
     for (int tw = 4; tw <= ((d.w + 3) & ~3) && tw <= pix_cap; tw += 4) {
+        if (pool && (tw & 7)) continue;                  // pooled epilogue: tiles are 2 x 8 blocks of the box
         int th = pix_cap / tw;
-        if (th > d.h) th = d.h;
+        if (th > d.h) th = pool ? ((d.h + 1) & ~1) : d.h;
+        if (pool) th &= ~1;
+        if (th < (pool ? 2 : 1)) continue;
         int nb = 1;
-        if (th == d.h && tw >= d.w) {
+        if (th >= d.h && tw >= d.w) {
             nb = pix_cap / (th * tw);
             if (nb > d.n) nb = d.n;
             if (nb < 1) nb = 1;
         }
         while (nb > 1 && nb * (th + d.kh - 1) * (tw + d.kw - 1) > cap_pos) --nb;
-        while (th > 1 && nb * (th + d.kh - 1) * (tw + d.kw - 1) > cap_pos) --th;
+        while (th > (pool ? 2 : 1) && nb * (th + d.kh - 1) * (tw + d.kw - 1) > cap_pos) th -= pool ? 2 : 1;
         if (nb * (th + d.kh - 1) * (tw + d.kw - 1) > cap_pos) continue;
         const long nt = (long)fsc::ceil_div(d.n, nb) * fsc::ceil_div(d.h, th) * fsc::ceil_div(d.w, tw);
         const long pen = (tw >= 32 || tw >= d.w) ? 100 : tw >= 16 ? 102 : tw >= 8 ? 108 : 125;
@@ -696,17 +782,42 @@ bool plan_l16(const fsc_conv_desc& d, int dgrad, LPlan* out) {
     return plan_l16_pt(d, dgrad, 1, taps == 1 ? 8 : 10, out);
 }
 
+// forward convolution fused with the 2 x 2 max-pool behind it: the same channel tiling as plan_l16 (the packed weights are
+// shared), a box of 2 x 8 blocks
+bool plan_l16_pool(const fsc_conv_desc& d, LPlan* out) {
+    if (d.arith != FSC_ARITH_DEFAULT && d.arith != 3) return false;
+    if (getenv("FSC_NO_L16") || getenv("FSC_NO_L16_POOL")) return false;
+    if (d.kh != 3 || d.kw != 3 || d.h < 2 || d.w < 8) return false;
+    LPlan plain;
+    if (!plan_l16(d, 0, &plain) || plain.pt != 2) return false;
+    if (!plan_l16_pt(d, 0, 2, 8, out, true)) return false;
+    return out->cot == plain.cot && out->co_blocks == plain.co_blocks && out->g.steps == plain.g.steps &&
+           out->cot >= 4 && out->cot <= 8;
+}
+
 size_t l16_limb_floats(const LPlan& p) { return (size_t)p.co_blocks * p.g.steps * p.cot * 2 * 256; }
 
 template <int KH, int KW, int COT, int PT>
 int launch_l16(const LPlan& p, const uint4* in, const float* packed, const float* bias, float* out, int accumulate,
                const float* in_amax, hipStream_t st) {
-    auto kern = conv_l16_fwd_kernel<KH, KW, COT, PT>;
+    auto kern = conv_l16_fwd_kernel<KH, KW, COT, PT, false>;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes);
     const float* w_amax = packed + l16_limb_floats(p);
     hipLaunchKernelGGL(kern, dim3((unsigned)p.workers), dim3(kWaves * 64), p.lds_bytes, st, p.g, in, packed, bias, out,
-                       accumulate, in_amax, w_amax);
+                       accumulate, in_amax, w_amax, (uint8_t*)nullptr);
     FSC_LAUNCH_CHECK("fsc_conv_l16_fwd");
+    return 0;
+}
+
+template <int COT>
+int launch_l16_pool(const LPlan& p, const uint4* in, const float* packed, const float* bias, float* pooled, uint8_t* idx,
+                    const float* in_amax, hipStream_t st) {
+    auto kern = conv_l16_fwd_kernel<3, 3, COT, 2, true>;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes);
+    const float* w_amax = packed + l16_limb_floats(p);
+    hipLaunchKernelGGL(kern, dim3((unsigned)p.workers), dim3(kWaves * 64), p.lds_bytes, st, p.g, in, packed, bias, pooled, 0,
+                       in_amax, w_amax, idx);
+    FSC_LAUNCH_CHECK("fsc_conv_l16_pool_fwd");
     return 0;
 }
 
@@ -826,6 +937,27 @@ int fsc_conv_l16_fwd(const fsc_conv_desc* d, const void* in_l16, const float* in
     const uint4* in = reinterpret_cast<const uint4*>(in_l16);
     if (d->kh == 3) return launch_l16_cot<3, 3>(p, in, packed, bias, out, accumulate, in_amax, st);
     return launch_l16_cot<1, 1>(p, in, packed, bias, out, accumulate, in_amax, st);
+}
+
+int fsc_conv_l16_pool_supported(const fsc_conv_desc* d) {
+    LPlan p;
+    return valid_l16_desc(d) && plan_l16_pool(*d, &p) ? 1 : 0;
+}
+
+int fsc_conv_l16_pool_fwd(const fsc_conv_desc* d, const void* in_l16, const float* in_amax, const float* packed,
+                          const float* bias, float* pooled, uint8_t* idx, fsc_stream_t stream) {
+    LPlan p;
+    FSC_CHECK_ARG(valid_l16_desc(d) && in_l16 && in_amax && packed && pooled && idx, "fsc_conv_l16_pool_fwd: bad descriptor or null pointer");
+    FSC_CHECK_ARG(plan_l16_pool(*d, &p), "fsc_conv_l16_pool_fwd: unsupported shape (see fsc_conv_l16_pool_supported)");
+    hipStream_t st = fsc::as_stream(stream);
+    const uint4* in = reinterpret_cast<const uint4*>(in_l16);
+    switch (p.cot) {
+        case 4: return launch_l16_pool<4>(p, in, packed, bias, pooled, idx, in_amax, st);
+        case 5: return launch_l16_pool<5>(p, in, packed, bias, pooled, idx, in_amax, st);
+        case 6: return launch_l16_pool<6>(p, in, packed, bias, pooled, idx, in_amax, st);
+        case 7: return launch_l16_pool<7>(p, in, packed, bias, pooled, idx, in_amax, st);
+        default: return launch_l16_pool<8>(p, in, packed, bias, pooled, idx, in_amax, st);
+    }
 }
 
 int fsc_conv_l16_plan_describe(const fsc_conv_desc* d, int dgrad, char* buf, size_t buf_len) {

@@ -343,6 +343,30 @@ def conv_l16(t, weight, bias, dgrad=False, accumulate_into=None, prepacked=None)
     return out
 
 
+def conv_l16_pool(t, weight, bias, prepacked=None):
+    """3x3 convolution on an L16 operand fused with MaxPool2d(2) (fsc_conv_l16_pool_fwd): (pooled, window index, conv output
+    shape), or None when the library has no fused tiling for the shape."""
+    c_out, c_in, kh, kw = weight.shape
+    n, _, h, w = t.shape
+    d = _desc(n, c_in, c_out, h, w, kh, kw, 3)
+    if (kh, kw) != (3, 3) or not _lib.load().fsc_conv_l16_pool_supported(C.byref(d)):
+        return None
+    _, packed = prepacked if prepacked is not None else conv_l16_pack(weight, n, h, w, False)
+    y = torch.empty((n, c_out, h // 2, w // 2), device=weight.device, dtype=torch.float32)
+    idx = torch.empty((n, c_out, h // 2, w // 2), device=weight.device, dtype=torch.uint8)
+    if TIMER is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    call("fsc_conv_l16_pool_fwd", C.byref(d), ptr(t.data), ptr(t.amax), ptr(packed), ptr(bias), ptr(y), ptr(idx), stream_ptr())
+    if TIMER is not None:
+        e1.record()
+        TIMER.records.append((l16_plan_name(d, 0), 2.0 * n * h * w * c_in * c_out * kh * kw, e0, e1))
+    return y, idx, (n, c_out, h, w)
+
+
+POOL_FUSION = True
+
+
 def conv_l16_wgrad_supported(desc):
     return bool(_lib.load().fsc_conv_l16_wgrad_supported(C.byref(desc)))
 
@@ -811,10 +835,25 @@ def _block_forward(x, mods, training, want_head, ph, keep, sync=None):
         if keep:
             packs.append(None)
     else:
-        c = _conv_fwd_any(a, a_16, w_a, b_a, a_max, packs)
-        p, pidx = maxpool_forward(c, ph)
-        k.c_shape = tuple(c.shape)
-        del c
+        pooled = None
+        if POOL_FUSION and ph == 2 and a_16 is not None and _l16_ok_for(a_16.shape, w_a, False):
+            n_, _, h_, w_ = a_16.shape
+            pf, pd = conv_l16_pack_pair(w_a, n_, h_, w_) if keep else (conv_l16_pack(w_a, n_, h_, w_, False), None)
+            pooled = conv_l16_pool(a_16, w_a, b_a, prepacked=pf)          # conv + max-pool in one kernel (no full-res output)
+            if pooled is not None:
+                p, pidx, k.c_shape = pooled
+                if keep:
+                    packs.append(pd)
+            else:
+                c = conv_l16(a_16, w_a, b_a, prepacked=pf)
+                if keep:
+                    packs.append(pd)
+        else:
+            c = _conv_fwd_any(a, a_16, w_a, b_a, a_max, packs)
+        if pooled is None:
+            p, pidx = maxpool_forward(c, ph)
+            k.c_shape = tuple(c.shape)
+            del c
     st_b = bn_prepare(p, bn_b, training, sync)
     w1, b1 = _conv_params(res.conv1)
     b, b_max, b_16 = _bn_fwd_for_conv(p, st_b, prelu_b.weight, w1, keep_f32=True)      # (the residual reads it)

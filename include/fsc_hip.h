@@ -160,6 +160,12 @@ int fsc_conv_l16_pack_weights_pair(const fsc_conv_desc* d, const float* weight, 
 int fsc_conv_l16_fwd(const fsc_conv_desc* d, const void* in_l16, const float* in_amax, const float* packed,
                      const float* bias, int dgrad, int accumulate, float* out, fsc_stream_t stream);
 int fsc_conv_l16_plan_describe(const fsc_conv_desc* d, int dgrad, char* buf, size_t buf_len);
+/* Forward 3x3 convolution fused with the MaxPool2d(2) behind it (classifiers.py:526-532, the blocks after the stem): writes
+ * the pooled tensor (N, c_out, H/2, W/2) and the uint8 window indices of fsc_maxpool_fwd (same first-maximum / NaN rule);
+ * the full-resolution output is never materialised.  `packed` from fsc_conv_l16_pack_weights(dgrad = 0). */
+int fsc_conv_l16_pool_supported(const fsc_conv_desc* d);
+int fsc_conv_l16_pool_fwd(const fsc_conv_desc* d, const void* in_l16, const float* in_amax, const float* packed,
+                          const float* bias, float* pooled, uint8_t* idx, fsc_stream_t stream);
 /* Weight gradient from L16 operands: dweight (c_out, c_in, kh, kw) = sum over pixels dout x in (overwrites dweight), 3x3 and
  * 1x1, same arithmetic as fsc_conv_wgrad with arith 3.  in_l16 is the (N, c_in, H, W) input of the convolution, dout_l16 the
  * (N, c_out, H, W) gradient of its output, each with the amax buffer its scale derives from. */

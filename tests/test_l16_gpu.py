@@ -264,3 +264,36 @@ def test_first_block_bn_grads_from_weight_gradient():
     for name in g0:                            # everything else is untouched (up to the order of the channel-sum atomics)
         if not name.startswith("conv_modules.0.0."):
             assert (g0[name] - g1[name]).abs().max().item() <= 1e-5 * max(1e-1, g0[name].abs().max().item()), name
+
+
+@pytest.mark.parametrize("case", [(8, 100, 150, 64, 215), (16, 150, 225, 32, 107), (32, 225, 337, 16, 53), (64, 337, 506, 8, 26),
+                                  (24, 64, 96, 17, 43), (12, 48, 80, 30, 64), (128, 506, 759, 4, 13),
+                                  (16, 100, 150, 31, 107), (16, 100, 150, 33, 105), (40, 64, 96, 23, 45)],
+                         ids=lambda c: "x".join(map(str, c)))
+def test_conv_l16_fused_with_maxpool(case):
+    """fsc_conv_l16_pool_fwd == fsc_conv_l16_fwd followed by fsc_maxpool_fwd, bit for bit (values and window indices),
+    including odd heights / widths (floor mode) and boxes that overhang the image."""
+    n, cin, cout, h, w = case
+    F.set_conv_arith("f16x3")
+    try:
+        torch.manual_seed(sum(case))
+        x = torch.randn(n, cin, h, w, device=DEV)
+        wt = torch.randn(cout, cin, 3, 3, device=DEV) / (cin * 9) ** 0.5
+        bias = torch.randn(cout, device=DEV)
+        d = F._desc(n, cin, cout, h, w, 3, 3, 3)
+        if not F.conv_l16_supported(d, 0):
+            pytest.skip("no L16 tiling")
+        t = F.l16_pack(x)
+        fused = F.conv_l16_pool(t, wt, bias)
+        if n * h * w >= 128 * 16 * 53 and h % 2 == 0:
+            assert fused is not None, "no fused tiling for a benchmark-size layer"
+        if fused is None:
+            pytest.skip("no fused tiling")
+        p, idx, c_shape = fused
+        c = F.conv_l16(t, wt, bias)
+        p_ref, idx_ref = F.maxpool_forward(c, 2)
+        assert c_shape == tuple(c.shape)
+        assert torch.equal(p, p_ref)
+        assert torch.equal(idx, idx_ref)
+    finally:
+        F.set_conv_arith(None)
