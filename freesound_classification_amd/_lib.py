@@ -74,6 +74,9 @@ SIGNATURES = {
     "fsc_bn_workspace_bytes": (_SZ, [_I]),
     "fsc_bn_train_stats": (_I, [_P, _I, _I, _L, _P, _P, _F, _F, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P]),
     "fsc_bn_eval_prepare": (_I, [_I, _P, _P, _P, _P, _F, _P, _P, _P]),
+    "fsc_bn_records_bytes": (_SZ, [_I, _I, _L]),
+    "fsc_bn_act_fwd_rec": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _L, _P, _P]),
+    "fsc_bn_records_fold": (_I, [_P, _P, _I, _I, _L, _P, _P, _P, _P]),
     "fsc_bn_act_fwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _L, _P, _P, _P, _P]),
     "fsc_bn_act_bwd": (_I, [_P] * 16 + [_I, _I, _L, _P, _P, _P, _I, _P, _P]),
     "fsc_bn_act_bwd_unpool": (_I, [_P] * 13 + [_I, _I, _I, _I, _I, _P, _P, _P, _I, _P, _P]),

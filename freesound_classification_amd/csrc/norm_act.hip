@@ -45,6 +45,34 @@ __global__ __launch_bounds__(kThreads) void stats_partial_kernel(
     float s1 = 0.f, s2 = 0.f;
     float mn = pivot, mx = pivot;          // smallest / largest x of the channel (the L16 producers' operand bound)
     const bool vec = (hw & 3) == 0 && hwp == kThreads;
+    if ((hw & 3) == 0 && hw <= 2 * kThreads) {
+        // planes of at most 128 quads: a lane owns one quad of a plane, 256 / 2^l4 images side by side, four of those
+        // groups in flight (one image per trip left the 208-pixel layers of cfg 2 at 1 TB/s).  Idle lanes and trips past the
+        // batch read the pivot, which adds nothing to the shifted sums and lies inside [min, max].
+        const int n4 = (int)(hw >> 2);
+        int l4 = 0;
+        while ((1 << l4) < n4) ++l4;
+        const int g4 = kThreads >> l4, tn4 = threadIdx.x >> l4, ti4 = threadIdx.x & ((1 << l4) - 1);
+        const bool live = ti4 < n4;
+        const int stride = nsplit * g4;
+        const float4 fill = make_float4(pivot, pivot, pivot, pivot);
+        for (int b = sp * g4 + tn4; b < n; b += 4 * stride) {
+            float4 v[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int bb = b + k * stride;
+                v[k] = (live && bb < n) ? reinterpret_cast<const float4*>(x + ((long)bb * c + ch) * hw)[ti4] : fill;
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float a0 = v[k].x - pivot, a1 = v[k].y - pivot, a2 = v[k].z - pivot, a3 = v[k].w - pivot;
+                s1 += (a0 + a1) + (a2 + a3);
+                s2 += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
+                mn = fminf(fminf(mn, fminf(v[k].x, v[k].y)), fminf(v[k].z, v[k].w));
+                mx = fmaxf(fmaxf(mx, fmaxf(v[k].x, v[k].y)), fmaxf(v[k].z, v[k].w));
+            }
+        }
+    } else
     for (int b = sp * groups + tn; b < n; b += nsplit * groups) {
         const float* p = x + ((long)b * c + ch) * hw;
         if (vec) {
@@ -280,6 +308,180 @@ __global__ __launch_bounds__(kThreads) void fwd_wave_kernel(
     if (y_amax) fsc::publish_amax(y_amax, mx);
 }
 
+// ---------------------------------------------------------------- forward apply that leaves records
+// The output of a block's last unit is read twice more right away: by the statistics pass of the NEXT block's input
+// BatchNorm (classifiers.py:524) and by the global max-pool of the hierarchical head (classifiers.py:586-590).  These
+// variants of the plane / wave kernels reduce what both need while they hold the values: per (plane, slice) the sums of
+// (y - pivot), (y - pivot)^2 with the pivot of stats_partial_kernel (y at image 0, position 0 of the channel -- recomputed
+// from x by every block with the same instruction sequence as the element that is stored), min / max, and the (value,
+// index) key of pool.hip's global max.  fold_records_kernel turns them into the statistics partials and the pooled values.
+struct PlaneRec { double s1, s2; float mn, mx; unsigned long long key; };
+
+__device__ __forceinline__ unsigned long long rec_key(float v, unsigned idx) {      // (= pool.hip gmax_key)
+    unsigned u;
+    if (v != v) {
+        u = 0xFFFFFFFFu;
+    } else {
+        if (v == 0.f) v = 0.f;
+        u = __float_as_uint(v);
+        u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+    }
+    return ((unsigned long long)u << 32) | (unsigned long long)(0xFFFFFFFFu - idx);
+}
+
+__device__ __forceinline__ float bn_point(float x, float r, bool has_res, float sc, float sh, float al, bool has_alpha) {
+    float z = fmaf(x, sc, sh);
+    if (has_res) z += r;
+    return act(z, al, has_alpha);
+}
+
+struct RecAcc {
+    float s1 = 0.f, s2 = 0.f, mn, mx;
+    unsigned long long key = 0ull;
+    float pivot;
+    __device__ __forceinline__ void init(float p) { pivot = p; mn = p; mx = p; }
+    __device__ __forceinline__ void add(float z, unsigned idx) {
+        const float a = z - pivot;
+        s1 += a;
+        s2 += a * a;
+        mn = fminf(mn, z);
+        mx = fmaxf(mx, z);
+        const unsigned long long k = rec_key(z, idx);
+        key = k > key ? k : key;
+    }
+    // wave-level fold; lane 0 holds the result
+    __device__ __forceinline__ void wave_fold(double& d1, double& d2) {
+        d1 = (double)s1; d2 = (double)s2;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            d1 += __shfl_xor(d1, o, 64);
+            d2 += __shfl_xor(d2, o, 64);
+            mn = fminf(mn, __shfl_xor(mn, o, 64));
+            mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+            const unsigned long long other = __shfl_xor(key, o, 64);
+            key = other > key ? other : key;
+        }
+    }
+};
+
+__global__ __launch_bounds__(kThreads) void fwd_plane_rec_kernel(
+    const float* __restrict__ x, const float* __restrict__ res, const float* __restrict__ scale,
+    const float* __restrict__ shift, const float* __restrict__ alpha, float* __restrict__ y, int c, long hw,
+    PlaneRec* __restrict__ rec) {
+    __shared__ PlaneRec fold[kThreads / 64];
+    const long plane = blockIdx.x;
+    const int ch = (int)(plane % c);
+    const float sc = scale[ch], sh = shift[ch];
+    const bool has_alpha = alpha != nullptr, has_res = res != nullptr;
+    const float al = has_alpha ? alpha[ch] : 0.f;
+    const float* px = x + plane * hw;
+    const float* pr = has_res ? res + plane * hw : nullptr;
+    float* py = y + plane * hw;
+    RecAcc acc;
+    acc.init(bn_point(x[(long)ch * hw], has_res ? res[(long)ch * hw] : 0.f, has_res, sc, sh, al, has_alpha));
+    if ((hw & 3) == 0) {
+        const long n4 = hw >> 2;
+        for (long i = (long)blockIdx.y * kThreads + threadIdx.x; i < n4; i += (long)gridDim.y * kThreads) {
+            const float4 v = reinterpret_cast<const float4*>(px)[i];
+            float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (has_res) r = reinterpret_cast<const float4*>(pr)[i];
+            float4 z;
+            z.x = bn_point(v.x, r.x, has_res, sc, sh, al, has_alpha);
+            z.y = bn_point(v.y, r.y, has_res, sc, sh, al, has_alpha);
+            z.z = bn_point(v.z, r.z, has_res, sc, sh, al, has_alpha);
+            z.w = bn_point(v.w, r.w, has_res, sc, sh, al, has_alpha);
+            reinterpret_cast<float4*>(py)[i] = z;
+            const unsigned i0 = (unsigned)(i * 4);
+            acc.add(z.x, i0); acc.add(z.y, i0 + 1); acc.add(z.z, i0 + 2); acc.add(z.w, i0 + 3);
+        }
+    } else {
+        for (long i = (long)blockIdx.y * kThreads + threadIdx.x; i < hw; i += (long)gridDim.y * kThreads) {
+            const float z = bn_point(px[i], has_res ? pr[i] : 0.f, has_res, sc, sh, al, has_alpha);
+            py[i] = z;
+            acc.add(z, (unsigned)i);
+        }
+    }
+    double d1, d2;
+    acc.wave_fold(d1, d2);
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    if (lane == 0) fold[wid] = PlaneRec{d1, d2, acc.mn, acc.mx, acc.key};
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        PlaneRec o = fold[0];
+#pragma unroll
+        for (int k = 1; k < kThreads / 64; ++k) {
+            o.s1 += fold[k].s1; o.s2 += fold[k].s2;
+            o.mn = fminf(o.mn, fold[k].mn); o.mx = fmaxf(o.mx, fold[k].mx);
+            o.key = fold[k].key > o.key ? fold[k].key : o.key;
+        }
+        rec[plane * gridDim.y + blockIdx.y] = o;
+    }
+}
+
+// planes of 2..511 pixels: one wavefront per plane, one record per plane
+__global__ __launch_bounds__(kThreads) void fwd_wave_rec_kernel(
+    const float* __restrict__ x, const float* __restrict__ res, const float* __restrict__ scale,
+    const float* __restrict__ shift, const float* __restrict__ alpha, float* __restrict__ y, int c, long hw,
+    long planes, PlaneRec* __restrict__ rec) {
+    const long plane = (long)blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6);
+    if (plane >= planes) return;
+    const int lane = threadIdx.x & 63;
+    const int ch = (int)(plane % c);
+    const float sc = scale[ch], sh = shift[ch];
+    const bool has_alpha = alpha != nullptr, has_res = res != nullptr;
+    const float al = has_alpha ? alpha[ch] : 0.f;
+    const long base = plane * hw;
+    RecAcc acc;
+    acc.init(bn_point(x[(long)ch * hw], has_res ? res[(long)ch * hw] : 0.f, has_res, sc, sh, al, has_alpha));
+    for (long i = lane; i < hw; i += 64) {
+        const float z = bn_point(x[base + i], has_res ? res[base + i] : 0.f, has_res, sc, sh, al, has_alpha);
+        y[base + i] = z;
+        acc.add(z, (unsigned)i);
+    }
+    double d1, d2;
+    acc.wave_fold(d1, d2);
+    if (lane == 0) rec[plane] = PlaneRec{d1, d2, acc.mn, acc.mx, acc.key};
+}
+
+// one workgroup per channel: a thread folds the slices of one image's plane (-> the global max of that plane), the block
+// folds the images (-> split 0 of the statistics partials, what stats_finalize_kernel reads with nsplit = 1)
+__global__ __launch_bounds__(kThreads) void fold_records_kernel(const PlaneRec* __restrict__ rec, int slices, int n, int c, long hw,
+                                                                const float* __restrict__ y, double* __restrict__ part,
+                                                                float* __restrict__ gmax, int* __restrict__ gmax_idx) {
+    __shared__ double scratch[kThreads / 64];
+    __shared__ float mm[2][kThreads / 64];
+    const int ch = blockIdx.x;
+    double s1 = 0.0, s2 = 0.0;
+    float mn = rec[(long)ch * slices].mn, mx = mn;          // (image 0: a value of the channel)
+    for (int b = threadIdx.x; b < n; b += kThreads) {
+        const long plane = (long)b * c + ch;
+        const PlaneRec* r = rec + plane * slices;
+        unsigned long long key = 0ull;
+        for (int j = 0; j < slices; ++j) {
+            s1 += r[j].s1; s2 += r[j].s2;
+            mn = fminf(mn, r[j].mn); mx = fmaxf(mx, r[j].mx);
+            key = r[j].key > key ? r[j].key : key;
+        }
+        if (gmax) {
+            const unsigned ii = 0xFFFFFFFFu - (unsigned)(key & 0xFFFFFFFFull);
+            gmax[plane] = y[plane * hw + ii];
+            gmax_idx[plane] = (int)ii;
+        }
+    }
+    if (!part) return;
+    const double t1 = fsc::block_sum<double, kThreads / 64>(s1, scratch);
+    const double t2 = fsc::block_sum<double, kThreads / 64>(s2, scratch);
+    mx = fsc::wave_max(mx);
+    mn = -fsc::wave_max(-mn);
+    if ((threadIdx.x & 63) == 0) { mm[0][threadIdx.x >> 6] = mn; mm[1][threadIdx.x >> 6] = mx; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int i = 1; i < kThreads / 64; ++i) { mn = fminf(mn, mm[0][i]); mx = fmaxf(mx, mm[1][i]); }
+        double* o = part + (size_t)ch * kMaxSplit * kPartStride;
+        o[0] = t1; o[1] = t2; o[2] = (double)mn; o[3] = (double)mx;
+    }
+}
+
 // hw == 1 (BatchNorm1d on (N, C)): flat indexing
 __global__ void fwd_flat_kernel(const float* __restrict__ x, const float* __restrict__ res,
                                 const float* __restrict__ scale, const float* __restrict__ shift,
@@ -454,6 +656,51 @@ __global__ __launch_bounds__(kThreads) void bwd_partial_kernel(BwdArgs a, int ns
     const int tn = threadIdx.x >> hwp_log2, ti = threadIdx.x & (hwp - 1);
     float s0 = 0.f, s1 = 0.f, s2 = 0.f;
     float mdz = 0.f, mxh = 0.f;            // max |dz|, max |xhat|: the bound of |dx| for the L16 apply pass
+    auto quad = [&](const float4& xv, const float4& rv, const float4& uv) {
+        const float xs[4] = {xv.x, xv.y, xv.z, xv.w}, rs[4] = {rv.x, rv.y, rv.z, rv.w}, us[4] = {uv.x, uv.y, uv.z, uv.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float xh = (xs[e] - mean) * invstd;
+            const float z = fmaf(xh, g, b) + rs[e];
+            const bool neg = has_alpha && !(z > 0.f);
+            const float dz = neg ? al * us[e] : us[e];
+            s0 += dz;
+            s1 += dz * xh;
+            s2 += us[e] * (neg ? z : 0.f);
+            mdz = fmaxf(mdz, fabsf(dz));
+            mxh = fmaxf(mxh, fabsf(xh));
+        }
+    };
+    if ((a.hw & 3) == 0 && a.hw <= 2 * kThreads) {
+        // small planes: one quad per lane, several images side by side, two groups of them in flight (see stats_partial_kernel);
+        // idle lanes take x = mean, dy = 0, which add nothing
+        const int n4 = (int)(a.hw >> 2);
+        int l4 = 0;
+        while ((1 << l4) < n4) ++l4;
+        const int g4 = kThreads >> l4, tn4 = threadIdx.x >> l4, ti4 = threadIdx.x & ((1 << l4) - 1);
+        const bool live = ti4 < n4;
+        const int stride = nsplit * g4;
+        const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f), mean4 = make_float4(mean, mean, mean, mean);
+        for (int nb = sp * g4 + tn4; nb < a.n; nb += 2 * stride) {
+            float4 xv[2], rv[2], uv[2];
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int bb = nb + k * stride;
+                const bool ok = live && bb < a.n;
+                const long plane = (long)(ok ? bb : nb) * a.c + ch;
+                xv[k] = ok ? reinterpret_cast<const float4*>(a.x + plane * a.hw)[ti4] : mean4;
+                rv[k] = (ok && a.res) ? reinterpret_cast<const float4*>(a.res + plane * a.hw)[ti4] : zero4;
+                uv[k] = (ok && a.dy) ? reinterpret_cast<const float4*>(a.dy + plane * a.hw)[ti4] : zero4;
+                if (ok && a.gmax_dy) {
+                    const int d = a.gmax_idx[plane] - ti4 * 4;
+                    const float gval = a.gmax_dy[plane];
+                    if (d == 0) uv[k].x += gval; else if (d == 1) uv[k].y += gval; else if (d == 2) uv[k].z += gval; else if (d == 3) uv[k].w += gval;
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 2; ++k) quad(xv[k], rv[k], uv[k]);
+        }
+    } else
     for (int nb = sp * groups + tn; nb < a.n; nb += nsplit * groups) {
         const long plane = (long)nb * a.c + ch;
         const float* px = a.x + plane * a.hw;
@@ -471,19 +718,7 @@ __global__ __launch_bounds__(kThreads) void bwd_partial_kernel(BwdArgs a, int ns
                 if (pdy) uv = reinterpret_cast<const float4*>(pdy)[i4];
                 const long d = gpos - i4 * 4;
                 if (d >= 0 && d < 4) { if (d == 0) uv.x += gval; else if (d == 1) uv.y += gval; else if (d == 2) uv.z += gval; else uv.w += gval; }
-                const float xs[4] = {xv.x, xv.y, xv.z, xv.w}, rs[4] = {rv.x, rv.y, rv.z, rv.w}, us[4] = {uv.x, uv.y, uv.z, uv.w};
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float xh = (xs[e] - mean) * invstd;
-                    const float z = fmaf(xh, g, b) + rs[e];
-                    const bool neg = has_alpha && !(z > 0.f);
-                    const float dz = neg ? al * us[e] : us[e];
-                    s0 += dz;
-                    s1 += dz * xh;
-                    s2 += us[e] * (neg ? z : 0.f);
-                    mdz = fmaxf(mdz, fabsf(dz));
-                    mxh = fmaxf(mxh, fabsf(xh));
-                }
+                quad(xv, rv, uv);
             }
             continue;
         }
@@ -1010,7 +1245,8 @@ __global__ void bwd_apply_flat_kernel(BwdArgs a, const float* __restrict__ coef,
 int pick_split(int n, int c, long hw) {
     // enough blocks to fill 256 CUs a few times over, bounded by the batch and the workspace
     long want = (256L * 8 + c - 1) / c;
-    long by_work = ((long)n * hw + 16383) / 16384;   // >= 16K elements per block
+    const long per_block = hw <= 2 * kThreads ? 4096 : 16384;      // (small planes are latency-bound: more, shorter blocks)
+    long by_work = ((long)n * hw + per_block - 1) / per_block;
     long s = want < by_work ? want : by_work;
     if (s > n) s = n;
     if (s > kMaxSplit) s = kMaxSplit;
@@ -1065,13 +1301,16 @@ int fsc_bn_train_stats(const float* x, int n, int c, long hw, const float* gamma
                        float* save_invstd, float* scale, float* shift, void* workspace, double* sync, int phase,
                        float* x_minmax, fsc_stream_t stream) {
     FSC_CHECK_ARG(x && save_mean && save_invstd && scale && shift && workspace, "fsc_bn_train_stats: null pointer");
-    FSC_CHECK_ARG(phase == 0 || ((phase == 1 || phase == 2) && sync), "fsc_bn_train_stats: phase 1 / 2 need `sync`");
+    FSC_CHECK_ARG((phase & ~FSC_BN_STATS_FOLDED) == 0 || (((phase & 3) == 1 || (phase & 3) == 2) && sync),
+                  "fsc_bn_train_stats: phase 1 / 2 need `sync`");
     FSC_CHECK_ARG(n > 0 && c > 0 && hw > 0, "fsc_bn_train_stats: bad shape (%d, %d, %ld)", n, c, hw);
     FSC_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr), "fsc_bn_train_stats: running stats must come in pairs");
     hipStream_t st = fsc::as_stream(stream);
     Partials p = carve(workspace, c);
     int nsplit = 1;
-    if (phase != 2) {
+    const bool folded = (phase & FSC_BN_STATS_FOLDED) != 0;      // split 0 of the partials is there already (fsc_bn_records_fold)
+    phase &= ~FSC_BN_STATS_FOLDED;
+    if (phase != 2 && !folded) {
         if (hw == 1) {
             hipLaunchKernelGGL(stats_rows_kernel, dim3(fsc::ceil_div(c, 128)), dim3(128), 0, st, x, n, c, p.part);
         } else {
@@ -1093,6 +1332,43 @@ int fsc_bn_eval_prepare(int c, const float* gamma, const float* beta, const floa
     hipLaunchKernelGGL(eval_prepare_kernel, dim3(fsc::ceil_div(c, 128)), dim3(128), 0, fsc::as_stream(stream), c,
                        gamma, beta, running_mean, running_var, eps, scale, shift);
     FSC_LAUNCH_CHECK("fsc_bn_eval_prepare");
+    return 0;
+}
+
+static int rec_slices(long hw) { return hw >= 512 ? plane_grid_y(hw) : 1; }
+
+size_t fsc_bn_records_bytes(int n, int c, long hw) {
+    if (n <= 0 || c <= 0 || hw < 2) return 0;
+    return (size_t)n * c * rec_slices(hw) * sizeof(PlaneRec);
+}
+
+int fsc_bn_act_fwd_rec(const float* x, const float* residual, const float* scale, const float* shift,
+                       const float* alpha, float* y, int n, int c, long hw, void* records, fsc_stream_t stream) {
+    FSC_CHECK_ARG(x && scale && shift && y && records, "fsc_bn_act_fwd_rec: null pointer");
+    FSC_CHECK_ARG(n > 0 && c > 0 && hw > 1, "fsc_bn_act_fwd_rec: bad shape (%d, %d, %ld)", n, c, hw);
+    hipStream_t st = fsc::as_stream(stream);
+    PlaneRec* rec = reinterpret_cast<PlaneRec*>(records);
+    const long planes = (long)n * c;
+    if (hw >= 512) {
+        hipLaunchKernelGGL(fwd_plane_rec_kernel, dim3((unsigned)planes, plane_grid_y(hw)), dim3(kThreads), 0, st, x, residual,
+                           scale, shift, alpha, y, c, hw, rec);
+    } else {
+        hipLaunchKernelGGL(fwd_wave_rec_kernel, dim3((unsigned)((planes + 3) / 4)), dim3(kThreads), 0, st, x, residual, scale,
+                           shift, alpha, y, c, hw, planes, rec);
+    }
+    FSC_LAUNCH_CHECK("fsc_bn_act_fwd_rec");
+    return 0;
+}
+
+int fsc_bn_records_fold(const void* records, const float* y, int n, int c, long hw, void* stats_workspace, float* gmax,
+                        int* gmax_idx, fsc_stream_t stream) {
+    FSC_CHECK_ARG(records && y && (stats_workspace || gmax), "fsc_bn_records_fold: null pointer");
+    FSC_CHECK_ARG((gmax == nullptr) == (gmax_idx == nullptr), "fsc_bn_records_fold: gmax / gmax_idx must come in pairs");
+    FSC_CHECK_ARG(n > 0 && c > 0 && hw > 1, "fsc_bn_records_fold: bad shape (%d, %d, %ld)", n, c, hw);
+    double* part = stats_workspace ? carve(stats_workspace, c).part : nullptr;
+    hipLaunchKernelGGL(fold_records_kernel, dim3(c), dim3(kThreads), 0, fsc::as_stream(stream),
+                       reinterpret_cast<const PlaneRec*>(records), rec_slices(hw), n, c, hw, y, part, gmax, gmax_idx);
+    FSC_LAUNCH_CHECK("fsc_bn_records_fold");
     return 0;
 }
 

@@ -501,6 +501,41 @@ def _sync_buffer(c, like):
     return torch.empty(4 * c, device=like.device, dtype=torch.float64)      # FSC_BN_SYNC_DOUBLES(c)
 
 
+FUSE_OUT_STATS = True          # the block's last unit reduces the next BatchNorm's statistics and the global max itself
+_STATS_FOLDED = 4              # FSC_BN_STATS_FOLDED
+_PRESTATS = {}                 # at most one entry: (data_ptr, shape, version) of a block output -> its folded BN workspace
+
+
+def _take_prestats(x):
+    """The BatchNorm workspace the producer of `x` filled (bn_act_forward_rec), if x is that very tensor, unmodified."""
+    if not _PRESTATS:
+        return None
+    key, (ws, _alive) = _PRESTATS.popitem()          # (the entry held the tensor, so its address was not reused meanwhile)
+    if key == (x.data_ptr(), tuple(x.shape), x._version, x.device):
+        return ws
+    return None
+
+
+def bn_act_forward_rec(x, st, alpha, residual, want_stats, want_gmax):
+    """bn_act_forward (fp32 output) that also reduces, while it writes y, what the next readers of y need: the statistics
+    partials of the BatchNorm that follows (kept for the bn_prepare call on this very tensor) and the global max-pool.
+    Returns (y, feat or None, feat_idx or None)."""
+    n, c = x.shape[0], x.shape[1]
+    hw = x.numel() // (n * c)
+    y = torch.empty_like(x)
+    rec = torch.empty((_lib.load().fsc_bn_records_bytes(n, c, hw) + 7) // 8, device=x.device, dtype=torch.float64)
+    call("fsc_bn_act_fwd_rec", ptr(x), ptr(residual), ptr(st.scale), ptr(st.shift), ptr(alpha), ptr(y), n, c, hw, ptr(rec),
+         stream_ptr())
+    ws = _bn_ws(c, x) if want_stats else None
+    feat = _empty((n, c), x) if want_gmax else None
+    fidx = _empty((n, c), x, torch.int32) if want_gmax else None
+    call("fsc_bn_records_fold", ptr(rec), ptr(y), n, c, hw, ptr(ws), ptr(feat), ptr(fidx), stream_ptr())
+    _PRESTATS.clear()
+    if want_stats:
+        _PRESTATS[(y.data_ptr(), tuple(y.shape), y._version, y.device)] = (ws, y)
+    return y, feat, fidx
+
+
 def bn_prepare(x, bn, training, sync=None):
     """Batch statistics (training; also updates the running stats, once) or running statistics
     (eval) -> per-channel scale/shift.  `sync` (a callable that sum-all-reduces a device tensor in place over the
@@ -521,16 +556,19 @@ def bn_prepare(x, bn, training, sync=None):
             bn.num_batches_tracked.add_(1)
             if bn.momentum is None:
                 momentum = 1.0 / float(bn.num_batches_tracked)
-        ws = _bn_ws(c, x)                                  # (kept alive across both phases)
+        ws = _take_prestats(x)                             # reduced by the kernel that wrote x?
+        folded = _STATS_FOLDED if ws is not None else 0
+        if ws is None:
+            ws = _bn_ws(c, x)                              # (kept alive across both phases)
         st.minmax = _empty((2 * c,), x)                    # per-channel [min, max] of x: the L16 producers' bound
         args = (ptr(x), n, c, hw, ptr(gamma), ptr(beta), bn.eps, momentum,
                 ptr(bn.running_mean) if track else None, ptr(bn.running_var) if track else None,
                 ptr(st.mean), ptr(st.invstd), ptr(st.scale), ptr(st.shift), ptr(ws))
         if sync is None:
-            call("fsc_bn_train_stats", *args, None, 0, ptr(st.minmax), stream_ptr())
+            call("fsc_bn_train_stats", *args, None, folded, ptr(st.minmax), stream_ptr())
         else:
             moments = _sync_buffer(c, x)                   # [sum x, sum x^2, count, 0] per channel, fp64
-            call("fsc_bn_train_stats", *args, ptr(moments), 1, ptr(st.minmax), stream_ptr())
+            call("fsc_bn_train_stats", *args, ptr(moments), 1 | folded, ptr(st.minmax), stream_ptr())
             sync(moments)
             call("fsc_bn_train_stats", *args, ptr(moments), 2, ptr(st.minmax), stream_ptr())
     else:
@@ -817,7 +855,7 @@ def _l16_of(m):
     return m if isinstance(m, L16) else None
 
 
-def _block_forward(x, mods, training, want_head, ph, keep, sync=None):
+def _block_forward(x, mods, training, want_head, ph, keep, sync=None, next_bn=False):
     """BN -> conv3 -> maxpool -> BN+PReLU -> residual unit (-> global max).  `mods` is the
     reference's nn.Sequential of parameter holders.  Returns (out, feat, ctx)."""
     bn_a, conv_a, _pool, bn_b, prelu_b, res = mods[0], mods[1], mods[2], mods[3], mods[4], mods[5]
@@ -867,10 +905,13 @@ def _block_forward(x, mods, training, want_head, ph, keep, sync=None):
     s2, s2_max, s2_16 = _bn_fwd_for_conv(r2, st2, res.prelu2.weight, w3)
     r3 = _conv_fwd_any(s2, s2_16, w3, b3, s2_max, packs)
     st3 = bn_prepare(r3, res.bn3, training, sync)
-    out = bn_act_forward(r3, st3, res.prelu3.weight, residual=b)
     feat, fidx = (None, None)
-    if want_head:
-        feat, fidx = global_maxpool_forward(out)
+    if FUSE_OUT_STATS and h_w_min(r3) * max(r3.shape[2], r3.shape[3]) > 1 and (want_head or (training and next_bn)):
+        out, feat, fidx = bn_act_forward_rec(r3, st3, res.prelu3.weight, b, training and next_bn, want_head)
+    else:
+        out = bn_act_forward(r3, st3, res.prelu3.weight, residual=b)
+        if want_head:
+            feat, fidx = global_maxpool_forward(out)
     if keep:
         k.x, k.a, k.pidx, k.p, k.b = x, a, pidx, p, b
         k.r1, k.s1, k.r2, k.s2, k.r3 = r1, s1, r2, s2, r3
@@ -963,12 +1004,12 @@ class ConvBlockFn(torch.autograd.Function):
     (:589-591) as a single autograd node with a hand-written backward."""
 
     @staticmethod
-    def forward(ctx, x, mods, training, want_head, ph, sync, *params):
+    def forward(ctx, x, mods, training, want_head, ph, sync, next_bn, *params):
         keep = any(ctx.needs_input_grad)
         if keep and not training:
             raise _lib.FscError("conv_block: gradients in eval mode (BatchNorm on running statistics) are not on the "
                                 "accelerated path; call model.train() or wrap the forward in torch.no_grad()")
-        out, feat, k = _block_forward(x, mods, training, want_head, ph, keep, sync)
+        out, feat, k = _block_forward(x, mods, training, want_head, ph, keep, sync, next_bn)
         ctx.k = k
         ctx.sync = sync
         ctx.mods = mods
@@ -1074,19 +1115,20 @@ class ConvBlockFn(torch.autograd.Function):
                  like(res.conv2.weight, dw2), dbias2, dg2, dbt2, dal2,
                  like(res.conv3.weight, dw3), dbias3, dg3, dbt3, dal3]
         ctx.k = None
-        return (dx, None, None, None, None, None) + tuple(grads)
+        return (dx, None, None, None, None, None, None) + tuple(grads)
 
 
-def conv_block(x, mods, training, want_head, ph, sync=None):
-    """Differentiable block call.  Returns (out, feat or None).  `sync`: cross-replica BN statistics (bn_prepare)."""
+def conv_block(x, mods, training, want_head, ph, sync=None, next_bn=False):
+    """Differentiable block call.  Returns (out, feat or None).  `sync`: cross-replica BN statistics (bn_prepare).
+    next_bn: the output goes straight into another block (whose input BatchNorm then finds its statistics reduced)."""
     _need_cuda(x, "conv_block")
     x = x.contiguous()
     if not training:
         sync = None
     if torch.is_grad_enabled() and any(p.requires_grad for p in _block_params(mods)):
-        out, feat = ConvBlockFn.apply(x, mods, training, want_head, ph, sync, *_block_params(mods))
+        out, feat = ConvBlockFn.apply(x, mods, training, want_head, ph, sync, next_bn, *_block_params(mods))
     else:
-        out, feat, _ = _block_forward(x, mods, training, want_head, ph, keep=False, sync=sync)
+        out, feat, _ = _block_forward(x, mods, training, want_head, ph, keep=False, sync=sync, next_bn=next_bn)
     return out, (feat if want_head else None)
 
 

@@ -176,7 +176,7 @@ class _TaggingModel(nn.Module):
         feats = []
         for k, mods in enumerate(self.conv_modules):
             use_max = k >= start and self.aggregation == "max"
-            h, feat = F.conv_block(h, mods, self.training, use_max, ph, self._bn_sync)
+            h, feat = F.conv_block(h, mods, self.training, use_max, ph, self._bn_sync, next_bn=k + 1 < len(self.conv_modules))
             if k >= start and self.aggregation == "rnn":
                 feat = F.rnn_head(h, self.rnns[k - start])
             if feat is not None:

@@ -200,7 +200,23 @@ int fsc_bn_train_stats(const float* x, int n, int c, long hw, const float* gamma
                        float* scale, float* shift, void* workspace, double* sync, int phase,
                        float* x_minmax, fsc_stream_t stream);
 /* x_minmax (2*C floats, may be NULL): per channel [min x, max x] of the local batch -- what fsc_bn_act_fwd needs to
- * bound its output before it writes an L16 tensor. */
+ * bound its output before it writes an L16 tensor.
+ * phase | FSC_BN_STATS_FOLDED: the reduction over x was done by the kernel that WROTE x (fsc_bn_act_fwd_rec +
+ * fsc_bn_records_fold into this `workspace`): no statistics pass, only the finalisation (x is still read for the pivot). */
+#define FSC_BN_STATS_FOLDED 4
+/* The last unit of a block (classifiers.py:102-104: bn3 + residual + PReLU) writes a tensor that the next block's input
+ * BatchNorm (classifiers.py:524) and the hierarchical head's global max-pool (classifiers.py:586-590) read again at once.
+ * fsc_bn_act_fwd_rec = fsc_bn_act_fwd (fp32 y, hw > 1, no amax) that also leaves one record per (plane, slice) --
+ * fsc_bn_records_bytes(n, c, hw) bytes -- with the pivot-shifted sums, min / max and global-max key of what it wrote;
+ * fsc_bn_records_fold turns them into split 0 of a BatchNorm workspace (`stats_workspace`, fsc_bn_workspace_bytes(c);
+ * pass it to fsc_bn_train_stats with FSC_BN_STATS_FOLDED; may be NULL) and / or the (n, c) global max + argmax of y
+ * (same first-maximum / NaN rule as fsc_global_maxpool_fwd; may be NULL).  Bit-identical statistics inputs are NOT
+ * promised (the summation order differs from the statistics pass); the pooled values and indices are identical. */
+size_t fsc_bn_records_bytes(int n, int c, long hw);
+int fsc_bn_act_fwd_rec(const float* x, const float* residual, const float* scale, const float* shift,
+                       const float* alpha, float* y, int n, int c, long hw, void* records, fsc_stream_t stream);
+int fsc_bn_records_fold(const void* records, const float* y, int n, int c, long hw, void* stats_workspace,
+                        float* gmax, int* gmax_idx, fsc_stream_t stream);
 /* eval: scale/shift from the running statistics */
 int fsc_bn_eval_prepare(int c, const float* gamma, const float* beta, const float* running_mean,
                         const float* running_var, float eps, float* scale, float* shift,

@@ -297,3 +297,51 @@ def test_conv_l16_fused_with_maxpool(case):
         assert torch.equal(idx, idx_ref)
     finally:
         F.set_conv_arith(None)
+
+
+REC_CASES = BN_CASES + [(3, 5, 23, 45), (5, 4, 1, 700), (2, 3, 1, 37), (300, 6, 8, 26)]
+
+
+@pytest.mark.parametrize("case", REC_CASES, ids=lambda c: "x".join(map(str, c)))
+def test_bn_forward_leaves_statistics_and_global_max(case):
+    """The block's last unit (bn3 + residual + PReLU, classifiers.py:102-104) reduces the next BatchNorm's statistics and the
+    head's global max-pool while it writes its output: same y bit for bit, same pooled values / indices, statistics equal to
+    the separate pass up to summation order."""
+    n, c, h, w = case
+    bn, prelu = _bn_units(c)
+    bn_next, _ = _bn_units(c)
+    x = torch.randn(n, c, h, w, device=DEV) * 2.0 + 0.3
+    res = torch.randn_like(x)
+    st = F.bn_prepare(x, bn, True)
+    for alpha, r in ((prelu.weight, res), (None, None), (prelu.weight, None)):
+        y_ref = F.bn_act_forward(x, st, alpha, residual=r)
+        f_ref, i_ref = F.global_maxpool_forward(y_ref)
+        y, feat, fidx = F.bn_act_forward_rec(x, st, alpha, r, True, True)
+        assert torch.equal(y, y_ref) and torch.equal(feat, f_ref) and torch.equal(fidx, i_ref)
+        assert F._PRESTATS
+        rm0 = bn_next.running_mean.clone()
+        st_new = F.bn_prepare(y, bn_next, True)             # takes the folded statistics
+        assert not F._PRESTATS
+        st_ref = F.bn_prepare(y_ref.clone(), bn_next, True)  # a different tensor: the separate pass
+        assert not torch.equal(bn_next.running_mean, rm0)
+        assert torch.equal(st_new.minmax, st_ref.minmax)
+        torch.testing.assert_close(st_new.mean, st_ref.mean, rtol=1e-6, atol=1e-7)
+        torch.testing.assert_close(st_new.invstd, st_ref.invstd, rtol=1e-6, atol=0)
+        torch.testing.assert_close(st_new.scale, st_ref.scale, rtol=1e-6, atol=0)
+        torch.testing.assert_close(st_new.shift, st_ref.shift, rtol=1e-5, atol=1e-6)
+    # only the pooled values (inference), ties and NaN: first maximum, NaN wins -- as torch.max
+    x2 = torch.randint(-2, 3, (n, c, h, w), device=DEV).float()
+    x2[0, 0].view(-1)[h * w // 2] = float("nan")
+    st.scale.fill_(1.0)
+    st.shift.fill_(0.0)
+    y2, feat2, fidx2 = F.bn_act_forward_rec(x2, st, None, None, False, True)
+    assert not F._PRESTATS
+    f_ref, i_ref = F.global_maxpool_forward(y2)
+    assert torch.equal(fidx2, i_ref) and torch.equal(feat2.isnan(), f_ref.isnan())
+    assert torch.equal(feat2.nan_to_num(7.0), f_ref.nan_to_num(7.0))
+    assert fidx2[0, 0].item() == h * w // 2
+    # a modified tensor does not take stale statistics
+    y3, _, _ = F.bn_act_forward_rec(x, st, None, None, True, False)
+    y3.add_(1.0)
+    st3 = F.bn_prepare(y3, bn_next, True)
+    torch.testing.assert_close(st3.mean, y3.mean((0, 2, 3)), rtol=1e-5, atol=1e-5)
