@@ -56,8 +56,14 @@ __device__ __attribute__((aligned(16))) float g_zero16_l[4] = {0.f, 0.f, 0.f, 0.
 
 __device__ __forceinline__ int fdiv(int x, float inv) { return (int)(((float)x + 0.5f) * inv); }
 
+// 16-byte LDS-DMA (lane i writes lds_wave_base + 16 i).  Issued as inline assembly on purpose: hipcc knows that the builtin
+// writes LDS and, unable to tell the stages of the dynamic LDS block apart, puts `s_waitcnt vmcnt(0)` in front of the next LDS
+// read -- i.e. waits for the copy it has just issued for a LATER step before computing the current one (measured: the kernels
+// ran 20-37 % faster with the copies removed, and not at all faster with the explicit waits removed).  The waits of these
+// kernels are explicit (`s_waitcnt vmcnt(N)` before the barrier that publishes a stage).
 __device__ __forceinline__ void glds16(const void* src, void* lds_wave_base) {
-    __builtin_amdgcn_global_load_lds((glb_ptr)src, (lds_ptr)lds_wave_base, 16, 0, 0);
+    const unsigned m = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_ptr)lds_wave_base);
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(m) : "memory", "m0");
 }
 
 using l16::split2_pair;
@@ -66,6 +72,14 @@ using l16::field_to_float;
 using l16::inv_scale;
 __device__ __forceinline__ f32x4 mfma16(u32x4 a, u32x4 b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+// lane ^ 1 and lane ^ 8 inside a row of 16 lanes as DPP moves (quad_perm [1,0,3,2], row_ror:8): __shfl_xor goes through
+// ds_bpermute and the LDS queue
+__device__ __forceinline__ float dpp_xor1(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float dpp_xor8(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x128, 0xF, 0xF, true));
 }
 __device__ __forceinline__ void raw_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
@@ -569,9 +583,9 @@ __global__ __launch_bounds__(kWaves * 64) void conv_l16_fwd_kernel(LGeom g, cons
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const float v0 = fmaf(acc[i][j][r] * inv_x, inv_w, bv[r]);
-                        const float v1 = __shfl_xor(v0, 1);
-                        const float v2 = __shfl_xor(v0, 8);
-                        const float v3 = __shfl_xor(v1, 8);
+                        const float v1 = dpp_xor1(v0);
+                        const float v2 = dpp_xor8(v0);
+                        const float v3 = dpp_xor8(v1);
                         float best = v0;                     // first maximum in window order, NaN wins (fsc_maxpool_fwd)
                         int bi = 0;
                         if (v1 > best || v1 != v1) { best = v1; bi = 1; }

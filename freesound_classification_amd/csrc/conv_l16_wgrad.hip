@@ -53,8 +53,11 @@ struct WGeom {
 
 __device__ __attribute__((aligned(16))) float g_zero16_w[4] = {0.f, 0.f, 0.f, 0.f};
 
+// 16-byte LDS-DMA as inline assembly (see conv_l16.hip glds16: behind the builtin hipcc waits for the copy of the NEXT unit
+// before the first LDS read of the current one).  The wait is explicit: vmcnt(0) before the barrier that opens a unit.
 __device__ __forceinline__ void glds16(const void* src, void* lds_wave_base) {
-    __builtin_amdgcn_global_load_lds((glb_ptr)src, (lds_ptr)lds_wave_base, 16, 0, 0);
+    const unsigned m = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_ptr)lds_wave_base);
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(m) : "memory", "m0");
 }
 __device__ __forceinline__ f32x4 mfma16(u32x4 a, u32x4 b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
@@ -216,7 +219,8 @@ __global__ __launch_bounds__(kWaves * 64) void conv_l16_wgrad_kernel(WGeom g, co
         if (split < g.units) issue_unit(split, 0);
 #pragma unroll 1
         for (int u = split; u < g.units; u += g.nsplit) {
-            __syncthreads();                  // unit u has landed (vmcnt drained); everyone is done with the other stage
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // unit u has landed ...
+            __syncthreads();                  // ... for every wave; everyone is done with the other stage
             if (u + g.nsplit < g.units) issue_unit(u + g.nsplit, stage ^ 1);
             const char* dl = reinterpret_cast<const char*>(smem4 + stage * stage_u4);
             const char* il = dl + (size_t)co_oct * 2 * g.du * 16;
