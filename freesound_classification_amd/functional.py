@@ -377,8 +377,8 @@ def l16_wgrad_plan_name(desc):
     return buf.value.decode().split(" ")[0]
 
 
-def conv_l16_wgrad(x16, dout16, weight_shape):
-    """Weight gradient from the L16 input and L16 output gradient of a stride-1 same-pad convolution."""
+def conv_l16_wgrad(x16, dout16, weight_shape, out=None):
+    """Weight gradient from the L16 input and L16 output gradient of a stride-1 same-pad convolution (into `out` if given)."""
     c_out, c_in, kh, kw = weight_shape
     n, _, h, w = x16.shape
     d = _desc(n, c_in, c_out, h, w, kh, kw, 3)
@@ -386,7 +386,7 @@ def conv_l16_wgrad(x16, dout16, weight_shape):
     if nbytes == 0:
         raise _lib.FscError("conv_l16_wgrad: unsupported shape %s" % [getattr(d, f) for f, _ in d._fields_])
     ws = torch.empty(nbytes // 4, device=x16.data.device, dtype=torch.float32)
-    dw = torch.empty(tuple(weight_shape), device=x16.data.device, dtype=torch.float32)
+    dw = out if out is not None else torch.empty(tuple(weight_shape), device=x16.data.device, dtype=torch.float32)
     if TIMER is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -455,7 +455,7 @@ def join_side_stream(device):
         torch.cuda.current_stream(device).wait_stream(_SIDE[str(device)])
 
 
-def conv_wgrad(x, dout, weight_shape, on_side_stream=False, x_amax=None, dout_amax=None):
+def conv_wgrad(x, dout, weight_shape, on_side_stream=False, x_amax=None, dout_amax=None, out=None):
     """Weight gradient.  With on_side_stream the kernel is launched on the side stream and the caller
     must `join_side_stream` before the result is consumed (ConvBlockFn does)."""
     n, c_in, h, w = x.shape
@@ -467,7 +467,7 @@ def conv_wgrad(x, dout, weight_shape, on_side_stream=False, x_amax=None, dout_am
 
     def run():
         ws = torch.empty(nbytes // 4, device=x.device, dtype=torch.float32)
-        dw = _empty(tuple(weight_shape), x)
+        dw = out if out is not None else _empty(tuple(weight_shape), x)
         xa, da = _operand_amax(x, x_amax), _operand_amax(dout, dout_amax)
         with _timed(d, 2):
             call("fsc_conv_wgrad", C.byref(d), ptr(x), ptr(dout), ptr(dw), ptr(ws), ptr(xa), ptr(da), stream_ptr())
@@ -833,10 +833,14 @@ def _conv_dgrad_any(dout, dout_16, weight, x_shape, dout_amax, accumulate_into=N
     return conv_dgrad(dout, weight, x_shape, accumulate_into=accumulate_into, dout_amax=dout_amax)
 
 
+GRAD_OUT = None       # callable(weight) -> tensor to write that weight's gradient into, or None (parallel.BucketedGradReducer.grad_view)
+
+
 def _conv_wgrad_any(x, x_16, x_amax, dout, dout_16, dout_amax, weight):
+    out = GRAD_OUT(weight) if GRAD_OUT is not None else None        # data-parallel: straight into the all-reduce bucket
     if x_16 is not None and dout_16 is not None and _l16_wgrad_ok_for(x_16.shape, weight):
-        return conv_l16_wgrad(x_16, dout_16, weight.shape)
-    return conv_wgrad(x, dout, weight.shape, True, x_amax=x_amax, dout_amax=dout_amax)
+        return conv_l16_wgrad(x_16, dout_16, weight.shape, out=out)
+    return conv_wgrad(x, dout, weight.shape, True, x_amax=x_amax, dout_amax=dout_amax, out=out)
 
 
 def _grad_formats(x_shape, weight):

@@ -336,6 +336,7 @@ class _TaggingModel(nn.Module):
         if parallel.world_size() > 1 or (parallel.initialized() and os.environ.get("FSC_FORCE_DP") == "1"):
             parallel.broadcast_module(self)
             self._reducer = parallel.BucketedGradReducer(list(self.parameters()))
+            F.GRAD_OUT = self._reducer.grad_view       # weight gradients are written straight into the buckets
             self.optimizer.grad_scale = 1.0 / parallel.world_size()
             if self.sync_bn:
                 self._bn_sync = parallel.SyncBN()

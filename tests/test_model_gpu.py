@@ -403,7 +403,12 @@ def test_data_parallel_path_on_device_single_rank():
                 logits, _, _ = m.training_step(x, y)
                 first = logits.detach().clone() if first is None else first
             torch.cuda.synchronize()
+            if force == "1":
+                # the weight gradients of the accelerated convolutions were written straight into their buckets (no flat copy)
+                n_conv = sum(1 for k, p in m.named_parameters() if p.dim() == 4) - 1      # (the stem has its own path)
+                assert n_conv > 0 and m._reducer.in_place >= n_conv, (m._reducer.in_place, n_conv)
             results.append((first, {k: v.detach().clone() for k, v in m.state_dict().items()}))
+        F.GRAD_OUT = None
         assert torch.equal(results[0][0], results[1][0])          # same init, same first forward
         # after two Adam steps: equal up to the float-atomic ordering noise of the conv-bias gradients
         # (analytically zero; Adam turns that noise into +-lr moves)
