@@ -360,7 +360,7 @@ def conv_l16_pool(t, weight, bias, prepacked=None):
     call("fsc_conv_l16_pool_fwd", C.byref(d), ptr(t.data), ptr(t.amax), ptr(packed), ptr(bias), ptr(y), ptr(idx), stream_ptr())
     if TIMER is not None:
         e1.record()
-        TIMER.records.append((l16_plan_name(d, 0), 2.0 * n * h * w * c_in * c_out * kh * kw, e0, e1))
+        TIMER.records.append((l16_plan_name(d, 0).replace(">", ",pool>"), 2.0 * n * h * w * c_in * c_out * kh * kw, e0, e1))
     return y, idx, (n, c_out, h, w)
 
 
@@ -536,7 +536,7 @@ def bn_act_forward_rec(x, st, alpha, residual, want_stats, want_gmax):
     return y, feat, fidx
 
 
-def bn_prepare(x, bn, training, sync=None):
+def bn_prepare(x, bn, training, sync=None, defer=None):
     """Batch statistics (training; also updates the running stats, once) or running statistics
     (eval) -> per-channel scale/shift.  `sync` (a callable that sum-all-reduces a device tensor in place over the
     data-parallel replicas, see parallel.SyncBN) turns the batch statistics into cross-replica statistics."""
@@ -553,7 +553,10 @@ def bn_prepare(x, bn, training, sync=None):
         track = training and bn.track_running_stats and bn.running_mean is not None
         momentum = 0.1 if bn.momentum is None else bn.momentum
         if track:
-            bn.num_batches_tracked.add_(1)
+            if defer is not None and bn.momentum is not None:
+                defer.append(bn.num_batches_tracked)       # (the caller bumps the counters of a block in one launch)
+            else:
+                bn.num_batches_tracked.add_(1)
             if bn.momentum is None:
                 momentum = 1.0 / float(bn.num_batches_tracked)
         ws = _take_prestats(x)                             # reduced by the kernel that wrote x?
@@ -864,8 +867,9 @@ def _block_forward(x, mods, training, want_head, ph, keep, sync=None, next_bn=Fa
     reference's nn.Sequential of parameter holders.  Returns (out, feat, ctx)."""
     bn_a, conv_a, _pool, bn_b, prelu_b, res = mods[0], mods[1], mods[2], mods[3], mods[4], mods[5]
     k = _BlockCtx()
+    counters = []                      # num_batches_tracked of the five BatchNorms: one launch at the end
     k.x_shape = tuple(x.shape)
-    st_a = bn_prepare(x, bn_a, training, sync)
+    st_a = bn_prepare(x, bn_a, training, sync, counters)
     w_a, b_a = _conv_params(conv_a)
     # Operands of convolutions that have an L16 tiling are written pre-split by the BN / PReLU kernel that produces them
     # (`*_16`); the fp32 copy stays for the weight gradient (and, for b, the residual).
@@ -896,19 +900,19 @@ def _block_forward(x, mods, training, want_head, ph, keep, sync=None, next_bn=Fa
             p, pidx = maxpool_forward(c, ph)
             k.c_shape = tuple(c.shape)
             del c
-    st_b = bn_prepare(p, bn_b, training, sync)
+    st_b = bn_prepare(p, bn_b, training, sync, counters)
     w1, b1 = _conv_params(res.conv1)
     b, b_max, b_16 = _bn_fwd_for_conv(p, st_b, prelu_b.weight, w1, keep_f32=True)      # (the residual reads it)
     r1 = _conv_fwd_any(b, b_16, w1, b1, b_max, packs)
-    st1 = bn_prepare(r1, res.bn1, training, sync)
+    st1 = bn_prepare(r1, res.bn1, training, sync, counters)
     w2, b2 = _conv_params(res.conv2)
     s1, s1_max, s1_16 = _bn_fwd_for_conv(r1, st1, res.prelu1.weight, w2)
     r2 = _conv_fwd_any(s1, s1_16, w2, b2, s1_max, packs)
-    st2 = bn_prepare(r2, res.bn2, training, sync)
+    st2 = bn_prepare(r2, res.bn2, training, sync, counters)
     w3, b3 = _conv_params(res.conv3)
     s2, s2_max, s2_16 = _bn_fwd_for_conv(r2, st2, res.prelu2.weight, w3)
     r3 = _conv_fwd_any(s2, s2_16, w3, b3, s2_max, packs)
-    st3 = bn_prepare(r3, res.bn3, training, sync)
+    st3 = bn_prepare(r3, res.bn3, training, sync, counters)
     feat, fidx = (None, None)
     if FUSE_OUT_STATS and h_w_min(r3) * max(r3.shape[2], r3.shape[3]) > 1 and (want_head or (training and next_bn)):
         out, feat, fidx = bn_act_forward_rec(r3, st3, res.prelu3.weight, b, training and next_bn, want_head)
@@ -924,6 +928,8 @@ def _block_forward(x, mods, training, want_head, ph, keep, sync=None, next_bn=Fa
         k.amax = (a_max, b_max, s1_max, s2_max)
         k.l16 = (a_16, b_16, s1_16, s2_16)
         k.packs = packs                    # [conv_a, conv1, conv2, conv3]
+    if counters:
+        torch._foreach_add_(counters, 1)
     return out, feat, k
 
 
