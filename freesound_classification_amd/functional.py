@@ -5,6 +5,7 @@ memory, streams, the autograd tape); every number is produced by a hand-written 
 Layout: activations are NCHW fp32 like the reference; the 1-d model runs with H == 1.
 """
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -378,26 +379,47 @@ def l16_wgrad_plan_name(desc):
 
 
 def conv_l16_wgrad(x16, dout16, weight_shape, out=None):
-    """Weight gradient from the L16 input and L16 output gradient of a stride-1 same-pad convolution (into `out` if given)."""
+    """Weight gradient from the L16 input and L16 output gradient of a stride-1 same-pad convolution (into `out` if given).
+    With L16_WGRAD_SIDE the kernel runs on the side stream (the caller joins it: ConvBlockFn.backward does)."""
     c_out, c_in, kh, kw = weight_shape
     n, _, h, w = x16.shape
     d = _desc(n, c_in, c_out, h, w, kh, kw, 3)
     nbytes = _lib.load().fsc_conv_l16_wgrad_workspace_bytes(C.byref(d))
     if nbytes == 0:
         raise _lib.FscError("conv_l16_wgrad: unsupported shape %s" % [getattr(d, f) for f, _ in d._fields_])
-    ws = torch.empty(nbytes // 4, device=x16.data.device, dtype=torch.float32)
-    dw = out if out is not None else torch.empty(tuple(weight_shape), device=x16.data.device, dtype=torch.float32)
-    if TIMER is not None:
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-    call("fsc_conv_l16_wgrad", C.byref(d), ptr(x16.data), ptr(x16.amax), ptr(dout16.data), ptr(dout16.amax), ptr(dw), ptr(ws),
-         stream_ptr())
-    if TIMER is not None:
-        e1.record()
-        TIMER.records.append((l16_wgrad_plan_name(d), 2.0 * n * h * w * c_in * c_out * kh * kw, e0, e1))
+    dev = x16.data.device
+
+    def run():
+        ws = torch.empty(nbytes // 4, device=dev, dtype=torch.float32)
+        dw = out if out is not None else torch.empty(tuple(weight_shape), device=dev, dtype=torch.float32)
+        if TIMER is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        call("fsc_conv_l16_wgrad", C.byref(d), ptr(x16.data), ptr(x16.amax), ptr(dout16.data), ptr(dout16.amax), ptr(dw), ptr(ws),
+             stream_ptr())
+        if TIMER is not None:
+            e1.record()
+            TIMER.records.append((l16_wgrad_plan_name(d), 2.0 * n * h * w * c_in * c_out * kh * kw, e0, e1))
+        return dw
+
+    if not L16_WGRAD_SIDE:
+        return run()
+    main = torch.cuda.current_stream(dev)
+    side = _side_stream(dev)
+    side.wait_stream(main)                    # operands were produced on the main stream
+    with torch.cuda.stream(side):
+        dw = run()
+    for t in (x16.data, x16.amax, dout16.data, dout16.amax):
+        t.record_stream(side)                 # keep the allocator from recycling them under the kernel
+    dw.record_stream(main)
     return dw
 
 
+# FSC_L16_WGRAD_SIDE=1: the L16 weight-gradient kernels run on the side stream beside the BatchNorm backward passes of the next
+# layer (measured at cfg 2, same box: 36.92 -> 36.36 ms per step).  Off by default: with two kernels sharing the CUs the per-kernel
+# durations that bench.py's roofline and the rocprof tables attribute are no longer those of the kernel alone (the weight-gradient
+# launches read 2.2x longer while the step gets shorter).
+L16_WGRAD_SIDE = os.environ.get("FSC_L16_WGRAD_SIDE", "0") == "1"
 _L16_OK = {}
 USE_L16 = True        # route convolutions through the pre-split (L16) kernels where the library has a tiling for them
 
