@@ -78,6 +78,9 @@ __device__ __forceinline__ f32x4 mfma16(u32x4 a, u32x4 b, f32x4 c) {
 __device__ __forceinline__ float dpp_xor1(float v) {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true));
 }
+__device__ __forceinline__ float dpp_xor2(float v) {      // quad_perm [2,3,0,1]
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true));
+}
 __device__ __forceinline__ float dpp_xor8(float v) {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x128, 0xF, 0xF, true));
 }
@@ -233,14 +236,22 @@ __global__ __launch_bounds__(256) void l16_wmax_kernel(const float* __restrict__
 // sit in lanes lm, lm + 1, lm + 8, lm + 9 of one MFMA column group -- the epilogue pools with two shuffles per value (same
 // first-maximum / NaN rule as fsc_maxpool_fwd) and writes the pooled tensor and the window indices; the full-resolution output
 // (1 GB at the first such layer of cfg 2) is never written and the separate max-pool pass disappears.  `out` = pooled tensor.
-template <int KH, int KW, int COT, int PT, bool POOL = false>
+// STATS: the forward of a convolution whose output goes into a BatchNorm (every convolution of a block: classifiers.py:78-101,
+// 524-533): the epilogue also accumulates, per lane and output channel, sum (y - pivot), sum (y - pivot)^2, min y, max y of what
+// it stores (y = the pooled value with POOL) -- the statistics pass over the output disappears.  A worker keeps ONE channel
+// block for all its items (the host makes the worker count a multiple of the channel blocks), so the sums stay in registers
+// until the end of the kernel: one float4 record per (worker, wave, channel) in `stat_rec`, folded by
+// fsc_bn_records_fold_conv.  pivot = stat_pivot[channel] (the BatchNorm's running mean: close to the batch mean) or 0.
+template <int KH, int KW, int COT, int PT, bool POOL = false, bool STATS = false>
 __global__ __launch_bounds__(kWaves * 64) void conv_l16_fwd_kernel(LGeom g, const uint4* __restrict__ in,
                                                                     const float* __restrict__ packed,
                                                                     const float* __restrict__ bias,
                                                                     float* __restrict__ out, int accumulate,
                                                                     const float* __restrict__ in_amax,
                                                                     const float* __restrict__ w_amax,
-                                                                    uint8_t* __restrict__ pool_idx = nullptr) {
+                                                                    uint8_t* __restrict__ pool_idx = nullptr,
+                                                                    const float* __restrict__ stat_pivot = nullptr,
+                                                                    float4* __restrict__ stat_rec = nullptr) {
     constexpr int TAPS = KH * KW;
     constexpr int CO_BLK = COT * 16;
     constexpr int PADH = KH / 2, PADW = KW / 2;
@@ -322,6 +333,18 @@ __global__ __launch_bounds__(kWaves * 64) void conv_l16_fwd_kernel(LGeom g, cons
     for (int i = 0; i < COT; ++i)
 #pragma unroll
         for (int j = 0; j < PT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    constexpr int NST = STATS ? COT : 1;
+    float st_s1[NST], st_s2[NST], st_mn[NST], st_mx[NST];
+#pragma unroll
+    for (int i = 0; i < NST; ++i) { st_s1[i] = 0.f; st_s2[i] = 0.f; st_mn[i] = INFINITY; st_mx[i] = -INFINITY; }
+    auto stat_add = [&](int i, float y, float pv) {
+        const float a = y - pv;
+        st_s1[i] += a;
+        st_s2[i] = fmaf(a, a, st_s2[i]);
+        st_mn[i] = fminf(st_mn[i], y);
+        st_mx[i] = fmaxf(st_mx[i], y);
+    };
 
     // ---- DMA issue
     const uint4* const zero = reinterpret_cast<const uint4*>(g_zero16_l);
@@ -578,6 +601,8 @@ __global__ __launch_bounds__(kWaves * 64) void conv_l16_fwd_kernel(LGeom g, cons
                     bv[r] = (bias_p != nullptr && cob < g.cout) ? bias_p[cob] : 0.f;
                 }
                 const int co = co0 + i * 16 + chp;
+                float pv = 0.f;
+                if (STATS && stat_pivot != nullptr && co < g.cout) pv = stat_pivot[co];
 #pragma unroll
                 for (int j = 0; j < PT; ++j) {
 #pragma unroll
@@ -601,6 +626,7 @@ __global__ __launch_bounds__(kWaves * 64) void conv_l16_fwd_kernel(LGeom g, cons
                     if (co < g.cout && pool_g[j] >= 0) {
                         out[pool_g[j] + (long)co * ohw] = val;
                         pool_idx[pool_g[j] + (long)co * ohw] = (uint8_t)bidx;
+                        if (STATS) stat_add(i, val, pv);
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);
@@ -652,11 +678,23 @@ __global__ __launch_bounds__(kWaves * 64) void conv_l16_fwd_kernel(LGeom g, cons
                 bv[r] = (add_bias && cob < g.cout) ? bias_t[cob] : 0.f;
             }
             const int co = co0 + i * 16 + ch;
+            float pv = 0.f;
+            if (STATS && stat_pivot != nullptr && co < g.cout) pv = stat_pivot[co];
 #pragma unroll
             for (int j = 0; j < PT; ++j) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) scratch[(kq * 4 + r) * kScr + lm] = fmaf(acc[i][j][r] * inv_x, inv_w, bv[r]);
                 const f32x4 v = *reinterpret_cast<const f32x4*>(scratch + ch * kScr + (lane & 3) * 4);
+                if (STATS && co < g.cout && quad_ok[j]) {
+                    if (quad_ok[j] == 15) {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) stat_add(i, v[k], pv);
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k)
+                            if (quad_ok[j] & (1 << k)) stat_add(i, v[k], pv);
+                    }
+                }
                 if (co < g.cout && quad_ok[j]) {
                     float* o = out + quad_g[j] + (long)co * hw_t;
                     if (!accumulate && quad_ok[j] == 15) {
@@ -678,6 +716,19 @@ __global__ __launch_bounds__(kWaves * 64) void conv_l16_fwd_kernel(LGeom g, cons
 #pragma unroll
             for (int j = 0; j < PT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
         drain = true;                                       // (1x1) the stores above share the DMA counter
+    }
+    if constexpr (STATS) {
+        // the four lanes of a quad hold the same channel: fold them, lane (lane & 3) == 0 writes the record
+#pragma unroll
+        for (int i = 0; i < COT; ++i) {
+            float a = st_s1[i], b = st_s2[i], mn = st_mn[i], mx = st_mx[i];
+            a += dpp_xor1(a); a += dpp_xor2(a);
+            b += dpp_xor1(b); b += dpp_xor2(b);
+            mn = fminf(mn, dpp_xor1(mn)); mn = fminf(mn, dpp_xor2(mn));
+            mx = fmaxf(mx, dpp_xor1(mx)); mx = fmaxf(mx, dpp_xor2(mx));
+            if ((lane & 3) == 0)
+                stat_rec[((long)blockIdx.x * kWaves + wid) * CO_BLK + i * 16 + (lane >> 2)] = make_float4(a, b, mn, mx);
+        }
     }
 }
 
@@ -811,49 +862,72 @@ bool plan_l16_pool(const fsc_conv_desc& d, LPlan* out) {
 
 size_t l16_limb_floats(const LPlan& p) { return (size_t)p.co_blocks * p.g.steps * p.cot * 2 * 256; }
 
+// statistics records (STATS kernels): the worker count is cut to a multiple of the channel blocks so that a worker keeps its block
+struct StatArgs { const float* pivot; float4* rec; };
+unsigned stat_workers(const LPlan& p) { return (unsigned)(p.workers - p.workers % p.co_blocks); }
+bool stats_ok(const LPlan& p) { return p.cot <= 8 && p.workers >= p.co_blocks; }
+
 template <int KH, int KW, int COT, int PT>
 int launch_l16(const LPlan& p, const uint4* in, const float* packed, const float* bias, float* out, int accumulate,
-               const float* in_amax, hipStream_t st) {
+               const float* in_amax, hipStream_t st, StatArgs sa = StatArgs{nullptr, nullptr}) {
+    const float* w_amax = packed + l16_limb_floats(p);
+    if constexpr (COT <= 8) {
+        if (sa.rec) {
+            auto kern = conv_l16_fwd_kernel<KH, KW, COT, PT, false, true>;
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes);
+            hipLaunchKernelGGL(kern, dim3(stat_workers(p)), dim3(kWaves * 64), p.lds_bytes, st, p.g, in, packed, bias, out, 0, in_amax,
+                               w_amax, (uint8_t*)nullptr, sa.pivot, sa.rec);
+            FSC_LAUNCH_CHECK("fsc_conv_l16_fwd_stats");
+            return 0;
+        }
+    }
     auto kern = conv_l16_fwd_kernel<KH, KW, COT, PT, false>;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes);
-    const float* w_amax = packed + l16_limb_floats(p);
     hipLaunchKernelGGL(kern, dim3((unsigned)p.workers), dim3(kWaves * 64), p.lds_bytes, st, p.g, in, packed, bias, out,
-                       accumulate, in_amax, w_amax, (uint8_t*)nullptr);
+                       accumulate, in_amax, w_amax, (uint8_t*)nullptr, (const float*)nullptr, (float4*)nullptr);
     FSC_LAUNCH_CHECK("fsc_conv_l16_fwd");
     return 0;
 }
 
 template <int COT>
 int launch_l16_pool(const LPlan& p, const uint4* in, const float* packed, const float* bias, float* pooled, uint8_t* idx,
-                    const float* in_amax, hipStream_t st) {
+                    const float* in_amax, hipStream_t st, StatArgs sa = StatArgs{nullptr, nullptr}) {
+    const float* w_amax = packed + l16_limb_floats(p);
+    if (sa.rec) {
+        auto kern = conv_l16_fwd_kernel<3, 3, COT, 2, true, true>;
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes);
+        hipLaunchKernelGGL(kern, dim3(stat_workers(p)), dim3(kWaves * 64), p.lds_bytes, st, p.g, in, packed, bias, pooled, 0, in_amax,
+                           w_amax, idx, sa.pivot, sa.rec);
+        FSC_LAUNCH_CHECK("fsc_conv_l16_pool_fwd_stats");
+        return 0;
+    }
     auto kern = conv_l16_fwd_kernel<3, 3, COT, 2, true>;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes);
-    const float* w_amax = packed + l16_limb_floats(p);
     hipLaunchKernelGGL(kern, dim3((unsigned)p.workers), dim3(kWaves * 64), p.lds_bytes, st, p.g, in, packed, bias, pooled, 0,
-                       in_amax, w_amax, idx);
+                       in_amax, w_amax, idx, (const float*)nullptr, (float4*)nullptr);
     FSC_LAUNCH_CHECK("fsc_conv_l16_pool_fwd");
     return 0;
 }
 
 template <int KH, int KW, int COT>
 int launch_l16_pt(const LPlan& p, const uint4* in, const float* packed, const float* bias, float* out, int accumulate,
-                  const float* in_amax, hipStream_t st) {
-    if (p.pt == 2) return launch_l16<KH, KW, COT, 2>(p, in, packed, bias, out, accumulate, in_amax, st);
-    return launch_l16<KH, KW, COT, 1>(p, in, packed, bias, out, accumulate, in_amax, st);
+                  const float* in_amax, hipStream_t st, StatArgs sa = StatArgs{nullptr, nullptr}) {
+    if (p.pt == 2) return launch_l16<KH, KW, COT, 2>(p, in, packed, bias, out, accumulate, in_amax, st, sa);
+    return launch_l16<KH, KW, COT, 1>(p, in, packed, bias, out, accumulate, in_amax, st, sa);
 }
 
 template <int KH, int KW>
 int launch_l16_cot(const LPlan& p, const uint4* in, const float* packed, const float* bias, float* out, int accumulate,
-                   const float* in_amax, hipStream_t st) {
+                   const float* in_amax, hipStream_t st, StatArgs sa = StatArgs{nullptr, nullptr}) {
     switch (p.cot) {
-        case 3: return launch_l16_pt<KH, KW, 3>(p, in, packed, bias, out, accumulate, in_amax, st);
-        case 4: return launch_l16_pt<KH, KW, 4>(p, in, packed, bias, out, accumulate, in_amax, st);
-        case 5: return launch_l16_pt<KH, KW, 5>(p, in, packed, bias, out, accumulate, in_amax, st);
-        case 6: return launch_l16_pt<KH, KW, 6>(p, in, packed, bias, out, accumulate, in_amax, st);
-        case 7: return launch_l16_pt<KH, KW, 7>(p, in, packed, bias, out, accumulate, in_amax, st);
-        case 8: return launch_l16_pt<KH, KW, 8>(p, in, packed, bias, out, accumulate, in_amax, st);
-        case 9: if constexpr (KH * KW > 1) return launch_l16_pt<KH, KW, 9>(p, in, packed, bias, out, accumulate, in_amax, st); break;
-        case 10: if constexpr (KH * KW > 1) return launch_l16_pt<KH, KW, 10>(p, in, packed, bias, out, accumulate, in_amax, st); break;
+        case 3: return launch_l16_pt<KH, KW, 3>(p, in, packed, bias, out, accumulate, in_amax, st, sa);
+        case 4: return launch_l16_pt<KH, KW, 4>(p, in, packed, bias, out, accumulate, in_amax, st, sa);
+        case 5: return launch_l16_pt<KH, KW, 5>(p, in, packed, bias, out, accumulate, in_amax, st, sa);
+        case 6: return launch_l16_pt<KH, KW, 6>(p, in, packed, bias, out, accumulate, in_amax, st, sa);
+        case 7: return launch_l16_pt<KH, KW, 7>(p, in, packed, bias, out, accumulate, in_amax, st, sa);
+        case 8: return launch_l16_pt<KH, KW, 8>(p, in, packed, bias, out, accumulate, in_amax, st, sa);
+        case 9: if constexpr (KH * KW > 1) return launch_l16_pt<KH, KW, 9>(p, in, packed, bias, out, accumulate, in_amax, st, sa); break;
+        case 10: if constexpr (KH * KW > 1) return launch_l16_pt<KH, KW, 10>(p, in, packed, bias, out, accumulate, in_amax, st, sa); break;
         default: break;
     }
     fsc::set_error("fsc_conv_l16_fwd: internal: no instantiation for %d channel tiles", p.cot);
@@ -953,25 +1027,60 @@ int fsc_conv_l16_fwd(const fsc_conv_desc* d, const void* in_l16, const float* in
     return launch_l16_cot<1, 1>(p, in, packed, bias, out, accumulate, in_amax, st);
 }
 
+/* statistics records of the STATS forward: out3 = {workers, channel blocks, channels per block}; the records are
+ * workers * 8 * channels-per-block float4 {sum (y - pivot), sum (y - pivot)^2, min, max}; worker w holds channel block w % blocks */
+int fsc_conv_l16_stats_layout(const fsc_conv_desc* d, int pool, int* out3) {
+    LPlan p;
+    if (!valid_l16_desc(d) || !out3) return 0;
+    if (!(pool ? plan_l16_pool(*d, &p) : plan_l16(*d, 0, &p)) || !stats_ok(p)) return 0;
+    out3[0] = (int)stat_workers(p); out3[1] = p.co_blocks; out3[2] = p.cot * 16;
+    return 1;
+}
+
+int fsc_conv_l16_fwd_stats(const fsc_conv_desc* d, const void* in_l16, const float* in_amax, const float* packed,
+                           const float* bias, float* out, const float* stat_pivot, void* stat_rec, fsc_stream_t stream) {
+    LPlan p;
+    FSC_CHECK_ARG(valid_l16_desc(d) && in_l16 && in_amax && packed && out && stat_rec, "fsc_conv_l16_fwd_stats: bad descriptor or null pointer");
+    FSC_CHECK_ARG(plan_l16(*d, 0, &p) && stats_ok(p), "fsc_conv_l16_fwd_stats: unsupported shape (see fsc_conv_l16_stats_layout)");
+    hipStream_t st = fsc::as_stream(stream);
+    const uint4* in = reinterpret_cast<const uint4*>(in_l16);
+    const StatArgs sa{stat_pivot, reinterpret_cast<float4*>(stat_rec)};
+    if (d->kh == 3) return launch_l16_cot<3, 3>(p, in, packed, bias, out, 0, in_amax, st, sa);
+    return launch_l16_cot<1, 1>(p, in, packed, bias, out, 0, in_amax, st, sa);
+}
+
 int fsc_conv_l16_pool_supported(const fsc_conv_desc* d) {
     LPlan p;
     return valid_l16_desc(d) && plan_l16_pool(*d, &p) ? 1 : 0;
 }
 
-int fsc_conv_l16_pool_fwd(const fsc_conv_desc* d, const void* in_l16, const float* in_amax, const float* packed,
-                          const float* bias, float* pooled, uint8_t* idx, fsc_stream_t stream) {
+static int pool_fwd_impl(const fsc_conv_desc* d, const void* in_l16, const float* in_amax, const float* packed, const float* bias,
+                         float* pooled, uint8_t* idx, StatArgs sa, fsc_stream_t stream) {
     LPlan p;
     FSC_CHECK_ARG(valid_l16_desc(d) && in_l16 && in_amax && packed && pooled && idx, "fsc_conv_l16_pool_fwd: bad descriptor or null pointer");
     FSC_CHECK_ARG(plan_l16_pool(*d, &p), "fsc_conv_l16_pool_fwd: unsupported shape (see fsc_conv_l16_pool_supported)");
+    FSC_CHECK_ARG(!sa.rec || stats_ok(p), "fsc_conv_l16_pool_fwd_stats: unsupported shape (see fsc_conv_l16_stats_layout)");
     hipStream_t st = fsc::as_stream(stream);
     const uint4* in = reinterpret_cast<const uint4*>(in_l16);
     switch (p.cot) {
-        case 4: return launch_l16_pool<4>(p, in, packed, bias, pooled, idx, in_amax, st);
-        case 5: return launch_l16_pool<5>(p, in, packed, bias, pooled, idx, in_amax, st);
-        case 6: return launch_l16_pool<6>(p, in, packed, bias, pooled, idx, in_amax, st);
-        case 7: return launch_l16_pool<7>(p, in, packed, bias, pooled, idx, in_amax, st);
-        default: return launch_l16_pool<8>(p, in, packed, bias, pooled, idx, in_amax, st);
+        case 4: return launch_l16_pool<4>(p, in, packed, bias, pooled, idx, in_amax, st, sa);
+        case 5: return launch_l16_pool<5>(p, in, packed, bias, pooled, idx, in_amax, st, sa);
+        case 6: return launch_l16_pool<6>(p, in, packed, bias, pooled, idx, in_amax, st, sa);
+        case 7: return launch_l16_pool<7>(p, in, packed, bias, pooled, idx, in_amax, st, sa);
+        default: return launch_l16_pool<8>(p, in, packed, bias, pooled, idx, in_amax, st, sa);
     }
+}
+
+int fsc_conv_l16_pool_fwd(const fsc_conv_desc* d, const void* in_l16, const float* in_amax, const float* packed,
+                          const float* bias, float* pooled, uint8_t* idx, fsc_stream_t stream) {
+    return pool_fwd_impl(d, in_l16, in_amax, packed, bias, pooled, idx, StatArgs{nullptr, nullptr}, stream);
+}
+
+int fsc_conv_l16_pool_fwd_stats(const fsc_conv_desc* d, const void* in_l16, const float* in_amax, const float* packed,
+                                const float* bias, float* pooled, uint8_t* idx, const float* stat_pivot, void* stat_rec,
+                                fsc_stream_t stream) {
+    FSC_CHECK_ARG(stat_rec, "fsc_conv_l16_pool_fwd_stats: null records");
+    return pool_fwd_impl(d, in_l16, in_amax, packed, bias, pooled, idx, StatArgs{stat_pivot, reinterpret_cast<float4*>(stat_rec)}, stream);
 }
 
 int fsc_conv_l16_plan_describe(const fsc_conv_desc* d, int dgrad, char* buf, size_t buf_len) {

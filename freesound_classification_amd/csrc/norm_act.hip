@@ -179,7 +179,7 @@ __global__ void stats_finalize_kernel(const float* __restrict__ x, int c, long h
                                       const float* __restrict__ beta, float eps, float momentum,
                                       float* running_mean, float* running_var, float* save_mean,
                                       float* save_invstd, float* scale, float* shift, double* __restrict__ sync,
-                                      int phase, float* __restrict__ x_minmax) {
+                                      int phase, float* __restrict__ x_minmax, int pivot_rm) {
     const int ch = blockIdx.x * blockDim.x + threadIdx.x;
     if (ch >= c) return;
     if (x_minmax && phase != 2) {          // (phase 2 re-runs on the partials of phase 1: already written)
@@ -201,7 +201,9 @@ __global__ void stats_finalize_kernel(const float* __restrict__ x, int c, long h
             s1 += part[((size_t)ch * kMaxSplit + s) * kPartStride];
             s2 += part[((size_t)ch * kMaxSplit + s) * kPartStride + 1];
         }
-        pivot = (double)x[(long)ch * hw];
+        // pivot of the shifted sums: the channel's first element, or (sums from a STATS convolution) the running mean as it is
+        // BEFORE this call updates it -- 0 without running statistics
+        pivot = pivot_rm ? (running_mean ? (double)running_mean[ch] : 0.0) : (double)x[(long)ch * hw];
         if (phase == 1) {                                  // moments about zero: sum (a + p) and sum (a + p)^2
             sync[ch * 4] = s1 + count * pivot;
             sync[ch * 4 + 1] = s2 + 2.0 * pivot * s1 + count * pivot * pivot;
@@ -469,6 +471,35 @@ __global__ __launch_bounds__(kThreads) void fold_records_kernel(const PlaneRec* 
         }
     }
     if (!part) return;
+    const double t1 = fsc::block_sum<double, kThreads / 64>(s1, scratch);
+    const double t2 = fsc::block_sum<double, kThreads / 64>(s2, scratch);
+    mx = fsc::wave_max(mx);
+    mn = -fsc::wave_max(-mn);
+    if ((threadIdx.x & 63) == 0) { mm[0][threadIdx.x >> 6] = mn; mm[1][threadIdx.x >> 6] = mx; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int i = 1; i < kThreads / 64; ++i) { mn = fminf(mn, mm[0][i]); mx = fmaxf(mx, mm[1][i]); }
+        double* o = part + (size_t)ch * kMaxSplit * kPartStride;
+        o[0] = t1; o[1] = t2; o[2] = (double)mn; o[3] = (double)mx;
+    }
+}
+
+// records of a STATS convolution (conv_l16.hip): float4 {s1, s2, min, max} at [(worker * 8 + wave) * co_blk + channel in block],
+// worker w holds channel block w % blocks.  One workgroup per channel -> split 0 of the statistics partials.
+__global__ __launch_bounds__(kThreads) void fold_conv_records_kernel(const float4* __restrict__ rec, int workers, int blocks, int co_blk,
+                                                                     double* __restrict__ part) {
+    __shared__ double scratch[kThreads / 64];
+    __shared__ float mm[2][kThreads / 64];
+    const int ch = blockIdx.x, cb = ch / co_blk, within = ch - cb * co_blk;
+    const int nrec = (workers / blocks) * 8;
+    double s1 = 0.0, s2 = 0.0;
+    float mn = INFINITY, mx = -INFINITY;
+    for (int r = threadIdx.x; r < nrec; r += kThreads) {
+        const int w = cb + (r >> 3) * blocks, wv = r & 7;
+        const float4 v = rec[((long)w * 8 + wv) * co_blk + within];
+        s1 += (double)v.x; s2 += (double)v.y;
+        mn = fminf(mn, v.z); mx = fmaxf(mx, v.w);
+    }
     const double t1 = fsc::block_sum<double, kThreads / 64>(s1, scratch);
     const double t2 = fsc::block_sum<double, kThreads / 64>(s2, scratch);
     mx = fsc::wave_max(mx);
@@ -1301,7 +1332,7 @@ int fsc_bn_train_stats(const float* x, int n, int c, long hw, const float* gamma
                        float* save_invstd, float* scale, float* shift, void* workspace, double* sync, int phase,
                        float* x_minmax, fsc_stream_t stream) {
     FSC_CHECK_ARG(x && save_mean && save_invstd && scale && shift && workspace, "fsc_bn_train_stats: null pointer");
-    FSC_CHECK_ARG((phase & ~FSC_BN_STATS_FOLDED) == 0 || (((phase & 3) == 1 || (phase & 3) == 2) && sync),
+    FSC_CHECK_ARG((phase & 3) == 0 || (((phase & 3) == 1 || (phase & 3) == 2) && sync),
                   "fsc_bn_train_stats: phase 1 / 2 need `sync`");
     FSC_CHECK_ARG(n > 0 && c > 0 && hw > 0, "fsc_bn_train_stats: bad shape (%d, %d, %ld)", n, c, hw);
     FSC_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr), "fsc_bn_train_stats: running stats must come in pairs");
@@ -1309,7 +1340,8 @@ int fsc_bn_train_stats(const float* x, int n, int c, long hw, const float* gamma
     Partials p = carve(workspace, c);
     int nsplit = 1;
     const bool folded = (phase & FSC_BN_STATS_FOLDED) != 0;      // split 0 of the partials is there already (fsc_bn_records_fold)
-    phase &= ~FSC_BN_STATS_FOLDED;
+    const int pivot_rm = (phase & FSC_BN_STATS_PIVOT_RM) ? 1 : 0;
+    phase &= ~(FSC_BN_STATS_FOLDED | FSC_BN_STATS_PIVOT_RM);
     if (phase != 2 && !folded) {
         if (hw == 1) {
             hipLaunchKernelGGL(stats_rows_kernel, dim3(fsc::ceil_div(c, 128)), dim3(128), 0, st, x, n, c, p.part);
@@ -1321,7 +1353,7 @@ int fsc_bn_train_stats(const float* x, int n, int c, long hw, const float* gamma
     }
     hipLaunchKernelGGL(stats_finalize_kernel, dim3(fsc::ceil_div(c, 128)), dim3(128), 0, st, x, c, hw,
                        (double)n * (double)hw, nsplit, p.part, gamma, beta, eps, momentum, running_mean,
-                       running_var, save_mean, save_invstd, scale, shift, sync, phase, x_minmax);
+                       running_var, save_mean, save_invstd, scale, shift, sync, phase, x_minmax, pivot_rm);
     FSC_LAUNCH_CHECK("fsc_bn_train_stats");
     return 0;
 }
@@ -1369,6 +1401,16 @@ int fsc_bn_records_fold(const void* records, const float* y, int n, int c, long 
     hipLaunchKernelGGL(fold_records_kernel, dim3(c), dim3(kThreads), 0, fsc::as_stream(stream),
                        reinterpret_cast<const PlaneRec*>(records), rec_slices(hw), n, c, hw, y, part, gmax, gmax_idx);
     FSC_LAUNCH_CHECK("fsc_bn_records_fold");
+    return 0;
+}
+
+int fsc_bn_records_fold_conv(const void* records, int workers, int blocks, int co_blk, int c, void* stats_workspace,
+                             fsc_stream_t stream) {
+    FSC_CHECK_ARG(records && stats_workspace && workers > 0 && blocks > 0 && co_blk > 0 && c > 0 && workers % blocks == 0 &&
+                      c <= blocks * co_blk, "fsc_bn_records_fold_conv: bad arguments");
+    hipLaunchKernelGGL(fold_conv_records_kernel, dim3(c), dim3(kThreads), 0, fsc::as_stream(stream),
+                       reinterpret_cast<const float4*>(records), workers, blocks, co_blk, carve(stats_workspace, c).part);
+    FSC_LAUNCH_CHECK("fsc_bn_records_fold_conv");
     return 0;
 }
 

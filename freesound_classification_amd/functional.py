@@ -323,9 +323,49 @@ def conv_l16_pack_pair(weight, n, h, w):
     return ((d, pf) if nf else None), ((d, pd) if nd else None)
 
 
-def conv_l16(t, weight, bias, dgrad=False, accumulate_into=None, prepacked=None):
+CONV_STATS = os.environ.get("FSC_CONV_STATS", "1") == "1"      # forward convolutions reduce the statistics of the BatchNorm they feed
+_STATS_PIVOT_RM = 8        # FSC_BN_STATS_PIVOT_RM
+_STATS_LAYOUT = {}
+
+
+def _stats_layout(d, pool):
+    """(workers, channel blocks, channels per block) of the statistics records of a STATS convolution, or None."""
+    key = tuple(getattr(d, f) for f, _ in d._fields_) + (pool,)
+    if key not in _STATS_LAYOUT:
+        out3 = (C.c_int * 3)()
+        ok = _lib.load().fsc_conv_l16_stats_layout(C.byref(d), 1 if pool else 0, out3)
+        _STATS_LAYOUT[key] = tuple(out3) if ok else None
+    return _STATS_LAYOUT[key]
+
+
+def bn_tracks(bn, training):
+    return bool(training and bn.track_running_stats and bn.running_mean is not None)
+
+
+def _stats_begin(d, pool, stats_bn, like):
+    """Records buffer and pivot of a STATS convolution feeding `stats_bn` = (BatchNorm, training), or (None, None, None)."""
+    if not CONV_STATS or stats_bn is None:
+        return None, None, None
+    lay = _stats_layout(d, pool)
+    if lay is None:
+        return None, None, None
+    bn, training = stats_bn
+    rec = torch.empty(lay[0] * 8 * lay[2] * 4, device=like.device, dtype=torch.float32)
+    return lay, rec, (bn.running_mean if bn_tracks(bn, training) else None)
+
+
+def _stats_end(lay, rec, y, c_out):
+    """Folds the records of the convolution that wrote `y` into a BatchNorm workspace and leaves it for bn_prepare(y, ...)."""
+    ws = _bn_ws(c_out, y)
+    call("fsc_bn_records_fold_conv", ptr(rec), lay[0], lay[1], lay[2], c_out, ptr(ws), stream_ptr())
+    _PRESTATS.clear()
+    _PRESTATS[(y.data_ptr(), tuple(y.shape), y._version, y.device)] = (ws, y, _STATS_FOLDED | _STATS_PIVOT_RM)
+
+
+def conv_l16(t, weight, bias, dgrad=False, accumulate_into=None, prepacked=None, stats_bn=None):
     """Forward (dgrad False: t = input, (N, Cin, H, W)) or input gradient (dgrad True: t = dout (N, Cout, H, W)) of a
-    stride-1 same-pad convolution on an L16 operand; fp32 NCHW result."""
+    stride-1 same-pad convolution on an L16 operand; fp32 NCHW result.  stats_bn = (BatchNorm module, training) (forward only):
+    the kernel also reduces that BatchNorm's statistics of the output (picked up by bn_prepare on this very tensor)."""
     c_out, c_in, kh, kw = weight.shape
     n, _, h, w = t.shape
     dg = 1 if dgrad else 0
@@ -334,17 +374,24 @@ def conv_l16(t, weight, bias, dgrad=False, accumulate_into=None, prepacked=None)
         out, acc = accumulate_into, 1
     else:
         out, acc = torch.empty((n, c_in if dgrad else c_out, h, w), device=weight.device, dtype=torch.float32), 0
+    lay, rec, pivot = _stats_begin(d, False, stats_bn, out) if (not dgrad and acc == 0) else (None, None, None)
     if TIMER is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    call("fsc_conv_l16_fwd", C.byref(d), ptr(t.data), ptr(t.amax), ptr(packed), ptr(bias), dg, acc, ptr(out), stream_ptr())
+    if lay is not None:
+        call("fsc_conv_l16_fwd_stats", C.byref(d), ptr(t.data), ptr(t.amax), ptr(packed), ptr(bias), ptr(out), ptr(pivot), ptr(rec),
+             stream_ptr())
+    else:
+        call("fsc_conv_l16_fwd", C.byref(d), ptr(t.data), ptr(t.amax), ptr(packed), ptr(bias), dg, acc, ptr(out), stream_ptr())
     if TIMER is not None:
         e1.record()
         TIMER.records.append((l16_plan_name(d, dg), 2.0 * n * h * w * c_in * c_out * kh * kw, e0, e1))
+    if lay is not None:
+        _stats_end(lay, rec, out, c_out)
     return out
 
 
-def conv_l16_pool(t, weight, bias, prepacked=None):
+def conv_l16_pool(t, weight, bias, prepacked=None, stats_bn=None):
     """3x3 convolution on an L16 operand fused with MaxPool2d(2) (fsc_conv_l16_pool_fwd): (pooled, window index, conv output
     shape), or None when the library has no fused tiling for the shape."""
     c_out, c_in, kh, kw = weight.shape
@@ -358,10 +405,17 @@ def conv_l16_pool(t, weight, bias, prepacked=None):
     if TIMER is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    call("fsc_conv_l16_pool_fwd", C.byref(d), ptr(t.data), ptr(t.amax), ptr(packed), ptr(bias), ptr(y), ptr(idx), stream_ptr())
+    lay, rec, pivot = _stats_begin(d, True, stats_bn, y)
+    if lay is not None:
+        call("fsc_conv_l16_pool_fwd_stats", C.byref(d), ptr(t.data), ptr(t.amax), ptr(packed), ptr(bias), ptr(y), ptr(idx),
+             ptr(pivot), ptr(rec), stream_ptr())
+    else:
+        call("fsc_conv_l16_pool_fwd", C.byref(d), ptr(t.data), ptr(t.amax), ptr(packed), ptr(bias), ptr(y), ptr(idx), stream_ptr())
     if TIMER is not None:
         e1.record()
         TIMER.records.append((l16_plan_name(d, 0).replace(">", ",pool>"), 2.0 * n * h * w * c_in * c_out * kh * kw, e0, e1))
+    if lay is not None:
+        _stats_end(lay, rec, y, c_out)
     return y, idx, (n, c_out, h, w)
 
 
@@ -532,9 +586,9 @@ def _take_prestats(x):
     """The BatchNorm workspace the producer of `x` filled (bn_act_forward_rec), if x is that very tensor, unmodified."""
     if not _PRESTATS:
         return None
-    key, (ws, _alive) = _PRESTATS.popitem()          # (the entry held the tensor, so its address was not reused meanwhile)
+    key, (ws, _alive, flags) = _PRESTATS.popitem()   # (the entry held the tensor, so its address was not reused meanwhile)
     if key == (x.data_ptr(), tuple(x.shape), x._version, x.device):
-        return ws
+        return ws, flags
     return None
 
 
@@ -554,7 +608,7 @@ def bn_act_forward_rec(x, st, alpha, residual, want_stats, want_gmax):
     call("fsc_bn_records_fold", ptr(rec), ptr(y), n, c, hw, ptr(ws), ptr(feat), ptr(fidx), stream_ptr())
     _PRESTATS.clear()
     if want_stats:
-        _PRESTATS[(y.data_ptr(), tuple(y.shape), y._version, y.device)] = (ws, y)
+        _PRESTATS[(y.data_ptr(), tuple(y.shape), y._version, y.device)] = (ws, y, _STATS_FOLDED)
     return y, feat, fidx
 
 
@@ -581,10 +635,10 @@ def bn_prepare(x, bn, training, sync=None, defer=None):
                 bn.num_batches_tracked.add_(1)
             if bn.momentum is None:
                 momentum = 1.0 / float(bn.num_batches_tracked)
-        ws = _take_prestats(x)                             # reduced by the kernel that wrote x?
-        folded = _STATS_FOLDED if ws is not None else 0
-        if ws is None:
-            ws = _bn_ws(c, x)                              # (kept alive across both phases)
+        pre = _take_prestats(x)                            # reduced by the kernel that wrote x?
+        if pre is not None and (pre[1] & _STATS_PIVOT_RM) and not training:
+            pre = None                                     # (sums about a running mean that this call would not pass: never in practice)
+        ws, folded = pre if pre is not None else (_bn_ws(c, x), 0)      # (kept alive across both phases)
         st.minmax = _empty((2 * c,), x)                    # per-channel [min, max] of x: the L16 producers' bound
         args = (ptr(x), n, c, hw, ptr(gamma), ptr(beta), bn.eps, momentum,
                 ptr(bn.running_mean) if track else None, ptr(bn.running_var) if track else None,
@@ -837,7 +891,7 @@ def _bn_fwd_for_conv(x, st, alpha, weight, keep_f32=False):
     return y, y_max, None
 
 
-def _conv_fwd_any(x, x_16, weight, bias, x_amax, packs=None):
+def _conv_fwd_any(x, x_16, weight, bias, x_amax, packs=None, stats_bn=None):
     """`packs` (a list, training only): the input-gradient fragments of this weight are packed in the same call as the
     forward ones and appended for the backward pass (or None when that direction does not run on the L16 kernels)."""
     if x_16 is not None and _l16_ok_for(x_16.shape, weight, False):
@@ -845,8 +899,8 @@ def _conv_fwd_any(x, x_16, weight, bias, x_amax, packs=None):
             n, _, h, w = x_16.shape
             pf, pd = conv_l16_pack_pair(weight, n, h, w)
             packs.append(pd)
-            return conv_l16(x_16, weight, bias, prepacked=pf)
-        return conv_l16(x_16, weight, bias)
+            return conv_l16(x_16, weight, bias, prepacked=pf, stats_bn=stats_bn)
+        return conv_l16(x_16, weight, bias, stats_bn=stats_bn)
     if packs is not None:
         packs.append(None)
     return conv_forward(x, weight, bias, x_amax=x_amax)
@@ -907,7 +961,7 @@ def _block_forward(x, mods, training, want_head, ph, keep, sync=None, next_bn=Fa
         if POOL_FUSION and ph == 2 and a_16 is not None and _l16_ok_for(a_16.shape, w_a, False):
             n_, _, h_, w_ = a_16.shape
             pf, pd = conv_l16_pack_pair(w_a, n_, h_, w_) if keep else (conv_l16_pack(w_a, n_, h_, w_, False), None)
-            pooled = conv_l16_pool(a_16, w_a, b_a, prepacked=pf)          # conv + max-pool in one kernel (no full-res output)
+            pooled = conv_l16_pool(a_16, w_a, b_a, prepacked=pf, stats_bn=(bn_b, training))     # conv + max-pool (+ bn_b statistics)
             if pooled is not None:
                 p, pidx, k.c_shape = pooled
                 if keep:
@@ -925,15 +979,15 @@ def _block_forward(x, mods, training, want_head, ph, keep, sync=None, next_bn=Fa
     st_b = bn_prepare(p, bn_b, training, sync, counters)
     w1, b1 = _conv_params(res.conv1)
     b, b_max, b_16 = _bn_fwd_for_conv(p, st_b, prelu_b.weight, w1, keep_f32=True)      # (the residual reads it)
-    r1 = _conv_fwd_any(b, b_16, w1, b1, b_max, packs)
+    r1 = _conv_fwd_any(b, b_16, w1, b1, b_max, packs, (res.bn1, training))
     st1 = bn_prepare(r1, res.bn1, training, sync, counters)
     w2, b2 = _conv_params(res.conv2)
     s1, s1_max, s1_16 = _bn_fwd_for_conv(r1, st1, res.prelu1.weight, w2)
-    r2 = _conv_fwd_any(s1, s1_16, w2, b2, s1_max, packs)
+    r2 = _conv_fwd_any(s1, s1_16, w2, b2, s1_max, packs, (res.bn2, training))
     st2 = bn_prepare(r2, res.bn2, training, sync, counters)
     w3, b3 = _conv_params(res.conv3)
     s2, s2_max, s2_16 = _bn_fwd_for_conv(r2, st2, res.prelu2.weight, w3)
-    r3 = _conv_fwd_any(s2, s2_16, w3, b3, s2_max, packs)
+    r3 = _conv_fwd_any(s2, s2_16, w3, b3, s2_max, packs, (res.bn3, training))
     st3 = bn_prepare(r3, res.bn3, training, sync, counters)
     feat, fidx = (None, None)
     if FUSE_OUT_STATS and h_w_min(r3) * max(r3.shape[2], r3.shape[3]) > 1 and (want_head or (training and next_bn)):

@@ -204,6 +204,9 @@ int fsc_bn_train_stats(const float* x, int n, int c, long hw, const float* gamma
  * phase | FSC_BN_STATS_FOLDED: the reduction over x was done by the kernel that WROTE x (fsc_bn_act_fwd_rec +
  * fsc_bn_records_fold into this `workspace`): no statistics pass, only the finalisation (x is still read for the pivot). */
 #define FSC_BN_STATS_FOLDED 4
+/* phase | FSC_BN_STATS_PIVOT_RM (with FSC_BN_STATS_FOLDED): the folded sums are about `running_mean` as it is BEFORE this call
+ * (0 when running_mean is NULL) instead of the channel's first element: the convention of the STATS convolutions below. */
+#define FSC_BN_STATS_PIVOT_RM 8
 /* The last unit of a block (classifiers.py:102-104: bn3 + residual + PReLU) writes a tensor that the next block's input
  * BatchNorm (classifiers.py:524) and the hierarchical head's global max-pool (classifiers.py:586-590) read again at once.
  * fsc_bn_act_fwd_rec = fsc_bn_act_fwd (fp32 y, hw > 1, no amax) that also leaves one record per (plane, slice) --
@@ -217,6 +220,22 @@ int fsc_bn_act_fwd_rec(const float* x, const float* residual, const float* scale
                        const float* alpha, float* y, int n, int c, long hw, void* records, fsc_stream_t stream);
 int fsc_bn_records_fold(const void* records, const float* y, int n, int c, long hw, void* stats_workspace,
                         float* gmax, int* gmax_idx, fsc_stream_t stream);
+/* Statistics from the convolution that PRODUCES the BatchNorm input (classifiers.py:78-101, 524-533: every convolution of a
+ * block feeds a BatchNorm): fsc_conv_l16_fwd_stats / fsc_conv_l16_pool_fwd_stats are fsc_conv_l16_fwd (forward) /
+ * fsc_conv_l16_pool_fwd whose epilogue also accumulates sum (y - pivot), sum (y - pivot)^2, min y, max y per output channel of what
+ * it stores (the pooled values for the pool variant); pivot = stat_pivot[channel] (pass the BatchNorm's running_mean; NULL = 0).
+ * fsc_conv_l16_stats_layout -> 1 and out3 = {workers, channel blocks, channels per block} when the shape has such a kernel;
+ * `stat_rec` holds workers * 8 * channels-per-block records of 16 bytes.  fsc_bn_records_fold_conv folds them into split 0 of a
+ * BatchNorm workspace; then fsc_bn_train_stats(..., phase | FSC_BN_STATS_FOLDED | FSC_BN_STATS_PIVOT_RM, ...) with the SAME
+ * running_mean pointer only finalises.  min / max are exact; mean / variance agree with the separate pass to rounding. */
+int fsc_conv_l16_stats_layout(const fsc_conv_desc* d, int pool, int* out3);
+int fsc_conv_l16_fwd_stats(const fsc_conv_desc* d, const void* in_l16, const float* in_amax, const float* packed,
+                           const float* bias, float* out, const float* stat_pivot, void* stat_rec, fsc_stream_t stream);
+int fsc_conv_l16_pool_fwd_stats(const fsc_conv_desc* d, const void* in_l16, const float* in_amax, const float* packed,
+                                const float* bias, float* pooled, uint8_t* idx, const float* stat_pivot, void* stat_rec,
+                                fsc_stream_t stream);
+int fsc_bn_records_fold_conv(const void* records, int workers, int blocks, int co_blk, int c, void* stats_workspace,
+                             fsc_stream_t stream);
 /* eval: scale/shift from the running statistics */
 int fsc_bn_eval_prepare(int c, const float* gamma, const float* beta, const float* running_mean,
                         const float* running_var, float eps, float* scale, float* shift,

@@ -218,9 +218,24 @@ def test_block_with_and_without_l16_agree():
             F._L16_OK.clear()
     assert used == [False, True], "the test shape must exercise the L16 kernels"
     (l0, g0), (l1, g1) = results
+    # The L16 kernels themselves are bit-identical to the fp32-input ones; the L16 route also takes the BatchNorm statistics from
+    # the convolution epilogues (1e-7 relative differences in mean / invstd, tools/dbg_l16_paths.py), which this network's
+    # gradients amplify to a few 1e-4 of their maximum (with CONV_STATS off the two routes agree to 2e-7).
     assert (l0 - l1).abs().max().item() <= 1e-4
     for k in g0:
-        assert (g0[k] - g1[k]).abs().max().item() <= 1e-4 * max(1.0, g0[k].abs().max().item()), k
+        assert (g0[k] - g1[k]).abs().max().item() <= 1e-3 * max(1.0, g0[k].abs().max().item()), k
+    F.CONV_STATS = False
+    try:
+        F._L16_OK.clear()
+        for prm in model.parameters():
+            prm.grad = None
+        logits, per, loss = model.training_step(signal, labels, step_optimizer=False)
+        g2 = {k: v.grad.detach().clone() for k, v in model.named_parameters() if v.grad is not None}
+    finally:
+        F.CONV_STATS = True
+    assert torch.equal(logits, l0)
+    for k in g0:
+        assert (g0[k] - g2[k]).abs().max().item() <= 1e-5 * max(1.0, g0[k].abs().max().item()), k
 
 
 def test_first_block_bn_grads_from_weight_gradient():
@@ -345,3 +360,83 @@ def test_bn_forward_leaves_statistics_and_global_max(case):
     y3.add_(1.0)
     st3 = F.bn_prepare(y3, bn_next, True)
     torch.testing.assert_close(st3.mean, y3.mean((0, 2, 3)), rtol=1e-5, atol=1e-5)
+
+
+STAT_CASES = [(4, 100, 100, 64, 215, 3), (8, 150, 150, 32, 107, 3), (16, 225, 337, 16, 53, 3), (64, 337, 337, 8, 26, 3),
+              (128, 506, 506, 4, 13, 3), (4, 100, 100, 64, 215, 1), (16, 150, 225, 32, 107, 1), (6, 64, 96, 17, 43, 3),
+              (64, 64, 64, 32, 87, 1), (64, 64, 64, 32, 87, 3), (64, 96, 96, 16, 43, 3), (64, 64, 96, 32, 87, 3), (64, 96, 96, 16, 43, 1)]
+
+
+def _same_bn(bn):
+    other = nn.BatchNorm2d(bn.num_features).to(DEV)
+    other.load_state_dict(bn.state_dict())
+    return other
+
+
+@pytest.mark.parametrize("case", STAT_CASES, ids=lambda c: "x".join(map(str, c)))
+def test_conv_epilogue_reduces_batchnorm_statistics(case):
+    """Every convolution of a block feeds a BatchNorm (classifiers.py:78-101, 524-533): the STATS forward kernels reduce its batch
+    statistics in their epilogue.  Same output bit for bit; min / max exact; mean / invstd / running statistics equal to the
+    separate pass to rounding; works with a non-zero pivot (the running mean) and over odd shapes."""
+    n, cin, cout, h, w, k = case
+    torch.manual_seed(3)
+    x = torch.randn(n, cin, h, w, device=DEV)
+    wt = torch.randn(cout, cin, k, k, device=DEV) / (cin * k * k) ** 0.5
+    bias = torch.randn(cout, device=DEV) * 3.0                      # (mean far from zero: the pivot matters)
+    d = F._desc(n, cin, cout, h, w, k, k, 3)
+    if not F.conv_l16_supported(d, 0):
+        pytest.skip("no L16 tiling")
+    t = F.l16_pack(x, F.amax(x))
+    bn, _ = _bn_units(cout)
+    bn.running_mean.copy_(bias + 0.1 * torch.randn(cout, device=DEV))
+    bn_ref = _same_bn(bn)
+    y_ref = F.conv_l16(t, wt, bias)
+    y = F.conv_l16(t, wt, bias, stats_bn=(bn, True))
+    if F._stats_layout(d, False) is None:
+        assert not F._PRESTATS
+        pytest.skip("no statistics variant for this tiling")
+    assert torch.equal(y, y_ref) and F._PRESTATS
+    st = F.bn_prepare(y, bn, True)
+    assert not F._PRESTATS
+    st_ref = F.bn_prepare(y_ref, bn_ref, True)
+    assert torch.equal(st.minmax, st_ref.minmax)
+    torch.testing.assert_close(st.mean, st_ref.mean, rtol=2e-6, atol=2e-6)
+    torch.testing.assert_close(st.invstd, st_ref.invstd, rtol=2e-5, atol=0)
+    torch.testing.assert_close(bn.running_mean, bn_ref.running_mean, rtol=2e-6, atol=2e-6)
+    torch.testing.assert_close(bn.running_var, bn_ref.running_var, rtol=2e-5, atol=1e-7)
+    # against torch on the output itself
+    torch.testing.assert_close(st.mean, y.double().mean((0, 2, 3)).float(), rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(st.invstd, (y.double().var((0, 2, 3), unbiased=False) + bn.eps).rsqrt().float(), rtol=1e-4, atol=0)
+    # a BatchNorm without running statistics: pivot 0
+    bn0 = nn.BatchNorm2d(cout, track_running_stats=False).to(DEV)
+    y0 = F.conv_l16(t, wt, bias, stats_bn=(bn0, True))
+    st0 = F.bn_prepare(y0, bn0, True)
+    torch.testing.assert_close(st0.mean, st_ref.mean, rtol=2e-6, atol=2e-6)
+    torch.testing.assert_close(st0.invstd, st_ref.invstd, rtol=1e-4, atol=0)
+
+
+@pytest.mark.parametrize("case", [(8, 100, 150, 64, 215), (16, 150, 225, 32, 107), (32, 225, 337, 16, 53), (16, 100, 150, 31, 107)],
+                         ids=lambda c: "x".join(map(str, c)))
+def test_pooled_conv_epilogue_reduces_batchnorm_statistics(case):
+    n, cin, cout, h, w = case
+    torch.manual_seed(4)
+    x = torch.randn(n, cin, h, w, device=DEV)
+    wt = torch.randn(cout, cin, 3, 3, device=DEV) / (cin * 9) ** 0.5
+    bias = torch.randn(cout, device=DEV)
+    t = F.l16_pack(x, F.amax(x))
+    bn, _ = _bn_units(cout)
+    bn.running_mean.copy_(bias + 0.5)
+    bn_ref = _same_bn(bn)
+    ref = F.conv_l16_pool(t, wt, bias)
+    if ref is None:
+        pytest.skip("no fused tiling")
+    got = F.conv_l16_pool(t, wt, bias, stats_bn=(bn, True))
+    assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1])
+    if F._stats_layout(F._desc(n, cin, cout, h, w, 3, 3, 3), True) is None:
+        pytest.skip("no statistics variant")
+    assert F._PRESTATS
+    st = F.bn_prepare(got[0], bn, True)
+    st_ref = F.bn_prepare(ref[0], bn_ref, True)
+    assert torch.equal(st.minmax, st_ref.minmax)
+    torch.testing.assert_close(st.mean, st_ref.mean, rtol=2e-6, atol=2e-6)
+    torch.testing.assert_close(st.invstd, st_ref.invstd, rtol=2e-5, atol=0)
