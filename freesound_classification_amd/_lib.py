@@ -77,7 +77,7 @@ SIGNATURES = {
     "fsc_conv_l16_stats_layout": (_I, [_D, _I, _P]),
     "fsc_conv_l16_fwd_stats": (_I, [_D, _P, _P, _P, _P, _P, _P, _P, _P]),
     "fsc_conv_l16_pool_fwd_stats": (_I, [_D, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
-    "fsc_bn_records_fold_conv": (_I, [_P, _I, _I, _I, _I, _P, _P]),
+    "fsc_bn_records_fold_conv": (_I, [_P, _I, _I, _I, _I, _I, _P, _P]),
     "fsc_bn_records_bytes": (_SZ, [_I, _I, _L]),
     "fsc_bn_act_fwd_rec": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _L, _P, _P]),
     "fsc_bn_records_fold": (_I, [_P, _P, _I, _I, _L, _P, _P, _P, _P]),

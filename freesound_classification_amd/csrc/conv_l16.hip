@@ -50,6 +50,7 @@ struct LGeom {
     int nfull, tail_oct, tail_steps, steps;
     int coblk;
     long img_stride;          // 16-byte units between images of the input: oct_in * 2 * hw
+    int xcd;                  // item order: the channel blocks of a tile on workers of one XCD (see the kernel)
 };
 
 __device__ __attribute__((aligned(16))) float g_zero16_l[4] = {0.f, 0.f, 0.f, 0.f};
@@ -304,7 +305,20 @@ __global__ __launch_bounds__(kWaves * 64) void conv_l16_fwd_kernel(LGeom g, cons
         pix_b[pt] = pl * 16;
     }
     const int ntiles = g.tiles_n * g.tiles_h * g.tiles_w;
-    const int nitems = ntiles * g.coblk;
+    // Items = (pixel tile, channel block).  A worker keeps ONE channel block and walks tiles t0, t0 + ts, ... (the worker count is
+    // a multiple of the channel blocks).  With g.xcd the `coblk` workers that share a tile are neighbours on one XCD (workgroups
+    // go to XCDs round-robin: worker b runs on XCD b % 8), so the second read of a tile's input boxes hits that XCD's L2
+    // instead of going out again: tile t belongs to XCD t % 8, local slot (t / 8) % (workers per XCD / coblk).
+    int cb_w, t0;
+    const int ts = (int)gridDim.x / g.coblk;
+    if (g.xcd) {
+        const int l = (int)blockIdx.x >> 3;
+        cb_w = l % g.coblk;
+        t0 = ((int)blockIdx.x & 7) + 8 * (l / g.coblk);
+    } else {
+        cb_w = (int)blockIdx.x % g.coblk;
+        t0 = (int)blockIdx.x / g.coblk;
+    }
     const int nchunks = g.nfull + (g.tail_oct ? 1 : 0);
 
     int pos_off[kNptMax];        // source offset (16-byte units, relative to unit 0 of image 0) of staged positions; -1 = zeros
@@ -372,35 +386,31 @@ __global__ __launch_bounds__(kWaves * 64) void conv_l16_fwd_kernel(LGeom g, cons
     };
 
     // ---- producers: W runs three steps ahead of the MFMA steps, the input DAHEAD chunks, both across items
-    int wp_item = blockIdx.x, wp_left = g.steps, wp_slot = 0;      // wp_left: steps of wp_item not issued yet
-    const float* wp_src = packed + lane * 4;
-    auto wp_set_item = [&]() {
-        if (wp_item < nitems) {
-            const int tile = wp_item / g.coblk;
-            wp_src = packed + (long)(wp_item - tile * g.coblk) * g.steps * WSLOT_F + lane * 4;
-        }
-    };
+    int wp_item = t0, wp_left = g.steps, wp_slot = 0;      // wp_left: steps of tile wp_item not issued yet
+    const float* const wp_base = packed + (long)cb_w * g.steps * WSLOT_F + lane * 4;
+    const float* wp_src = wp_base;
+    auto wp_set_item = [&]() { wp_src = wp_base; };
     auto produce_w = [&]() -> bool {
-        if (wp_item >= nitems) return false;
+        if (wp_item >= ntiles) return false;
         issue_w(wp_src, wp_slot);
         wp_src += WSLOT_F;
         wp_slot = wp_slot == RING - 1 ? 0 : wp_slot + 1;
         if (--wp_left == 0) {
             wp_left = g.steps;
-            wp_item += gridDim.x;
+            wp_item += ts;
             wp_set_item();
         }
         return true;
     };
-    int ip_item = blockIdx.x, ip_c = 0, ip_stg = 0;
+    int ip_item = t0, ip_c = 0, ip_stg = 0;
     auto produce_i = [&]() -> bool {
-        if (ip_item >= nitems) return false;
+        if (ip_item >= ntiles) return false;
         issue_i(ip_stg, ip_c);
         ip_stg = ip_stg == NSTG - 1 ? 0 : ip_stg + 1;
         if (++ip_c == nchunks) {
             ip_c = 0;
-            ip_item += gridDim.x;
-            if (ip_item < nitems) plan_input(ip_item / g.coblk);
+            ip_item += ts;
+            if (ip_item < ntiles) plan_input(ip_item);
         }
         return true;
     };
@@ -445,10 +455,10 @@ __global__ __launch_bounds__(kWaves * 64) void conv_l16_fwd_kernel(LGeom g, cons
                 if (pr * 2 + t < COT) dst.v[t][l] = wl[((pr * 2 + t) * 2 + l) * 64];
     };
 
-    int item = blockIdx.x;
+    int item = t0;                 // (the tile of the current item)
     int slot = 0;
-    if (item < nitems) {
-        plan_input(item / g.coblk);
+    if (item < ntiles) {
+        plan_input(item);
         wp_set_item();
 #pragma unroll
         for (int d = 0; d < DAHEAD; ++d) produce_i();
@@ -552,9 +562,9 @@ __global__ __launch_bounds__(kWaves * 64) void conv_l16_fwd_kernel(LGeom g, cons
     };
 
     const bool add_bias = bias != nullptr;
-    for (; item < nitems; item += gridDim.x) {
-        const int tile = item / g.coblk;
-        const int co0 = (item - tile * g.coblk) * CO_BLK;
+    for (; item < ntiles; item += ts) {
+        const int tile = item;
+        const int co0 = cb_w * CO_BLK;
 #pragma unroll 1
         for (int S = 0; S + 1 < g.steps; S += 2) {
             step(true, true, fb0, fb1, fa0, fa1);
@@ -832,6 +842,8 @@ bool plan_l16_pt(const fsc_conv_desc& d_in, int dgrad, int pt, int max_cot, LPla
     if (items < 128) return false;                  // small late layers: the split-K kernels of conv.hip fill the chip better
     p.workers = items < 256 ? items : 256;
     if (items > 256 && items <= 512) p.workers = (items + 1) / 2;     // two items each instead of 256 + a short second wave
+    p.workers -= p.workers % p.co_blocks;           // a worker keeps one channel block
+    g.xcd = (p.co_blocks > 1 && p.workers % (8 * p.co_blocks) == 0 && !getenv("FSC_L16_NO_XCD")) ? 1 : 0;
     *out = p;
     return true;
 }
@@ -864,7 +876,7 @@ size_t l16_limb_floats(const LPlan& p) { return (size_t)p.co_blocks * p.g.steps 
 
 // statistics records (STATS kernels): the worker count is cut to a multiple of the channel blocks so that a worker keeps its block
 struct StatArgs { const float* pivot; float4* rec; };
-unsigned stat_workers(const LPlan& p) { return (unsigned)(p.workers - p.workers % p.co_blocks); }
+unsigned stat_workers(const LPlan& p) { return (unsigned)p.workers; }
 bool stats_ok(const LPlan& p) { return p.cot <= 8 && p.workers >= p.co_blocks; }
 
 template <int KH, int KW, int COT, int PT>
@@ -1027,13 +1039,14 @@ int fsc_conv_l16_fwd(const fsc_conv_desc* d, const void* in_l16, const float* in
     return launch_l16_cot<1, 1>(p, in, packed, bias, out, accumulate, in_amax, st);
 }
 
-/* statistics records of the STATS forward: out3 = {workers, channel blocks, channels per block}; the records are
- * workers * 8 * channels-per-block float4 {sum (y - pivot), sum (y - pivot)^2, min, max}; worker w holds channel block w % blocks */
+/* statistics records of the STATS forward: out3[4] = {workers, channel blocks, channels per block, order}; the records are
+ * workers * 8 * channels-per-block float4 {sum (y - pivot), sum (y - pivot)^2, min, max}; worker w holds channel block
+ * w % blocks (order 0) or (w / 8) % blocks (order 1: XCD-aware item order) */
 int fsc_conv_l16_stats_layout(const fsc_conv_desc* d, int pool, int* out3) {
     LPlan p;
     if (!valid_l16_desc(d) || !out3) return 0;
     if (!(pool ? plan_l16_pool(*d, &p) : plan_l16(*d, 0, &p)) || !stats_ok(p)) return 0;
-    out3[0] = (int)stat_workers(p); out3[1] = p.co_blocks; out3[2] = p.cot * 16;
+    out3[0] = (int)stat_workers(p); out3[1] = p.co_blocks; out3[2] = p.cot * 16; out3[3] = p.g.xcd;
     return 1;
 }
 

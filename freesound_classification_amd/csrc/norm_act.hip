@@ -487,15 +487,16 @@ __global__ __launch_bounds__(kThreads) void fold_records_kernel(const PlaneRec* 
 // records of a STATS convolution (conv_l16.hip): float4 {s1, s2, min, max} at [(worker * 8 + wave) * co_blk + channel in block],
 // worker w holds channel block w % blocks.  One workgroup per channel -> split 0 of the statistics partials.
 __global__ __launch_bounds__(kThreads) void fold_conv_records_kernel(const float4* __restrict__ rec, int workers, int blocks, int co_blk,
-                                                                     double* __restrict__ part) {
+                                                                     int order, double* __restrict__ part) {
     __shared__ double scratch[kThreads / 64];
     __shared__ float mm[2][kThreads / 64];
     const int ch = blockIdx.x, cb = ch / co_blk, within = ch - cb * co_blk;
-    const int nrec = (workers / blocks) * 8;
+    const int nrec = workers * 8;
     double s1 = 0.0, s2 = 0.0;
     float mn = INFINITY, mx = -INFINITY;
     for (int r = threadIdx.x; r < nrec; r += kThreads) {
-        const int w = cb + (r >> 3) * blocks, wv = r & 7;
+        const int w = r >> 3, wv = r & 7;
+        if ((order ? (w >> 3) % blocks : w % blocks) != cb) continue;       // (another channel block's worker)
         const float4 v = rec[((long)w * 8 + wv) * co_blk + within];
         s1 += (double)v.x; s2 += (double)v.y;
         mn = fminf(mn, v.z); mx = fmaxf(mx, v.w);
@@ -1404,12 +1405,12 @@ int fsc_bn_records_fold(const void* records, const float* y, int n, int c, long 
     return 0;
 }
 
-int fsc_bn_records_fold_conv(const void* records, int workers, int blocks, int co_blk, int c, void* stats_workspace,
+int fsc_bn_records_fold_conv(const void* records, int workers, int blocks, int co_blk, int order, int c, void* stats_workspace,
                              fsc_stream_t stream) {
     FSC_CHECK_ARG(records && stats_workspace && workers > 0 && blocks > 0 && co_blk > 0 && c > 0 && workers % blocks == 0 &&
                       c <= blocks * co_blk, "fsc_bn_records_fold_conv: bad arguments");
     hipLaunchKernelGGL(fold_conv_records_kernel, dim3(c), dim3(kThreads), 0, fsc::as_stream(stream),
-                       reinterpret_cast<const float4*>(records), workers, blocks, co_blk, carve(stats_workspace, c).part);
+                       reinterpret_cast<const float4*>(records), workers, blocks, co_blk, order, carve(stats_workspace, c).part);
     FSC_LAUNCH_CHECK("fsc_bn_records_fold_conv");
     return 0;
 }

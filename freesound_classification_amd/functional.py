@@ -332,7 +332,7 @@ def _stats_layout(d, pool):
     """(workers, channel blocks, channels per block) of the statistics records of a STATS convolution, or None."""
     key = tuple(getattr(d, f) for f, _ in d._fields_) + (pool,)
     if key not in _STATS_LAYOUT:
-        out3 = (C.c_int * 3)()
+        out3 = (C.c_int * 4)()
         ok = _lib.load().fsc_conv_l16_stats_layout(C.byref(d), 1 if pool else 0, out3)
         _STATS_LAYOUT[key] = tuple(out3) if ok else None
     return _STATS_LAYOUT[key]
@@ -357,7 +357,7 @@ def _stats_begin(d, pool, stats_bn, like):
 def _stats_end(lay, rec, y, c_out):
     """Folds the records of the convolution that wrote `y` into a BatchNorm workspace and leaves it for bn_prepare(y, ...)."""
     ws = _bn_ws(c_out, y)
-    call("fsc_bn_records_fold_conv", ptr(rec), lay[0], lay[1], lay[2], c_out, ptr(ws), stream_ptr())
+    call("fsc_bn_records_fold_conv", ptr(rec), lay[0], lay[1], lay[2], lay[3], c_out, ptr(ws), stream_ptr())
     _PRESTATS.clear()
     _PRESTATS[(y.data_ptr(), tuple(y.shape), y._version, y.device)] = (ws, y, _STATS_FOLDED | _STATS_PIVOT_RM)
 

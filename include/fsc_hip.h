@@ -224,7 +224,7 @@ int fsc_bn_records_fold(const void* records, const float* y, int n, int c, long 
  * block feeds a BatchNorm): fsc_conv_l16_fwd_stats / fsc_conv_l16_pool_fwd_stats are fsc_conv_l16_fwd (forward) /
  * fsc_conv_l16_pool_fwd whose epilogue also accumulates sum (y - pivot), sum (y - pivot)^2, min y, max y per output channel of what
  * it stores (the pooled values for the pool variant); pivot = stat_pivot[channel] (pass the BatchNorm's running_mean; NULL = 0).
- * fsc_conv_l16_stats_layout -> 1 and out3 = {workers, channel blocks, channels per block} when the shape has such a kernel;
+ * fsc_conv_l16_stats_layout -> 1 and out3[4] = {workers, channel blocks, channels per block, worker order} when the shape has such a kernel;
  * `stat_rec` holds workers * 8 * channels-per-block records of 16 bytes.  fsc_bn_records_fold_conv folds them into split 0 of a
  * BatchNorm workspace; then fsc_bn_train_stats(..., phase | FSC_BN_STATS_FOLDED | FSC_BN_STATS_PIVOT_RM, ...) with the SAME
  * running_mean pointer only finalises.  min / max are exact; mean / variance agree with the separate pass to rounding. */
@@ -234,8 +234,8 @@ int fsc_conv_l16_fwd_stats(const fsc_conv_desc* d, const void* in_l16, const flo
 int fsc_conv_l16_pool_fwd_stats(const fsc_conv_desc* d, const void* in_l16, const float* in_amax, const float* packed,
                                 const float* bias, float* pooled, uint8_t* idx, const float* stat_pivot, void* stat_rec,
                                 fsc_stream_t stream);
-int fsc_bn_records_fold_conv(const void* records, int workers, int blocks, int co_blk, int c, void* stats_workspace,
-                             fsc_stream_t stream);
+int fsc_bn_records_fold_conv(const void* records, int workers, int blocks, int co_blk, int order, int c,
+                             void* stats_workspace, fsc_stream_t stream);
 /* eval: scale/shift from the running statistics */
 int fsc_bn_eval_prepare(int c, const float* gamma, const float* beta, const float* running_mean,
                         const float* running_var, float eps, float* scale, float* shift,
