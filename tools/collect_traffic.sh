@@ -21,7 +21,7 @@ for c, mult in (("FETCH_SIZE", 2.0), ("WRITE_SIZE", 1.0)):
             if not m: continue
             base, args = m.group(1), [a.strip() for a in m.group(2).split(",")]
             if base == "conv_fwd_kernel": args = args[:4]                       # timer name drops the K-chunk argument
-            if base == "conv_l16_fwd_kernel": args = args[:4] + (["pool"] if args[4:] == ["true"] else [])
+            if base == "conv_l16_fwd_kernel": args = args[:4] + (["pool"] if args[4:5] == ["true"] else [])   # (<KH,KW,COT,PT,POOL,STATS>)
             if base == "conv_wgrad_kernel": args = args[:3] + (["packed"] if args[3] == "true" else [])
             key = "%s<%s>" % (base, ",".join(args))
             tot[key] += float(r["Counter_Value"]) * 1024.0 * mult
