@@ -226,9 +226,17 @@ def run_inference(args, w, device, world, rank):
             result["roofline"] = {"kernel": dom_name, "bound": "mfma", "achieved": ach * per, "peak": peak, "unit": "TFLOP/s",
                                   "frac": ach * per / peak, "traffic": None, "algorithmic_fp32_tflops": ach,
                                   "conv_ms_total": sum(v["ms"] for v in summ.values()), "wall_ms": 1e3 * elapsed}
-        print(json.dumps(result))
+        _emit(json.dumps(result))
     if dist.is_initialized():
         dist.destroy_process_group()
+
+
+_RESULT_FD = None
+
+
+def _emit(line):
+    sys.stdout.flush()
+    os.write(_RESULT_FD if _RESULT_FD is not None else 1, (line + "\n").encode())
 
 
 def main():
@@ -245,6 +253,13 @@ def main():
     ap.add_argument("--arith", default=None, choices=["f32", "bf16", "f16x3", "bf16x6", "bf16x9"],
                     help="conv arithmetic (default: the workload's, else the library default f16x3)")
     args = ap.parse_args()
+
+    # stdout carries exactly ONE line, the JSON result: anything the libraries print there (RCCL writes its version banner to
+    # stdout when the first communicator comes up) goes to stderr instead
+    global _RESULT_FD
+    sys.stdout.flush()
+    _RESULT_FD = os.dup(1)
+    os.dup2(2, 1)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -458,7 +473,7 @@ def main():
             result["with_h2d"] = h2d
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(w)
-        print(json.dumps(result))
+        _emit(json.dumps(result))
     if dist.is_initialized():
         dist.destroy_process_group()
 

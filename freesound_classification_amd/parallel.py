@@ -112,7 +112,7 @@ class BucketedGradReducer:
             items.append((p, off, p.numel()))
             self._where[id(p)] = (len(self.buckets), off)
             off += p.numel()
-        self.buckets.append(dict(flat=flat, items=items, pending=len(items), handle=None, launched=False))
+        self.buckets.append(dict(flat=flat, items=items, pending=len(items), handle=None, launched=False, copy_dst=[], copy_src=[]))
 
     def bucket_sizes(self):
         return [b["flat"].numel() for b in self.buckets]
@@ -125,6 +125,7 @@ class BucketedGradReducer:
             b["pending"] = len(b["items"])
             b["handle"] = None
             b["launched"] = False
+            b["copy_dst"], b["copy_src"] = [], []
 
     def grad_view(self, weight):
         """The slice of its bucket where the gradient of `weight` (a parameter or a detached alias of one) belongs, shaped
@@ -138,6 +139,12 @@ class BucketedGradReducer:
             return None
         bi, off = self._where[id(p)]
         return self.buckets[bi]["flat"][off:off + p.numel()].view(p.shape)
+
+    @staticmethod
+    def _flush_copies(b):
+        if b["copy_dst"]:
+            torch._foreach_copy_(b["copy_dst"], b["copy_src"])
+            b["copy_dst"], b["copy_src"] = [], []
 
     def _launch(self, b):
         flat = b["flat"]
@@ -159,10 +166,12 @@ class BucketedGradReducer:
         flat = b["flat"]
         if p.grad.data_ptr() == flat.data_ptr() + off * flat.element_size() and p.grad.is_contiguous():
             self.in_place += 1                   # written there by the kernel that computed it
-        else:
-            flat[off:off + p.numel()].copy_(p.grad.reshape(-1))
+        else:                                    # (the many small BN / bias gradients: ONE multi-tensor copy per bucket)
+            b["copy_dst"].append(flat[off:off + p.numel()])
+            b["copy_src"].append(p.grad.reshape(-1))
         b["pending"] -= 1
         if b["pending"] == 0:
+            self._flush_copies(b)
             self._launch(b)
 
     def finish(self):
@@ -175,6 +184,7 @@ class BucketedGradReducer:
                 for p, off, n in b["items"]:
                     if p.grad is None:
                         b["flat"][off:off + n].zero_()
+                self._flush_copies(b)
                 self._launch(b)
         for b in self.buckets:
             b["handle"].wait()
