@@ -346,10 +346,12 @@ def _stats_begin(d, pool, stats_bn, like):
     """Records buffer and pivot of a STATS convolution feeding `stats_bn` = (BatchNorm, training), or (None, None, None)."""
     if not CONV_STATS or stats_bn is None:
         return None, None, None
+    bn, training = stats_bn
+    if not (training or bn.running_mean is None):          # (eval: bn_prepare takes the running statistics)
+        return None, None, None
     lay = _stats_layout(d, pool)
     if lay is None:
         return None, None, None
-    bn, training = stats_bn
     rec = torch.empty(lay[0] * 8 * lay[2] * 4, device=like.device, dtype=torch.float32)
     return lay, rec, (bn.running_mean if bn_tracks(bn, training) else None)
 
