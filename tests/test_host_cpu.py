@@ -237,6 +237,18 @@ def test_l16_plans_cover_the_cfg2_training_layers():
                 assert lib.fsc_conv_l16_packed_floats(ctypes.byref(d), dgrad) > 0
                 assert lib.fsc_conv_l16_plan_describe(ctypes.byref(d), dgrad, buf, 256) == 0
                 assert buf.value.decode().startswith("conv_l16_fwd_kernel<%d,%d," % (k, k))
+        # statistics variant of the forward (and of the pooled entry convolution): a worker keeps one channel block
+        for pool in (0, 1):
+            lay = (ctypes.c_int * 4)()
+            if lib.fsc_conv_l16_stats_layout(ctypes.byref(d), pool, lay):
+                workers, blocks, co_blk, order = list(lay)
+                assert 0 < workers <= 256 and workers % blocks == 0 and co_blk % 16 == 0 and blocks * co_blk >= c_out
+                assert order in (0, 1) and (order == 0 or (blocks > 1 and workers % (8 * blocks) == 0))
+                assert not pool or (k == 3 and lib.fsc_conv_l16_pool_supported(ctypes.byref(d)))
+            elif big and not pool:
+                raise AssertionError("no statistics variant for %s" % ((c_in, c_out, h, w, k),))
+        if (c_in, c_out, h) in ((100, 150, 64), (150, 225, 32), (225, 337, 16)):
+            assert lib.fsc_conv_l16_pool_supported(ctypes.byref(d))       # blocks 1-3: conv + max-pool in one kernel
         okw = lib.fsc_conv_l16_wgrad_supported(ctypes.byref(d))
         if c_in >= 100 and c_out <= 337:
             assert okw, (c_in, c_out, h, w, k)
