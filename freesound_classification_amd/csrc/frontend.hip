@@ -260,6 +260,14 @@ __device__ __forceinline__ float2 tw2048(const float2* tw, int m) {
     return (m & 1024) ? make_float2(-v.x, -v.y) : v;
 }
 
+// lane ^ 1 / lane ^ 2 inside a quad as DPP moves (quad_perm [1,0,3,2] / [2,3,0,1]); __shfl_xor takes the LDS crossbar
+__device__ __forceinline__ float quad_xor1(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float quad_xor2(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true));
+}
+
 template <bool MEL>
 __global__ __launch_bounds__(kThreads, 3) void frontend2048_kernel(FrontendArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -287,14 +295,23 @@ __global__ __launch_bounds__(kThreads, 3) void frontend2048_kernel(FrontendArgs 
         // ---- A: load + window + pack: z[j] = (x[2j] w[2j], x[2j+1] w[2j+1]), j = 64 n1 + lane
         float2 x[16];
         const long s0 = (long)f * a.hop - NC;
+        // interior frames with an 8-byte aligned start read sample pairs (hop and clip stride even: every cfg); frames that
+        // touch a clip end take the reflect-padded scalar path (ops/utils.py:110-127: center=True, pad_mode="reflect")
+        const bool pairs = s0 >= 0 && s0 + 2 * NC <= t && ((s0 | a.wave_stride) & 1) == 0 &&
+                           (reinterpret_cast<uintptr_t>(a.wave) & 7) == 0;
 #pragma unroll
         for (int n1 = 0; n1 < 16; ++n1) {
             const int j = 64 * n1 + lane;
-            long i0 = s0 + 2 * j, i1 = i0 + 1;
-            if (i0 < 0) i0 = -i0; else if (i0 >= t) i0 = 2L * (t - 1) - i0;
-            if (i1 < 0) i1 = -i1; else if (i1 >= t) i1 = 2L * (t - 1) - i1;
             const float2 w = reinterpret_cast<const float2*>(win)[j];
-            x[n1] = make_float2(wav[i0] * w.x, wav[i1] * w.y);
+            if (pairs) {
+                const float2 v = *reinterpret_cast<const float2*>(wav + s0 + 2 * j);
+                x[n1] = make_float2(v.x * w.x, v.y * w.y);
+            } else {
+                long i0 = s0 + 2 * j, i1 = i0 + 1;
+                if (i0 < 0) i0 = -i0; else if (i0 >= t) i0 = 2L * (t - 1) - i0;
+                if (i1 < 0) i1 = -i1; else if (i1 >= t) i1 = 2L * (t - 1) - i1;
+                x[n1] = make_float2(wav[i0] * w.x, wav[i1] * w.y);
+            }
         }
         fft16(x);
         // twiddle W_1024^(lane k1) = exp(-2 pi i 2 lane k1 / 2048), then rows [k1][n2 = lane] into the patch
@@ -312,10 +329,10 @@ __global__ __launch_bounds__(kThreads, 3) void frontend2048_kernel(FrontendArgs 
 #pragma unroll
         for (int k = 0; k < 16; ++k) {
             const float2 v = x[k];
-            const float2 o2 = make_float2(__shfl_xor(v.x, 2), __shfl_xor(v.y, 2));
+            const float2 o2 = make_float2(quad_xor2(v.x), quad_xor2(v.y));
             float2 s = (cq & 2) ? csub(o2, v) : cadd(v, o2);          // lanes 0,1: a_c + a_{c+2}; lanes 2,3: a_{c-2} - a_c
             if (cq == 3) s = mul_mi(s);                                // -i (a1 - a3)
-            const float2 o1 = make_float2(__shfl_xor(s.x, 1), __shfl_xor(s.y, 1));
+            const float2 o1 = make_float2(quad_xor1(s.x), quad_xor1(s.y));
             x[k] = (cq & 1) ? csub(o1, s) : cadd(s, o1);              // even lane: t + t'; odd lane: t' - t (= t_even - t_odd)
         }
         // ---- spectrum Z[k1q + 16 k + 256 k2q] to the patch in natural order (+ 8 pad per 256: conflict-free)
