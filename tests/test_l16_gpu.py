@@ -440,3 +440,37 @@ def test_pooled_conv_epilogue_reduces_batchnorm_statistics(case):
     assert torch.equal(st.minmax, st_ref.minmax)
     torch.testing.assert_close(st.mean, st_ref.mean, rtol=2e-6, atol=2e-6)
     torch.testing.assert_close(st.invstd, st_ref.invstd, rtol=2e-5, atol=0)
+
+
+def test_conv_epilogue_statistics_at_the_cfg2_batch():
+    """Batch 128 (BASELINE.json configs[1]): 256 persistent workers x 27 items each accumulate the statistics in registers -- the
+    result still matches the separate pass and torch's own reduction of the output (fp64) to rounding; the pooled entry
+    convolution of block 1 likewise."""
+    torch.manual_seed(11)
+    n, c, h, w = 128, 100, 64, 215
+    x = torch.randn(n, c, h, w, device=DEV)
+    t = F.l16_pack(x, F.amax(x))
+    del x
+    for cout, pool in ((100, False), (150, True)):
+        wt = torch.randn(cout, c, 3, 3, device=DEV) / (c * 9) ** 0.5
+        bias = torch.randn(cout, device=DEV) * 2.0
+        bn, _ = _bn_units(cout)
+        bn.running_mean.copy_(bias * 0.5)                       # a pivot that is off by about one sigma
+        bn_ref = _same_bn(bn)
+        if pool:
+            y = F.conv_l16_pool(t, wt, bias, stats_bn=(bn, True))[0]
+        else:
+            y = F.conv_l16(t, wt, bias, stats_bn=(bn, True))
+        assert F._PRESTATS and F._stats_layout(F._desc(n, c, cout, h, w, 3, 3, 3), pool)[0] == 256
+        st = F.bn_prepare(y, bn, True)
+        st_ref = F.bn_prepare(y.clone(), bn_ref, True)
+        assert torch.equal(st.minmax, st_ref.minmax)
+        mean64 = y.double().mean((0, 2, 3))
+        var64 = (y.double() - mean64[None, :, None, None]).pow(2).mean((0, 2, 3))
+        std = var64.sqrt().float()
+        assert ((st.mean - mean64.float()).abs() / std).max().item() < 2e-6
+        assert ((st_ref.mean - mean64.float()).abs() / std).max().item() < 2e-6
+        inv64 = (var64 + bn.eps).rsqrt().float()
+        assert ((st.invstd - inv64).abs() / inv64).max().item() < 3e-6
+        assert ((st_ref.invstd - inv64).abs() / inv64).max().item() < 3e-6
+        del y, st, st_ref
