@@ -179,7 +179,7 @@ __global__ void stats_finalize_kernel(const float* __restrict__ x, int c, long h
                                       const float* __restrict__ beta, float eps, float momentum,
                                       float* running_mean, float* running_var, float* save_mean,
                                       float* save_invstd, float* scale, float* shift, double* __restrict__ sync,
-                                      int phase, float* __restrict__ x_minmax, int pivot_rm) {
+                                      int phase, float* __restrict__ x_minmax, int pivot_rm, int minmax_only) {
     const int ch = blockIdx.x * blockDim.x + threadIdx.x;
     if (ch >= c) return;
     if (x_minmax && phase != 2) {          // (phase 2 re-runs on the partials of phase 1: already written)
@@ -191,6 +191,7 @@ __global__ void stats_finalize_kernel(const float* __restrict__ x, int c, long h
         x_minmax[2 * ch] = mn;
         x_minmax[2 * ch + 1] = mx;
     }
+    if (minmax_only) return;               // (inference: the BatchNorm runs on its running statistics)
     double s1 = 0.0, s2 = 0.0, pivot = 0.0;
     if (phase == 2) {
         s1 = sync[ch * 4];
@@ -1332,7 +1333,10 @@ int fsc_bn_train_stats(const float* x, int n, int c, long hw, const float* gamma
                        float momentum, float* running_mean, float* running_var, float* save_mean,
                        float* save_invstd, float* scale, float* shift, void* workspace, double* sync, int phase,
                        float* x_minmax, fsc_stream_t stream) {
-    FSC_CHECK_ARG(x && save_mean && save_invstd && scale && shift && workspace, "fsc_bn_train_stats: null pointer");
+    const int minmax_only = (phase & FSC_BN_STATS_MINMAX_ONLY) ? 1 : 0;
+    FSC_CHECK_ARG(x && workspace && (minmax_only ? (x_minmax != nullptr && (phase & 3) == 0)
+                                                 : (save_mean && save_invstd && scale && shift)),
+                  "fsc_bn_train_stats: null pointer");
     FSC_CHECK_ARG((phase & 3) == 0 || (((phase & 3) == 1 || (phase & 3) == 2) && sync),
                   "fsc_bn_train_stats: phase 1 / 2 need `sync`");
     FSC_CHECK_ARG(n > 0 && c > 0 && hw > 0, "fsc_bn_train_stats: bad shape (%d, %d, %ld)", n, c, hw);
@@ -1342,7 +1346,7 @@ int fsc_bn_train_stats(const float* x, int n, int c, long hw, const float* gamma
     int nsplit = 1;
     const bool folded = (phase & FSC_BN_STATS_FOLDED) != 0;      // split 0 of the partials is there already (fsc_bn_records_fold)
     const int pivot_rm = (phase & FSC_BN_STATS_PIVOT_RM) ? 1 : 0;
-    phase &= ~(FSC_BN_STATS_FOLDED | FSC_BN_STATS_PIVOT_RM);
+    phase &= ~(FSC_BN_STATS_FOLDED | FSC_BN_STATS_PIVOT_RM | FSC_BN_STATS_MINMAX_ONLY);
     if (phase != 2 && !folded) {
         if (hw == 1) {
             hipLaunchKernelGGL(stats_rows_kernel, dim3(fsc::ceil_div(c, 128)), dim3(128), 0, st, x, n, c, p.part);
@@ -1354,7 +1358,7 @@ int fsc_bn_train_stats(const float* x, int n, int c, long hw, const float* gamma
     }
     hipLaunchKernelGGL(stats_finalize_kernel, dim3(fsc::ceil_div(c, 128)), dim3(128), 0, st, x, c, hw,
                        (double)n * (double)hw, nsplit, p.part, gamma, beta, eps, momentum, running_mean,
-                       running_var, save_mean, save_invstd, scale, shift, sync, phase, x_minmax, pivot_rm);
+                       running_var, save_mean, save_invstd, scale, shift, sync, phase, x_minmax, pivot_rm, minmax_only);
     FSC_LAUNCH_CHECK("fsc_bn_train_stats");
     return 0;
 }

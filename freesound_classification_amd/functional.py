@@ -323,6 +323,8 @@ def conv_l16_pack_pair(weight, n, h, w):
     return ((d, pf) if nf else None), ((d, pd) if nd else None)
 
 
+EVAL_L16 = os.environ.get("FSC_EVAL_L16", "1") == "1"          # inference also takes the L16 kernels (needs the range of each BN input)
+_STATS_MINMAX_ONLY = 16    # FSC_BN_STATS_MINMAX_ONLY
 CONV_STATS = os.environ.get("FSC_CONV_STATS", "1") == "1"      # forward convolutions reduce the statistics of the BatchNorm they feed
 _STATS_PIVOT_RM = 8        # FSC_BN_STATS_PIVOT_RM
 _STATS_LAYOUT = {}
@@ -347,7 +349,7 @@ def _stats_begin(d, pool, stats_bn, like):
     if not CONV_STATS or stats_bn is None:
         return None, None, None
     bn, training = stats_bn
-    if not (training or bn.running_mean is None):          # (eval: bn_prepare takes the running statistics)
+    if not (training or bn.running_mean is None or EVAL_L16):     # (eval: only the range of the output is of use, for L16)
         return None, None, None
     lay = _stats_layout(d, pool)
     if lay is None:
@@ -614,7 +616,7 @@ def bn_act_forward_rec(x, st, alpha, residual, want_stats, want_gmax):
     return y, feat, fidx
 
 
-def bn_prepare(x, bn, training, sync=None, defer=None):
+def bn_prepare(x, bn, training, sync=None, defer=None, want_minmax=False):
     """Batch statistics (training; also updates the running stats, once) or running statistics
     (eval) -> per-channel scale/shift.  `sync` (a callable that sum-all-reduces a device tensor in place over the
     data-parallel replicas, see parallel.SyncBN) turns the batch statistics into cross-replica statistics."""
@@ -657,6 +659,14 @@ def bn_prepare(x, bn, training, sync=None, defer=None):
         st.invstd = None
         call("fsc_bn_eval_prepare", c, ptr(gamma), ptr(beta), ptr(bn.running_mean), ptr(bn.running_var),
              bn.eps, ptr(st.scale), ptr(st.shift), stream_ptr())
+        pre = _take_prestats(x)
+        if want_minmax and EVAL_L16 and hw > 1:
+            # inference on the L16 kernels: the producer that writes the conv operand needs the range of x up front -- from the
+            # records of the kernel that wrote x, else from one reduction pass
+            ws, folded = pre if pre is not None else (_bn_ws(c, x), 0)
+            st.minmax = _empty((2 * c,), x)
+            call("fsc_bn_train_stats", ptr(x), n, c, hw, None, None, bn.eps, 0.0, None, None, None, None, None, None, ptr(ws),
+                 None, (folded & _STATS_FOLDED) | _STATS_MINMAX_ONLY, ptr(st.minmax), stream_ptr())
     return st
 
 
@@ -880,13 +890,13 @@ class _BlockCtx:
     pass
 
 
-def _bn_fwd_for_conv(x, st, alpha, weight, keep_f32=False):
+def _bn_fwd_for_conv(x, st, alpha, weight, keep_f32=False, need_wgrad=True):
     """BN (+ PReLU) output that feeds the convolution `weight`: (y fp32 or None, max |y| buffer or None, y as L16 or None).
     The L16 form is written when the forward convolution or its weight gradient reads it; the fp32 form when one of the two
     does not (or the caller needs it: keep_f32)."""
-    fw, wg = _l16_ok_for(x.shape, weight, False), _l16_wgrad_ok_for(x.shape, weight)
+    fw, wg = _l16_ok_for(x.shape, weight, False), need_wgrad and _l16_wgrad_ok_for(x.shape, weight)
     if (fw or wg) and st.minmax is not None:
-        y, t = bn_act_forward(x, st, alpha, l16=True, want_f32=keep_f32 or not (fw and wg))
+        y, t = bn_act_forward(x, st, alpha, l16=True, want_f32=keep_f32 or not (fw and (wg or not need_wgrad)))
         if t is not None:
             return y, t.amax, t
     y, y_max = bn_act_forward(x, st, alpha, with_amax=True)
@@ -947,11 +957,15 @@ def _block_forward(x, mods, training, want_head, ph, keep, sync=None, next_bn=Fa
     k = _BlockCtx()
     counters = []                      # num_batches_tracked of the five BatchNorms: one launch at the end
     k.x_shape = tuple(x.shape)
-    st_a = bn_prepare(x, bn_a, training, sync, counters)
     w_a, b_a = _conv_params(conv_a)
+
+    def mm(t, wt):           # inference: the BatchNorm in front of a convolution with an L16 tiling also reports the range of its input
+        return (not training) and EVAL_L16 and t.dim() == 4 and _l16_ok_for(t.shape, wt, False)
+
+    st_a = bn_prepare(x, bn_a, training, sync, counters, want_minmax=mm(x, w_a))
     # Operands of convolutions that have an L16 tiling are written pre-split by the BN / PReLU kernel that produces them
     # (`*_16`); the fp32 copy stays for the weight gradient (and, for b, the residual).
-    a, a_max, a_16 = _bn_fwd_for_conv(x, st_a, None, w_a)
+    a, a_max, a_16 = _bn_fwd_for_conv(x, st_a, None, w_a, need_wgrad=keep)
     packs = [] if keep else None          # input-gradient weight fragments packed along with the forward ones
     fused = conv_pool_forward(a, w_a, b_a) if (ph == 2 and a is not None) else None
     if fused is not None:
@@ -978,22 +992,23 @@ def _block_forward(x, mods, training, want_head, ph, keep, sync=None, next_bn=Fa
             p, pidx = maxpool_forward(c, ph)
             k.c_shape = tuple(c.shape)
             del c
-    st_b = bn_prepare(p, bn_b, training, sync, counters)
     w1, b1 = _conv_params(res.conv1)
-    b, b_max, b_16 = _bn_fwd_for_conv(p, st_b, prelu_b.weight, w1, keep_f32=True)      # (the residual reads it)
+    st_b = bn_prepare(p, bn_b, training, sync, counters, want_minmax=mm(p, w1))
+    b, b_max, b_16 = _bn_fwd_for_conv(p, st_b, prelu_b.weight, w1, keep_f32=True, need_wgrad=keep)      # (the residual reads it)
     r1 = _conv_fwd_any(b, b_16, w1, b1, b_max, packs, (res.bn1, training))
-    st1 = bn_prepare(r1, res.bn1, training, sync, counters)
     w2, b2 = _conv_params(res.conv2)
-    s1, s1_max, s1_16 = _bn_fwd_for_conv(r1, st1, res.prelu1.weight, w2)
+    st1 = bn_prepare(r1, res.bn1, training, sync, counters, want_minmax=mm(r1, w2))
+    s1, s1_max, s1_16 = _bn_fwd_for_conv(r1, st1, res.prelu1.weight, w2, need_wgrad=keep)
     r2 = _conv_fwd_any(s1, s1_16, w2, b2, s1_max, packs, (res.bn2, training))
-    st2 = bn_prepare(r2, res.bn2, training, sync, counters)
     w3, b3 = _conv_params(res.conv3)
-    s2, s2_max, s2_16 = _bn_fwd_for_conv(r2, st2, res.prelu2.weight, w3)
+    st2 = bn_prepare(r2, res.bn2, training, sync, counters, want_minmax=mm(r2, w3))
+    s2, s2_max, s2_16 = _bn_fwd_for_conv(r2, st2, res.prelu2.weight, w3, need_wgrad=keep)
     r3 = _conv_fwd_any(s2, s2_16, w3, b3, s2_max, packs, (res.bn3, training))
     st3 = bn_prepare(r3, res.bn3, training, sync, counters)
     feat, fidx = (None, None)
-    if FUSE_OUT_STATS and h_w_min(r3) * max(r3.shape[2], r3.shape[3]) > 1 and (want_head or (training and next_bn)):
-        out, feat, fidx = bn_act_forward_rec(r3, st3, res.prelu3.weight, b, training and next_bn, want_head)
+    next_stats = next_bn and (training or EVAL_L16)          # (inference: the next block's input BatchNorm wants the range)
+    if FUSE_OUT_STATS and h_w_min(r3) * max(r3.shape[2], r3.shape[3]) > 1 and (want_head or next_stats):
+        out, feat, fidx = bn_act_forward_rec(r3, st3, res.prelu3.weight, b, next_stats, want_head)
     else:
         out = bn_act_forward(r3, st3, res.prelu3.weight, residual=b)
         if want_head:

@@ -207,6 +207,9 @@ int fsc_bn_train_stats(const float* x, int n, int c, long hw, const float* gamma
 /* phase | FSC_BN_STATS_PIVOT_RM (with FSC_BN_STATS_FOLDED): the folded sums are about `running_mean` as it is BEFORE this call
  * (0 when running_mean is NULL) instead of the channel's first element: the convention of the STATS convolutions below. */
 #define FSC_BN_STATS_PIVOT_RM 8
+/* phase | FSC_BN_STATS_MINMAX_ONLY (phase 0): only x_minmax is written (everything else may be NULL) -- inference, where the
+ * BatchNorm runs on its running statistics but fsc_bn_act_fwd still needs the range of x to write an L16 tensor. */
+#define FSC_BN_STATS_MINMAX_ONLY 16
 /* The last unit of a block (classifiers.py:102-104: bn3 + residual + PReLU) writes a tensor that the next block's input
  * BatchNorm (classifiers.py:524) and the hierarchical head's global max-pool (classifiers.py:586-590) read again at once.
  * fsc_bn_act_fwd_rec = fsc_bn_act_fwd (fp32 y, hw > 1, no amax) that also leaves one record per (plane, slice) --

@@ -474,3 +474,48 @@ def test_conv_epilogue_statistics_at_the_cfg2_batch():
         assert ((st.invstd - inv64).abs() / inv64).max().item() < 3e-6
         assert ((st_ref.invstd - inv64).abs() / inv64).max().item() < 3e-6
         del y, st, st_ref
+
+
+def test_inference_takes_the_l16_kernels():
+    """Eval mode: BatchNorm runs on its running statistics, but the producers still learn the range of each conv operand (from
+    the records of the kernel that wrote it, or one reduction pass) and write it pre-split -- same logits as the fp32-input route."""
+    from freesound_classification_amd.networks.classifiers import TwoDimensionalCNNClassificationModel
+
+    class NS(dict):
+        __getattr__ = dict.__getitem__
+
+    exp = NS(config=NS(
+        network=NS(num_conv_blocks=3, start_deep_supervision_on=1, conv_base_depth=64, growth_rate=1.5,
+                   output_dropout=0.0, aggregation_type="max"),
+        data=NS(features="mel_1024_512_64", _input_dim=64, _n_classes=80),
+        train=NS(accumulation_steps=1, optimizer="adam", learning_rate=1e-3, weight_decay=0.0,
+                 scheduler="1cycle_0.0001_0.005")))
+    torch.manual_seed(5)
+    model = TwoDimensionalCNNClassificationModel(exp, device="cuda:0")
+    for mod in model.modules():
+        if isinstance(mod, nn.modules.batchnorm._BatchNorm):
+            mod.running_mean.normal_(0, 0.2)
+            mod.running_var.uniform_(0.5, 1.5)
+    model.eval()
+    signal = 0.1 * torch.randn(48, 3 * 44100, 1, device=DEV)
+    outs, calls = {}, {}
+    real = F.conv_l16
+    for on in (False, True):
+        count = [0]
+
+        def counted(*a, **kw):
+            count[0] += 1
+            return real(*a, **kw)
+
+        F.EVAL_L16 = on
+        F.conv_l16 = counted
+        try:
+            with torch.no_grad():
+                outs[on] = model(signal)["class_logits"].clone()
+        finally:
+            F.EVAL_L16 = True
+            F.conv_l16 = real
+        calls[on] = count[0]
+    assert calls[False] == 0 and calls[True] >= 4, calls
+    scale = outs[False].abs().max().item()
+    assert (outs[True] - outs[False]).abs().max().item() <= 1e-4 * max(1.0, scale)
