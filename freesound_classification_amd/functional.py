@@ -295,6 +295,30 @@ def l16_plan_name(desc, dgrad):
     return buf.value.decode().split(" ")[0]
 
 
+# Inference: the forward fragments of a weight are reused across batches.  The fragment layout depends on the tiling only through
+# (channel tiles per block, channel blocks), so length-grouped batches of different shapes share one packing.  Entries are keyed by
+# the weight's address AND version; the library's own optimizers write through raw pointers (no version bump) and therefore call
+# forget_packed_weights() in their step().
+_EVAL_PACKS = {}
+_PLAN_SIG = {}
+
+
+def forget_packed_weights():
+    _EVAL_PACKS.clear()
+
+
+def _l16_plan_sig(d):
+    key = tuple(getattr(d, f) for f, _ in d._fields_)
+    if key not in _PLAN_SIG:
+        buf = C.create_string_buffer(256)
+        call("fsc_conv_l16_plan_describe", C.byref(d), 0, buf, 256)
+        txt = buf.value.decode()                     # conv_l16_fwd_kernel<kh,kw,cot,pt> box=... items=TILESxBLOCKS ...
+        cot = int(txt.split("<")[1].split(">")[0].split(",")[2])
+        blocks = int(txt.split("items=")[1].split(" ")[0].split("x")[1])
+        _PLAN_SIG[key] = (cot, blocks)
+    return _PLAN_SIG[key]
+
+
 def conv_l16_pack(weight, n, h, w, dgrad):
     """Packed A fragments of `weight` for fsc_conv_l16_fwd on (n, ., h, w) activations: (descriptor, packed)."""
     c_out, c_in, kh, kw = weight.shape
@@ -303,8 +327,18 @@ def conv_l16_pack(weight, n, h, w, dgrad):
     nfl = _lib.load().fsc_conv_l16_packed_floats(C.byref(d), dg)
     if nfl == 0:
         raise _lib.FscError("conv_l16: unsupported shape %s" % [getattr(d, f) for f, _ in d._fields_])
+    key = None
+    if not dgrad and not torch.is_grad_enabled():
+        key = (weight.data_ptr(), weight._version, tuple(weight.shape), nfl) + _l16_plan_sig(d)
+        hit = _EVAL_PACKS.get(key)
+        if hit is not None:
+            return d, hit[0]
     packed = torch.empty(nfl, device=weight.device, dtype=torch.float32)
     call("fsc_conv_l16_pack_weights", C.byref(d), ptr(weight), dg, ptr(packed), stream_ptr())
+    if key is not None:
+        if len(_EVAL_PACKS) > 4096:
+            _EVAL_PACKS.clear()
+        _EVAL_PACKS[key] = (packed, weight)          # (the weight is kept alive: its address cannot be reused meanwhile)
     return d, packed
 
 

@@ -13,6 +13,12 @@ from .. import _lib
 from .._lib import OptTensor, call, stream_ptr
 
 
+def _forget_packed_weights():
+    # the kernels below update the weights through raw pointers (no tensor version bump): packed copies kept for inference go
+    from .. import functional
+    functional.forget_packed_weights()
+
+
 def _table(entries):
     arr = (OptTensor * len(entries))()
     for i, (p, g, s0, s1, s2) in enumerate(entries):
@@ -52,6 +58,7 @@ class FusedAdam(Optimizer):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
+        _forget_packed_weights()
         for group in self.param_groups:
             entries = []
             step = None
@@ -100,6 +107,7 @@ class FusedSGD(Optimizer):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
+        _forget_packed_weights()
         for group in self.param_groups:
             fresh, warm = [], []
             for p in group["params"]:
