@@ -14,7 +14,7 @@
 namespace {
 
 constexpr int kThreads = 256;
-constexpr int kTileRows = 8;            // pooled rows per block
+constexpr int kTileRows = 4;            // pooled rows per block
 
 template <int CIN>
 __global__ __launch_bounds__(kThreads) void stem_wgrad_pooled_kernel(const float* __restrict__ a, const float* __restrict__ dp,
@@ -25,11 +25,16 @@ __global__ __launch_bounds__(kThreads) void stem_wgrad_pooled_kernel(const float
     const int n = blockIdx.y, r0 = blockIdx.x * kTileRows;            // first pooled row of the tile
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     // ---- the conv input rows 2 r0 - 1 .. 2 r0 + 2 kTileRows, columns -1 .. w (zero outside the image)
+    // A tile row is stored de-interleaved: even tile columns in [0, wh), odd ones in [wh, 2 wh) with wh = 32 (mod 64) -- lane ox
+    // reads tile column 2 ox + rx + tx, i.e. element ox + ((rx + tx) >> 1) of the even or the odd half: consecutive lanes hit
+    // consecutive banks and the two halves sit 32 banks apart (interleaved, the stride-2 gather was a 2-way bank conflict).
+    const int wh = wp >> 1;
     for (int i = threadIdx.x; i < CIN * TROWS * wp; i += kThreads) {
         const int ci = i / (TROWS * wp), rem = i - ci * (TROWS * wp);
         const int tr = rem / wp, tc = rem - tr * wp;
         const int y = 2 * r0 - 1 + tr, x = tc - 1;
-        atile[i] = (y >= 0 && y < h && x >= 0 && x < w) ? a[((long)(n * CIN + ci) * h + y) * w + x] : 0.f;
+        atile[(ci * TROWS + tr) * wp + (tc & 1) * wh + (tc >> 1)] =
+            (y >= 0 && y < h && x >= 0 && x < w) ? a[((long)(n * CIN + ci) * h + y) * w + x] : 0.f;
     }
     __syncthreads();
     const int rows = min(kTileRows, oh - r0);
@@ -63,14 +68,20 @@ __global__ __launch_bounds__(kThreads) void stem_wgrad_pooled_kernel(const float
                 const int pos = pv[buf][cch];
                 const int ry = pos >> 1, rx = pos & 1;
                 const int y = 2 * pr + ry, x = ox < ow ? 2 * ox + rx : 0;   // tile row of tap ty = 0 / column of tap tx = 0
-                const float* t = atile + y * wp + x;
+                const int oxs = ox < ow ? ox : 0;
+                // tile column x + tx = 2 oxs + rx + tx -> half (rx + tx) & 1, element oxs + ((rx + tx) >> 1)
+                const float* t0 = atile + y * wp + oxs + (rx ? wh : 0);            // tx = 0
+                const float* t1 = atile + y * wp + oxs + (rx ? 1 : wh);            // tx = 1
+                const float* t2 = atile + y * wp + oxs + (rx ? wh + 1 : 1);        // tx = 2
 #pragma unroll
                 for (int ci = 0; ci < CIN; ++ci)
 #pragma unroll
-                    for (int ty = 0; ty < 3; ++ty)
-#pragma unroll
-                        for (int tx = 0; tx < 3; ++tx)
-                            acc[(ci * 3 + ty) * 3 + tx] = fmaf(d, t[(ci * TROWS + ty) * wp + tx], acc[(ci * 3 + ty) * 3 + tx]);
+                    for (int ty = 0; ty < 3; ++ty) {
+                        const int o = (ci * TROWS + ty) * wp;
+                        acc[(ci * 3 + ty) * 3 + 0] = fmaf(d, t0[o], acc[(ci * 3 + ty) * 3 + 0]);
+                        acc[(ci * 3 + ty) * 3 + 1] = fmaf(d, t1[o], acc[(ci * 3 + ty) * 3 + 1]);
+                        acc[(ci * 3 + ty) * 3 + 2] = fmaf(d, t2[o], acc[(ci * 3 + ty) * 3 + 2]);
+                    }
                 const int gy = 2 * (r0 + pr) + ry;                           // position of the non-zero in the un-pooled gradient
                 const bool top = gy == 0, bot = gy == h - 1, lef = x == 0, rig = x == w - 1;
                 bs[0] += top ? d : 0.f; bs[1] += bot ? d : 0.f; bs[2] += lef ? d : 0.f; bs[3] += rig ? d : 0.f;
@@ -115,9 +126,16 @@ __global__ __launch_bounds__(kThreads) void stem_wgrad_pooled_kernel(const float
     }
 }
 
+// tile row pitch: >= w + 2, even, half of it = 32 (mod 64) floats (the two de-interleaved halves 32 banks apart)
+int tile_pitch(int w) {
+    int wh = (w + 2 + 1) / 2;
+    wh += (32 - (wh & 63) + 64) & 63;
+    return 2 * wh;
+}
+
 bool supported(const fsc_conv_desc* d) {
     return d && d->kh == 3 && d->kw == 3 && d->c_in >= 1 && d->c_in <= 2 && d->h >= 2 && d->w >= 8 && d->n > 0 && d->c_out > 0 &&
-           (size_t)d->c_in * (2 * kTileRows + 2) * (d->w + 2 + 3) * sizeof(float) <= 64 * 1024;
+           (size_t)d->c_in * (2 * kTileRows + 2) * tile_pitch(d->w) * sizeof(float) <= 80 * 1024;
 }
 
 }  // namespace
@@ -134,10 +152,12 @@ int fsc_conv_stem_wgrad_pooled(const fsc_conv_desc* d, const float* in, const fl
                                float* partial, fsc_stream_t stream) {
     FSC_CHECK_ARG(supported(d) && in && dpooled && pool_idx && partial, "fsc_conv_stem_wgrad_pooled: unsupported shape or null pointer");
     const int oh = d->h / 2, ow = d->w / 2;
-    const int wp = (d->w + 2 + 3) & ~3;
+    const int wp = tile_pitch(d->w);
     dim3 grid(fsc::ceil_div(oh, kTileRows), d->n);
     const size_t lds = sizeof(float) * (size_t)d->c_in * (2 * kTileRows + 2) * wp;
     hipStream_t st = fsc::as_stream(stream);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&stem_wgrad_pooled_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&stem_wgrad_pooled_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (d->c_in == 1)
         hipLaunchKernelGGL(stem_wgrad_pooled_kernel<1>, grid, dim3(kThreads), lds, st, in, dpooled, pool_idx, partial, d->c_out, d->h, d->w, oh, ow, wp);
     else
