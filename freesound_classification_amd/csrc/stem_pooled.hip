@@ -82,11 +82,16 @@ __global__ __launch_bounds__(kThreads) void stem_wgrad_pooled_kernel(const float
                         acc[(ci * 3 + ty) * 3 + 1] = fmaf(d, t1[o], acc[(ci * 3 + ty) * 3 + 1]);
                         acc[(ci * 3 + ty) * 3 + 2] = fmaf(d, t2[o], acc[(ci * 3 + ty) * 3 + 2]);
                     }
+                // border sums: only the first / last pooled row and the chunks that hold the first / last pooled column can
+                // contribute (wave-uniform test)
                 const int gy = 2 * (r0 + pr) + ry;                           // position of the non-zero in the un-pooled gradient
-                const bool top = gy == 0, bot = gy == h - 1, lef = x == 0, rig = x == w - 1;
-                bs[0] += top ? d : 0.f; bs[1] += bot ? d : 0.f; bs[2] += lef ? d : 0.f; bs[3] += rig ? d : 0.f;
-                bs[4] += (top && lef) ? d : 0.f; bs[5] += (top && rig) ? d : 0.f;
-                bs[6] += (bot && lef) ? d : 0.f; bs[7] += (bot && rig) ? d : 0.f;
+                const int c_abs = cch0 + cch;
+                if (r0 + pr == 0 || 2 * (r0 + pr) + 1 >= h - 1 || c_abs == 0 || c_abs == ((ow - 1) >> 6)) {
+                    const bool top = gy == 0, bot = gy == h - 1, lef = x == 0, rig = x == w - 1;
+                    bs[0] += top ? d : 0.f; bs[1] += bot ? d : 0.f; bs[2] += lef ? d : 0.f; bs[3] += rig ? d : 0.f;
+                    bs[4] += (top && lef) ? d : 0.f; bs[5] += (top && rig) ? d : 0.f;
+                    bs[6] += (bot && lef) ? d : 0.f; bs[7] += (bot && rig) ? d : 0.f;
+                }
             }
         };
         if (ow <= kChunks * 64) {
