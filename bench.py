@@ -18,6 +18,8 @@ box's host cores on a bounded sample: batch 8 of the same model and clip length,
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -231,6 +233,76 @@ def run_inference(args, w, device, world, rank):
         dist.destroy_process_group()
 
 
+XGMI_LINK_GBPS = 153.0            # per link and direction; 7 links per GPU (MI355X_MICROARCH.md / SURVEY section 5)
+GRAD_BYTES_CFG2 = 21545583 * 4    # the one exchange of the path: a sum all-reduce of the fp32 gradients (86.18 MB)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def self_launch(n):
+    """`python bench.py --gpus N` with N > 1 and no torch.distributed.run environment: start the N ranks ourselves
+    (one process per GPU on this node, rendezvous on 127.0.0.1) with the same arguments; rank 0's JSON line is the only
+    thing that reaches this process's stdout.  Returns the launcher's exit code."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC (RCCL across processes on this driver)
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 1) // n)))
+    return subprocess.call(cmd, env=env)
+
+
+def allreduce_probe(device, world, nbytes, iters=10, warm=3):
+    """Sum all-reduce of an `nbytes` fp32 buffer (the gradient payload) alone on the wire: ms, algorithm GB/s (payload / time)
+    and bus GB/s (2 (n - 1) / n x payload / time: what each GPU sends and receives), next to what xGMI offers."""
+    buf = torch.ones(nbytes // 4, device=device, dtype=torch.float32)
+    sync = torch.cuda.synchronize if device.type == "cuda" else (lambda: None)
+    for _ in range(warm):
+        dist.all_reduce(buf)
+    sync()
+    dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        dist.all_reduce(buf)
+    sync()
+    dt = (time.perf_counter() - t0) / iters
+    t = torch.tensor([dt], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
+    bus = 2.0 * (world - 1) / world * nbytes / dt / 1e9
+    return {"payload_bytes": int(nbytes), "ms": 1e3 * dt, "algo_GBps": nbytes / dt / 1e9, "bus_GBps": bus,
+            "xgmi_link_GBps": XGMI_LINK_GBPS, "xgmi_links_per_gpu": 7,
+            "frac_of_one_link": bus / XGMI_LINK_GBPS, "backend": dist.get_backend()}
+
+
+def launch_check(args, world, rank, local_rank):
+    """--launch-check: the rendezvous, barrier and gradient-sized all-reduce of the N-rank job without the model (backend
+    `gloo` runs on CPU: tests/test_parallel_cpu.py drives the self-launcher through it; `nccl` = RCCL measures the
+    86.18 MB exchange alone).  Rank 0 prints one JSON line."""
+    for k, v in (("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "29533"), ("RANK", "0"), ("WORLD_SIZE", "1")):
+        os.environ.setdefault(k, v)
+    if args.backend == "nccl":
+        torch.cuda.set_device(local_rank)
+        device = torch.device("cuda", local_rank)
+        dist.init_process_group("nccl", device_id=device)
+    else:
+        device = torch.device("cpu")
+        dist.init_process_group("gloo")
+    assert dist.get_world_size() == world and dist.get_rank() == rank
+    dist.barrier()
+    probe = allreduce_probe(device, world, args.check_bytes, iters=3, warm=1)
+    ranks = [None] * world
+    dist.all_gather_object(ranks, (rank, local_rank, os.getpid()))
+    if rank == 0:
+        _emit(json.dumps({"launch_check": True, "n_gpus": world, "ranks": ranks, "allreduce": probe}))
+    dist.destroy_process_group()
+
+
 _RESULT_FD = None
 
 
@@ -252,7 +324,19 @@ def main():
     ap.add_argument("--kernel-table", action="store_true", help="print per-kernel timing to stderr")
     ap.add_argument("--arith", default=None, choices=["f32", "bf16", "f16x3", "bf16x6", "bf16x9"],
                     help="conv arithmetic (default: the workload's, else the library default f16x3)")
+    ap.add_argument("--launch-check", action="store_true",
+                    help="rendezvous + barrier + gradient-sized all-reduce only (no model); with --backend gloo it runs on CPU")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="process-group backend (gloo: --launch-check only)")
+    ap.add_argument("--check-bytes", type=int, default=GRAD_BYTES_CFG2, help="payload of the --launch-check all-reduce")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.backend != "nccl" and not args.launch_check:
+        raise SystemExit("--backend gloo is for --launch-check only: the step itself needs the GPUs (no CPU fallback)")
+
+    # N > 1 without a launcher environment: become the launcher (the driver calls `python bench.py --gpus N ...`)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args.gpus))
 
     # stdout carries exactly ONE line, the JSON result: anything the libraries print there (RCCL writes its version banner to
     # stdout when the first communicator comes up) goes to stderr instead
@@ -265,7 +349,9 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch N > 1 with torch.distributed.run" % (args.gpus, world))
+        raise SystemExit("--gpus %d but the launcher environment says WORLD_SIZE=%d" % (args.gpus, world))
+    if args.launch_check:
+        return launch_check(args, world, rank, local_rank)
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1 or os.environ.get("FSC_FORCE_DP") == "1":
@@ -331,10 +417,16 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - t0
     F.TIMER = None
+    per_rank = None
+    exchange = None
     if world > 1:
-        tmax = torch.tensor([elapsed], device=device, dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
+        mine = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        per_rank = [batch * args.steps / float(t.item()) for t in every]          # clips/s of each rank over its own clock
+        elapsed = max(float(t.item()) for t in every)
+        # the exchange step alone (outside the timed region): the gradient all-reduce with nothing else on the wire
+        exchange = allreduce_probe(device, world, 4 * sum(p.numel() for p in model.parameters()))
     final_loss = float(loss.detach())
     # The same workload with the native fp32-MFMA conv kernels (FSC_CONV_ARITH=f32), for readers who want the
     # number without the split-limb arithmetic; N = 1 only, outside the timed region of `value`.
@@ -411,7 +503,10 @@ def main():
             "vs_baseline": None,
             # f32: tensors, accumulators and results are fp32 (see roofline.arithmetic for how the conv products are formed);
             # bf16: conv operands rounded to bf16, fp32 accumulation / storage / master weights
-            "dtype": "bf16" if F.get_conv_arith() == 1 else "f32",
+            # (f16x3 products: every fp32 product is formed from two scaled fp16 limbs per operand, low x low dropped)
+            "dtype": {0: "f32", 1: "bf16", 3: "f32 (f16x3 products)", 6: "f32 (bf16x6 products)",
+                      9: "f32 (bf16x9 products)"}[F.get_conv_arith()],
+            "arith_bits": {0: 24, 1: 8, 3: 22, 6: 23, 9: 24}[F.get_conv_arith()],   # significand bits a conv product keeps
             "data": "synthetic",
             "config": {"workload": "%s: batch %d x %.0f s @ %.1f kHz, %s, %d-block %dd CNN base %d growth %g, "
                                    "LSEP, Adam-amsgrad, dropout %g" % (
@@ -467,8 +562,12 @@ def main():
                 "conv_ms_per_step": {k: v["ms"] / args.steps for k, v in fam.items()},
                 "conv_tflops": {k: v["flops"] / v["ms"] / 1e9 for k, v in fam.items()},
             }
+        if per_rank is not None:
+            result["per_rank_clips_per_s"] = per_rank
+            result["allreduce"] = exchange
         if alt is not None:
             result["alt_f32"] = alt
+            result["config"]["strict_f32_clips_per_s"] = alt["value"]      # the same step on the native fp32-MFMA kernels
         if h2d is not None:
             result["with_h2d"] = h2d
         if world == 1 and not args.no_cpu_baseline:

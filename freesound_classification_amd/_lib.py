@@ -51,7 +51,9 @@ SIGNATURES = {
     "fsc_conv_pool_supported": (_I, [_D]),
     "fsc_conv_pool_fwd": (_I, [_D, _P, _P, _P, _P, _P, _P]),
     "fsc_conv_stem_wgrad_pooled_blocks": (_SZ, [_D]),
-    "fsc_conv_stem_wgrad_pooled": (_I, [_D, _P, _P, _P, _P, _P]),
+    "fsc_conv_stem_wgrad_pooled": (_I, [_D, _P, _P, _P, _P, _P, _P, _P]),
+    "fsc_conv_stem_grads_finish": (_I, [_D, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P]),
+    "fsc_absmin": (_I, [_P, _L, _P, _P]),
     "fsc_conv_plan_describe": (_I, [_D, _I, C.c_char_p, _SZ]),
     "fsc_conv_default_arith": (_I, []),
     "fsc_conv_wgrad_workspace_bytes": (_SZ, [_D]),

@@ -24,6 +24,17 @@ __global__ void fill_kernel(float* __restrict__ x, float v, long count) {
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (long)gridDim.x * blockDim.x) x[i] = v;
 }
 
+__global__ __launch_bounds__(256) void absmin_kernel(const float* __restrict__ x, long n, float* __restrict__ out) {
+    __shared__ float part[4];
+    float m = INFINITY;
+    for (long i = threadIdx.x; i < n; i += 256) m = fminf(m, fabsf(x[i]));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fminf(m, __shfl_xor(m, o, 64));
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) out[0] = fminf(fminf(part[0], part[1]), fminf(part[2], part[3]));
+}
+
 __global__ void axpy_kernel(const float* __restrict__ x, float a, float* __restrict__ y, long count) {
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (long)gridDim.x * blockDim.x)
         y[i] = fmaf(a, x[i], y[i]);
@@ -177,6 +188,13 @@ extern "C" {
 int fsc_version(void) { return 100; /* 0.1.0 */ }
 
 const char* fsc_last_error_string(void) { return fsc::g_error; }
+
+int fsc_absmin(const float* x, long n, float* out, fsc_stream_t stream) {
+    FSC_CHECK_ARG(x && out && n > 0, "fsc_absmin: bad arguments");
+    hipLaunchKernelGGL(absmin_kernel, dim3(1), dim3(256), 0, fsc::as_stream(stream), x, n, out);
+    FSC_LAUNCH_CHECK("fsc_absmin");
+    return 0;
+}
 
 int fsc_fill(float* x, float value, long count, fsc_stream_t stream) {
     FSC_CHECK_ARG(x && count > 0, "fsc_fill: bad arguments");

@@ -171,64 +171,111 @@ __global__ void stats_rows_kernel(const float* __restrict__ x, int n, int c, dou
     o[3] = (double)mx;
 }
 
-// Cross-replica statistics (SyncBN, SURVEY 8e): `sync` holds per channel [sum x, sum x^2, count, -] about ZERO in
-// fp64.  phase 1 stops after writing the local moments there; the caller sum-all-reduces the buffer; phase 2
-// finalises from it.  phase 0 is the single-replica path (local pivot-shifted sums, no detour through `sync`).
-__global__ void stats_finalize_kernel(const float* __restrict__ x, int c, long hw, double count, int nsplit,
-                                      const double* __restrict__ part, const float* __restrict__ gamma,
-                                      const float* __restrict__ beta, float eps, float momentum,
-                                      float* running_mean, float* running_var, float* save_mean,
-                                      float* save_invstd, float* scale, float* shift, double* __restrict__ sync,
-                                      int phase, float* __restrict__ x_minmax, int pivot_rm, int minmax_only) {
-    const int ch = blockIdx.x * blockDim.x + threadIdx.x;
-    if (ch >= c) return;
-    if (x_minmax && phase != 2) {          // (phase 2 re-runs on the partials of phase 1: already written)
-        float mn = (float)part[(size_t)ch * kMaxSplit * kPartStride + 2], mx = (float)part[(size_t)ch * kMaxSplit * kPartStride + 3];
-        for (int s = 1; s < nsplit; ++s) {
-            mn = fminf(mn, (float)part[((size_t)ch * kMaxSplit + s) * kPartStride + 2]);
-            mx = fmaxf(mx, (float)part[((size_t)ch * kMaxSplit + s) * kPartStride + 3]);
-        }
-        x_minmax[2 * ch] = mn;
-        x_minmax[2 * ch + 1] = mx;
-    }
-    if (minmax_only) return;               // (inference: the BatchNorm runs on its running statistics)
-    double s1 = 0.0, s2 = 0.0, pivot = 0.0;
-    if (phase == 2) {
-        s1 = sync[ch * 4];
-        s2 = sync[ch * 4 + 1];
-        count = sync[ch * 4 + 2];
-    } else {
-        for (int s = 0; s < nsplit; ++s) {
-            s1 += part[((size_t)ch * kMaxSplit + s) * kPartStride];
-            s2 += part[((size_t)ch * kMaxSplit + s) * kPartStride + 1];
-        }
-        // pivot of the shifted sums: the channel's first element, or (sums from a STATS convolution) the running mean as it is
-        // BEFORE this call updates it -- 0 without running statistics
-        pivot = pivot_rm ? (running_mean ? (double)running_mean[ch] : 0.0) : (double)x[(long)ch * hw];
-        if (phase == 1) {                                  // moments about zero: sum (a + p) and sum (a + p)^2
-            sync[ch * 4] = s1 + count * pivot;
-            sync[ch * 4 + 1] = s2 + 2.0 * pivot * s1 + count * pivot * pivot;
-            sync[ch * 4 + 2] = count;
-            sync[ch * 4 + 3] = 0.0;
-            return;
-        }
+struct FinalizeArgs {
+    const float* x; int c; long hw; double count; int nsplit; const double* part; const float* gamma; const float* beta;
+    float eps, momentum; float* running_mean; float* running_var; float* save_mean; float* save_invstd; float* scale; float* shift;
+    double* sync; int phase; float* x_minmax; int pivot_rm, minmax_only;
+};
+
+// (s1, s2): the channel's sums of (x - pivot), (x - pivot)^2 over `count` elements (unused in phase 2)
+__device__ __forceinline__ void finalize_channel(const FinalizeArgs& a, int ch, double s1, double s2, double pivot) {
+    double count = a.count;
+    if (a.phase == 2) {
+        s1 = a.sync[ch * 4];
+        s2 = a.sync[ch * 4 + 1];
+        count = a.sync[ch * 4 + 2];
+        pivot = 0.0;
+    } else if (a.phase == 1) {                               // moments about zero: sum (a + p) and sum (a + p)^2
+        a.sync[ch * 4] = s1 + count * pivot;
+        a.sync[ch * 4 + 1] = s2 + 2.0 * pivot * s1 + count * pivot * pivot;
+        a.sync[ch * 4 + 2] = count;
+        a.sync[ch * 4 + 3] = 0.0;
+        return;
     }
     const double m1 = s1 / count;
     const double mean = pivot + m1;
     double var = s2 / count - m1 * m1;
     if (var < 0.0) var = 0.0;
-    const double invstd = 1.0 / sqrt(var + (double)eps);
-    if (running_mean) {
+    const double invstd = 1.0 / sqrt(var + (double)a.eps);
+    if (a.running_mean) {
         const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
-        running_mean[ch] = (float)((1.0 - momentum) * running_mean[ch] + momentum * mean);
-        running_var[ch] = (float)((1.0 - momentum) * running_var[ch] + momentum * unbiased);
+        a.running_mean[ch] = (float)((1.0 - a.momentum) * a.running_mean[ch] + a.momentum * mean);
+        a.running_var[ch] = (float)((1.0 - a.momentum) * a.running_var[ch] + a.momentum * unbiased);
     }
-    save_mean[ch] = (float)mean;
-    save_invstd[ch] = (float)invstd;
-    const float g = gamma ? gamma[ch] : 1.f, b = beta ? beta[ch] : 0.f;
+    a.save_mean[ch] = (float)mean;
+    a.save_invstd[ch] = (float)invstd;
+    const float g = a.gamma ? a.gamma[ch] : 1.f, b = a.beta ? a.beta[ch] : 0.f;
     const float sc = g * (float)invstd;
-    scale[ch] = sc;
-    shift[ch] = b - (float)mean * sc;
+    a.scale[ch] = sc;
+    a.shift[ch] = b - (float)mean * sc;
+}
+
+// Cross-replica statistics (SyncBN, SURVEY 8e): `sync` holds per channel [sum x, sum x^2, count, -] about ZERO in
+// fp64.  phase 1 stops after writing the local moments there; the caller sum-all-reduces the buffer; phase 2
+// finalises from it.  phase 0 is the single-replica path (local pivot-shifted sums, no detour through `sync`).
+__global__ void stats_finalize_kernel(FinalizeArgs a) {
+    const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ch >= a.c) return;
+    const double* part = a.part;
+    if (a.x_minmax && a.phase != 2) {      // (phase 2 re-runs on the partials of phase 1: already written)
+        float mn = (float)part[(size_t)ch * kMaxSplit * kPartStride + 2], mx = (float)part[(size_t)ch * kMaxSplit * kPartStride + 3];
+        for (int s = 1; s < a.nsplit; ++s) {
+            mn = fminf(mn, (float)part[((size_t)ch * kMaxSplit + s) * kPartStride + 2]);
+            mx = fmaxf(mx, (float)part[((size_t)ch * kMaxSplit + s) * kPartStride + 3]);
+        }
+        a.x_minmax[2 * ch] = mn;
+        a.x_minmax[2 * ch + 1] = mx;
+    }
+    if (a.minmax_only) return;             // (inference: the BatchNorm runs on its running statistics)
+    double s1 = 0.0, s2 = 0.0, pivot = 0.0;
+    if (a.phase != 2) {
+        for (int s = 0; s < a.nsplit; ++s) {
+            s1 += part[((size_t)ch * kMaxSplit + s) * kPartStride];
+            s2 += part[((size_t)ch * kMaxSplit + s) * kPartStride + 1];
+        }
+        // pivot of the shifted sums: the channel's first element, or (sums from a STATS convolution) the running mean as it is
+        // BEFORE this call updates it -- 0 without running statistics
+        pivot = a.pivot_rm ? (a.running_mean ? (double)a.running_mean[ch] : 0.0) : (double)a.x[(long)ch * a.hw];
+    }
+    finalize_channel(a, ch, s1, s2, pivot);
+}
+
+// The same for sums that a STATS convolution took about the BatchNorm's RUNNING mean (pivot_rm, split 0 only; phases 0 and 1),
+// one workgroup per channel.  Those sums are fp32 per lane: when the batch mean lies far from the pivot (the first step after
+// loading a checkpoint from another domain, a large conv bias under running_mean = 0) sum (y - p)^2 - (sum (y - p))^2 / n
+// cancels and the variance loses (mean - p)^2 / var of its digits.  Gate: |mean - p| > kGateSigmas standard deviations (or a
+// non-positive variance estimate) -> the workgroup re-reduces its channel of x about the (accurate) mean estimate, in fp64, and
+// finalises from that.  The min / max of the records are exact either way.
+constexpr double kGateSigmas = 4.0;
+__global__ __launch_bounds__(kThreads) void stats_finalize_gated_kernel(FinalizeArgs a, int n) {
+    __shared__ double scratch[kThreads / 64];
+    const int ch = blockIdx.x;
+    const double* part = a.part + (size_t)ch * kMaxSplit * kPartStride;
+    if (a.x_minmax && threadIdx.x == 0) {
+        a.x_minmax[2 * ch] = (float)part[2];
+        a.x_minmax[2 * ch + 1] = (float)part[3];
+    }
+    double s1 = part[0], s2 = part[1];
+    double pivot = a.running_mean ? (double)a.running_mean[ch] : 0.0;
+    const double m1 = s1 / a.count, var = s2 / a.count - m1 * m1;
+    if (!(var > 0.0) || m1 * m1 > kGateSigmas * kGateSigmas * var) {      // (workgroup-uniform)
+        const double p2 = pivot + m1;
+        const float p2f = (float)p2;
+        double t1 = 0.0, t2 = 0.0;
+        for (int b = 0; b < n; ++b) {
+            const float* px = a.x + ((long)b * a.c + ch) * a.hw;
+            for (long i = threadIdx.x; i < a.hw; i += kThreads) {
+                const double d = (double)(px[i] - p2f);
+                t1 += d;
+                t2 += d * d;
+            }
+        }
+        __syncthreads();
+        s1 = fsc::block_sum<double, kThreads / 64>(t1, scratch);
+        s2 = fsc::block_sum<double, kThreads / 64>(t2, scratch);
+        pivot = (double)p2f;
+    }
+    if (threadIdx.x == 0) finalize_channel(a, ch, s1, s2, pivot);
 }
 
 __global__ void eval_prepare_kernel(int c, const float* gamma, const float* beta, const float* rm,
@@ -1356,9 +1403,12 @@ int fsc_bn_train_stats(const float* x, int n, int c, long hw, const float* gamma
                                hwp_log2_for(hw), p.part);
         }
     }
-    hipLaunchKernelGGL(stats_finalize_kernel, dim3(fsc::ceil_div(c, 128)), dim3(128), 0, st, x, c, hw,
-                       (double)n * (double)hw, nsplit, p.part, gamma, beta, eps, momentum, running_mean,
-                       running_var, save_mean, save_invstd, scale, shift, sync, phase, x_minmax, pivot_rm, minmax_only);
+    FinalizeArgs fa{x, c, hw, (double)n * (double)hw, nsplit, p.part, gamma, beta, eps, momentum, running_mean, running_var,
+                    save_mean, save_invstd, scale, shift, sync, phase, x_minmax, pivot_rm, minmax_only};
+    if (folded && pivot_rm && phase != 2 && !minmax_only && hw > 1)
+        hipLaunchKernelGGL(stats_finalize_gated_kernel, dim3(c), dim3(kThreads), 0, st, fa, n);
+    else
+        hipLaunchKernelGGL(stats_finalize_kernel, dim3(fsc::ceil_div(c, 128)), dim3(128), 0, st, fa);
     FSC_LAUNCH_CHECK("fsc_bn_train_stats");
     return 0;
 }

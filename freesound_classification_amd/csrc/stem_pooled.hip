@@ -8,7 +8,12 @@
 // owns pooled columns, gathers its 18 inputs from an LDS tile of the (tiny) conv input and accumulates the 18 sums of one
 // output channel; a wave walks its channels one after the other.  The same pass yields the eight border sums of dc that
 // functional._stem_bn_grads needs (first / last row, first / last column, corners).
-// Output: per (block, channel) 32 floats [18 weight-gradient sums | 8 border sums | pad], summed over blocks by the caller.
+// Output: per (block, channel) 32 floats [18 weight-gradient sums | 8 border sums | pad], summed over blocks by
+// fsc_conv_stem_grads_finish, which also turns them into the parameter gradients of the BatchNorm in front of the stem.
+// With (mean, invstd) given the kernel reads the BatchNorm's INPUT x and correlates the gradient with xhat = (x - mean) invstd
+// (zero outside the image, like the padded conv input): dW' = sum dc xhat.  Then, with a = gamma xhat + beta the conv input,
+//     dW = gamma dW' + beta T          dgamma = sum da xhat = sum_{co,tap} w dW'          dbeta = sum da = sum_{co,tap} w T
+// (T[co][tap] = sum of dc[co] over the pixels whose tap neighbour lies inside the image) -- no division by gamma anywhere.
 #include "common.h"
 
 namespace {
@@ -17,7 +22,8 @@ constexpr int kThreads = 256;
 constexpr int kTileRows = 4;            // pooled rows per block
 
 template <int CIN>
-__global__ __launch_bounds__(kThreads) void stem_wgrad_pooled_kernel(const float* __restrict__ a, const float* __restrict__ dp,
+__global__ __launch_bounds__(kThreads) void stem_wgrad_pooled_kernel(const float* __restrict__ a, const float* __restrict__ mean,
+                                                                      const float* __restrict__ invstd, const float* __restrict__ dp,
                                                                       const uint8_t* __restrict__ idx, float* __restrict__ part,
                                                                       int cout, int h, int w, int oh, int ow, int wp) {
     extern __shared__ __attribute__((aligned(16))) float atile[];      // [CIN][2 * kTileRows + 2][wp]
@@ -29,12 +35,19 @@ __global__ __launch_bounds__(kThreads) void stem_wgrad_pooled_kernel(const float
     // reads tile column 2 ox + rx + tx, i.e. element ox + ((rx + tx) >> 1) of the even or the odd half: consecutive lanes hit
     // consecutive banks and the two halves sit 32 banks apart (interleaved, the stride-2 gather was a 2-way bank conflict).
     const int wh = wp >> 1;
+    float sc[CIN], sh[CIN];                 // input affine: identity, or x -> xhat
+#pragma unroll
+    for (int ci = 0; ci < CIN; ++ci) {
+        sc[ci] = mean ? invstd[ci] : 1.f;
+        sh[ci] = mean ? -mean[ci] * invstd[ci] : 0.f;
+    }
     for (int i = threadIdx.x; i < CIN * TROWS * wp; i += kThreads) {
         const int ci = i / (TROWS * wp), rem = i - ci * (TROWS * wp);
         const int tr = rem / wp, tc = rem - tr * wp;
         const int y = 2 * r0 - 1 + tr, x = tc - 1;
+        const float s_ = (CIN == 1 || ci == 0) ? sc[0] : sc[CIN - 1], t_ = (CIN == 1 || ci == 0) ? sh[0] : sh[CIN - 1];
         atile[(ci * TROWS + tr) * wp + (tc & 1) * wh + (tc >> 1)] =
-            (y >= 0 && y < h && x >= 0 && x < w) ? a[((long)(n * CIN + ci) * h + y) * w + x] : 0.f;
+            (y >= 0 && y < h && x >= 0 && x < w) ? fmaf(a[((long)(n * CIN + ci) * h + y) * w + x], s_, t_) : 0.f;
     }
     __syncthreads();
     const int rows = min(kTileRows, oh - r0);
@@ -131,6 +144,84 @@ __global__ __launch_bounds__(kThreads) void stem_wgrad_pooled_kernel(const float
     }
 }
 
+// Sums the partial rows of one output channel over the blocks and finishes what can be finished per channel: the weight gradient
+// (xhat mode: dW = gamma dW' + beta T), the border sums, and this channel's terms of the BatchNorm parameter gradients, which it
+// leaves in pad floats 26 .. 26 + 2 CIN of its own row of block 0 ([sum_tap w T | sum_tap w dW(')] per input channel).
+template <int CIN>
+__global__ __launch_bounds__(256) void stem_grads_reduce_kernel(float* __restrict__ part, int blocks, int cout,
+                                                                 const float* __restrict__ weight, const float* __restrict__ chan_sum,
+                                                                 const float* __restrict__ gamma, const float* __restrict__ beta, int xhat,
+                                                                 float* __restrict__ dweight, float* __restrict__ borders) {
+    __shared__ float red[8][32];
+    const int co = blockIdx.x, k = threadIdx.x & 31, g = threadIdx.x >> 5;
+    float acc = 0.f;
+    for (int b = g; b < blocks; b += 8) acc += part[((long)b * cout + co) * 32 + k];
+    red[g][k] = acc;
+    __syncthreads();
+    if (threadIdx.x < 32) {
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) t += red[i][k];
+        red[0][k] = t;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float* tot = red[0];
+        const float s = chan_sum[co];
+        float T[9];
+        for (int ty = 0; ty < 3; ++ty)
+            for (int tx = 0; tx < 3; ++tx) {
+                float v = s;
+                if (ty == 0) v -= tot[18 + 0];
+                if (ty == 2) v -= tot[18 + 1];
+                if (tx == 0) v -= tot[18 + 2];
+                if (tx == 2) v -= tot[18 + 3];
+                if (ty == 0 && tx == 0) v += tot[18 + 4];
+                if (ty == 0 && tx == 2) v += tot[18 + 5];
+                if (ty == 2 && tx == 0) v += tot[18 + 6];
+                if (ty == 2 && tx == 2) v += tot[18 + 7];
+                T[ty * 3 + tx] = v;
+            }
+        float* scratch = part + (long)co * 32 + 26;
+        for (int ci = 0; ci < CIN; ++ci) {
+            float cb = 0.f, cs = 0.f;
+            for (int tap = 0; tap < 9; ++tap) {
+                const float wv = weight[((long)co * CIN + ci) * 9 + tap], dwx = tot[ci * 9 + tap];
+                cb = fmaf(wv, T[tap], cb);
+                cs = fmaf(wv, dwx, cs);
+                dweight[((long)co * CIN + ci) * 9 + tap] = xhat ? fmaf(gamma[ci], dwx, beta[ci] * T[tap]) : dwx;
+            }
+            scratch[2 * ci] = cb;
+            scratch[2 * ci + 1] = cs;
+        }
+        if (borders)
+            for (int i = 0; i < 8; ++i) borders[co * 8 + i] = tot[18 + i];
+    }
+}
+
+// dbeta[ci] = sum_co cb, dgamma[ci] = sum_co cs (xhat mode) or (sum_co cs - beta dbeta) / gamma (the conv input itself was
+// correlated: singular at gamma = 0, callers guard it -- functional._gamma_ok).
+template <int CIN>
+__global__ __launch_bounds__(256) void stem_bn_finish_kernel(const float* __restrict__ part, int cout, const float* __restrict__ gamma,
+                                                              const float* __restrict__ beta, int xhat, float* __restrict__ dgamma,
+                                                              float* __restrict__ dbeta) {
+    __shared__ float scratch[4];
+    float v[2 * CIN];
+#pragma unroll
+    for (int i = 0; i < 2 * CIN; ++i) v[i] = 0.f;
+    for (int co = threadIdx.x; co < cout; co += 256)
+#pragma unroll
+        for (int i = 0; i < 2 * CIN; ++i) v[i] += part[(long)co * 32 + 26 + i];
+#pragma unroll
+    for (int i = 0; i < 2 * CIN; ++i) v[i] = fsc::block_sum<float, 4>(v[i], scratch);
+    if (threadIdx.x == 0)
+        for (int ci = 0; ci < CIN; ++ci) {
+            const float db = v[2 * ci], x = v[2 * ci + 1];
+            dbeta[ci] = db;
+            dgamma[ci] = xhat ? x : (x - beta[ci] * db) / gamma[ci];
+        }
+}
+
 // tile row pitch: >= w + 2, even, half of it = 32 (mod 64) floats (the two de-interleaved halves 32 banks apart)
 int tile_pitch(int w) {
     int wh = (w + 2 + 1) / 2;
@@ -153,9 +244,10 @@ size_t fsc_conv_stem_wgrad_pooled_blocks(const fsc_conv_desc* d) {
     return (size_t)fsc::ceil_div(d->h / 2, kTileRows) * d->n;
 }
 
-int fsc_conv_stem_wgrad_pooled(const fsc_conv_desc* d, const float* in, const float* dpooled, const uint8_t* pool_idx,
-                               float* partial, fsc_stream_t stream) {
+int fsc_conv_stem_wgrad_pooled(const fsc_conv_desc* d, const float* in, const float* in_mean, const float* in_invstd,
+                               const float* dpooled, const uint8_t* pool_idx, float* partial, fsc_stream_t stream) {
     FSC_CHECK_ARG(supported(d) && in && dpooled && pool_idx && partial, "fsc_conv_stem_wgrad_pooled: unsupported shape or null pointer");
+    FSC_CHECK_ARG((in_mean == nullptr) == (in_invstd == nullptr), "fsc_conv_stem_wgrad_pooled: in_mean and in_invstd come together");
     const int oh = d->h / 2, ow = d->w / 2;
     const int wp = tile_pitch(d->w);
     dim3 grid(fsc::ceil_div(oh, kTileRows), d->n);
@@ -164,10 +256,32 @@ int fsc_conv_stem_wgrad_pooled(const fsc_conv_desc* d, const float* in, const fl
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&stem_wgrad_pooled_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&stem_wgrad_pooled_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (d->c_in == 1)
-        hipLaunchKernelGGL(stem_wgrad_pooled_kernel<1>, grid, dim3(kThreads), lds, st, in, dpooled, pool_idx, partial, d->c_out, d->h, d->w, oh, ow, wp);
+        hipLaunchKernelGGL(stem_wgrad_pooled_kernel<1>, grid, dim3(kThreads), lds, st, in, in_mean, in_invstd, dpooled, pool_idx, partial, d->c_out, d->h, d->w, oh, ow, wp);
     else
-        hipLaunchKernelGGL(stem_wgrad_pooled_kernel<2>, grid, dim3(kThreads), lds, st, in, dpooled, pool_idx, partial, d->c_out, d->h, d->w, oh, ow, wp);
+        hipLaunchKernelGGL(stem_wgrad_pooled_kernel<2>, grid, dim3(kThreads), lds, st, in, in_mean, in_invstd, dpooled, pool_idx, partial, d->c_out, d->h, d->w, oh, ow, wp);
     FSC_LAUNCH_CHECK("fsc_conv_stem_wgrad_pooled");
+    return 0;
+}
+
+int fsc_conv_stem_grads_finish(const fsc_conv_desc* d, float* partial, const float* weight, const float* chan_sum,
+                               const float* gamma, const float* beta, int xhat, float* dweight, float* borders, float* dgamma,
+                               float* dbeta, fsc_stream_t stream) {
+    FSC_CHECK_ARG(supported(d) && partial && weight && chan_sum && dweight, "fsc_conv_stem_grads_finish: unsupported shape or null pointer");
+    FSC_CHECK_ARG(!xhat || (gamma && beta), "fsc_conv_stem_grads_finish: xhat mode needs gamma and beta");
+    FSC_CHECK_ARG((dgamma == nullptr) == (dbeta == nullptr) && (!dgamma || (gamma && beta)),
+                  "fsc_conv_stem_grads_finish: dgamma and dbeta come together and need gamma and beta");
+    const int blocks = (int)fsc_conv_stem_wgrad_pooled_blocks(d);
+    hipStream_t st = fsc::as_stream(stream);
+    if (d->c_in == 1) {
+        hipLaunchKernelGGL(stem_grads_reduce_kernel<1>, dim3(d->c_out), dim3(256), 0, st, partial, blocks, d->c_out, weight, chan_sum,
+                           gamma, beta, xhat, dweight, borders);
+        if (dgamma) hipLaunchKernelGGL(stem_bn_finish_kernel<1>, dim3(1), dim3(256), 0, st, partial, d->c_out, gamma, beta, xhat, dgamma, dbeta);
+    } else {
+        hipLaunchKernelGGL(stem_grads_reduce_kernel<2>, dim3(d->c_out), dim3(256), 0, st, partial, blocks, d->c_out, weight, chan_sum,
+                           gamma, beta, xhat, dweight, borders);
+        if (dgamma) hipLaunchKernelGGL(stem_bn_finish_kernel<2>, dim3(1), dim3(256), 0, st, partial, d->c_out, gamma, beta, xhat, dgamma, dbeta);
+    }
+    FSC_LAUNCH_CHECK("fsc_conv_stem_grads_finish");
     return 0;
 }
 

@@ -1069,26 +1069,34 @@ def _block_params(mods):
             res.conv3.weight, res.conv3.bias, res.bn3.weight, res.bn3.bias, res.prelu3.weight]
 
 
-def stem_wgrad_pooled(a, dp, pidx, weight_shape):
-    """Stem weight gradient straight from the pooled-resolution gradient and the pool indices (fsc_conv_stem_wgrad_pooled):
-    (dW (c_out, c_in, 3, 3), border sums of the never-materialised un-pooled gradient (c_out, 8)), or None when the shape
-    is not a stem layer."""
-    n, c_in, h, w = a.shape
-    c_out = weight_shape[0]
+def stem_grads_pooled(x, st, dp, pidx, weight, chan_sum, bn):
+    """Stem weight gradient straight from the pooled-resolution gradient `dp` and the pool indices, plus the parameter gradients
+    of the BatchNorm `bn` in front of the stem, without the stem's input gradient (fsc_conv_stem_wgrad_pooled +
+    fsc_conv_stem_grads_finish).  x = the BatchNorm's INPUT, st = its statistics: the kernel correlates the gradient
+    with xhat = (x - mean) invstd, from which dW = gamma dW' + beta T, dgamma = sum w dW', dbeta = sum w T follow without any
+    division by gamma.  chan_sum = per-channel total of dp.  Returns (dW, dgamma, dbeta), or None when the shape is not a stem
+    layer."""
+    n, c_in, h, w = x.shape
+    c_out = weight.shape[0]
     d = _desc(n, c_in, c_out, h, w, 3, 3)
     blocks = _lib.load().fsc_conv_stem_wgrad_pooled_blocks(C.byref(d))
-    if blocks == 0 or tuple(weight_shape[2:]) != (3, 3):
+    if blocks == 0 or tuple(weight.shape[2:]) != (3, 3) or st.mean is None:
         return None
-    part = torch.empty(blocks, c_out, 32, device=a.device, dtype=torch.float32)
+    part = torch.empty(blocks, c_out, 32, device=x.device, dtype=torch.float32)
     if TIMER is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    call("fsc_conv_stem_wgrad_pooled", C.byref(d), ptr(a), ptr(dp), ptr(pidx), ptr(part), stream_ptr())
+    call("fsc_conv_stem_wgrad_pooled", C.byref(d), ptr(x), ptr(st.mean), ptr(st.invstd), ptr(dp), ptr(pidx), ptr(part), stream_ptr())
     if TIMER is not None:
         e1.record()
         TIMER.records.append(("conv_stem_wgrad_pooled_kernel<%d>" % c_in, 2.0 * n * h * w * c_in * c_out * 9, e0, e1))
-    tot = part.sum(0)
-    return tot[:, :c_in * 9].reshape(c_out, c_in, 3, 3).contiguous(), tot[:, 18:26].contiguous()
+    dw = GRAD_OUT(weight) if GRAD_OUT is not None else None
+    if dw is None:
+        dw = torch.empty(tuple(weight.shape), device=x.device, dtype=torch.float32)
+    dgamma, dbeta = _empty((c_in,), x), _empty((c_in,), x)
+    call("fsc_conv_stem_grads_finish", C.byref(d), ptr(part), ptr(weight), ptr(chan_sum), ptr(bn.weight), ptr(bn.bias), 1,
+         ptr(dw), None, ptr(dgamma), ptr(dbeta), stream_ptr())
+    return dw, dgamma, dbeta
 
 
 STEM_BN_IDENTITY = True
@@ -1096,6 +1104,29 @@ STEM_BN_IDENTITY = True
 
 def h_w_min(t):
     return min(t.shape[2], t.shape[3])
+
+
+GAMMA_FLOOR = 1e-3     # below this |gamma| the quotient in _stem_bn_grads amplifies fp32 cancellation: take the explicit route
+
+
+class _GammaGuard:
+    """min |gamma| of a BatchNorm weight, computed on the device when the block's forward is enqueued and read on the host
+    when its backward is (a 4-byte pinned copy; the wait ends when the GPU has passed that point of the SAME step's forward,
+    so the host still runs up to one step ahead)."""
+
+    def __init__(self, gamma):
+        dev = _empty((1,), gamma)
+        call("fsc_absmin", ptr(gamma.detach()), gamma.numel(), ptr(dev), stream_ptr())
+        self.host = torch.empty(1, dtype=torch.float32, pin_memory=True)
+        self.host.copy_(dev, non_blocking=True)
+        self.event = torch.cuda.Event()
+        self.event.record()
+        self._keep = dev
+
+    def ok(self):
+        self.event.synchronize()
+        v = float(self.host[0])
+        return v == v and v >= GAMMA_FLOOR
 
 
 def _stem_bn_grads(dc, dc_chan_sum, weight, dweight, bn, borders=None):
@@ -1147,6 +1178,11 @@ class ConvBlockFn(torch.autograd.Function):
             raise _lib.FscError("conv_block: gradients in eval mode (BatchNorm on running statistics) are not on the "
                                 "accelerated path; call model.train() or wrap the forward in torch.no_grad()")
         out, feat, k = _block_forward(x, mods, training, want_head, ph, keep, sync, next_bn)
+        k.gamma_guard = None
+        if (keep and STEM_BN_IDENTITY and not ctx.needs_input_grad[0] and mods[0].weight is not None and x.dim() == 4
+                and tuple(_conv_params(mods[1])[0].shape[2:]) == (3, 3) and not (ph == 2 and _lib.load().fsc_conv_stem_wgrad_pooled_blocks(
+                    C.byref(_desc(x.shape[0], x.shape[1], mods[1].weight.shape[0], x.shape[2], x.shape[3], 3, 3))))):
+            k.gamma_guard = _GammaGuard(mods[0].weight)     # (the quotient route of _stem_bn_grads may be taken in backward)
         ctx.k = k
         ctx.sync = sync
         ctx.mods = mods
@@ -1211,7 +1247,7 @@ class ConvBlockFn(torch.autograd.Function):
         # ---- b = prelu(bn_b(p))
         a_shape = tuple(k.c_shape[:1]) + (wa.shape[1],) + tuple(k.c_shape[2:])
         stem = None
-        if (STEM_BN_IDENTITY and not ctx.x_needs_grad and ph == 2 and k.a is not None and k.a.dim() == 4 and bn_a.weight is not None
+        if (STEM_BN_IDENTITY and not ctx.x_needs_grad and ph == 2 and k.x.dim() == 4 and bn_a.weight is not None and k.st_a.mean is not None
                 and _lib.load().fsc_conv_stem_wgrad_pooled_blocks(C.byref(_desc(a_shape[0], a_shape[1], wa.shape[0], a_shape[2], a_shape[3], 3, 3)))):
             # First block (its input needs no gradient): BN-b backward at the POOLED resolution, the stem weight gradient
             # straight from that and the pool indices, and bn_a's parameter gradients from the weight gradient --
@@ -1219,9 +1255,8 @@ class ConvBlockFn(torch.autograd.Function):
             dp, _, dgb, dbtb, dalb, dbias_a = bn_act_backward(db.contiguous(), k.p, k.st_b, bn_b, prelu_b.weight,
                                                               want_chan_sum=True, sync=sync)
             del db
-            stem = stem_wgrad_pooled(k.a, dp, k.pidx, wa.shape)
-            dwa, borders = stem
-            dga, dbta = _stem_bn_grads(None, dbias_a, wa, dwa, bn_a, borders=borders)
+            stem = stem_grads_pooled(k.x, k.st_a, dp, k.pidx, wa, dbias_a, bn_a)
+            dwa, dga, dbta = stem
             dx = None
             del dp
         if stem is None:
@@ -1231,7 +1266,7 @@ class ConvBlockFn(torch.autograd.Function):
             del db
             dwa = _conv_wgrad_any(k.a, a_16, a_max, dc, _l16_of(dc_m), _amax_of(dc_m), wa)
             if (STEM_BN_IDENTITY and not ctx.x_needs_grad and dc is not None and dc.dim() == 4 and tuple(wa.shape[2:]) == (3, 3)
-                    and bn_a.weight is not None and h_w_min(dc) >= 2):
+                    and bn_a.weight is not None and h_w_min(dc) >= 2 and k.gamma_guard is not None and k.gamma_guard.ok()):
                 # the block input needs no gradient: bn_a's parameter gradients from the weight gradient (no dgrad, no BN backward)
                 dga, dbta = _stem_bn_grads(dc, dbias_a, wa, dwa, bn_a)
                 dx = None

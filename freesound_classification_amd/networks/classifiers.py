@@ -132,6 +132,7 @@ class _TaggingModel(nn.Module):
         self.sync_bn = bool(sync_bn)
         self._bn_sync = None
         self._dropout_state = F.DropoutState()
+        self._froze_gc = False
 
     # ------------------------------------------------------------------ forward
     def _front_end(self, signal):
@@ -160,7 +161,7 @@ class _TaggingModel(nn.Module):
             return self._forward(signal)
 
     def _forward(self, signal):
-        return self.forward_features(self._front_end(signal))
+        return self._forward_features(self._front_end(signal))
 
     def features(self, signal):
         """Front-end only: (N, T, 1) waveforms -> the spectrogram tensor the conv blocks consume.  An ensemble of
@@ -170,6 +171,10 @@ class _TaggingModel(nn.Module):
 
     def forward_features(self, h):
         """Conv blocks + heads + classifier on a precomputed front-end output."""
+        with self._on_device():
+            return self._forward_features(h)
+
+    def _forward_features(self, h):
         if self.dims == 1:
             h = h.unsqueeze(2)              # (N, C, 1, L): the 1-d model is the H == 1 case
         start = self.config.network.start_deep_supervision_on
@@ -230,6 +235,10 @@ class _TaggingModel(nn.Module):
         return class_logits, per, loss
 
     def train_epoch(self, train_loader, epoch, log_interval, write_summary=True):
+        with self._on_device():
+            return self._train_epoch(train_loader, epoch, log_interval, write_summary)
+
+    def _train_epoch(self, train_loader, epoch, log_interval, write_summary=True):
         self.train()
         print("\n" + " " * 10 + "****** Epoch {epoch} ******\n".format(epoch=epoch))
         training_losses = []
@@ -262,6 +271,10 @@ class _TaggingModel(nn.Module):
             self.add_histogram_summaries(training_losses, self.train_writer, self.global_step)
 
     def evaluate(self, loader, verbose=False, write_summary=False, epoch=None):
+        with self._on_device():
+            return self._evaluate(loader, verbose, write_summary, epoch)
+
+    def _evaluate(self, loader, verbose=False, write_summary=False, epoch=None):
         self.eval()
         valid_loss = 0.0
         all_class_probs, all_labels = [], []
@@ -289,6 +302,10 @@ class _TaggingModel(nn.Module):
         return self.evaluate(valid_loader, verbose=True, write_summary=True, epoch=epoch)
 
     def predict(self, loader, n_tta=1):
+        with self._on_device():
+            return self._predict(loader, n_tta)
+
+    def _predict(self, loader, n_tta=1):
         self.eval()
         all_class_probs = []
         for _ in range(n_tta):
@@ -328,8 +345,24 @@ class _TaggingModel(nn.Module):
                 best_score = validation_score
         return scores
 
+    def close(self):
+        """End of a training run with this model: detach the gradient reducer (its autograd hooks hold it and it holds the
+        parameters -- a cycle; the buckets are 86 MB at cfg 2), stop redirecting weight gradients, and return the objects
+        make_optimizer parked in the garbage collector's permanent generation.  The drivers call it once per fold."""
+        if self._reducer is not None:
+            if F.GRAD_OUT == self._reducer.grad_view:
+                F.GRAD_OUT = None
+            self._reducer.remove()
+            self._reducer = None
+        self._bn_sync = None
+        if self._froze_gc:
+            gc.unfreeze()
+            self._froze_gc = False
+
     def make_optimizer(self, max_steps):
         train = self.config.train
+        if self._reducer is not None:              # (a second call on the same model: drop the previous reducer's hooks first)
+            self.close()
         self.optimizer = OPTIMIZERS[train.optimizer](
             self.parameters(), train.learning_rate, weight_decay=train.weight_decay)
         self.scheduler = make_scheduler(train.scheduler, max_steps=max_steps)(self.optimizer)
@@ -341,11 +374,16 @@ class _TaggingModel(nn.Module):
             self.optimizer.grad_scale = 1.0 / parallel.world_size()
             if self.sync_bn:
                 self._bn_sync = parallel.SyncBN()
+            # every replica is seeded alike (same initial weights): give each its own stretch of the counter-based dropout
+            # stream, or row i of every rank would draw the same mask each step
+            self._dropout_state.offset = parallel.rank() << 40
         # The interpreter's full garbage collections walk every object imported so far (torch alone: ~100 ms) and the training
         # loop triggers one every few steps -- in the data-parallel path (hooks, bucket views) as early as the sixth step, a
         # 100 ms hole in a 37 ms step.  Everything alive now is long-lived: park it in the permanent generation.
+        # Undone by close() (fit_validate's callers: once per fold).
         gc.collect()
         gc.freeze()
+        self._froze_gc = True
 
     def load_best_model(self, fold):
         path = os.path.join(self.experiment.checkpoints, "fold_{}".format(fold), "best_model.pth")
@@ -359,5 +397,7 @@ class TwoDimensionalCNNClassificationModel(_TaggingModel):
 
 class HierarchicalCNNClassificationModel(_TaggingModel):
     """Reference networks/classifiers.py:107-480 (spectrogram bins as channels, 1-d blocks).
-    Its training loop uses the scalar-mean LSEP on `logits.squeeze()` (:268-275)."""
+    The reference's 1-d training loop takes the scalar-mean LSEP of `logits.squeeze()` (:268-275); here both models share
+    the per-sample LSEP followed by the mean (`_per_sample_loss`): the same number for batches of two or more clips.  At
+    batch 1 the reference's `squeeze()` drops the batch axis and its loss indexes a 1-d tensor -- not reproduced."""
     dims = 1

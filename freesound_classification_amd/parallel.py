@@ -147,10 +147,25 @@ class BucketedGradReducer:
             b["copy_dst"], b["copy_src"] = [], []
 
     def _launch(self, b):
+        """Stream ordering of a bucket (why no further fences are needed):
+        * backward kernels and the multi-tensor copy write `flat` on the compute stream; the comm stream waits for the
+          compute stream (`wait_stream`) BEFORE the all-reduce is enqueued, so the collective reads finished gradients;
+          under RCCL the collective itself runs on the process group's internal stream, which in turn waits for the comm
+          stream at enqueue time;
+        * finish(): `handle.wait()` makes the compute stream wait for the collective (stream-side, no host block), and the
+          explicit `wait_stream(comm)` orders it behind anything else queued on the comm stream -- the optimizer kernels that
+          read `flat` (through p.grad) are enqueued after both;
+        * the NEXT step's weight-gradient kernels write `flat` through grad_view() on the compute stream, i.e. behind that
+          optimizer step in stream order, hence behind the collective;
+        * `flat` lives as long as the reducer and is never returned to the caching allocator while a step is in flight, so no
+          other tensor can be handed its memory; it is still registered with the comm stream once (`record_stream`, below) so
+          that dropping the reducer mid-flight cannot recycle a bucket under a running collective."""
         flat = b["flat"]
         if flat.is_cuda:
             if self._comm_stream is None:
                 self._comm_stream = torch.cuda.Stream(device=flat.device)
+                for other in self.buckets:
+                    other["flat"].record_stream(self._comm_stream)
             self._comm_stream.wait_stream(torch.cuda.current_stream(flat.device))
             with torch.cuda.stream(self._comm_stream):
                 b["handle"] = all_reduce_sum(flat, self.group, async_op=True)
@@ -195,6 +210,15 @@ class BucketedGradReducer:
         self._sync = False
 
     def remove(self):
+        """Detach from the parameters (the hooks hold the reducer, the reducer holds the parameters: a cycle that only this
+        call breaks) and give the gradients back their own storage, so the buckets can be freed."""
         for h in self._hooks:
             h.remove()
         self._hooks = []
+        for b in self.buckets:
+            for p, _off, _n in b["items"]:
+                if p.grad is not None and p.grad.untyped_storage().data_ptr() == b["flat"].untyped_storage().data_ptr():
+                    p.grad = None
+        self.buckets = []
+        self._where = {}
+        self._by_ptr = {}

@@ -104,10 +104,22 @@ int fsc_conv_pool_fwd(const fsc_conv_desc* d, const float* in, const float* pack
  * (N, c_out, H/2, W/2) and the window indices of fsc_conv_pool_fwd / fsc_maxpool_fwd -- the un-pooled gradient (one non-zero
  * per 2x2 window) is never materialised.  partial: fsc_conv_stem_wgrad_pooled_blocks(d) x c_out x 32 floats; per channel
  * [c_in * 9 weight-gradient sums (ci, ty, tx) | at 18: 8 border sums of the un-pooled gradient in the order of
- * fsc_plane_border_sums | pad]; the caller sums the blocks. */
+ * fsc_plane_border_sums | pad]; fsc_conv_stem_grads_finish sums the blocks.
+ * in_mean / in_invstd (per input channel, both or neither): `in` is then the INPUT of the BatchNorm in front of the stem
+ * (classifiers.py:524) and the sums are taken against xhat = (in - mean) * invstd (zero outside the image) instead of `in`. */
 size_t fsc_conv_stem_wgrad_pooled_blocks(const fsc_conv_desc* d);
-int fsc_conv_stem_wgrad_pooled(const fsc_conv_desc* d, const float* in, const float* dpooled, const uint8_t* pool_idx,
-                               float* partial, fsc_stream_t stream);
+int fsc_conv_stem_wgrad_pooled(const fsc_conv_desc* d, const float* in, const float* in_mean, const float* in_invstd,
+                               const float* dpooled, const uint8_t* pool_idx, float* partial, fsc_stream_t stream);
+/* Finishes fsc_conv_stem_wgrad_pooled: dweight (c_out, c_in, 3, 3) from the partial rows (which it uses as scratch), optionally
+ * the 8 border sums per channel (c_out, 8), and optionally the parameter gradients (c_in each) of the BatchNorm in front of the
+ * stem WITHOUT the stem's input gradient (classifiers.py:524-531).  chan_sum[c_out] = per-channel total of the
+ * un-pooled gradient (= of dpooled).  xhat = 1: the partials were taken against xhat; dweight = gamma dW' + beta T,
+ * dgamma = sum w dW', dbeta = sum w T (T[co][tap]: total minus the border sums the tap excludes) -- no division.  xhat = 0:
+ * the partials were taken against the conv input a = gamma xhat + beta; dgamma = (sum w dW - beta dbeta) / gamma, singular at
+ * gamma = 0 (callers check fsc_absmin(gamma) first). */
+int fsc_conv_stem_grads_finish(const fsc_conv_desc* d, float* partial, const float* weight, const float* chan_sum,
+                               const float* gamma, const float* beta, int xhat, float* dweight, float* borders, float* dgamma,
+                               float* dbeta, fsc_stream_t stream);
 /* human-readable tiling chosen for this shape (mode 0 fwd, 1 dgrad, 2 wgrad): kernel
  * instantiation, pixel box, grid, LDS bytes.  For logs, DESIGN.md tables and profiles. */
 int fsc_conv_plan_describe(const fsc_conv_desc* d, int mode, char* buf, size_t buf_len);
@@ -205,7 +217,10 @@ int fsc_bn_train_stats(const float* x, int n, int c, long hw, const float* gamma
  * fsc_bn_records_fold into this `workspace`): no statistics pass, only the finalisation (x is still read for the pivot). */
 #define FSC_BN_STATS_FOLDED 4
 /* phase | FSC_BN_STATS_PIVOT_RM (with FSC_BN_STATS_FOLDED): the folded sums are about `running_mean` as it is BEFORE this call
- * (0 when running_mean is NULL) instead of the channel's first element: the convention of the STATS convolutions below. */
+ * (0 when running_mean is NULL) instead of the channel's first element: the convention of the STATS convolutions below.
+ * Those sums come from fp32 lane accumulators: when the estimated batch mean lies more than 4 standard deviations from the
+ * pivot (or the variance estimate is not positive) the finalisation re-reduces that channel of x about the mean estimate in
+ * fp64 (one workgroup per channel; never in steady-state training, where the running mean tracks the batch mean). */
 #define FSC_BN_STATS_PIVOT_RM 8
 /* phase | FSC_BN_STATS_MINMAX_ONLY (phase 0): only x_minmax is written (everything else may be NULL) -- inference, where the
  * BatchNorm runs on its running statistics but fsc_bn_act_fwd still needs the range of x to write an L16 tensor. */
@@ -413,6 +428,8 @@ int fsc_sgd_nesterov_step(const fsc_opt_tensor* tensors_host, int n_tensors, flo
  * last column and the four corner elements.  Used to obtain the first block's input-BN parameter gradients from the stem
  * convolution's weight gradient instead of its input gradient (classifiers.py:524-531). */
 int fsc_plane_border_sums(const float* x, int n, int c, int h, int w, float* out, fsc_stream_t stream);
+/* out[0] = min |x[i]| over n >= 1 floats (one small launch: the guard of a division by a parameter vector) */
+int fsc_absmin(const float* x, long n, float* out, fsc_stream_t stream);
 int fsc_fill(float* x, float value, long count, fsc_stream_t stream);
 /* y = a*x + y  (used for gradient accumulation / bucket flattening) */
 int fsc_axpy(const float* x, float a, float* y, long count, fsc_stream_t stream);

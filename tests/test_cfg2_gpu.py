@@ -67,15 +67,17 @@ def _report(line):
         f.write(line + "\n")
 
 
-@pytest.mark.parametrize("batch", ["bench", 4], ids=["n128plan", "n4"])
-@pytest.mark.parametrize("arith", [3, 0], ids=["f16x3", "f32"])
-@pytest.mark.parametrize("layer", LAYERS, ids=["%dto%d_%dx%d_k%d" % l for l in LAYERS])
+# (batch 4 on the planes above 32 x 107 is covered by the batch-128 plan at batch 2 .. 64: not generated)
+_LAYER_CASES = [(l, a, b) for l in LAYERS for a in (3, 0) for b in ("bench", 4) if not (b == 4 and l[2] * l[3] > 32 * 107)]
+
+
+@pytest.mark.parametrize("layer,arith,batch", _LAYER_CASES,
+                         ids=["%dto%d_%dx%d_k%d" % l + "-" + {3: "f16x3", 0: "f32"}[a] + "-" + ("n128plan" if b == "bench" else "n4")
+                              for l, a, b in _LAYER_CASES])
 def test_cfg2_layer_against_fp64(layer, arith, batch):
     """batch "bench": the kernel instantiations (and, up to 8 x 26, the exact plans) batch 128 runs.  batch 4: the
     plans the full-model parity step below runs (split-K, several images per box, partly filled tiles)."""
     c_in, c_out, h, w, k = layer
-    if batch == 4 and h * w > 32 * 107:
-        pytest.skip("batch 4 on the large planes is covered by the batch-128 plan at batch 2 .. 64")
     n = _batch_for(layer, arith) if batch == "bench" else 4
     names = [F.plan_name(F._desc(n, c_in, c_out, h, w, k, k, arith), m) for m in (0, 1, 2)]
     if batch == "bench":

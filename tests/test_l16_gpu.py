@@ -17,16 +17,13 @@ import torch.nn.functional as TF  # noqa: E402
 
 from freesound_classification_amd import functional as F  # noqa: E402
 
+import l16_tables as T  # noqa: E402
+
 DEV = torch.device("cuda:0")
 
 # (n, c_in, c_out, h, w, k): channel counts around the octet / chunk / tile edges, odd widths, boxes that overhang,
 # several images per box, the cfg-2 shapes at a reduced batch
-CONV_CASES = [
-    (16, 100, 100, 64, 215, 3), (16, 100, 150, 64, 215, 3), (24, 150, 150, 32, 107, 3), (32, 150, 225, 32, 107, 3),
-    (64, 225, 225, 16, 53, 3), (128, 337, 337, 8, 26, 3), (128, 506, 506, 4, 13, 3), (16, 100, 100, 64, 215, 1),
-    (32, 150, 150, 32, 107, 1), (128, 225, 225, 16, 53, 1), (40, 33, 49, 17, 29, 3), (40, 64, 48, 30, 31, 3),
-    (36, 57, 130, 23, 40, 3), (64, 95, 64, 9, 77, 1), (48, 127, 97, 12, 20, 3),
-]
+CONV_CASES = list(T.CONV_CASES)          # with the instantiation each one must run (tests/l16_tables.py)
 
 
 def _conv_ref(x, w, b):
@@ -39,6 +36,8 @@ def test_conv_l16_forward_and_dgrad(case):
     F.set_conv_arith("f16x3")
     try:
         d = F._desc(n, cin, cout, h, w, k, k, 3)
+        # the instantiations this test runs are the expected ones (for the cfg-2 shapes: the ones batch 128 selects)
+        assert T.plans(F, *case)[:2] == T.CONV_CASES[case], (T.plans(F, *case)[:2], T.CONV_CASES[case])
         torch.manual_seed(sum(case))
         x = torch.randn(n, cin, h, w, device=DEV) * 3.0
         wt = torch.randn(cout, cin, k, k, device=DEV) / (cin * k * k) ** 0.5
@@ -75,8 +74,7 @@ def test_conv_l16_forward_and_dgrad(case):
             acc = F.conv_l16(t, wt, None, dgrad=True, accumulate_into=base.clone())
             assert (acc - (base + got)).abs().max().item() <= 1e-6 * max(1.0, got.abs().max().item())
             ran += 1
-        if n * h * w >= 128 * 256 and min(cin, cout) >= 48:
-            assert ran > 0, "no L16 tiling for a benchmark-size layer"
+        assert ran == sum(v is not None for v in T.CONV_CASES[case])
     finally:
         F.set_conv_arith(None)
 
@@ -281,10 +279,7 @@ def test_first_block_bn_grads_from_weight_gradient():
             assert (g0[name] - g1[name]).abs().max().item() <= 1e-5 * max(1e-1, g0[name].abs().max().item()), name
 
 
-@pytest.mark.parametrize("case", [(8, 100, 150, 64, 215), (16, 150, 225, 32, 107), (32, 225, 337, 16, 53), (64, 337, 506, 8, 26),
-                                  (24, 64, 96, 17, 43), (12, 48, 80, 30, 64), (128, 506, 759, 4, 13),
-                                  (16, 100, 150, 31, 107), (16, 100, 150, 33, 105), (40, 64, 96, 23, 45)],
-                         ids=lambda c: "x".join(map(str, c)))
+@pytest.mark.parametrize("case", list(T.POOL_CASES), ids=lambda c: "x".join(map(str, c)))
 def test_conv_l16_fused_with_maxpool(case):
     """fsc_conv_l16_pool_fwd == fsc_conv_l16_fwd followed by fsc_maxpool_fwd, bit for bit (values and window indices),
     including odd heights / widths (floor mode) and boxes that overhang the image."""
@@ -296,14 +291,12 @@ def test_conv_l16_fused_with_maxpool(case):
         wt = torch.randn(cout, cin, 3, 3, device=DEV) / (cin * 9) ** 0.5
         bias = torch.randn(cout, device=DEV)
         d = F._desc(n, cin, cout, h, w, 3, 3, 3)
-        if not F.conv_l16_supported(d, 0):
-            pytest.skip("no L16 tiling")
+        assert F.conv_l16_supported(d, 0)
         t = F.l16_pack(x)
         fused = F.conv_l16_pool(t, wt, bias)
-        if n * h * w >= 128 * 16 * 53 and h % 2 == 0:
-            assert fused is not None, "no fused tiling for a benchmark-size layer"
+        assert (fused is not None) == T.POOL_CASES[case][0], "fused conv + pool tiling: expected %s" % (T.POOL_CASES[case][0],)
         if fused is None:
-            pytest.skip("no fused tiling")
+            return                                            # (expected: this shape keeps the separate pool pass)
         p, idx, c_shape = fused
         c = F.conv_l16(t, wt, bias)
         p_ref, idx_ref = F.maxpool_forward(c, 2)
@@ -362,9 +355,7 @@ def test_bn_forward_leaves_statistics_and_global_max(case):
     torch.testing.assert_close(st3.mean, y3.mean((0, 2, 3)), rtol=1e-5, atol=1e-5)
 
 
-STAT_CASES = [(4, 100, 100, 64, 215, 3), (8, 150, 150, 32, 107, 3), (16, 225, 337, 16, 53, 3), (64, 337, 337, 8, 26, 3),
-              (128, 506, 506, 4, 13, 3), (4, 100, 100, 64, 215, 1), (16, 150, 225, 32, 107, 1), (6, 64, 96, 17, 43, 3),
-              (64, 64, 64, 32, 87, 1), (64, 64, 64, 32, 87, 3), (64, 96, 96, 16, 43, 3), (64, 64, 96, 32, 87, 3), (64, 96, 96, 16, 43, 1)]
+STAT_CASES = list(T.STAT_CASES)
 
 
 def _same_bn(bn):
@@ -384,17 +375,19 @@ def test_conv_epilogue_reduces_batchnorm_statistics(case):
     wt = torch.randn(cout, cin, k, k, device=DEV) / (cin * k * k) ** 0.5
     bias = torch.randn(cout, device=DEV) * 3.0                      # (mean far from zero: the pivot matters)
     d = F._desc(n, cin, cout, h, w, k, k, 3)
+    assert F._stats_layout(d, False) == T.STAT_CASES[case], (F._stats_layout(d, False), T.STAT_CASES[case])
     if not F.conv_l16_supported(d, 0):
-        pytest.skip("no L16 tiling")
+        assert T.STAT_CASES[case] is None
+        return                                                # (expected: no L16 tiling for this shape)
     t = F.l16_pack(x, F.amax(x))
     bn, _ = _bn_units(cout)
     bn.running_mean.copy_(bias + 0.1 * torch.randn(cout, device=DEV))
     bn_ref = _same_bn(bn)
     y_ref = F.conv_l16(t, wt, bias)
     y = F.conv_l16(t, wt, bias, stats_bn=(bn, True))
-    if F._stats_layout(d, False) is None:
-        assert not F._PRESTATS
-        pytest.skip("no statistics variant for this tiling")
+    if T.STAT_CASES[case] is None:
+        assert not F._PRESTATS and torch.equal(y, y_ref)      # (expected: the tiling has no statistics variant)
+        return
     assert torch.equal(y, y_ref) and F._PRESTATS
     st = F.bn_prepare(y, bn, True)
     assert not F._PRESTATS
@@ -428,12 +421,10 @@ def test_pooled_conv_epilogue_reduces_batchnorm_statistics(case):
     bn.running_mean.copy_(bias + 0.5)
     bn_ref = _same_bn(bn)
     ref = F.conv_l16_pool(t, wt, bias)
-    if ref is None:
-        pytest.skip("no fused tiling")
+    assert ref is not None and T.POOL_CASES[case][0], "these shapes have a fused conv + pool tiling"
     got = F.conv_l16_pool(t, wt, bias, stats_bn=(bn, True))
     assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1])
-    if F._stats_layout(F._desc(n, cin, cout, h, w, 3, 3, 3), True) is None:
-        pytest.skip("no statistics variant")
+    assert F._stats_layout(F._desc(n, cin, cout, h, w, 3, 3, 3), True) == T.POOL_CASES[case][1] is not None
     assert F._PRESTATS
     st = F.bn_prepare(got[0], bn, True)
     st_ref = F.bn_prepare(ref[0], bn_ref, True)

@@ -226,6 +226,11 @@ def main(model_cls=TwoDimensionalCNNClassificationModel, default_label="2d_cnn",
                 per_rank = len(train) // world
                 lo = parallel.rank() * per_rank
                 train = train[lo:lo + per_rank]
+                # ... and of the noisy rows, so the clean : noisy sampling ratio (and the number of times a noisy clip is
+                # seen per epoch) does not depend on the number of GPUs
+                per_rank = len(noisy_files) // world
+                lo = parallel.rank() * per_rank
+                noisy_files, noisy_labels = noisy_files[lo:lo + per_rank], noisy_labels[lo:lo + per_rank]
             files = [join(args.train_data_dir, f) for f in train_df.fname[train]] + noisy_files
             labels = _split_labels(train_df.labels[train]) + noisy_labels
             clean_tf = [loader_tf, SampleLongAudio(max_length=args.max_audio_length), MapLabels(class_map=class_map)]
@@ -273,6 +278,7 @@ def main(model_cls=TwoDimensionalCNNClassificationModel, default_label="2d_cnn",
                 if is_main:
                     experiment.register_result("fold{}.holdout_metric".format(fold), holdout_metric)
                 print("\nHoldout metric: {:.4f}".format(holdout_metric))
+            model.close()
             del model
             torch.cuda.empty_cache()
 
