@@ -139,3 +139,30 @@ def test_bucket_layout_of_the_real_cfg2_model():
             assert offs[0][0] == 0 and all(a[1] == c[0] for a, c in zip(offs, offs[1:])) and offs[-1][1] == b["flat"].numel()
     finally:
         reducer.remove()
+
+
+@pytest.mark.timeout(300)
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher environment (how the driver calls it) must start two ranks itself; the
+    `--launch-check --backend gloo` leg runs the rendezvous, the barrier and a gradient-sized all-reduce on CPU and prints ONE JSON
+    line on rank 0."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--launch-check", "--backend", "gloo",
+                          "--check-bytes", "262144"], env=env, capture_output=True, text=True, timeout=280)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, out.stdout
+    res = json.loads(lines[0])
+    assert res["launch_check"] is True and res["n_gpus"] == 2
+    assert sorted(r[0] for r in res["ranks"]) == [0, 1] and len({r[2] for r in res["ranks"]}) == 2      # two processes
+    assert res["allreduce"]["payload_bytes"] == 262144 and res["allreduce"]["backend"] == "gloo"
+    # and the mismatch the old entry point died on is now only reported when a launcher environment disagrees
+    env["WORLD_SIZE"] = "3"
+    bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--launch-check", "--backend", "gloo"],
+                         env=env, capture_output=True, text=True, timeout=120)
+    assert bad.returncode != 0 and "WORLD_SIZE=3" in bad.stderr
