@@ -481,8 +481,17 @@ __global__ __launch_bounds__(kWaves * 64) void conv_l16_fwd_kernel(LGeom g, cons
     // fragments read fresh) is followed by a `follow` tap that runs straight on from registers: its B fragments and first A
     // fragments were read behind the lead's MFMAs (both weight slots of a pair land before its barrier).  1x1 kernels (every
     // tap opens a chunk) keep one barrier per tap with counted waits and read the next tap's first A fragments across it.
+    // SPREAD (3x3): the copies of a pair are not issued in one burst behind the barrier -- eight waves x ~5 KB at once queue up in
+    // front of the CU's one-line-per-clock vector memory path (~40 KB = ~650 cycles during which every wave that has a copy to issue
+    // stands still, and both waves of a SIMD do so together) -- but piecewise between the MFMA groups of the lead tap: the next
+    // pair's first weight slot after channel-tile pair 0, its second after pair 1, the input box (when a chunk opens) after pair 2.
     constexpr bool TWO = TAPS > 1;
+#ifndef FSC_L16_SPREAD
+#define FSC_L16_SPREAD 1
+#endif
+    constexpr bool SPREAD = TWO && FSC_L16_SPREAD != 0;
     auto step = [&](bool lead, bool has_follow, const Frag& bcur, Frag& bnxt, const AFrag& acur, AFrag& anxt) {
+        bool opens = false;
         if (!TWO) {
             if (!first_step) {
                 // the barrier covers W(S+1) (issued two steps ago); W(S+2) may stay in flight.  Stores share the counter and
@@ -502,10 +511,12 @@ __global__ __launch_bounds__(kWaves * 64) void conv_l16_fwd_kernel(LGeom g, cons
             first_step = false;
             // weights of the NEXT pair into the two slots the previous pair used; the input box DAHEAD chunks ahead when a
             // chunk opens in either tap of this pair
-            const bool opens = sc == 0 || (has_follow && sc + 1 == nst);
-            produce_w();
-            if (has_follow) produce_w();
-            if (opens) produce_i();
+            opens = sc == 0 || (has_follow && sc + 1 == nst);
+            if (!SPREAD) {
+                produce_w();
+                if (has_follow) produce_w();
+                if (opens) produce_i();
+            }
         }
         // the next step and the byte offset of its B operand
         int noff;
@@ -558,6 +569,12 @@ __global__ __launch_bounds__(kWaves * 64) void conv_l16_fwd_kernel(LGeom g, cons
                 if (k < nrd) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);     // one LDS read
             }
             __builtin_amdgcn_sched_barrier(0);
+            if (SPREAD && lead) {
+                if (pr == 0) produce_w();
+                if (pr == (NPAIR > 1 ? 1 : 0) && has_follow) produce_w();
+                if (pr == (NPAIR > 2 ? 2 : NPAIR - 1) && opens) produce_i();
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
     };
 
@@ -932,14 +949,16 @@ template <int KH, int KW>
 int launch_l16_cot(const LPlan& p, const uint4* in, const float* packed, const float* bias, float* out, int accumulate,
                    const float* in_amax, hipStream_t st, StatArgs sa = StatArgs{nullptr, nullptr}) {
     switch (p.cot) {
+#ifndef FSC_L16_DEV          // (development builds: only the instantiations of the cfg-2 layers, a third of the compile time)
         case 3: return launch_l16_pt<KH, KW, 3>(p, in, packed, bias, out, accumulate, in_amax, st, sa);
         case 4: return launch_l16_pt<KH, KW, 4>(p, in, packed, bias, out, accumulate, in_amax, st, sa);
-        case 5: return launch_l16_pt<KH, KW, 5>(p, in, packed, bias, out, accumulate, in_amax, st, sa);
         case 6: return launch_l16_pt<KH, KW, 6>(p, in, packed, bias, out, accumulate, in_amax, st, sa);
-        case 7: return launch_l16_pt<KH, KW, 7>(p, in, packed, bias, out, accumulate, in_amax, st, sa);
-        case 8: return launch_l16_pt<KH, KW, 8>(p, in, packed, bias, out, accumulate, in_amax, st, sa);
         case 9: if constexpr (KH * KW > 1) return launch_l16_pt<KH, KW, 9>(p, in, packed, bias, out, accumulate, in_amax, st, sa); break;
         case 10: if constexpr (KH * KW > 1) return launch_l16_pt<KH, KW, 10>(p, in, packed, bias, out, accumulate, in_amax, st, sa); break;
+#endif
+        case 5: return launch_l16_pt<KH, KW, 5>(p, in, packed, bias, out, accumulate, in_amax, st, sa);
+        case 7: return launch_l16_pt<KH, KW, 7>(p, in, packed, bias, out, accumulate, in_amax, st, sa);
+        case 8: return launch_l16_pt<KH, KW, 8>(p, in, packed, bias, out, accumulate, in_amax, st, sa);
         default: break;
     }
     fsc::set_error("fsc_conv_l16_fwd: internal: no instantiation for %d channel tiles", p.cot);
@@ -1076,9 +1095,11 @@ static int pool_fwd_impl(const fsc_conv_desc* d, const void* in_l16, const float
     hipStream_t st = fsc::as_stream(stream);
     const uint4* in = reinterpret_cast<const uint4*>(in_l16);
     switch (p.cot) {
+#ifndef FSC_L16_DEV
         case 4: return launch_l16_pool<4>(p, in, packed, bias, pooled, idx, in_amax, st, sa);
-        case 5: return launch_l16_pool<5>(p, in, packed, bias, pooled, idx, in_amax, st, sa);
         case 6: return launch_l16_pool<6>(p, in, packed, bias, pooled, idx, in_amax, st, sa);
+#endif
+        case 5: return launch_l16_pool<5>(p, in, packed, bias, pooled, idx, in_amax, st, sa);
         case 7: return launch_l16_pool<7>(p, in, packed, bias, pooled, idx, in_amax, st, sa);
         default: return launch_l16_pool<8>(p, in, packed, bias, pooled, idx, in_amax, st, sa);
     }
