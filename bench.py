@@ -18,8 +18,6 @@ box's host cores on a bounded sample: batch 8 of the same model and clip length,
 import argparse
 import json
 import os
-import socket
-import subprocess
 import sys
 import time
 
@@ -32,6 +30,7 @@ sys.path.insert(0, ROOT)
 # /opt/skills/guides/MI355X_MICROARCH.md, chip-level parameters
 PEAK_F32_MFMA_TFLOPS = 157.3      # v_mfma_f32_16x16x4_f32 (native fp32 kernels)
 PEAK_BF16_MFMA_TFLOPS = 2500.0    # dense fp16 = bf16 MFMA (the split kernels execute 3 (fp16 limbs) or 6 / 9 (bf16 limbs) MFMA flops per fp32 flop)
+PEAK_HBM_GBPS = 8000.0            # HBM3E spec (6290 GB/s measured by a float4 copy)
 
 
 class NS(dict):
@@ -108,8 +107,12 @@ def cpu_baseline(w, steps=3, batch=8):
     cores = physical_cores()
     torch.set_num_threads(cores)
     torch.manual_seed(0)
-    model = oref.TagCNN2d(w["features"], w["blocks"], w["base"], w["growth"], w["start"], 80,
-                          output_dropout=w["dropout"])
+    if w.get("dims") == 1:
+        model = oref.TagCNN1d(w["features"], w["blocks"], w["base"], w["growth"], w["start"], 80,
+                              output_dropout=w["dropout"], input_dim=w["n_mel"])
+    else:
+        model = oref.TagCNN2d(w["features"], w["blocks"], w["base"], w["growth"], w["start"], 80,
+                              output_dropout=w["dropout"])
     opt = oref.make_adam(model, 3e-3)
     signal, labels = synthetic_batch(w, batch, torch.device("cpu"), 99)
     times = []
@@ -237,24 +240,12 @@ XGMI_LINK_GBPS = 153.0            # per link and direction; 7 links per GPU (MI3
 GRAD_BYTES_CFG2 = 21545583 * 4    # the one exchange of the path: a sum all-reduce of the fp32 gradients (86.18 MB)
 
 
-def _free_port():
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
-    return port
-
-
 def self_launch(n):
     """`python bench.py --gpus N` with N > 1 and no torch.distributed.run environment: start the N ranks ourselves
     (one process per GPU on this node, rendezvous on 127.0.0.1) with the same arguments; rank 0's JSON line is the only
     thing that reaches this process's stdout.  Returns the launcher's exit code."""
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
-           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
-    env = dict(os.environ)
-    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC (RCCL across processes on this driver)
-    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 1) // n)))
-    return subprocess.call(cmd, env=env)
+    from freesound_classification_amd import parallel
+    return parallel.launch_ranks(__file__, sys.argv[1:], n)
 
 
 def allreduce_probe(device, world, nbytes, iters=10, warm=3):
@@ -488,6 +479,30 @@ def main():
                "note": "host->device copy of the waveform batch inside the timed region (pinned, double-buffered, copy stream)"}
     if not torch.isfinite(torch.tensor(final_loss)):
         raise SystemExit("non-finite loss in the benchmark: %r" % final_loss)
+    # The HBM-bound stages of BASELINE.md section 3 (front-end, BatchNorm / PReLU / pooling passes, optimizer): a few extra steps
+    # with a HIP event pair around every such call (outside the timed region of `value`: ~250 event pairs per step), algorithmic
+    # bytes of the call over its time against the 8.0 TB/s HBM peak.  N = 1 only.
+    stages = None
+    if world == 1 and not args.no_alt and timer is not None:
+        F.STAGE_TIMER = F.StageTimer()
+        k_s = 3
+        for _ in range(k_s):
+            one_step()
+        torch.cuda.synchronize()
+        summ_s, F.STAGE_TIMER = F.STAGE_TIMER.summary(), None
+        names = {"frontend": "front-end: waveform -> log-mel / log-STFT (reads 4 T, writes 4 F frames per clip)",
+                 "bn_stats": "BatchNorm statistics passes that are not folded into a producer (1 read)",
+                 "bn_act_fwd": "BatchNorm + PReLU (+ residual) apply passes, forward (reads + writes counted once each)",
+                 "bn_act_bwd": "BatchNorm + PReLU backward: reduce pass + apply pass (+ un-pooling), both passes' reads and writes",
+                 "pool": "stand-alone max-pool / global max-pool passes", "optimizer": "Adam-amsgrad, nine fp32 streams"}
+        stages = {}
+        for k, r in summ_s.items():
+            if r["bytes"] <= 0 or r["ms"] <= 0:
+                continue
+            tbps = r["bytes"] / r["ms"] / 1e9
+            stages[k] = {"what": names.get(k, k), "bound": "hbm", "achieved": tbps * 1e3, "peak": PEAK_HBM_GBPS, "unit": "GB/s",
+                         "frac": tbps * 1e3 / PEAK_HBM_GBPS, "ms_per_step": r["ms"] / k_s, "GB_per_step": r["bytes"] / k_s / 1e9,
+                         "calls_per_step": r["calls"] / k_s}
 
     if rank == 0:
         result = {
@@ -562,6 +577,8 @@ def main():
                 "conv_ms_per_step": {k: v["ms"] / args.steps for k, v in fam.items()},
                 "conv_tflops": {k: v["flops"] / v["ms"] / 1e9 for k, v in fam.items()},
             }
+            if stages:
+                result["roofline"]["stages"] = stages
         if per_rank is not None:
             result["per_rank_clips_per_s"] = per_rank
             result["allreduce"] = exchange

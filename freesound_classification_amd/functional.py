@@ -75,10 +75,12 @@ def frontend_logmel(wave, n_fft, hop, bands, freq_channel):
     frames = 1 + t // hop
     planes = 2 if freq_channel else 1
     out = _empty((n, planes, bands.n_mel, frames), wave)
-    call("fsc_frontend_logmel_fwd", ptr(wave), n, t, t, n_fft, hop,
-         ptr(_frontend_tables(n_fft, wave.device)), ptr(bands.start), ptr(bands.length),
-         ptr(bands.weights), bands.n_mel, bands.max_band, LOG_EPS, ptr(out),
-         planes * bands.n_mel * frames, 1 if freq_channel else 0, stream_ptr())
+    tables = _frontend_tables(n_fft, wave.device)
+    with _stage("frontend", 4 * n * t + 4 * n * bands.n_mel * frames):      # (the frequency channel is synthesised)
+        call("fsc_frontend_logmel_fwd", ptr(wave), n, t, t, n_fft, hop,
+             ptr(tables), ptr(bands.start), ptr(bands.length),
+             ptr(bands.weights), bands.n_mel, bands.max_band, LOG_EPS, ptr(out),
+             planes * bands.n_mel * frames, 1 if freq_channel else 0, stream_ptr())
     return out
 
 
@@ -95,9 +97,11 @@ def frontend_stft(wave, n_fft, hop, apply_log, freq_channel=False):
     else:
         out = _empty((n, bins, frames), wave)
         stride = bins * frames
-    call("fsc_frontend_stft_fwd", ptr(wave), n, t, t, n_fft, hop,
-         ptr(_frontend_tables(n_fft, wave.device)), 1 if apply_log else 0, LOG_EPS, ptr(out),
-         stride, 1 if freq_channel else 0, stream_ptr())
+    tables = _frontend_tables(n_fft, wave.device)
+    with _stage("frontend", 4 * n * t + 4 * n * bins * frames):
+        call("fsc_frontend_stft_fwd", ptr(wave), n, t, t, n_fft, hop,
+             ptr(tables), 1 if apply_log else 0, LOG_EPS, ptr(out),
+             stride, 1 if freq_channel else 0, stream_ptr())
     return out
 
 
@@ -129,6 +133,62 @@ class KernelTimer:
 
 
 TIMER = None
+
+
+class StageTimer:
+    """Optional timing of the HBM-bound stages (front-end, BatchNorm / PReLU / pooling passes, optimizer) with HIP events on the
+    launch stream, next to the ALGORITHMIC bytes of each call: every tensor a pass reads or writes counted once (a backward call
+    is two passes: reduce + apply).  bench.py runs a few extra steps under it, outside the timed region, for the per-stage
+    `roofline.stages` block.  Off by default."""
+
+    def __init__(self):
+        self.records = []      # (stage, bytes, start event, end event)
+
+    def summary(self):
+        out = {}
+        for name, nbytes, e0, e1 in self.records:
+            r = out.setdefault(name, dict(calls=0, bytes=0.0, ms=0.0))
+            r["calls"] += 1
+            r["bytes"] += nbytes
+            r["ms"] += e0.elapsed_time(e1)
+        return out
+
+
+STAGE_TIMER = None
+
+
+class _stage:
+    def __init__(self, name, nbytes):
+        self.on = STAGE_TIMER is not None
+        self.name, self.nbytes = name, nbytes
+
+    def __enter__(self):
+        if self.on:
+            # the stream is drained first: an event behind a long kernel (a convolution) is stamped while that kernel still runs
+            # and the pair would charge its tail to this stage (measured: 390 us for a 5 us finalisation).  Stage timing is a
+            # separate diagnostic pass, never part of a timed region.
+            torch.cuda.current_stream().synchronize()
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e1 = torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+
+    def __exit__(self, *exc):
+        if self.on:
+            self.e1.record()
+            nbytes = float(self.nbytes() if callable(self.nbytes) else self.nbytes)
+            if nbytes > 0:
+                STAGE_TIMER.records.append((self.name, nbytes, self.e0, self.e1))
+
+
+def _nb(*tensors):
+    """Bytes of the given tensors (None skipped; L16 tensors by their data buffer)."""
+    total = 0
+    for t in tensors:
+        if t is None:
+            continue
+        t = t.data if isinstance(t, L16) else t
+        total += t.numel() * t.element_size()
+    return total
 
 
 def plan_name(desc, mode):
@@ -638,8 +698,9 @@ def bn_act_forward_rec(x, st, alpha, residual, want_stats, want_gmax):
     hw = x.numel() // (n * c)
     y = torch.empty_like(x)
     rec = torch.empty((_lib.load().fsc_bn_records_bytes(n, c, hw) + 7) // 8, device=x.device, dtype=torch.float64)
-    call("fsc_bn_act_fwd_rec", ptr(x), ptr(residual), ptr(st.scale), ptr(st.shift), ptr(alpha), ptr(y), n, c, hw, ptr(rec),
-         stream_ptr())
+    with _stage("bn_act_fwd", _nb(x, residual, y)):
+        call("fsc_bn_act_fwd_rec", ptr(x), ptr(residual), ptr(st.scale), ptr(st.shift), ptr(alpha), ptr(y), n, c, hw, ptr(rec),
+             stream_ptr())
     ws = _bn_ws(c, x) if want_stats else None
     feat = _empty((n, c), x) if want_gmax else None
     fidx = _empty((n, c), x, torch.int32) if want_gmax else None
@@ -682,7 +743,8 @@ def bn_prepare(x, bn, training, sync=None, defer=None, want_minmax=False):
                 ptr(bn.running_mean) if track else None, ptr(bn.running_var) if track else None,
                 ptr(st.mean), ptr(st.invstd), ptr(st.scale), ptr(st.shift), ptr(ws))
         if sync is None:
-            call("fsc_bn_train_stats", *args, None, folded, ptr(st.minmax), stream_ptr())
+            with _stage("bn_stats", 0 if folded else _nb(x)):      # (folded: the producer of x reduced them; only the finalisation runs)
+                call("fsc_bn_train_stats", *args, None, folded, ptr(st.minmax), stream_ptr())
         else:
             moments = _sync_buffer(c, x)                   # [sum x, sum x^2, count, 0] per channel, fp64
             call("fsc_bn_train_stats", *args, ptr(moments), 1 | folded, ptr(st.minmax), stream_ptr())
@@ -718,13 +780,15 @@ def bn_act_forward(x, st, alpha=None, residual=None, with_amax=False, l16=False,
     if l16 and st.minmax is not None and residual is None and hw > 1:
         y = torch.empty_like(x) if want_f32 else None
         t = L16(l16_empty(x.shape, x), _empty((AMAX_FLOATS,), x), x.shape)
-        call("fsc_bn_act_fwd", ptr(x), None, ptr(st.scale), ptr(st.shift), ptr(alpha), ptr(y),
-             n, c, hw, ptr(t.amax), ptr(st.minmax), ptr(t.data), stream_ptr())
+        with _stage("bn_act_fwd", _nb(x, y, t)):
+            call("fsc_bn_act_fwd", ptr(x), None, ptr(st.scale), ptr(st.shift), ptr(alpha), ptr(y),
+                 n, c, hw, ptr(t.amax), ptr(st.minmax), ptr(t.data), stream_ptr())
         return y, t
     y = torch.empty_like(x)
     y_amax = _empty((AMAX_FLOATS,), x) if (with_amax or l16) and _want_amax() else None
-    call("fsc_bn_act_fwd", ptr(x), ptr(residual), ptr(st.scale), ptr(st.shift), ptr(alpha), ptr(y),
-         n, c, hw, ptr(y_amax), None, None, stream_ptr())
+    with _stage("bn_act_fwd", _nb(x, residual, y)):
+        call("fsc_bn_act_fwd", ptr(x), ptr(residual), ptr(st.scale), ptr(st.shift), ptr(alpha), ptr(y),
+             n, c, hw, ptr(y_amax), None, None, stream_ptr())
     if l16:
         return y, None
     return (y, y_amax) if with_amax else y
@@ -753,7 +817,9 @@ def bn_act_backward(dy, x, st, bn, alpha=None, residual=None, gmax=None, want_dx
             ptr(dbeta), ptr(dalpha), ptr(csum), n, c, hw, ptr(ws), ptr(dx_amax))
     t_ptr = ptr(t.data) if l16 else None
     if sync is None:
-        call("fsc_bn_act_bwd", *args, None, 0, t_ptr, stream_ptr())
+        # reduce pass reads dy, x, residual; apply pass reads them again and writes dx (fp32 and / or L16) and dresidual
+        with _stage("bn_act_bwd", 2 * _nb(dy, x, residual) + _nb(dx, dres, t)):
+            call("fsc_bn_act_bwd", *args, None, 0, t_ptr, stream_ptr())
     else:
         sums = _sync_buffer(c, x)                          # [sum dz, sum dz * xhat, count, 0] per channel
         call("fsc_bn_act_bwd", *args, ptr(sums), 1, t_ptr, stream_ptr())
@@ -782,7 +848,8 @@ def bn_act_backward_unpool(dy, x, st, bn, alpha, pool_idx, c_shape, ph, sync=Non
             ptr(ws), ptr(dc_amax))
     t_ptr = ptr(t.data) if l16 else None
     if sync is None:
-        call("fsc_bn_act_bwd_unpool", *args, None, 0, t_ptr, stream_ptr())
+        with _stage("bn_act_bwd", 2 * _nb(dy, x) + _nb(pool_idx, dc, t)):
+            call("fsc_bn_act_bwd_unpool", *args, None, 0, t_ptr, stream_ptr())
     else:
         sums = _sync_buffer(c, x)
         call("fsc_bn_act_bwd_unpool", *args, ptr(sums), 1, t_ptr, stream_ptr())
@@ -796,7 +863,8 @@ def maxpool_forward(x, ph):
     n, c, h, w = x.shape
     y = _empty((n, c, h // ph, w // 2), x)
     idx = _empty((n, c, h // ph, w // 2), x, torch.uint8)
-    call("fsc_maxpool_fwd", ptr(x), ptr(y), ptr(idx), n * c, h, w, ph, stream_ptr())
+    with _stage("pool", _nb(x, y, idx)):
+        call("fsc_maxpool_fwd", ptr(x), ptr(y), ptr(idx), n * c, h, w, ph, stream_ptr())
     return y, idx
 
 
@@ -812,7 +880,8 @@ def global_maxpool_forward(x):
     hw = x.numel() // (n * c)
     y = _empty((n, c), x)
     idx = _empty((n, c), x, torch.int32)
-    call("fsc_global_maxpool_fwd", ptr(x), ptr(y), ptr(idx), n * c, hw, stream_ptr())
+    with _stage("pool", _nb(x, y, idx)):
+        call("fsc_global_maxpool_fwd", ptr(x), ptr(y), ptr(idx), n * c, hw, stream_ptr())
     return y, idx
 
 

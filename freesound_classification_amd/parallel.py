@@ -10,8 +10,34 @@ gradient on a side stream, so communication overlaps the rest of backward.  xGMI
 point-to-point (ring collectives are per-link bound), hence few large buckets rather than
 many small ones.  The 1/world factor is folded into the fused optimizer (`grad_scale`).
 """
+import os
+import socket
+import subprocess
+import sys
+
 import torch
 import torch.distributed as dist
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_ranks(script, argv, n):
+    """Start `n` ranks of `script argv...` on this node -- one process per GPU, rendezvous on 127.0.0.1 -- through
+    torch.distributed.run and return the launcher's exit code.  What `python bench.py --gpus N` / `train_2d_cnn.py --gpus N` /
+    `predict_2d_cnn.py --gpus N` do when no launcher environment (WORLD_SIZE) is present; the children see RANK, LOCAL_RANK,
+    WORLD_SIZE, MASTER_ADDR, MASTER_PORT as under any torchrun launch."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(script)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC (RCCL across processes on this driver)
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 1) // n)))
+    return subprocess.call(cmd, env=env)
 
 
 def initialized():

@@ -128,7 +128,11 @@ def main():
     p.add_argument("--bucket_seconds", type=float, default=2.0)
     p.add_argument("--max_batch_seconds", type=float, default=1280.0, help="samples per batch = 128 x 10 s")
     p.add_argument("--seed", type=int, default=7)
+    p.add_argument("--gpus", type=int, default=1, help="ranks to start on this node (one process per GPU, batches round-robin)")
     args = p.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        import sys
+        raise SystemExit(parallel.launch_ranks(__file__, sys.argv[1:], args.gpus))
 
     device = args.device
     if int(os.environ.get("WORLD_SIZE", "1")) > 1:

@@ -55,6 +55,8 @@ def build_parser(default_label="2d_cnn"):
     p.add_argument("--save_every", type=int, default=1, help="how frequently to save a model")
     p.add_argument("--device", type=str, default="cuda", choices=("cuda", "cpu"),
                    help="the accelerated path runs on an MI355X (\"cuda\" under ROCm); \"cpu\" raises: there is no CPU fallback")
+    p.add_argument("--gpus", type=int, default=1,
+                   help="data-parallel ranks to start on this node (one process per GPU, RCCL gradient all-reduce); not a reference flag")
     p.add_argument("--aggregation_type", type=str, default="max", choices=("max", "rnn"), help="how to aggregate outputs")
     p.add_argument("--num_conv_blocks", type=int, default=5, help="number of conv blocks")
     p.add_argument("--start_deep_supervision_on", type=int, default=2,
@@ -137,6 +139,10 @@ def _split_labels(values):
 
 def main(model_cls=TwoDimensionalCNNClassificationModel, default_label="2d_cnn", argv=None):
     args = build_parser(default_label).parse_args(argv)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:          # become the launcher: N ranks of this very command
+        import sys
+        script = sys.modules[main.__module__].__file__ if model_cls is TwoDimensionalCNNClassificationModel else sys.argv[0]
+        raise SystemExit(parallel.launch_ranks(script, sys.argv[1:] if argv is None else argv, args.gpus))
     torch.manual_seed(42)
     if torch.cuda.is_available():
         torch.cuda.manual_seed_all(42)
