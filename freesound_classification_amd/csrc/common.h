@@ -9,6 +9,7 @@
 namespace fsc {
 
 void set_error(const char* fmt, ...);
+int l16_fwd_clock(double* shader_mhz);      // conv_l16.hip: shader clock of the last forward / dgrad launch (fsc_conv_l16_last_clock)
 
 inline hipStream_t as_stream(fsc_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 

@@ -57,6 +57,27 @@ __device__ __attribute__((aligned(16))) float g_zero16_l[4] = {0.f, 0.f, 0.f, 0.
 
 __device__ __forceinline__ int fdiv(int x, float inv) { return (int)(((float)x + 0.5f) * inv); }
 
+// Shader clock of the last launch: workgroup 0 stamps the shader-cycle counter (s_memtime) and the constant 100 MHz reference
+// counter (s_memrealtime) at both ends of the kernel; their ratio is the clock the chip actually ran the kernel at (the MFMA-bound
+// launches of cfg 2 run near 1.6 GHz under the power limit, not at the 2.4 GHz the peak is quoted for).  fsc_conv_l16_last_clock.
+__device__ unsigned long long g_l16_clock[2];
+
+// Development (-DFSC_L16_PROFILE): shader-clock stamps around the phases of a step, summed per wave of workgroup 0 into
+// g_l16_prof[wave][phase]; read back and cleared by fsc_debug_l16_prof.  Phases: 0 wait + barrier, 1 barrier -> first MFMA group
+// (copy issue of the un-spread variant, control, fresh A fragments), 2 MFMA groups (with the spread copies between them),
+// 3 epilogue, 4 steps counted, 5 whole kernel.
+#ifdef FSC_L16_PROFILE
+__device__ unsigned long long g_l16_prof[8][8];
+__device__ __forceinline__ unsigned long long prof_now() { return __builtin_readcyclecounter(); }
+#define PROF_DECL unsigned long long pf_t = 0, pf_acc[7] = {0, 0, 0, 0, 0, 0, 0}; const unsigned long long pf_k0 = prof_now(), pf_r0 = __builtin_amdgcn_s_memrealtime();
+#define PROF_MARK() (pf_t = prof_now())
+#define PROF_ADD(i) do { const unsigned long long n_ = prof_now(); pf_acc[i] += n_ - pf_t; pf_t = n_; } while (0)
+#else
+#define PROF_DECL
+#define PROF_MARK()
+#define PROF_ADD(i)
+#endif
+
 // 16-byte LDS-DMA (lane i writes lds_wave_base + 16 i).  Issued as inline assembly on purpose: hipcc knows that the builtin
 // writes LDS and, unable to tell the stages of the dynamic LDS block apart, puts `s_waitcnt vmcnt(0)` in front of the next LDS
 // read -- i.e. waits for the copy it has just issued for a LATER step before computing the current one (measured: the kernels
@@ -274,7 +295,14 @@ __global__ __launch_bounds__(kWaves * 64) void conv_l16_fwd_kernel(LGeom g, cons
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lm = lane & 15, kq = lane >> 4;
+    const unsigned long long ck0 = __builtin_readcyclecounter(), cr0 = __builtin_amdgcn_s_memrealtime();
 
+#ifndef FSC_L16_PRIO
+#define FSC_L16_PRIO 0
+#endif
+    // the second-dispatched half of the workgroup loses every issue arbitration against its older SIMD partner (priority, then
+    // age): a static priority evens the two halves out (MI355X_MICROARCH.md, two waves per SIMD, item 4)
+    if (FSC_L16_PRIO && wid >= 4) __builtin_amdgcn_s_setprio(1);
     // ---- operand scales (before any DMA lands in the ring)
     const float ax = block_amax512(in_amax, smem);
     const float aw = *w_amax;
@@ -348,6 +376,7 @@ __global__ __launch_bounds__(kWaves * 64) void conv_l16_fwd_kernel(LGeom g, cons
 #pragma unroll
         for (int j = 0; j < PT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+    PROF_DECL
     constexpr int NST = STATS ? COT : 1;
     float st_s1[NST], st_s2[NST], st_mn[NST], st_mx[NST];
 #pragma unroll
@@ -492,6 +521,8 @@ __global__ __launch_bounds__(kWaves * 64) void conv_l16_fwd_kernel(LGeom g, cons
     constexpr bool SPREAD = TWO && FSC_L16_SPREAD != 0;
     auto step = [&](bool lead, bool has_follow, const Frag& bcur, Frag& bnxt, const AFrag& acur, AFrag& anxt) {
         bool opens = false;
+        AFrag t0, t1, af;
+        PROF_MARK();
         if (!TWO) {
             if (!first_step) {
                 // the barrier covers W(S+1) (issued two steps ago); W(S+2) may stay in flight.  Stores share the counter and
@@ -507,6 +538,14 @@ __global__ __launch_bounds__(kWaves * 64) void conv_l16_fwd_kernel(LGeom g, cons
             if (!first_step) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // everything issued a pair ago has landed (weights of this
                 raw_barrier();                                       // pair, a young input box, the previous item's stores)
+            }
+            PROF_ADD(0);
+#ifndef FSC_L16_EARLY_A
+#define FSC_L16_EARLY_A 1
+#endif
+            if (FSC_L16_EARLY_A) {        // this tap's first A fragments are on their way while the scalar bookkeeping below runs
+                read_a(reinterpret_cast<const u32x4*>(wring + slot * WSLOT_F) + lane, 0, af);
+                __builtin_amdgcn_sched_barrier(0);
             }
             first_step = false;
             // weights of the NEXT pair into the two slots the previous pair used; the input box DAHEAD chunks ahead when a
@@ -538,8 +577,8 @@ __global__ __launch_bounds__(kWaves * 64) void conv_l16_fwd_kernel(LGeom g, cons
         const u32x4* wln = reinterpret_cast<const u32x4*>(wring + slot * WSLOT_F) + lane;
         const bool fresh_a = TWO && lead;                    // (uniform) this tap's first pair is read now, behind the barrier
         const bool next_a = TWO ? (lead && has_follow) : true;   // the next tap's first pair can be read at the end of this one
-        AFrag t0, t1, af;
-        if (fresh_a) read_a(wl, 0, af);
+        if (fresh_a && !FSC_L16_EARLY_A) read_a(wl, 0, af);
+        PROF_ADD(1);
         constexpr int kLa[3] = {1, 0, 0}, kLb[3] = {0, 1, 0};     // (A limb, B limb): l*h, h*l, h*h -- smallest first
 #pragma unroll
         for (int pr = 0; pr < NPAIR; ++pr) {
@@ -576,6 +615,10 @@ __global__ __launch_bounds__(kWaves * 64) void conv_l16_fwd_kernel(LGeom g, cons
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
+        PROF_ADD(2);
+#ifdef FSC_L16_PROFILE
+        pf_acc[4] += 1;
+#endif
     };
 
     const bool add_bias = bias != nullptr;
@@ -593,6 +636,7 @@ __global__ __launch_bounds__(kWaves * 64) void conv_l16_fwd_kernel(LGeom g, cons
             fa0 = fa1;
         }
 
+        PROF_MARK();
         if constexpr (POOL) {
             // ---- pooled epilogue.  After the shuffles the four even lanes lm = 0, 2, 4, 6 of a column group hold the pooled
             //      value and window index of 4 channels x one window; through the scratch tile lane L = (channel L >> 2,
@@ -663,6 +707,7 @@ __global__ __launch_bounds__(kWaves * 64) void conv_l16_fwd_kernel(LGeom g, cons
 #pragma unroll
                 for (int j = 0; j < PT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
             drain = true;
+            PROF_ADD(3);
             continue;
         }
         // ---- epilogue: D row = channel (kq*4 + r), column = pixel (lm) -> scratch[ch][px] -> lane = (channel, quad).
@@ -743,6 +788,18 @@ __global__ __launch_bounds__(kWaves * 64) void conv_l16_fwd_kernel(LGeom g, cons
 #pragma unroll
             for (int j = 0; j < PT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
         drain = true;                                       // (1x1) the stores above share the DMA counter
+        PROF_ADD(3);
+    }
+#ifdef FSC_L16_PROFILE
+    if (blockIdx.x == 0 && lane == 0) {
+        pf_acc[5] = prof_now() - pf_k0;
+        pf_acc[6] = __builtin_amdgcn_s_memrealtime() - pf_r0;          // constant 100 MHz reference clock
+        for (int i = 0; i < 7; ++i) atomicAdd(&g_l16_prof[wid][i], pf_acc[i]);
+    }
+#endif
+    if (blockIdx.x == 0 && tid == 0) {
+        g_l16_clock[0] = __builtin_readcyclecounter() - ck0;
+        g_l16_clock[1] = __builtin_amdgcn_s_memrealtime() - cr0;
     }
     if constexpr (STATS) {
         // the four lanes of a quad hold the same channel: fold them, lane (lane & 3) == 0 writes the record
@@ -1117,6 +1174,17 @@ int fsc_conv_l16_pool_fwd_stats(const fsc_conv_desc* d, const void* in_l16, cons
     return pool_fwd_impl(d, in_l16, in_amax, packed, bias, pooled, idx, StatArgs{stat_pivot, reinterpret_cast<float4*>(stat_rec)}, stream);
 }
 
+#ifdef FSC_L16_PROFILE
+/* development: copies the 8 x 8 phase counters to `out64` (host) and clears them */
+int fsc_debug_l16_prof(unsigned long long* out64) {
+    hipDeviceSynchronize();
+    hipMemcpyFromSymbol(out64, HIP_SYMBOL(g_l16_prof), sizeof(unsigned long long) * 64);
+    unsigned long long z[64] = {0};
+    hipMemcpyToSymbol(HIP_SYMBOL(g_l16_prof), z, sizeof(z));
+    return 0;
+}
+#endif
+
 int fsc_conv_l16_plan_describe(const fsc_conv_desc* d, int dgrad, char* buf, size_t buf_len) {
     LPlan p;
     FSC_CHECK_ARG(valid_l16_desc(d) && buf && buf_len > 0 && plan_l16(*d, dgrad, &p), "fsc_conv_l16_plan_describe: unsupported shape");
@@ -1126,3 +1194,14 @@ int fsc_conv_l16_plan_describe(const fsc_conv_desc* d, int dgrad, char* buf, siz
 }
 
 }  // extern "C"
+
+namespace fsc {
+int l16_fwd_clock(double* shader_mhz) {
+    FSC_CHECK_ARG(shader_mhz, "fsc_conv_l16_last_clock: null pointer");
+    unsigned long long v[2] = {0, 0};
+    hipError_t e = hipMemcpyFromSymbol(v, HIP_SYMBOL(g_l16_clock), sizeof(v));
+    if (e != hipSuccess) { fsc::set_error("fsc_conv_l16_last_clock: %s", hipGetErrorString(e)); return (int)e; }
+    *shader_mhz = v[1] ? 100.0 * (double)v[0] / (double)v[1] : 0.0;
+    return 0;
+}
+}  // namespace fsc

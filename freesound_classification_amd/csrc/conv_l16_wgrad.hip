@@ -52,6 +52,7 @@ struct WGeom {
 };
 
 __device__ __attribute__((aligned(16))) float g_zero16_w[4] = {0.f, 0.f, 0.f, 0.f};
+__device__ unsigned long long g_l16w_clock[2];      // shader cycles / 100 MHz reference ticks of the last launch (see conv_l16.hip)
 
 // 16-byte LDS-DMA as inline assembly (see conv_l16.hip glds16: behind the builtin hipcc waits for the copy of the NEXT unit
 // before the first LDS read of the current one).  The wait is explicit: vmcnt(0) before the barrier that opens a unit.
@@ -109,6 +110,7 @@ __global__ __launch_bounds__(kWaves * 64) void conv_l16_wgrad_kernel(WGeom g, co
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const unsigned long long ck0 = __builtin_readcyclecounter(), cr0 = __builtin_amdgcn_s_memrealtime();
     const int kq = lane >> 4, li = lane & 15, c4 = li & 3, lj = li >> 2;
     const int lm = li;
     const int cog = wid / g.nt, cig = wid - cog * g.nt;
@@ -272,6 +274,10 @@ __global__ __launch_bounds__(kWaves * 64) void conv_l16_wgrad_kernel(WGeom g, co
         default: if constexpr (MT >= 4) run_units(std::integral_constant<int, 4>{}); break;
     }
 
+    if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) {
+        g_l16w_clock[0] = __builtin_readcyclecounter() - ck0;
+        g_l16w_clock[1] = __builtin_amdgcn_s_memrealtime() - cr0;
+    }
     // partial[split][tap][ci][co]; D row = co (kq*4 + r), column = ci (lm)
 #pragma unroll
     for (int s = 0; s < NB; ++s) {
@@ -461,6 +467,20 @@ int fsc_conv_l16_wgrad(const fsc_conv_desc* d, const void* in_l16, const float* 
     hipLaunchKernelGGL(l16_wgrad_reduce_kernel, dim3(fsc::ceil_div(d->c_out, rthreads), taps * d->c_in), dim3(rthreads), 0, st,
                        part, dweight, d->c_out, d->c_in, taps, p.g.ci_pad, p.g.co_pad, p.g.nsplit);
     FSC_LAUNCH_CHECK("fsc_conv_l16_wgrad(reduce)");
+    return 0;
+}
+
+/* which = 0: the last fsc_conv_l16_fwd / _pool_fwd (_stats) launch, 1: the last fsc_conv_l16_wgrad launch.  Synchronises the
+ * device (a measurement aid: bench.py reads it after re-running the dominant layer, outside any timed region). */
+int fsc_conv_l16_last_clock(int which, double* shader_mhz) {
+    FSC_CHECK_ARG(shader_mhz && (which == 0 || which == 1), "fsc_conv_l16_last_clock: bad arguments");
+    hipError_t e = hipDeviceSynchronize();
+    if (e != hipSuccess) { fsc::set_error("fsc_conv_l16_last_clock: %s", hipGetErrorString(e)); return (int)e; }
+    if (which == 0) return fsc::l16_fwd_clock(shader_mhz);
+    unsigned long long v[2] = {0, 0};
+    e = hipMemcpyFromSymbol(v, HIP_SYMBOL(g_l16w_clock), sizeof(v));
+    if (e != hipSuccess) { fsc::set_error("fsc_conv_l16_last_clock: %s", hipGetErrorString(e)); return (int)e; }
+    *shader_mhz = v[1] ? 100.0 * (double)v[0] / (double)v[1] : 0.0;
     return 0;
 }
 

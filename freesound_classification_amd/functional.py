@@ -120,6 +120,11 @@ class KernelTimer:
 
     def __init__(self):
         self.records = []      # (kernel name, algorithmic flops, start event, end event)
+        self.shapes = {}       # kernel name -> (flops, (n, c_in, c_out, h, w, kh, kw), "fwd" | "dgrad" | "wgrad") of its largest call
+
+    def note(self, name, flops, shape, kind):
+        if name not in self.shapes or flops > self.shapes[name][0]:
+            self.shapes[name] = (flops, tuple(shape), kind)
 
     def summary(self):
         """name -> dict(launches, flops, ms); call after a device synchronise."""
@@ -484,6 +489,7 @@ def conv_l16(t, weight, bias, dgrad=False, accumulate_into=None, prepacked=None,
     if TIMER is not None:
         e1.record()
         TIMER.records.append((l16_plan_name(d, dg), 2.0 * n * h * w * c_in * c_out * kh * kw, e0, e1))
+        TIMER.note(l16_plan_name(d, dg), 2.0 * n * h * w * c_in * c_out * kh * kw, (n, c_in, c_out, h, w, kh, kw), "dgrad" if dgrad else "fwd")
     if lay is not None:
         _stats_end(lay, rec, out, c_out)
     return out
@@ -552,6 +558,7 @@ def conv_l16_wgrad(x16, dout16, weight_shape, out=None):
         if TIMER is not None:
             e1.record()
             TIMER.records.append((l16_wgrad_plan_name(d), 2.0 * n * h * w * c_in * c_out * kh * kw, e0, e1))
+            TIMER.note(l16_wgrad_plan_name(d), 2.0 * n * h * w * c_in * c_out * kh * kw, (n, c_in, c_out, h, w, kh, kw), "wgrad")
         return dw
 
     if not L16_WGRAD_SIDE:
@@ -565,6 +572,36 @@ def conv_l16_wgrad(x16, dout16, weight_shape, out=None):
         t.record_stream(side)                 # keep the allocator from recycling them under the kernel
     dw.record_stream(main)
     return dw
+
+
+def measure_l16_clock(shape, kind, iters=40):
+    """Shader clock (MHz) the chip sustains while it runs the L16 convolution `kind` ("fwd" | "dgrad" | "wgrad") of
+    shape (n, c_in, c_out, h, w, kh, kw) back to back on random operands (fsc_conv_l16_last_clock: the kernel stamps the
+    shader-cycle and the 100 MHz reference counters itself).  A measurement aid for bench.py; synchronises the device."""
+    n, c_in, c_out, h, w, kh, kw = shape
+    dev = torch.device("cuda", torch.cuda.current_device())
+    gen = torch.Generator(device=dev).manual_seed(3)
+    x = torch.randn(n, c_in, h, w, device=dev, generator=gen)
+    gy = torch.randn(n, c_out, h, w, device=dev, generator=gen)
+    wt = torch.randn(c_out, c_in, kh, kw, device=dev, generator=gen) / (c_in * kh * kw) ** 0.5
+    timer, globals()["TIMER"] = TIMER, None
+    try:
+        if kind == "wgrad":
+            x16, g16 = l16_pack(x), l16_pack(gy)
+            del x, gy
+            for _ in range(iters):
+                conv_l16_wgrad(x16, g16, wt.shape)
+        else:
+            t = l16_pack(gy if kind == "dgrad" else x)
+            del x, gy
+            pp = conv_l16_pack(wt, n, h, w, kind == "dgrad")
+            for _ in range(iters):
+                conv_l16(t, wt, None, dgrad=kind == "dgrad", prepacked=pp)
+        mhz = C.c_double(0.0)
+        call("fsc_conv_l16_last_clock", 1 if kind == "wgrad" else 0, C.byref(mhz))
+    finally:
+        globals()["TIMER"] = timer
+    return mhz.value
 
 
 # FSC_L16_WGRAD_SIDE=1: the L16 weight-gradient kernels run on the side stream beside the BatchNorm backward passes of the next

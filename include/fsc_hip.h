@@ -246,6 +246,11 @@ int fsc_bn_records_fold(const void* records, const float* y, int n, int c, long 
  * `stat_rec` holds workers * 8 * channels-per-block records of 16 bytes.  fsc_bn_records_fold_conv folds them into split 0 of a
  * BatchNorm workspace; then fsc_bn_train_stats(..., phase | FSC_BN_STATS_FOLDED | FSC_BN_STATS_PIVOT_RM, ...) with the SAME
  * running_mean pointer only finalises.  min / max are exact; mean / variance agree with the separate pass to rounding. */
+/* Shader clock (MHz) the chip ran the LAST L16 convolution launch at (which = 0: fsc_conv_l16_fwd family, 1: fsc_conv_l16_wgrad):
+ * workgroup 0 stamps the shader-cycle counter and the constant 100 MHz reference counter at both ends of the kernel.  The
+ * MFMA-bound launches run well below the 2.4 GHz the peak figures assume (power limit); bench.py reports it next to `roofline`.
+ * Synchronises the device: a measurement aid, not for the training path. */
+int fsc_conv_l16_last_clock(int which, double* shader_mhz);
 int fsc_conv_l16_stats_layout(const fsc_conv_desc* d, int pool, int* out3);
 int fsc_conv_l16_fwd_stats(const fsc_conv_desc* d, const void* in_l16, const float* in_amax, const float* packed,
                            const float* bias, float* out, const float* stat_pivot, void* stat_rec, fsc_stream_t stream);
