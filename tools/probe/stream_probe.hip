@@ -17,10 +17,11 @@ __device__ __forceinline__ f32x16 mfma32(u32x4 a, u32x4 b, f32x16 c) {
 
 // SHAPE 16: wave tile = TM x TN tiles of 16 x 16, K = 32 per step: A frags TM x 2 limbs, B frags TN x 2 limbs, TM * TN * 3 MFMAs
 // SHAPE 32: wave tile = TM x TN tiles of 32 x 32, K = 32 per step = 2 k-halves: A TM x 2 x 2, B TN x 2 x 2, TM * TN * 2 * 3 MFMAs
-template <int SHAPE, int TM, int TN>
+template <int SHAPE, int TM, int TN, bool LDS = true>
 __global__ __launch_bounds__(512) void stream(float* out, int steps) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x & 63;
+    const unsigned long long ck0 = __builtin_readcyclecounter(), cr0 = __builtin_amdgcn_s_memrealtime();
     for (int i = threadIdx.x; i < 32 * 1024 / 4 * 4; i += 512) smem[i] = (float)(i & 1023) * 1e-6f;
     __syncthreads();
     const u32x4* wl = reinterpret_cast<const u32x4*>(smem) + lane;           // A: 64 KB ring of 1 KB fragments
@@ -40,8 +41,9 @@ __global__ __launch_bounds__(512) void stream(float* out, int steps) {
         for (int i = 0; i < NB; ++i) bd[i] = bl[(s & 1) * 512 + (i & 7) * 64];
     };
     rd(0, a[0], b[0]);
+    if (!LDS) rd(1, a[1], b[1]);
     auto body = [&](int s, u32x4* ac, u32x4* bc, u32x4* an, u32x4* bn) {
-        rd(s + 1, an, bn);
+        if (LDS) rd(s + 1, an, bn);
         constexpr int kLa[3] = {1, 0, 0}, kLb[3] = {0, 1, 0};
         if constexpr (SHAPE == 16) {
 #pragma unroll
@@ -65,7 +67,7 @@ __global__ __launch_bounds__(512) void stream(float* out, int steps) {
 #pragma unroll
         for (int k = 0; k < NM; ++k) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            if (k < NR) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            if (LDS && k < NR) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
     };
@@ -78,15 +80,19 @@ __global__ __launch_bounds__(512) void stream(float* out, int steps) {
     for (auto& v : acc16) r += v[0] + v[1] + v[2] + v[3];
     for (auto& v : acc32) for (int e = 0; e < 16; ++e) r += v[e];
     out[blockIdx.x * 512 + threadIdx.x] = r;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        out[256 * 512] = (float)(__builtin_readcyclecounter() - ck0);
+        out[256 * 512 + 1] = (float)(__builtin_amdgcn_s_memrealtime() - cr0);
+    }
 }
 
-template <int SHAPE, int TM, int TN>
+template <int SHAPE, int TM, int TN, bool LDS = true>
 void run(const char* name) {
     float* d;
-    hipMalloc(&d, 256 * 512 * 4);
-    auto kern = stream<SHAPE, TM, TN>;
+    hipMalloc(&d, 256 * 512 * 4 + 64);
+    auto kern = stream<SHAPE, TM, TN, LDS>;
     hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-    const int steps = 4000;
+    const int steps = 40000;      // ~30 ms per launch: long enough for the clock to settle
     kern<<<256, 512, 96 * 1024>>>(d, 200);
     hipDeviceSynchronize();
     hipEvent_t e0, e1;
@@ -103,21 +109,24 @@ void run(const char* name) {
     const double tile = SHAPE * SHAPE;
     const double flop = 2.0 * tile * 32 * TM * TN * 3 * (double)steps * 8 * 256;   // per step a wave does TM*TN tiles x K 32 x 3 products
     const int nm = TM * TN * 3 * (SHAPE == 32 ? 2 : 1), nr = (TM + TN) * 2 * (SHAPE == 32 ? 2 : 1);
-    printf("%-10s tile %3d x %3d  MFMA/step %3d  LDS reads/step %2d : %7.3f ms  %7.1f TF executed (%.2f of 2500)\n", name, SHAPE * TM, SHAPE * TN, nm,
-           nr, best, flop / best / 1e9, flop / best / 1e9 / 2500.0);
+    float ck[2];
+    hipMemcpy(ck, d + 256 * 512, 8, hipMemcpyDeviceToHost);
+    const double mhz = 100.0 * ck[0] / ck[1];
+    printf("%-10s tile %3d x %3d  MFMA/step %3d  LDS reads/step %2d : %7.3f ms  %7.1f TF executed (%.2f of 2500)  clock %4.0f MHz  %.1f cycles per MFMA and SIMD\n",
+           name, SHAPE * TM, SHAPE * TN, nm, nr, best, flop / best / 1e9, flop / best / 1e9 / 2500.0, mhz, ck[0] / ((double)steps * nm * 2));
     hipFree(d);
 }
 
 int main() {
     run<16, 8, 2>("16: 8x2");
     run<16, 7, 2>("16: 7x2");
-    run<16, 4, 4>("16: 4x4");
-    run<16, 5, 2>("16: 5x2");
     run<32, 4, 1>("32: 4x1");
+    run<16, 8, 2, false>("16: 8x2 reg");
+    run<16, 4, 4, false>("16: 4x4 reg");
+    run<32, 4, 1, false>("32: 4x1 reg");
+    run<32, 2, 2, false>("32: 2x2 reg");
+    run<16, 8, 2>("16: 8x2");
     run<32, 2, 2>("32: 2x2");
-    run<32, 5, 1>("32: 5x1");
-
-    run<32, 3, 1>("32: 3x1");
-    run<32, 3, 2>("32: 3x2");
+    run<16, 4, 4>("16: 4x4");
     return 0;
 }
