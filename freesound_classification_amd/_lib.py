@@ -55,6 +55,7 @@ SIGNATURES = {
     "fsc_conv_stem_grads_finish": (_I, [_D, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P]),
     "fsc_absmin": (_I, [_P, _L, _P, _P]),
     "fsc_conv_l16_last_clock": (_I, [_I, C.POINTER(C.c_double)]),
+    "fsc_conv_l16_pack_weights_multi": (_I, [_I, _P, _P, _P, _P, _P]),
     "fsc_conv_plan_describe": (_I, [_D, _I, C.c_char_p, _SZ]),
     "fsc_conv_default_arith": (_I, []),
     "fsc_conv_wgrad_workspace_bytes": (_SZ, [_D]),

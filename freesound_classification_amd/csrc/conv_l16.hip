@@ -203,11 +203,53 @@ struct PackDir {
     long total;
     int blocks;
 };
+__device__ __forceinline__ void pack_dir_block(const float* __restrict__ w, int c_out, int c_in, int taps, const PackDir& dir, int blk,
+                                               const float* __restrict__ wmax_part);
 __global__ void l16_pack_w_kernel(const float* __restrict__ w, int c_out, int c_in, int taps, PackDir a, PackDir b,
                                   const float* __restrict__ wmax_part) {
     const bool second = (int)blockIdx.x >= a.blocks;
-    const PackDir& dir = second ? b : a;
-    const int blk = second ? blockIdx.x - a.blocks : blockIdx.x;
+    pack_dir_block(w, c_out, c_in, taps, second ? b : a, second ? blockIdx.x - a.blocks : blockIdx.x, wmax_part);
+}
+
+// max |w| in two stages without a clear: kWmaxBlocks partial maxima behind the fragments, folded by every block of the pack
+// kernel (and published as w_amax[0] for the conv kernel by its first thread)
+__global__ __launch_bounds__(256) void l16_wmax_kernel(const float* __restrict__ x, long n, float* __restrict__ part) {
+    __shared__ float sm[4];
+    float m = 0.f;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) m = fmaxf(m, fabsf(x[i]));
+    m = fsc::wave_max(m);
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.x] = fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3]));
+}
+
+// The same two kernels for several weights at once (fsc_conv_l16_pack_weights_multi: one pair of launches per kMultiPack layers
+// instead of one per layer -- 40 tiny launches per training step at cfg 2).
+constexpr int kMultiPack = 8;
+struct PackJob {
+    const float* w;
+    int c_out, c_in, taps;
+    long count;              // elements of w
+    float* part;             // kWmaxBlocks partial maxima (behind the first direction's fragments)
+    PackDir a, b;            // b.blocks == 0: one direction only
+    int first_block;         // of this job in the pack launch
+};
+struct PackJobs { PackJob j[kMultiPack]; int n; };
+
+__global__ __launch_bounds__(256) void l16_wmax_multi_kernel(PackJobs jobs) {
+    __shared__ float sm[4];
+    const int job = blockIdx.x / kWmaxBlocks, blk = blockIdx.x - job * kWmaxBlocks;
+    const PackJob& pj = jobs.j[job];
+    float m = 0.f;
+    for (long i = (long)blk * 256 + threadIdx.x; i < pj.count; i += (long)kWmaxBlocks * 256) m = fmaxf(m, fabsf(pj.w[i]));
+    m = fsc::wave_max(m);
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) pj.part[blk] = fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3]));
+}
+
+__device__ __forceinline__ void pack_dir_block(const float* __restrict__ w, int c_out, int c_in, int taps, const PackDir& dir, int blk,
+                                               const float* __restrict__ wmax_part) {
     float wm = 0.f;
     for (int i = 0; i < kWmaxBlocks; ++i) wm = fmaxf(wm, wmax_part[i]);
     if (blk == 0 && threadIdx.x == 0) dir.w_amax[0] = wm;
@@ -238,16 +280,15 @@ __global__ void l16_pack_w_kernel(const float* __restrict__ w, int c_out, int c_
     }
 }
 
-// max |w| in two stages without a clear: kWmaxBlocks partial maxima behind the fragments, folded by every block of the pack
-// kernel (and published as w_amax[0] for the conv kernel by its first thread)
-__global__ __launch_bounds__(256) void l16_wmax_kernel(const float* __restrict__ x, long n, float* __restrict__ part) {
-    __shared__ float sm[4];
-    float m = 0.f;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) m = fmaxf(m, fabsf(x[i]));
-    m = fsc::wave_max(m);
-    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = m;
-    __syncthreads();
-    if (threadIdx.x == 0) part[blockIdx.x] = fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3]));
+__global__ void l16_pack_w_multi_kernel(PackJobs jobs) {
+    int job = 0;
+#pragma unroll 1
+    for (int k = 1; k < jobs.n; ++k)
+        if ((int)blockIdx.x >= jobs.j[k].first_block) job = k;
+    const PackJob& pj = jobs.j[job];
+    const int rel = (int)blockIdx.x - pj.first_block;
+    const bool second = rel >= pj.a.blocks;
+    pack_dir_block(pj.w, pj.c_out, pj.c_in, pj.taps, second ? pj.b : pj.a, second ? rel - pj.a.blocks : rel, pj.part);
 }
 
 // -------------------------------------------------------------------------------------------
@@ -1101,6 +1142,44 @@ int fsc_conv_l16_pack_weights_pair(const fsc_conv_desc* d, const float* weight, 
 
 int fsc_conv_l16_pack_weights(const fsc_conv_desc* d, const float* weight, int dgrad, float* packed, fsc_stream_t stream) {
     return fsc_conv_l16_pack_weights_pair(d, weight, dgrad ? nullptr : packed, dgrad ? packed : nullptr, stream);
+}
+
+/* fsc_conv_l16_pack_weights_pair for `count` weights in ceil(count / 8) pairs of launches.  packed_fwd[i] / packed_dgrad[i] may be
+ * NULL for a direction that is not wanted (never both). */
+int fsc_conv_l16_pack_weights_multi(int count, const fsc_conv_desc* descs, const float* const* weights, float* const* packed_fwd,
+                                    float* const* packed_dgrad, fsc_stream_t stream) {
+    FSC_CHECK_ARG(count > 0 && descs && weights && packed_fwd && packed_dgrad, "fsc_conv_l16_pack_weights_multi: bad arguments");
+    hipStream_t st = fsc::as_stream(stream);
+    for (int base = 0; base < count; base += kMultiPack) {
+        PackJobs jobs{};
+        jobs.n = count - base < kMultiPack ? count - base : kMultiPack;
+        int blocks = 0;
+        for (int k = 0; k < jobs.n; ++k) {
+            const fsc_conv_desc* d = descs + base + k;
+            float* pf_out = packed_fwd[base + k];
+            float* pd_out = packed_dgrad[base + k];
+            FSC_CHECK_ARG(valid_l16_desc(d) && weights[base + k] && (pf_out || pd_out), "fsc_conv_l16_pack_weights_multi: bad entry %d", base + k);
+            LPlan pf{}, pd{};
+            FSC_CHECK_ARG(!pf_out || plan_l16(*d, 0, &pf), "fsc_conv_l16_pack_weights_multi: no forward tiling for entry %d", base + k);
+            FSC_CHECK_ARG(!pd_out || plan_l16(*d, 1, &pd), "fsc_conv_l16_pack_weights_multi: no dgrad tiling for entry %d", base + k);
+            PackJob& pj = jobs.j[k];
+            pj.w = weights[base + k];
+            pj.c_out = d->c_out; pj.c_in = d->c_in; pj.taps = d->kh * d->kw;
+            pj.count = (long)d->c_out * d->c_in * pj.taps;
+            PackDir a{}, b{};
+            if (pf_out) a = make_pack_dir(pf, pf_out, 0);
+            if (pd_out) b = make_pack_dir(pd, pd_out, 1);
+            if (!pf_out) { a = b; b = PackDir{}; }
+            pj.a = a; pj.b = b;
+            pj.part = a.w_amax + 4;
+            pj.first_block = blocks;
+            blocks += a.blocks + b.blocks;
+        }
+        hipLaunchKernelGGL(l16_wmax_multi_kernel, dim3((unsigned)(jobs.n * kWmaxBlocks)), dim3(256), 0, st, jobs);
+        hipLaunchKernelGGL(l16_pack_w_multi_kernel, dim3((unsigned)blocks), dim3(256), 0, st, jobs);
+    }
+    FSC_LAUNCH_CHECK("fsc_conv_l16_pack_weights_multi");
+    return 0;
 }
 
 int fsc_conv_l16_fwd(const fsc_conv_desc* d, const void* in_l16, const float* in_amax, const float* packed,

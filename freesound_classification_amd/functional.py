@@ -407,15 +407,77 @@ def conv_l16_pack(weight, n, h, w, dgrad):
     return d, packed
 
 
+# Training: the weights of every L16 convolution are re-packed each step.  The first forward of a (model, input shape) records
+# which (weight, n, h, w) it packs; from then on prepack_begin() packs them all up front with fsc_conv_l16_pack_weights_multi
+# (6 launches instead of 40 at cfg 2) and conv_l16_pack_pair() hands the fragments out.
+MULTI_PACK = os.environ.get("FSC_MULTI_PACK", "1") == "1"
+_PACK_PLAN = {}        # key -> [(weight, n, h, w), ...]
+_PACK_RECORD = None    # list being recorded, or None
+_PREPACKED = {}        # weight.data_ptr() -> ((n, h, w), fwd or None, dgrad or None), consumed once
+
+
+def prepack_begin(key):
+    """Call at the start of a training forward; `key` identifies (model, input shape).  Returns a token for prepack_end."""
+    global _PACK_RECORD
+    _PREPACKED.clear()
+    if not MULTI_PACK or get_conv_arith() != 3 or not USE_L16:
+        return None
+    plan = _PACK_PLAN.get(key)
+    if plan is None:
+        _PACK_RECORD = []
+        return ("record", key)
+    lib = _lib.load()
+    count = len(plan)
+    descs = (ConvDesc * count)()
+    wp, fp, dp = (C.c_void_p * count)(), (C.c_void_p * count)(), (C.c_void_p * count)()
+    made = []
+    for i, (weight, n, h, w) in enumerate(plan):
+        c_out, c_in, kh, kw = weight.shape
+        d = _desc(n, c_in, c_out, h, w, kh, kw, 3)
+        nf, nd = lib.fsc_conv_l16_packed_floats(C.byref(d), 0), lib.fsc_conv_l16_packed_floats(C.byref(d), 1)
+        pf = torch.empty(nf, device=weight.device, dtype=torch.float32) if nf else None
+        pd = torch.empty(nd, device=weight.device, dtype=torch.float32) if nd else None
+        descs[i] = d
+        wp[i], fp[i], dp[i] = ptr(weight), ptr(pf), ptr(pd)
+        made.append((weight, (n, h, w), d, pf, pd))
+    call("fsc_conv_l16_pack_weights_multi", count, descs, wp, fp, dp, stream_ptr())
+    for weight, shape, d, pf, pd in made:
+        _PREPACKED[weight.data_ptr()] = (shape, (d, pf) if pf is not None else None, (d, pd) if pd is not None else None)
+    return ("packed", key)
+
+
+def prepack_end(token):
+    global _PACK_RECORD
+    if token is not None and token[0] == "record" and _PACK_RECORD is not None:
+        if _PACK_RECORD:
+            if len(_PACK_PLAN) > 64:
+                _PACK_PLAN.clear()
+            _PACK_PLAN[token[1]] = _PACK_RECORD
+    if token is not None and token[0] == "packed" and _PREPACKED:
+        _PACK_PLAN.pop(token[1], None)       # fragments nobody asked for: the plan is stale (another model at this id) -- re-record
+    _PACK_RECORD = None
+    _PREPACKED.clear()
+
+
+def prepack_forget(model_id):
+    for key in [k for k in _PACK_PLAN if k[0] == model_id]:
+        del _PACK_PLAN[key]
+
+
 def conv_l16_pack_pair(weight, n, h, w):
     """Forward and input-gradient fragments of one weight in one call: ((desc, packed_fwd) or None, (desc, packed_dgrad) or
     None), for the directions fsc_conv_l16_fwd has a tiling for."""
+    hit = _PREPACKED.pop(weight.data_ptr(), None)
+    if hit is not None and hit[0] == (n, h, w):
+        return hit[1], hit[2]
     c_out, c_in, kh, kw = weight.shape
     d = _desc(n, c_in, c_out, h, w, kh, kw, 3)
     lib = _lib.load()
     nf, nd = lib.fsc_conv_l16_packed_floats(C.byref(d), 0), lib.fsc_conv_l16_packed_floats(C.byref(d), 1)
     if nf == 0 and nd == 0:
         return None, None
+    if _PACK_RECORD is not None:
+        _PACK_RECORD.append((weight, n, h, w))
     pf = torch.empty(nf, device=weight.device, dtype=torch.float32) if nf else None
     pd = torch.empty(nd, device=weight.device, dtype=torch.float32) if nd else None
     call("fsc_conv_l16_pack_weights_pair", C.byref(d), ptr(weight), ptr(pf), ptr(pd), stream_ptr())

@@ -175,6 +175,15 @@ class _TaggingModel(nn.Module):
             return self._forward_features(h)
 
     def _forward_features(self, h):
+        token = None
+        if self.training and torch.is_grad_enabled():
+            token = F.prepack_begin((id(self), tuple(h.shape)))     # all L16 weight fragments of the step in a few launches
+        try:
+            return self._forward_blocks(h)
+        finally:
+            F.prepack_end(token)
+
+    def _forward_blocks(self, h):
         if self.dims == 1:
             h = h.unsqueeze(2)              # (N, C, 1, L): the 1-d model is the H == 1 case
         start = self.config.network.start_deep_supervision_on
@@ -355,6 +364,7 @@ class _TaggingModel(nn.Module):
             self._reducer.remove()
             self._reducer = None
         self._bn_sync = None
+        F.prepack_forget(id(self))
         if self._froze_gc:
             gc.unfreeze()
             self._froze_gc = False

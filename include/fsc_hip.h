@@ -168,6 +168,11 @@ int fsc_conv_l16_pack_weights(const fsc_conv_desc* d, const float* weight, int d
 /* both directions of one weight in one call (either pointer may be NULL): shares the max |w| pass and the launch */
 int fsc_conv_l16_pack_weights_pair(const fsc_conv_desc* d, const float* weight, float* packed_fwd,
                                    float* packed_dgrad, fsc_stream_t stream);
+/* The same for `count` weights at once (ceil(count / 8) pairs of launches instead of one pair per weight: the 20 L16 convolutions of
+ * a cfg-2 training step re-pack their weights every step).  descs[i] / weights[i] / packed_fwd[i] / packed_dgrad[i] as for the pair
+ * call; host arrays, read before the call returns. */
+int fsc_conv_l16_pack_weights_multi(int count, const fsc_conv_desc* descs, const float* const* weights, float* const* packed_fwd,
+                                    float* const* packed_dgrad, fsc_stream_t stream);
 /* out (fp32 NCHW) = conv(in) + bias, or += with accumulate; dgrad as in fsc_conv_fwd */
 int fsc_conv_l16_fwd(const fsc_conv_desc* d, const void* in_l16, const float* in_amax, const float* packed,
                      const float* bias, int dgrad, int accumulate, float* out, fsc_stream_t stream);

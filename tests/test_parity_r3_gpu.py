@@ -443,3 +443,76 @@ def test_cfg3_stated_shape_against_the_oracle(arith):
         # gradients: 1e-3 rms per tensor on its scale, or -- where the reference's own fp32 arithmetic is further than that from
         # fp64 on this batch (ten max-pools and a global max per block in front of a batch-8 head) -- no further than twice that
         assert worst[1] < max(1e-3, 2.0 * worst_cpu[1]), (worst, worst_cpu)
+
+
+# ------------------------------------------------------------------------------ all weight fragments of a step in one go
+def test_multi_tensor_weight_packing_equals_the_per_layer_calls():
+    """fsc_conv_l16_pack_weights_multi (what a training forward uses from its second step on) writes bit for bit what the
+    per-layer fsc_conv_l16_pack_weights_pair calls write -- 11 weights: two launch chunks, forward-only and both-direction entries."""
+    import ctypes as C
+    lib = F._lib.load()
+    torch.manual_seed(9)
+    shapes = [c for c, v in T.CONV_CASES.items() if v != (None, None)][:11]         # (n, c_in, c_out, h, w, k) with an L16 tiling
+    count = len(shapes)
+    assert count == 11
+    descs = (F.ConvDesc * count)()
+    wp, fp, dp = (C.c_void_p * count)(), (C.c_void_p * count)(), (C.c_void_p * count)()
+    keep, ref = [], []
+    for i, (n, cin, cout, h, w, k) in enumerate(shapes):
+        wt = torch.randn(cout, cin, k, k, device=DEV) * (0.5 + i)
+        d = F._desc(n, cin, cout, h, w, k, k, 3)
+        nf, nd = lib.fsc_conv_l16_packed_floats(C.byref(d), 0), lib.fsc_conv_l16_packed_floats(C.byref(d), 1)
+        assert nf or nd
+        pf = torch.zeros(nf, device=DEV) if nf else None
+        pd = torch.zeros(nd, device=DEV) if nd else None
+        descs[i] = d
+        wp[i], fp[i], dp[i] = F.ptr(wt), F.ptr(pf), F.ptr(pd)
+        keep.append((wt, pf, pd))
+        ref.append(F.conv_l16_pack_pair(wt, n, h, w))
+    F.call("fsc_conv_l16_pack_weights_multi", count, descs, wp, fp, dp, F.stream_ptr())
+    for (wt, pf, pd), (rf, rd) in zip(keep, ref):
+        for got, want in ((pf, rf), (pd, rd)):
+            assert (got is None) == (want is None)
+            if got is not None:
+                m = got.numel() - 68                      # fragments | max |w| (+ 3 pad) | 64 partial maxima
+                assert torch.equal(got[:m].view(torch.int32), want[1][:m].view(torch.int32))
+                assert float(got[m]) == float(want[1][m]) == float(wt.abs().max())
+
+
+def test_training_forward_uses_the_recorded_pack_plan():
+    """Second step of a model: one fsc_conv_l16_pack_weights_multi call instead of per-layer packing, same logits and gradients."""
+    torch.manual_seed(4)
+    model = _small_2d(blocks=2, base=64)
+    model.train()
+    signal = 0.1 * torch.randn(16, 2 * 44100, 1, device=DEV)
+    labels = torch.zeros(16, 80, device=DEV)
+    labels[torch.arange(16), torch.randint(0, 80, (16,))] = 1.0
+    real = F.call
+    seen = []
+
+    def counting(name, *a):
+        seen.append(name)
+        return real(name, *a)
+
+    outs = []
+    F._PACK_PLAN.clear()
+    try:
+        F.call = counting
+        for step in range(2):
+            for prm in model.parameters():
+                prm.grad = None
+            seen.clear()
+            logits, per, loss = model.training_step(signal, labels, step_optimizer=False)
+            outs.append((logits.detach().clone(), {k: v.grad.detach().clone() for k, v in model.named_parameters() if v.grad is not None},
+                         seen.count("fsc_conv_l16_pack_weights_pair"), seen.count("fsc_conv_l16_pack_weights_multi")))
+    finally:
+        F.call = real
+    (l0, g0, pair0, multi0), (l1, g1, pair1, multi1) = outs
+    assert pair0 >= 2 and multi0 == 0, (pair0, multi0)            # first step: recorded
+    assert pair1 == 0 and multi1 == 1, (pair1, multi1)            # second step: one call for all of them
+    # (the two steps differ only in the pivot of the conv-epilogue statistics -- the running mean moved -- i.e. in the last bits)
+    assert (l0 - l1).abs().max().item() <= 1e-5 * max(1.0, l0.abs().max().item())
+    for k in g0:
+        assert (g0[k] - g1[k]).abs().max().item() <= 1e-4 * max(1.0, g0[k].abs().max().item()), k
+    model.close()
+    assert not any(key[0] == id(model) for key in F._PACK_PLAN)
