@@ -294,22 +294,29 @@ __global__ __launch_bounds__(kWaves * 64) void conv_l16_wgrad_kernel(WGeom g, co
     }
 }
 
-// blockIdx.y = (tap, ci) row of the partial slices, threads run along co (coalesced reads)
-__global__ void l16_wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, int c_out, int c_in,
-                                        int taps, int ci_pad, int co_pad, int nsplit) {
-    const int co = blockIdx.x * blockDim.x + threadIdx.x;
-    if (co >= c_out) return;
+// blockIdx.y = (tap, ci) row of the partial slices; threadIdx.x runs along co (coalesced reads), threadIdx.y over four interleaved
+// groups of split-K slices (one thread walking all <= 256 slices of its element was a chain of dependent loads: 22 us per layer)
+constexpr int kRedX = 64, kRedY = 4;
+__global__ __launch_bounds__(kRedX * kRedY) void l16_wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, int c_out,
+                                                                          int c_in, int taps, int ci_pad, int co_pad, int nsplit) {
+    __shared__ float red[kRedY][kRedX];
+    const int co = blockIdx.x * kRedX + threadIdx.x;
     const int tap = blockIdx.y / c_in, ci = blockIdx.y - tap * c_in;
     const long slice = (long)taps * ci_pad * co_pad;
-    const float* p = part + ((long)tap * ci_pad + ci) * co_pad + co;
     float s0 = 0.f, s1 = 0.f;
-    int sp = 0;
-    for (; sp + 1 < nsplit; sp += 2) {
-        s0 += p[(long)sp * slice];
-        s1 += p[(long)(sp + 1) * slice];
+    if (co < c_out) {
+        const float* p = part + ((long)tap * ci_pad + ci) * co_pad + co;
+        int sp = threadIdx.y;
+        for (; sp + kRedY < nsplit; sp += 2 * kRedY) {
+            s0 += p[(long)sp * slice];
+            s1 += p[(long)(sp + kRedY) * slice];
+        }
+        if (sp < nsplit) s0 += p[(long)sp * slice];
     }
-    if (sp < nsplit) s0 += p[(long)sp * slice];
-    dw[((long)co * c_in + ci) * taps + tap] = s0 + s1;
+    red[threadIdx.y][threadIdx.x] = s0 + s1;
+    __syncthreads();
+    if (threadIdx.y == 0 && co < c_out)
+        dw[((long)co * c_in + ci) * taps + tap] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 
 // -------------------------------------------------------------------------------------------
@@ -463,8 +470,7 @@ int fsc_conv_l16_wgrad(const fsc_conv_desc* d, const void* in_l16, const float* 
 #undef FSC_WL
     FSC_LAUNCH_CHECK("fsc_conv_l16_wgrad");
     const int taps = d->kh * d->kw;
-    const int rthreads = d->c_out >= 128 ? 128 : 64;
-    hipLaunchKernelGGL(l16_wgrad_reduce_kernel, dim3(fsc::ceil_div(d->c_out, rthreads), taps * d->c_in), dim3(rthreads), 0, st,
+    hipLaunchKernelGGL(l16_wgrad_reduce_kernel, dim3(fsc::ceil_div(d->c_out, kRedX), taps * d->c_in), dim3(kRedX, kRedY), 0, st,
                        part, dweight, d->c_out, d->c_in, taps, p.g.ci_pad, p.g.co_pad, p.g.nsplit);
     FSC_LAUNCH_CHECK("fsc_conv_l16_wgrad(reduce)");
     return 0;

@@ -212,7 +212,16 @@ __global__ __launch_bounds__(kThreads) void frontend_kernel(FrontendArgs a) {
 // Then the spectrum goes back to LDS in natural order, lane pairs (k, 1024 - k) unpack the real transform, and the
 // magnitudes feed the banded mel sums.  The generic kernel above takes 5 radix-4 passes with a workgroup barrier each,
 // one butterfly per thread: 0.78 ms at cfg 2 against 0.03 ms of HBM time.
-constexpr int kF2Frames = 16;                      // frames per workgroup (mel mode); 4 waves x 4 frames
+// Measured at cfg 2 (tools/ab/fe.sh, same box): 16 frames / launch bound 3 waves per SIMD 0.335 ms; branch-free reflect indexing +
+// v_sqrt_f32 (no spilled lane masks) with the bound relaxed to 2: 0.251 ms; 12 frames per workgroup: 0.243 ms; 8: 0.251; 32: 0.297.
+// (With the bound at 3 the same source compiles to a 0.366 ms kernel at the same 166 VGPRs: the scheduler's choice, not occupancy.)
+#ifndef FSC_FE_FRAMES
+#define FSC_FE_FRAMES 12
+#endif
+#ifndef FSC_FE_MINWAVES
+#define FSC_FE_MINWAVES 2
+#endif
+constexpr int kF2Frames = FSC_FE_FRAMES;           // frames per workgroup (mel mode); 4 waves x 3 frames
 constexpr int kF2Patch = 16 * 68;                  // float2 per wave: 16 rows of 64 (+ 4 pad: conflict-free column reads)
 
 __device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
@@ -269,7 +278,7 @@ __device__ __forceinline__ float quad_xor2(float v) {
 }
 
 template <bool MEL>
-__global__ __launch_bounds__(kThreads, 3) void frontend2048_kernel(FrontendArgs a) {
+__global__ __launch_bounds__(kThreads, FSC_FE_MINWAVES) void frontend2048_kernel(FrontendArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int NC = 1024;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -299,17 +308,23 @@ __global__ __launch_bounds__(kThreads, 3) void frontend2048_kernel(FrontendArgs 
         // touch a clip end take the reflect-padded scalar path (ops/utils.py:110-127: center=True, pad_mode="reflect")
         const bool pairs = s0 >= 0 && s0 + 2 * NC <= t && ((s0 | a.wave_stride) & 1) == 0 &&
                            (reinterpret_cast<uintptr_t>(a.wave) & 7) == 0;
+        if (pairs) {                                        // (wave-uniform: one of the two loops runs)
+            const float2* src = reinterpret_cast<const float2*>(wav + s0) + lane;
 #pragma unroll
-        for (int n1 = 0; n1 < 16; ++n1) {
-            const int j = 64 * n1 + lane;
-            const float2 w = reinterpret_cast<const float2*>(win)[j];
-            if (pairs) {
-                const float2 v = *reinterpret_cast<const float2*>(wav + s0 + 2 * j);
+            for (int n1 = 0; n1 < 16; ++n1) {
+                const float2 w = reinterpret_cast<const float2*>(win)[64 * n1 + lane];
+                const float2 v = src[64 * n1];
                 x[n1] = make_float2(v.x * w.x, v.y * w.y);
-            } else {
-                long i0 = s0 + 2 * j, i1 = i0 + 1;
-                if (i0 < 0) i0 = -i0; else if (i0 >= t) i0 = 2L * (t - 1) - i0;
-                if (i1 < 0) i1 = -i1; else if (i1 >= t) i1 = 2L * (t - 1) - i1;
+            }
+        } else {
+            // reflect padding without branches: index -> |index|, then mirrored at t - 1 (one reflection suffices: t > n_fft / 2)
+            const int base = (int)s0 + 2 * lane, hi = 2 * (t - 1);
+#pragma unroll
+            for (int n1 = 0; n1 < 16; ++n1) {
+                const float2 w = reinterpret_cast<const float2*>(win)[64 * n1 + lane];
+                int i0 = base + 128 * n1, i1 = i0 + 1;
+                i0 = i0 < 0 ? -i0 : i0; i1 = i1 < 0 ? -i1 : i1;
+                i0 = i0 >= t ? hi - i0 : i0; i1 = i1 >= t ? hi - i1 : i1;
                 x[n1] = make_float2(wav[i0] * w.x, wav[i1] * w.y);
             }
         }
@@ -356,10 +371,12 @@ __global__ __launch_bounds__(kThreads, 3) void frontend2048_kernel(FrontendArgs 
                 const float2 o = make_float2(0.5f * (zk.y + zr.y), -0.5f * (zk.x - zr.x));
                 const float2 wo = cmul(tw[k], o);
                 const float re = e.x + wo.x, im = e.y + wo.y;
-                mg_lo[i] = sqrtf(re * re + im * im);
+                // v_sqrt_f32 (1 ulp): the IEEE-exact sqrtf expands to a dozen instructions and three lane masks each -- eighteen of
+                // them unrolled were the kernel's 84 spilled SGPRs
+                mg_lo[i] = __builtin_amdgcn_sqrtf(re * re + im * im);
                 // bin 1024 - k: E' = conj(E), O' = conj(O), W^(1024 - k) = -conj(W^k)  =>  X[1024 - k] = conj(E - W^k O)
                 const float re2 = e.x - wo.x, im2 = e.y - wo.y;
-                mg_hi[i] = sqrtf(re2 * re2 + im2 * im2);
+                mg_hi[i] = __builtin_amdgcn_sqrtf(re2 * re2 + im2 * im2);
             }
         }
         // every lane has read its spectrum values: the magnitudes overwrite the patch (1025 floats)
