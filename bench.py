@@ -419,28 +419,11 @@ def main():
         # the exchange step alone (outside the timed region): the gradient all-reduce with nothing else on the wire
         exchange = allreduce_probe(device, world, 4 * sum(p.numel() for p in model.parameters()))
     final_loss = float(loss.detach())
-    # The same workload with the native fp32-MFMA conv kernels (FSC_CONV_ARITH=f32), for readers who want the
-    # number without the split-limb arithmetic; N = 1 only, outside the timed region of `value`.
-    alt = None
-    if world == 1 and not args.no_alt and F.get_conv_arith() not in (0, 1):
-        mode0 = F.get_conv_arith()
-        F.set_conv_arith(0)
-        for _ in range(2):
-            one_step()
-        torch.cuda.synchronize()
-        k_alt = max(2, min(args.steps, 5))
-        F.TIMER = F.KernelTimer() if timer is not None else None      # same per-call event overhead as the timed region
-        t1 = time.perf_counter()
-        for _ in range(k_alt):
-            one_step()
-        torch.cuda.synchronize()
-        e_alt = time.perf_counter() - t1
-        F.TIMER = None
-        F.set_conv_arith(mode0)
-        alt = {"conv_arith": "f32", "value": batch * k_alt / e_alt, "unit": "clips/s", "steps": k_alt, "ms_per_step": 1e3 * e_alt / k_alt}
     # The same step with the batch arriving from the host: the 4 * T * N bytes (226 MB at cfg 2) are copied from a pinned
     # staging buffer on a copy stream into one of two device buffers while the previous step computes (double
     # buffering, as ops/device_pipeline.py does for real loaders).  N = 1 only, outside the timed region of `value`.
+    # (Measured before the native-fp32 re-run below: straight after those steps the same loop runs 5-11 ms per step slower -- 2750-3100
+    # clips/s -- although a resident step does not; not reproduced outside bench.py, tools/h2d_probe.py.)
     h2d = None
     if world == 1 and not args.no_alt and not w.get("mixup"):
         pinned = signal.cpu().pin_memory()
@@ -477,6 +460,25 @@ def main():
         h2d = {"value": batch * k_h / e_h, "unit": "clips/s", "steps": k_h, "ms_per_step": 1e3 * e_h / k_h,
                "h2d_bytes_per_step": pinned.numel() * 4,
                "note": "host->device copy of the waveform batch inside the timed region (pinned, double-buffered, copy stream)"}
+    # The same workload with the native fp32-MFMA conv kernels (FSC_CONV_ARITH=f32), for readers who want the
+    # number without the split-limb arithmetic; N = 1 only, outside the timed region of `value`.
+    alt = None
+    if world == 1 and not args.no_alt and F.get_conv_arith() not in (0, 1):
+        mode0 = F.get_conv_arith()
+        F.set_conv_arith(0)
+        for _ in range(2):
+            one_step()
+        torch.cuda.synchronize()
+        k_alt = max(2, min(args.steps, 5))
+        F.TIMER = F.KernelTimer() if timer is not None else None      # same per-call event overhead as the timed region
+        t1 = time.perf_counter()
+        for _ in range(k_alt):
+            one_step()
+        torch.cuda.synchronize()
+        e_alt = time.perf_counter() - t1
+        F.TIMER = None
+        F.set_conv_arith(mode0)
+        alt = {"conv_arith": "f32", "value": batch * k_alt / e_alt, "unit": "clips/s", "steps": k_alt, "ms_per_step": 1e3 * e_alt / k_alt}
     if not torch.isfinite(torch.tensor(final_loss)):
         raise SystemExit("non-finite loss in the benchmark: %r" % final_loss)
     # The HBM-bound stages of BASELINE.md section 3 (front-end, BatchNorm / PReLU / pooling passes, optimizer): a few extra steps
