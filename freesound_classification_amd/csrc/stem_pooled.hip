@@ -21,6 +21,22 @@ namespace {
 constexpr int kThreads = 256;
 constexpr int kTileRows = 4;            // pooled rows per block
 
+// Sum over the 64 lanes as DPP moves inside the rows of 16 (xor 1, xor 2, half-row mirror, row mirror) and four v_readlane across
+// the rows: 26 sums per (wave, channel) through __shfl_xor -- six ds_bpermute round trips each -- cost as much as the FMAs they fold.
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+    v += dpp_mov<0xB1>(v);          // quad_perm [1,0,3,2]
+    v += dpp_mov<0x4E>(v);          // quad_perm [2,3,0,1]
+    v += dpp_mov<0x141>(v);         // row_half_mirror
+    v += dpp_mov<0x140>(v);         // row_mirror: every lane holds its row's total
+    const int b = __float_as_int(v);
+    return (__int_as_float(__builtin_amdgcn_readlane(b, 0)) + __int_as_float(__builtin_amdgcn_readlane(b, 16))) +
+           (__int_as_float(__builtin_amdgcn_readlane(b, 32)) + __int_as_float(__builtin_amdgcn_readlane(b, 48)));
+}
+
 template <int CIN>
 __global__ __launch_bounds__(kThreads) void stem_wgrad_pooled_kernel(const float* __restrict__ a, const float* __restrict__ mean,
                                                                       const float* __restrict__ invstd, const float* __restrict__ dp,
@@ -132,12 +148,12 @@ __global__ __launch_bounds__(kThreads) void stem_wgrad_pooled_kernel(const float
         float* o = part + (((long)blockIdx.y * gridDim.x + blockIdx.x) * cout + co) * 32;
 #pragma unroll
         for (int k = 0; k < CIN * 9; ++k) {
-            const float v = fsc::wave_sum(acc[k]);
+            const float v = wave_sum_dpp(acc[k]);
             if (lane == 0) o[k] = v;
         }
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-            const float v = fsc::wave_sum(bs[k]);
+            const float v = wave_sum_dpp(bs[k]);
             if (lane == 0) o[18 + k] = v;
         }
         if (lane < 32 && (lane >= 26 || (lane >= CIN * 9 && lane < 18))) o[lane] = 0.f;
