@@ -56,6 +56,7 @@ SIGNATURES = {
     "fsc_absmin": (_I, [_P, _L, _P, _P]),
     "fsc_conv_l16_last_clock": (_I, [_I, C.POINTER(C.c_double)]),
     "fsc_conv_l16_pack_weights_multi": (_I, [_I, _P, _P, _P, _P, _P]),
+    "fsc_bn_train_stats_conv": (_I, [_P, _I, _I, _I, _I, _P, _I, _I, _L, _P, _P, _F, _F, _P, _P, _P, _P, _P, _P, _P, _P]),
     "fsc_conv_plan_describe": (_I, [_D, _I, C.c_char_p, _SZ]),
     "fsc_conv_default_arith": (_I, []),
     "fsc_conv_wgrad_workspace_bytes": (_SZ, [_D]),

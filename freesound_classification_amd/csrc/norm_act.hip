@@ -562,6 +562,57 @@ __global__ __launch_bounds__(kThreads) void fold_conv_records_kernel(const float
     }
 }
 
+// fold_conv_records_kernel + stats_finalize_gated_kernel in one launch (single replica, training): the workgroup of a channel folds
+// the channel's records of the STATS convolution and finalises straight away (fsc_bn_train_stats_conv).
+__global__ __launch_bounds__(kThreads) void stats_fold_finalize_kernel(FinalizeArgs a, int n, const float4* __restrict__ rec, int workers,
+                                                                        int blocks, int co_blk, int order) {
+    __shared__ double scratch[kThreads / 64];
+    __shared__ float mm[2][kThreads / 64];
+    __shared__ double bc[2];
+    const int ch = blockIdx.x, cb = ch / co_blk, within = ch - cb * co_blk;
+    const int nrec = workers * 8;
+    double s1 = 0.0, s2 = 0.0;
+    float mn = INFINITY, mx = -INFINITY;
+    for (int r = threadIdx.x; r < nrec; r += kThreads) {
+        const int w = r >> 3, wv = r & 7;
+        if ((order ? (w >> 3) % blocks : w % blocks) != cb) continue;
+        const float4 v = rec[((long)w * 8 + wv) * co_blk + within];
+        s1 += (double)v.x; s2 += (double)v.y;
+        mn = fminf(mn, v.z); mx = fmaxf(mx, v.w);
+    }
+    double t1 = fsc::block_sum<double, kThreads / 64>(s1, scratch);
+    double t2 = fsc::block_sum<double, kThreads / 64>(s2, scratch);
+    mx = fsc::wave_max(mx);
+    mn = -fsc::wave_max(-mn);
+    if ((threadIdx.x & 63) == 0) { mm[0][threadIdx.x >> 6] = mn; mm[1][threadIdx.x >> 6] = mx; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int i = 1; i < kThreads / 64; ++i) { mn = fminf(mn, mm[0][i]); mx = fmaxf(mx, mm[1][i]); }
+        if (a.x_minmax) { a.x_minmax[2 * ch] = mn; a.x_minmax[2 * ch + 1] = mx; }
+    }
+    double pivot = a.running_mean ? (double)a.running_mean[ch] : 0.0;
+    const double m1 = t1 / a.count, var = t2 / a.count - m1 * m1;
+    if (!(var > 0.0) || m1 * m1 > kGateSigmas * kGateSigmas * var) {      // (workgroup-uniform: see stats_finalize_gated_kernel)
+        const double p2 = pivot + m1;
+        const float p2f = (float)p2;
+        double u1 = 0.0, u2 = 0.0;
+        for (int b = 0; b < n; ++b) {
+            const float* px = a.x + ((long)b * a.c + ch) * a.hw;
+            for (long i = threadIdx.x; i < a.hw; i += kThreads) {
+                const double d = (double)(px[i] - p2f);
+                u1 += d;
+                u2 += d * d;
+            }
+        }
+        __syncthreads();
+        t1 = fsc::block_sum<double, kThreads / 64>(u1, scratch);
+        t2 = fsc::block_sum<double, kThreads / 64>(u2, scratch);
+        pivot = (double)p2f;
+    }
+    if (threadIdx.x == 0) finalize_channel(a, ch, t1, t2, pivot);
+    (void)bc;
+}
+
 // hw == 1 (BatchNorm1d on (N, C)): flat indexing
 __global__ void fwd_flat_kernel(const float* __restrict__ x, const float* __restrict__ res,
                                 const float* __restrict__ scale, const float* __restrict__ shift,
@@ -1466,6 +1517,22 @@ int fsc_bn_records_fold_conv(const void* records, int workers, int blocks, int c
     hipLaunchKernelGGL(fold_conv_records_kernel, dim3(c), dim3(kThreads), 0, fsc::as_stream(stream),
                        reinterpret_cast<const float4*>(records), workers, blocks, co_blk, order, carve(stats_workspace, c).part);
     FSC_LAUNCH_CHECK("fsc_bn_records_fold_conv");
+    return 0;
+}
+
+int fsc_bn_train_stats_conv(const void* records, int workers, int blocks, int co_blk, int order, const float* x, int n, int c, long hw,
+                            const float* gamma, const float* beta, float eps, float momentum, float* running_mean,
+                            float* running_var, float* save_mean, float* save_invstd, float* scale, float* shift, float* x_minmax,
+                            fsc_stream_t stream) {
+    FSC_CHECK_ARG(records && x && save_mean && save_invstd && scale && shift, "fsc_bn_train_stats_conv: null pointer");
+    FSC_CHECK_ARG(workers > 0 && blocks > 0 && co_blk > 0 && workers % blocks == 0 && c > 0 && c <= blocks * co_blk && n > 0 && hw > 1,
+                  "fsc_bn_train_stats_conv: bad arguments");
+    FSC_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr), "fsc_bn_train_stats_conv: running stats must come in pairs");
+    FinalizeArgs fa{x, c, hw, (double)n * (double)hw, 1, nullptr, gamma, beta, eps, momentum, running_mean, running_var,
+                    save_mean, save_invstd, scale, shift, nullptr, 0, x_minmax, 1, 0};
+    hipLaunchKernelGGL(stats_fold_finalize_kernel, dim3(c), dim3(kThreads), 0, fsc::as_stream(stream), fa, n,
+                       reinterpret_cast<const float4*>(records), workers, blocks, co_blk, order);
+    FSC_LAUNCH_CHECK("fsc_bn_train_stats_conv");
     return 0;
 }
 

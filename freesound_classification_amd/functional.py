@@ -519,12 +519,21 @@ def _stats_begin(d, pool, stats_bn, like):
     return lay, rec, (bn.running_mean if bn_tracks(bn, training) else None)
 
 
+_STATS_CONV_REC = 32       # (host-side flag) the entry holds the raw records of a STATS convolution, not a folded workspace
+
+
 def _stats_end(lay, rec, y, c_out):
-    """Folds the records of the convolution that wrote `y` into a BatchNorm workspace and leaves it for bn_prepare(y, ...)."""
-    ws = _bn_ws(c_out, y)
-    call("fsc_bn_records_fold_conv", ptr(rec), lay[0], lay[1], lay[2], lay[3], c_out, ptr(ws), stream_ptr())
+    """Leaves the records of the convolution that wrote `y` for bn_prepare(y, ...): folded and finalised there in one launch
+    (fsc_bn_train_stats_conv), or folded into a BatchNorm workspace first where that entry point does not apply."""
     _PRESTATS.clear()
-    _PRESTATS[(y.data_ptr(), tuple(y.shape), y._version, y.device)] = (ws, y, _STATS_FOLDED | _STATS_PIVOT_RM)
+    _PRESTATS[(y.data_ptr(), tuple(y.shape), y._version, y.device)] = ((rec, lay, c_out), y, _STATS_CONV_REC | _STATS_FOLDED | _STATS_PIVOT_RM)
+
+
+def _fold_conv_records(entry, like):
+    rec, lay, c_out = entry
+    ws = _bn_ws(c_out, like)
+    call("fsc_bn_records_fold_conv", ptr(rec), lay[0], lay[1], lay[2], lay[3], c_out, ptr(ws), stream_ptr())
+    return ws
 
 
 def conv_l16(t, weight, bias, dgrad=False, accumulate_into=None, prepacked=None, stats_bn=None):
@@ -836,8 +845,17 @@ def bn_prepare(x, bn, training, sync=None, defer=None, want_minmax=False):
         pre = _take_prestats(x)                            # reduced by the kernel that wrote x?
         if pre is not None and (pre[1] & _STATS_PIVOT_RM) and not training:
             pre = None                                     # (sums about a running mean that this call would not pass: never in practice)
-        ws, folded = pre if pre is not None else (_bn_ws(c, x), 0)      # (kept alive across both phases)
         st.minmax = _empty((2 * c,), x)                    # per-channel [min, max] of x: the L16 producers' bound
+        if pre is not None and (pre[1] & _STATS_CONV_REC):
+            if sync is None and hw > 1:                    # fold + finalise in one launch
+                rec, lay, _c = pre[0]
+                with _stage("bn_stats", 0):
+                    call("fsc_bn_train_stats_conv", ptr(rec), lay[0], lay[1], lay[2], lay[3], ptr(x), n, c, hw, ptr(gamma), ptr(beta),
+                         bn.eps, momentum, ptr(bn.running_mean) if track else None, ptr(bn.running_var) if track else None,
+                         ptr(st.mean), ptr(st.invstd), ptr(st.scale), ptr(st.shift), ptr(st.minmax), stream_ptr())
+                return st
+            pre = (_fold_conv_records(pre[0], x), pre[1] & ~_STATS_CONV_REC)
+        ws, folded = pre if pre is not None else (_bn_ws(c, x), 0)      # (kept alive across both phases)
         args = (ptr(x), n, c, hw, ptr(gamma), ptr(beta), bn.eps, momentum,
                 ptr(bn.running_mean) if track else None, ptr(bn.running_var) if track else None,
                 ptr(st.mean), ptr(st.invstd), ptr(st.scale), ptr(st.shift), ptr(ws))
@@ -855,6 +873,8 @@ def bn_prepare(x, bn, training, sync=None, defer=None, want_minmax=False):
         call("fsc_bn_eval_prepare", c, ptr(gamma), ptr(beta), ptr(bn.running_mean), ptr(bn.running_var),
              bn.eps, ptr(st.scale), ptr(st.shift), stream_ptr())
         pre = _take_prestats(x)
+        if pre is not None and (pre[1] & _STATS_CONV_REC):
+            pre = (_fold_conv_records(pre[0], x), pre[1] & ~_STATS_CONV_REC) if (want_minmax and EVAL_L16 and hw > 1) else None
         if want_minmax and EVAL_L16 and hw > 1:
             # inference on the L16 kernels: the producer that writes the conv operand needs the range of x up front -- from the
             # records of the kernel that wrote x, else from one reduction pass

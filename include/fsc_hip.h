@@ -264,6 +264,13 @@ int fsc_conv_l16_pool_fwd_stats(const fsc_conv_desc* d, const void* in_l16, cons
                                 fsc_stream_t stream);
 int fsc_bn_records_fold_conv(const void* records, int workers, int blocks, int co_blk, int order, int c,
                              void* stats_workspace, fsc_stream_t stream);
+/* fsc_bn_records_fold_conv + fsc_bn_train_stats(phase 0 | FSC_BN_STATS_FOLDED | FSC_BN_STATS_PIVOT_RM) in ONE launch (single replica,
+ * training): the workgroup of a channel folds the records of the STATS convolution that wrote x and finalises (pivot = running_mean
+ * as it is before this call, 0 when NULL; the far-pivot re-reduction included).  No workspace. */
+int fsc_bn_train_stats_conv(const void* records, int workers, int blocks, int co_blk, int order, const float* x, int n, int c, long hw,
+                            const float* gamma, const float* beta, float eps, float momentum, float* running_mean,
+                            float* running_var, float* save_mean, float* save_invstd, float* scale, float* shift, float* x_minmax,
+                            fsc_stream_t stream);
 /* eval: scale/shift from the running statistics */
 int fsc_bn_eval_prepare(int c, const float* gamma, const float* beta, const float* running_mean,
                         const float* running_var, float eps, float* scale, float* shift,
