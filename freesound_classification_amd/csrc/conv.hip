@@ -1945,23 +1945,29 @@ __global__ __launch_bounds__(kWgxWaves * 64) void conv_wgrad_x3_kernel(WgxGeom g
         }
 }
 
-// blockIdx.y = (tap, ci) row of the partial slices, threads run along co (coalesced reads); no
-// integer division per element.
-__global__ void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, int c_out, int c_in,
-                                    int taps, int ci_pad, int co_pad, int nsplit) {
-    const int co = blockIdx.x * blockDim.x + threadIdx.x;
-    if (co >= c_out) return;
+// blockIdx.y = (tap, ci) row of the partial slices; threadIdx.x runs along co (coalesced reads), threadIdx.y over four interleaved
+// groups of split-K slices (as l16_wgrad_reduce_kernel: one thread walking every slice was a chain of dependent loads).
+constexpr int kRedX = 64, kRedY = 4;
+__global__ __launch_bounds__(kRedX * kRedY) void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, int c_out,
+                                                                      int c_in, int taps, int ci_pad, int co_pad, int nsplit) {
+    __shared__ float red[kRedY][kRedX];
+    const int co = blockIdx.x * kRedX + threadIdx.x;
     const int tap = blockIdx.y / c_in, ci = blockIdx.y - tap * c_in;
     const long slice = (long)taps * ci_pad * co_pad;
-    const float* p = part + ((long)tap * ci_pad + ci) * co_pad + co;
     float s0 = 0.f, s1 = 0.f;
-    int sp = 0;
-    for (; sp + 1 < nsplit; sp += 2) {
-        s0 += p[(long)sp * slice];
-        s1 += p[(long)(sp + 1) * slice];
+    if (co < c_out) {
+        const float* p = part + ((long)tap * ci_pad + ci) * co_pad + co;
+        int sp = threadIdx.y;
+        for (; sp + kRedY < nsplit; sp += 2 * kRedY) {
+            s0 += p[(long)sp * slice];
+            s1 += p[(long)(sp + kRedY) * slice];
+        }
+        if (sp < nsplit) s0 += p[(long)sp * slice];
     }
-    if (sp < nsplit) s0 += p[(long)sp * slice];
-    dw[((long)co * c_in + ci) * taps + tap] = s0 + s1;
+    red[threadIdx.y][threadIdx.x] = s0 + s1;
+    __syncthreads();
+    if (threadIdx.y == 0 && co < c_out)
+        dw[((long)co * c_in + ci) * taps + tap] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 
 // -------------------------------------------------------------------------------------------
@@ -2820,8 +2826,7 @@ int fsc_conv_wgrad(const fsc_conv_desc* d, const float* in, const float* dout, f
         else rc = launch_wgrad_x3<1, 3>(px, in, dout, part, in_amax, dout_amax, st);
         if (rc) return rc;
         const int taps = d->kh * d->kw;
-        const int rthreads = d->c_out >= 128 ? 128 : 64;
-        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(fsc::ceil_div(d->c_out, rthreads), taps * d->c_in), dim3(rthreads), 0, st,
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(fsc::ceil_div(d->c_out, kRedX), taps * d->c_in), dim3(kRedX, kRedY), 0, st,
                            part, dweight, d->c_out, d->c_in, taps, px.g.ci_pad, px.g.co_pad, px.g.nsplit);
         FSC_LAUNCH_CHECK("fsc_conv_wgrad(reduce)");
         return 0;
@@ -2833,8 +2838,7 @@ int fsc_conv_wgrad(const fsc_conv_desc* d, const float* in, const float* dout, f
     else rc = launch_wgrad<1, 1>(p, in, dout, part, st);
     if (rc) return rc;
     const int taps = d->kh * d->kw;
-    const int rthreads = d->c_out >= 128 ? 128 : 64;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(fsc::ceil_div(d->c_out, rthreads), taps * d->c_in), dim3(rthreads), 0, st,
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(fsc::ceil_div(d->c_out, kRedX), taps * d->c_in), dim3(kRedX, kRedY), 0, st,
                        part, dweight, d->c_out, d->c_in, taps, p.g.ci_pad, p.g.co_pad, p.part_splits);
     FSC_LAUNCH_CHECK("fsc_conv_wgrad(reduce)");
     return 0;

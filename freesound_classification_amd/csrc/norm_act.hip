@@ -44,7 +44,7 @@ __global__ __launch_bounds__(kThreads) void stats_partial_kernel(
     const int tn = threadIdx.x >> hwp_log2, ti = threadIdx.x & (hwp - 1);
     float s1 = 0.f, s2 = 0.f;
     float mn = pivot, mx = pivot;          // smallest / largest x of the channel (the L16 producers' operand bound)
-    const bool vec = (hw & 3) == 0 && hwp == kThreads;
+    const bool vec = hwp == kThreads;          // planes of >= 256 pixels: 16-byte loads behind an alignment peel
     if ((hw & 3) == 0 && hw <= 2 * kThreads) {
         // planes of at most 128 quads: a lane owns one quad of a plane, 256 / 2^l4 images side by side, four of those
         // groups in flight (one image per trip left the 208-pixel layers of cfg 2 at 1 TB/s).  Idle lanes and trips past the
@@ -76,8 +76,19 @@ __global__ __launch_bounds__(kThreads) void stats_partial_kernel(
     for (int b = sp * groups + tn; b < n; b += nsplit * groups) {
         const float* p = x + ((long)b * c + ch) * hw;
         if (vec) {
-            const float4* p4 = reinterpret_cast<const float4*>(p);
-            const long n4 = hw >> 2;
+            const int head = (int)((4 - ((((long)b * c + ch) * hw) & 3)) & 3);
+            const float4* p4 = reinterpret_cast<const float4*>(p + head);
+            const long n4 = (hw - head) >> 2;
+            if (ti < 8) {                                   // the <= 6 elements outside the whole quads
+                const long e = ti < head ? (long)ti : head + 4 * n4 + (ti - head);
+                if (e < hw && (ti < head || e >= head + 4 * n4)) {
+                    const float a0 = p[e] - pivot;
+                    s1 += a0;
+                    s2 += a0 * a0;
+                    mn = fminf(mn, p[e]);
+                    mx = fmaxf(mx, p[e]);
+                }
+            }
             long i = ti;
             // four 16-byte loads in flight per thread (one reached 4.1 TB/s on the 704 MB tensors, short of the
             // ~5.5 TB/s of the apply passes)
@@ -307,28 +318,34 @@ __global__ __launch_bounds__(kThreads) void fwd_plane_kernel(
     const float* px = x + plane * hw;
     const float* pr = res ? res + plane * hw : nullptr;
     float* py = y + plane * hw;
-    if ((hw & 3) == 0) {
-        const long n4 = hw >> 2;
-        for (long i = (long)blockIdx.y * kThreads + threadIdx.x; i < n4; i += (long)gridDim.y * kThreads) {
-            float4 v = reinterpret_cast<const float4*>(px)[i];
-            float4 z = make_float4(fmaf(v.x, sc, sh), fmaf(v.y, sc, sh), fmaf(v.z, sc, sh), fmaf(v.w, sc, sh));
-            if (pr) {
-                const float4 r = reinterpret_cast<const float4*>(pr)[i];
-                z.x += r.x; z.y += r.y; z.z += r.z; z.w += r.w;
-            }
-            z.x = act(z.x, al, has_alpha); z.y = act(z.y, al, has_alpha);
-            z.z = act(z.z, al, has_alpha); z.w = act(z.w, al, has_alpha);
-            reinterpret_cast<float4*>(py)[i] = z;
-            mx = fmaxf(fmaxf(mx, fabsf(z.x)), fmaxf(fabsf(z.y), fmaxf(fabsf(z.z), fabsf(z.w))));
+    // 16-byte accesses for any plane length: `head` elements up to the first 16-byte boundary of the plane (planes of odd length
+    // -- the 1-d model's 1723, 861, ... frames -- start at any 4-byte offset), whole quads, then the tail; the <= 6 stragglers are
+    // done by the first threads of slice 0
+    const int head = (int)((4 - ((plane * hw) & 3)) & 3);
+    const long n4 = (hw - head) >> 2;
+    auto point = [&](long i) {
+        float z = fmaf(px[i], sc, sh);
+        if (pr) z += pr[i];
+        z = act(z, al, has_alpha);
+        py[i] = z;
+        mx = fmaxf(mx, fabsf(z));
+    };
+    for (long i = (long)blockIdx.y * kThreads + threadIdx.x; i < n4; i += (long)gridDim.y * kThreads) {
+        float4 v = reinterpret_cast<const float4*>(px + head)[i];
+        float4 z = make_float4(fmaf(v.x, sc, sh), fmaf(v.y, sc, sh), fmaf(v.z, sc, sh), fmaf(v.w, sc, sh));
+        if (pr) {
+            const float4 r = reinterpret_cast<const float4*>(pr + head)[i];
+            z.x += r.x; z.y += r.y; z.z += r.z; z.w += r.w;
         }
-    } else {
-        for (long i = (long)blockIdx.y * kThreads + threadIdx.x; i < hw; i += (long)gridDim.y * kThreads) {
-            float z = fmaf(px[i], sc, sh);
-            if (pr) z += pr[i];
-            z = act(z, al, has_alpha);
-            py[i] = z;
-            mx = fmaxf(mx, fabsf(z));
-        }
+        z.x = act(z.x, al, has_alpha); z.y = act(z.y, al, has_alpha);
+        z.z = act(z.z, al, has_alpha); z.w = act(z.w, al, has_alpha);
+        reinterpret_cast<float4*>(py + head)[i] = z;
+        mx = fmaxf(fmaxf(mx, fabsf(z.x)), fmaxf(fabsf(z.y), fmaxf(fabsf(z.z), fabsf(z.w))));
+    }
+    if (blockIdx.y == 0 && threadIdx.x < 8) {
+        const long t = threadIdx.x;
+        if (t < head) point(t);
+        else if (head + 4 * n4 + (t - head) < hw) point(head + 4 * n4 + (t - head));
     }
     if (y_amax) fsc::publish_amax(y_amax, mx);
 }
@@ -839,17 +856,35 @@ __global__ __launch_bounds__(kThreads) void bwd_partial_kernel(BwdArgs a, int ns
         const float* pdy = a.dy ? a.dy + plane * a.hw : nullptr;
         const float gval = a.gmax_dy ? a.gmax_dy[plane] : 0.f;
         const long gpos = a.gmax_dy ? (long)a.gmax_idx[plane] : -1;
-        if ((a.hw & 3) == 0 && hwp == kThreads) {
-            // 16-byte loads: planes of >= 256 pixels with hw % 4 == 0 (every benchmark layer)
-            const long n4 = a.hw >> 2;
+        if (hwp == kThreads) {
+            // 16-byte loads for planes of >= 256 pixels, whatever their length: head elements up to the plane's first 16-byte
+            // boundary (odd lengths -- the 1-d model -- put planes at any 4-byte offset), whole quads, tail
+            const int head = (int)((4 - ((plane * a.hw) & 3)) & 3);
+            const long n4 = (a.hw - head) >> 2;
             for (long i4 = ti; i4 < n4; i4 += kThreads) {
-                const float4 xv = reinterpret_cast<const float4*>(px)[i4];
+                const float4 xv = reinterpret_cast<const float4*>(px + head)[i4];
                 float4 rv = make_float4(0.f, 0.f, 0.f, 0.f), uv = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (pr) rv = reinterpret_cast<const float4*>(pr)[i4];
-                if (pdy) uv = reinterpret_cast<const float4*>(pdy)[i4];
-                const long d = gpos - i4 * 4;
+                if (pr) rv = reinterpret_cast<const float4*>(pr + head)[i4];
+                if (pdy) uv = reinterpret_cast<const float4*>(pdy + head)[i4];
+                const long d = gpos - (head + i4 * 4);
                 if (d >= 0 && d < 4) { if (d == 0) uv.x += gval; else if (d == 1) uv.y += gval; else if (d == 2) uv.z += gval; else uv.w += gval; }
                 quad(xv, rv, uv);
+            }
+            if (ti < 8) {
+                const long i = ti < head ? (long)ti : head + 4 * n4 + (ti - head);
+                if (i < a.hw && (ti < head || i >= head + 4 * n4)) {
+                    const float xh = (px[i] - mean) * invstd;
+                    float z = fmaf(xh, g, b);
+                    if (pr) z += pr[i];
+                    const float up = upstream(a, pdy, i, gval, gpos);
+                    const bool neg = has_alpha && !(z > 0.f);
+                    const float dz = neg ? al * up : up;
+                    s0 += dz;
+                    s1 += dz * xh;
+                    s2 += up * (neg ? z : 0.f);
+                    mdz = fmaxf(mdz, fabsf(dz));
+                    mxh = fmaxf(mxh, fabsf(xh));
+                }
             }
             continue;
         }
@@ -975,42 +1010,45 @@ __global__ __launch_bounds__(kThreads) void bwd_apply_plane_kernel(BwdArgs a, co
     float* pdx = dx + plane * a.hw;
     float* pdr = dres ? dres + plane * a.hw : nullptr;
     float acc = 0.f;
-    if ((a.hw & 3) == 0) {
-        const long n4 = a.hw >> 2;
-        for (long i4 = (long)blockIdx.y * kThreads + threadIdx.x; i4 < n4; i4 += (long)gridDim.y * kThreads) {
-            const float4 xv = reinterpret_cast<const float4*>(px)[i4];
-            float4 rv = make_float4(0.f, 0.f, 0.f, 0.f), uv = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (pr) rv = reinterpret_cast<const float4*>(pr)[i4];
-            if (pdy) uv = reinterpret_cast<const float4*>(pdy)[i4];
-            const long dd = gpos - i4 * 4;
-            if (dd >= 0 && dd < 4) { if (dd == 0) uv.x += gval; else if (dd == 1) uv.y += gval; else if (dd == 2) uv.z += gval; else uv.w += gval; }
-            const float xs[4] = {xv.x, xv.y, xv.z, xv.w}, rs[4] = {rv.x, rv.y, rv.z, rv.w}, us[4] = {uv.x, uv.y, uv.z, uv.w};
-            float dv[4], zv[4];
+    const int head = (int)((4 - ((plane * a.hw) & 3)) & 3);       // (see fwd_plane_kernel: 16-byte accesses for any plane length)
+    const long n4 = (a.hw - head) >> 2;
+    auto point = [&](long i) {
+        const float xh = (px[i] - mean) * invstd;
+        float z = fmaf(xh, g, b);
+        if (pr) z += pr[i];
+        const float up = upstream(a, pdy, i, gval, gpos);
+        const float dz = (has_alpha && !(z > 0.f)) ? al * up : up;
+        const float d = k * (dz - c1 - xh * c2);
+        pdx[i] = d;
+        if (pdr) pdr[i] = dz;
+        acc += d;
+        mx = fmaxf(mx, fabsf(d));
+    };
+    for (long i4 = (long)blockIdx.y * kThreads + threadIdx.x; i4 < n4; i4 += (long)gridDim.y * kThreads) {
+        const float4 xv = reinterpret_cast<const float4*>(px + head)[i4];
+        float4 rv = make_float4(0.f, 0.f, 0.f, 0.f), uv = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (pr) rv = reinterpret_cast<const float4*>(pr + head)[i4];
+        if (pdy) uv = reinterpret_cast<const float4*>(pdy + head)[i4];
+        const long dd = gpos - (head + i4 * 4);
+        if (dd >= 0 && dd < 4) { if (dd == 0) uv.x += gval; else if (dd == 1) uv.y += gval; else if (dd == 2) uv.z += gval; else uv.w += gval; }
+        const float xs[4] = {xv.x, xv.y, xv.z, xv.w}, rs[4] = {rv.x, rv.y, rv.z, rv.w}, us[4] = {uv.x, uv.y, uv.z, uv.w};
+        float dv[4], zv[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float xh = (xs[e] - mean) * invstd;
-                const float z = fmaf(xh, g, b) + rs[e];
-                zv[e] = (has_alpha && !(z > 0.f)) ? al * us[e] : us[e];
-                dv[e] = k * (zv[e] - c1 - xh * c2);
-                acc += dv[e];
-                mx = fmaxf(mx, fabsf(dv[e]));
-            }
-            reinterpret_cast<float4*>(pdx)[i4] = make_float4(dv[0], dv[1], dv[2], dv[3]);
-            if (pdr) reinterpret_cast<float4*>(pdr)[i4] = make_float4(zv[0], zv[1], zv[2], zv[3]);
+        for (int e = 0; e < 4; ++e) {
+            const float xh = (xs[e] - mean) * invstd;
+            const float z = fmaf(xh, g, b) + rs[e];
+            zv[e] = (has_alpha && !(z > 0.f)) ? al * us[e] : us[e];
+            dv[e] = k * (zv[e] - c1 - xh * c2);
+            acc += dv[e];
+            mx = fmaxf(mx, fabsf(dv[e]));
         }
-    } else {
-        for (long i = (long)blockIdx.y * kThreads + threadIdx.x; i < a.hw; i += (long)gridDim.y * kThreads) {
-            const float xh = (px[i] - mean) * invstd;
-            float z = fmaf(xh, g, b);
-            if (pr) z += pr[i];
-            const float up = upstream(a, pdy, i, gval, gpos);
-            const float dz = (has_alpha && !(z > 0.f)) ? al * up : up;
-            const float d = k * (dz - c1 - xh * c2);
-            pdx[i] = d;
-            if (pdr) pdr[i] = dz;
-            acc += d;
-            mx = fmaxf(mx, fabsf(d));
-        }
+        reinterpret_cast<float4*>(pdx + head)[i4] = make_float4(dv[0], dv[1], dv[2], dv[3]);
+        if (pdr) reinterpret_cast<float4*>(pdr + head)[i4] = make_float4(zv[0], zv[1], zv[2], zv[3]);
+    }
+    if (blockIdx.y == 0 && threadIdx.x < 8) {
+        const long t = threadIdx.x;
+        if (t < head) point(t);
+        else if (head + 4 * n4 + (t - head) < a.hw) point(head + 4 * n4 + (t - head));
     }
     if (dx_chan_sum) {
         const float t = fsc::block_sum<float, kThreads / 64>(acc, scratch);
