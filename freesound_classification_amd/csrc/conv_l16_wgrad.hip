@@ -34,6 +34,19 @@ typedef __attribute__((address_space(1))) const void* glb_ptr;
 
 constexpr int kWaves = 8;
 constexpr int kMaxXI = 4;          // input DMA instructions per (octet, limb) plane: plane <= 256 positions
+#ifndef FSC_L16W_COPYW
+#define FSC_L16W_COPYW 4
+#endif
+// 3x3 kernels: waves 0 .. 3 (one per SIMD) issue all copies of the next unit; the other wave of each SIMD goes straight to its
+// MFMAs and has the matrix pipe to itself meanwhile.  With all eight waves copying, the burst (LDS-DMA accepts ~30 B per cycle
+// and CU) kept the pipe idle for 2500-3300 cycles of a 9400-cycle unit: +6-9 % on every 3x3 layer of cfg 2.  (Spreading the
+// copies over the MFMA slots instead lost 4 %; the short units of the 1x1 kernels are 3 % faster with all eight waves copying;
+// giving the copying waves the smaller co-tile groups changed nothing.)
+constexpr int kCopyWaves3x3 = FSC_L16W_COPYW;
+#ifndef FSC_L16W_AHEAD
+#define FSC_L16W_AHEAD 1
+#endif
+constexpr int kAhead = FSC_L16W_AHEAD;     // B (input) fragments are read this many MFMA slots ahead of their use (2, 3: no faster)
 // Unit pitches (positions) are padded to == 2 (mod 8) where the LDS allows: an octet (two units) is then 64 bytes (mod 256) from
 // the next, and the transpose read's lanes of octet A and octet B hit disjoint bank halves (unpadded: a 2-way conflict on every read).
 
@@ -53,6 +66,16 @@ struct WGeom {
 
 __device__ __attribute__((aligned(16))) float g_zero16_w[4] = {0.f, 0.f, 0.f, 0.f};
 __device__ unsigned long long g_l16w_clock[2];      // shader cycles / 100 MHz reference ticks of the last launch (see conv_l16.hip)
+// Development (-DFSC_L16_PROFILE): cycle stamps around the phases of a unit, summed per wave of workgroup (0, 0):
+// 0 wait for the copies + barrier, 1 copy issue, 2 MFMA k-steps, 3 units, 4 whole kernel (fsc_debug_l16w_prof)
+#ifdef FSC_L16_PROFILE
+__device__ unsigned long long g_l16w_prof[8][8];
+#define WPROF_MARK() (pf_t = __builtin_readcyclecounter())
+#define WPROF_ADD(i) do { const unsigned long long n_ = __builtin_readcyclecounter(); pf_acc[i] += n_ - pf_t; pf_t = n_; } while (0)
+#else
+#define WPROF_MARK()
+#define WPROF_ADD(i)
+#endif
 
 // 16-byte LDS-DMA as inline assembly (see conv_l16.hip glds16: behind the builtin hipcc waits for the copy of the NEXT unit
 // before the first LDS read of the current one).  The wait is explicit: vmcnt(0) before the barrier that opens a unit.
@@ -68,6 +91,14 @@ __device__ __forceinline__ u32x4 tr_read8(const char* p) {
     const u32x2 lo = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s)(p)));
     const u32x2 hi = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s)(p + 64)));
     return (u32x4){lo[0], lo[1], hi[0], hi[1]};
+}
+
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
 }
 
 // same co-tile spreading as conv.hip wgx_group
@@ -103,6 +134,7 @@ __global__ __launch_bounds__(kWaves * 64) void conv_l16_wgrad_kernel(WGeom g, co
     constexpr int PADH = KH / 2, PADW = KW / 2;
     constexpr int NB = TAPS * CT;                  // B slots of a wave: (ci tile, tap)
     static_assert(TAPS == 1 || CT == 1, "3x3: one ci tile per wave");
+    constexpr int kCopyWaves = TAPS == 1 ? kWaves : kCopyWaves3x3;
 
     extern __shared__ __attribute__((aligned(16))) uint4 smem4[];
     const int co_oct = g.ng * g.tpg * 2, ci_oct = g.nt * CT * 2;             // octets staged per operand
@@ -166,6 +198,7 @@ __global__ __launch_bounds__(kWaves * 64) void conv_l16_wgrad_kernel(WGeom g, co
     const uint4* const zero = reinterpret_cast<const uint4*>(g_zero16_w);
     const long do_img = (long)g.oct_out * 2 * g.hw, in_img = (long)g.oct_in * 2 * g.hw;
     auto issue_unit = [&](int u, int stage) {
+        if (wid >= kCopyWaves) return;
         uint4* dl = smem4 + stage * stage_u4;
         uint4* il = dl + co_oct * 2 * g.du;
         int t = u;
@@ -176,7 +209,7 @@ __global__ __launch_bounds__(kWaves * 64) void conv_l16_wgrad_kernel(WGeom g, co
             const bool live = h0 + pr < g.h && w0 + pc < g.w;
             const uint4* src = dout + (long)n0 * do_img + (long)(tile0 * 2) * 2 * g.hw + (long)(h0 + pr) * g.w + (w0 + pc);
 #pragma unroll 1
-            for (int un = wid; un < co_oct_live * 2; un += kWaves)            // unit = (octet, limb)
+            for (int un = wid; un < co_oct_live * 2; un += kCopyWaves)        // unit = (octet, limb)
                 glds16(live ? src + (long)un * g.hw : zero, dl + un * g.du);
         }
 #pragma unroll
@@ -186,7 +219,7 @@ __global__ __launch_bounds__(kWaves * 64) void conv_l16_wgrad_kernel(WGeom g, co
                 const bool live = gh >= 0 && gh < g.h && gw >= 0 && gw < g.w;
                 const uint4* src = in + (long)n0 * in_img + (long)(cit0 * 2) * 2 * g.hw + (long)gh * g.w + gw;
 #pragma unroll 1
-                for (int un = wid; un < ci_oct_live * 2; un += kWaves)
+                for (int un = wid; un < ci_oct_live * 2; un += kCopyWaves)
                     glds16(live ? src + (long)un * g.hw : zero, il + un * g.plane + j * 64);
             }
         }
@@ -215,15 +248,21 @@ __global__ __launch_bounds__(kWaves * 64) void conv_l16_wgrad_kernel(WGeom g, co
 
     // The whole unit loop is specialised on the wave's live co tiles (dead tiles of a block's last group are skipped without
     // a branch per MFMA; a switch INSIDE the loop makes hipcc keep two copies of the accumulators).
+#ifdef FSC_L16_PROFILE
+    unsigned long long pf_t = 0, pf_acc[5] = {0, 0, 0, 0, 0};
+#endif
     auto run_units = [&](auto live_c) {
         constexpr int LIVE = decltype(live_c)::value;
         int stage = 0;
         if (split < g.units) issue_unit(split, 0);
 #pragma unroll 1
         for (int u = split; u < g.units; u += g.nsplit) {
+            WPROF_MARK();
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // unit u has landed ...
             __syncthreads();                  // ... for every wave; everyone is done with the other stage
+            WPROF_ADD(0);
             if (u + g.nsplit < g.units) issue_unit(u + g.nsplit, stage ^ 1);
+            WPROF_ADD(1);
             const char* dl = reinterpret_cast<const char*>(smem4 + stage * stage_u4);
             const char* il = dl + (size_t)co_oct * 2 * g.du * 16;
             if constexpr (LIVE > 0) {
@@ -236,7 +275,7 @@ __global__ __launch_bounds__(kWaves * 64) void conv_l16_wgrad_kernel(WGeom g, co
                     for (int i = 0; i < LIVE; ++i)
 #pragma unroll
                         for (int l = 0; l < 2; ++l) af[i][l] = tr_read8(ap + (i * 4 + l) * g.du * 16);
-                    u32x4 bf[2][2];                                            // [buffer][limb]
+                    u32x4 bf[kAhead + 1][2];                                   // [buffer][limb]
                     auto read_slot = [&](int s, u32x4 (&dst)[2]) {
                         const int ct = s / TAPS, tap = s - ct * TAPS;
                         const int ty = tap / KW, tx = tap - ty * KW;
@@ -244,26 +283,32 @@ __global__ __launch_bounds__(kWaves * 64) void conv_l16_wgrad_kernel(WGeom g, co
                         dst[0] = tr_read8(p);
                         dst[1] = tr_read8(p + limb_b);
                     };
-                    read_slot(0, bf[0]);
 #pragma unroll
-                    for (int s = 0; s < NB; ++s) {
-                        if (s + 1 < NB) read_slot(s + 1, bf[(s + 1) & 1]);
+                    for (int s = 0; s < kAhead && s < NB; ++s) read_slot(s, bf[s]);
+                    static_for<0, NB>([&](auto s_c) {
+                        constexpr int s = decltype(s_c)::value;
+                        if (s + kAhead < NB) read_slot(s + kAhead, bf[(s + kAhead) % (kAhead + 1)]);
 #pragma unroll
                         for (int gq = 0; gq < 3; ++gq)
 #pragma unroll
-                            for (int i = 0; i < LIVE; ++i) acc[s][i] = mfma16(af[i][kLa[gq]], bf[s & 1][kLb[gq]], acc[s][i]);
-                        // the next slot's four reads go behind the first MFMAs of this one; nothing else moves across slots
-                        // (unpinned, the scheduler hoists every slot's reads to the top of the k-step: +56 registers)
+                            for (int i = 0; i < LIVE; ++i)
+                                acc[s][i] = mfma16(af[i][kLa[gq]], bf[s % (kAhead + 1)][kLb[gq]], acc[s][i]);
+                        // the four reads of the slot kAhead ahead go behind the first MFMAs of this one; nothing else moves across
+                        // slots (unpinned, the scheduler hoists every slot's reads to the top of the k-step: +56 registers)
 #pragma unroll
                         for (int k = 0; k < 4; ++k) {
                             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                            if (s + 1 < NB) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                            if (s + kAhead < NB) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
                         }
                         __builtin_amdgcn_sched_barrier(0);
-                    }
+                    });
                 }
             }
             stage ^= 1;
+            WPROF_ADD(2);
+#ifdef FSC_L16_PROFILE
+            pf_acc[3] += 1;
+#endif
         }
     };
     switch (mt_live) {
@@ -274,6 +319,12 @@ __global__ __launch_bounds__(kWaves * 64) void conv_l16_wgrad_kernel(WGeom g, co
         default: if constexpr (MT >= 4) run_units(std::integral_constant<int, 4>{}); break;
     }
 
+#ifdef FSC_L16_PROFILE
+    if (blockIdx.x == 0 && blockIdx.y == 0 && lane == 0) {
+        pf_acc[4] = __builtin_readcyclecounter() - ck0;
+        for (int i = 0; i < 5; ++i) atomicAdd(&g_l16w_prof[wid][i], pf_acc[i]);
+    }
+#endif
     if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) {
         g_l16w_clock[0] = __builtin_readcyclecounter() - ck0;
         g_l16w_clock[1] = __builtin_amdgcn_s_memrealtime() - cr0;
@@ -342,15 +393,27 @@ bool plan_l16_wgrad(const fsc_conv_desc& d, WPlan* out) {
     g.n = d.n; g.cin = d.c_in; g.cout = d.c_out; g.h = h; g.w = w; g.hw = (long)h * w;
     g.oct_in = (d.c_in + 7) / 8; g.oct_out = (d.c_out + 7) / 8;
     if ((long)d.n * g.oct_in * 2 * g.hw >= (1L << 31) || (long)d.n * g.oct_out * 2 * g.hw >= (1L << 31)) return false;
+    // box = th x tw = 64 pixels: the fewest padded pixels first; among boxes within 1 % of that, the smallest halo'd window
+    // (8 x 8: 100 positions = two DMA instructions per plane; 2 x 32: 136 = three.  Measured on cfg 2 with the box pinned:
+    // 64 x 215 planes +5 % with 8 x 8 over 2 x 32, 32 x 107 planes +6 % / -2.5 % over 4 x 16 at equal padding)
     long best_px = -1;
-    for (int tw = 64; tw >= 8; tw >>= 1) {
-        const int th = 64 / tw;
-        if (th > 1 && h == 1) continue;
-        if ((th + d.kh - 1) * (tw + d.kw - 1) > 64 * kMaxXI - 8) continue;
-        const long px = (long)fsc::ceil_div(h, th) * fsc::ceil_div(w, tw) * 64;
-        // wider boxes fetch less halo: prefer them unless they waste more than ~6 % of the pixels
-        if (best_px < 0 || px * 100 < best_px * 94) { best_px = px; g.th = th; g.tw = tw; }
-    }
+    int best_npos = 0;
+    const char* force_tw = getenv("FSC_L16W_TW");              // development: pin the box width
+    for (int pass = 0; pass < 2; ++pass)                       // 0: the fewest padded pixels; 1: the box
+        for (int tw = 64; tw >= 8; tw >>= 1) {
+            const int th = 64 / tw;
+            if (force_tw && atoi(force_tw) != tw && taps > 1) continue;
+            if (th > 1 && h == 1) continue;
+            const int npos = (th + d.kh - 1) * (tw + d.kw - 1);
+            if (npos > 64 * kMaxXI - 8) continue;
+            const long px = (long)fsc::ceil_div(h, th) * fsc::ceil_div(w, tw) * 64;
+            if (pass == 0) {
+                if (best_px < 0 || px < best_px) best_px = px;
+            } else if (px * 100 <= best_px * 101 && (best_npos == 0 || npos < best_npos)) {
+                best_npos = npos; g.th = th; g.tw = tw;
+            }
+        }
+    if (best_npos > 0) best_px = (long)fsc::ceil_div(h, g.th) * fsc::ceil_div(w, g.tw) * 64;
     if (best_px < 0 || (double)h * w < 0.6 * (double)best_px) return false;
     g.tiles_h = fsc::ceil_div(h, g.th); g.tiles_w = fsc::ceil_div(w, g.tw);
     g.units = d.n * g.tiles_h * g.tiles_w;
@@ -489,6 +552,16 @@ int fsc_conv_l16_last_clock(int which, double* shader_mhz) {
     *shader_mhz = v[1] ? 100.0 * (double)v[0] / (double)v[1] : 0.0;
     return 0;
 }
+
+#ifdef FSC_L16_PROFILE
+int fsc_debug_l16w_prof(unsigned long long* out64) {
+    hipDeviceSynchronize();
+    hipMemcpyFromSymbol(out64, HIP_SYMBOL(g_l16w_prof), sizeof(unsigned long long) * 64);
+    unsigned long long z[64] = {0};
+    hipMemcpyToSymbol(HIP_SYMBOL(g_l16w_prof), z, sizeof(z));
+    return 0;
+}
+#endif
 
 int fsc_conv_l16_wgrad_plan_describe(const fsc_conv_desc* d, char* buf, size_t buf_len) {
     WPlan p;

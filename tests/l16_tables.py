@@ -28,7 +28,7 @@ CFG2_N128 = {
     (2, 100, 128, 431, 3): (None, None, None, False, None, None),                      # stem: direct fp32 kernels
     (100, 100, 64, 215, 1): (F1 % (7, 2), F1 % (7, 2), WG % (1, 1, 2, 4), None, (256, 1, 112, 0), None),
     (100, 100, 64, 215, 3): (F3 % (7, 2), F3 % (7, 2), WG % (3, 3, 4, 1), True, (256, 1, 112, 0), (256, 1, 112, 0)),
-    (100, 150, 64, 215, 3): (F3 % (5, 2), F3 % (7, 2), WG % (3, 3, 3, 1), True, (256, 2, 80, 1), (256, 2, 80, 1)),
+    (100, 150, 64, 215, 3): (F3 % (5, 2), F3 % (7, 2), WG % (3, 3, 4, 1), True, (256, 2, 80, 1), (256, 2, 80, 1)),
     (150, 150, 32, 107, 1): (F1 % (5, 2), F1 % (5, 2), WG % (1, 1, 3, 4), None, (256, 2, 80, 1), None),
     (150, 150, 32, 107, 3): (F3 % (5, 2), F3 % (5, 2), WG % (3, 3, 3, 1), True, (256, 2, 80, 1), (256, 2, 80, 1)),
     (150, 225, 32, 107, 3): (F3 % (8, 2), F3 % (5, 2), WG % (3, 3, 4, 1), True, (256, 2, 128, 1), (256, 2, 128, 1)),
