@@ -491,6 +491,11 @@ def main():
         for _ in range(k_s):
             one_step()
         torch.cuda.synchronize()
+        if os.environ.get("FSC_STAGE_DUMP"):           # development: every call of the last step, (stage, MB, us)
+            rows = [(nm, nb / 1e6, 1e3 * e0.elapsed_time(e1)) for nm, nb, e0, e1 in F.STAGE_TIMER.records]
+            with open(os.environ["FSC_STAGE_DUMP"], "w") as fh:
+                for nm, mb, us in rows[-(len(rows) // k_s):]:
+                    fh.write("%-12s %10.1f MB %9.1f us %7.2f TB/s\n" % (nm, mb, us, mb / max(us, 1e-3)))
         summ_s, F.STAGE_TIMER = F.STAGE_TIMER.summary(), None
         names = {"frontend": "front-end: waveform -> log-mel / log-STFT (reads 4 T, writes 4 F frames per clip)",
                  "bn_stats": "BatchNorm statistics passes that are not folded into a producer (1 read)",

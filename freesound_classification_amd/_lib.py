@@ -54,6 +54,8 @@ SIGNATURES = {
     "fsc_conv_stem_wgrad_pooled": (_I, [_D, _P, _P, _P, _P, _P, _P, _P]),
     "fsc_conv_stem_grads_finish": (_I, [_D, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P]),
     "fsc_absmin": (_I, [_P, _L, _P, _P]),
+    "fsc_cat_cols": (_I, [_P, _P, _I, _I, _P, _I, _P]),
+    "fsc_bump_counters": (_I, [_P, _I, _P]),
     "fsc_conv_l16_last_clock": (_I, [_I, C.POINTER(C.c_double)]),
     "fsc_conv_l16_pack_weights_multi": (_I, [_I, _P, _P, _P, _P, _P]),
     "fsc_bn_train_stats_conv": (_I, [_P, _I, _I, _I, _I, _P, _I, _I, _L, _P, _P, _F, _F, _P, _P, _P, _P, _P, _P, _P, _P]),

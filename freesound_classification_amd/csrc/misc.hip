@@ -23,6 +23,35 @@ namespace {
 __global__ void fill_kernel(float* __restrict__ x, float v, long count) {
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (long)gridDim.x * blockDim.x) x[i] = v;
 }
+// (N, sum widths) row-major <-> its column pieces (N, w_i), each contiguous: the features of the deep-supervision heads
+// (classifiers.py:586-595 torch.cat) and the way back for their gradient.  Tables travel in the kernel arguments.
+constexpr int kMaxPieces = 16;
+struct ColPieces {
+    float* ptr[kMaxPieces];
+    int start[kMaxPieces + 1];
+    int count;
+};
+__global__ void cat_cols_kernel(ColPieces cp, float* __restrict__ full, int rows, int total, int split) {
+    const long n = (long)rows * total;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const int r = (int)(i / total), col = (int)(i - (long)r * total);
+        int k = 0;
+        while (k + 1 < cp.count && col >= cp.start[k + 1]) ++k;
+        float* piece = cp.ptr[k] + (long)r * (cp.start[k + 1] - cp.start[k]) + (col - cp.start[k]);
+        if (split) *piece = full[i]; else full[i] = *piece;
+    }
+}
+
+// num_batches_tracked of every BatchNorm a training forward went through, one launch (torch/nn/modules/batchnorm.py: += 1)
+constexpr int kMaxCounters = 64;
+struct CounterTable {
+    long* ptr[kMaxCounters];
+    int count;
+};
+__global__ void bump_counters_kernel(CounterTable t) {
+    if ((int)threadIdx.x < t.count) *t.ptr[threadIdx.x] += 1;
+}
+
 
 __global__ __launch_bounds__(256) void absmin_kernel(const float* __restrict__ x, long n, float* __restrict__ out) {
     __shared__ float part[4];
@@ -188,6 +217,39 @@ extern "C" {
 int fsc_version(void) { return 100; /* 0.1.0 */ }
 
 const char* fsc_last_error_string(void) { return fsc::g_error; }
+
+int fsc_cat_cols(const float* const* pieces, const int* widths, int count, int rows, float* out, int split, fsc_stream_t stream) {
+    FSC_CHECK_ARG(pieces && widths && out && rows > 0 && count > 0 && count <= kMaxPieces, "fsc_cat_cols: bad arguments");
+    ColPieces cp{};
+    int total = 0;
+    for (int i = 0; i < count; ++i) {
+        FSC_CHECK_ARG(pieces[i] && widths[i] > 0, "fsc_cat_cols: piece %d is empty", i);
+        cp.ptr[i] = const_cast<float*>(pieces[i]);
+        cp.start[i] = total;
+        total += widths[i];
+    }
+    cp.start[count] = total;
+    cp.count = count;
+    const long n = (long)rows * total;
+    hipLaunchKernelGGL(cat_cols_kernel, dim3(grid_for(n)), dim3(256), 0, fsc::as_stream(stream), cp, out, rows, total, split);
+    FSC_LAUNCH_CHECK("fsc_cat_cols");
+    return 0;
+}
+
+int fsc_bump_counters(long* const* counters, int count, fsc_stream_t stream) {
+    FSC_CHECK_ARG(counters && count > 0, "fsc_bump_counters: bad arguments");
+    for (int first = 0; first < count; first += kMaxCounters) {
+        CounterTable t{};
+        t.count = count - first < kMaxCounters ? count - first : kMaxCounters;
+        for (int i = 0; i < t.count; ++i) {
+            FSC_CHECK_ARG(counters[first + i], "fsc_bump_counters: null counter %d", first + i);
+            t.ptr[i] = counters[first + i];
+        }
+        hipLaunchKernelGGL(bump_counters_kernel, dim3(1), dim3(kMaxCounters), 0, fsc::as_stream(stream), t);
+    }
+    FSC_LAUNCH_CHECK("fsc_bump_counters");
+    return 0;
+}
 
 int fsc_absmin(const float* x, long n, float* out, fsc_stream_t stream) {
     FSC_CHECK_ARG(x && out && n > 0, "fsc_absmin: bad arguments");

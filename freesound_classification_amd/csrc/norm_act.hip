@@ -33,10 +33,51 @@ inline Partials carve(void* ws, int c) {
 }
 
 // ---------------------------------------------------------------- statistics
+struct FinalizeArgs {
+    const float* x; int c; long hw; double count; int nsplit; const double* part; const float* gamma; const float* beta;
+    float eps, momentum; float* running_mean; float* running_var; float* save_mean; float* save_invstd; float* scale; float* shift;
+    double* sync; int phase; float* x_minmax; int pivot_rm, minmax_only;
+};
+
+// (s1, s2): the channel's sums of (x - pivot), (x - pivot)^2 over `count` elements (unused in phase 2)
+__device__ __forceinline__ void finalize_channel(const FinalizeArgs& a, int ch, double s1, double s2, double pivot) {
+    double count = a.count;
+    if (a.phase == 2) {
+        s1 = a.sync[ch * 4];
+        s2 = a.sync[ch * 4 + 1];
+        count = a.sync[ch * 4 + 2];
+        pivot = 0.0;
+    } else if (a.phase == 1) {                               // moments about zero: sum (a + p) and sum (a + p)^2
+        a.sync[ch * 4] = s1 + count * pivot;
+        a.sync[ch * 4 + 1] = s2 + 2.0 * pivot * s1 + count * pivot * pivot;
+        a.sync[ch * 4 + 2] = count;
+        a.sync[ch * 4 + 3] = 0.0;
+        return;
+    }
+    const double m1 = s1 / count;
+    const double mean = pivot + m1;
+    double var = s2 / count - m1 * m1;
+    if (var < 0.0) var = 0.0;
+    const double invstd = 1.0 / sqrt(var + (double)a.eps);
+    if (a.running_mean) {
+        const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+        a.running_mean[ch] = (float)((1.0 - a.momentum) * a.running_mean[ch] + a.momentum * mean);
+        a.running_var[ch] = (float)((1.0 - a.momentum) * a.running_var[ch] + a.momentum * unbiased);
+    }
+    a.save_mean[ch] = (float)mean;
+    a.save_invstd[ch] = (float)invstd;
+    const float g = a.gamma ? a.gamma[ch] : 1.f, b = a.beta ? a.beta[ch] : 0.f;
+    const float sc = g * (float)invstd;
+    a.scale[ch] = sc;
+    a.shift[ch] = b - (float)mean * sc;
+}
+
 // Threads are split into (image lane tn, pixel lane ti) with `hwp` = power of two >= min(hw, 256)
 // pixel lanes, so planes smaller than the block still keep every lane busy.
+// With `tickets` the workgroup that finishes a channel last also finalises it (stats_finalize_kernel's arithmetic in the same
+// order; see bwd_partial_kernel): the single-replica statistics pass is one launch.
 __global__ __launch_bounds__(kThreads) void stats_partial_kernel(
-    const float* __restrict__ x, int n, int c, long hw, int nsplit, int hwp_log2, double* __restrict__ part) {
+    const float* __restrict__ x, int n, int c, long hw, int nsplit, int hwp_log2, double* part, FinalizeArgs fa, unsigned* tickets) {
     __shared__ double scratch[kThreads / 64];
     const int ch = blockIdx.x, sp = blockIdx.y;
     const float pivot = x[(long)ch * hw];
@@ -150,14 +191,35 @@ __global__ __launch_bounds__(kThreads) void stats_partial_kernel(
     __shared__ float mm[2][kThreads / 64];
     if ((threadIdx.x & 63) == 0) { mm[0][threadIdx.x >> 6] = mn; mm[1][threadIdx.x >> 6] = mx; }
     __syncthreads();
-    if (threadIdx.x == 0) {
-        double* o = part + ((size_t)ch * kMaxSplit + sp) * kPartStride;
-        o[0] = t1;
-        o[1] = t2;
-        for (int i = 1; i < kThreads / 64; ++i) { mn = fminf(mn, mm[0][i]); mx = fmaxf(mx, mm[1][i]); }
-        o[2] = (double)mn;
-        o[3] = (double)mx;
+    if (threadIdx.x != 0) return;
+    double* o = part + ((size_t)ch * kMaxSplit + sp) * kPartStride;
+    for (int i = 1; i < kThreads / 64; ++i) { mn = fminf(mn, mm[0][i]); mx = fmaxf(mx, mm[1][i]); }
+    const double vals[4] = {t1, t2, (double)mn, (double)mx};
+    if (tickets == nullptr) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o[k] = vals[k];
+        return;
     }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) __hip_atomic_store(o + k, vals[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (atomicAdd(tickets + ch, 1u) != (unsigned)nsplit - 1u) return;
+    tickets[ch] = 0u;
+    double f1 = 0.0, f2 = 0.0;
+    float fmn = INFINITY, fmx = -INFINITY;
+    for (int k = 0; k < nsplit; ++k) {
+        double* q = part + ((size_t)ch * kMaxSplit + k) * kPartStride;
+        f1 += __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        f2 += __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        fmn = fminf(fmn, (float)__hip_atomic_load(q + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        fmx = fmaxf(fmx, (float)__hip_atomic_load(q + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    }
+    if (fa.x_minmax) {
+        fa.x_minmax[2 * ch] = fmn;
+        fa.x_minmax[2 * ch + 1] = fmx;
+    }
+    if (fa.minmax_only) return;
+    finalize_channel(fa, ch, f1, f2, (double)pivot);
 }
 
 // HW == 1: x is (N, C); one thread per channel, coalesced across channels.
@@ -180,45 +242,6 @@ __global__ void stats_rows_kernel(const float* __restrict__ x, int n, int c, dou
     o[1] = s2;
     o[2] = (double)mn;
     o[3] = (double)mx;
-}
-
-struct FinalizeArgs {
-    const float* x; int c; long hw; double count; int nsplit; const double* part; const float* gamma; const float* beta;
-    float eps, momentum; float* running_mean; float* running_var; float* save_mean; float* save_invstd; float* scale; float* shift;
-    double* sync; int phase; float* x_minmax; int pivot_rm, minmax_only;
-};
-
-// (s1, s2): the channel's sums of (x - pivot), (x - pivot)^2 over `count` elements (unused in phase 2)
-__device__ __forceinline__ void finalize_channel(const FinalizeArgs& a, int ch, double s1, double s2, double pivot) {
-    double count = a.count;
-    if (a.phase == 2) {
-        s1 = a.sync[ch * 4];
-        s2 = a.sync[ch * 4 + 1];
-        count = a.sync[ch * 4 + 2];
-        pivot = 0.0;
-    } else if (a.phase == 1) {                               // moments about zero: sum (a + p) and sum (a + p)^2
-        a.sync[ch * 4] = s1 + count * pivot;
-        a.sync[ch * 4 + 1] = s2 + 2.0 * pivot * s1 + count * pivot * pivot;
-        a.sync[ch * 4 + 2] = count;
-        a.sync[ch * 4 + 3] = 0.0;
-        return;
-    }
-    const double m1 = s1 / count;
-    const double mean = pivot + m1;
-    double var = s2 / count - m1 * m1;
-    if (var < 0.0) var = 0.0;
-    const double invstd = 1.0 / sqrt(var + (double)a.eps);
-    if (a.running_mean) {
-        const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
-        a.running_mean[ch] = (float)((1.0 - a.momentum) * a.running_mean[ch] + a.momentum * mean);
-        a.running_var[ch] = (float)((1.0 - a.momentum) * a.running_var[ch] + a.momentum * unbiased);
-    }
-    a.save_mean[ch] = (float)mean;
-    a.save_invstd[ch] = (float)invstd;
-    const float g = a.gamma ? a.gamma[ch] : 1.f, b = a.beta ? a.beta[ch] : 0.f;
-    const float sc = g * (float)invstd;
-    a.scale[ch] = sc;
-    a.shift[ch] = b - (float)mean * sc;
 }
 
 // Cross-replica statistics (SyncBN): `sync` holds per channel [sum x, sum x^2, count, -] about ZERO in
@@ -792,8 +815,17 @@ __device__ __forceinline__ float upstream(const BwdArgs& a, const float* pdy, lo
 }
 
 // partial sums per (channel, split): [0]=sum dz, [1]=sum dz*xhat, [2]=sum dy*min(z,0)
+// With fin.tickets the block that finishes a channel LAST (a ticket counter per channel, left at zero again) also does what
+// bwd_finalize_kernel does for that channel, in the same order of additions: the single-replica backward is two launches, not three.
+struct BwdFinish {
+    unsigned* tickets;      // null: bwd_finalize_kernel follows
+    double count;
+    float* dgamma; float* dbeta; float* dalpha; float* coef; float* dx_chan_sum; float* dx_amax;
+    int want_bound;
+};
+
 __global__ __launch_bounds__(kThreads) void bwd_partial_kernel(BwdArgs a, int nsplit, int hwp_log2,
-                                                               double* __restrict__ part) {
+                                                               double* part, BwdFinish fin) {
     __shared__ double scratch[kThreads / 64];
     const int ch = blockIdx.x, sp = blockIdx.y;
     const float mean = a.mean[ch], invstd = a.invstd[ch];
@@ -910,9 +942,52 @@ __global__ __launch_bounds__(kThreads) void bwd_partial_kernel(BwdArgs a, int ns
     mxh = block_max256(mxh, mred);
     if (threadIdx.x == 0) {
         double* o = part + ((size_t)ch * kMaxSplit + sp) * kPartStride;
-        o[0] = t0; o[1] = t1; o[2] = t2;
-        o[3] = (double)mdz; o[4] = (double)mxh;
+        const double vals[5] = {t0, t1, t2, (double)mdz, (double)mxh};
+        if (fin.tickets) {
+            // device-coherent stores and loads for the five numbers other workgroups (other XCDs: other L2s) read below.  A
+            // __threadfence() here instead writes back and invalidates the XCD's whole L2 once per workgroup: the pass took twice
+            // as long (2.6 -> 5.3 ms per step).
+#pragma unroll
+            for (int k = 0; k < 5; ++k) __hip_atomic_store(o + k, vals[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 5; ++k) o[k] = vals[k];
+        }
     }
+    if (fin.tickets == nullptr) return;
+    if (fin.dx_amax && !fin.want_bound && ch == 0 && sp == 0)          // (the L16 apply pass stores the bound itself)
+        for (int i = threadIdx.x; i < fsc::kAmaxFloats; i += kThreads) fin.dx_amax[i] = 0.f;
+    __shared__ int last_s;
+    __shared__ double fold_s[kMaxSplit][5];
+    if (threadIdx.x == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // the stores above have been acknowledged: now the ticket
+        last_s = atomicAdd(fin.tickets + ch, 1u) == (unsigned)nsplit - 1u;
+    }
+    __syncthreads();
+    if (!last_s) return;
+    if ((int)threadIdx.x < nsplit) {
+        double* p = part + ((size_t)ch * kMaxSplit + threadIdx.x) * kPartStride;
+#pragma unroll
+        for (int k = 0; k < 5; ++k) fold_s[threadIdx.x][k] = __hip_atomic_load(p + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    fin.tickets[ch] = 0u;
+    double f0 = 0.0, f1 = 0.0, f2 = 0.0;
+    float fdz = 0.f, fxh = 0.f;
+    for (int k = 0; k < nsplit; ++k) {
+        f0 += fold_s[k][0]; f1 += fold_s[k][1]; f2 += fold_s[k][2];
+        fdz = fmaxf(fdz, (float)fold_s[k][3]);
+        fxh = fmaxf(fxh, (float)fold_s[k][4]);
+    }
+    if (fin.dbeta) fin.dbeta[ch] = (float)f0;
+    if (fin.dgamma) fin.dgamma[ch] = (float)f1;
+    if (fin.dalpha) fin.dalpha[ch] = (float)f2;
+    const float c1 = (float)(f0 / fin.count), c2 = (float)(f1 / fin.count);
+    fin.coef[ch * 2] = c1;
+    fin.coef[ch * 2 + 1] = c2;
+    if (fin.dx_chan_sum) fin.dx_chan_sum[ch] = 0.f;
+    if (fin.want_bound) fin.coef[2 * a.c + ch] = fabsf(g * invstd) * (fdz + fabsf(c1) + fxh * fabsf(c2));
 }
 
 // HW == 1 version: thread per channel
@@ -1465,6 +1540,22 @@ size_t fsc_bn_workspace_bytes(int c) {
     return part_doubles(c) * sizeof(double) + (size_t)c * 4 * sizeof(float);
 }
 
+// per-channel ticket counters of the fused finalisations (zero between launches: the last block of a channel resets its own);
+// region 0: backward reduce pass, region 1: statistics pass
+static unsigned* bn_tickets(int c, int region) {
+    constexpr int kRegion = 1 << 16;
+    static unsigned* buf[16] = {};
+    int dev = 0;
+    if (c > kRegion || hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+    if (!buf[dev]) {
+        unsigned* nb = nullptr;
+        if (hipMalloc(&nb, sizeof(unsigned) * 2 * kRegion) != hipSuccess) return nullptr;
+        if (hipMemset(nb, 0, sizeof(unsigned) * 2 * kRegion) != hipSuccess) return nullptr;
+        buf[dev] = nb;
+    }
+    return buf[dev] + region * kRegion;
+}
+
 int fsc_bn_train_stats(const float* x, int n, int c, long hw, const float* gamma, const float* beta, float eps,
                        float momentum, float* running_mean, float* running_var, float* save_mean,
                        float* save_invstd, float* scale, float* shift, void* workspace, double* sync, int phase,
@@ -1488,8 +1579,19 @@ int fsc_bn_train_stats(const float* x, int n, int c, long hw, const float* gamma
             hipLaunchKernelGGL(stats_rows_kernel, dim3(fsc::ceil_div(c, 128)), dim3(128), 0, st, x, n, c, p.part);
         } else {
             nsplit = pick_split(n, c, hw);
+            FinalizeArgs fa{x, c, hw, (double)n * (double)hw, nsplit, p.part, gamma, beta, eps, momentum, running_mean, running_var,
+                            save_mean, save_invstd, scale, shift, sync, phase, x_minmax, pivot_rm, minmax_only};
+            unsigned* tickets = nullptr;
+            if (phase == 0 && !pivot_rm) {
+                tickets = bn_tickets(c, 1);
+                FSC_CHECK_ARG(tickets, "fsc_bn_train_stats: no ticket buffer");
+            }
             hipLaunchKernelGGL(stats_partial_kernel, dim3(c, nsplit), dim3(kThreads), 0, st, x, n, c, hw, nsplit,
-                               hwp_log2_for(hw), p.part);
+                               hwp_log2_for(hw), p.part, fa, tickets);
+            if (tickets) {
+                FSC_LAUNCH_CHECK("fsc_bn_train_stats");
+                return 0;
+            }
         }
     }
     FinalizeArgs fa{x, c, hw, (double)n * (double)hw, nsplit, p.part, gamma, beta, eps, momentum, running_mean, running_var,
@@ -1631,17 +1733,23 @@ int fsc_bn_act_bwd(const float* dy, const float* gmax_dy, const int* gmax_idx, c
     Partials p = carve(workspace, c);
     BwdArgs a{dy, gmax_dy, gmax_idx, x, residual, save_mean, save_invstd, gamma, beta, alpha, n, c, hw};
     const int nsplit = hw == 1 ? 1 : pick_split(n, c, hw);
+    BwdFinish fin{};
+    if (phase == 0 && hw > 1) {
+        fin = BwdFinish{bn_tickets(c, 0), (double)n * (double)hw, dgamma, dbeta, dalpha, p.coef, dx_chan_sum, dx_amax, dx_l16 ? 1 : 0};
+        FSC_CHECK_ARG(fin.tickets, "fsc_bn_act_bwd: no ticket buffer");
+    }
     if (phase != 2) {
         if (hw == 1) {
             FSC_CHECK_ARG(gmax_dy == nullptr, "fsc_bn_act_bwd: global-max gradient needs hw > 1");
             hipLaunchKernelGGL(bwd_rows_kernel, dim3(fsc::ceil_div(c, 128)), dim3(128), 0, st, a, p.part);
         } else {
-            hipLaunchKernelGGL(bwd_partial_kernel, dim3(c, nsplit), dim3(kThreads), 0, st, a, nsplit, hwp_log2_for(hw), p.part);
+            hipLaunchKernelGGL(bwd_partial_kernel, dim3(c, nsplit), dim3(kThreads), 0, st, a, nsplit, hwp_log2_for(hw), p.part, fin);
         }
     }
-    hipLaunchKernelGGL(bwd_finalize_kernel, dim3(fsc::ceil_div(c, 128)), dim3(128), 0, st, c, (double)n * (double)hw,
-                       nsplit, p.part, dgamma, dbeta, dalpha, p.coef, dx_chan_sum, dx_amax, sync, phase, gamma, save_invstd,
-                       dx_l16 ? 1 : 0);
+    if (!fin.tickets)
+        hipLaunchKernelGGL(bwd_finalize_kernel, dim3(fsc::ceil_div(c, 128)), dim3(128), 0, st, c, (double)n * (double)hw,
+                           nsplit, p.part, dgamma, dbeta, dalpha, p.coef, dx_chan_sum, dx_amax, sync, phase, gamma, save_invstd,
+                           dx_l16 ? 1 : 0);
     if (phase == 1) {
         FSC_LAUNCH_CHECK("fsc_bn_act_bwd");
         return 0;
@@ -1690,11 +1798,17 @@ int fsc_bn_act_bwd_unpool(const float* dy, const float* x, const float* save_mea
     Partials p = carve(workspace, c);
     BwdArgs a{dy, nullptr, nullptr, x, nullptr, save_mean, save_invstd, gamma, beta, alpha, n, c, hw};
     const int nsplit = pick_split(n, c, hw);
+    BwdFinish fin{};
+    if (phase == 0) {
+        fin = BwdFinish{bn_tickets(c, 0), (double)n * (double)hw, dgamma, dbeta, dalpha, p.coef, dx_chan_sum, dc_amax, dc_l16 ? 1 : 0};
+        FSC_CHECK_ARG(fin.tickets, "fsc_bn_act_bwd_unpool: no ticket buffer");
+    }
     if (phase != 2)
-        hipLaunchKernelGGL(bwd_partial_kernel, dim3(c, nsplit), dim3(kThreads), 0, st, a, nsplit, hwp_log2_for(hw), p.part);
-    hipLaunchKernelGGL(bwd_finalize_kernel, dim3(fsc::ceil_div(c, 128)), dim3(128), 0, st, c, (double)n * (double)hw,
-                       nsplit, p.part, dgamma, dbeta, dalpha, p.coef, dx_chan_sum, dc_amax, sync, phase, gamma, save_invstd,
-                       dc_l16 ? 1 : 0);
+        hipLaunchKernelGGL(bwd_partial_kernel, dim3(c, nsplit), dim3(kThreads), 0, st, a, nsplit, hwp_log2_for(hw), p.part, fin);
+    if (!fin.tickets)
+        hipLaunchKernelGGL(bwd_finalize_kernel, dim3(fsc::ceil_div(c, 128)), dim3(128), 0, st, c, (double)n * (double)hw,
+                           nsplit, p.part, dgamma, dbeta, dalpha, p.coef, dx_chan_sum, dc_amax, sync, phase, gamma, save_invstd,
+                           dc_l16 ? 1 : 0);
     if (phase == 1) {
         FSC_LAUNCH_CHECK("fsc_bn_act_bwd_unpool");
         return 0;

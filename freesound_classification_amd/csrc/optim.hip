@@ -33,25 +33,50 @@ __device__ __forceinline__ int find_tensor(const Table& tb, int chunk) {
     return i;
 }
 
+__device__ __forceinline__ void adam_one(const AdamHyper& h, float& p, float g, float& m, float& v, float& vmax) {
+    g *= h.grad_scale;
+    if (h.weight_decay != 0.f) g = fmaf(h.weight_decay, p, g);
+    m = m + (1.f - h.beta1) * (g - m);
+    v = fmaf(v, h.beta2, (1.f - h.beta2) * g * g);
+    vmax = fmaxf(vmax, v);
+    const float denom = sqrtf(vmax) * h.inv_bc2_sqrt + h.eps;
+    p = p - h.step_size * (m / denom);
+}
+
 __global__ __launch_bounds__(kThreads) void adam_kernel(Table tb, AdamHyper h) {
     const int ti = find_tensor(tb, blockIdx.x);
     const fsc_opt_tensor t = tb.t[ti];
     const long base = (long)(blockIdx.x - tb.chunk_start[ti]) * kChunk;
     const long end = base + kChunk < t.count ? base + kChunk : t.count;
-    for (long i = base + threadIdx.x; i < end; i += kThreads) {
-        const float p = t.param[i];
-        float g = t.grad[i] * h.grad_scale;
-        if (h.weight_decay != 0.f) g = fmaf(h.weight_decay, p, g);
-        float m = t.state0[i];
-        m = m + (1.f - h.beta1) * (g - m);
-        float v = t.state1[i];
-        v = fmaf(v, h.beta2, (1.f - h.beta2) * g * g);
-        const float vmax = fmaxf(t.state2[i], v);
-        const float denom = sqrtf(vmax) * h.inv_bc2_sqrt + h.eps;
+    long i0 = base;
+    // nine 16-byte streams when the five arrays allow it (a gradient that aliases a bucket of the reducer may sit at any 4-byte
+    // offset); the dword loop below takes the rest
+    const size_t bits = (size_t)t.param | (size_t)t.grad | (size_t)t.state0 | (size_t)t.state1 | (size_t)t.state2;
+    if ((bits & 15) == 0) {
+        const long n4 = (end - base) >> 2;
+        float4* p4 = reinterpret_cast<float4*>(t.param + base);
+        const float4* g4 = reinterpret_cast<const float4*>(t.grad + base);
+        float4* m4 = reinterpret_cast<float4*>(t.state0 + base);
+        float4* v4 = reinterpret_cast<float4*>(t.state1 + base);
+        float4* x4 = reinterpret_cast<float4*>(t.state2 + base);
+        for (long i = threadIdx.x; i < n4; i += kThreads) {
+            float4 p = p4[i], m = m4[i], v = v4[i], x = x4[i];
+            const float4 g = g4[i];
+            adam_one(h, p.x, g.x, m.x, v.x, x.x);
+            adam_one(h, p.y, g.y, m.y, v.y, x.y);
+            adam_one(h, p.z, g.z, m.z, v.z, x.z);
+            adam_one(h, p.w, g.w, m.w, v.w, x.w);
+            m4[i] = m; v4[i] = v; x4[i] = x; p4[i] = p;
+        }
+        i0 = base + 4 * n4;
+    }
+    for (long i = i0 + threadIdx.x; i < end; i += kThreads) {
+        float p = t.param[i], m = t.state0[i], v = t.state1[i], vmax = t.state2[i];
+        adam_one(h, p, t.grad[i], m, v, vmax);
         t.state0[i] = m;
         t.state1[i] = v;
         t.state2[i] = vmax;
-        t.param[i] = p - h.step_size * (m / denom);
+        t.param[i] = p;
     }
 }
 

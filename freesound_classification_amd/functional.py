@@ -836,8 +836,9 @@ def bn_prepare(x, bn, training, sync=None, defer=None, want_minmax=False):
         track = training and bn.track_running_stats and bn.running_mean is not None
         momentum = 0.1 if bn.momentum is None else bn.momentum
         if track:
-            if defer is not None and bn.momentum is not None:
-                defer.append(bn.num_batches_tracked)       # (the caller bumps the counters of a block in one launch)
+            if bn.momentum is not None and (defer is not None or _COUNTER_SINK is not None):
+                # (bumped later: by the caller for its block, or by counters_flush for the whole forward, in one launch)
+                (defer if defer is not None else _COUNTER_SINK).append(bn.num_batches_tracked)
             else:
                 bn.num_batches_tracked.add_(1)
             if bn.momentum is None:
@@ -1244,7 +1245,10 @@ def _block_forward(x, mods, training, want_head, ph, keep, sync=None, next_bn=Fa
         k.l16 = (a_16, b_16, s1_16, s2_16)
         k.packs = packs                    # [conv_a, conv1, conv2, conv3]
     if counters:
-        torch._foreach_add_(counters, 1)
+        if _COUNTER_SINK is not None:
+            _COUNTER_SINK.extend(counters)
+        else:
+            torch._foreach_add_(counters, 1)
     return out, feat, k
 
 
@@ -1514,6 +1518,59 @@ class BNActFn(torch.autograd.Function):
         alpha = ctx.prelu.weight if ctx.prelu is not None else None
         dx, _, dg, db, dal, _ = bn_act_backward(dy.contiguous(), x, st, ctx.bn, alpha, sync=ctx.sync)
         return dx, None, None, None, None, dg, db, dal
+
+
+_COUNTER_SINK = None       # num_batches_tracked tensors of the BatchNorms a training forward has gone through so far
+
+
+def counters_begin():
+    """From here on the training-mode BatchNorms only note their num_batches_tracked; counters_flush() adds 1 to all of them
+    in one launch (torch/nn/modules/batchnorm.py bumps each in its own forward: same values once the forward is over)."""
+    global _COUNTER_SINK
+    _COUNTER_SINK = []
+
+
+def counters_flush():
+    global _COUNTER_SINK
+    sink, _COUNTER_SINK = _COUNTER_SINK, None
+    if sink:
+        table = (C.c_void_p * len(sink))(*[t.data_ptr() for t in sink])
+        call("fsc_bump_counters", table, len(sink), stream_ptr())
+
+
+def _cat_cols(pieces, widths, rows, full, split):
+    table = (C.c_void_p * len(pieces))(*[t.data_ptr() for t in pieces])
+    wtab = (C.c_int * len(pieces))(*widths)
+    call("fsc_cat_cols", table, wtab, len(pieces), rows, ptr(full), split, stream_ptr())
+
+
+class CatColsFn(torch.autograd.Function):
+    """torch.cat(pieces, -1) of 2-d fp32 tensors (classifiers.py:595: the deep-supervision features) and its way back, one
+    launch each."""
+
+    @staticmethod
+    def forward(ctx, *pieces):
+        pieces = [t.contiguous() for t in pieces]
+        rows, widths = pieces[0].shape[0], [int(t.shape[1]) for t in pieces]
+        out = _empty((rows, sum(widths)), pieces[0])
+        _cat_cols(pieces, widths, rows, out, 0)
+        ctx.widths = widths
+        return out
+
+    @staticmethod
+    def backward(ctx, d):
+        d = d.contiguous()
+        outs = [_empty((d.shape[0], w), d) for w in ctx.widths]
+        _cat_cols(outs, ctx.widths, d.shape[0], d, 1)
+        return tuple(outs)
+
+
+def cat_features(feats):
+    if len(feats) == 1:
+        return feats[0]
+    if len(feats) > 16 or any(t.dim() != 2 or t.dtype != torch.float32 for t in feats):
+        return torch.cat(feats, -1)
+    return CatColsFn.apply(*feats)
 
 
 def bn_act(x, bn, prelu, training, sync=None):

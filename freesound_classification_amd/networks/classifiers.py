@@ -178,9 +178,12 @@ class _TaggingModel(nn.Module):
         token = None
         if self.training and torch.is_grad_enabled():
             token = F.prepack_begin((id(self), tuple(h.shape)))     # all L16 weight fragments of the step in a few launches
+        if self.training:
+            F.counters_begin()                                       # every BatchNorm's num_batches_tracked in one launch
         try:
             return self._forward_blocks(h)
         finally:
+            F.counters_flush()
             F.prepack_end(token)
 
     def _forward_blocks(self, h):
@@ -196,7 +199,7 @@ class _TaggingModel(nn.Module):
                 feat = F.rnn_head(h, self.rnns[k - start])
             if feat is not None:
                 feats.append(feat)
-        feats = torch.cat(feats, -1)
+        feats = F.cat_features(feats)
         ot = self.output_transform
         z = F.bn_act(feats, ot[0], None, self.training, self._bn_sync)
         z = F.linear(z, ot[1].weight, ot[1].bias)

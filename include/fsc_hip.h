@@ -447,6 +447,11 @@ int fsc_sgd_nesterov_step(const fsc_opt_tensor* tensors_host, int n_tensors, flo
 int fsc_plane_border_sums(const float* x, int n, int c, int h, int w, float* out, fsc_stream_t stream);
 /* out[0] = min |x[i]| over n >= 1 floats (one small launch: the guard of a division by a parameter vector) */
 int fsc_absmin(const float* x, long n, float* out, fsc_stream_t stream);
+/* split = 0: out (rows, sum widths) = the `count` <= 16 column pieces (rows, widths[i]) side by side (torch.cat(feats, -1),
+ * classifiers.py:595); split = 1: the pieces from `out` (the gradient's way back).  `pieces` / `widths` are HOST arrays. */
+int fsc_cat_cols(const float* const* pieces, const int* widths, int count, int rows, float* out, int split, fsc_stream_t stream);
+/* *counters[i] += 1 for `count` int64 device scalars (HOST array of device pointers): BatchNorm.num_batches_tracked */
+int fsc_bump_counters(long* const* counters, int count, fsc_stream_t stream);
 int fsc_fill(float* x, float value, long count, fsc_stream_t stream);
 /* y = a*x + y  (used for gradient accumulation / bucket flattening) */
 int fsc_axpy(const float* x, float a, float* y, long count, fsc_stream_t stream);

@@ -516,3 +516,87 @@ def test_training_forward_uses_the_recorded_pack_plan():
         assert (g0[k] - g1[k]).abs().max().item() <= 1e-4 * max(1.0, g0[k].abs().max().item()), k
     model.close()
     assert not any(key[0] == id(model) for key in F._PACK_PLAN)
+
+
+def test_cat_features_equals_torch_cat_both_ways():
+    """fsc_cat_cols (classifiers.py:595 torch.cat(features, -1) and its gradient slices): bit for bit."""
+    torch.manual_seed(5)
+    widths = [100, 150, 225, 337, 506, 759]
+    pieces = [torch.randn(128, w, device=DEV, requires_grad=True) for w in widths]
+    ref = [p.detach().clone().requires_grad_(True) for p in pieces]
+    out, want = F.cat_features(pieces), torch.cat(ref, -1)
+    assert torch.equal(out, want)
+    up = torch.randn_like(want)
+    out.backward(up)
+    want.backward(up)
+    for p, r in zip(pieces, ref):
+        assert p.grad.is_contiguous() and torch.equal(p.grad, r.grad)
+    assert F.cat_features(pieces[:1]) is pieces[0]
+    odd = [torch.randn(3, 1, device=DEV), torch.randn(3, 7, device=DEV)]
+    assert torch.equal(F.cat_features(odd), torch.cat(odd, -1))
+
+
+def test_training_forward_bumps_every_batchnorm_counter_once_in_one_launch():
+    """num_batches_tracked (torch/nn/modules/batchnorm.py: += 1 per training forward) of all BatchNorms: fsc_bump_counters once
+    per forward, no ATen add; an eval forward leaves the counters alone."""
+    torch.manual_seed(6)
+    model = _small_2d(blocks=2, base=64)
+    signal = 0.1 * torch.randn(8, 2 * 44100, 1, device=DEV)
+    bns = [m for m in model.modules() if isinstance(m, (nn.BatchNorm1d, nn.BatchNorm2d))]
+    assert len(bns) >= 10
+    real, seen = F.call, []
+
+    def counting(name, *a):
+        seen.append(name)
+        return real(name, *a)
+
+    try:
+        F.call = counting
+        model.train()
+        for step in (1, 2):
+            seen.clear()
+            model(signal)
+            assert seen.count("fsc_bump_counters") == 1
+            assert all(int(m.num_batches_tracked) == step for m in bns), [int(m.num_batches_tracked) for m in bns]
+        model.eval()
+        seen.clear()
+        with torch.no_grad():
+            model(signal)
+        assert seen.count("fsc_bump_counters") == 0 and all(int(m.num_batches_tracked) == 2 for m in bns)
+    finally:
+        F.call = real
+    assert F._COUNTER_SINK is None
+    model.close()
+
+
+@pytest.mark.parametrize("shape", [(128, 100, 16, 53), (64, 37, 5, 9), (16, 759, 2, 6), (4, 3, 40, 41)])
+def test_bn_backward_with_the_finalisation_fused_into_the_reduce_pass(shape):
+    """Single-replica fsc_bn_act_bwd: the last block of a channel in bwd_partial_kernel finalises it (two launches, not three).
+    Against torch autograd in fp64, repeated calls (the ticket counters must be back at zero), with and without residual."""
+    n, c, h, w = shape
+    torch.manual_seed(7)
+    bn = nn.BatchNorm2d(c).to(DEV)
+    prelu = nn.PReLU(c).to(DEV)
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5)
+        bn.bias.uniform_(-0.5, 0.5)
+        prelu.weight.uniform_(0.1, 0.4)
+    for rep in range(3):
+        x = torch.randn(n, c, h, w, device=DEV) * 2 + 0.3
+        res = torch.randn_like(x) if rep != 1 else None
+        dy = torch.randn_like(x)
+        st = F.bn_prepare(x, bn, True)
+        dx, dres, dg, db, da, _ = F.bn_act_backward(dy, x, st, bn, prelu.weight, residual=res, want_dres=res is not None)
+        xd = x.double().requires_grad_(True)
+        rd = res.double().requires_grad_(True) if res is not None else None
+        g, b, a = (t.detach().double().requires_grad_(True) for t in (bn.weight, bn.bias, prelu.weight))
+        z = torch.nn.functional.batch_norm(xd, None, None, g, b, True, 0.1, bn.eps)
+        if rd is not None:
+            z = z + rd
+        y = torch.nn.functional.prelu(z, a)
+        y.backward(dy.double())
+        for name, got, want in (("dx", dx, xd.grad), ("dgamma", dg, g.grad), ("dbeta", db, b.grad), ("dalpha", da, a.grad)):
+            err = (got.double() - want).abs().max().item()
+            assert err <= 2e-4 * max(1.0, want.abs().max().item()), (name, rep, err)
+        if rd is not None:
+            assert (dres.double() - rd.grad).abs().max().item() <= 1e-5 * max(1.0, rd.grad.abs().max().item())
