@@ -223,13 +223,17 @@ __global__ __launch_bounds__(kThreads) void stats_partial_kernel(
 }
 
 // HW == 1: x is (N, C); one thread per channel, coalesced across channels.
+// blockIdx.y = one of gridDim.y row groups (split `sp` of the partials takes rows sp, sp + gridDim.y, ...): one thread walking all
+// rows of its channel was a chain of 128 loads on 17 workgroups (34 us for 1 MB)
+__host__ __device__ inline int rows_split(int n) { return n >= 64 ? 16 : n >= 16 ? 4 : 1; }
+
 __global__ void stats_rows_kernel(const float* __restrict__ x, int n, int c, double* __restrict__ part) {
     const int ch = blockIdx.x * blockDim.x + threadIdx.x;
     if (ch >= c) return;
     const float pivot = x[ch];
     double s1 = 0.0, s2 = 0.0;
     float mn = pivot, mx = pivot;
-    for (int b = 0; b < n; ++b) {
+    for (int b = blockIdx.y; b < n; b += gridDim.y) {
         const float v = x[(long)b * c + ch];
         const double a = (double)(v - pivot);
         s1 += a;
@@ -237,7 +241,7 @@ __global__ void stats_rows_kernel(const float* __restrict__ x, int n, int c, dou
         mn = fminf(mn, v);
         mx = fmaxf(mx, v);
     }
-    double* o = part + (size_t)ch * kMaxSplit * kPartStride;
+    double* o = part + ((size_t)ch * kMaxSplit + blockIdx.y) * kPartStride;
     o[0] = s1;
     o[1] = s2;
     o[2] = (double)mn;
@@ -373,22 +377,35 @@ __global__ __launch_bounds__(kThreads) void fwd_plane_kernel(
     if (y_amax) fsc::publish_amax(y_amax, mx);
 }
 
-// planes of 2..511 pixels: one wavefront per (n, c) plane, four planes per workgroup
+// Planes of 2..511 pixels: a group of 2^glog <= 64 lanes per (n, c) plane, 64 >> glog consecutive planes per wavefront (a
+// 2 x 6 plane of the last cfg-2 block on a whole wave left 52 lanes idle: 97 k waves for 4.7 MB, 55 us for the backward apply).
+__host__ __device__ inline int group_log2(long hw) {
+    int l = 2;
+    while (l < 6 && (1L << l) < hw) ++l;
+    return l;
+}
+template <typename T>
+__device__ __forceinline__ T group_sum(T v, int glog) {       // sum over the lane's group, valid in every lane of it
+    for (int o = (1 << glog) >> 1; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
 __global__ __launch_bounds__(kThreads) void fwd_wave_kernel(
     const float* __restrict__ x, const float* __restrict__ res, const float* __restrict__ scale,
     const float* __restrict__ shift, const float* __restrict__ alpha, float* __restrict__ y, int c, long hw,
-    long planes, float* y_amax) {
-    long plane = (long)blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6);
+    long planes, float* y_amax, int glog) {
+    const int gsz = 1 << glog;
+    long plane = ((long)blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6)) * (64 >> glog) + ((threadIdx.x & 63) >> glog);
     const long hw_live = plane < planes ? hw : 0;        // (no early exit: publish_amax synchronises the block)
     if (plane >= planes) plane = planes - 1;
-    const int lane = threadIdx.x & 63;
+    const int lane = threadIdx.x & (gsz - 1);
     const int ch = (int)(plane % c);
     const float sc = scale[ch], sh = shift[ch];
     const bool has_alpha = alpha != nullptr;
     const float al = has_alpha ? alpha[ch] : 0.f;
     const long base = plane * hw;
     float mx = 0.f;
-    for (long i = lane; i < hw_live; i += 64) {
+    for (long i = lane; i < hw_live; i += gsz) {
         float z = fmaf(x[base + i], sc, sh);
         if (res) z += res[base + i];
         z = act(z, al, has_alpha);
@@ -439,11 +456,10 @@ struct RecAcc {
         const unsigned long long k = rec_key(z, idx);
         key = k > key ? k : key;
     }
-    // wave-level fold; lane 0 holds the result
-    __device__ __forceinline__ void wave_fold(double& d1, double& d2) {
+    // fold over aligned groups of 2 * top lanes (the whole wave by default); every lane of a group holds the result
+    __device__ __forceinline__ void wave_fold(double& d1, double& d2, int top = 32) {
         d1 = (double)s1; d2 = (double)s2;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
+        for (int o = top; o > 0; o >>= 1) {
             d1 += __shfl_xor(d1, o, 64);
             d2 += __shfl_xor(d2, o, 64);
             mn = fminf(mn, __shfl_xor(mn, o, 64));
@@ -512,10 +528,13 @@ __global__ __launch_bounds__(kThreads) void fwd_plane_rec_kernel(
 __global__ __launch_bounds__(kThreads) void fwd_wave_rec_kernel(
     const float* __restrict__ x, const float* __restrict__ res, const float* __restrict__ scale,
     const float* __restrict__ shift, const float* __restrict__ alpha, float* __restrict__ y, int c, long hw,
-    long planes, PlaneRec* __restrict__ rec) {
-    const long plane = (long)blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6);
-    if (plane >= planes) return;
-    const int lane = threadIdx.x & 63;
+    long planes, PlaneRec* __restrict__ rec, int glog) {
+    const int gsz = 1 << glog;
+    long plane = ((long)blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6)) * (64 >> glog) + ((threadIdx.x & 63) >> glog);
+    const long hw_live = plane < planes ? hw : 0;        // (a dead group of a live wave still takes part in the fold's shuffles)
+    const bool dead = plane >= planes;
+    if (dead) plane = planes - 1;
+    const int lane = threadIdx.x & (gsz - 1);
     const int ch = (int)(plane % c);
     const float sc = scale[ch], sh = shift[ch];
     const bool has_alpha = alpha != nullptr, has_res = res != nullptr;
@@ -523,14 +542,14 @@ __global__ __launch_bounds__(kThreads) void fwd_wave_rec_kernel(
     const long base = plane * hw;
     RecAcc acc;
     acc.init(bn_point(x[(long)ch * hw], has_res ? res[(long)ch * hw] : 0.f, has_res, sc, sh, al, has_alpha));
-    for (long i = lane; i < hw; i += 64) {
+    for (long i = lane; i < hw_live; i += gsz) {
         const float z = bn_point(x[base + i], has_res ? res[base + i] : 0.f, has_res, sc, sh, al, has_alpha);
         y[base + i] = z;
         acc.add(z, (unsigned)i);
     }
     double d1, d2;
-    acc.wave_fold(d1, d2);
-    if (lane == 0) rec[plane] = PlaneRec{d1, d2, acc.mn, acc.mx, acc.key};
+    acc.wave_fold(d1, d2, gsz >> 1);
+    if (lane == 0 && !dead) rec[plane] = PlaneRec{d1, d2, acc.mn, acc.mx, acc.key};
 }
 
 // one workgroup per channel: a thread folds the slices of one image's plane (-> the global max of that plane), the block
@@ -999,7 +1018,7 @@ __global__ void bwd_rows_kernel(BwdArgs a, double* __restrict__ part) {
     const bool has_alpha = a.alpha != nullptr;
     const float al = has_alpha ? a.alpha[ch] : 1.f;
     double s0 = 0.0, s1 = 0.0, s2 = 0.0;
-    for (int nb = 0; nb < a.n; ++nb) {
+    for (int nb = blockIdx.y; nb < a.n; nb += gridDim.y) {
         const long i = (long)nb * a.c + ch;
         const float xh = (a.x[i] - mean) * invstd;
         float z = fmaf(xh, g, b);
@@ -1010,7 +1029,7 @@ __global__ void bwd_rows_kernel(BwdArgs a, double* __restrict__ part) {
         s0 += dz; s1 += (double)dz * xh;
         s2 += (double)up * (neg ? z : 0.f);
     }
-    double* o = part + (size_t)ch * kMaxSplit * kPartStride;
+    double* o = part + ((size_t)ch * kMaxSplit + blockIdx.y) * kPartStride;
     o[0] = s0; o[1] = s1; o[2] = s2; o[3] = 0.0; o[4] = 0.0;
 }
 
@@ -1136,11 +1155,12 @@ __global__ __launch_bounds__(kThreads) void bwd_apply_plane_kernel(BwdArgs a, co
 // ONE atomic (the flat kernel below issued one per element and serialised on C addresses)
 __global__ __launch_bounds__(kThreads) void bwd_apply_wave_kernel(BwdArgs a, const float* __restrict__ coef,
                                                                    float* __restrict__ dx, float* __restrict__ dres,
-                                                                   float* dx_chan_sum, long planes, float* dx_amax) {
-    long plane = (long)blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6);
+                                                                   float* dx_chan_sum, long planes, float* dx_amax, int glog) {
+    const int gsz = 1 << glog;
+    long plane = ((long)blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6)) * (64 >> glog) + ((threadIdx.x & 63) >> glog);
     const long hw_live = plane < planes ? a.hw : 0;      // (no early exit: publish_amax synchronises the block)
     if (plane >= planes) plane = planes - 1;
-    const int lane = threadIdx.x & 63;
+    const int lane = threadIdx.x & (gsz - 1);
     const int ch = (int)(plane % a.c);
     const float mean = a.mean[ch], invstd = a.invstd[ch];
     const float g = a.gamma ? a.gamma[ch] : 1.f, b = a.beta ? a.beta[ch] : 0.f;
@@ -1152,7 +1172,7 @@ __global__ __launch_bounds__(kThreads) void bwd_apply_wave_kernel(BwdArgs a, con
     const float gval = a.gmax_dy ? a.gmax_dy[plane] : 0.f;
     const long gpos = a.gmax_dy ? (long)a.gmax_idx[plane] : -1;
     float acc = 0.f, mx = 0.f;
-    for (long i = lane; i < hw_live; i += 64) {
+    for (long i = lane; i < hw_live; i += gsz) {
         const float xh = (a.x[base + i] - mean) * invstd;
         float z = fmaf(xh, g, b);
         if (a.res) z += a.res[base + i];
@@ -1166,7 +1186,7 @@ __global__ __launch_bounds__(kThreads) void bwd_apply_wave_kernel(BwdArgs a, con
         mx = fmaxf(mx, fabsf(d));
     }
     if (dx_chan_sum) {
-        acc = fsc::wave_sum(acc);
+        acc = group_sum(acc, glog);
         if (lane == 0 && hw_live) atomicAdd(dx_chan_sum + ch, acc);
     }
     if (dx_amax) fsc::publish_amax(dx_amax, mx);
@@ -1576,7 +1596,8 @@ int fsc_bn_train_stats(const float* x, int n, int c, long hw, const float* gamma
     phase &= ~(FSC_BN_STATS_FOLDED | FSC_BN_STATS_PIVOT_RM | FSC_BN_STATS_MINMAX_ONLY);
     if (phase != 2 && !folded) {
         if (hw == 1) {
-            hipLaunchKernelGGL(stats_rows_kernel, dim3(fsc::ceil_div(c, 128)), dim3(128), 0, st, x, n, c, p.part);
+            nsplit = rows_split(n);
+            hipLaunchKernelGGL(stats_rows_kernel, dim3(fsc::ceil_div(c, 128), nsplit), dim3(128), 0, st, x, n, c, p.part);
         } else {
             nsplit = pick_split(n, c, hw);
             FinalizeArgs fa{x, c, hw, (double)n * (double)hw, nsplit, p.part, gamma, beta, eps, momentum, running_mean, running_var,
@@ -1631,8 +1652,9 @@ int fsc_bn_act_fwd_rec(const float* x, const float* residual, const float* scale
         hipLaunchKernelGGL(fwd_plane_rec_kernel, dim3((unsigned)planes, plane_grid_y(hw)), dim3(kThreads), 0, st, x, residual,
                            scale, shift, alpha, y, c, hw, rec);
     } else {
-        hipLaunchKernelGGL(fwd_wave_rec_kernel, dim3((unsigned)((planes + 3) / 4)), dim3(kThreads), 0, st, x, residual, scale,
-                           shift, alpha, y, c, hw, planes, rec);
+        const int glog = group_log2(hw), per = 4 * (64 >> glog);
+        hipLaunchKernelGGL(fwd_wave_rec_kernel, dim3((unsigned)((planes + per - 1) / per)), dim3(kThreads), 0, st, x, residual, scale,
+                           shift, alpha, y, c, hw, planes, rec, glog);
     }
     FSC_LAUNCH_CHECK("fsc_bn_act_fwd_rec");
     return 0;
@@ -1705,8 +1727,9 @@ int fsc_bn_act_fwd(const float* x, const float* residual, const float* scale, co
                            residual, scale, shift, alpha, y, c, hw, y_amax);
     } else if (hw > 1) {
         const long planes = (long)n * c;
-        hipLaunchKernelGGL(fwd_wave_kernel, dim3((unsigned)((planes + 3) / 4)), dim3(kThreads), 0, st, x, residual,
-                           scale, shift, alpha, y, c, hw, planes, y_amax);
+        const int glog = group_log2(hw), per = 4 * (64 >> glog);
+        hipLaunchKernelGGL(fwd_wave_kernel, dim3((unsigned)((planes + per - 1) / per)), dim3(kThreads), 0, st, x, residual,
+                           scale, shift, alpha, y, c, hw, planes, y_amax, glog);
     } else {
         long blocks = (total + 255) / 256;
         if (blocks > 8192) blocks = 8192;
@@ -1732,7 +1755,7 @@ int fsc_bn_act_bwd(const float* dy, const float* gmax_dy, const int* gmax_idx, c
     hipStream_t st = fsc::as_stream(stream);
     Partials p = carve(workspace, c);
     BwdArgs a{dy, gmax_dy, gmax_idx, x, residual, save_mean, save_invstd, gamma, beta, alpha, n, c, hw};
-    const int nsplit = hw == 1 ? 1 : pick_split(n, c, hw);
+    const int nsplit = hw == 1 ? rows_split(n) : pick_split(n, c, hw);
     BwdFinish fin{};
     if (phase == 0 && hw > 1) {
         fin = BwdFinish{bn_tickets(c, 0), (double)n * (double)hw, dgamma, dbeta, dalpha, p.coef, dx_chan_sum, dx_amax, dx_l16 ? 1 : 0};
@@ -1741,7 +1764,7 @@ int fsc_bn_act_bwd(const float* dy, const float* gmax_dy, const int* gmax_idx, c
     if (phase != 2) {
         if (hw == 1) {
             FSC_CHECK_ARG(gmax_dy == nullptr, "fsc_bn_act_bwd: global-max gradient needs hw > 1");
-            hipLaunchKernelGGL(bwd_rows_kernel, dim3(fsc::ceil_div(c, 128)), dim3(128), 0, st, a, p.part);
+            hipLaunchKernelGGL(bwd_rows_kernel, dim3(fsc::ceil_div(c, 128), nsplit), dim3(128), 0, st, a, p.part);
         } else {
             hipLaunchKernelGGL(bwd_partial_kernel, dim3(c, nsplit), dim3(kThreads), 0, st, a, nsplit, hwp_log2_for(hw), p.part, fin);
         }
@@ -1771,8 +1794,9 @@ int fsc_bn_act_bwd(const float* dy, const float* gmax_dy, const int* gmax_idx, c
                            st, a, p.coef, dx, dresidual, dx_chan_sum, dx_amax);
     } else if (hw > 1) {
         const long planes = (long)n * c;
-        hipLaunchKernelGGL(bwd_apply_wave_kernel, dim3((unsigned)((planes + 3) / 4)), dim3(kThreads), 0, st, a, p.coef,
-                           dx, dresidual, dx_chan_sum, planes, dx_amax);
+        const int glog = group_log2(hw), per = 4 * (64 >> glog);
+        hipLaunchKernelGGL(bwd_apply_wave_kernel, dim3((unsigned)((planes + per - 1) / per)), dim3(kThreads), 0, st, a, p.coef,
+                           dx, dresidual, dx_chan_sum, planes, dx_amax, glog);
     } else {
         long blocks = (total + 255) / 256;
         if (blocks > 8192) blocks = 8192;
