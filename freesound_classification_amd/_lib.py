@@ -146,7 +146,15 @@ def exported_symbols():
     return sorted(SIGNATURES)
 
 
+_get_device = torch._C._cuda_getDevice if hasattr(torch._C, "_cuda_getDevice") else torch.cuda.current_device
+_get_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def stream_ptr():
+    """Raw handle of torch's current stream on the current device.  (torch.cuda.current_stream() builds a Stream object through
+    three Python layers: 8.5 us a call, 3.6 ms of a 12.8 ms launch-bound cfg-3 step.)"""
+    if _get_raw_stream is not None:
+        return _get_raw_stream(_get_device())
     return torch.cuda.current_stream().cuda_stream
 
 
@@ -159,7 +167,7 @@ def ptr(t):
                        "path has no CPU fallback." % t.device)
     if not t.is_contiguous():
         raise FscError("non-contiguous tensor passed to a libfsc_hip kernel")
-    if t.device.index is not None and t.device.index != torch.cuda.current_device():
+    if t.device.index is not None and t.device.index != _get_device():
         # kernels are launched on the CURRENT device's stream (stream_ptr): a tensor of another GPU would be read through
         # peer access or fault.  Callers select the device first (torch.cuda.set_device / `with torch.cuda.device(...)`).
         raise FscError("tensor on %s passed to a libfsc_hip kernel while the current device is cuda:%d"

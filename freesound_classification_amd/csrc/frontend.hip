@@ -71,6 +71,14 @@ __global__ __launch_bounds__(kThreads) void frontend_kernel(FrontendArgs a) {
     const float* win = a.tables;
     const float2* tw_g = reinterpret_cast<const float2*>(a.tables + n_fft);
     for (int i = tid; i < n_fft; i += kThreads) tw[i] = tw_g[i];
+    __syncthreads();
+    // a frame's buffers belong to its `tpf` threads: with one wavefront per frame (n_fft <= 256) the passes of a frame are
+    // ordered by the wave's own LDS queue and need no workgroup barrier (seven per frame otherwise)
+    const bool wave_frames = tpf == 64;
+    auto frame_sync = [&]() {
+        if (wave_frames) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier(); }
+        else __syncthreads();
+    };
 
     const float* wav = a.wave + (long)clip * a.wave_stride;
     const int t = a.t;
@@ -90,7 +98,7 @@ __global__ __launch_bounds__(kThreads) void frontend_kernel(FrontendArgs a) {
                 buf0[j] = make_float2(wav[i0] * win[2 * j], wav[i1] * win[2 * j + 1]);
             }
         }
-        __syncthreads();
+        frame_sync();
         // ---- Stockham FFT of nc complex points
         float2* src = buf0;
         float2* dst = buf1;
@@ -117,7 +125,7 @@ __global__ __launch_bounds__(kThreads) void frontend_kernel(FrontendArgs a) {
                     dst[j + 3 * p] = make_float2(v1.x - v3.x, v1.y - v3.y);
                 }
             }
-            __syncthreads();
+            frame_sync();
             float2* tmp = src; src = dst; dst = tmp;
             p <<= 2;
         }
@@ -134,7 +142,7 @@ __global__ __launch_bounds__(kThreads) void frontend_kernel(FrontendArgs a) {
                     dst[j + p] = make_float2(u0.x - u1.x, u0.y - u1.y);
                 }
             }
-            __syncthreads();
+            frame_sync();
             float2* tmp = src; src = dst; dst = tmp;
         }
         // ---- unpack to the one-sided spectrum of the real frame, magnitude -> dst (as floats)
@@ -151,7 +159,7 @@ __global__ __launch_bounds__(kThreads) void frontend_kernel(FrontendArgs a) {
                 mag[k] = sqrtf(re * re + im * im);
             }
         }
-        __syncthreads();
+        frame_sync();
         if (live) {
             if (MEL) {
                 // the band of a high mel bin is ~90 spectrum bins long: four independent partial sums keep four
@@ -178,8 +186,9 @@ __global__ __launch_bounds__(kThreads) void frontend_kernel(FrontendArgs a) {
                     tile[k * tile_ld + fl] = a.apply_log ? logf(mag[k] + a.log_eps) : mag[k];
             }
         }
-        __syncthreads();
+        frame_sync();
     }
+    __syncthreads();
     // ---- coalesced store of the tile: rows = features, contiguous along frames
     const int fvalid = min(a.fg, a.frames - f_base);
     float* dst_g = a.out + (long)clip * a.out_n_stride;
