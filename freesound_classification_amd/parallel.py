@@ -117,11 +117,11 @@ class BucketedGradReducer:
         cur, cur_elems = [], 0
         limit = max(1, bucket_bytes // 4)
         for p in order:
-            if cur and cur_elems + p.numel() > limit:
+            if cur and cur_elems + self._slot(p) > limit:
                 self._close(cur)
                 cur, cur_elems = [], 0
             cur.append(p)
-            cur_elems += p.numel()
+            cur_elems += self._slot(p)
         if cur:
             self._close(cur)
         self._sync = False
@@ -130,14 +130,20 @@ class BucketedGradReducer:
         self._by_ptr = {p.data_ptr(): p for p in self.params}
         self.in_place = 0          # gradients that arrived already inside their bucket (grad_view), since prepare()
 
+    @staticmethod
+    def _slot(p):
+        """Elements a parameter occupies in its bucket: rounded up to 16 bytes, so that every gradient view starts on a 16-byte
+        boundary (the optimizer and the reduce kernels take their 16-byte paths on gradients that alias a bucket; the pad stays 0)."""
+        return (p.numel() + 3) // 4 * 4
+
     def _close(self, plist):
-        total = sum(p.numel() for p in plist)
+        total = sum(self._slot(p) for p in plist)
         flat = torch.zeros(total, device=plist[0].device, dtype=plist[0].dtype)
         items, off = [], 0
         for p in plist:
             items.append((p, off, p.numel()))
             self._where[id(p)] = (len(self.buckets), off)
-            off += p.numel()
+            off += self._slot(p)
         self.buckets.append(dict(flat=flat, items=items, pending=len(items), handle=None, launched=False, copy_dst=[], copy_src=[]))
 
     def bucket_sizes(self):
