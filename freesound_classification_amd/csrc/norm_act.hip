@@ -1561,7 +1561,8 @@ size_t fsc_bn_workspace_bytes(int c) {
 }
 
 // per-channel ticket counters of the fused finalisations (zero between launches: the last block of a channel resets its own);
-// region 0: backward reduce pass, region 1: statistics pass
+// region 0: backward reduce pass, region 1: statistics pass.  nullptr (more than 65 536 channels, no memory): the callers launch the
+// separate finalisation kernel instead
 static unsigned* bn_tickets(int c, int region) {
     constexpr int kRegion = 1 << 16;
     static unsigned* buf[16] = {};
@@ -1605,7 +1606,6 @@ int fsc_bn_train_stats(const float* x, int n, int c, long hw, const float* gamma
             unsigned* tickets = nullptr;
             if (phase == 0 && !pivot_rm) {
                 tickets = bn_tickets(c, 1);
-                FSC_CHECK_ARG(tickets, "fsc_bn_train_stats: no ticket buffer");
             }
             hipLaunchKernelGGL(stats_partial_kernel, dim3(c, nsplit), dim3(kThreads), 0, st, x, n, c, hw, nsplit,
                                hwp_log2_for(hw), p.part, fa, tickets);
@@ -1759,7 +1759,6 @@ int fsc_bn_act_bwd(const float* dy, const float* gmax_dy, const int* gmax_idx, c
     BwdFinish fin{};
     if (phase == 0 && hw > 1) {
         fin = BwdFinish{bn_tickets(c, 0), (double)n * (double)hw, dgamma, dbeta, dalpha, p.coef, dx_chan_sum, dx_amax, dx_l16 ? 1 : 0};
-        FSC_CHECK_ARG(fin.tickets, "fsc_bn_act_bwd: no ticket buffer");
     }
     if (phase != 2) {
         if (hw == 1) {
@@ -1825,7 +1824,6 @@ int fsc_bn_act_bwd_unpool(const float* dy, const float* x, const float* save_mea
     BwdFinish fin{};
     if (phase == 0) {
         fin = BwdFinish{bn_tickets(c, 0), (double)n * (double)hw, dgamma, dbeta, dalpha, p.coef, dx_chan_sum, dc_amax, dc_l16 ? 1 : 0};
-        FSC_CHECK_ARG(fin.tickets, "fsc_bn_act_bwd_unpool: no ticket buffer");
     }
     if (phase != 2)
         hipLaunchKernelGGL(bwd_partial_kernel, dim3(c, nsplit), dim3(kThreads), 0, st, a, nsplit, hwp_log2_for(hw), p.part, fin);
