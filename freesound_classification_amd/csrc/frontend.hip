@@ -49,6 +49,7 @@ struct FrontendArgs {
     int freq_channel;
     int fg;        // frames per workgroup
     int tpf;       // threads per frame (power of two, 64..256)
+    int block_sync;   // FSC_FE_BLOCK_SYNC: workgroup barriers between the passes of a frame even with one wave per frame (debugging)
 };
 
 // MEL = true: banded mel projection + log.  MEL = false: (log) magnitude of every bin.
@@ -74,7 +75,7 @@ __global__ __launch_bounds__(kThreads) void frontend_kernel(FrontendArgs a) {
     __syncthreads();
     // a frame's buffers belong to its `tpf` threads: with one wavefront per frame (n_fft <= 256) the passes of a frame are
     // ordered by the wave's own LDS queue and need no workgroup barrier (seven per frame otherwise)
-    const bool wave_frames = tpf == 64;
+    const bool wave_frames = tpf == 64 && !a.block_sync;
     auto frame_sync = [&]() {
         if (wave_frames) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier(); }
         else __syncthreads();
@@ -474,6 +475,7 @@ int launch(const FrontendArgs& base, bool mel, int n, hipStream_t stream) {
     if (tpf < 64) tpf = 64;
     if (tpf > kThreads) tpf = kThreads;
     a.tpf = tpf;
+    a.block_sync = getenv("FSC_FE_BLOCK_SYNC") ? 1 : 0;
     const int fpb = kThreads / tpf;
     int fg = 32;
     auto lds_bytes = [&](int g) {

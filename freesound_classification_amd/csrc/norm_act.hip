@@ -1565,6 +1565,8 @@ size_t fsc_bn_workspace_bytes(int c) {
 // separate finalisation kernel instead
 static unsigned* bn_tickets(int c, int region) {
     constexpr int kRegion = 1 << 16;
+    static const bool off = getenv("FSC_BN_NO_TICKETS") != nullptr;      // the separate finalisation launches (debugging)
+    if (off) return nullptr;
     static unsigned* buf[16] = {};
     int dev = 0;
     if (c > kRegion || hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
