@@ -368,8 +368,12 @@ _EVAL_PACKS = {}
 _PLAN_SIG = {}
 
 
+_EVAL_BN = {}
+
+
 def forget_packed_weights():
     _EVAL_PACKS.clear()
+    _EVAL_BN.clear()
 
 
 def _l16_plan_sig(d):
@@ -831,6 +835,8 @@ def bn_prepare(x, bn, training, sync=None, defer=None, want_minmax=False):
     st.minmax = None
     gamma, beta = bn.weight, bn.bias
     if training or bn.running_mean is None:
+        if _EVAL_BN:
+            _EVAL_BN.clear()                                # (running statistics are about to move under raw pointers)
         st.mean = _empty((c,), x)
         st.invstd = _empty((c,), x)
         track = training and bn.track_running_stats and bn.running_mean is not None
@@ -871,8 +877,22 @@ def bn_prepare(x, bn, training, sync=None, defer=None, want_minmax=False):
     else:
         st.mean = None
         st.invstd = None
-        call("fsc_bn_eval_prepare", c, ptr(gamma), ptr(beta), ptr(bn.running_mean), ptr(bn.running_var),
-             bn.eps, ptr(st.scale), ptr(st.shift), stream_ptr())
+        # the folded scale / shift of an eval-mode BatchNorm are reused across batches (keyed like the packed weights: addresses
+        # and versions; a training forward or an optimizer step of this library drops the cache)
+        key = None
+        if not torch.is_grad_enabled():
+            key = tuple((t.data_ptr(), t._version) if t is not None else None
+                        for t in (gamma, beta, bn.running_mean, bn.running_var)) + (bn.eps,)
+            hit = _EVAL_BN.get(key)
+        if key is not None and hit is not None:
+            st.scale, st.shift = hit[0], hit[1]
+        else:
+            call("fsc_bn_eval_prepare", c, ptr(gamma), ptr(beta), ptr(bn.running_mean), ptr(bn.running_var),
+                 bn.eps, ptr(st.scale), ptr(st.shift), stream_ptr())
+            if key is not None:
+                if len(_EVAL_BN) > 4096:
+                    _EVAL_BN.clear()
+                _EVAL_BN[key] = (st.scale, st.shift, bn)          # (the module is kept alive: its addresses cannot be reused)
         pre = _take_prestats(x)
         if pre is not None and (pre[1] & _STATS_CONV_REC):
             pre = (_fold_conv_records(pre[0], x), pre[1] & ~_STATS_CONV_REC) if (want_minmax and EVAL_L16 and hw > 1) else None

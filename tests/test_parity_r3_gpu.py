@@ -600,3 +600,39 @@ def test_bn_backward_with_the_finalisation_fused_into_the_reduce_pass(shape):
             assert err <= 2e-4 * max(1.0, want.abs().max().item()), (name, rep, err)
         if rd is not None:
             assert (dres.double() - rd.grad).abs().max().item() <= 1e-5 * max(1.0, rd.grad.abs().max().item())
+
+
+def test_eval_batchnorm_scale_shift_are_cached_and_invalidated():
+    """Inference: fsc_bn_eval_prepare runs once per BatchNorm, not once per batch; parameter / statistics updates (version bumps,
+    this library's optimizer step, a training forward) drop the cached scale / shift."""
+    torch.manual_seed(8)
+    model = _small_2d(blocks=2, base=64)
+    signal = 0.1 * torch.randn(8, 2 * 44100, 1, device=DEV)
+    model.train()
+    model(signal)                                             # running statistics away from their initial values
+    model.eval()
+    real, seen = F.call, []
+
+    def counting(name, *a):
+        seen.append(name)
+        return real(name, *a)
+
+    try:
+        F.call = counting
+        with torch.no_grad():
+            first = model(signal)["class_logits"].clone()
+            n_first = seen.count("fsc_bn_eval_prepare")
+            seen.clear()
+            second = model(signal)["class_logits"].clone()
+            assert n_first >= 10 and seen.count("fsc_bn_eval_prepare") == 0
+            assert torch.equal(first, second)
+            bn = next(m for m in model.modules() if isinstance(m, nn.BatchNorm2d))
+            bn.running_mean.add_(0.5)                         # (an in-place torch op: the version moves)
+            seen.clear()
+            third = model(signal)["class_logits"]
+            assert seen.count("fsc_bn_eval_prepare") == 1 and not torch.equal(first, third)
+        F.forget_packed_weights()
+        assert not F._EVAL_BN
+    finally:
+        F.call = real
+    model.close()
