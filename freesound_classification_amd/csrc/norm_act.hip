@@ -649,6 +649,7 @@ __global__ __launch_bounds__(kThreads) void stats_fold_finalize_kernel(FinalizeA
         for (int i = 1; i < kThreads / 64; ++i) { mn = fminf(mn, mm[0][i]); mx = fmaxf(mx, mm[1][i]); }
         if (a.x_minmax) { a.x_minmax[2 * ch] = mn; a.x_minmax[2 * ch + 1] = mx; }
     }
+    if (a.minmax_only) return;
     double pivot = a.running_mean ? (double)a.running_mean[ch] : 0.0;
     const double m1 = t1 / a.count, var = t2 / a.count - m1 * m1;
     if (!(var > 0.0) || m1 * m1 > kGateSigmas * kGateSigmas * var) {      // (workgroup-uniform: see stats_finalize_gated_kernel)
@@ -1688,12 +1689,16 @@ int fsc_bn_train_stats_conv(const void* records, int workers, int blocks, int co
                             const float* gamma, const float* beta, float eps, float momentum, float* running_mean,
                             float* running_var, float* save_mean, float* save_invstd, float* scale, float* shift, float* x_minmax,
                             fsc_stream_t stream) {
-    FSC_CHECK_ARG(records && x && save_mean && save_invstd && scale && shift, "fsc_bn_train_stats_conv: null pointer");
+    // save_mean == NULL: only the per-channel min / max of the records (inference: the BatchNorm runs on its running statistics,
+    // the L16 producer still needs the range of x)
+    const int minmax_only = save_mean == nullptr ? 1 : 0;
+    FSC_CHECK_ARG(records && x && (minmax_only ? x_minmax != nullptr : (save_invstd && scale && shift)),
+                  "fsc_bn_train_stats_conv: null pointer");
     FSC_CHECK_ARG(workers > 0 && blocks > 0 && co_blk > 0 && workers % blocks == 0 && c > 0 && c <= blocks * co_blk && n > 0 && hw > 1,
                   "fsc_bn_train_stats_conv: bad arguments");
     FSC_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr), "fsc_bn_train_stats_conv: running stats must come in pairs");
     FinalizeArgs fa{x, c, hw, (double)n * (double)hw, 1, nullptr, gamma, beta, eps, momentum, running_mean, running_var,
-                    save_mean, save_invstd, scale, shift, nullptr, 0, x_minmax, 1, 0};
+                    save_mean, save_invstd, scale, shift, nullptr, 0, x_minmax, 1, minmax_only};
     hipLaunchKernelGGL(stats_fold_finalize_kernel, dim3(c), dim3(kThreads), 0, fsc::as_stream(stream), fa, n,
                        reinterpret_cast<const float4*>(records), workers, blocks, co_blk, order);
     FSC_LAUNCH_CHECK("fsc_bn_train_stats_conv");

@@ -895,7 +895,13 @@ def bn_prepare(x, bn, training, sync=None, defer=None, want_minmax=False):
                 _EVAL_BN[key] = (st.scale, st.shift, bn)          # (the module is kept alive: its addresses cannot be reused)
         pre = _take_prestats(x)
         if pre is not None and (pre[1] & _STATS_CONV_REC):
-            pre = (_fold_conv_records(pre[0], x), pre[1] & ~_STATS_CONV_REC) if (want_minmax and EVAL_L16 and hw > 1) else None
+            if want_minmax and EVAL_L16 and hw > 1:          # min / max straight from the conv epilogue's records, one launch
+                rec, lay, _c = pre[0]
+                st.minmax = _empty((2 * c,), x)
+                call("fsc_bn_train_stats_conv", ptr(rec), lay[0], lay[1], lay[2], lay[3], ptr(x), n, c, hw, None, None, bn.eps, 0.0,
+                     None, None, None, None, None, None, ptr(st.minmax), stream_ptr())
+                return st
+            pre = None
         if want_minmax and EVAL_L16 and hw > 1:
             # inference on the L16 kernels: the producer that writes the conv operand needs the range of x up front -- from the
             # records of the kernel that wrote x, else from one reduction pass

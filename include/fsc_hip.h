@@ -266,7 +266,8 @@ int fsc_bn_records_fold_conv(const void* records, int workers, int blocks, int c
                              void* stats_workspace, fsc_stream_t stream);
 /* fsc_bn_records_fold_conv + fsc_bn_train_stats(phase 0 | FSC_BN_STATS_FOLDED | FSC_BN_STATS_PIVOT_RM) in ONE launch (single replica,
  * training): the workgroup of a channel folds the records of the STATS convolution that wrote x and finalises (pivot = running_mean
- * as it is before this call, 0 when NULL; the far-pivot re-reduction included).  No workspace. */
+ * as it is before this call, 0 when NULL; the far-pivot re-reduction included).  No workspace.  save_mean == NULL: only x_minmax is written (inference: the
+ * BatchNorm runs on its running statistics, the L16 producer still needs the range of x). */
 int fsc_bn_train_stats_conv(const void* records, int workers, int blocks, int co_blk, int order, const float* x, int n, int c, long hw,
                             const float* gamma, const float* beta, float eps, float momentum, float* running_mean,
                             float* running_var, float* save_mean, float* save_invstd, float* scale, float* shift, float* x_minmax,
