@@ -79,6 +79,8 @@ SIGNATURES = {
     "fsc_conv_l16_wgrad": (_I, [_D, _P, _P, _P, _P, _P, _P, _P]),
     "fsc_conv_l16_wgrad_plan_describe": (_I, [_D, C.c_char_p, _SZ]),
     "fsc_bn_workspace_bytes": (_SZ, [_I]),
+    "fsc_bn_workspace_ticket_offset": (_SZ, [_I]),
+    "fsc_bn_workspace_reset": (_I, [_P, _I, _P]),
     "fsc_bn_train_stats": (_I, [_P, _I, _I, _L, _P, _P, _F, _F, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P]),
     "fsc_bn_eval_prepare": (_I, [_I, _P, _P, _P, _P, _F, _P, _P, _P]),
     "fsc_conv_l16_stats_layout": (_I, [_D, _I, _P]),

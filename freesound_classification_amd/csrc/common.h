@@ -13,6 +13,13 @@ int l16_fwd_clock(double* shader_mhz);      // conv_l16.hip: shader clock of the
 
 inline hipStream_t as_stream(fsc_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 
+// Development switches (FSC_* environment variables), read ONCE when the first entry point needs them -- never on the per-call path.
+struct EnvFlags {
+    bool no_l16, no_l16_pool, no_l16_wgrad, l16_no_xcd, l16_vec1, dbg_noksplit, frontend_generic, fe_block_sync, l16_v1;
+    int l16_cot, l16_pt, l16w_tw;        // 0 = not forced
+};
+const EnvFlags& env();                   // misc.hip
+
 #define FSC_CHECK_ARG(cond, ...)            \
     do {                                    \
         if (!(cond)) {                      \

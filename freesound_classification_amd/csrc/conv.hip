@@ -2123,7 +2123,7 @@ bool plan_fwd_x3_pt(const fsc_conv_desc& d_in, int dgrad, int nprod, int pt, int
     {
         const long wgs = p.grid_x * p.co_blocks;
         const int nchunks = g.x_nfull + (g.x_tail_oct ? 1 : 0);
-        if (wgs < 200 && !getenv("FSC_DBG_NOKSPLIT")) {
+        if (wgs < 200 && !fsc::env().dbg_noksplit) {
             long ks = (384 + wgs - 1) / wgs;
             if (ks > 8) ks = 8;
             if (ks > nchunks / 2) ks = nchunks / 2;

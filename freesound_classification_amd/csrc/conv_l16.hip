@@ -901,9 +901,9 @@ bool plan_l16_pt(const fsc_conv_desc& d_in, int dgrad, int pt, int max_cot, LPla
     const int tiles = fsc::ceil_div(g.cout, 16);
     int best_cot = 1, best_blocks = tiles;
     long best_cost = -1;
-    const char* force_cot = getenv("FSC_L16_COT");          // development: force the channel tiles per workgroup
+    const int force_cot = fsc::env().l16_cot;               // development (FSC_L16_COT): force the channel tiles per workgroup
     for (int cot = 1; cot <= max_cot; ++cot) {
-        if (force_cot && cot != atoi(force_cot)) continue;
+        if (force_cot && cot != force_cot) continue;
         const int blocks = fsc::ceil_div(tiles, cot);
         const long cost = (long)blocks * (cot * 3 + 4);
         if (best_cost < 0 || cost < best_cost || (cost == best_cost && blocks < best_blocks)) {
@@ -969,19 +969,19 @@ bool plan_l16_pt(const fsc_conv_desc& d_in, int dgrad, int pt, int max_cot, LPla
     p.workers = items < 256 ? items : 256;
     if (items > 256 && items <= 512) p.workers = (items + 1) / 2;     // two items each instead of 256 + a short second wave
     p.workers -= p.workers % p.co_blocks;           // a worker keeps one channel block
-    g.xcd = (p.co_blocks > 1 && p.workers % (8 * p.co_blocks) == 0 && !getenv("FSC_L16_NO_XCD")) ? 1 : 0;
+    g.xcd = (p.co_blocks > 1 && p.workers % (8 * p.co_blocks) == 0 && !fsc::env().l16_no_xcd) ? 1 : 0;
     *out = p;
     return true;
 }
 
 bool plan_l16(const fsc_conv_desc& d, int dgrad, LPlan* out) {
     if (d.arith != FSC_ARITH_DEFAULT && d.arith != 3) return false;
-    if (getenv("FSC_NO_L16")) return false;
+    if (fsc::env().no_l16) return false;
     const int taps = d.kh * d.kw;
-    const char* force_pt = getenv("FSC_L16_PT");            // development: force the pixel tiles per wave
+    const int force_pt = fsc::env().l16_pt;                 // development (FSC_L16_PT): force the pixel tiles per wave
     // (9 / 10 tiles per block leave too little LDS for a 256-pixel box: 150-channel layers run 7 % faster as 2 x 5 tiles)
-    if ((!force_pt || atoi(force_pt) == 2) && plan_l16_pt(d, dgrad, 2, 8, out)) return true;
-    if (force_pt && atoi(force_pt) == 2) return false;
+    if ((!force_pt || force_pt == 2) && plan_l16_pt(d, dgrad, 2, 8, out)) return true;
+    if (force_pt == 2) return false;
     return plan_l16_pt(d, dgrad, 1, taps == 1 ? 8 : 10, out);
 }
 
@@ -989,7 +989,7 @@ bool plan_l16(const fsc_conv_desc& d, int dgrad, LPlan* out) {
 // shared), a box of 2 x 8 blocks
 bool plan_l16_pool(const fsc_conv_desc& d, LPlan* out) {
     if (d.arith != FSC_ARITH_DEFAULT && d.arith != 3) return false;
-    if (getenv("FSC_NO_L16") || getenv("FSC_NO_L16_POOL")) return false;
+    if (fsc::env().no_l16 || fsc::env().no_l16_pool) return false;
     if (d.kh != 3 || d.kw != 3 || d.h < 2 || d.w < 8) return false;
     LPlan plain;
     if (!plan_l16(d, 0, &plain) || plain.pt != 2) return false;

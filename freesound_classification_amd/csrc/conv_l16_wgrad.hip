@@ -379,7 +379,7 @@ struct WPlan {
 
 bool plan_l16_wgrad(const fsc_conv_desc& d, WPlan* out) {
     if (d.arith != FSC_ARITH_DEFAULT && d.arith != 3) return false;
-    if (getenv("FSC_NO_L16") || getenv("FSC_NO_L16_WGRAD")) return false;
+    if (fsc::env().no_l16 || fsc::env().no_l16_wgrad) return false;
     const int taps = d.kh * d.kw;
     if (!((d.kh == 3 && d.kw == 3) || (d.kh == 1 && d.kw == 1))) return false;
     if (d.c_in < 32 || d.c_out < 32) return false;
@@ -398,11 +398,11 @@ bool plan_l16_wgrad(const fsc_conv_desc& d, WPlan* out) {
     // 64 x 215 planes +5 % with 8 x 8 over 2 x 32, 32 x 107 planes +6 % / -2.5 % over 4 x 16 at equal padding)
     long best_px = -1;
     int best_npos = 0;
-    const char* force_tw = getenv("FSC_L16W_TW");              // development: pin the box width
+    const int force_tw = fsc::env().l16w_tw;                   // development (FSC_L16W_TW): pin the box width
     for (int pass = 0; pass < 2; ++pass)                       // 0: the fewest padded pixels; 1: the box
         for (int tw = 64; tw >= 8; tw >>= 1) {
             const int th = 64 / tw;
-            if (force_tw && atoi(force_tw) != tw && taps > 1) continue;
+            if (force_tw && force_tw != tw && taps > 1) continue;
             if (th > 1 && h == 1) continue;
             const int npos = (th + d.kh - 1) * (tw + d.kw - 1);
             if (npos > 64 * kMaxXI - 8) continue;

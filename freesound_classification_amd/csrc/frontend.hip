@@ -465,7 +465,7 @@ bool pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
 int launch2048(const FrontendArgs& base, bool mel, int n, hipStream_t stream);
 
 int launch(const FrontendArgs& base, bool mel, int n, hipStream_t stream) {
-    if (base.n_fft == 2048 && !getenv("FSC_FRONTEND_GENERIC")) {
+    if (base.n_fft == 2048 && !fsc::env().frontend_generic) {
         const int rc = launch2048(base, mel, n, stream);
         if (rc >= 0) return rc;
     }
@@ -475,7 +475,7 @@ int launch(const FrontendArgs& base, bool mel, int n, hipStream_t stream) {
     if (tpf < 64) tpf = 64;
     if (tpf > kThreads) tpf = kThreads;
     a.tpf = tpf;
-    a.block_sync = getenv("FSC_FE_BLOCK_SYNC") ? 1 : 0;
+    a.block_sync = fsc::env().fe_block_sync ? 1 : 0;
     const int fpb = kThreads / tpf;
     int fg = 32;
     auto lds_bytes = [&](int g) {

@@ -4,6 +4,31 @@
 #include <string.h>
 
 #include "common.h"
+#include <stdlib.h>
+
+namespace fsc {
+const EnvFlags& env() {
+    static const EnvFlags flags = [] {
+        auto on = [](const char* name) { return getenv(name) != nullptr; };
+        auto num = [](const char* name) { const char* v = getenv(name); return v ? atoi(v) : 0; };
+        EnvFlags f{};
+        f.no_l16 = on("FSC_NO_L16");
+        f.no_l16_pool = on("FSC_NO_L16_POOL");
+        f.no_l16_wgrad = on("FSC_NO_L16_WGRAD");
+        f.l16_no_xcd = on("FSC_L16_NO_XCD");
+        f.l16_vec1 = on("FSC_L16_VEC1");
+        f.dbg_noksplit = on("FSC_DBG_NOKSPLIT");
+        f.frontend_generic = on("FSC_FRONTEND_GENERIC");
+        f.fe_block_sync = on("FSC_FE_BLOCK_SYNC");
+        f.l16_v1 = on("FSC_L16_V1");
+        f.l16_cot = num("FSC_L16_COT");
+        f.l16_pt = num("FSC_L16_PT");
+        f.l16w_tw = num("FSC_L16W_TW");
+        return f;
+    }();
+    return flags;
+}
+}  // namespace fsc
 
 namespace fsc {
 
@@ -49,7 +74,8 @@ struct CounterTable {
     int count;
 };
 __global__ void bump_counters_kernel(CounterTable t) {
-    if ((int)threadIdx.x < t.count) *t.ptr[threadIdx.x] += 1;
+    // (atomic: a BatchNorm applied twice in one forward appears twice in the table and must advance by two, like torch's add_)
+    if ((int)threadIdx.x < t.count) atomicAdd(reinterpret_cast<unsigned long long*>(t.ptr[threadIdx.x]), 1ull);
 }
 
 

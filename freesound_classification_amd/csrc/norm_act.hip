@@ -18,8 +18,9 @@ constexpr int kMaxSplit = 64;
 
 // workspace layout (doubles): partial[c][split][8], then coef[c][4] floats
 struct Partials {
-    double* part;   // c * kMaxSplit * kPartStride
-    float* coef;    // c * 4
+    double* part;       // c * kMaxSplit * kPartStride
+    float* coef;        // c * 4
+    unsigned* tickets;  // c arrival counters of the fused finalisations (zero between calls, see fsc_hip.h FSC_BN_TICKETS)
 };
 
 constexpr int kPartStride = 8;
@@ -29,7 +30,35 @@ inline Partials carve(void* ws, int c) {
     Partials p;
     p.part = reinterpret_cast<double*>(ws);
     p.coef = reinterpret_cast<float*>(p.part + part_doubles(c));
+    p.tickets = reinterpret_cast<unsigned*>(p.coef + (size_t)c * 4);
     return p;
+}
+
+// Arrival ticket of one channel's partial results (include/fsc_hip.h, FSC_BN_TICKETS): the workgroup that arrives LAST folds the
+// partials of all `nsplit` workgroups and finalises the channel, so the reduce pass needs no second launch.  Called by the ONE
+// thread that stored its workgroup's partials with device-scope atomic stores (`global_store ... sc1`: written through to the
+// memory side, no line kept in this XCD's L2).  The hand-off is the "8-byte agent-scope atomics on both sides + drained flag"
+// form of MI355X_MICROARCH.md (inter-workgroup visibility): `s_waitcnt vmcnt(0)` holds the ticket back until the partial stores
+// are acknowledged, and the winner reads the partials with device-scope atomic loads (served by neither its L1 nor a stale line of
+// its own XCD's L2).  For the language: the inline asm and the signal fence keep the compiler from moving the stores below / the
+// loads above the ticket, and the winner alone runs an agent-scope acquire fence (`buffer_inv sc1`: one per channel and launch,
+// nothing measurable).  -DFSC_BN_TICKET_RELEASE builds the textbook form instead -- a release fetch_add, i.e. `buffer_wbl2 sc1`
+// (write-back of the XCD's whole L2) in EVERY workgroup: measured 2.6 -> 5.3 ms per cfg-2 step on the backward reduce pass with a
+// full fence, see DESIGN.md section 4.7 for the release-only figure.
+// The winner leaves the counter at zero: a workspace that starts zeroed stays usable call after call.
+__device__ __forceinline__ bool ticket_last(unsigned* ticket, int nsplit) {
+#ifdef FSC_BN_TICKET_RELEASE
+    const unsigned prev = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+#else
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __atomic_signal_fence(__ATOMIC_SEQ_CST);
+    const unsigned prev = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __atomic_signal_fence(__ATOMIC_SEQ_CST);
+#endif
+    if (prev != (unsigned)nsplit - 1u) return false;
+    __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    return true;
 }
 
 // ---------------------------------------------------------------- statistics
@@ -202,9 +231,7 @@ __global__ __launch_bounds__(kThreads) void stats_partial_kernel(
     }
 #pragma unroll
     for (int k = 0; k < 4; ++k) __hip_atomic_store(o + k, vals[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (atomicAdd(tickets + ch, 1u) != (unsigned)nsplit - 1u) return;
-    tickets[ch] = 0u;
+    if (!ticket_last(tickets + ch, nsplit)) return;
     double f1 = 0.0, f2 = 0.0;
     float fmn = INFINITY, fmx = -INFINITY;
     for (int k = 0; k < nsplit; ++k) {
@@ -979,10 +1006,7 @@ __global__ __launch_bounds__(kThreads) void bwd_partial_kernel(BwdArgs a, int ns
         for (int i = threadIdx.x; i < fsc::kAmaxFloats; i += kThreads) fin.dx_amax[i] = 0.f;
     __shared__ int last_s;
     __shared__ double fold_s[kMaxSplit][5];
-    if (threadIdx.x == 0) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // the stores above have been acknowledged: now the ticket
-        last_s = atomicAdd(fin.tickets + ch, 1u) == (unsigned)nsplit - 1u;
-    }
+    if (threadIdx.x == 0) last_s = ticket_last(fin.tickets + ch, nsplit) ? 1 : 0;      // (thread 0 issued the stores above)
     __syncthreads();
     if (!last_s) return;
     if ((int)threadIdx.x < nsplit) {
@@ -992,7 +1016,6 @@ __global__ __launch_bounds__(kThreads) void bwd_partial_kernel(BwdArgs a, int ns
     }
     __syncthreads();
     if (threadIdx.x != 0) return;
-    fin.tickets[ch] = 0u;
     double f0 = 0.0, f1 = 0.0, f2 = 0.0;
     float fdz = 0.f, fxh = 0.f;
     for (int k = 0; k < nsplit; ++k) {
@@ -1529,7 +1552,7 @@ int hwp_log2_for(long hw) {
 struct L16Grid { int hwp_log2; bool uni; dim3 grid; int vec; };
 L16Grid l16_grid(int n, int c, long hw, bool allow_vec) {
     L16Grid r;
-    r.vec = (allow_vec && (hw & 3) == 0 && !getenv("FSC_L16_VEC1")) ? 4 : 1;
+    r.vec = (allow_vec && (hw & 3) == 0 && !fsc::env().l16_vec1) ? 4 : 1;
     const long nq = hw / r.vec;
     const long groups_total = (long)n * ((c + 7) / 8);
     r.uni = nq >= kThreads;
@@ -1558,26 +1581,16 @@ int plane_grid_y(long hw) {
 extern "C" {
 
 size_t fsc_bn_workspace_bytes(int c) {
-    return part_doubles(c) * sizeof(double) + (size_t)c * 4 * sizeof(float);
+    return part_doubles(c) * sizeof(double) + (size_t)c * 4 * sizeof(float) + (((size_t)c * sizeof(unsigned) + 7) & ~(size_t)7);
 }
 
-// per-channel ticket counters of the fused finalisations (zero between launches: the last block of a channel resets its own);
-// region 0: backward reduce pass, region 1: statistics pass.  nullptr (more than 65 536 channels, no memory): the callers launch the
-// separate finalisation kernel instead
-static unsigned* bn_tickets(int c, int region) {
-    constexpr int kRegion = 1 << 16;
-    static const bool off = getenv("FSC_BN_NO_TICKETS") != nullptr;      // the separate finalisation launches (debugging)
-    if (off) return nullptr;
-    static unsigned* buf[16] = {};
-    int dev = 0;
-    if (c > kRegion || hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
-    if (!buf[dev]) {
-        unsigned* nb = nullptr;
-        if (hipMalloc(&nb, sizeof(unsigned) * 2 * kRegion) != hipSuccess) return nullptr;
-        if (hipMemset(nb, 0, sizeof(unsigned) * 2 * kRegion) != hipSuccess) return nullptr;
-        buf[dev] = nb;
-    }
-    return buf[dev] + region * kRegion;
+size_t fsc_bn_workspace_ticket_offset(int c) { return part_doubles(c) * sizeof(double) + (size_t)c * 4 * sizeof(float); }
+
+int fsc_bn_workspace_reset(void* workspace, int c, fsc_stream_t stream) {
+    FSC_CHECK_ARG(workspace && c > 0, "fsc_bn_workspace_reset: bad arguments");
+    hipError_t e = hipMemsetAsync(carve(workspace, c).tickets, 0, (size_t)c * sizeof(unsigned), fsc::as_stream(stream));
+    FSC_CHECK_ARG(e == hipSuccess, "fsc_bn_workspace_reset: memset failed: %s", hipGetErrorString(e));
+    return 0;
 }
 
 int fsc_bn_train_stats(const float* x, int n, int c, long hw, const float* gamma, const float* beta, float eps,
@@ -1597,7 +1610,8 @@ int fsc_bn_train_stats(const float* x, int n, int c, long hw, const float* gamma
     int nsplit = 1;
     const bool folded = (phase & FSC_BN_STATS_FOLDED) != 0;      // split 0 of the partials is there already (fsc_bn_records_fold)
     const int pivot_rm = (phase & FSC_BN_STATS_PIVOT_RM) ? 1 : 0;
-    phase &= ~(FSC_BN_STATS_FOLDED | FSC_BN_STATS_PIVOT_RM | FSC_BN_STATS_MINMAX_ONLY);
+    const bool zero_tickets = (phase & FSC_BN_TICKETS) != 0;   // the caller vouches for the workspace's ticket words
+    phase &= ~(FSC_BN_STATS_FOLDED | FSC_BN_STATS_PIVOT_RM | FSC_BN_STATS_MINMAX_ONLY | FSC_BN_TICKETS);
     if (phase != 2 && !folded) {
         if (hw == 1) {
             nsplit = rows_split(n);
@@ -1607,9 +1621,7 @@ int fsc_bn_train_stats(const float* x, int n, int c, long hw, const float* gamma
             FinalizeArgs fa{x, c, hw, (double)n * (double)hw, nsplit, p.part, gamma, beta, eps, momentum, running_mean, running_var,
                             save_mean, save_invstd, scale, shift, sync, phase, x_minmax, pivot_rm, minmax_only};
             unsigned* tickets = nullptr;
-            if (phase == 0 && !pivot_rm) {
-                tickets = bn_tickets(c, 1);
-            }
+            if (phase == 0 && !pivot_rm && zero_tickets) tickets = p.tickets;
             hipLaunchKernelGGL(stats_partial_kernel, dim3(c, nsplit), dim3(kThreads), 0, st, x, n, c, hw, nsplit,
                                hwp_log2_for(hw), p.part, fa, tickets);
             if (tickets) {
@@ -1754,6 +1766,8 @@ int fsc_bn_act_bwd(const float* dy, const float* gmax_dy, const int* gmax_idx, c
                    void* workspace, float* dx_amax, double* sync, int phase, void* dx_l16, fsc_stream_t stream) {
     FSC_CHECK_ARG(x && save_mean && save_invstd && (dx || dx_l16) && workspace, "fsc_bn_act_bwd: null pointer");
     FSC_CHECK_ARG(!dx_l16 || (dx_amax && hw > 1), "fsc_bn_act_bwd: the L16 output needs dx_amax and hw > 1");
+    const bool zero_tickets = (phase & FSC_BN_TICKETS) != 0;
+    phase &= ~FSC_BN_TICKETS;
     FSC_CHECK_ARG(phase == 0 || ((phase == 1 || phase == 2) && sync), "fsc_bn_act_bwd: phase 1 / 2 need `sync`");
     FSC_CHECK_ARG(dy || gmax_dy, "fsc_bn_act_bwd: no upstream gradient");
     FSC_CHECK_ARG((gmax_dy == nullptr) == (gmax_idx == nullptr), "fsc_bn_act_bwd: gmax_dy / gmax_idx must come in pairs");
@@ -1764,8 +1778,8 @@ int fsc_bn_act_bwd(const float* dy, const float* gmax_dy, const int* gmax_idx, c
     BwdArgs a{dy, gmax_dy, gmax_idx, x, residual, save_mean, save_invstd, gamma, beta, alpha, n, c, hw};
     const int nsplit = hw == 1 ? rows_split(n) : pick_split(n, c, hw);
     BwdFinish fin{};
-    if (phase == 0 && hw > 1) {
-        fin = BwdFinish{bn_tickets(c, 0), (double)n * (double)hw, dgamma, dbeta, dalpha, p.coef, dx_chan_sum, dx_amax, dx_l16 ? 1 : 0};
+    if (phase == 0 && hw > 1 && zero_tickets) {
+        fin = BwdFinish{p.tickets, (double)n * (double)hw, dgamma, dbeta, dalpha, p.coef, dx_chan_sum, dx_amax, dx_l16 ? 1 : 0};
     }
     if (phase != 2) {
         if (hw == 1) {
@@ -1820,6 +1834,8 @@ int fsc_bn_act_bwd_unpool(const float* dy, const float* x, const float* save_mea
                           void* dc_l16, fsc_stream_t stream) {
     FSC_CHECK_ARG(dy && x && save_mean && save_invstd && pool_idx && (dc || dc_l16) && workspace, "fsc_bn_act_bwd_unpool: null pointer");
     FSC_CHECK_ARG(!dc_l16 || dc_amax, "fsc_bn_act_bwd_unpool: the L16 output needs dc_amax");
+    const bool zero_tickets = (phase & FSC_BN_TICKETS) != 0;
+    phase &= ~FSC_BN_TICKETS;
     FSC_CHECK_ARG(phase == 0 || ((phase == 1 || phase == 2) && sync), "fsc_bn_act_bwd_unpool: phase 1 / 2 need `sync`");
     FSC_CHECK_ARG((ph == 1 || ph == 2) && n > 0 && c > 0 && h >= ph && w >= 2, "fsc_bn_act_bwd_unpool: bad shape");
     const int oh = h / ph, ow = w / 2;
@@ -1829,8 +1845,8 @@ int fsc_bn_act_bwd_unpool(const float* dy, const float* x, const float* save_mea
     BwdArgs a{dy, nullptr, nullptr, x, nullptr, save_mean, save_invstd, gamma, beta, alpha, n, c, hw};
     const int nsplit = pick_split(n, c, hw);
     BwdFinish fin{};
-    if (phase == 0) {
-        fin = BwdFinish{bn_tickets(c, 0), (double)n * (double)hw, dgamma, dbeta, dalpha, p.coef, dx_chan_sum, dc_amax, dc_l16 ? 1 : 0};
+    if (phase == 0 && zero_tickets) {
+        fin = BwdFinish{p.tickets, (double)n * (double)hw, dgamma, dbeta, dalpha, p.coef, dx_chan_sum, dc_amax, dc_l16 ? 1 : 0};
     }
     if (phase != 2)
         hipLaunchKernelGGL(bwd_partial_kernel, dim3(c, nsplit), dim3(kThreads), 0, st, a, nsplit, hwp_log2_for(hw), p.part, fin);

@@ -6,6 +6,7 @@ Layout: activations are NCHW fp32 like the reference; the 1-d model runs with H 
 """
 import ctypes as C
 import os
+import sys
 
 import numpy as np
 import torch
@@ -372,6 +373,11 @@ _EVAL_BN = {}
 
 
 def forget_packed_weights():
+    """THE invalidation hook of the inference caches (packed weight fragments, folded eval-mode BatchNorm scale / shift).  The
+    caches are keyed by address and torch version counter, so every in-place torch op invalidates them by itself; anything that
+    writes parameters or BatchNorm buffers through raw pointers (this library's optimizers do, an external EMA / SWA kernel would)
+    must call this.  Called by the Fused* optimizers' step(), a training-mode bn_prepare, and the model's train() /
+    load_state_dict() / load_best_model() / close()."""
     _EVAL_PACKS.clear()
     _EVAL_BN.clear()
 
@@ -773,9 +779,35 @@ def conv_wgrad(x, dout, weight_shape, on_side_stream=False, x_amax=None, dout_am
 
 
 # ------------------------------------------------------------------------------ BN + PReLU
+# BatchNorm workspaces.  With FSC_BN_TICKETS (include/fsc_hip.h) the reduce pass of a call also finalises and counts arrivals in
+# the workspace's ticket words, which must be zero when the call is enqueued and are zero again when it has run.  So workspaces
+# come from a pool of buffers that were zeroed ONCE, keyed by (device, stream, channels): calls on one stream are ordered, and a
+# buffer is handed out again only when nobody holds it any more (reference count) -- two calls that could overlap (different
+# streams: the side stream of the weight gradients, SyncBN's communication stream, a second model on its own stream) never share
+# one.  FSC_BN_NO_TICKETS=1 (read once, at import): plain torch.empty workspaces and the separate finalisation launches.
+BN_TICKETS = 0 if os.environ.get("FSC_BN_NO_TICKETS") else 32          # FSC_BN_TICKETS
+_BN_WS_POOL = {}
+
+
 def _bn_ws(c, like):
     nbytes = _lib.load().fsc_bn_workspace_bytes(c)
-    return torch.empty((nbytes + 7) // 8, device=like.device, dtype=torch.float64)
+    if not BN_TICKETS:
+        return torch.empty((nbytes + 7) // 8, device=like.device, dtype=torch.float64)
+    key = (like.device.index, stream_ptr(), c)
+    pool = _BN_WS_POOL.get(key)
+    if pool is None:
+        pool = _BN_WS_POOL[key] = []
+    for ws in pool:
+        if sys.getrefcount(ws) == 3:                        # the pool's list, the loop variable, getrefcount's argument
+            return ws
+    ws = torch.zeros((nbytes + 7) // 8, device=like.device, dtype=torch.float64)
+    pool.append(ws)
+    return ws
+
+
+def drop_bn_workspaces():
+    """Forget the pooled BatchNorm workspaces (after a device error: their ticket words may be left non-zero)."""
+    _BN_WS_POOL.clear()
 
 
 class BNState:
@@ -868,7 +900,7 @@ def bn_prepare(x, bn, training, sync=None, defer=None, want_minmax=False):
                 ptr(st.mean), ptr(st.invstd), ptr(st.scale), ptr(st.shift), ptr(ws))
         if sync is None:
             with _stage("bn_stats", 0 if folded else _nb(x)):      # (folded: the producer of x reduced them; only the finalisation runs)
-                call("fsc_bn_train_stats", *args, None, folded, ptr(st.minmax), stream_ptr())
+                call("fsc_bn_train_stats", *args, None, folded if pre is not None else BN_TICKETS, ptr(st.minmax), stream_ptr())
         else:
             moments = _sync_buffer(c, x)                   # [sum x, sum x^2, count, 0] per channel, fp64
             call("fsc_bn_train_stats", *args, ptr(moments), 1 | folded, ptr(st.minmax), stream_ptr())
@@ -908,7 +940,7 @@ def bn_prepare(x, bn, training, sync=None, defer=None, want_minmax=False):
             ws, folded = pre if pre is not None else (_bn_ws(c, x), 0)
             st.minmax = _empty((2 * c,), x)
             call("fsc_bn_train_stats", ptr(x), n, c, hw, None, None, bn.eps, 0.0, None, None, None, None, None, None, ptr(ws),
-                 None, (folded & _STATS_FOLDED) | _STATS_MINMAX_ONLY, ptr(st.minmax), stream_ptr())
+                 None, ((folded & _STATS_FOLDED) if pre is not None else BN_TICKETS) | _STATS_MINMAX_ONLY, ptr(st.minmax), stream_ptr())
     return st
 
 
@@ -965,7 +997,7 @@ def bn_act_backward(dy, x, st, bn, alpha=None, residual=None, gmax=None, want_dx
     if sync is None:
         # reduce pass reads dy, x, residual; apply pass reads them again and writes dx (fp32 and / or L16) and dresidual
         with _stage("bn_act_bwd", 2 * _nb(dy, x, residual) + _nb(dx, dres, t)):
-            call("fsc_bn_act_bwd", *args, None, 0, t_ptr, stream_ptr())
+            call("fsc_bn_act_bwd", *args, None, BN_TICKETS, t_ptr, stream_ptr())
     else:
         sums = _sync_buffer(c, x)                          # [sum dz, sum dz * xhat, count, 0] per channel
         call("fsc_bn_act_bwd", *args, ptr(sums), 1, t_ptr, stream_ptr())
@@ -995,7 +1027,7 @@ def bn_act_backward_unpool(dy, x, st, bn, alpha, pool_idx, c_shape, ph, sync=Non
     t_ptr = ptr(t.data) if l16 else None
     if sync is None:
         with _stage("bn_act_bwd", 2 * _nb(dy, x) + _nb(pool_idx, dc, t)):
-            call("fsc_bn_act_bwd_unpool", *args, None, 0, t_ptr, stream_ptr())
+            call("fsc_bn_act_bwd_unpool", *args, None, BN_TICKETS, t_ptr, stream_ptr())
     else:
         sums = _sync_buffer(c, x)
         call("fsc_bn_act_bwd_unpool", *args, ptr(sums), 1, t_ptr, stream_ptr())
@@ -1560,12 +1592,12 @@ def counters_flush():
     global _COUNTER_SINK
     sink, _COUNTER_SINK = _COUNTER_SINK, None
     if sink:
-        table = (C.c_void_p * len(sink))(*[t.data_ptr() for t in sink])
+        table = (C.c_void_p * len(sink))(*[ptr(t) for t in sink])
         call("fsc_bump_counters", table, len(sink), stream_ptr())
 
 
 def _cat_cols(pieces, widths, rows, full, split):
-    table = (C.c_void_p * len(pieces))(*[t.data_ptr() for t in pieces])
+    table = (C.c_void_p * len(pieces))(*[ptr(t) for t in pieces])
     wtab = (C.c_int * len(pieces))(*widths)
     call("fsc_cat_cols", table, wtab, len(pieces), rows, ptr(full), split, stream_ptr())
 

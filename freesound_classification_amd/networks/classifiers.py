@@ -368,6 +368,7 @@ class _TaggingModel(nn.Module):
             self._reducer = None
         self._bn_sync = None
         F.prepack_forget(id(self))
+        F.forget_packed_weights()
         if self._froze_gc:
             gc.unfreeze()
             self._froze_gc = False
@@ -401,6 +402,15 @@ class _TaggingModel(nn.Module):
     def load_best_model(self, fold):
         path = os.path.join(self.experiment.checkpoints, "fold_{}".format(fold), "best_model.pth")
         self.load_state_dict(torch.load(path, map_location=self.device))
+
+    def load_state_dict(self, *args, **kwargs):
+        F.forget_packed_weights()                  # (copy_ bumps the versions too; explicit so that no cache outlives a checkpoint)
+        return super().load_state_dict(*args, **kwargs)
+
+    def train(self, mode=True):
+        if mode:
+            F.forget_packed_weights()              # inference caches do not survive a return to training
+        return super().train(mode)
 
 
 class TwoDimensionalCNNClassificationModel(_TaggingModel):

@@ -12,7 +12,9 @@
  *   - activations are NCHW (the reference's layout); the 1-d model uses H == 1;
  *   - all launches are asynchronous on `stream` (a hipStream_t passed as void*);
  *   - the caller owns every buffer, including workspaces sized by the *_workspace_bytes /
- *     *_floats queries; no entry point allocates device memory;
+ *     *_floats queries; no entry point allocates device memory, and the library keeps no device-side state between calls
+ *     (the one piece of state a call can leave behind -- the arrival counters of FSC_BN_TICKETS -- lives in the caller's
+ *     workspace and is the caller's to vouch for);
  *   - return value 0 = success; anything else is an error whose text
  *     fsc_last_error_string() returns.  No entry point synchronises the device.
  */
@@ -198,6 +200,20 @@ int fsc_conv_l16_wgrad_plan_describe(const fsc_conv_desc* d, char* buf, size_t b
  * x is (N, C, HW); HW == 1 covers BatchNorm1d on (N, C). */
 
 size_t fsc_bn_workspace_bytes(int c);
+/* phase | FSC_BN_TICKETS (fsc_bn_train_stats, fsc_bn_act_bwd, fsc_bn_act_bwd_unpool; single replica, i.e. (phase & 3) == 0): the
+ * reduce pass also finalises -- the workgroup that finishes a channel LAST folds the channel's partial sums -- so the call is one
+ * launch fewer.  It counts arrivals in the `c` 32-bit words at byte fsc_bn_workspace_ticket_offset(c) of `workspace`.  Contract:
+ *   - those words are ZERO when the call is enqueued; the call leaves them zero again (the last workgroup of a channel resets its
+ *     word), so a workspace that was zeroed once after allocation (hipMemsetAsync, or fsc_bn_workspace_reset) can be passed call
+ *     after call;
+ *   - a workspace belongs to ONE call at a time: calls that may overlap (different streams) need different workspaces -- nothing
+ *     is shared between calls except what the caller passes;
+ *   - if a launch of the call fails (a sticky device error), zero the words again before the next use.
+ * Without the flag the workspace needs no initialisation and a separate finalisation kernel runs (same arithmetic, same order of
+ * additions: bit-identical results). */
+#define FSC_BN_TICKETS 32
+size_t fsc_bn_workspace_ticket_offset(int c);
+int fsc_bn_workspace_reset(void* workspace, int c, fsc_stream_t stream);
 /* Cross-replica batch statistics (SyncBN for data parallelism; the reference is single-process so its
  * BatchNorm at classifiers.py:524,533,78-82,543,545 always sees the whole batch).  The three training entry points
  * below take `sync` -- FSC_BN_SYNC_DOUBLES(c) doubles, per channel [sum a, sum b, count, 0] -- and `phase`:

@@ -1,0 +1,238 @@
+"""Round 4: state and concurrency of the BatchNorm reduce passes (include/fsc_hip.h FSC_BN_TICKETS), through the C ABI.
+
+The fused finalisation counts arrivals in ticket words that live in the CALLER's workspace: nothing is shared between calls,
+so two streams may run the BatchNorm entry points on the same channel indices at once.  Reference call sites replaced:
+nn.BatchNorm2d / nn.PReLU forward and backward, /root/reference/networks/classifiers.py:524, 533-534, 37-104.
+
+* with and without the flag the entry points give bit-identical results (same arithmetic, same order of additions);
+* the ticket words are zero again after every call; a poisoned workspace is repaired by fsc_bn_workspace_reset;
+* two streams running fsc_bn_act_bwd / fsc_bn_train_stats on the same channels concurrently reproduce the serial results bit
+  for bit, repetition after repetition;
+* the same training step repeated from the same state (tools/race_hunt.py as a test): logits and gradients reproduce the first
+  repetition within the noise of the atomic channel sums.
+"""
+import copy
+import ctypes as C
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+if not torch.cuda.is_available():
+    pytest.skip("needs an MI355X", allow_module_level=True)
+
+import torch.nn as nn  # noqa: E402
+
+from freesound_classification_amd import _lib  # noqa: E402
+from freesound_classification_amd import functional as F  # noqa: E402
+from freesound_classification_amd._lib import call, ptr, stream_ptr  # noqa: E402
+
+DEV = torch.device("cuda:0")
+TICKETS = 32
+
+
+def _ws(c, zero=True):
+    nbytes = _lib.load().fsc_bn_workspace_bytes(c)
+    maker = torch.zeros if zero else torch.empty
+    ws = maker((nbytes + 7) // 8, device=DEV, dtype=torch.float64)
+    if not zero:
+        ws.view(torch.int32).fill_(0x5A5A5A5A)               # garbage: legal without the flag
+    return ws
+
+
+def _tickets(ws, c):
+    off = _lib.load().fsc_bn_workspace_ticket_offset(c)
+    assert off % 4 == 0 and off + 4 * c <= ws.numel() * 8
+    return ws.view(torch.int32)[off // 4: off // 4 + c]
+
+
+def _bwd(x, dy, res, mean, invstd, gamma, beta, alpha, ws, flag, l16=False):
+    n, c = x.shape[:2]
+    hw = x.numel() // (n * c)
+    out = {k: torch.empty(c, device=DEV) for k in ("dgamma", "dbeta", "dalpha", "csum")}
+    dx = torch.empty_like(x)
+    dres = torch.empty_like(x) if res is not None else None
+    amax = torch.empty(F.AMAX_FLOATS, device=DEV)
+    d16 = F.l16_empty(x.shape, x) if l16 else None
+    call("fsc_bn_act_bwd", ptr(dy), None, None, ptr(x), ptr(res), ptr(mean), ptr(invstd), ptr(gamma), ptr(beta), ptr(alpha),
+         ptr(dx), ptr(dres), ptr(out["dgamma"]), ptr(out["dbeta"]), ptr(out["dalpha"]), ptr(out["csum"]), n, c, hw, ptr(ws),
+         ptr(amax), None, flag, ptr(d16), stream_ptr())
+    out.update(dx=dx, dres=dres, amax=amax, d16=d16)
+    return out
+
+
+def _stats(x, gamma, beta, ws, flag):
+    n, c = x.shape[:2]
+    hw = x.numel() // (n * c)
+    out = {k: torch.empty(c, device=DEV) for k in ("mean", "invstd", "scale", "shift")}
+    out["minmax"] = torch.empty(2 * c, device=DEV)
+    out["rm"] = torch.zeros(c, device=DEV)
+    out["rv"] = torch.ones(c, device=DEV)
+    call("fsc_bn_train_stats", ptr(x), n, c, hw, ptr(gamma), ptr(beta), 1e-5, 0.1, ptr(out["rm"]), ptr(out["rv"]), ptr(out["mean"]),
+         ptr(out["invstd"]), ptr(out["scale"]), ptr(out["shift"]), ptr(ws), None, flag, ptr(out["minmax"]), stream_ptr())
+    return out
+
+
+def _same(a, b, what):
+    for k in a:
+        if a[k] is None:
+            continue
+        if k == "csum":                                      # per-channel atomic float sums of the apply pass: order-dependent
+            assert torch.allclose(a[k], b[k], rtol=1e-4, atol=1e-3), (what, k)
+            continue
+        assert torch.equal(a[k], b[k]), (what, k, float((a[k].float() - b[k].float()).abs().max()))
+
+
+def _case(shape, seed):
+    n, c, h, w = shape
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    x = (torch.randn(n, c, h, w, generator=g) * 2 + 0.3).to(DEV)
+    dy = torch.randn(n, c, h, w, generator=g).to(DEV)
+    res = torch.randn(n, c, h, w, generator=g).to(DEV)
+    gamma = (torch.rand(c, generator=g) + 0.5).to(DEV)
+    beta = (torch.rand(c, generator=g) - 0.5).to(DEV)
+    alpha = (torch.rand(c, generator=g) * 0.3 + 0.1).to(DEV)
+    return x, dy, res, gamma, beta, alpha
+
+
+SHAPES = [(128, 100, 16, 53), (64, 37, 5, 9), (16, 759, 2, 6), (4, 3, 40, 41), (32, 150, 32, 107)]
+
+
+@pytest.mark.parametrize("shape", SHAPES)
+def test_bn_ticketed_and_separate_finalisation_are_bit_identical(shape):
+    """FSC_BN_TICKETS folds the partial sums in the order of the separate finalisation kernels: identical bits.  The ticket words
+    are zero again after every call (three calls on the same workspace), and the un-flagged call tolerates a garbage workspace."""
+    c = shape[1]
+    x, dy, res, gamma, beta, alpha = _case(shape, 3)
+    ws_t, ws_plain = _ws(c), _ws(c, zero=False)
+    s_plain = _stats(x, gamma, beta, ws_plain, 0)
+    b_plain = _bwd(x, dy, res, s_plain["mean"], s_plain["invstd"], gamma, beta, alpha, ws_plain, 0)
+    b16_plain = _bwd(x, dy, None, s_plain["mean"], s_plain["invstd"], gamma, beta, alpha, ws_plain, 0, l16=True)
+    for rep in range(3):
+        s_t = _stats(x, gamma, beta, ws_t, TICKETS)
+        assert int(_tickets(ws_t, c).abs().max()) == 0, "statistics pass left tickets behind (rep %d)" % rep
+        _same(s_plain, s_t, "stats rep %d" % rep)
+        b_t = _bwd(x, dy, res, s_t["mean"], s_t["invstd"], gamma, beta, alpha, ws_t, TICKETS)
+        assert int(_tickets(ws_t, c).abs().max()) == 0, "backward pass left tickets behind (rep %d)" % rep
+        _same(b_plain, b_t, "bwd rep %d" % rep)
+        b16_t = _bwd(x, dy, None, s_t["mean"], s_t["invstd"], gamma, beta, alpha, ws_t, TICKETS, l16=True)
+        _same(b16_plain, b16_t, "bwd l16 rep %d" % rep)
+
+
+def test_bn_workspace_reset_repairs_a_poisoned_workspace():
+    """A launch that died mid-way leaves arrival counts behind; fsc_bn_workspace_reset zeroes them (and nothing else is state)."""
+    shape = (32, 64, 16, 53)
+    c = shape[1]
+    x, dy, res, gamma, beta, alpha = _case(shape, 5)
+    ws = _ws(c)
+    want = _stats(x, gamma, beta, ws, TICKETS)
+    _tickets(ws, c).fill_(1)                                  # "one workgroup of every channel arrived, then the launch died"
+    call("fsc_bn_workspace_reset", ptr(ws), c, stream_ptr())
+    assert int(_tickets(ws, c).abs().max()) == 0
+    got = _stats(x, gamma, beta, ws, TICKETS)
+    _same(want, got, "after reset")
+
+
+@pytest.mark.parametrize("shape", [(64, 100, 32, 107), (128, 225, 16, 53), (128, 100, 8, 26)])
+def test_bn_entry_points_on_two_streams_concurrently(shape):
+    """Two streams run fsc_bn_train_stats + fsc_bn_act_bwd on the SAME channel indices at once, each with its own workspace (the
+    ABI's contract: a workspace belongs to one call at a time): every repetition reproduces the serial results bit for bit.  With
+    the round-3 process-global ticket array this interleaving finalised channels early or never."""
+    c = shape[1]
+    a, b = _case(shape, 11), _case(shape, 12)
+    serial = []
+    for x, dy, res, gamma, beta, alpha in (a, b):
+        ws = _ws(c)
+        s = _stats(x, gamma, beta, ws, TICKETS)
+        serial.append((s, _bwd(x, dy, res, s["mean"], s["invstd"], gamma, beta, alpha, ws, TICKETS)))
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(device=DEV), torch.cuda.Stream(device=DEV)]
+    wss = [_ws(c), _ws(c)]
+    torch.cuda.synchronize()
+    for rep in range(25):
+        got = [None, None]
+        for k in (0, 1, 0, 1):                                # interleave the enqueues so that the kernels overlap on the device
+            x, dy, res, gamma, beta, alpha = (a, b)[k]
+            with torch.cuda.stream(streams[k]):
+                s = _stats(x, gamma, beta, wss[k], TICKETS)
+                got[k] = (s, _bwd(x, dy, res, s["mean"], s["invstd"], gamma, beta, alpha, wss[k], TICKETS))
+        torch.cuda.synchronize()
+        for k in (0, 1):
+            _same(serial[k][0], got[k][0], "stats stream %d rep %d" % (k, rep))
+            _same(serial[k][1], got[k][1], "bwd stream %d rep %d" % (k, rep))
+            assert int(_tickets(wss[k], c).abs().max()) == 0
+
+
+def test_pooled_workspaces_are_per_stream_and_reused_in_stream_order():
+    """functional._bn_ws: zeroed once, never shared between streams, handed out again only when nobody holds the buffer."""
+    if not F.BN_TICKETS:
+        pytest.skip("FSC_BN_NO_TICKETS is set")
+    like = torch.empty(1, device=DEV)
+    F.drop_bn_workspaces()
+    w1 = F._bn_ws(100, like)
+    w2 = F._bn_ws(100, like)
+    assert w1.data_ptr() != w2.data_ptr()                     # both alive: two buffers
+    p1 = w1.data_ptr()
+    del w1
+    w3 = F._bn_ws(100, like)
+    assert w3.data_ptr() == p1                                # released: reused
+    side = torch.cuda.Stream(device=DEV)
+    del w3
+    with torch.cuda.stream(side):
+        w4 = F._bn_ws(100, like)
+    assert w4.data_ptr() not in (p1, w2.data_ptr())           # another stream: its own pool
+    assert int(_tickets(w4, 100).abs().max()) == 0
+    F.drop_bn_workspaces()
+
+
+def _small_2d(blocks=3, base=48):
+    from test_parity_r3_gpu import _small_2d as make
+    return make(blocks=blocks, base=base)
+
+
+@pytest.mark.parametrize("arith", ["f16x3"])
+def test_training_step_repeats_within_atomic_summation_noise(arith):
+    """tools/race_hunt.py as a test: the same training step (same state, same inputs, no optimizer step) 40 times.  The only
+    sources of run-to-run variation are the atomic float sums (per-channel bias gradients, split-K convolutions on the small late
+    layers): logits within 1e-5 of the first repetition, every gradient tensor within 1e-3 of its scale.  A race in a finalisation
+    (a channel finalised before its last partial arrived) shows as an O(1) deviation of that BatchNorm's gradients."""
+    torch.manual_seed(42)
+    model = _small_2d(blocks=3, base=64)
+    model.train()
+    model.global_step = 0
+    model.make_optimizer(max_steps=100)
+    signal = 0.1 * torch.randn(16, 2 * 44100, 1, device=DEV)
+    labels = (torch.rand(16, 80, device=DEV) < 0.05).float()
+    for _ in range(2):
+        model.training_step(signal, labels)
+    state = copy.deepcopy(model.state_dict())
+    dstate = copy.deepcopy(model._dropout_state) if hasattr(model, "_dropout_state") else None
+
+    def once():
+        model.load_state_dict(state)
+        if dstate is not None:
+            model._dropout_state = copy.deepcopy(dstate)
+        for p in model.parameters():
+            p.grad = None
+        logits, per, loss = model.training_step(signal, labels, step_optimizer=False)
+        torch.cuda.synchronize()
+        return logits.detach().clone(), {k: v.grad.detach().clone() for k, v in model.named_parameters() if v.grad is not None}
+
+    l0, g0 = once()
+    assert torch.isfinite(l0).all()
+    gmax = max(float(v.abs().max()) for v in g0.values())
+    worst_l, worst_g = 0.0, (0.0, None)
+    for rep in range(40):
+        l, g = once()
+        worst_l = max(worst_l, float((l - l0).abs().max()))
+        for k in g0:
+            scale = float(g0[k].abs().max())
+            if scale < 1e-4 * gmax:                           # (a conv bias in front of a BatchNorm: its gradient is rounding noise)
+                continue
+            d = float((g[k] - g0[k]).abs().max()) / scale
+            if d > worst_g[0]:
+                worst_g = (d, k)
+    assert worst_l <= 1e-5 * max(1.0, float(l0.abs().max())), worst_l
+    assert worst_g[0] <= 1e-3, worst_g
+    model.close()
