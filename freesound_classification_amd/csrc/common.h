@@ -15,10 +15,11 @@ inline hipStream_t as_stream(fsc_stream_t s) { return reinterpret_cast<hipStream
 
 // Development switches (FSC_* environment variables), read ONCE when the first entry point needs them -- never on the per-call path.
 struct EnvFlags {
-    bool no_l16, no_l16_pool, no_l16_wgrad, l16_no_xcd, l16_vec1, dbg_noksplit, frontend_generic, fe_block_sync, l16_v1;
+    bool no_l16, no_l16_pool, no_l16_wgrad, l16_no_xcd, l16_vec1, dbg_noksplit, frontend_generic, fe_block_sync;
     int l16_cot, l16_pt, l16w_tw;        // 0 = not forced
 };
 const EnvFlags& env();                   // misc.hip
+
 
 #define FSC_CHECK_ARG(cond, ...)            \
     do {                                    \

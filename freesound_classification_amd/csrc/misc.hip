@@ -20,7 +20,6 @@ const EnvFlags& env() {
         f.dbg_noksplit = on("FSC_DBG_NOKSPLIT");
         f.frontend_generic = on("FSC_FRONTEND_GENERIC");
         f.fe_block_sync = on("FSC_FE_BLOCK_SYNC");
-        f.l16_v1 = on("FSC_L16_V1");
         f.l16_cot = num("FSC_L16_COT");
         f.l16_pt = num("FSC_L16_PT");
         f.l16w_tw = num("FSC_L16W_TW");

@@ -1,0 +1,680 @@
+// Forward / input-gradient kernel of the L16 convolutions and what it shares with its ping-pong variant (conv_l16_pp.hip): tile
+// geometry, LDS-DMA, fragment helpers, the plan.  See conv_l16.hip for the format and the host side.
+#pragma once
+#include "common.h"
+#include "l16.h"
+#include <stdlib.h>
+#include <string.h>
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef __attribute__((address_space(3))) void* lds_ptr;
+typedef __attribute__((address_space(1))) const void* glb_ptr;
+
+constexpr int kWaves = 8;            // two waves per SIMD
+constexpr int kChunk = 32;           // channels per K chunk = 4 octets
+constexpr int kNptMax = 6;           // input DMA instructions per (octet, limb) plane: plane <= 384 positions
+constexpr int kScr = 20;             // epilogue scratch row stride (floats)
+constexpr int kWmaxBlocks = 64;      // partial maxima of the weights (l16_wmax_kernel)
+
+struct LGeom {
+    int n, cin, cout, h, w;
+    long hw;
+    int oct_in;               // octets of the input tensor
+    int nb, th, tw;           // pixel box: images x rows x cols
+    int tiles_n, tiles_h, tiles_w;
+    int rows, cols;           // staged box incl. halo
+    int plane;                // positions per staged (octet, limb) plane, multiple of 8
+    int npos, npix, npt;
+    int nfull, tail_oct, tail_steps, steps;
+    int coblk;
+    long img_stride;          // 16-byte units between images of the input: oct_in * 2 * hw
+    int xcd;                  // item order: the channel blocks of a tile on workers of one XCD (see the kernel)
+};
+
+__device__ __attribute__((aligned(16))) float g_zero16_l[4] = {0.f, 0.f, 0.f, 0.f};
+
+__device__ __forceinline__ int fdiv(int x, float inv) { return (int)(((float)x + 0.5f) * inv); }
+
+// Shader clock of the last launch: workgroup 0 stamps the shader-cycle counter (s_memtime) and the constant 100 MHz reference
+// counter (s_memrealtime) at both ends of the kernel; their ratio is the clock the chip actually ran the kernel at (the MFMA-bound
+// launches of cfg 2 run near 1.6 GHz under the power limit, not at the 2.4 GHz the peak is quoted for).  fsc_conv_l16_last_clock.
+__device__ unsigned long long g_l16_clock[2];
+
+// Development (-DFSC_L16_PROFILE): shader-clock stamps around the phases of a step, summed per wave of workgroup 0 into
+// g_l16_prof[wave][phase]; read back and cleared by fsc_debug_l16_prof.  Phases: 0 wait + barrier, 1 barrier -> first MFMA group
+// (copy issue of the un-spread variant, control, fresh A fragments), 2 MFMA groups (with the spread copies between them),
+// 3 epilogue, 4 steps counted, 5 whole kernel.
+#ifdef FSC_L16_PROFILE
+__device__ unsigned long long g_l16_prof[8][8];
+__device__ __forceinline__ unsigned long long prof_now() { return __builtin_readcyclecounter(); }
+#define PROF_DECL unsigned long long pf_t = 0, pf_acc[7] = {0, 0, 0, 0, 0, 0, 0}; const unsigned long long pf_k0 = prof_now(), pf_r0 = __builtin_amdgcn_s_memrealtime();
+#define PROF_MARK() (pf_t = prof_now())
+#define PROF_ADD(i) do { const unsigned long long n_ = prof_now(); pf_acc[i] += n_ - pf_t; pf_t = n_; } while (0)
+#else
+#define PROF_DECL
+#define PROF_MARK()
+#define PROF_ADD(i)
+#endif
+
+// 16-byte LDS-DMA (lane i writes lds_wave_base + 16 i).  Issued as inline assembly on purpose: hipcc knows that the builtin
+// writes LDS and, unable to tell the stages of the dynamic LDS block apart, puts `s_waitcnt vmcnt(0)` in front of the next LDS
+// read -- i.e. waits for the copy it has just issued for a LATER step before computing the current one (measured: the kernels
+// ran 20-37 % faster with the copies removed, and not at all faster with the explicit waits removed).  The waits of these
+// kernels are explicit (`s_waitcnt vmcnt(N)` before the barrier that publishes a stage).
+__device__ __forceinline__ void glds16(const void* src, void* lds_wave_base) {
+    const unsigned m = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_ptr)lds_wave_base);
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(m) : "memory", "m0");
+}
+
+using l16::split2_pair;
+using l16::scale_field;
+using l16::field_to_float;
+using l16::inv_scale;
+__device__ __forceinline__ f32x4 mfma16(u32x4 a, u32x4 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+// lane ^ 1 and lane ^ 8 inside a row of 16 lanes as DPP moves (quad_perm [1,0,3,2], row_ror:8): __shfl_xor goes through
+// ds_bpermute and the LDS queue
+__device__ __forceinline__ float dpp_xor1(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float dpp_xor2(float v) {      // quad_perm [2,3,0,1]
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float dpp_xor8(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x128, 0xF, 0xF, true));
+}
+__device__ __forceinline__ void raw_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// maximum over an FSC_AMAX_FLOATS slot buffer (one float per thread of a 512-thread block), uniform result
+__device__ __forceinline__ float block_amax512(const float* amax, float* red) {
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const float mw = fsc::wave_max(amax[tid]);
+    if (lane == 0) red[wid] = mw;
+    __syncthreads();
+    float ax = red[0];
+#pragma unroll
+    for (int i = 1; i < kWaves; ++i) ax = fmaxf(ax, red[i]);
+    ax = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, ax)));
+    __syncthreads();
+    return ax;
+}
+
+// -------------------------------------------------------------------------------------------
+// Forward / dgrad.  Workgroup = 8 waves, tile = COT*16 output channels x (8 * PT * 16) pixels, persistent over
+// (pixel tile, channel block) items.  One MFMA step = one tap x 32 channels: COT * PT * 3 MFMAs per wave.
+// POOL: forward of a convolution that is followed by MaxPool2d(2) (classifiers.py:526-532 for the blocks after the stem): a
+// wave's 16-pixel tiles are 2 x 8 blocks of the box instead of 16 consecutive pixels, so the four pixels of every pooling window
+// sit in lanes lm, lm + 1, lm + 8, lm + 9 of one MFMA column group -- the epilogue pools with two shuffles per value (same
+// first-maximum / NaN rule as fsc_maxpool_fwd) and writes the pooled tensor and the window indices; the full-resolution output
+// (1 GB at the first such layer of cfg 2) is never written and the separate max-pool pass disappears.  `out` = pooled tensor.
+// STATS: the forward of a convolution whose output goes into a BatchNorm (every convolution of a block: classifiers.py:78-101,
+// 524-533): the epilogue also accumulates, per lane and output channel, sum (y - pivot), sum (y - pivot)^2, min y, max y of what
+// it stores (y = the pooled value with POOL) -- the statistics pass over the output disappears.  A worker keeps ONE channel
+// block for all its items (the host makes the worker count a multiple of the channel blocks), so the sums stay in registers
+// until the end of the kernel: one float4 record per (worker, wave, channel) in `stat_rec`, folded by
+// fsc_bn_records_fold_conv.  pivot = stat_pivot[channel] (the BatchNorm's running mean: close to the batch mean) or 0.
+template <int KH, int KW, int COT, int PT, bool POOL = false, bool STATS = false>
+__global__ __launch_bounds__(kWaves * 64) void conv_l16_fwd_kernel(LGeom g, const uint4* __restrict__ in,
+                                                                    const float* __restrict__ packed,
+                                                                    const float* __restrict__ bias,
+                                                                    float* __restrict__ out, int accumulate,
+                                                                    const float* __restrict__ in_amax,
+                                                                    const float* __restrict__ w_amax,
+                                                                    uint8_t* __restrict__ pool_idx = nullptr,
+                                                                    const float* __restrict__ stat_pivot = nullptr,
+                                                                    float4* __restrict__ stat_rec = nullptr) {
+    constexpr int TAPS = KH * KW;
+    constexpr int CO_BLK = COT * 16;
+    constexpr int PADH = KH / 2, PADW = KW / 2;
+    constexpr int DAHEAD = TAPS == 1 ? 2 : 1;       // the input DMA runs this many chunks ahead
+    constexpr int NSTG = DAHEAD + 1;
+    constexpr int WUNITS = COT * 2;                 // 1 KB fragment images per step
+    constexpr int WSLOT_F = WUNITS * 256;           // floats per ring slot
+    constexpr int NWQ = (WUNITS + kWaves - 1) / kWaves;
+    constexpr int RING = 4;                         // weight slots: W runs three steps ahead
+    constexpr int NWLO = WUNITS / kWaves;           // weight DMAs every wave issues per step (at least)
+    constexpr int NPAIR = (COT + 1) / 2;
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* const wring = smem;
+    uint4* const ibase = reinterpret_cast<uint4*>(smem + RING * WSLOT_F);
+    const int istage = 8 * g.plane;                 // uint4 per stage
+    float* const scratch = reinterpret_cast<float*>(ibase + NSTG * istage) + (threadIdx.x >> 6) * (16 * kScr);
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lm = lane & 15, kq = lane >> 4;
+    const unsigned long long ck0 = __builtin_readcyclecounter(), cr0 = __builtin_amdgcn_s_memrealtime();
+
+#ifndef FSC_L16_PRIO
+#define FSC_L16_PRIO 0
+#endif
+    // the second-dispatched half of the workgroup loses every issue arbitration against its older SIMD partner (priority, then
+    // age): a static priority evens the two halves out (MI355X_MICROARCH.md, two waves per SIMD, item 4)
+    if (FSC_L16_PRIO && wid >= 4) __builtin_amdgcn_s_setprio(1);
+    // ---- operand scales (before any DMA lands in the ring)
+    const float ax = block_amax512(in_amax, smem);
+    const float aw = *w_amax;
+    const int fx = scale_field(ax), fw = scale_field(aw);
+    const float inv_x = inv_scale(fx, ax), inv_w = inv_scale(fw, aw);
+
+    const float inv_per = 1.0f / (float)(g.rows * g.cols), inv_cols = 1.0f / (float)g.cols;
+    const float inv_tw = 1.0f / (float)g.tw, inv_thw = 1.0f / (float)(g.th * g.tw);
+    int pix_b[PT];               // byte offset of this lane's pixel inside a staged plane
+#pragma unroll
+    for (int pt = 0; pt < PT; ++pt) {
+        const int p = (wid * PT + pt) * 16 + lm;
+        int pl = 0;
+        if (p < g.npix) {
+            if (POOL) {                                  // tile = a 2 x 8 block: (image, row pair, column octet)
+                const int tpr = g.tw >> 3, tpi = (g.th >> 1) * tpr;
+                const int t = wid * PT + pt;
+                const int b = t / tpi, rem = t - b * tpi;
+                const int tr = rem / tpr, tc = rem - tr * tpr;
+                pl = (b * g.rows + 2 * tr + (lm >> 3)) * g.cols + 8 * tc + (lm & 7);
+            } else {
+                const int per = g.th * g.tw;
+                const int b = fdiv(p, inv_thw), rem = p - b * per;
+                const int r = fdiv(rem, inv_tw), c = rem - r * g.tw;
+                pl = (b * g.rows + r) * g.cols + c;
+            }
+        }
+        pix_b[pt] = pl * 16;
+    }
+    const int ntiles = g.tiles_n * g.tiles_h * g.tiles_w;
+    // Items = (pixel tile, channel block).  A worker keeps ONE channel block and walks tiles t0, t0 + ts, ... (the worker count is
+    // a multiple of the channel blocks).  With g.xcd the `coblk` workers that share a tile are neighbours on one XCD (workgroups
+    // go to XCDs round-robin: worker b runs on XCD b % 8), so the second read of a tile's input boxes hits that XCD's L2
+    // instead of going out again: tile t belongs to XCD t % 8, local slot (t / 8) % (workers per XCD / coblk).
+    int cb_w, t0;
+    const int ts = (int)gridDim.x / g.coblk;
+    if (g.xcd) {
+        const int l = (int)blockIdx.x >> 3;
+        cb_w = l % g.coblk;
+        t0 = ((int)blockIdx.x & 7) + 8 * (l / g.coblk);
+    } else {
+        cb_w = (int)blockIdx.x % g.coblk;
+        t0 = (int)blockIdx.x / g.coblk;
+    }
+    const int nchunks = g.nfull + (g.tail_oct ? 1 : 0);
+
+    int pos_off[kNptMax];        // source offset (16-byte units, relative to unit 0 of image 0) of staged positions; -1 = zeros
+    auto plan_input = [&](int tile) {                       // (once per item: the decode is redone instead of kept in registers)
+        int t = tile;
+        const int twi = t % g.tiles_w; t /= g.tiles_w;
+        const int thi = t % g.tiles_h; t /= g.tiles_h;
+        const int n0 = t * g.nb, h0 = thi * g.th, w0 = twi * g.tw;
+#pragma unroll
+        for (int q = 0; q < kNptMax; ++q) {
+            const int pos = q * 64 + lane;
+            pos_off[q] = -1;
+            if (pos < g.npos) {
+                const int per = g.rows * g.cols;
+                const int b = fdiv(pos, inv_per), rem = pos - b * per;
+                const int rr = fdiv(rem, inv_cols), cc = rem - rr * g.cols;
+                const int gh = h0 + rr - PADH, gw = w0 + cc - PADW;
+                if (n0 + b < g.n && gh >= 0 && gh < g.h && gw >= 0 && gw < g.w)
+                    pos_off[q] = (int)((long)(n0 + b) * g.img_stride + (long)gh * g.w + gw);
+            }
+        }
+    };
+
+    f32x4 acc[COT][PT];
+#pragma unroll
+    for (int i = 0; i < COT; ++i)
+#pragma unroll
+        for (int j = 0; j < PT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    PROF_DECL
+    constexpr int NST = STATS ? COT : 1;
+    float st_s1[NST], st_s2[NST], st_mn[NST], st_mx[NST];
+#pragma unroll
+    for (int i = 0; i < NST; ++i) { st_s1[i] = 0.f; st_s2[i] = 0.f; st_mn[i] = INFINITY; st_mx[i] = -INFINITY; }
+    auto stat_add = [&](int i, float y, float pv) {
+        const float a = y - pv;
+        st_s1[i] += a;
+        st_s2[i] = fmaf(a, a, st_s2[i]);
+        st_mn[i] = fminf(st_mn[i], y);
+        st_mx[i] = fmaxf(st_mx[i], y);
+    };
+
+    // ---- DMA issue
+    const uint4* const zero = reinterpret_cast<const uint4*>(g_zero16_l);
+    auto issue_w = [&](const float* src, int slot) {        // src: this lane's pointer into the step's fragments
+        float* dst = wring + slot * WSLOT_F;
+#pragma unroll
+        for (int q = 0; q < NWQ; ++q) {
+            const int u = q * kWaves + wid;
+            if ((q + 1) * kWaves <= WUNITS || u < WUNITS) glds16(src + u * 256, dst + u * 256);
+        }
+    };
+    // input of chunk c into `stage`: wave wid copies unit wid = (octet wid / 2, limb wid % 2); always g.npt instructions
+    auto issue_i = [&](int stage, int c) {
+        const int oct = c * 4 + (wid >> 1);
+        const bool live_u = oct < g.oct_in;
+        const uint4* src = in + (long)(oct * 2 + (wid & 1)) * g.hw;
+        uint4* dst = ibase + stage * istage + wid * g.plane;
+#pragma unroll
+        for (int q = 0; q < kNptMax; ++q) {
+            if (q < g.npt && q * 64 + lane < g.plane) {         // (lanes past the plane would land in the next unit)
+                const bool live = live_u && pos_off[q] >= 0;
+                glds16(live ? src + pos_off[q] : zero, dst + q * 64);
+            }
+        }
+    };
+
+    // ---- producers: W runs three steps ahead of the MFMA steps, the input DAHEAD chunks, both across items
+    int wp_item = t0, wp_left = g.steps, wp_slot = 0;      // wp_left: steps of tile wp_item not issued yet
+    const float* const wp_base = packed + (long)cb_w * g.steps * WSLOT_F + lane * 4;
+    const float* wp_src = wp_base;
+    auto wp_set_item = [&]() { wp_src = wp_base; };
+    auto produce_w = [&]() -> bool {
+        if (wp_item >= ntiles) return false;
+        issue_w(wp_src, wp_slot);
+        wp_src += WSLOT_F;
+        wp_slot = wp_slot == RING - 1 ? 0 : wp_slot + 1;
+        if (--wp_left == 0) {
+            wp_left = g.steps;
+            wp_item += ts;
+            wp_set_item();
+        }
+        return true;
+    };
+    int ip_item = t0, ip_c = 0, ip_stg = 0;
+    auto produce_i = [&]() -> bool {
+        if (ip_item >= ntiles) return false;
+        issue_i(ip_stg, ip_c);
+        ip_stg = ip_stg == NSTG - 1 ? 0 : ip_stg + 1;
+        if (++ip_c == nchunks) {
+            ip_c = 0;
+            ip_item += ts;
+            if (ip_item < ntiles) plan_input(ip_item);
+        }
+        return true;
+    };
+
+    // ---- B operand address of (stage, chunk, step) for this lane: byte offset from ibase of its octet's high limb
+    //      at the step's tap (without the pixel).  Full chunks: lane group kq = octet kq, uniform tap.
+    const int limb_b = g.plane * 16;                        // bytes between the limb planes of an octet
+    const int stage_b = 8 * limb_b;
+    const int kq_b = kq * 2 * limb_b;
+    auto b_off_tail = [&](int stage, int s) -> int {        // remainder chunk: (tap, octet) flattened over lane groups
+        const int noct = g.tail_oct;
+        int gi = 4 * s + kq;
+        if (gi >= TAPS * noct) gi = 0;                     // its weights are zero
+        const int tap = TAPS == 1 ? 0 : fdiv(gi, 1.0f / (float)noct);
+        const int oct = gi - tap * noct;
+        const int ty = TAPS == 1 ? 0 : fdiv(tap, 1.0f / (float)KW), tx = tap - ty * KW;
+        return stage * stage_b + oct * 2 * limb_b + (ty * g.cols + tx) * 16;
+    };
+    auto b_off = [&](int stage, int c, int s) -> int {      // (stage, c, s uniform)
+        if (c >= g.nfull) return b_off_tail(stage, s);
+        const int ty = TAPS == 1 ? 0 : (s * 11) >> 5, tx = s - ty * KW;          // s / 3 for s < 10
+        return stage * stage_b + (ty * g.cols + tx) * 16 + kq_b;
+    };
+
+    struct Frag { u32x4 v[2][PT]; };                        // B fragments of a step: [limb][pixel tile]
+    struct AFrag { u32x4 v[2][2]; };                        // A fragments of a pair of channel tiles: [tile][limb]
+    Frag fb0, fb1;
+    AFrag fa0, fa1;
+    const char* const ib = reinterpret_cast<const char*>(ibase);
+    auto read_b = [&](int off, Frag& dst) {
+#pragma unroll
+        for (int j = 0; j < PT; ++j) {
+            dst.v[0][j] = *reinterpret_cast<const u32x4*>(ib + off + pix_b[j]);
+            dst.v[1][j] = *reinterpret_cast<const u32x4*>(ib + off + pix_b[j] + limb_b);
+        }
+    };
+    auto read_a = [&](const u32x4* wl, int pr, AFrag& dst) {      // wl: this lane's fragments of a ring slot
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int l = 0; l < 2; ++l)
+                if (pr * 2 + t < COT) dst.v[t][l] = wl[((pr * 2 + t) * 2 + l) * 64];
+    };
+
+    int item = t0;                 // (the tile of the current item)
+    int slot = 0;
+    if (item < ntiles) {
+        plan_input(item);
+        wp_set_item();
+#pragma unroll
+        for (int d = 0; d < DAHEAD; ++d) produce_i();
+        produce_w();
+        produce_w();
+        if (TAPS == 1) produce_w();                          // (3x3: the first pair's two slots; each lead tap issues the next pair)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        raw_barrier();
+        read_b(b_off(0, 0, 0), fb0);
+        read_a(reinterpret_cast<const u32x4*>(wring) + lane, 0, fa0);
+    }
+
+    // consumer position (all uniform): chunk c, step sc of nst inside it, input stage stg; wait state
+    int c = 0, sc = 0, nst = g.nfull > 0 ? TAPS : g.tail_steps, stg = 0;
+    bool first_step = true, drain = false;
+
+    // One MFMA step = one tap x 32 channels.  3x3 kernels synchronise every TWO taps (TWO): the workgroup barrier, the DMA
+    // issue and the wait for the weights cost ~1150 cycles per barrier whatever the number of MFMAs behind it (measured: step
+    // time 2260 cycles at 24 MFMAs per wave, 3090 at 42), so a `lead` tap (barrier, DMA issue for the next pair, its first A
+    // fragments read fresh) is followed by a `follow` tap that runs straight on from registers: its B fragments and first A
+    // fragments were read behind the lead's MFMAs (both weight slots of a pair land before its barrier).  1x1 kernels (every
+    // tap opens a chunk) keep one barrier per tap with counted waits and read the next tap's first A fragments across it.
+    // SPREAD (3x3): the copies of a pair are not issued in one burst behind the barrier -- eight waves x ~5 KB at once queue up in
+    // front of the CU's one-line-per-clock vector memory path (~40 KB = ~650 cycles during which every wave that has a copy to issue
+    // stands still, and both waves of a SIMD do so together) -- but piecewise between the MFMA groups of the lead tap: the next
+    // pair's first weight slot after channel-tile pair 0, its second after pair 1, the input box (when a chunk opens) after pair 2.
+    constexpr bool TWO = TAPS > 1;
+#ifndef FSC_L16_SPREAD
+#define FSC_L16_SPREAD 1
+#endif
+    constexpr bool SPREAD = TWO && FSC_L16_SPREAD != 0;
+    auto step = [&](bool lead, bool has_follow, const Frag& bcur, Frag& bnxt, const AFrag& acur, AFrag& anxt) {
+        bool opens = false;
+        AFrag t0, t1, af;
+        PROF_MARK();
+        if (!TWO) {
+            if (!first_step) {
+                // the barrier covers W(S+1) (issued two steps ago); W(S+2) may stay in flight.  Stores share the counter and
+                // retire out of order, and a dry weight producer leaves nothing younger: drain then.
+                if (drain) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NWLO) : "memory");
+                raw_barrier();
+            }
+            first_step = false;
+            produce_i();
+            drain = !produce_w();
+        } else if (lead) {
+            if (!first_step) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // everything issued a pair ago has landed (weights of this
+                raw_barrier();                                       // pair, a young input box, the previous item's stores)
+            }
+            PROF_ADD(0);
+#ifndef FSC_L16_EARLY_A
+#define FSC_L16_EARLY_A 1
+#endif
+            if (FSC_L16_EARLY_A) {        // this tap's first A fragments are on their way while the scalar bookkeeping below runs
+                read_a(reinterpret_cast<const u32x4*>(wring + slot * WSLOT_F) + lane, 0, af);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            first_step = false;
+            // weights of the NEXT pair into the two slots the previous pair used; the input box DAHEAD chunks ahead when a
+            // chunk opens in either tap of this pair
+            opens = sc == 0 || (has_follow && sc + 1 == nst);
+            if (!SPREAD) {
+                produce_w();
+                if (has_follow) produce_w();
+                if (opens) produce_i();
+            }
+        }
+        // the next step and the byte offset of its B operand
+        int noff;
+        {
+            int sn = sc + 1;
+            if (sn < nst) {
+                noff = b_off(stg, c, sn);
+            } else {                                        // first step of the next chunk (of the next item at the end)
+                sn = 0;
+                stg = stg == NSTG - 1 ? 0 : stg + 1;
+                c = c + 1 < nchunks ? c + 1 : 0;
+                nst = c < g.nfull ? TAPS : g.tail_steps;
+                noff = b_off(stg, c, 0);
+            }
+            sc = sn;
+        }
+        const u32x4* wl = reinterpret_cast<const u32x4*>(wring + slot * WSLOT_F) + lane;
+        slot = slot == RING - 1 ? 0 : slot + 1;
+        const u32x4* wln = reinterpret_cast<const u32x4*>(wring + slot * WSLOT_F) + lane;
+        const bool fresh_a = TWO && lead;                    // (uniform) this tap's first pair is read now, behind the barrier
+        const bool next_a = TWO ? (lead && has_follow) : true;   // the next tap's first pair can be read at the end of this one
+        if (fresh_a && !FSC_L16_EARLY_A) read_a(wl, 0, af);
+        PROF_ADD(1);
+        constexpr int kLa[3] = {1, 0, 0}, kLb[3] = {0, 1, 0};     // (A limb, B limb): l*h, h*l, h*h -- smallest first
+#pragma unroll
+        for (int pr = 0; pr < NPAIR; ++pr) {
+            const AFrag& a = pr == 0 ? (fresh_a ? af : acur) : (pr & 1) ? t1 : t0;
+            AFrag& an = pr + 1 == NPAIR ? anxt : (pr & 1) ? t0 : t1;
+            // reads behind this pair's MFMAs: the next pair's A fragments (the next tap's first pair from the next slot at
+            // the end) and, with the first pair, the next tap's B fragments
+            if (pr + 1 < NPAIR) read_a(wl, pr + 1, an);
+            else if (next_a) read_a(wln, 0, an);
+            if (pr == 0) read_b(noff, bnxt);
+            const int ntile = pr * 2 + 1 < COT ? 2 : 1;
+#pragma unroll
+            for (int gq = 0; gq < 3; ++gq)
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const int i = pr * 2 + t;
+                    if (i < COT) {
+#pragma unroll
+                        for (int j = 0; j < PT; ++j) acc[i][j] = mfma16(a.v[t][kLa[gq]], bcur.v[kLb[gq]][j], acc[i][j]);
+                    }
+                }
+            // one LDS read behind each of the first MFMAs of the pair
+            const int nrd = (pr + 1 < NPAIR ? (((pr + 1) * 2 + 1 < COT) ? 4 : 2) : (COT > 1 ? 4 : 2)) + (pr == 0 ? 2 * PT : 0);
+#pragma unroll
+            for (int k = 0; k < 3 * ntile * PT; ++k) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                  // one MFMA
+                if (k < nrd) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);     // one LDS read
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (SPREAD && lead) {
+                if (pr == 0) produce_w();
+                if (pr == (NPAIR > 1 ? 1 : 0) && has_follow) produce_w();
+                if (pr == (NPAIR > 2 ? 2 : NPAIR - 1) && opens) produce_i();
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        PROF_ADD(2);
+#ifdef FSC_L16_PROFILE
+        pf_acc[4] += 1;
+#endif
+    };
+
+    const bool add_bias = bias != nullptr;
+    for (; item < ntiles; item += ts) {
+        const int tile = item;
+        const int co0 = cb_w * CO_BLK;
+#pragma unroll 1
+        for (int S = 0; S + 1 < g.steps; S += 2) {
+            step(true, true, fb0, fb1, fa0, fa1);
+            step(false, false, fb1, fb0, fa1, fa0);
+        }
+        if (g.steps & 1) {                                  // odd number of steps: the next item starts from fb0 / fa0 again
+            step(true, false, fb0, fb1, fa0, fa1);
+            fb0 = fb1;
+            fa0 = fa1;
+        }
+
+        PROF_MARK();
+        if constexpr (POOL) {
+            // ---- pooled epilogue.  After the shuffles the four even lanes lm = 0, 2, 4, 6 of a column group hold the pooled
+            //      value and window index of 4 channels x one window; through the scratch tile lane L = (channel L >> 2,
+            //      window L & 3) stores four bytes of four consecutive pooled pixels of a channel.
+            int t = tile;
+            const int twi = t % g.tiles_w; t /= g.tiles_w;
+            const int thi = t % g.tiles_h; t /= g.tiles_h;
+            const int n0 = t * g.nb, h0 = thi * g.th, w0 = twi * g.tw;
+            const int oh = g.h >> 1, ow = g.w >> 1;
+            const int tpr = g.tw >> 3, tpi = (g.th >> 1) * tpr;
+            long pool_g[PT];                                // pooled offset (channel 0) of this lane's window; -1 = outside
+#pragma unroll
+            for (int pt = 0; pt < PT; ++pt) {
+                const int tt = wid * PT + pt;
+                pool_g[pt] = -1;
+                if (tt * 16 < g.npix) {
+                    const int b = tt / tpi, rem = tt - b * tpi;
+                    const int tr = rem / tpr, tc = rem - tr * tpr;
+                    const int pr = (h0 >> 1) + tr, pc = (w0 >> 1) + 4 * tc + (lane & 3);
+                    if (n0 + b < g.n && pr < oh && pc < ow) pool_g[pt] = ((long)(n0 + b) * g.cout * oh + pr) * ow + pc;
+                }
+            }
+            const long ohw = (long)oh * ow;
+            const float* bias_p = bias;
+            asm volatile("" : "+s"(bias_p));
+            const int chp = lane >> 2;
+#pragma unroll
+            for (int i = 0; i < COT; ++i) {
+                float bv[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int cob = co0 + i * 16 + kq * 4 + r;
+                    bv[r] = (bias_p != nullptr && cob < g.cout) ? bias_p[cob] : 0.f;
+                }
+                const int co = co0 + i * 16 + chp;
+                float pv = 0.f;
+                if (STATS && stat_pivot != nullptr && co < g.cout) pv = stat_pivot[co];
+#pragma unroll
+                for (int j = 0; j < PT; ++j) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float v0 = fmaf(acc[i][j][r] * inv_x, inv_w, bv[r]);
+                        const float v1 = dpp_xor1(v0);
+                        const float v2 = dpp_xor8(v0);
+                        const float v3 = dpp_xor8(v1);
+                        float best = v0;                     // first maximum in window order, NaN wins (fsc_maxpool_fwd)
+                        int bi = 0;
+                        if (v1 > best || v1 != v1) { best = v1; bi = 1; }
+                        if ((v2 > best || v2 != v2) && best == best) { best = v2; bi = 2; }
+                        if ((v3 > best || v3 != v3) && best == best) { best = v3; bi = 3; }
+                        if ((lm & 9) == 0) {                 // lanes lm = 0, 2, 4, 6: the window's first pixel
+                            scratch[(kq * 4 + r) * kScr + (lm >> 1)] = best;
+                            scratch[(kq * 4 + r) * kScr + 8 + (lm >> 1)] = __int_as_float(bi);
+                        }
+                    }
+                    const float val = scratch[chp * kScr + (lane & 3)];
+                    const int bidx = __float_as_int(scratch[chp * kScr + 8 + (lane & 3)]);
+                    if (co < g.cout && pool_g[j] >= 0) {
+                        out[pool_g[j] + (long)co * ohw] = val;
+                        pool_idx[pool_g[j] + (long)co * ohw] = (uint8_t)bidx;
+                        if (STATS) stat_add(i, val, pv);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int i = 0; i < COT; ++i)
+#pragma unroll
+                for (int j = 0; j < PT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            drain = true;
+            PROF_ADD(3);
+            continue;
+        }
+        // ---- epilogue: D row = channel (kq*4 + r), column = pixel (lm) -> scratch[ch][px] -> lane = (channel, quad).
+        //      This lane's quads (four consecutive pixels of a box row) are decoded here, once per item.
+        long quad_g[PT];
+        int quad_ok[PT];
+        {
+            int t = tile;
+            const int twi = t % g.tiles_w; t /= g.tiles_w;
+            const int thi = t % g.tiles_h; t /= g.tiles_h;
+            const int n0 = t * g.nb, h0 = thi * g.th, w0 = twi * g.tw;
+#pragma unroll
+            for (int pt = 0; pt < PT; ++pt) {
+                const int p = (wid * PT + pt) * 16 + (lane & 3) * 4;
+                quad_g[pt] = 0;
+                quad_ok[pt] = 0;
+                if (p < g.npix) {
+                    const int per = g.th * g.tw;
+                    const int b = fdiv(p, inv_thw), rem = p - b * per;
+                    const int r = fdiv(rem, inv_tw), cq = rem - r * g.tw;
+                    if (n0 + b < g.n && h0 + r < g.h) {
+                        quad_g[pt] = (long)(n0 + b) * g.cout * g.hw + (long)(h0 + r) * g.w + (w0 + cq);
+                        const int left = g.w - (w0 + cq), inbox = g.npix - p;
+                        const int nv = left < inbox ? left : inbox;
+                        quad_ok[pt] = nv >= 4 ? 15 : nv <= 0 ? 0 : (1 << nv) - 1;
+                    }
+                }
+            }
+        }
+        long hw_t = g.hw;
+        const float* bias_t = bias;
+        asm volatile("" : "+s"(hw_t), "+s"(bias_t));
+        const int ch = lane >> 2;
+#pragma unroll
+        for (int i = 0; i < COT; ++i) {
+            float bv[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int cob = co0 + i * 16 + kq * 4 + r;
+                bv[r] = (add_bias && cob < g.cout) ? bias_t[cob] : 0.f;
+            }
+            const int co = co0 + i * 16 + ch;
+            float pv = 0.f;
+            if (STATS && stat_pivot != nullptr && co < g.cout) pv = stat_pivot[co];
+#pragma unroll
+            for (int j = 0; j < PT; ++j) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) scratch[(kq * 4 + r) * kScr + lm] = fmaf(acc[i][j][r] * inv_x, inv_w, bv[r]);
+                const f32x4 v = *reinterpret_cast<const f32x4*>(scratch + ch * kScr + (lane & 3) * 4);
+                if (STATS && co < g.cout && quad_ok[j]) {
+                    if (quad_ok[j] == 15) {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) stat_add(i, v[k], pv);
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k)
+                            if (quad_ok[j] & (1 << k)) stat_add(i, v[k], pv);
+                    }
+                }
+                if (co < g.cout && quad_ok[j]) {
+                    float* o = out + quad_g[j] + (long)co * hw_t;
+                    if (!accumulate && quad_ok[j] == 15) {
+                        *reinterpret_cast<f32x4*>(o) = v;
+                    } else if (quad_ok[j] == 15) {
+                        const f32x4 old = *reinterpret_cast<const f32x4*>(o);
+                        *reinterpret_cast<f32x4*>(o) = old + v;
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k)
+                            if (quad_ok[j] & (1 << k)) o[k] = accumulate ? o[k] + v[k] : v[k];
+                    }
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int i = 0; i < COT; ++i)
+#pragma unroll
+            for (int j = 0; j < PT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        drain = true;                                       // (1x1) the stores above share the DMA counter
+        PROF_ADD(3);
+    }
+#ifdef FSC_L16_PROFILE
+    if (blockIdx.x == 0 && lane == 0) {
+        pf_acc[5] = prof_now() - pf_k0;
+        pf_acc[6] = __builtin_amdgcn_s_memrealtime() - pf_r0;          // constant 100 MHz reference clock
+        for (int i = 0; i < 7; ++i) atomicAdd(&g_l16_prof[wid][i], pf_acc[i]);
+    }
+#endif
+    if (blockIdx.x == 0 && tid == 0) {
+        g_l16_clock[0] = __builtin_readcyclecounter() - ck0;
+        g_l16_clock[1] = __builtin_amdgcn_s_memrealtime() - cr0;
+    }
+    if constexpr (STATS) {
+        // the four lanes of a quad hold the same channel: fold them, lane (lane & 3) == 0 writes the record
+#pragma unroll
+        for (int i = 0; i < COT; ++i) {
+            float a = st_s1[i], b = st_s2[i], mn = st_mn[i], mx = st_mx[i];
+            a += dpp_xor1(a); a += dpp_xor2(a);
+            b += dpp_xor1(b); b += dpp_xor2(b);
+            mn = fminf(mn, dpp_xor1(mn)); mn = fminf(mn, dpp_xor2(mn));
+            mx = fmaxf(mx, dpp_xor1(mx)); mx = fmaxf(mx, dpp_xor2(mx));
+            if ((lane & 3) == 0)
+                stat_rec[((long)blockIdx.x * kWaves + wid) * CO_BLK + i * 16 + (lane >> 2)] = make_float4(a, b, mn, mx);
+        }
+    }
+}
+
+struct LPlan {
+    LGeom g;
+    int cot, pt, co_blocks;
+    size_t lds_bytes;
+    long tiles, workers;
+};
+
+}  // namespace
