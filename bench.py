@@ -140,6 +140,81 @@ def cpu_baseline(w, steps=3, batch=8):
                        "(median), %s" % (batch, steps, cpu_model))
 
 
+def price_kernel(name):
+    """(peak TFLOP/s, executed 16-bit MFMA flops per algorithmic fp32 flop, arithmetic) of a timed conv kernel, by its plan name.
+    Split kernels (`..._x3_kernel<..., NPROD>`, `conv_l16_*`): every algorithmic fp32 flop costs NPROD 16-bit MFMA flops, so the
+    achieved rate counts EXECUTED 16-bit flops and is priced against the dense fp16 / bf16 peak."""
+    if "conv_l16_" in name:            # pre-split (L16) operands: the 2-limb fp16 arithmetic, 3 products
+        return PEAK_BF16_MFMA_TFLOPS, 3, ("fp32 via 2-limb fp16 split with per-tensor power-of-two scaling (operands pre-split by their "
+                                          "producers: L16 tensors), 3 fp16 MFMA products per fp32 product, fp32 accumulate")
+    if "_x3_kernel" in name:
+        per = int(name.rstrip(">").split(",")[-1])
+        arith = "fp32 via exact 3-limb bf16 split, %d bf16 MFMA products per fp32 product, fp32 accumulate" % per
+        if per == 1:
+            arith = "bf16 operands (one rounding each), bf16 MFMA, fp32 accumulate"
+        if per == 3:                   # (the dense fp16 and bf16 MFMA peaks are equal)
+            arith = "fp32 via 2-limb fp16 split with per-tensor power-of-two scaling, 3 fp16 MFMA products per fp32 product, fp32 accumulate"
+        return PEAK_BF16_MFMA_TFLOPS, per, arith
+    return PEAK_F32_MFMA_TFLOPS, 1, "native fp32 MFMA"
+
+
+def cpu_baseline_inference(w, batch=8, runs=2):
+    """cfg 5 on the host cores: the oracle's eval-mode forward of one batch of `batch` 10 s clips through five fold models
+    (1 warm-up + `runs` timed passes, median) -> clips/s through the whole ensemble."""
+    from oracle import ref_torch as oref
+    cores = physical_cores()
+    torch.set_num_threads(cores)
+    folds = w["inference"]["folds"]
+    models = []
+    for fold in range(folds):
+        torch.manual_seed(100 + fold)
+        models.append(oref.TagCNN2d(w["features"], w["blocks"], w["base"], w["growth"], w["start"], 80,
+                                    output_dropout=w["dropout"]).eval())
+    signal, _ = synthetic_batch(w, batch, torch.device("cpu"), 99)
+    times = []
+    with torch.no_grad():
+        for i in range(runs + 1):
+            t0 = time.perf_counter()
+            acc = None
+            for m in models:
+                p = torch.sigmoid(m(signal)["class_logits"])
+                acc = p if acc is None else acc + p
+            times.append(time.perf_counter() - t0)
+    times = sorted(times[1:])
+    med = times[len(times) // 2]
+    return dict(value=batch / med, unit="clips/s", cores=cores, kind="port",
+                sample="oracle eval-mode forward of %d x 10 s clips through %d fold models (sigmoid mean), 1 warm-up + %d timed "
+                       "passes (median)" % (batch, folds, runs))
+
+
+def run_other_workloads():
+    """cfg 3 and cfg 5 as short runs of this script in fresh processes (N = 1), so that the driver's default invocation also observes
+    them: their one-line results, trimmed, go into `other_workloads` of the cfg-2 line.  ~1 minute."""
+    import subprocess
+    out = {}
+    for name, extra in (("cfg3", ["--steps", "20", "--warmup", "5"]), ("cfg5", ["--warmup", "2"])):
+        cmd = [sys.executable, os.path.abspath(__file__), "--workload", name, "--no-cpu-baseline", "--no-alt", "--no-other"] + extra
+        try:
+            r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600, cwd=ROOT)
+            line = [l for l in r.stdout.decode().splitlines() if l.startswith("{")]
+            if r.returncode != 0 or not line:
+                out[name] = {"error": "rc %d: %s" % (r.returncode, r.stderr.decode()[-300:])}
+                continue
+            d = json.loads(line[-1])
+        except Exception as e:                                  # a failed side measurement must not take the cfg-2 line down
+            out[name] = {"error": repr(e)[:300]}
+            continue
+        roof = d.get("roofline") or {}
+        out[name] = {"metric": d["metric"], "value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"], "steps": d["steps"],
+                     "dtype": d["dtype"], "scaling": d["scaling"], "workload": d["config"]["workload"],
+                     "roofline": {k: roof.get(k) for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "launches_per_step",
+                                                           "avg_launch_ms", "conv_ms_per_step", "stages") if k in roof}}
+        for k in ("final_loss", "audio_seconds_per_s", "abi_calls_per_step"):
+            if k in d:
+                out[name][k] = d[k]
+    return out
+
+
 def run_inference(args, w, device, world, rank):
     """cfg 5: length-grouped fold-ensemble inference (reference predict_2d_cnn.py:72-125, README.md:37).  All fold
     weight sets and all padded batches are resident in HBM before the timed region; batches are dealt round-robin to
@@ -229,12 +304,22 @@ def run_inference(args, w, device, world, rank):
         if timer is not None:
             summ = timer.summary()
             dom_name, dom = max(summ.items(), key=lambda kv: kv[1]["ms"])
-            per = 3 if dom_name.endswith(",3>") else 1
-            peak = PEAK_BF16_MFMA_TFLOPS if per == 3 else PEAK_F32_MFMA_TFLOPS
+            peak, per, arith = price_kernel(dom_name)
             ach = dom["flops"] / dom["ms"] / 1e9
+            fam = {}
+            for name, r in summ.items():
+                f = fam.setdefault(name.split("<")[0], dict(flops=0.0, ms=0.0))
+                f["flops"] += r["flops"]
+                f["ms"] += r["ms"]
             result["roofline"] = {"kernel": dom_name, "bound": "mfma", "achieved": ach * per, "peak": peak, "unit": "TFLOP/s",
-                                  "frac": ach * per / peak, "traffic": None, "algorithmic_fp32_tflops": ach,
+                                  "frac": ach * per / peak, "traffic": None, "arithmetic": arith, "algorithmic_fp32_tflops": ach,
+                                  "launches_per_step": dom["launches"] / n_steps, "avg_launch_ms": dom["ms"] / dom["launches"],
+                                  "algorithmic_gflop_per_launch": dom["flops"] / dom["launches"] / 1e9,
+                                  "conv_ms_per_step": {k: v["ms"] / n_steps for k, v in fam.items()},
+                                  "conv_tflops": {k: v["flops"] / v["ms"] / 1e9 for k, v in fam.items()},
                                   "conv_ms_total": sum(v["ms"] for v in summ.values()), "wall_ms": 1e3 * elapsed}
+        if world == 1 and not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline_inference(w)
         _emit(json.dumps(result))
     if dist.is_initialized():
         dist.destroy_process_group()
@@ -316,6 +401,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-alt", action="store_true", help="skip the extra native-fp32-MFMA measurement (alt_f32)")
     ap.add_argument("--no-kernel-timer", action="store_true")
+    ap.add_argument("--no-other", action="store_true", help="skip the short cfg3 / cfg5 runs attached to the default cfg2 line (other_workloads)")
     ap.add_argument("--kernel-table", action="store_true", help="print per-kernel timing to stderr")
     ap.add_argument("--arith", default=None, choices=["f32", "bf16", "f16x3", "bf16x6", "bf16x9"],
                     help="conv arithmetic (default: the workload's, else the library default f16x3)")
@@ -404,6 +490,7 @@ def main():
     if world > 1:
         dist.barrier()
     F.TIMER = timer
+    calls0 = F._lib.CALLS[0]
     t0 = time.perf_counter()
     for _ in range(args.steps):
         logits, per, loss = one_step()
@@ -412,6 +499,7 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - t0
     F.TIMER = None
+    abi_calls = (F._lib.CALLS[0] - calls0) / max(1, args.steps)
     per_rank = None
     exchange = None
     if world > 1:
@@ -464,6 +552,24 @@ def main():
         h2d = {"value": batch * k_h / e_h, "unit": "clips/s", "steps": k_h, "ms_per_step": 1e3 * e_h / k_h,
                "h2d_bytes_per_step": pinned.numel() * 4,
                "note": "host->device copy of the waveform batch inside the timed region (pinned, double-buffered, copy stream)"}
+    # The same step with the L16 weight-gradient kernels on a side stream beside the next layer's BatchNorm backward passes
+    # (functional.L16_WGRAD_SIDE; off in the timed region so that the per-kernel event times behind `roofline` are those of kernels
+    # running alone).  N = 1 only, outside the timed region of `value`.
+    side = None
+    if world == 1 and not args.no_alt and hasattr(F, "L16_WGRAD_SIDE") and not F.L16_WGRAD_SIDE and not w.get("dims"):
+        F.L16_WGRAD_SIDE = True
+        for _ in range(2):
+            one_step()
+        torch.cuda.synchronize()
+        k_side = max(2, min(args.steps, 10))
+        t3 = time.perf_counter()
+        for _ in range(k_side):
+            one_step()
+        torch.cuda.synchronize()
+        e_side = time.perf_counter() - t3
+        F.L16_WGRAD_SIDE = False
+        side = {"value": batch * k_side / e_side, "unit": "clips/s", "steps": k_side, "ms_per_step": 1e3 * e_side / k_side,
+                "note": "L16 weight-gradient kernels on a side stream (FSC_L16_WGRAD_SIDE=1), overlapping the HBM-bound BatchNorm backward"}
     # The same workload with the native fp32-MFMA conv kernels (FSC_CONV_ARITH=f32), for readers who want the
     # number without the split-limb arithmetic; N = 1 only, outside the timed region of `value`.
     alt = None
@@ -541,6 +647,7 @@ def main():
                        "global_batch": world * batch, "parallelism": "dp%d" % world,
                        "conv_arith": {0: "f32", 1: "bf16", 3: "f16x3", 6: "bf16x6", 9: "bf16x9"}[F.get_conv_arith()]},
             "final_loss": final_loss,
+            "abi_calls_per_step": abi_calls,           # entry-point calls of libfsc_hip.so per step (each enqueues one to three kernels)
         }
         if timer is not None:
             summ = timer.summary()
@@ -561,23 +668,7 @@ def main():
             if os.path.exists(tpath):
                 with open(tpath) as f:
                     traffic = json.load(f).get(dom_name)
-            # split kernels (name ..._x3_kernel<..., NPROD>): every algorithmic fp32 flop costs NPROD 16-bit
-            # MFMA flops, so `achieved` counts EXECUTED 16-bit flops and is priced against the dense fp16 / bf16 peak
-            peak, executed_per_flop, arith = PEAK_F32_MFMA_TFLOPS, 1, "native fp32 MFMA"
-            if "conv_l16_" in dom_name:        # pre-split (L16) operands: the same 2-limb fp16 arithmetic, 3 products
-                executed_per_flop = 3
-                peak = PEAK_BF16_MFMA_TFLOPS
-                arith = ("fp32 via 2-limb fp16 split with per-tensor power-of-two scaling (operands pre-split by their "
-                         "producers: L16 tensors), 3 fp16 MFMA products per fp32 product, fp32 accumulate")
-            elif "_x3_kernel" in dom_name:
-                executed_per_flop = int(dom_name.rstrip(">").split(",")[-1])
-                peak = PEAK_BF16_MFMA_TFLOPS
-                arith = "fp32 via exact 3-limb bf16 split, %d bf16 MFMA products per fp32 product, fp32 accumulate" % executed_per_flop
-                if executed_per_flop == 1:
-                    arith = "bf16 operands (one rounding each), bf16 MFMA, fp32 accumulate"
-                if executed_per_flop == 3:      # (the dense fp16 and bf16 MFMA peaks are equal)
-                    arith = ("fp32 via 2-limb fp16 split with per-tensor power-of-two scaling, 3 fp16 MFMA products "
-                             "per fp32 product, fp32 accumulate")
+            peak, executed_per_flop, arith = price_kernel(dom_name)
             result["roofline"] = {
                 "kernel": dom_name, "bound": "mfma", "achieved": achieved * executed_per_flop, "peak": peak,
                 "unit": "TFLOP/s", "frac": achieved * executed_per_flop / peak, "traffic": traffic,
@@ -609,8 +700,15 @@ def main():
             result["config"]["strict_f32_clips_per_s"] = alt["value"]      # the same step on the native fp32-MFMA kernels
         if h2d is not None:
             result["with_h2d"] = h2d
+        if side is not None:
+            result["with_side_stream_wgrad"] = side
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(w)
+        if world == 1 and args.workload == "cfg2" and not args.no_other and not args.no_alt and args.batch is None:
+            del model, signal, logits, per, loss               # the side runs get the whole GPU
+            F.forget_packed_weights()
+            torch.cuda.empty_cache()
+            result["other_workloads"] = run_other_workloads()
         _emit(json.dumps(result))
     if dist.is_initialized():
         dist.destroy_process_group()

@@ -177,8 +177,12 @@ def ptr(t):
     return t.data_ptr()
 
 
+CALLS = [0]          # entry-point calls so far (bench.py reports calls per step: the launch-bound workloads are priced by it)
+
+
 def call(name, *args):
     lib = load()
+    CALLS[0] += 1
     rc = getattr(lib, name)(*args)
     if rc != 0:
         raise FscError("%s failed (%d): %s" % (name, rc, lib.fsc_last_error_string().decode()))
