@@ -552,24 +552,6 @@ def main():
         h2d = {"value": batch * k_h / e_h, "unit": "clips/s", "steps": k_h, "ms_per_step": 1e3 * e_h / k_h,
                "h2d_bytes_per_step": pinned.numel() * 4,
                "note": "host->device copy of the waveform batch inside the timed region (pinned, double-buffered, copy stream)"}
-    # The same step with the L16 weight-gradient kernels on a side stream beside the next layer's BatchNorm backward passes
-    # (functional.L16_WGRAD_SIDE; off in the timed region so that the per-kernel event times behind `roofline` are those of kernels
-    # running alone).  N = 1 only, outside the timed region of `value`.
-    side = None
-    if world == 1 and not args.no_alt and hasattr(F, "L16_WGRAD_SIDE") and not F.L16_WGRAD_SIDE and not w.get("dims"):
-        F.L16_WGRAD_SIDE = True
-        for _ in range(2):
-            one_step()
-        torch.cuda.synchronize()
-        k_side = max(2, min(args.steps, 10))
-        t3 = time.perf_counter()
-        for _ in range(k_side):
-            one_step()
-        torch.cuda.synchronize()
-        e_side = time.perf_counter() - t3
-        F.L16_WGRAD_SIDE = False
-        side = {"value": batch * k_side / e_side, "unit": "clips/s", "steps": k_side, "ms_per_step": 1e3 * e_side / k_side,
-                "note": "L16 weight-gradient kernels on a side stream (FSC_L16_WGRAD_SIDE=1), overlapping the HBM-bound BatchNorm backward"}
     # The same workload with the native fp32-MFMA conv kernels (FSC_CONV_ARITH=f32), for readers who want the
     # number without the split-limb arithmetic; N = 1 only, outside the timed region of `value`.
     alt = None
@@ -700,8 +682,6 @@ def main():
             result["config"]["strict_f32_clips_per_s"] = alt["value"]      # the same step on the native fp32-MFMA kernels
         if h2d is not None:
             result["with_h2d"] = h2d
-        if side is not None:
-            result["with_side_stream_wgrad"] = side
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(w)
         if world == 1 and args.workload == "cfg2" and not args.no_other and not args.no_alt and args.batch is None:
