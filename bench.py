@@ -192,8 +192,8 @@ def run_other_workloads():
     them: their one-line results, trimmed, go into `other_workloads` of the cfg-2 line.  ~1 minute."""
     import subprocess
     out = {}
-    for name, extra in (("cfg3", ["--steps", "20", "--warmup", "5"]), ("cfg5", ["--warmup", "2"])):
-        cmd = [sys.executable, os.path.abspath(__file__), "--workload", name, "--no-cpu-baseline", "--no-alt", "--no-other"] + extra
+    for name, extra in (("cfg3", ["--steps", "20", "--warmup", "5"]), ("cfg5", ["--warmup", "2", "--no-alt"])):
+        cmd = [sys.executable, os.path.abspath(__file__), "--workload", name, "--no-cpu-baseline", "--no-other"] + extra
         try:
             r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600, cwd=ROOT)
             line = [l for l in r.stdout.decode().splitlines() if l.startswith("{")]
@@ -209,7 +209,7 @@ def run_other_workloads():
                      "dtype": d["dtype"], "scaling": d["scaling"], "workload": d["config"]["workload"],
                      "roofline": {k: roof.get(k) for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "launches_per_step",
                                                            "avg_launch_ms", "conv_ms_per_step", "stages") if k in roof}}
-        for k in ("final_loss", "audio_seconds_per_s", "abi_calls_per_step"):
+        for k in ("final_loss", "audio_seconds_per_s", "abi_calls_per_step", "hip_graph"):
             if k in d:
                 out[name][k] = d[k]
     return out
@@ -401,6 +401,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-alt", action="store_true", help="skip the extra native-fp32-MFMA measurement (alt_f32)")
     ap.add_argument("--no-kernel-timer", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="cfg3: eager steps instead of the recorded HIP graph (CapturedTrainingStep)")
     ap.add_argument("--no-other", action="store_true", help="skip the short cfg3 / cfg5 runs attached to the default cfg2 line (other_workloads)")
     ap.add_argument("--kernel-table", action="store_true", help="print per-kernel timing to stderr")
     ap.add_argument("--arith", default=None, choices=["f32", "bf16", "f16x3", "bf16x6", "bf16x9"],
@@ -465,6 +466,8 @@ def main():
 
     mix_rng = __import__("numpy").random.RandomState(7 + rank)
 
+    step_fn = [model.training_step]
+
     def one_step():
         model.global_step += 1
         make_step(model.scheduler, step=model.global_step)
@@ -479,12 +482,25 @@ def main():
             mixed, y = F.mixup_batch(signal.squeeze(-1), signal.squeeze(-1)[partner].contiguous(), [t] * batch, [t] * batch,
                                      [0] * batch, mix_rng.uniform(0.4, 0.6, size=batch), labels, labels[partner].contiguous())
             x = mixed.unsqueeze(-1)
-        return model.training_step(x, y)
+        return step_fn[0](x, y)
 
     for _ in range(args.warmup):
         one_step()
+    # Launch-bound workload (cfg 3: ~510 entry-point calls per step, 9 ms of host time for ~5 ms of kernels): the step is recorded
+    # once as a HIP graph and replayed (ops/training.py CapturedTrainingStep: same entry points, same arguments, same order; the
+    # learning rate / step count travel through device memory).  MixUp stays outside (its draws are host-side).  The per-kernel
+    # times behind `roofline` then come from a few eager steps AFTER the timed region.
+    use_graph = (w.get("dims") == 1 and float(w["dropout"]) == 0.0 and world == 1 and not args.no_graph
+                 and os.environ.get("FSC_FORCE_DP") != "1")
+    captured = None
+    if use_graph:
+        from freesound_classification_amd.ops.training import CapturedTrainingStep
+        captured = CapturedTrainingStep(model, signal, labels)
+        step_fn[0] = captured
+        for _ in range(2):
+            one_step()
     timer = None
-    if not args.no_kernel_timer:
+    if not args.no_kernel_timer and not use_graph:
         timer = F.KernelTimer()
     torch.cuda.synchronize()
     if world > 1:
@@ -500,6 +516,26 @@ def main():
     elapsed = time.perf_counter() - t0
     F.TIMER = None
     abi_calls = (F._lib.CALLS[0] - calls0) / max(1, args.steps)
+    timer_steps = args.steps
+    graph_info = None
+    if use_graph:
+        captured.sync_state()
+        step_fn[0] = model.training_step
+        graph_info = {"replayed": True, "abi_calls_per_replayed_step": abi_calls}
+        if not args.no_kernel_timer:                     # per-kernel attribution: eager steps, outside the timed region
+            one_step()
+            torch.cuda.synchronize()
+            timer = F.KernelTimer()
+            timer_steps = 5
+            F.TIMER = timer
+            calls0 = F._lib.CALLS[0]
+            t_e = time.perf_counter()
+            for _ in range(timer_steps):
+                one_step()
+            torch.cuda.synchronize()
+            graph_info["eager_ms_per_step"] = 1e3 * (time.perf_counter() - t_e) / timer_steps
+            F.TIMER = None
+            abi_calls = (F._lib.CALLS[0] - calls0) / timer_steps
     per_rank = None
     exchange = None
     if world > 1:
@@ -629,8 +665,10 @@ def main():
                        "global_batch": world * batch, "parallelism": "dp%d" % world,
                        "conv_arith": {0: "f32", 1: "bf16", 3: "f16x3", 6: "bf16x6", 9: "bf16x9"}[F.get_conv_arith()]},
             "final_loss": final_loss,
-            "abi_calls_per_step": abi_calls,           # entry-point calls of libfsc_hip.so per step (each enqueues one to three kernels)
+            "abi_calls_per_step": abi_calls,           # entry-point calls of libfsc_hip.so per (eager) step (each enqueues one to three kernels)
         }
+        if graph_info is not None:
+            result["hip_graph"] = graph_info
         if timer is not None:
             summ = timer.summary()
             fam = {}
@@ -642,7 +680,7 @@ def main():
             if args.kernel_table:
                 for name, r in sorted(summ.items(), key=lambda kv: -kv[1]["ms"]):
                     print("%-36s launches %5d  ms/step %8.3f  TFLOP/s %7.2f" % (
-                        name, r["launches"], r["ms"] / args.steps, r["flops"] / r["ms"] / 1e9), file=sys.stderr)
+                        name, r["launches"], r["ms"] / timer_steps, r["flops"] / r["ms"] / 1e9), file=sys.stderr)
             dom_name, dom = max(summ.items(), key=lambda kv: kv[1]["ms"])
             achieved = dom["flops"] / dom["ms"] / 1e9          # TFLOP/s
             traffic = None
@@ -655,10 +693,10 @@ def main():
                 "kernel": dom_name, "bound": "mfma", "achieved": achieved * executed_per_flop, "peak": peak,
                 "unit": "TFLOP/s", "frac": achieved * executed_per_flop / peak, "traffic": traffic,
                 "arithmetic": arith, "algorithmic_fp32_tflops": achieved,
-                "launches_per_step": dom["launches"] / args.steps,
+                "launches_per_step": dom["launches"] / timer_steps,
                 "avg_launch_ms": dom["ms"] / dom["launches"],
                 "algorithmic_gflop_per_launch": dom["flops"] / dom["launches"] / 1e9,
-                "conv_ms_per_step": {k: v["ms"] / args.steps for k, v in fam.items()},
+                "conv_ms_per_step": {k: v["ms"] / timer_steps for k, v in fam.items()},
                 "conv_tflops": {k: v["flops"] / v["ms"] / 1e9 for k, v in fam.items()},
             }
             if stages:

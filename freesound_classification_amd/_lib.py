@@ -118,6 +118,8 @@ SIGNATURES = {
     "fsc_gru_step_fwd": (_I, [_P, _L, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P]),
     "fsc_gru_step_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _L, _P, _P, _I, _I, _P]),
     "fsc_adam_amsgrad_step": (_I, [C.POINTER(OptTensor), _I, _F, _F, _F, _F, _F, _I, _F, _P]),
+    "fsc_adam_step_factors": (None, [_F, _F, _F, _I, C.POINTER(C.c_float)]),
+    "fsc_adam_amsgrad_step_dev": (_I, [C.POINTER(OptTensor), _I, _P, _F, _F, _F, _F, _F, _P]),
     "fsc_sgd_nesterov_step": (_I, [C.POINTER(OptTensor), _I, _F, _F, _F, _I, _F, _P]),
     "fsc_plane_border_sums": (_I, [_P, _I, _I, _I, _I, _P, _P]),
     "fsc_fill": (_I, [_P, _F, _L, _P]),

@@ -20,6 +20,7 @@ struct Table {
 
 struct AdamHyper {
     float beta1, beta2, eps, weight_decay, step_size, inv_bc2_sqrt, grad_scale;
+    const float* dev;        // non-null: {step_size, inv_bc2_sqrt} are read from device memory (a step recorded in a HIP graph)
 };
 
 struct SgdHyper {
@@ -44,6 +45,10 @@ __device__ __forceinline__ void adam_one(const AdamHyper& h, float& p, float g, 
 }
 
 __global__ __launch_bounds__(kThreads) void adam_kernel(Table tb, AdamHyper h) {
+    if (h.dev != nullptr) {
+        h.step_size = h.dev[0];
+        h.inv_bc2_sqrt = h.dev[1];
+    }
     const int ti = find_tensor(tb, blockIdx.x);
     const fsc_opt_tensor t = tb.t[ti];
     const long base = (long)(blockIdx.x - tb.chunk_start[ti]) * kChunk;
@@ -127,8 +132,22 @@ int fsc_adam_amsgrad_step(const fsc_opt_tensor* tensors_host, int n_tensors, flo
     FSC_CHECK_ARG(tensors_host && n_tensors > 0 && step >= 1, "fsc_adam_amsgrad_step: bad arguments");
     const double bc1 = 1.0 - pow((double)beta1, (double)step);
     const double bc2 = 1.0 - pow((double)beta2, (double)step);
-    AdamHyper h{beta1, beta2, eps, weight_decay, (float)((double)lr / bc1), (float)(1.0 / sqrt(bc2)), grad_scale};
+    AdamHyper h{beta1, beta2, eps, weight_decay, (float)((double)lr / bc1), (float)(1.0 / sqrt(bc2)), grad_scale, nullptr};
     return run(tensors_host, n_tensors, h, adam_kernel, true, fsc::as_stream(stream), "fsc_adam_amsgrad_step");
+}
+
+void fsc_adam_step_factors(float lr, float beta1, float beta2, int step, float* out2_host) {
+    const double bc1 = 1.0 - pow((double)beta1, (double)step);
+    const double bc2 = 1.0 - pow((double)beta2, (double)step);
+    out2_host[0] = (float)((double)lr / bc1);
+    out2_host[1] = (float)(1.0 / sqrt(bc2));
+}
+
+int fsc_adam_amsgrad_step_dev(const fsc_opt_tensor* tensors_host, int n_tensors, const float* factors_dev, float beta1,
+                              float beta2, float eps, float weight_decay, float grad_scale, fsc_stream_t stream) {
+    FSC_CHECK_ARG(tensors_host && n_tensors > 0 && factors_dev, "fsc_adam_amsgrad_step_dev: bad arguments");
+    AdamHyper h{beta1, beta2, eps, weight_decay, 0.f, 0.f, grad_scale, factors_dev};
+    return run(tensors_host, n_tensors, h, adam_kernel, true, fsc::as_stream(stream), "fsc_adam_amsgrad_step_dev");
 }
 
 int fsc_sgd_nesterov_step(const fsc_opt_tensor* tensors_host, int n_tensors, float lr, float momentum,

@@ -51,6 +51,7 @@ class FusedAdam(Optimizer):
                                       "(reference ops/training.py:10)")
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, amsgrad=amsgrad))
         self.grad_scale = 1.0
+        self.factors_dev = None      # set while a step is recorded into a HIP graph (CapturedTrainingStep): lr / step from device memory
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -89,8 +90,12 @@ class FusedAdam(Optimizer):
         from .. import functional as F
         # reads p, g, m, v, vmax and writes p, m, v, vmax: nine fp32 streams (776 MB per step at cfg 2)
         with F._stage("optimizer", 9 * 4 * sum(e[0].numel() for e in entries)):
-            call("fsc_adam_amsgrad_step", tbl, len(entries), float(group["lr"]), b1, b2, group["eps"],
-                 group["weight_decay"], int(step), float(self.grad_scale), stream_ptr())
+            if self.factors_dev is not None:
+                call("fsc_adam_amsgrad_step_dev", tbl, len(entries), self.factors_dev.data_ptr(), b1, b2, group["eps"],
+                     group["weight_decay"], float(self.grad_scale), stream_ptr())
+            else:
+                call("fsc_adam_amsgrad_step", tbl, len(entries), float(group["lr"]), b1, b2, group["eps"],
+                     group["weight_decay"], int(step), float(self.grad_scale), stream_ptr())
 
 
 class FusedSGD(Optimizer):
@@ -180,3 +185,69 @@ def make_step(scheduler, epoch=None, step=None, val_score=None):
         scheduler.step(epoch)
     elif isinstance(scheduler, OneCycleScheduler) and step is not None:
         scheduler.step()
+
+
+class CapturedTrainingStep:
+    """One training step of a model -- forward, loss, backward, optimizer -- recorded ONCE as a HIP graph and replayed per batch.
+
+    For launch-bound models (cfg 3: ~700 kernels of 5 - 50 us behind ~510 entry-point calls, 9 ms of Python per 13 ms step) the
+    replay removes the host from the step: the GPU runs the recorded kernels back to back.  Nothing about the arithmetic
+    changes -- the same entry points with the same arguments, in the same order -- so a replayed step equals the eager step bit
+    for bit except where the eager step itself is not reproducible (atomic channel sums).
+
+    What makes it legal: every entry point of libfsc_hip.so is capture-safe (include/fsc_hip.h); the step-dependent scalars of
+    Adam travel through two device floats (fsc_adam_amsgrad_step_dev) refreshed in front of each replay; BatchNorm counters
+    are bumped by a kernel.  What it needs: fixed batch shape, Adam, accumulation_steps == 1, no dropout (its counter-based
+    stream takes the offset by value), single GPU (no reducer), at least one eager step before (lazy state exists).
+    `model.training_step` semantics otherwise: returns (class_logits, per-sample loss, loss) -- static tensors, valid until
+    the next call.
+    """
+
+    def __init__(self, model, signal, labels):
+        opt = model.optimizer
+        if not isinstance(opt, FusedAdam):
+            raise _lib.FscError("CapturedTrainingStep needs the fused Adam optimizer")
+        if model._reducer is not None or model.config.train.accumulation_steps != 1:
+            raise _lib.FscError("CapturedTrainingStep: single GPU, accumulation_steps == 1")
+        if float(model.config.network.output_dropout) > 0.0:
+            raise _lib.FscError("CapturedTrainingStep: dropout draws from a host-side counter; capture needs output_dropout == 0")
+        if len(opt.param_groups) != 1 or not all(opt.state[p] for p in opt.param_groups[0]["params"] if p.requires_grad):
+            raise _lib.FscError("CapturedTrainingStep: run one eager training step first (optimizer state must exist)")
+        self.model, self.opt = model, opt
+        self.group = opt.param_groups[0]
+        self.step_count = int(next(iter(opt.state.values()))["step"])
+        self.signal = signal.clone()
+        self.labels = labels.clone()
+        self.factors = torch.zeros(2, device=signal.device, dtype=torch.float32)
+        self._buf = (C.c_float * 2)()
+        self.graph = torch.cuda.CUDAGraph()
+        stream = torch.cuda.Stream(device=signal.device)
+        stream.wait_stream(torch.cuda.current_stream(signal.device))
+        opt.zero_grad()
+        opt.factors_dev = self.factors
+        try:
+            with torch.cuda.graph(self.graph, stream=stream, capture_error_mode="relaxed"):
+                self.outputs = model.training_step(self.signal, self.labels)
+        finally:
+            opt.factors_dev = None
+        # the recording ran the step's Python (not its kernels): undo the one host-side effect, the step counters
+        for st in opt.state.values():
+            st["step"] = self.step_count
+        torch.cuda.current_stream(signal.device).wait_stream(stream)
+
+    def __call__(self, signal, labels):
+        self.signal.copy_(signal, non_blocking=True)
+        self.labels.copy_(labels, non_blocking=True)
+        self.step_count += 1
+        b1, b2 = self.group["betas"]
+        _lib.load().fsc_adam_step_factors(float(self.group["lr"]), b1, b2, self.step_count, self._buf)
+        # (by-value kernel arguments: no host buffer that a later call could overwrite before an earlier copy has run)
+        call("fsc_fill", self.factors.data_ptr(), float(self._buf[0]), 1, stream_ptr())
+        call("fsc_fill", self.factors.data_ptr() + 4, float(self._buf[1]), 1, stream_ptr())
+        self.graph.replay()
+        return self.outputs
+
+    def sync_state(self):
+        """Write the step count back into the optimizer's state (state_dict compatibility) -- call before saving."""
+        for st in self.opt.state.values():
+            st["step"] = self.step_count

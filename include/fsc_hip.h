@@ -452,6 +452,15 @@ typedef struct {
 int fsc_adam_amsgrad_step(const fsc_opt_tensor* tensors_host, int n_tensors, float lr,
                           float beta1, float beta2, float eps, float weight_decay, int step,
                           float grad_scale, fsc_stream_t stream);
+/* The same step with its two step-dependent factors read from DEVICE memory -- factors_dev[0] = lr / (1 - beta1^step),
+ * factors_dev[1] = 1 / sqrt(1 - beta2^step), as fsc_adam_step_factors computes them on the host -- so that a training step recorded
+ * once in a HIP graph (hipStreamBeginCapture around the step's calls; every entry point of this library is capture-safe: no
+ * allocation, no synchronisation, no host read-back) can be replayed with a moving learning rate and step count: the caller
+ * updates the two floats on the replay stream in front of each hipGraphLaunch. */
+void fsc_adam_step_factors(float lr, float beta1, float beta2, int step, float* out2_host);
+int fsc_adam_amsgrad_step_dev(const fsc_opt_tensor* tensors_host, int n_tensors, const float* factors_dev,
+                              float beta1, float beta2, float eps, float weight_decay, float grad_scale,
+                              fsc_stream_t stream);
 /* first_step != 0: momentum buffer := gradient (torch's first-step rule) */
 int fsc_sgd_nesterov_step(const fsc_opt_tensor* tensors_host, int n_tensors, float lr,
                           float momentum, float weight_decay, int first_step,

@@ -236,3 +236,81 @@ def test_training_step_repeats_within_atomic_summation_noise(arith):
     assert worst_l <= 1e-5 * max(1.0, float(l0.abs().max())), worst_l
     assert worst_g[0] <= 1e-3, worst_g
     model.close()
+
+
+def _small_1d(blocks=4, base=32, weight_decay=0.0):
+    from freesound_classification_amd.networks.classifiers import HierarchicalCNNClassificationModel
+
+    class NS(dict):
+        __getattr__ = dict.__getitem__
+
+    exp = NS(config=NS(
+        network=NS(num_conv_blocks=blocks, start_deep_supervision_on=1, conv_base_depth=base, growth_rate=1.25,
+                   output_dropout=0.0, aggregation_type="max"),
+        data=NS(features="stft_256_128", _input_dim=129, _n_classes=80),
+        train=NS(accumulation_steps=1, optimizer="adam", learning_rate=1e-3, weight_decay=weight_decay,
+                 scheduler="1cycle_0.0001_0.001", switch_off_augmentations_on=1000, _save_every=1000)))
+    return HierarchicalCNNClassificationModel(exp, device="cuda:0")
+
+
+@pytest.mark.parametrize("arith", ["f16x3", "bf16"])
+def test_captured_training_step_equals_the_eager_step(arith):
+    """ops/training.py CapturedTrainingStep: the training step recorded once as a HIP graph and replayed (bench.py cfg 3) is the
+    eager step -- same entry points, arguments and order; learning rate and step count through device memory.  Four steps
+    with a moving one-cycle rate and changing batches from the same state, eager against replayed: logits of every step, every
+    parameter and the BatchNorm statistics agree to within three times the distance between two EAGER runs from that state (atomic
+    channel sums; Adam turns a noise-level gradient -- a conv bias in front of a BatchNorm -- into a +-lr step) or 1e-4; the
+    optimizer's step counters read the same.  (Measured: logits 5e-6 apart in f16x3, eager against eager the same.)"""
+    from freesound_classification_amd.ops.training import CapturedTrainingStep, make_step
+    F.set_conv_arith(arith)
+    try:
+        torch.manual_seed(5)
+        model = _small_1d(weight_decay=0.01)
+        model.train()
+        model.global_step = 0
+        model.make_optimizer(max_steps=12)
+        gen = torch.Generator(device=DEV).manual_seed(3)
+        batches = [(0.1 * torch.randn(16, 44100, 1, device=DEV, generator=gen),
+                    (torch.rand(16, 80, device=DEV, generator=gen) < 0.05).float()) for _ in range(4)]
+        model.global_step += 1
+        make_step(model.scheduler, step=model.global_step)
+        model.training_step(*batches[0])                       # lazy state (optimizer moments, tables) exists
+        state = copy.deepcopy(model.state_dict())
+        ostate = copy.deepcopy(model.optimizer.state_dict())
+        step0, epoch0 = model.global_step, model.scheduler.epoch      # (the one-cycle scheduler counts its own calls)
+
+        def restore():
+            model.load_state_dict(state)                                # (in place: addresses stay)
+            model.optimizer.load_state_dict(copy.deepcopy(ostate))      # (replaces the state tensors: before a capture only)
+
+        def run(step_fn):
+            model.global_step, model.scheduler.epoch = step0, epoch0
+            logits = []
+            for x, y in batches:
+                model.global_step += 1
+                make_step(model.scheduler, step=model.global_step)
+                logits.append(step_fn(x, y)[0].detach().clone())
+            torch.cuda.synchronize()
+            return logits, copy.deepcopy(model.state_dict())
+
+        restore()
+        eager_logits, eager_state = run(model.training_step)
+        restore()
+        again_logits, again_state = run(model.training_step)           # the yard-stick: how far two eager runs are apart
+        restore()
+        captured = CapturedTrainingStep(model, *batches[0])
+        assert all(int(st["step"]) == 1 for st in model.optimizer.state.values())       # recording is not a step
+        replay_logits, replay_state = run(captured)
+        captured.sync_state()
+        assert all(int(st["step"]) == 5 for st in model.optimizer.state.values())
+        for k, (a, b, c2) in enumerate(zip(eager_logits, replay_logits, again_logits)):
+            assert torch.isfinite(b).all()
+            noise = float((a - c2).abs().max())
+            assert float((a - b).abs().max()) <= max(1e-4 * max(1.0, float(a.abs().max())), 3.0 * noise), (k, float((a - b).abs().max()), noise)
+        for k in eager_state:
+            a, b, c2 = eager_state[k].double(), replay_state[k].double(), again_state[k].double()
+            noise = float((a - c2).abs().max())
+            assert float((a - b).abs().max()) <= max(1e-4 * max(1.0, float(a.abs().max())), 3.0 * noise), (k, float((a - b).abs().max()), noise)
+        model.close()
+    finally:
+        F.set_conv_arith(None)
