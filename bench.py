@@ -47,9 +47,13 @@ WORKLOADS = {
     # (`--arith f32` or `f16x3` re-times the same workload in fp32).
     "cfg3": dict(features="stft_256_128", blocks=10, base=64, growth=1.25, start=1, dropout=0.0,
                  batch=128, samples=441000, sr=44100, n_mel=129, dims=1, mixup=0.5, arith="bf16",
-                 # the whole one-cycle schedule is squeezed into the ~26 steps of a bench run: at a 0.005 peak the 10-block model
-                 # on white noise sits at the edge of LSEP's exp overflow around step 14 (loss = inf in 2 - 5 % of the runs, decided
-                 # by atomic-summation noise; tools/nan_steps.py) -- the arithmetic per step does not depend on the rate
+                 # the whole one-cycle schedule is squeezed into the ~26 steps of a bench run: at a 0.005 peak the 10-block model on
+                 # white noise blows its logits up -- the largest score gap of a run reaches 150 ... 330 in EVERY trial, and LSEP
+                 # (reference networks/losses.py:47-58, un-stabilised) overflows fp32 once a negative class leads a positive one by
+                 # 88: loss = inf in 2 / 40 trials with the separate BatchNorm finalisation launches and 4 / 40 with the ticketed
+                 # ones (the same within counting noise; 0 / 20 and gaps <= 38 at this 0.001 peak): profiles/r04h_nan_steps.txt,
+                 # tools/nan_steps.py.  An overflow of the reference's own loss, not a race; the arithmetic per step does not
+                 # depend on the rate
                  scheduler="1cycle_0.0001_0.001"),
     # BASELINE.json configs[0] shape (used for quick checks: --workload cfg1)
     "cfg1": dict(features="mel_1024_512_64", blocks=3, base=32, growth=2, start=1, dropout=0.0,
