@@ -7,7 +7,7 @@ cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout -k 5 400 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $R/gpurun_out/traffic/$c -o p -- \
-      python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timer --no-alt > $R/gpurun_out/traffic_$c.log 2>&1
+      python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timer --no-alt --no-other > $R/gpurun_out/traffic_$c.log 2>&1
 done
 python - <<PY
 import csv, glob, json, re, collections
