@@ -22,7 +22,10 @@ def timeit(fn, iters=10):
 
 
 dev = torch.device("cuda")
-for (n, c, h, w) in [(128, 100, 64, 215), (128, 150, 32, 107), (128, 337, 8, 26)]:
+SHAPES = [(128, 100, 64, 215), (128, 150, 32, 107), (128, 337, 8, 26)]
+if len(sys.argv) > 1 and sys.argv[1] == "cfg3":          # the 1-d model's planes (odd lengths)
+    SHAPES = [(128, 64, 1, 3446), (128, 64, 1, 1723), (128, 80, 1, 861), (128, 100, 1, 430), (128, 125, 1, 215), (128, 195, 1, 53)]
+for (n, c, h, w) in SHAPES:
     bn = nn.BatchNorm2d(c).to(dev)
     prelu = nn.PReLU(c).to(dev)
     x = torch.randn(n, c, h, w, device=dev)
@@ -40,6 +43,11 @@ for (n, c, h, w) in [(128, 100, 64, 215), (128, 150, 32, 107), (128, 337, 8, 26)
         ("bwd f32 +csum", lambda: F.bn_act_backward(dy, x, st, bn, prelu.weight, with_amax=True, want_chan_sum=True), 5),
         ("bwd l16 +csum", lambda: F.bn_act_backward(dy, x, st, bn, prelu.weight, with_amax=True, l16=True, want_f32=False, want_chan_sum=True), 5),
     ]
+    if len(sys.argv) > 1 and sys.argv[1] == "cfg3":
+        res = torch.randn_like(x)
+        rows = [rows[0], rows[1], rows[4],
+                ("fwd f32 +res", lambda: F.bn_act_forward(x, st, prelu.weight, residual=res), 3),
+                ("bwd f32 +res", lambda: F.bn_act_backward(dy, x, st, bn, prelu.weight, residual=res, want_dres=True), 8)]
     for name, fn, passes in rows:
         ms = timeit(fn)
         print("%-22s %-12s %7.3f ms  %5.2f TB/s (%d tensor passes)" % ((n, c, h, w), name, ms, passes * gb / ms, passes), flush=True)
