@@ -196,7 +196,7 @@ def run_other_workloads():
     them: their one-line results, trimmed, go into `other_workloads` of the cfg-2 line.  ~1 minute."""
     import subprocess
     out = {}
-    for name, extra in (("cfg3", ["--steps", "20", "--warmup", "5"]), ("cfg5", ["--warmup", "2", "--no-alt"])):
+    for name, extra in (("cfg3", ["--steps", "20", "--warmup", "5", "--graph"]), ("cfg5", ["--warmup", "2", "--no-alt"])):
         cmd = [sys.executable, os.path.abspath(__file__), "--workload", name, "--no-cpu-baseline", "--no-other"] + extra
         try:
             r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600, cwd=ROOT)
@@ -405,7 +405,13 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-alt", action="store_true", help="skip the extra native-fp32-MFMA measurement (alt_f32)")
     ap.add_argument("--no-kernel-timer", action="store_true")
-    ap.add_argument("--no-graph", action="store_true", help="cfg3: eager steps instead of the recorded HIP graph (CapturedTrainingStep)")
+    ap.add_argument("--no-kernel-timer-in-value", action="store_true",
+                    help="time `value` without the per-kernel HIP events and take the per-kernel times behind `roofline` from a few extra "
+                         "steps after it (launch-bound workloads: cfg 3 issues ~700 kernels per step, an event pair around each makes "
+                         "the host the bottleneck: 13.2 instead of 11.5 ms)")
+    ap.add_argument("--graph", action="store_true", help="cfg3: replay the step from a recorded HIP graph (CapturedTrainingStep) instead "
+                                                         "of issuing it eagerly; the whole run then lives on one non-default stream")
+    ap.add_argument("--no-graph", action="store_true", help="(default; kept for the profile scripts)")
     ap.add_argument("--no-other", action="store_true", help="skip the short cfg3 / cfg5 runs attached to the default cfg2 line (other_workloads)")
     ap.add_argument("--kernel-table", action="store_true", help="print per-kernel timing to stderr")
     ap.add_argument("--arith", default=None, choices=["f32", "bf16", "f16x3", "bf16x6", "bf16x9"],
@@ -460,12 +466,19 @@ def main():
             args.steps = 0                      # one pass over every length-grouped batch
         return run_inference(args, w, device, world, rank)
     batch = args.batch or w["batch"]
+    if args.graph:
+        # CapturedTrainingStep wants eager steps, recording and replays on ONE non-default stream
+        run_stream = torch.cuda.Stream(device=device)
+        run_stream.wait_stream(torch.cuda.current_stream(device))
+        torch.cuda.set_stream(run_stream)
     torch.manual_seed(42)
     model_cls = HierarchicalCNNClassificationModel if w.get("dims") == 1 else TwoDimensionalCNNClassificationModel
     model = model_cls(make_experiment(w), device=str(device))
     model.train()
     model.global_step = 0
-    model.make_optimizer(max_steps=args.steps + args.warmup + 1)
+    # (every step the run takes must lie inside the one-cycle schedule -- past its end the rate goes negative: warm-up, the timed steps,
+    # the extra measurements behind them, two replays after a graph capture)
+    model.make_optimizer(max_steps=args.steps + args.warmup + 24)
     signal, labels = synthetic_batch(w, batch, device, 1234 + rank)
 
     mix_rng = __import__("numpy").random.RandomState(7 + rank)
@@ -486,25 +499,37 @@ def main():
             mixed, y = F.mixup_batch(signal.squeeze(-1), signal.squeeze(-1)[partner].contiguous(), [t] * batch, [t] * batch,
                                      [0] * batch, mix_rng.uniform(0.4, 0.6, size=batch), labels, labels[partner].contiguous())
             x = mixed.unsqueeze(-1)
-        return step_fn[0](x, y)
+        out = step_fn[0](x, y)
+        if os.environ.get("FSC_BENCH_SYNC_ALL"):
+            torch.cuda.synchronize()
+            print("step %d loss %.3f max|logit| %.1f" % (model.global_step, float(out[2].detach()), float(out[0].detach().abs().max())), file=sys.stderr)
+        return out
 
     for _ in range(args.warmup):
         one_step()
-    # Launch-bound workload (cfg 3: ~510 entry-point calls per step, 9 ms of host time for ~5 ms of kernels): the step is recorded
-    # once as a HIP graph and replayed (ops/training.py CapturedTrainingStep: same entry points, same arguments, same order; the
-    # learning rate / step count travel through device memory).  MixUp stays outside (its draws are host-side).  The per-kernel
-    # times behind `roofline` then come from a few eager steps AFTER the timed region.
-    use_graph = (w.get("dims") == 1 and float(w["dropout"]) == 0.0 and world == 1 and not args.no_graph
+    # --graph (cfg 3): the step is recorded once as a HIP graph and replayed (ops/training.py CapturedTrainingStep: same entry points,
+    # arguments and order; learning rate / step count through device memory; MixUp stays outside, its draws are host-side).  Off by
+    # default: this host issues the 510 entry-point calls of a cfg-3 step in 9 ms against 11.5 ms of kernels, so the replay
+    # measures the same 11.6 ms -- it pays on a slower host or a faster GPU.  The per-kernel times behind `roofline` then come
+    # from a few eager steps AFTER the timed region.
+    use_graph = (args.graph and w.get("dims") == 1 and float(w["dropout"]) == 0.0 and world == 1
                  and os.environ.get("FSC_FORCE_DP") != "1")
     captured = None
     if use_graph:
         from freesound_classification_amd.ops.training import CapturedTrainingStep
-        captured = CapturedTrainingStep(model, signal, labels)
+        # FSC_GRAPH_ASYNC_WGRAD=1: weight gradients on a forked stream -- in the recorded graph they become branches beside the
+        # BatchNorm / dgrad chain, so that the small late-block kernels could overlap instead of queueing
+        F.ASYNC_WGRAD = os.environ.get("FSC_GRAPH_ASYNC_WGRAD", "0") == "1"      # (measured: 11.71 against 11.53 - 11.60 ms, not a gain)
+        try:
+            captured = CapturedTrainingStep(model, signal, labels)
+        finally:
+            F.ASYNC_WGRAD = False
         step_fn[0] = captured
         for _ in range(2):
             one_step()
+    post_timer = (use_graph or args.no_kernel_timer_in_value) and not args.no_kernel_timer
     timer = None
-    if not args.no_kernel_timer and not use_graph:
+    if not args.no_kernel_timer and not post_timer:
         timer = F.KernelTimer()
     torch.cuda.synchronize()
     if world > 1:
@@ -512,12 +537,19 @@ def main():
     F.TIMER = timer
     calls0 = F._lib.CALLS[0]
     t0 = time.perf_counter()
+    trace = [] if os.environ.get("FSC_BENCH_TRACE_LOSS") else None      # development: the loss of every timed step (synchronises each)
     for _ in range(args.steps):
         logits, per, loss = one_step()
+        if trace is not None:
+            lg_ = logits.detach()
+            trace.append((float(loss.detach()), float(lg_.abs().max()), float((lg_.max(dim=1).values - lg_.min(dim=1).values).max()),
+                          float(model.optimizer.param_groups[0]["lr"])))
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    if trace is not None:
+        print("timed steps, loss / max |logit| / largest score gap / lr:", " ".join("%.3f/%.0f/%.0f/%.5f" % v for v in trace), file=sys.stderr)
     F.TIMER = None
     abi_calls = (F._lib.CALLS[0] - calls0) / max(1, args.steps)
     timer_steps = args.steps
@@ -526,20 +558,22 @@ def main():
         captured.sync_state()
         step_fn[0] = model.training_step
         graph_info = {"replayed": True, "abi_calls_per_replayed_step": abi_calls}
-        if not args.no_kernel_timer:                     # per-kernel attribution: eager steps, outside the timed region
+    if post_timer:                                       # per-kernel attribution: eager steps with the timer, outside the timed region
+        one_step()
+        torch.cuda.synchronize()
+        timer = F.KernelTimer()
+        timer_steps = 5
+        F.TIMER = timer
+        calls0 = F._lib.CALLS[0]
+        t_e = time.perf_counter()
+        for _ in range(timer_steps):
             one_step()
-            torch.cuda.synchronize()
-            timer = F.KernelTimer()
-            timer_steps = 5
-            F.TIMER = timer
-            calls0 = F._lib.CALLS[0]
-            t_e = time.perf_counter()
-            for _ in range(timer_steps):
-                one_step()
-            torch.cuda.synchronize()
-            graph_info["eager_ms_per_step"] = 1e3 * (time.perf_counter() - t_e) / timer_steps
-            F.TIMER = None
-            abi_calls = (F._lib.CALLS[0] - calls0) / timer_steps
+        torch.cuda.synchronize()
+        timed_ms = 1e3 * (time.perf_counter() - t_e) / timer_steps
+        F.TIMER = None
+        abi_calls = (F._lib.CALLS[0] - calls0) / timer_steps
+        if graph_info is not None:
+            graph_info["eager_ms_per_step_with_kernel_timer"] = timed_ms
     per_rank = None
     exchange = None
     if world > 1:
@@ -671,6 +705,8 @@ def main():
             "final_loss": final_loss,
             "abi_calls_per_step": abi_calls,           # entry-point calls of libfsc_hip.so per (eager) step (each enqueues one to three kernels)
         }
+        if post_timer:
+            result["kernel_timer"] = "separate pass: %d eager steps with a HIP event pair around every conv launch, after the timed region" % timer_steps
         if graph_info is not None:
             result["hip_graph"] = graph_info
         if timer is not None:

@@ -3,6 +3,9 @@
 The optimizers are fused multi-tensor HIP kernels with torch-compatible state dicts.
 """
 import ctypes as C
+import gc
+import os
+import warnings
 from functools import partial
 
 import torch
@@ -190,17 +193,29 @@ def make_step(scheduler, epoch=None, step=None, val_score=None):
 class CapturedTrainingStep:
     """One training step of a model -- forward, loss, backward, optimizer -- recorded ONCE as a HIP graph and replayed per batch.
 
-    For launch-bound models (cfg 3: ~700 kernels of 5 - 50 us behind ~510 entry-point calls, 9 ms of Python per 13 ms step) the
-    replay removes the host from the step: the GPU runs the recorded kernels back to back.  Nothing about the arithmetic
-    changes -- the same entry points with the same arguments, in the same order -- so a replayed step equals the eager step bit
-    for bit except where the eager step itself is not reproducible (atomic channel sums).
+    The same entry points with the same arguments in the same order as the eager step, so a replayed step equals the eager one
+    (40 replays of one recording stay within 1.5e-5 of the eager logits over four steps, tools/dbg_graph.py); what it removes is
+    the host: ~510 entry-point calls of Python per cfg-3 step.  On a host that issues the step faster than the GPU runs it
+    (this one: 9.2 ms against 11.5 ms) that buys nothing -- bench.py keeps eager steps and offers `--graph`.
 
-    What makes it legal: every entry point of libfsc_hip.so is capture-safe (include/fsc_hip.h); the step-dependent scalars of
-    Adam travel through two device floats (fsc_adam_amsgrad_step_dev) refreshed in front of each replay; BatchNorm counters
-    are bumped by a kernel.  What it needs: fixed batch shape, Adam, accumulation_steps == 1, no dropout (its counter-based
-    stream takes the offset by value), single GPU (no reducer), at least one eager step before (lazy state exists).
-    `model.training_step` semantics otherwise: returns (class_logits, per-sample loss, loss) -- static tensors, valid until
-    the next call.
+    What makes it legal: every entry point of libfsc_hip.so is capture-safe (include/fsc_hip.h: no allocation, no
+    synchronisation, no host read-back); the step-dependent scalars of Adam travel through two device floats
+    (fsc_adam_amsgrad_step_dev) refreshed in front of each replay; BatchNorm counters are bumped by a kernel.  What it needs:
+    fixed batch shape, Adam, accumulation_steps == 1, no dropout (its counter-based stream takes the offset by value), single
+    GPU (no reducer), at least one eager step before (lazy state exists).  `model.training_step` semantics otherwise: returns
+    (class_logits, per-sample loss, loss) -- static tensors, valid until the next call.
+
+    Two rules for the caller, both enforced:
+    * ONE NON-DEFAULT STREAM for everything -- the eager steps before, the recording, the replays: construct and call inside the
+      same `with torch.cuda.stream(s):`.  With the eager steps on torch's default stream (the legacy null stream) and the graph
+      on another, replays were wrong in ways that depended on where the host synchronised (NaN logits within three replays with
+      a device synchronise after every step; a stalled loss, or a NaN in one run of six, with bench.py's pattern; correct with a
+      read-back after every step) -- tools/dbg_graph5.py reproduces it; nothing in the library or in torch's strictest capture
+      mode flags anything, and the same loop on one non-default stream is correct under every pattern tried.
+    * NO tensor of an earlier step's autograd graph may be alive at the recording (drop the eager steps' logits / losses first):
+      it keeps the parameters' AccumulateGrad nodes alive, which then run outside the recording.  The constructor drops the
+      library's own references (the BatchNorm statistics stash), collects garbage, and refuses the recording if torch reports
+      such a node.
     """
 
     def __init__(self, model, signal, labels):
@@ -213,6 +228,11 @@ class CapturedTrainingStep:
             raise _lib.FscError("CapturedTrainingStep: dropout draws from a host-side counter; capture needs output_dropout == 0")
         if len(opt.param_groups) != 1 or not all(opt.state[p] for p in opt.param_groups[0]["params"] if p.requires_grad):
             raise _lib.FscError("CapturedTrainingStep: run one eager training step first (optimizer state must exist)")
+        stream = torch.cuda.current_stream(signal.device)
+        if stream == torch.cuda.default_stream(signal.device):
+            raise _lib.FscError("CapturedTrainingStep: run the training loop -- eager steps, this constructor, the replays -- inside "
+                                "ONE `with torch.cuda.stream(s):` (not on the default stream; see the class docstring)")
+        self.stream = stream
         self.model, self.opt = model, opt
         self.group = opt.param_groups[0]
         self.step_count = int(next(iter(opt.state.values()))["step"])
@@ -221,21 +241,33 @@ class CapturedTrainingStep:
         self.factors = torch.zeros(2, device=signal.device, dtype=torch.float32)
         self._buf = (C.c_float * 2)()
         self.graph = torch.cuda.CUDAGraph()
-        stream = torch.cuda.Stream(device=signal.device)
-        stream.wait_stream(torch.cuda.current_stream(signal.device))
         opt.zero_grad()
+        from .. import functional
+        functional._PRESTATS.clear()             # (holds the last block output of the previous step, i.e. its autograd graph)
+        gc.collect()
         opt.factors_dev = self.factors
         try:
-            with torch.cuda.graph(self.graph, stream=stream, capture_error_mode="relaxed"):
-                self.outputs = model.training_step(self.signal, self.labels)
+            with warnings.catch_warnings(record=True) as caught:
+                warnings.simplefilter("always")
+                with torch.cuda.graph(self.graph, stream=stream, capture_error_mode=os.environ.get("FSC_CAPTURE_MODE", "relaxed")):
+                    self.outputs = model.training_step(self.signal, self.labels)
         finally:
             opt.factors_dev = None
         # the recording ran the step's Python (not its kernels): undo the one host-side effect, the step counters
         for st in opt.state.values():
             st["step"] = self.step_count
-        torch.cuda.current_stream(signal.device).wait_stream(stream)
+        stale = [w for w in caught if "AccumulateGrad" in str(w.message)]
+        for w in caught:
+            if w not in stale:
+                warnings.warn_explicit(w.message, w.category, w.filename, w.lineno)
+        if stale:
+            self.graph = None
+            raise _lib.FscError("CapturedTrainingStep: a tensor of an earlier step's autograd graph is still alive (its AccumulateGrad "
+                                "nodes would run outside the recording); drop the previous steps' outputs before recording")
 
     def __call__(self, signal, labels):
+        if torch.cuda.current_stream(self.signal.device) != self.stream:
+            raise _lib.FscError("CapturedTrainingStep: replay on the stream the step was recorded on")
         self.signal.copy_(signal, non_blocking=True)
         self.labels.copy_(labels, non_blocking=True)
         self.step_count += 1

@@ -263,6 +263,10 @@ def test_captured_training_step_equals_the_eager_step(arith):
     optimizer's step counters read the same.  (Measured: logits 5e-6 apart in f16x3, eager against eager the same.)"""
     from freesound_classification_amd.ops.training import CapturedTrainingStep, make_step
     F.set_conv_arith(arith)
+    side = torch.cuda.Stream(device=DEV)                      # eager steps, recording and replays on ONE non-default stream
+    side.wait_stream(torch.cuda.current_stream(DEV))
+    prev_stream = torch.cuda.current_stream(DEV)
+    torch.cuda.set_stream(side)
     try:
         torch.manual_seed(5)
         model = _small_1d(weight_decay=0.01)
@@ -332,4 +336,39 @@ def test_captured_training_step_equals_the_eager_step(arith):
             assert float((a - b).abs().max()) <= max(floor_s * max(1.0, float(a.abs().max())), 3.0 * noise), (k, float((a - b).abs().max()), noise)
         model.close()
     finally:
+        torch.cuda.synchronize()
+        torch.cuda.set_stream(prev_stream)
         F.set_conv_arith(None)
+
+
+def test_captured_training_step_refuses_the_default_stream():
+    """CapturedTrainingStep's stream rule is enforced: a recording on torch's default stream is refused (replays next to
+    default-stream eager steps went wrong depending on where the host synchronised, tools/dbg_graph5.py), and so is a replay
+    from another stream than the one the step was recorded on.  (With the eager steps on the recording stream an earlier step's
+    live outputs are harmless -- their AccumulateGrad nodes belong to that stream -- so that case records.)"""
+    from freesound_classification_amd._lib import FscError
+    from freesound_classification_amd.ops.training import CapturedTrainingStep, make_step
+    torch.manual_seed(6)
+    model = _small_1d()
+    model.train()
+    model.global_step = 0
+    model.make_optimizer(max_steps=12)
+    x = 0.1 * torch.randn(8, 22050, 1, device=DEV)
+    y = (torch.rand(8, 80, device=DEV) < 0.05).float()
+    make_step(model.scheduler, step=1)
+    model.training_step(x, y)
+    with pytest.raises(FscError, match="default stream"):
+        CapturedTrainingStep(model, x, y)
+    side = torch.cuda.Stream(device=DEV)
+    side.wait_stream(torch.cuda.current_stream(DEV))
+    with torch.cuda.stream(side):
+        kept = model.training_step(x, y)                        # outputs of an eager step on this stream, still alive: harmless
+        step = CapturedTrainingStep(model, x, y)
+        del kept
+        make_step(model.scheduler, step=3)
+        logits = step(x, y)[0]
+        assert torch.isfinite(logits).all()
+    torch.cuda.synchronize()
+    with pytest.raises(FscError, match="recorded on"):
+        step(x, y)                                              # (the caller's stream is the default one again)
+    model.close()

@@ -9,6 +9,7 @@ from test_r4_gpu import _small_1d, DEV
 
 F.set_conv_arith(sys.argv[1] if len(sys.argv) > 1 else "f16x3")
 torch.manual_seed(5)
+_side = torch.cuda.Stream(device=DEV); _side.wait_stream(torch.cuda.current_stream(DEV)); torch.cuda.set_stream(_side)   # one non-default stream for everything
 model = _small_1d(weight_decay=float(sys.argv[2]) if len(sys.argv) > 2 else 0.0)
 model.train(); model.global_step = 0
 model.make_optimizer(max_steps=12)
