@@ -662,6 +662,15 @@ def main():
             with open(os.environ["FSC_STAGE_DUMP"], "w") as fh:
                 for nm, mb, us in rows[-(len(rows) // k_s):]:
                     fh.write("%-12s %10.1f MB %9.1f us %7.2f TB/s\n" % (nm, mb, us, mb / max(us, 1e-3)))
+        # the same per stage over its LARGE calls only (>= 256 MB of algorithmic bytes: beyond the Infinity Cache): a stage's overall
+        # figure mixes them with the small late-block calls, which are launch- and latency-bound whatever the kernel does
+        large = {}
+        for nm, nb, e0, e1 in F.STAGE_TIMER.records:
+            if nb >= 256e6:
+                r = large.setdefault(nm, [0.0, 0.0, 0])
+                r[0] += nb
+                r[1] += e0.elapsed_time(e1)
+                r[2] += 1
         summ_s, F.STAGE_TIMER = F.STAGE_TIMER.summary(), None
         names = {"frontend": "front-end: waveform -> log-mel / log-STFT (reads 4 T, writes 4 F frames per clip)",
                  "bn_stats": "BatchNorm statistics passes that are not folded into a producer (1 read)",
@@ -676,6 +685,10 @@ def main():
             stages[k] = {"what": names.get(k, k), "bound": "hbm", "achieved": tbps * 1e3, "peak": PEAK_HBM_GBPS, "unit": "GB/s",
                          "frac": tbps * 1e3 / PEAK_HBM_GBPS, "ms_per_step": r["ms"] / k_s, "GB_per_step": r["bytes"] / k_s / 1e9,
                          "calls_per_step": r["calls"] / k_s}
+            if k in large and large[k][1] > 0:
+                lb, lms, lc = large[k]
+                stages[k]["large_calls"] = {"min_bytes": 256e6, "calls_per_step": lc / k_s, "ms_per_step": lms / k_s,
+                                            "achieved": lb / lms / 1e6, "frac": lb / lms / 1e6 / PEAK_HBM_GBPS}
 
     if rank == 0:
         result = {
