@@ -54,3 +54,17 @@ for name, fn, passes in (("bwd l16", bwd, 5), ("fwd l16", fwd, 2)):
     c_ = measure(fn, flush)
     print("%-8s back to back %.3f ms %.2f TB/s | behind an L16 conv %.3f ms %.2f TB/s | behind a 1.5 GB streaming pass %.3f ms %.2f TB/s" % (
         name, a, passes * gb / a, b, passes * gb / b, c_, passes * gb / c_))
+
+# ---- the other direction: a 1x1 L16 convolution back to back, behind the BatchNorm apply pass that writes its operand, behind a flush
+w1 = torch.randn(c, c, 1, 1, device=dev) / 10
+pp1 = F.conv_l16_pack(w1, n, h, w, False)
+fl = 2.0 * n * h * w * c * c
+def conv1():
+    return F.conv_l16(t16, w1, None, prepacked=pp1)
+def producer():
+    global t16
+    _, t16 = F.bn_act_forward(x, st, prelu.weight, l16=True, want_f32=False)
+a = measure(conv1, None); b = measure(conv1, producer); c_ = measure(conv1, flush); d_ = measure(conv1, conv)
+mv = (x.numel() * 4 * 2) / 1e9
+print("1x1 L16 conv 100->100: back to back %.3f ms %.2f TB/s | behind its producer (fwd_l16) %.3f ms %.2f TB/s | behind a flush %.3f ms | behind a 3x3 conv %.3f ms" % (
+    a, mv / a, b, mv / b, c_, d_))
