@@ -861,7 +861,16 @@ __device__ __forceinline__ float upstream(const BwdArgs& a, const float* pdy, lo
     return g;
 }
 
-// partial sums per (channel, split): [0]=sum dz, [1]=sum dz*xhat, [2]=sum dy*min(z,0)
+// The per-channel sum of dx (the bias gradient of the convolution in front of this BatchNorm) in closed form: with
+// dx = k (dz - c1 - xhat c2) over `count` elements, sum dx = k (sum dz - count c1 - c2 sum xhat), from the sums the reduce pass has
+// anyway (+ sum xhat).  Analytically zero (c1 = mean dz, sum xhat = 0): like the sum of the stored dx it is rounding residue, but
+// no apply kernel has to add its planes into C addresses (one device-scope atomic per plane, 128 per address at batch 128, cost the
+// apply pass of the 1-d model's planes 40 - 77 us per call: tools/bn_atomics_probe.py).
+__host__ __device__ inline float chan_sum_of_dx(float k, double sum_dz, double sum_xhat, double count, float c1, float c2) {
+    return (float)((double)k * (sum_dz - count * (double)c1 - (double)c2 * sum_xhat));
+}
+constexpr int kBwdVals = 6;
+// partial sums per (channel, split): [0]=sum dz, [1]=sum dz*xhat, [2]=sum dy*min(z,0), [3]=max|dz|, [4]=max|xhat|, [5]=sum xhat
 // With fin.tickets the block that finishes a channel LAST (a ticket counter per channel, left at zero again) also does what
 // bwd_finalize_kernel does for that channel, in the same order of additions: the single-replica backward is two launches, not three.
 struct BwdFinish {
@@ -881,7 +890,7 @@ __global__ __launch_bounds__(kThreads) void bwd_partial_kernel(BwdArgs a, int ns
     const float al = has_alpha ? a.alpha[ch] : 1.f;
     const int hwp = 1 << hwp_log2, groups = kThreads >> hwp_log2;
     const int tn = threadIdx.x >> hwp_log2, ti = threadIdx.x & (hwp - 1);
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
     float mdz = 0.f, mxh = 0.f;            // max |dz|, max |xhat|: the bound of |dx| for the L16 apply pass
     auto quad = [&](const float4& xv, const float4& rv, const float4& uv) {
         const float xs[4] = {xv.x, xv.y, xv.z, xv.w}, rs[4] = {rv.x, rv.y, rv.z, rv.w}, us[4] = {uv.x, uv.y, uv.z, uv.w};
@@ -894,6 +903,7 @@ __global__ __launch_bounds__(kThreads) void bwd_partial_kernel(BwdArgs a, int ns
             s0 += dz;
             s1 += dz * xh;
             s2 += us[e] * (neg ? z : 0.f);
+            s3 += xh;
             mdz = fmaxf(mdz, fabsf(dz));
             mxh = fmaxf(mxh, fabsf(xh));
         }
@@ -961,6 +971,7 @@ __global__ __launch_bounds__(kThreads) void bwd_partial_kernel(BwdArgs a, int ns
                     s0 += dz;
                     s1 += dz * xh;
                     s2 += up * (neg ? z : 0.f);
+                    s3 += xh;
                     mdz = fmaxf(mdz, fabsf(dz));
                     mxh = fmaxf(mxh, fabsf(xh));
                 }
@@ -977,6 +988,7 @@ __global__ __launch_bounds__(kThreads) void bwd_partial_kernel(BwdArgs a, int ns
             s0 += dz;
             s1 += dz * xh;
             s2 += up * (neg ? z : 0.f);
+            s3 += xh;
             mdz = fmaxf(mdz, fabsf(dz));
             mxh = fmaxf(mxh, fabsf(xh));
         }
@@ -984,42 +996,43 @@ __global__ __launch_bounds__(kThreads) void bwd_partial_kernel(BwdArgs a, int ns
     const double t0 = fsc::block_sum<double, kThreads / 64>((double)s0, scratch);
     const double t1 = fsc::block_sum<double, kThreads / 64>((double)s1, scratch);
     const double t2 = fsc::block_sum<double, kThreads / 64>((double)s2, scratch);
+    const double t3 = fsc::block_sum<double, kThreads / 64>((double)s3, scratch);
     __shared__ float mred[kThreads / 64];
     mdz = block_max256(mdz, mred);
     mxh = block_max256(mxh, mred);
     if (threadIdx.x == 0) {
         double* o = part + ((size_t)ch * kMaxSplit + sp) * kPartStride;
-        const double vals[5] = {t0, t1, t2, (double)mdz, (double)mxh};
+        const double vals[kBwdVals] = {t0, t1, t2, (double)mdz, (double)mxh, t3};
         if (fin.tickets) {
-            // device-coherent stores and loads for the five numbers other workgroups (other XCDs: other L2s) read below.  A
+            // device-coherent stores and loads for the six numbers other workgroups (other XCDs: other L2s) read below.  A
             // __threadfence() here instead writes back and invalidates the XCD's whole L2 once per workgroup: the pass took twice
             // as long (2.6 -> 5.3 ms per step).
 #pragma unroll
-            for (int k = 0; k < 5; ++k) __hip_atomic_store(o + k, vals[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int k = 0; k < kBwdVals; ++k) __hip_atomic_store(o + k, vals[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         } else {
 #pragma unroll
-            for (int k = 0; k < 5; ++k) o[k] = vals[k];
+            for (int k = 0; k < kBwdVals; ++k) o[k] = vals[k];
         }
     }
     if (fin.tickets == nullptr) return;
     if (fin.dx_amax && !fin.want_bound && ch == 0 && sp == 0)          // (the L16 apply pass stores the bound itself)
         for (int i = threadIdx.x; i < fsc::kAmaxFloats; i += kThreads) fin.dx_amax[i] = 0.f;
     __shared__ int last_s;
-    __shared__ double fold_s[kMaxSplit][5];
+    __shared__ double fold_s[kMaxSplit][kBwdVals];
     if (threadIdx.x == 0) last_s = ticket_last(fin.tickets + ch, nsplit) ? 1 : 0;      // (thread 0 issued the stores above)
     __syncthreads();
     if (!last_s) return;
     if ((int)threadIdx.x < nsplit) {
         double* p = part + ((size_t)ch * kMaxSplit + threadIdx.x) * kPartStride;
 #pragma unroll
-        for (int k = 0; k < 5; ++k) fold_s[threadIdx.x][k] = __hip_atomic_load(p + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int k = 0; k < kBwdVals; ++k) fold_s[threadIdx.x][k] = __hip_atomic_load(p + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __syncthreads();
     if (threadIdx.x != 0) return;
-    double f0 = 0.0, f1 = 0.0, f2 = 0.0;
+    double f0 = 0.0, f1 = 0.0, f2 = 0.0, f3 = 0.0;
     float fdz = 0.f, fxh = 0.f;
     for (int k = 0; k < nsplit; ++k) {
-        f0 += fold_s[k][0]; f1 += fold_s[k][1]; f2 += fold_s[k][2];
+        f0 += fold_s[k][0]; f1 += fold_s[k][1]; f2 += fold_s[k][2]; f3 += fold_s[k][5];
         fdz = fmaxf(fdz, (float)fold_s[k][3]);
         fxh = fmaxf(fxh, (float)fold_s[k][4]);
     }
@@ -1029,7 +1042,7 @@ __global__ __launch_bounds__(kThreads) void bwd_partial_kernel(BwdArgs a, int ns
     const float c1 = (float)(f0 / fin.count), c2 = (float)(f1 / fin.count);
     fin.coef[ch * 2] = c1;
     fin.coef[ch * 2 + 1] = c2;
-    if (fin.dx_chan_sum) fin.dx_chan_sum[ch] = 0.f;
+    if (fin.dx_chan_sum) fin.dx_chan_sum[ch] = chan_sum_of_dx(g * invstd, f0, f3, fin.count, c1, c2);
     if (fin.want_bound) fin.coef[2 * a.c + ch] = fabsf(g * invstd) * (fdz + fabsf(c1) + fxh * fabsf(c2));
 }
 
@@ -1041,7 +1054,7 @@ __global__ void bwd_rows_kernel(BwdArgs a, double* __restrict__ part) {
     const float g = a.gamma ? a.gamma[ch] : 1.f, b = a.beta ? a.beta[ch] : 0.f;
     const bool has_alpha = a.alpha != nullptr;
     const float al = has_alpha ? a.alpha[ch] : 1.f;
-    double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
     for (int nb = blockIdx.y; nb < a.n; nb += gridDim.y) {
         const long i = (long)nb * a.c + ch;
         const float xh = (a.x[i] - mean) * invstd;
@@ -1052,9 +1065,10 @@ __global__ void bwd_rows_kernel(BwdArgs a, double* __restrict__ part) {
         const float dz = neg ? al * up : up;
         s0 += dz; s1 += (double)dz * xh;
         s2 += (double)up * (neg ? z : 0.f);
+        s3 += xh;
     }
     double* o = part + ((size_t)ch * kMaxSplit + blockIdx.y) * kPartStride;
-    o[0] = s0; o[1] = s1; o[2] = s2; o[3] = 0.0; o[4] = 0.0;
+    o[0] = s0; o[1] = s1; o[2] = s2; o[3] = 0.0; o[4] = 0.0; o[5] = s3;
 }
 
 // SyncBN: phase 1 writes the parameter gradients (LOCAL sums: the gradient all-reduce adds the replicas later) and
@@ -1069,6 +1083,12 @@ __global__ void bwd_finalize_kernel(int c, double count, int nsplit, const doubl
         for (int i = ch; i < fsc::kAmaxFloats; i += gridDim.x * blockDim.x) dx_amax[i] = 0.f;
     if (ch >= c) return;
     double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+    double l0 = 0.0, l3 = 0.0;                  // this replica's sum dz, sum xhat (phase 2: `part` still holds phase 1's partials)
+    const double local_count = count;
+    for (int s = 0; s < nsplit; ++s) {
+        const double* p = part + ((size_t)ch * kMaxSplit + s) * kPartStride;
+        l0 += p[0]; l3 += p[5];
+    }
     if (phase == 2) {
         s0 = sync[ch * 4];
         s1 = sync[ch * 4 + 1];
@@ -1092,7 +1112,7 @@ __global__ void bwd_finalize_kernel(int c, double count, int nsplit, const doubl
     const float c1 = (float)(s0 / count), c2 = (float)(s1 / count);
     coef[ch * 2] = c1;
     coef[ch * 2 + 1] = c2;
-    if (dx_chan_sum) dx_chan_sum[ch] = 0.f;
+    if (dx_chan_sum) dx_chan_sum[ch] = chan_sum_of_dx((gamma ? gamma[ch] : 1.f) * invstd[ch], l0, l3, local_count, c1, c2);
     if (want_bound) {
         // |dx| = |k (dz - c1 - xhat c2)| <= |k| (max |dz| + |c1| + max |xhat| |c2|): the declared maximum of the L16 tensor
         // (an over-estimate, by less than 2x for gradients whose means are small against their extremes; safe)
@@ -1109,8 +1129,7 @@ __global__ void bwd_finalize_kernel(int c, double count, int nsplit, const doubl
 
 __global__ __launch_bounds__(kThreads) void bwd_apply_plane_kernel(BwdArgs a, const float* __restrict__ coef,
                                                                     float* __restrict__ dx, float* __restrict__ dres,
-                                                                    float* dx_chan_sum, float* dx_amax) {
-    __shared__ float scratch[kThreads / 64];
+                                                                    float* dx_amax) {
     const long plane = blockIdx.x;
     float mx = 0.f;
     const int ch = (int)(plane % a.c);
@@ -1127,7 +1146,6 @@ __global__ __launch_bounds__(kThreads) void bwd_apply_plane_kernel(BwdArgs a, co
     const long gpos = a.gmax_dy ? (long)a.gmax_idx[plane] : -1;
     float* pdx = dx + plane * a.hw;
     float* pdr = dres ? dres + plane * a.hw : nullptr;
-    float acc = 0.f;
     const int head = (int)((4 - ((plane * a.hw) & 3)) & 3);       // (see fwd_plane_kernel: 16-byte accesses for any plane length)
     const long n4 = (a.hw - head) >> 2;
     auto point = [&](long i) {
@@ -1139,7 +1157,6 @@ __global__ __launch_bounds__(kThreads) void bwd_apply_plane_kernel(BwdArgs a, co
         const float d = k * (dz - c1 - xh * c2);
         pdx[i] = d;
         if (pdr) pdr[i] = dz;
-        acc += d;
         mx = fmaxf(mx, fabsf(d));
     };
     for (long i4 = (long)blockIdx.y * kThreads + threadIdx.x; i4 < n4; i4 += (long)gridDim.y * kThreads) {
@@ -1157,7 +1174,6 @@ __global__ __launch_bounds__(kThreads) void bwd_apply_plane_kernel(BwdArgs a, co
             const float z = fmaf(xh, g, b) + rs[e];
             zv[e] = (has_alpha && !(z > 0.f)) ? al * us[e] : us[e];
             dv[e] = k * (zv[e] - c1 - xh * c2);
-            acc += dv[e];
             mx = fmaxf(mx, fabsf(dv[e]));
         }
         reinterpret_cast<float4*>(pdx + head)[i4] = make_float4(dv[0], dv[1], dv[2], dv[3]);
@@ -1168,18 +1184,13 @@ __global__ __launch_bounds__(kThreads) void bwd_apply_plane_kernel(BwdArgs a, co
         if (t < head) point(t);
         else if (head + 4 * n4 + (t - head) < a.hw) point(head + 4 * n4 + (t - head));
     }
-    if (dx_chan_sum) {
-        const float t = fsc::block_sum<float, kThreads / 64>(acc, scratch);
-        if (threadIdx.x == 0) atomicAdd(dx_chan_sum + ch, t);
-    }
     if (dx_amax) fsc::publish_amax(dx_amax, mx);
 }
 
-// planes of 2..511 pixels: one wavefront per plane; the per-channel sum of dx leaves the wave as
-// ONE atomic (the flat kernel below issued one per element and serialised on C addresses)
+// planes of 2..511 pixels: one wavefront (or a lane group of it) per plane
 __global__ __launch_bounds__(kThreads) void bwd_apply_wave_kernel(BwdArgs a, const float* __restrict__ coef,
                                                                    float* __restrict__ dx, float* __restrict__ dres,
-                                                                   float* dx_chan_sum, long planes, float* dx_amax, int glog) {
+                                                                   long planes, float* dx_amax, int glog) {
     const int gsz = 1 << glog;
     long plane = ((long)blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6)) * (64 >> glog) + ((threadIdx.x & 63) >> glog);
     const long hw_live = plane < planes ? a.hw : 0;      // (no early exit: publish_amax synchronises the block)
@@ -1195,7 +1206,7 @@ __global__ __launch_bounds__(kThreads) void bwd_apply_wave_kernel(BwdArgs a, con
     const long base = plane * a.hw;
     const float gval = a.gmax_dy ? a.gmax_dy[plane] : 0.f;
     const long gpos = a.gmax_dy ? (long)a.gmax_idx[plane] : -1;
-    float acc = 0.f, mx = 0.f;
+    float mx = 0.f;
     for (long i = lane; i < hw_live; i += gsz) {
         const float xh = (a.x[base + i] - mean) * invstd;
         float z = fmaf(xh, g, b);
@@ -1206,12 +1217,7 @@ __global__ __launch_bounds__(kThreads) void bwd_apply_wave_kernel(BwdArgs a, con
         const float d = k * (dz - c1 - xh * c2);
         dx[base + i] = d;
         if (dres) dres[base + i] = dz;
-        acc += d;
         mx = fmaxf(mx, fabsf(d));
-    }
-    if (dx_chan_sum) {
-        acc = group_sum(acc, glog);
-        if (lane == 0 && hw_live) atomicAdd(dx_chan_sum + ch, acc);
     }
     if (dx_amax) fsc::publish_amax(dx_amax, mx);
 }
@@ -1223,13 +1229,12 @@ __global__ __launch_bounds__(kThreads) void bwd_apply_wave_kernel(BwdArgs a, con
 // max-pool backward pass.  Grid: blockIdx.x = (n, c) plane, blockIdx.y strides over pooled rows.
 __global__ __launch_bounds__(kThreads) void bwd_apply_unpool_kernel(BwdArgs a, const float* __restrict__ coef,
                                                                      const uint8_t* __restrict__ pool_idx,
-                                                                     float* __restrict__ dc, float* dx_chan_sum,
+                                                                     float* __restrict__ dc,
                                                                      int h, int w, int ph, int oh, int ow,
                                                                      int colp_log2, float* dc_amax, long row_units) {
     // A block owns kThreads >> colp_log2 consecutive ROW UNITS (plane, pooled row); a row unit is walked by 2^colp_log2 lanes.  (One
     // block per plane left 32 of 256 lanes busy on the 1-d model's single-row planes and paid a block's fixed cost -- parameter
     // loads, block reduction, two atomics -- per (image, channel): 54 us for a 0.7 MB tensor.)
-    __shared__ float part[kThreads / 64];
     const int colp = 1 << colp_log2, rows_per_block = kThreads >> colp_log2;
     const int tr = threadIdx.x >> colp_log2, tc = threadIdx.x & (colp - 1);
     const long unit = (long)blockIdx.x * rows_per_block + tr;
@@ -1248,7 +1253,7 @@ __global__ __launch_bounds__(kThreads) void bwd_apply_unpool_kernel(BwdArgs a, c
     const float* pdy = a.dy + plane * a.hw;
     const uint8_t* pi = pool_idx + plane * a.hw;
     float* pdc = dc + plane * h * w;
-    float acc = 0.f, mx = 0.f;
+    float mx = 0.f;
     if (live) {
         float* r0 = pdc + (long)oy * ph * w;
         for (int ox = tc; ox < ow; ox += colp) {
@@ -1259,7 +1264,6 @@ __global__ __launch_bounds__(kThreads) void bwd_apply_unpool_kernel(BwdArgs a, c
             const float up = pdy[i];
             const float dz = (has_alpha && !(z > 0.f)) ? al * up : up;
             const float d = k * (dz - c1 - xh * c2);
-            acc += d;
             mx = fmaxf(mx, fabsf(d));
             const int pos = pi[i];
             // one 8-byte store per window row (4-byte aligned): half the store instructions of the scalar form
@@ -1275,56 +1279,7 @@ __global__ __launch_bounds__(kThreads) void bwd_apply_unpool_kernel(BwdArgs a, c
             for (int xx = tc; xx < w; xx += colp) pdc[(long)(h - 1) * w + xx] = 0.f;
         }
     }
-    if (dx_chan_sum) {
-        // the row unit's sum: its lanes sit in one wave (colp <= 64) or in colp / 64 whole waves
-        const int span = colp < 64 ? colp : 64;
-        for (int o = span >> 1; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
-        if (colp > 64) {
-            if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
-            __syncthreads();
-            if (tc == 0) {
-                acc = 0.f;
-                for (int wv = 0; wv < colp / 64; ++wv) acc += part[(threadIdx.x >> 6) + wv];
-            }
-        }
-        if (tc == 0 && live) atomicAdd(dx_chan_sum + ch, acc);
-    }
     if (dc_amax) fsc::publish_amax(dc_amax, mx);
-}
-
-// Per-channel sums of a thread's 8 accumulators into dx_chan_sum.  Same-address float atomics are slow (~250 ns each under
-// contention: 2048 per channel cost the block-0 apply pass +0.5 ms), so a block whose threads all work on one octet
-// reduces through LDS and issues ONE hardware atomic per channel; mixed blocks reduce per wave where the wave is uniform.
-__device__ __forceinline__ void chan_sums_out(const float (&acc)[8], int o, bool g_live, int c, float* dx_chan_sum, bool block_uniform) {
-    __shared__ float cs[kThreads / 64][8];
-    __shared__ int co[kThreads / 64];
-    const int o0 = __builtin_amdgcn_readfirstlane(o);
-    const bool same = __all(o == o0 && g_live);
-    if (!block_uniform) {                       // groups of a block usually share the octet too (images run fastest)
-        if ((threadIdx.x & 63) == 0) co[threadIdx.x >> 6] = same ? o0 : -1 - (int)(threadIdx.x >> 6);
-        __syncthreads();
-        block_uniform = co[0] >= 0 && co[0] == co[1] && co[1] == co[2] && co[2] == co[3];
-    }
-    if (block_uniform) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const float t = fsc::wave_sum(g_live ? acc[e] : 0.f);
-            if ((threadIdx.x & 63) == 0) cs[threadIdx.x >> 6][e] = t;
-        }
-        __syncthreads();
-        if (threadIdx.x < 8 && o0 * 8 + threadIdx.x < c)
-            unsafeAtomicAdd(dx_chan_sum + o0 * 8 + threadIdx.x, (cs[0][threadIdx.x] + cs[1][threadIdx.x]) + (cs[2][threadIdx.x] + cs[3][threadIdx.x]));
-        return;
-    }
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        if (same) {
-            const float t = fsc::wave_sum(acc[e]);
-            if ((threadIdx.x & 63) == 0 && o0 * 8 + e < c) unsafeAtomicAdd(dx_chan_sum + o0 * 8 + e, t);
-        } else if (g_live && o * 8 + e < c) {
-            unsafeAtomicAdd(dx_chan_sum + o * 8 + e, acc[e]);
-        }
-    }
 }
 
 // Backward apply pass writing dx as an L16 tensor (and, optionally, as fp32 planes too).  Same arithmetic as
@@ -1332,7 +1287,7 @@ __device__ __forceinline__ void chan_sums_out(const float (&acc)[8], int o, bool
 template <int VEC, bool UNI>
 __global__ __launch_bounds__(kThreads) void bwd_apply_l16_kernel(BwdArgs a, const float* __restrict__ coef,
                                                                   float* __restrict__ dx, uint4* __restrict__ dx16,
-                                                                  float* __restrict__ dres, float* dx_chan_sum,
+                                                                  float* __restrict__ dres,
                                                                   float* __restrict__ dx_amax, int hwp_log2) {
     __shared__ float red[kThreads / 64];
     float m = 0.f;
@@ -1348,9 +1303,6 @@ __global__ __launch_bounds__(kThreads) void bwd_apply_l16_kernel(BwdArgs a, cons
     const bool g_live = g < (long)a.n * oct;
     const int o = g_live ? (int)(g / a.n) : 0, img = g_live ? (int)(g - (long)o * a.n) : 0;
     const bool has_alpha = a.alpha != nullptr;
-    float acc[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) acc[e] = 0.f;
     const long nq = g_live ? hw / VEC : 0;
     const long xbase = ((long)img * c + o * 8) * hw;
     uint4* const out_hi = dx16 + (((long)img * oct + o) * 2) * hw;
@@ -1395,7 +1347,6 @@ __global__ __launch_bounds__(kThreads) void bwd_apply_l16_kernel(BwdArgs a, cons
                     const float z = fmaf(xh, gm, bt) + rs[p];
                     zv[p] = (has_alpha && !(z > 0.f)) ? al * us[p] : us[p];
                     d[e][p] = k * (zv[p] - c1 - xh * c2);
-                    acc[e] += d[e][p];
                 }
                 if (VEC == 4) {
                     if (dx) reinterpret_cast<float4*>(dx + pb)[q] = make_float4(d[e][0], d[e][1 % VEC], d[e][2 % VEC], d[e][3 % VEC]);
@@ -1427,7 +1378,6 @@ __global__ __launch_bounds__(kThreads) void bwd_apply_l16_kernel(BwdArgs a, cons
             out_lo[q * VEC + p] = lo[p];
         }
     }
-    if (dx_chan_sum) chan_sums_out(acc, o, g_live, c, dx_chan_sum, UNI);
 }
 
 // L16 form of bwd_apply_unpool_kernel: a thread owns one pooled position x the 8 channels of an (octet, image) and writes the
@@ -1436,7 +1386,7 @@ __global__ __launch_bounds__(kThreads) void bwd_apply_l16_kernel(BwdArgs a, cons
 __global__ __launch_bounds__(kThreads) void bwd_apply_unpool_l16_kernel(BwdArgs a, const float* __restrict__ coef,
                                                                          const uint8_t* __restrict__ pool_idx,
                                                                          float* __restrict__ dc, uint4* __restrict__ dc16,
-                                                                         float* dx_chan_sum, int h, int w, int ph, int oh, int ow,
+                                                                         int h, int w, int ph, int oh, int ow,
                                                                          float* __restrict__ dc_amax, int hwp_log2) {
     __shared__ float red[kThreads / 64];
     float m = 0.f;
@@ -1452,9 +1402,6 @@ __global__ __launch_bounds__(kThreads) void bwd_apply_unpool_l16_kernel(BwdArgs 
     const bool g_live = g < (long)a.n * oct;
     const int o = g_live ? (int)(g / a.n) : 0, img = g_live ? (int)(g - (long)o * a.n) : 0;
     const bool has_alpha = a.alpha != nullptr;
-    float acc[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) acc[e] = 0.f;
     const long xbase = ((long)img * c + o * 8) * hw;
     uint4* const out_hi = dc16 + (((long)img * oct + o) * 2) * HW;
     uint4* const out_lo = out_hi + HW;
@@ -1480,7 +1427,6 @@ __global__ __launch_bounds__(kThreads) void bwd_apply_unpool_l16_kernel(BwdArgs 
                 const float up = a.dy[i];
                 const float dz = (has_alpha && !(z > 0.f)) ? al * up : up;
                 d[e] = k * (dz - coef[ch * 2] - xh * coef[ch * 2 + 1]);
-                acc[e] += d[e];
                 pos[e] = pool_idx[i];
                 if (dc) {                                   // fp32 planes as well (bwd_apply_unpool_kernel's stores)
                     typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -1520,11 +1466,10 @@ __global__ __launch_bounds__(kThreads) void bwd_apply_unpool_l16_kernel(BwdArgs 
                     if (o * 8 + e < c) dc[((long)img * c + o * 8 + e) * HW + (long)(h - 1) * w + xx] = 0.f;
         }
     }
-    if (dx_chan_sum) chan_sums_out(acc, o, g_live, c, dx_chan_sum, hwp == kThreads);
 }
 
 __global__ void bwd_apply_flat_kernel(BwdArgs a, const float* __restrict__ coef, float* __restrict__ dx,
-                                      float* __restrict__ dres, float* dx_chan_sum, long total, float* dx_amax) {
+                                      float* __restrict__ dres, long total, float* dx_amax) {
     float mx = 0.f;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const long plane = i / a.hw;
@@ -1540,7 +1485,6 @@ __global__ void bwd_apply_flat_kernel(BwdArgs a, const float* __restrict__ coef,
         const float d = g * invstd * (dz - coef[ch * 2] - xh * coef[ch * 2 + 1]);
         dx[i] = d;
         if (dres) dres[i] = dz;
-        if (dx_chan_sum) atomicAdd(dx_chan_sum + ch, d);
         mx = fmaxf(mx, fabsf(d));
     }
     if (dx_amax) fsc::publish_amax(dx_amax, mx);
@@ -1817,7 +1761,7 @@ int fsc_bn_act_bwd(const float* dy, const float* gmax_dy, const int* gmax_idx, c
         const L16Grid g = l16_grid(n, c, hw, true);
         uint4* dx16 = reinterpret_cast<uint4*>(dx_l16);
 #define FSC_BWD_L16(V_, U_) hipLaunchKernelGGL((bwd_apply_l16_kernel<V_, U_>), g.grid, dim3(kThreads), 0, st, a, p.coef, dx, dx16, \
-                                               dresidual, dx_chan_sum, dx_amax, g.hwp_log2)
+                                               dresidual, dx_amax, g.hwp_log2)
         if (g.vec == 4) { if (g.uni) FSC_BWD_L16(4, true); else FSC_BWD_L16(4, false); }
         else { if (g.uni) FSC_BWD_L16(1, true); else FSC_BWD_L16(1, false); }
 #undef FSC_BWD_L16
@@ -1827,17 +1771,17 @@ int fsc_bn_act_bwd(const float* dy, const float* gmax_dy, const int* gmax_idx, c
     const long total = (long)n * c * hw;
     if (hw >= 512) {
         hipLaunchKernelGGL(bwd_apply_plane_kernel, dim3((unsigned)((long)n * c), plane_grid_y(hw)), dim3(kThreads), 0,
-                           st, a, p.coef, dx, dresidual, dx_chan_sum, dx_amax);
+                           st, a, p.coef, dx, dresidual, dx_amax);
     } else if (hw > 1) {
         const long planes = (long)n * c;
         const int glog = group_log2(hw), per = 4 * (64 >> glog);
         hipLaunchKernelGGL(bwd_apply_wave_kernel, dim3((unsigned)((planes + per - 1) / per)), dim3(kThreads), 0, st, a, p.coef,
-                           dx, dresidual, dx_chan_sum, planes, dx_amax, glog);
+                           dx, dresidual, planes, dx_amax, glog);
     } else {
         long blocks = (total + 255) / 256;
         if (blocks > 8192) blocks = 8192;
         hipLaunchKernelGGL(bwd_apply_flat_kernel, dim3((unsigned)blocks), dim3(256), 0, st, a, p.coef, dx, dresidual,
-                           dx_chan_sum, total, dx_amax);
+                           total, dx_amax);
     }
     FSC_LAUNCH_CHECK("fsc_bn_act_bwd");
     return 0;
@@ -1878,7 +1822,7 @@ int fsc_bn_act_bwd_unpool(const float* dy, const float* x, const float* save_mea
         L16Grid g = l16_grid(n, c, hw, false);
         if (g.uni) g.hwp_log2 = 8;
         hipLaunchKernelGGL(bwd_apply_unpool_l16_kernel, g.grid, dim3(kThreads), 0, st, a, p.coef, pool_idx, dc,
-                           reinterpret_cast<uint4*>(dc_l16), dx_chan_sum, h, w, ph, oh, ow, dc_amax, g.hwp_log2);
+                           reinterpret_cast<uint4*>(dc_l16), h, w, ph, oh, ow, dc_amax, g.hwp_log2);
         FSC_LAUNCH_CHECK("fsc_bn_act_bwd_unpool(l16)");
         return 0;
     }
@@ -1887,7 +1831,7 @@ int fsc_bn_act_bwd_unpool(const float* dy, const float* x, const float* save_mea
     const int per_block = kThreads >> cl;                          // row units (plane, pooled row) per block
     const long row_units = (long)n * c * oh;
     hipLaunchKernelGGL(bwd_apply_unpool_kernel, dim3((unsigned)((row_units + per_block - 1) / per_block)), dim3(kThreads), 0, st, a,
-                       p.coef, pool_idx, dc, dx_chan_sum, h, w, ph, oh, ow, cl, dc_amax, row_units);
+                       p.coef, pool_idx, dc, h, w, ph, oh, ow, cl, dc_amax, row_units);
     FSC_LAUNCH_CHECK("fsc_bn_act_bwd_unpool");
     return 0;
 }

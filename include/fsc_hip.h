@@ -304,8 +304,9 @@ int fsc_bn_act_fwd(const float* x, const float* residual, const float* scale,
  * feeds a global max-pool head, gmax_dy[n*c] scattered at position gmax_idx[n*c] of each plane
  * (both NULL otherwise).  Outputs: dx; dresidual (may be NULL; equals the gradient at the
  * pre-activation); dgamma, dbeta, dalpha (C each; may be NULL); dx_chan_sum (C, may be NULL) =
- * per-channel sum of dx = bias gradient of the convolution that produced x; dx_amax (FSC_AMAX_FLOATS floats, may be
- * NULL) = max |dx|.
+ * per-channel sum of THIS call's dx = bias gradient of the convolution that produced x, evaluated in closed form from
+ * the reduce pass's fp64 sums (k (sum dz - count c1 - c2 sum xhat) for dx = k (dz - c1 - xhat c2)): the sum of the stored
+ * dx up to their own rounding, without one atomic per plane; dx_amax (FSC_AMAX_FLOATS floats, may be NULL) = max |dx|.
  * dx_l16 != NULL: dx is (also) written as an L16 tensor scaled by dx_amax, which then receives an upper bound of
  * max |dx| derived in the reduce pass (|k| (max |dz| + |mean dz| + max |xhat| |mean dz xhat|) per channel; an
  * over-estimate is safe); needs dx_amax and hw > 1; the fp32 `dx` may be NULL then. */

@@ -78,9 +78,6 @@ def _same(a, b, what):
     for k in a:
         if a[k] is None:
             continue
-        if k == "csum":                                      # per-channel atomic float sums of the apply pass: order-dependent
-            assert torch.allclose(a[k], b[k], rtol=1e-4, atol=1e-3), (what, k)
-            continue
         assert torch.equal(a[k], b[k]), (what, k, float((a[k].float() - b[k].float()).abs().max()))
 
 
