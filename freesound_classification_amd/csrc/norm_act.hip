@@ -101,29 +101,49 @@ __device__ __forceinline__ void finalize_channel(const FinalizeArgs& a, int ch, 
     a.shift[ch] = b - (float)mean * sc;
 }
 
-// Threads are split into (image lane tn, pixel lane ti) with `hwp` = power of two >= min(hw, 256)
-// pixel lanes, so planes smaller than the block still keep every lane busy.
+// Small planes in the two reduce passes: a lane owns ONE quad of a plane, 256 / 2^l4 planes side by side, several such groups in
+// flight.  Planes whose length is not a multiple of 4 (the 1-d model: 861, 215, 107, 53 ...) start at any 4-byte offset: their
+// whole 16-byte quads begin `head` elements in, and two more lanes of the plane take the <= 3 elements in front of them and the
+// <= 3 behind (one plane per trip and 53 of 256 lanes busy left the 215-pixel layers of cfg 3 at 0.5 - 1 TB/s).
+struct QuadPos { int base, count; };            // element index of .x inside the plane; elements that exist (4: a whole quad)
+__host__ __device__ inline int small_plane_lanes(long hw) { return (int)(hw >> 2) + ((hw & 3) ? 2 : 0); }
+__host__ __device__ inline bool small_planes(long hw) { return hw <= 4 * kThreads && small_plane_lanes(hw) <= kThreads; }
+__device__ __forceinline__ QuadPos quad_pos(long plane_off, int hw, int ti4) {
+    const int hr = (int)((4 - (plane_off & 3)) & 3);
+    const int head = hr < hw ? hr : hw;
+    const int n4 = (hw - head) >> 2;
+    if (ti4 < n4) return QuadPos{head + 4 * ti4, 4};
+    if (ti4 == n4) return QuadPos{0, head};
+    if (ti4 == n4 + 1) return QuadPos{head + 4 * n4, hw - head - 4 * n4};
+    return QuadPos{0, 0};
+}
+__device__ __forceinline__ float4 load_quad(const float* plane, QuadPos q, float fill) {
+    if (q.count == 4) return *reinterpret_cast<const float4*>(plane + q.base);
+    float4 r = make_float4(fill, fill, fill, fill);
+    if (q.count > 0) r.x = plane[q.base];
+    if (q.count > 1) r.y = plane[q.base + 1];
+    if (q.count > 2) r.z = plane[q.base + 2];
+    return r;
+}
+
+// Larger planes: one plane at a time per workgroup, 16-byte loads behind an alignment peel.
 // With `tickets` the workgroup that finishes a channel last also finalises it (stats_finalize_kernel's arithmetic in the same
 // order; see bwd_partial_kernel): the single-replica statistics pass is one launch.
 __global__ __launch_bounds__(kThreads) void stats_partial_kernel(
-    const float* __restrict__ x, int n, int c, long hw, int nsplit, int hwp_log2, double* part, FinalizeArgs fa, unsigned* tickets) {
+    const float* __restrict__ x, int n, int c, long hw, int nsplit, double* part, FinalizeArgs fa, unsigned* tickets) {
     __shared__ double scratch[kThreads / 64];
     const int ch = blockIdx.x, sp = blockIdx.y;
     const float pivot = x[(long)ch * hw];
-    const int hwp = 1 << hwp_log2, groups = kThreads >> hwp_log2;
-    const int tn = threadIdx.x >> hwp_log2, ti = threadIdx.x & (hwp - 1);
+    const int ti = threadIdx.x;
     float s1 = 0.f, s2 = 0.f;
     float mn = pivot, mx = pivot;          // smallest / largest x of the channel (the L16 producers' operand bound)
-    const bool vec = hwp == kThreads;          // planes of >= 256 pixels: 16-byte loads behind an alignment peel
-    if ((hw & 3) == 0 && hw <= 2 * kThreads) {
-        // planes of at most 128 quads: a lane owns one quad of a plane, 256 / 2^l4 images side by side, four of those
-        // groups in flight (one image per trip left the 208-pixel layers of cfg 2 at 1 TB/s).  Idle lanes and trips past the
-        // batch read the pivot, which adds nothing to the shifted sums and lies inside [min, max].
-        const int n4 = (int)(hw >> 2);
+    if (small_planes(hw)) {
+        // four groups of planes in flight (one image per trip left the 208-pixel layers of cfg 2 at 1 TB/s).  Idle lanes and
+        // trips past the batch read the pivot, which adds nothing to the shifted sums and lies inside [min, max].
+        const int q4 = small_plane_lanes(hw);
         int l4 = 0;
-        while ((1 << l4) < n4) ++l4;
+        while ((1 << l4) < q4) ++l4;
         const int g4 = kThreads >> l4, tn4 = threadIdx.x >> l4, ti4 = threadIdx.x & ((1 << l4) - 1);
-        const bool live = ti4 < n4;
         const int stride = nsplit * g4;
         const float4 fill = make_float4(pivot, pivot, pivot, pivot);
         for (int b = sp * g4 + tn4; b < n; b += 4 * stride) {
@@ -131,7 +151,8 @@ __global__ __launch_bounds__(kThreads) void stats_partial_kernel(
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const int bb = b + k * stride;
-                v[k] = (live && bb < n) ? reinterpret_cast<const float4*>(x + ((long)bb * c + ch) * hw)[ti4] : fill;
+                const long off = ((long)bb * c + ch) * hw;
+                v[k] = bb < n ? load_quad(x + off, quad_pos(off, (int)hw, ti4), pivot) : fill;
             }
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
@@ -143,9 +164,9 @@ __global__ __launch_bounds__(kThreads) void stats_partial_kernel(
             }
         }
     } else
-    for (int b = sp * groups + tn; b < n; b += nsplit * groups) {
+    for (int b = sp; b < n; b += nsplit) {
         const float* p = x + ((long)b * c + ch) * hw;
-        if (vec) {
+        {
             const int head = (int)((4 - ((((long)b * c + ch) * hw) & 3)) & 3);
             const float4* p4 = reinterpret_cast<const float4*>(p + head);
             const long n4 = (hw - head) >> 2;
@@ -203,14 +224,6 @@ __global__ __launch_bounds__(kThreads) void stats_partial_kernel(
             }
             s1 += (t1[0] + t1[1]) + t1[2];
             s2 += (t2[0] + t2[1]) + t2[2];
-        } else {
-            for (long i = ti; i < hw; i += hwp) {
-                const float a0 = p[i] - pivot;
-                s1 += a0;
-                s2 += a0 * a0;
-                mn = fminf(mn, p[i]);
-                mx = fmaxf(mx, p[i]);
-            }
         }
     }
     const double t1 = fsc::block_sum<double, kThreads / 64>((double)s1, scratch);
@@ -880,16 +893,14 @@ struct BwdFinish {
     int want_bound;
 };
 
-__global__ __launch_bounds__(kThreads) void bwd_partial_kernel(BwdArgs a, int nsplit, int hwp_log2,
-                                                               double* part, BwdFinish fin) {
+__global__ __launch_bounds__(kThreads) void bwd_partial_kernel(BwdArgs a, int nsplit, double* part, BwdFinish fin) {
     __shared__ double scratch[kThreads / 64];
     const int ch = blockIdx.x, sp = blockIdx.y;
     const float mean = a.mean[ch], invstd = a.invstd[ch];
     const float g = a.gamma ? a.gamma[ch] : 1.f, b = a.beta ? a.beta[ch] : 0.f;
     const bool has_alpha = a.alpha != nullptr;
     const float al = has_alpha ? a.alpha[ch] : 1.f;
-    const int hwp = 1 << hwp_log2, groups = kThreads >> hwp_log2;
-    const int tn = threadIdx.x >> hwp_log2, ti = threadIdx.x & (hwp - 1);
+    const int ti = threadIdx.x;
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
     float mdz = 0.f, mxh = 0.f;            // max |dz|, max |xhat|: the bound of |dx| for the L16 apply pass
     auto quad = [&](const float4& xv, const float4& rv, const float4& uv) {
@@ -908,46 +919,48 @@ __global__ __launch_bounds__(kThreads) void bwd_partial_kernel(BwdArgs a, int ns
             mxh = fmaxf(mxh, fabsf(xh));
         }
     };
-    if ((a.hw & 3) == 0 && a.hw <= 2 * kThreads) {
+    if (small_planes(a.hw)) {
         // small planes: one quad per lane, several images side by side, two groups of them in flight (see stats_partial_kernel);
-        // idle lanes take x = mean, dy = 0, which add nothing
-        const int n4 = (int)(a.hw >> 2);
+        // idle lanes and missing elements take x = mean, dy = 0, which add nothing
+        const int q4 = small_plane_lanes(a.hw);
         int l4 = 0;
-        while ((1 << l4) < n4) ++l4;
+        while ((1 << l4) < q4) ++l4;
         const int g4 = kThreads >> l4, tn4 = threadIdx.x >> l4, ti4 = threadIdx.x & ((1 << l4) - 1);
-        const bool live = ti4 < n4;
         const int stride = nsplit * g4;
-        const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f), mean4 = make_float4(mean, mean, mean, mean);
+        const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
         for (int nb = sp * g4 + tn4; nb < a.n; nb += 2 * stride) {
             float4 xv[2], rv[2], uv[2];
 #pragma unroll
             for (int k = 0; k < 2; ++k) {
                 const int bb = nb + k * stride;
-                const bool ok = live && bb < a.n;
+                const bool ok = bb < a.n;
                 const long plane = (long)(ok ? bb : nb) * a.c + ch;
-                xv[k] = ok ? reinterpret_cast<const float4*>(a.x + plane * a.hw)[ti4] : mean4;
-                rv[k] = (ok && a.res) ? reinterpret_cast<const float4*>(a.res + plane * a.hw)[ti4] : zero4;
-                uv[k] = (ok && a.dy) ? reinterpret_cast<const float4*>(a.dy + plane * a.hw)[ti4] : zero4;
-                if (ok && a.gmax_dy) {
-                    const int d = a.gmax_idx[plane] - ti4 * 4;
+                const long off = plane * a.hw;
+                QuadPos q = quad_pos(off, (int)a.hw, ti4);
+                if (!ok) q.count = 0;
+                xv[k] = load_quad(a.x + off, q, mean);
+                rv[k] = a.res ? load_quad(a.res + off, q, 0.f) : zero4;
+                uv[k] = a.dy ? load_quad(a.dy + off, q, 0.f) : zero4;
+                if (q.count > 0 && a.gmax_dy) {
+                    const int d = a.gmax_idx[plane] - q.base;
                     const float gval = a.gmax_dy[plane];
-                    if (d == 0) uv[k].x += gval; else if (d == 1) uv[k].y += gval; else if (d == 2) uv[k].z += gval; else if (d == 3) uv[k].w += gval;
+                    if (d >= 0 && d < q.count) { if (d == 0) uv[k].x += gval; else if (d == 1) uv[k].y += gval; else if (d == 2) uv[k].z += gval; else uv[k].w += gval; }
                 }
             }
 #pragma unroll
             for (int k = 0; k < 2; ++k) quad(xv[k], rv[k], uv[k]);
         }
     } else
-    for (int nb = sp * groups + tn; nb < a.n; nb += nsplit * groups) {
+    for (int nb = sp; nb < a.n; nb += nsplit) {
         const long plane = (long)nb * a.c + ch;
         const float* px = a.x + plane * a.hw;
         const float* pr = a.res ? a.res + plane * a.hw : nullptr;
         const float* pdy = a.dy ? a.dy + plane * a.hw : nullptr;
         const float gval = a.gmax_dy ? a.gmax_dy[plane] : 0.f;
         const long gpos = a.gmax_dy ? (long)a.gmax_idx[plane] : -1;
-        if (hwp == kThreads) {
-            // 16-byte loads for planes of >= 256 pixels, whatever their length: head elements up to the plane's first 16-byte
-            // boundary (odd lengths -- the 1-d model -- put planes at any 4-byte offset), whole quads, tail
+        {
+            // 16-byte loads whatever the plane's length: head elements up to the plane's first 16-byte boundary (odd lengths -- the
+            // 1-d model -- put planes at any 4-byte offset), whole quads, tail
             const int head = (int)((4 - ((plane * a.hw) & 3)) & 3);
             const long n4 = (a.hw - head) >> 2;
             for (long i4 = ti; i4 < n4; i4 += kThreads) {
@@ -976,21 +989,6 @@ __global__ __launch_bounds__(kThreads) void bwd_partial_kernel(BwdArgs a, int ns
                     mxh = fmaxf(mxh, fabsf(xh));
                 }
             }
-            continue;
-        }
-        for (long i = ti; i < a.hw; i += hwp) {
-            const float xh = (px[i] - mean) * invstd;
-            float z = fmaf(xh, g, b);
-            if (pr) z += pr[i];
-            const float up = upstream(a, pdy, i, gval, gpos);
-            const bool neg = has_alpha && !(z > 0.f);
-            const float dz = neg ? al * up : up;
-            s0 += dz;
-            s1 += dz * xh;
-            s2 += up * (neg ? z : 0.f);
-            s3 += xh;
-            mdz = fmaxf(mdz, fabsf(dz));
-            mxh = fmaxf(mxh, fabsf(xh));
         }
     }
     const double t0 = fsc::block_sum<double, kThreads / 64>((double)s0, scratch);
@@ -1493,19 +1491,13 @@ __global__ void bwd_apply_flat_kernel(BwdArgs a, const float* __restrict__ coef,
 int pick_split(int n, int c, long hw) {
     // enough blocks to fill 256 CUs a few times over, bounded by the batch and the workspace
     long want = (256L * 8 + c - 1) / c;
-    const long per_block = hw <= 2 * kThreads ? 4096 : 16384;      // (small planes are latency-bound: more, shorter blocks)
+    const long per_block = small_planes(hw) ? 4096 : 16384;        // (small planes are latency-bound: more, shorter blocks)
     long by_work = ((long)n * hw + per_block - 1) / per_block;
     long s = want < by_work ? want : by_work;
     if (s > n) s = n;
     if (s > kMaxSplit) s = kMaxSplit;
     if (s < 1) s = 1;
     return (int)s;
-}
-
-int hwp_log2_for(long hw) {
-    int l = 0;
-    while ((1L << l) < hw && l < 8) ++l;      // 2^l >= min(hw, 256)
-    return l;
 }
 
 // launch geometry of the L16 producer kernels: positions per group lane-split, blocks, UNI
@@ -1582,8 +1574,7 @@ int fsc_bn_train_stats(const float* x, int n, int c, long hw, const float* gamma
                             save_mean, save_invstd, scale, shift, sync, phase, x_minmax, pivot_rm, minmax_only};
             unsigned* tickets = nullptr;
             if (phase == 0 && !pivot_rm && zero_tickets) tickets = p.tickets;
-            hipLaunchKernelGGL(stats_partial_kernel, dim3(c, nsplit), dim3(kThreads), 0, st, x, n, c, hw, nsplit,
-                               hwp_log2_for(hw), p.part, fa, tickets);
+            hipLaunchKernelGGL(stats_partial_kernel, dim3(c, nsplit), dim3(kThreads), 0, st, x, n, c, hw, nsplit, p.part, fa, tickets);
             if (tickets) {
                 FSC_LAUNCH_CHECK("fsc_bn_train_stats");
                 return 0;
@@ -1746,7 +1737,7 @@ int fsc_bn_act_bwd(const float* dy, const float* gmax_dy, const int* gmax_idx, c
             FSC_CHECK_ARG(gmax_dy == nullptr, "fsc_bn_act_bwd: global-max gradient needs hw > 1");
             hipLaunchKernelGGL(bwd_rows_kernel, dim3(fsc::ceil_div(c, 128), nsplit), dim3(128), 0, st, a, p.part);
         } else {
-            hipLaunchKernelGGL(bwd_partial_kernel, dim3(c, nsplit), dim3(kThreads), 0, st, a, nsplit, hwp_log2_for(hw), p.part, fin);
+            hipLaunchKernelGGL(bwd_partial_kernel, dim3(c, nsplit), dim3(kThreads), 0, st, a, nsplit, p.part, fin);
         }
     }
     if (!fin.tickets)
@@ -1809,7 +1800,7 @@ int fsc_bn_act_bwd_unpool(const float* dy, const float* x, const float* save_mea
         fin = BwdFinish{p.tickets, (double)n * (double)hw, dgamma, dbeta, dalpha, p.coef, dx_chan_sum, dc_amax, dc_l16 ? 1 : 0};
     }
     if (phase != 2)
-        hipLaunchKernelGGL(bwd_partial_kernel, dim3(c, nsplit), dim3(kThreads), 0, st, a, nsplit, hwp_log2_for(hw), p.part, fin);
+        hipLaunchKernelGGL(bwd_partial_kernel, dim3(c, nsplit), dim3(kThreads), 0, st, a, nsplit, p.part, fin);
     if (!fin.tickets)
         hipLaunchKernelGGL(bwd_finalize_kernel, dim3(fsc::ceil_div(c, 128)), dim3(128), 0, st, c, (double)n * (double)hw,
                            nsplit, p.part, dgamma, dbeta, dalpha, p.coef, dx_chan_sum, dc_amax, sync, phase, gamma, save_invstd,

@@ -1,0 +1,6 @@
+for r in 1 2; do for v in old new; do cp tools/ab/libfsc_$v.so freesound_classification_amd/libfsc_hip.so
+python bench.py --workload cfg3 --steps 20 --warmup 5 --graph --no-cpu-baseline --no-other 2>/dev/null | python -c "import json,sys; d=json.load(sys.stdin); print('cfg3 $v', round(d['value'],1), round(d['ms_per_step'],3))"
+done; done
+cp tools/ab/libfsc_new.so freesound_classification_amd/libfsc_hip.so
+python -m pytest tests/test_kernels_gpu.py tests/test_l16_gpu.py tests/test_r4_gpu.py tests/test_model_gpu.py tests/test_parity_r3_gpu.py -x -q 2>&1 | tail -5
+bash tools/ab/run.sh 2>&1 | tail -6
