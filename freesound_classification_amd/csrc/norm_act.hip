@@ -1715,7 +1715,8 @@ int fsc_bn_act_bwd(const float* dy, const float* gmax_dy, const int* gmax_idx, c
                    const float* gamma, const float* beta, const float* alpha, float* dx, float* dresidual,
                    float* dgamma, float* dbeta, float* dalpha, float* dx_chan_sum, int n, int c, long hw,
                    void* workspace, float* dx_amax, double* sync, int phase, void* dx_l16, fsc_stream_t stream) {
-    FSC_CHECK_ARG(x && save_mean && save_invstd && (dx || dx_l16) && workspace, "fsc_bn_act_bwd: null pointer");
+    FSC_CHECK_ARG(x && save_mean && save_invstd && (dx || dx_l16 || (phase & ~FSC_BN_TICKETS) == 1) && workspace,
+                  "fsc_bn_act_bwd: null pointer");
     FSC_CHECK_ARG(!dx_l16 || (dx_amax && hw > 1), "fsc_bn_act_bwd: the L16 output needs dx_amax and hw > 1");
     const bool zero_tickets = (phase & FSC_BN_TICKETS) != 0;
     phase &= ~FSC_BN_TICKETS;

@@ -975,12 +975,13 @@ def bn_act_forward(x, st, alpha=None, residual=None, with_amax=False, l16=False,
 def bn_act_backward(dy, x, st, bn, alpha=None, residual=None, gmax=None, want_dx=True,
                     want_dres=False, want_chan_sum=False, with_amax=False, sync=None, l16=False, want_f32=True):
     """Returns (dx, dresidual, dgamma, dbeta, dalpha, dx_chan_sum) [+ (max |dx|,) with with_amax].
+    want_dx=False: only the parameter gradients (dx, dresidual, dx_chan_sum and the amax stay unwritten / None).
     l16 (with with_amax): dx is also (want_f32) or only written as an L16 tensor; the last element of the result is then
     that L16 (its .amax is the declared bound) instead of the amax buffer."""
     n, c = x.shape[0], x.shape[1]
     hw = x.numel() // (n * c)
-    l16 = l16 and with_amax and hw > 1
-    dx = torch.empty_like(x) if (want_f32 or not l16) else None     # (the apply pass also yields chan sums)
+    l16 = l16 and with_amax and hw > 1 and want_dx
+    dx = torch.empty_like(x) if (want_f32 or not l16) and want_dx else None
     dres = torch.empty_like(x) if want_dres else None
     dgamma = _empty((c,), x)
     dbeta = _empty((c,), x)
@@ -994,7 +995,12 @@ def bn_act_backward(dy, x, st, bn, alpha=None, residual=None, gmax=None, want_dx
             ptr(st.invstd), ptr(bn.weight), ptr(bn.bias), ptr(alpha), ptr(dx), ptr(dres), ptr(dgamma),
             ptr(dbeta), ptr(dalpha), ptr(csum), n, c, hw, ptr(ws), ptr(dx_amax))
     t_ptr = ptr(t.data) if l16 else None
-    if sync is None:
+    if not want_dx:
+        # parameter gradients only (an input that needs no gradient): the reduce pass and its finalisation -- phase 1 of the
+        # replicated form, whose sums (this replica's; the gradient all-reduce adds the replicas) nobody reads here
+        with _stage("bn_act_bwd", _nb(dy, x, residual)):
+            call("fsc_bn_act_bwd", *args, ptr(_sync_buffer(c, x)), 1, None, stream_ptr())
+    elif sync is None:
         # reduce pass reads dy, x, residual; apply pass reads them again and writes dx (fp32 and / or L16) and dresidual
         with _stage("bn_act_bwd", 2 * _nb(dy, x, residual) + _nb(dx, dres, t)):
             call("fsc_bn_act_bwd", *args, None, BN_TICKETS, t_ptr, stream_ptr())
@@ -1524,9 +1530,7 @@ class ConvBlockFn(torch.autograd.Function):
             else:
                 da = _conv_dgrad_any(dc, _l16_of(dc_m), wa, a_shape, _amax_of(dc_m), prepacked=pk_a)
                 del dc, dc_m
-                dx, _, dga, dbta, _, _ = bn_act_backward(da, k.x, k.st_a, bn_a, sync=sync)
-                if not ctx.x_needs_grad:
-                    dx = None
+                dx, _, dga, dbta, _, _ = bn_act_backward(da, k.x, k.st_a, bn_a, sync=sync, want_dx=ctx.x_needs_grad)
 
         def like(param, g):
             return g.reshape(param.shape) if g is not None else None

@@ -218,7 +218,8 @@ int fsc_bn_workspace_reset(void* workspace, int c, fsc_stream_t stream);
  * BatchNorm at classifiers.py:524,533,78-82,543,545 always sees the whole batch).  The three training entry points
  * below take `sync` -- FSC_BN_SYNC_DOUBLES(c) doubles, per channel [sum a, sum b, count, 0] -- and `phase`:
  *   0  single replica, `sync` unused (may be NULL);
- *   1  reduce the local batch, write the local sums to `sync`, return (no outputs besides the parameter gradients);
+ *   1  reduce the local batch, write the local sums to `sync`, return (no outputs besides the parameter gradients: a backward
+ *      call may pass dx = NULL -- also the way to get ONLY the parameter gradients when the input needs no gradient);
  *      the CALLER then sum-all-reduces `sync` over the replicas (RCCL; one small message per layer);
  *   2  finish from the reduced `sync` (statistics / input gradient use the global sums and count).
  * forward: [sum x, sum x^2, count] about zero; backward: [sum dz, sum dz*xhat, count].  dgamma / dbeta / dalpha are
