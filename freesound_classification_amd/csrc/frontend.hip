@@ -75,7 +75,7 @@ __global__ __launch_bounds__(kThreads) void frontend_kernel(FrontendArgs a) {
     __syncthreads();
     // a frame's buffers belong to its `tpf` threads: with one wavefront per frame (n_fft <= 256) the passes of a frame are
     // ordered by the wave's own LDS queue and need no workgroup barrier (seven per frame otherwise)
-    const bool wave_frames = tpf == 64 && !a.block_sync;
+    const bool wave_frames = tpf <= 64 && !a.block_sync;
     auto frame_sync = [&]() {
         if (wave_frames) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier(); }
         else __syncthreads();
@@ -443,6 +443,162 @@ __global__ __launch_bounds__(kThreads, FSC_FE_MINWAVES) void frontend2048_kernel
     }
 }
 
+// -------------------------------------------------------------------------------------------
+// n_fft = 256, magnitude / log-magnitude output (the 1-d model's stft_256_* features): EIGHT LANES per frame, eight frames per wave.
+// The 128-point complex FFT of the packed frame is 16 x 8 (decimation in time):
+//   A  lane L of a frame holds z[8 n1 + L], n1 = 0..15: a 16-point FFT in registers, twiddle W_128^(L k1);
+//   B  transpose through the wave's LDS patch: lane j takes rows k1 = 2 j, 2 j + 1 (8 columns each): two 8-point FFTs in registers;
+//   C  the spectrum returns to the patch in natural order and lane L unpacks bins L + 8 m of the real transform into the
+//      workgroup's [bin][frame] tile, which leaves as 128-byte runs along the frame axis.
+// Three LDS round trips per EIGHT frames of a wave; the generic kernel above takes seven per frame (one wave per frame, four
+// butterfly passes with half of the lanes idle): 0.47 ms for the 453 MB of cfg 3 (tools/frontend256_bench.py).
+constexpr int kF8Frames = 32;                     // frames per workgroup: 4 waves x 8
+constexpr int kF8Stride = 272;                    // floats per frame in a patch: 128 complex + 16 (frames of a lane group on disjoint banks)
+constexpr int kF8TileLd = 36;                     // tile row stride: lanes (frame, bin + 1) four banks apart
+
+// forward 8-point DFT in registers, natural order in and out
+__device__ __forceinline__ void fft8(float2 (&v)[8]) {
+    constexpr float h = 0.70710678118654752f;
+    float2 e0 = v[0], e1 = v[2], e2 = v[4], e3 = v[6], o0 = v[1], o1 = v[3], o2 = v[5], o3 = v[7];
+    dft4(e0, e1, e2, e3);
+    dft4(o0, o1, o2, o3);
+    o1 = cmul(o1, make_float2(h, -h));
+    o2 = mul_mi(o2);
+    o3 = cmul(o3, make_float2(-h, -h));
+    v[0] = cadd(e0, o0); v[4] = csub(e0, o0);
+    v[1] = cadd(e1, o1); v[5] = csub(e1, o1);
+    v[2] = cadd(e2, o2); v[6] = csub(e2, o2);
+    v[3] = cadd(e3, o3); v[7] = csub(e3, o3);
+}
+
+__global__ __launch_bounds__(kThreads) void frontend256_kernel(FrontendArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int NC = 128;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int fw = lane >> 3, L = lane & 7;
+    const int clip = blockIdx.y;
+    const int f_base = blockIdx.x * kF8Frames;
+    float2* tw = reinterpret_cast<float2*>(smem);                          // exp(-2 pi i m / 256), m = 0..255
+    float* win = smem + 512;                                               // Hann window, 256
+    float* patch = smem + 768 + (wid * 8 + fw) * kF8Stride;                // this frame's 128 complex
+    float* tile = smem + 768;                                              // 129 x kF8TileLd, over the patches once they are done
+    tw[tid] = reinterpret_cast<const float2*>(a.tables + 256)[tid];
+    win[tid] = a.tables[tid];
+    __syncthreads();
+
+    const float* wav = a.wave + (long)clip * a.wave_stride;
+    const int t = a.t;
+    const int fl = wid * 8 + fw;
+    const int f = f_base + fl;
+    if (f < a.frames) {
+        // ---- A: load + window + pack: z[n] = (x[2n] w[2n], x[2n+1] w[2n+1]), n = 8 n1 + L
+        float2 x[16];
+        const long s0 = (long)f * a.hop - NC;
+        const bool pairs = s0 >= 0 && s0 + 2 * NC <= t && ((s0 | a.wave_stride) & 1) == 0 &&
+                           (reinterpret_cast<uintptr_t>(a.wave) & 7) == 0;
+        if (pairs) {
+            const float2* src = reinterpret_cast<const float2*>(wav + s0) + L;
+#pragma unroll
+            for (int n1 = 0; n1 < 16; ++n1) {
+                const float2 w = reinterpret_cast<const float2*>(win)[8 * n1 + L];
+                const float2 v = src[8 * n1];
+                x[n1] = make_float2(v.x * w.x, v.y * w.y);
+            }
+        } else {
+            // reflect padding without branches (ops/utils.py:110-127: center=True, pad_mode="reflect"; t > n_fft / 2)
+            const int base = (int)s0 + 2 * L, hi = 2 * (t - 1);
+#pragma unroll
+            for (int n1 = 0; n1 < 16; ++n1) {
+                const float2 w = reinterpret_cast<const float2*>(win)[8 * n1 + L];
+                int i0 = base + 16 * n1, i1 = i0 + 1;
+                i0 = i0 < 0 ? -i0 : i0; i1 = i1 < 0 ? -i1 : i1;
+                i0 = i0 >= t ? hi - i0 : i0; i1 = i1 >= t ? hi - i1 : i1;
+                x[n1] = make_float2(wav[i0] * w.x, wav[i1] * w.y);
+            }
+        }
+        fft16(x);
+        // twiddle W_128^(L k1) = exp(-2 pi i 2 L k1 / 256); rows [k1][L] into the patch
+        float2* pc = reinterpret_cast<float2*>(patch);
+        pc[L] = x[0];
+#pragma unroll
+        for (int k1 = 1; k1 < 16; ++k1) pc[k1 * 8 + L] = cmul(x[k1], tw[2 * L * k1]);
+    }
+    // a frame's patch belongs to its eight lanes: the wave's own LDS queue orders the passes
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    if (f < a.frames) {
+        // ---- B: lane j = L takes rows k1 = 2 L, 2 L + 1: 16 consecutive complex of the patch
+        float2 r0[8], r1[8];
+        const float4* p4 = reinterpret_cast<const float4*>(patch + 32 * L);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 u = p4[q], v = p4[4 + q];
+            r0[2 * q] = make_float2(u.x, u.y); r0[2 * q + 1] = make_float2(u.z, u.w);
+            r1[2 * q] = make_float2(v.x, v.y); r1[2 * q + 1] = make_float2(v.z, v.w);
+        }
+        fft8(r0);
+        fft8(r1);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();                   // every lane of the frame has read its rows
+        // ---- C: Z[k1 + 16 k2] in natural order: (k1, k1 + 1) = (2 L, 2 L + 1) are neighbours
+        float4* o4 = reinterpret_cast<float4*>(patch + 4 * L);
+#pragma unroll
+        for (int k2 = 0; k2 < 8; ++k2) o4[8 * k2] = make_float4(r0[k2].x, r0[k2].y, r1[k2].x, r1[k2].y);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    float val[17];
+    if (f < a.frames) {
+        // ---- unpack the real transform: bins k = L + 8 m (m = 0..15) and bin 128 (lane 0 of the frame; the others repeat bin L)
+        const float2* pc = reinterpret_cast<const float2*>(patch);
+#pragma unroll
+        for (int m = 0; m <= 16; ++m) {
+            const int k = (m == 16 && L != 0) ? L : L + 8 * m;
+            const float2 zk = pc[k & (NC - 1)], zr = pc[(NC - k) & (NC - 1)];
+            const float2 e = make_float2(0.5f * (zk.x + zr.x), 0.5f * (zk.y - zr.y));
+            const float2 o = make_float2(0.5f * (zk.y + zr.y), -0.5f * (zk.x - zr.x));
+            const float2 wo = cmul(tw[k], o);
+            const float re = e.x + wo.x, im = e.y + wo.y;
+            const float mg = __builtin_amdgcn_sqrtf(re * re + im * im);
+            val[m] = a.apply_log ? logf(mg + a.log_eps) : mg;
+        }
+    }
+    __syncthreads();                                        // every wave is through with its patches: the tile takes their place
+    if (f < a.frames) {
+#pragma unroll
+        for (int m = 0; m < 16; ++m) tile[(L + 8 * m) * kF8TileLd + fl] = val[m];
+        if (L == 0) tile[NC * kF8TileLd + fl] = val[16];
+    }
+    __syncthreads();
+    // ---- coalesced store of the tile: rows = bins, 32 consecutive frames each
+    const int fvalid = min(kF8Frames, a.frames - f_base);
+    float* dst_g = a.out + (long)clip * a.out_n_stride;
+    for (int i = tid; i < (NC + 1) * kF8Frames; i += kThreads) {
+        const int row = i >> 5, c = i & 31;
+        if (c < fvalid) dst_g[(long)row * a.frames + f_base + c] = tile[row * kF8TileLd + c];
+    }
+    if (a.freq_channel) {
+        float* fq = dst_g + (long)(NC + 1) * a.frames;
+        const float step = 2.0f / (float)NC;
+        for (int i = tid; i < (NC + 1) * kF8Frames; i += kThreads) {
+            const int row = i >> 5, c = i & 31;
+            const float v = (row < (NC + 1) / 2) ? (-1.0f + step * (float)row) : (1.0f - step * (float)(NC - row));
+            if (c < fvalid) fq[(long)row * a.frames + f_base + c] = v;
+        }
+    }
+}
+
+int launch256(const FrontendArgs& base, int n, hipStream_t stream) {
+    FrontendArgs a = base;
+    a.fg = kF8Frames;
+    static_assert((kThreads / 8) * kF8Stride >= 129 * kF8TileLd, "the tile reuses the patches");
+    const size_t lds = sizeof(float) * ((size_t)768 + (size_t)(kThreads / 8) * kF8Stride);
+    dim3 grid(fsc::ceil_div(a.frames, kF8Frames), n);
+    hipLaunchKernelGGL(frontend256_kernel, grid, dim3(kThreads), lds, stream, a);
+    FSC_LAUNCH_CHECK("fsc_frontend(256)");
+    return 0;
+}
+
 int launch2048(const FrontendArgs& base, bool mel, int n, hipStream_t stream) {
     FrontendArgs a = base;
     a.fg = mel ? kF2Frames : 8;
@@ -463,16 +619,21 @@ int launch2048(const FrontendArgs& base, bool mel, int n, hipStream_t stream) {
 bool pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
 
 int launch2048(const FrontendArgs& base, bool mel, int n, hipStream_t stream);
+int launch256(const FrontendArgs& base, int n, hipStream_t stream);
 
 int launch(const FrontendArgs& base, bool mel, int n, hipStream_t stream) {
     if (base.n_fft == 2048 && !fsc::env().frontend_generic) {
         const int rc = launch2048(base, mel, n, stream);
         if (rc >= 0) return rc;
     }
+    if (base.n_fft == 256 && !mel && base.t > 128 && !fsc::env().frontend_generic) return launch256(base, n, stream);
     FrontendArgs a = base;
     const int nc = a.n_fft / 2;
     int tpf = nc / 8;            // two butterflies per thread and pass: two frames share the barriers of a workgroup
-    if (tpf < 64) tpf = 64;
+#ifndef FSC_FE_TPF_MIN
+#define FSC_FE_TPF_MIN 64
+#endif
+    if (tpf < FSC_FE_TPF_MIN) tpf = FSC_FE_TPF_MIN;
     if (tpf > kThreads) tpf = kThreads;
     a.tpf = tpf;
     a.block_sync = fsc::env().fe_block_sync ? 1 : 0;
