@@ -448,7 +448,7 @@ typedef struct {
     long count;
 } fsc_opt_tensor;
 
-/* tensors_host is a HOST array (copied into kernel arguments, 24 tensors per launch).
+/* tensors_host is a HOST array (copied into kernel arguments, 64 tensors per launch).
  * step = 1-based step count used for bias correction; grad_scale multiplies every gradient
  * first (1/world_size after a sum all-reduce). */
 int fsc_adam_amsgrad_step(const fsc_opt_tensor* tensors_host, int n_tensors, float lr,
