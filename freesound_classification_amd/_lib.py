@@ -46,6 +46,8 @@ SIGNATURES = {
     "fsc_frontend_stft_fwd": (_I, [_P, _I, _I, _L, _I, _I, _P, _I, _F, _P, _L, _I, _P]),
     "fsc_conv_packed_floats": (_SZ, [_D, _I]),
     "fsc_conv_pack_weights": (_I, [_D, _P, _I, _P, _P]),
+    "fsc_conv_pack_weights_multi_supported": (_I, [_D, _I]),
+    "fsc_conv_pack_weights_multi": (_I, [_I, _P, _P, _P, _P, _P]),
     "fsc_conv_fwd": (_I, [_D, _P, _P, _P, _I, _I, _P, _P, _P]),
     "fsc_amax": (_I, [_P, _L, _P, _P]),
     "fsc_conv_pool_supported": (_I, [_D]),

@@ -1053,12 +1053,12 @@ __global__ __launch_bounds__(256) void amax_kernel(const float* __restrict__ x, 
 // packed[co block][step][channel tile][limb][lane][8 bf16]; lane = (kq, m), its 8 values are the channels
 // of octet `oct` at tap `tap` where (tap, oct) = divmod(4 * step_in_chunk + kq, octets of the chunk)
 // `w_amax` != null: two fp16 limbs of the weights scaled by scale_field(*w_amax) instead of three bf16 limbs
-__global__ void pack_x3_kernel(const float* __restrict__ w, unsigned short* __restrict__ packed, int c_out, int c_in,
-                               int taps, int cot, int co_blocks, int nfull, int tail_oct, int steps, int nch, int dgrad,
-                               const float* __restrict__ w_amax, int nl) {
+__device__ __forceinline__ void pack_x3_items(const float* __restrict__ w, unsigned short* __restrict__ packed, int c_out, int c_in,
+                                              int taps, int cot, int co_blocks, int nfull, int tail_oct, int steps, int nch, int dgrad,
+                                              const float* __restrict__ w_amax, int nl, long first, long stride) {
     const long total = (long)co_blocks * steps * cot * 512;
     const float sw = w_amax ? field_to_float(scale_field(*w_amax)) : 1.f;
-    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    for (long idx = first; idx < total; idx += stride) {
         const int e = (int)(idx & 7), lane = (int)((idx >> 3) & 63);
         long rest = idx >> 9;
         const int i = (int)(rest % cot); rest /= cot;
@@ -1095,6 +1095,39 @@ __global__ void pack_x3_kernel(const float* __restrict__ w, unsigned short* __re
         packed[base + 512] = (unsigned short)mp;
         packed[base + 1024] = (unsigned short)lp;
     }
+}
+
+__global__ void pack_x3_kernel(const float* __restrict__ w, unsigned short* __restrict__ packed, int c_out, int c_in,
+                               int taps, int cot, int co_blocks, int nfull, int tail_oct, int steps, int nch, int dgrad,
+                               const float* __restrict__ w_amax, int nl) {
+    pack_x3_items(w, packed, c_out, c_in, taps, cot, co_blocks, nfull, tail_oct, steps, nch, dgrad, w_amax, nl,
+                  (long)blockIdx.x * blockDim.x + threadIdx.x, (long)gridDim.x * blockDim.x);
+}
+
+// Many weights in one launch (fsc_conv_pack_weights_multi: the 1-d model packs 80 small weights per step, 4.6 us each on their
+// own): the jobs travel in the kernel arguments, job j owns the workgroups [block_start[j], block_start[j + 1]).
+constexpr int kPackJobs = 48;
+struct X3PackJob {
+    const float* w;
+    unsigned short* packed;
+    int c_out, c_in, taps, cot, co_blocks, nfull, tail_oct, steps, dgrad, nl;
+};
+struct X3PackJobs {
+    X3PackJob j[kPackJobs];
+    int block_start[kPackJobs + 1];
+    int n;
+};
+
+__global__ void pack_x3_multi_kernel(X3PackJobs jobs) {
+    int lo = 0, hi = jobs.n - 1;
+    while (lo < hi) {                                   // the last job whose first workgroup is <= this one
+        const int mid = (lo + hi + 1) >> 1;
+        if ((int)blockIdx.x >= jobs.block_start[mid]) lo = mid; else hi = mid - 1;
+    }
+    const X3PackJob j = jobs.j[lo];
+    const int nb = jobs.block_start[lo + 1] - jobs.block_start[lo], b = (int)blockIdx.x - jobs.block_start[lo];
+    pack_x3_items(j.w, j.packed, j.c_out, j.c_in, j.taps, j.cot, j.co_blocks, j.nfull, j.tail_oct, j.steps, 1, j.dgrad, nullptr, j.nl,
+                  (long)b * blockDim.x + threadIdx.x, (long)nb * blockDim.x);
 }
 
 // -------------------------------------------------------------------------------------------
@@ -2702,6 +2735,41 @@ int fsc_conv_pack_weights(const fsc_conv_desc* d, const float* weight, int dgrad
     hipLaunchKernelGGL(pack_kernel, dim3((unsigned)blocks), dim3(256), 0, fsc::as_stream(stream), weight, packed,
                        d->c_out, d->c_in, d->kh, d->kw, p.g.k_pad, p.g.m_pad, dgrad);
     FSC_LAUNCH_CHECK("fsc_conv_pack_weights");
+    return 0;
+}
+
+int fsc_conv_pack_weights_multi_supported(const fsc_conv_desc* d, int dgrad) {
+    FwdPlan p;
+    return valid_desc(d) && plan_fwd(*d, dgrad, &p) && p.x3 != 0 && p.x3 != 3 ? 1 : 0;
+}
+
+int fsc_conv_pack_weights_multi(int count, const fsc_conv_desc* descs, const float* const* weights, const int* dgrad,
+                                float* const* packed, fsc_stream_t stream) {
+    FSC_CHECK_ARG(count > 0 && descs && weights && dgrad && packed, "fsc_conv_pack_weights_multi: bad arguments");
+    hipStream_t st = fsc::as_stream(stream);
+    for (int first = 0; first < count; first += kPackJobs) {
+        X3PackJobs jobs{};
+        jobs.n = count - first < kPackJobs ? count - first : kPackJobs;
+        int blocks = 0;
+        for (int i = 0; i < jobs.n; ++i) {
+            const fsc_conv_desc* d = descs + first + i;
+            FwdPlan p;
+            FSC_CHECK_ARG(valid_desc(d) && weights[first + i] && packed[first + i] && plan_fwd(*d, dgrad[first + i], &p) &&
+                              p.x3 != 0 && p.x3 != 3,
+                          "fsc_conv_pack_weights_multi: job %d is not a bf16-limb tiling (fsc_conv_pack_weights_multi_supported)", first + i);
+            jobs.j[i] = X3PackJob{weights[first + i], reinterpret_cast<unsigned short*>(packed[first + i]), d->c_out, d->c_in,
+                                  d->kh * d->kw, p.cot, p.co_blocks, p.g.x_nfull, p.g.x_tail_oct, p.g.x_steps, dgrad[first + i] ? 1 : 0,
+                                  limbs_of(p.x3)};
+            const long items = (long)p.co_blocks * p.g.x_steps * p.cot * 512;
+            long nb = (items + 4 * 256 - 1) / (4 * 256);              // four fragments' elements per thread
+            if (nb > 256) nb = 256;
+            jobs.block_start[i] = blocks;
+            blocks += (int)nb;
+        }
+        jobs.block_start[jobs.n] = blocks;
+        hipLaunchKernelGGL(pack_x3_multi_kernel, dim3((unsigned)blocks), dim3(256), 0, st, jobs);
+        FSC_LAUNCH_CHECK("fsc_conv_pack_weights_multi");
+    }
     return 0;
 }
 

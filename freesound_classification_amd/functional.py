@@ -260,14 +260,67 @@ def _operand_amax(x, given):
     return amax(x)
 
 
+def _desc_key(desc):
+    return tuple(getattr(desc, f) for f, _ in desc._fields_)
+
+
 def conv_pack(desc, weight, dgrad):
+    hit = _XPACKED.pop((weight.data_ptr(), dgrad), None)
+    if hit is not None and hit[0] == _desc_key(desc) and hit[2] == weight._version:
+        return hit[1]                                   # packed up front with the step's other weights (prepack_begin)
     lib = _lib.load()
     n = lib.fsc_conv_packed_floats(C.byref(desc), dgrad)
     if n == 0:
         raise _lib.FscError("conv: unsupported shape %s" % [getattr(desc, f) for f, _ in desc._fields_])
+    if _XPACK_RECORD is not None and lib.fsc_conv_pack_weights_multi_supported(C.byref(desc), dgrad):
+        _XPACK_RECORD.append((weight, _desc_key(desc), dgrad))
     packed = _empty((n,), weight)
     call("fsc_conv_pack_weights", C.byref(desc), ptr(weight), dgrad, ptr(packed), stream_ptr())
     return packed
+
+
+# Training on the bf16-limb kernels (cfg 3): every convolution packs its weight per use, forward and input gradient -- 80 launches
+# of ~4.6 us per step of the 1-d model.  Like the L16 fragments below, the first training forward AND backward of a (model, input
+# shape) record which (weight, descriptor, direction) they pack; from then on prepack_begin() packs them all with
+# fsc_conv_pack_weights_multi (two launches) and conv_pack() hands the fragments out -- the input-gradient ones in the backward of
+# the same step (the weights do not move in between; an entry whose weight has a newer version is dropped).
+_XPACK_PLAN = {}       # key -> [(weight, desc key, dgrad), ...]
+_XPACK_RECORD = None
+_XPACKED = {}          # (weight.data_ptr(), dgrad) -> (desc key, packed, weight version)
+
+
+def _xpack_begin(key):
+    """The x-path half of prepack_begin: True when this step records."""
+    global _XPACK_RECORD
+    _XPACKED.clear()
+    _XPACK_RECORD = None
+    if get_conv_arith() != 1:
+        return False
+    plan = _XPACK_PLAN.get(key)
+    if plan is None:
+        _XPACK_RECORD = []
+        _XPACK_PLAN[key] = _XPACK_RECORD               # (filled by this step's forward and backward)
+        if len(_XPACK_PLAN) > 64:
+            for k in [k for k in _XPACK_PLAN if k != key]:
+                del _XPACK_PLAN[k]
+        return True
+    if not plan:
+        return False
+    count = len(plan)
+    descs = (ConvDesc * count)()
+    wp, pp, dg = (C.c_void_p * count)(), (C.c_void_p * count)(), (C.c_int * count)()
+    lib = _lib.load()
+    made = []
+    for i, (weight, dkey, dgrad) in enumerate(plan):
+        d = ConvDesc(*dkey)
+        packed = _empty((lib.fsc_conv_packed_floats(C.byref(d), dgrad),), weight)
+        descs[i] = d
+        wp[i], pp[i], dg[i] = ptr(weight), ptr(packed), dgrad
+        made.append((weight, dkey, dgrad, packed))
+    call("fsc_conv_pack_weights_multi", count, descs, wp, dg, pp, stream_ptr())
+    for weight, dkey, dgrad, packed in made:
+        _XPACKED[(weight.data_ptr(), dgrad)] = (dkey, packed, weight._version)
+    return False
 
 
 def conv_forward(x, weight, bias, x_amax=None):
@@ -378,8 +431,11 @@ def forget_packed_weights():
     writes parameters or BatchNorm buffers through raw pointers (this library's optimizers do, an external EMA / SWA kernel would)
     must call this.  Called by the Fused* optimizers' step(), a training-mode bn_prepare, and the model's train() /
     load_state_dict() / load_best_model() / close()."""
+    global _XPACK_RECORD
     _EVAL_PACKS.clear()
     _EVAL_BN.clear()
+    _XPACKED.clear()          # (fragments packed up front for a step are that step's)
+    _XPACK_RECORD = None      # (and the recording of a first step ends with its optimizer step)
 
 
 def _l16_plan_sig(d):
@@ -430,6 +486,8 @@ def prepack_begin(key):
     """Call at the start of a training forward; `key` identifies (model, input shape).  Returns a token for prepack_end."""
     global _PACK_RECORD
     _PREPACKED.clear()
+    if MULTI_PACK:
+        _xpack_begin(key)
     if not MULTI_PACK or get_conv_arith() != 3 or not USE_L16:
         return None
     plan = _PACK_PLAN.get(key)
@@ -470,8 +528,13 @@ def prepack_end(token):
 
 
 def prepack_forget(model_id):
+    global _XPACK_RECORD
     for key in [k for k in _PACK_PLAN if k[0] == model_id]:
         del _PACK_PLAN[key]
+    for key in [k for k in _XPACK_PLAN if k[0] == model_id]:
+        del _XPACK_PLAN[key]
+    _XPACK_RECORD = None
+    _XPACKED.clear()
 
 
 def conv_l16_pack_pair(weight, n, h, w):

@@ -81,6 +81,13 @@ size_t fsc_conv_packed_floats(const fsc_conv_desc* d, int dgrad);
 /* weight (c_out, c_in, kh, kw) -> packed [tap][k][m]; dgrad != 0 packs the flipped transpose */
 int fsc_conv_pack_weights(const fsc_conv_desc* d, const float* weight, int dgrad,
                           float* packed, fsc_stream_t stream);
+/* `count` fsc_conv_pack_weights calls in ceil(count / 48) launches -- the weights of a whole training step up front (job i:
+ * descs[i], weights[i], dgrad[i] -> packed[i] of fsc_conv_packed_floats(&descs[i], dgrad[i]) floats; all four are HOST arrays).
+ * For the tilings whose fragments need no operand scale (arith 1, 6, 9 on the matrix-core path):
+ * fsc_conv_pack_weights_multi_supported says which; any other job fails the call. */
+int fsc_conv_pack_weights_multi_supported(const fsc_conv_desc* d, int dgrad);
+int fsc_conv_pack_weights_multi(int count, const fsc_conv_desc* descs, const float* const* weights,
+                                const int* dgrad, float* const* packed, fsc_stream_t stream);
 /* out = conv(in) + bias (accumulate == 0) or out += conv(in) + bias (accumulate != 0).
  * With dgrad != 0: in has c_out channels, out has c_in channels, bias must be NULL, and
  * `packed` must come from fsc_conv_pack_weights(dgrad=1). */
