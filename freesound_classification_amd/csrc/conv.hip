@@ -2511,7 +2511,12 @@ bool plan_wgrad(const fsc_conv_desc& d_in, WgPlan* out) {
     // Pick the split count (>= 4 units per split, partials <= 256 MB) with the best slot utilisation.
     const long base = (long)p.co_blocks * g.ci_blocks;
     const long part_bytes_per_split = (long)taps * g.ci_pad * g.co_pad * 4;
-    long ns_max = g.units / 4;
+#ifndef FSC_WGRAD_SMALL_UNITS
+#define FSC_WGRAD_SMALL_UNITS 64
+#endif
+    // (layers of fewer than 64 units -- the late blocks of the 1-d model: 7 ... 32 boxes of 64 pixels -- split down to one unit per
+    // workgroup: 20 workgroups walking 7 units each took 55 us for 0.17 GFLOP)
+    long ns_max = g.units < FSC_WGRAD_SMALL_UNITS ? g.units : g.units / 4;
     if (ns_max < 1) ns_max = 1;
     while (ns_max > 1 && ns_max * part_bytes_per_split > (256L << 20)) --ns_max;
     // resident workgroups per CU: 4-wave workgroups put one wave on each SIMD, so it is the waves/SIMD
