@@ -36,3 +36,31 @@ def test_pooled_and_statistics_variants_of_the_gpu_test_shapes():
     for case, lay in T.STAT_CASES.items():
         p = T.plans(F, *case)
         assert p[4] == lay, (case, p)
+
+
+def _describe(d, mode):
+    import ctypes as C
+    from freesound_classification_amd._lib import call
+    buf = C.create_string_buffer(256)
+    call("fsc_conv_plan_describe", C.byref(d), mode, buf, 256)
+    return buf.value.decode()
+
+
+def test_cfg3_late_blocks_weight_gradients_run_one_unit_per_workgroup():
+    """The 1-d model's last blocks (128 x 3 ... 13 positions: 7 - 32 boxes of 64 pixels) split their weight gradients down to one
+    unit per workgroup; layers of 64 units and more keep at least four units per split (conv.hip plan_wgrad)."""
+    want = {(476, 476, 3, 1): (7, 7), (476, 476, 3, 3): (7, 7), (381, 381, 6, 3): (13, 13), (305, 305, 13, 1): (32, 32),
+            (244, 244, 26, 1): (64, 16)}
+    for (ci, co, length, k), (units, split) in want.items():
+        txt = _describe(F._desc(128, ci, co, 1, length, 1, k, 1), 2)
+        assert "units=%d split=%d " % (units, split) in txt, txt
+
+
+def test_multi_pack_covers_the_bf16_limb_tilings_only():
+    lib = F._lib.load()
+    import ctypes as C
+    for (ci, co, length, k) in [(129, 64, 3446, 3), (100, 125, 430, 3), (476, 476, 3, 1)]:
+        for dgrad in (0, 1):
+            assert lib.fsc_conv_pack_weights_multi_supported(C.byref(F._desc(128, ci, co, 1, length, 1, k, 1)), dgrad)
+    assert not lib.fsc_conv_pack_weights_multi_supported(C.byref(F._desc(128, 759, 759, 2, 6, 3, 3, 3)), 0)     # scaled fp16 limbs
+    assert not lib.fsc_conv_pack_weights_multi_supported(C.byref(F._desc(128, 759, 759, 2, 6, 3, 3, 0)), 0)     # native fp32 tiling
