@@ -1038,20 +1038,20 @@ def bn_act_forward(x, st, alpha=None, residual=None, with_amax=False, l16=False,
 def bn_act_backward(dy, x, st, bn, alpha=None, residual=None, gmax=None, want_dx=True,
                     want_dres=False, want_chan_sum=False, with_amax=False, sync=None, l16=False, want_f32=True):
     """Returns (dx, dresidual, dgamma, dbeta, dalpha, dx_chan_sum) [+ (max |dx|,) with with_amax].
-    want_dx=False: only the parameter gradients (dx, dresidual, dx_chan_sum and the amax stay unwritten / None).
+    want_dx=False: only the parameter gradients (dx, dresidual, dx_chan_sum and the amax come back as None).
     l16 (with with_amax): dx is also (want_f32) or only written as an L16 tensor; the last element of the result is then
     that L16 (its .amax is the declared bound) instead of the amax buffer."""
     n, c = x.shape[0], x.shape[1]
     hw = x.numel() // (n * c)
     l16 = l16 and with_amax and hw > 1 and want_dx
     dx = torch.empty_like(x) if (want_f32 or not l16) and want_dx else None
-    dres = torch.empty_like(x) if want_dres else None
+    dres = torch.empty_like(x) if want_dres and want_dx else None
     dgamma = _empty((c,), x)
     dbeta = _empty((c,), x)
     dalpha = _empty((c,), x) if alpha is not None else None
-    csum = _empty((c,), x) if want_chan_sum else None
+    csum = _empty((c,), x) if want_chan_sum and want_dx else None
     gdy, gidx = gmax if gmax is not None else (None, None)
-    dx_amax = _empty((AMAX_FLOATS,), x) if with_amax and (_want_amax() or l16) else None
+    dx_amax = _empty((AMAX_FLOATS,), x) if with_amax and want_dx and (_want_amax() or l16) else None
     t = L16(l16_empty(x.shape, x), dx_amax, x.shape) if l16 else None
     ws = _bn_ws(c, x)                                      # (kept alive across both phases)
     args = (ptr(dy), ptr(gdy), ptr(gidx), ptr(x), ptr(residual), ptr(st.mean),
