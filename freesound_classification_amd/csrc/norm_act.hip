@@ -242,6 +242,16 @@ __global__ __launch_bounds__(kThreads) void stats_partial_kernel(
         for (int k = 0; k < 4; ++k) o[k] = vals[k];
         return;
     }
+    if (nsplit == 1) {
+        // the channel's only workgroup has nothing to hand over: no written-through partials, no ticket round trip, no re-load
+        // (3 - 4 us of the 9 - 11 us such a launch takes on the 1-d model's last blocks); the same numbers as a fold of one split
+        if (fa.x_minmax) {
+            fa.x_minmax[2 * ch] = mn;
+            fa.x_minmax[2 * ch + 1] = mx;
+        }
+        if (!fa.minmax_only) finalize_channel(fa, ch, 0.0 + t1, 0.0 + t2, (double)pivot);
+        return;
+    }
 #pragma unroll
     for (int k = 0; k < 4; ++k) __hip_atomic_store(o + k, vals[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (!ticket_last(tickets + ch, nsplit)) return;
@@ -998,7 +1008,8 @@ __global__ __launch_bounds__(kThreads) void bwd_partial_kernel(BwdArgs a, int ns
     __shared__ float mred[kThreads / 64];
     mdz = block_max256(mdz, mred);
     mxh = block_max256(mxh, mred);
-    if (threadIdx.x == 0) {
+    const bool alone = fin.tickets != nullptr && nsplit == 1;       // the channel's only workgroup: finalise from registers
+    if (threadIdx.x == 0 && !alone) {
         double* o = part + ((size_t)ch * kMaxSplit + sp) * kPartStride;
         const double vals[kBwdVals] = {t0, t1, t2, (double)mdz, (double)mxh, t3};
         if (fin.tickets) {
@@ -1017,22 +1028,30 @@ __global__ __launch_bounds__(kThreads) void bwd_partial_kernel(BwdArgs a, int ns
         for (int i = threadIdx.x; i < fsc::kAmaxFloats; i += kThreads) fin.dx_amax[i] = 0.f;
     __shared__ int last_s;
     __shared__ double fold_s[kMaxSplit][kBwdVals];
-    if (threadIdx.x == 0) last_s = ticket_last(fin.tickets + ch, nsplit) ? 1 : 0;      // (thread 0 issued the stores above)
-    __syncthreads();
-    if (!last_s) return;
-    if ((int)threadIdx.x < nsplit) {
-        double* p = part + ((size_t)ch * kMaxSplit + threadIdx.x) * kPartStride;
-#pragma unroll
-        for (int k = 0; k < kBwdVals; ++k) fold_s[threadIdx.x][k] = __hip_atomic_load(p + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    __syncthreads();
-    if (threadIdx.x != 0) return;
     double f0 = 0.0, f1 = 0.0, f2 = 0.0, f3 = 0.0;
     float fdz = 0.f, fxh = 0.f;
-    for (int k = 0; k < nsplit; ++k) {
-        f0 += fold_s[k][0]; f1 += fold_s[k][1]; f2 += fold_s[k][2]; f3 += fold_s[k][5];
-        fdz = fmaxf(fdz, (float)fold_s[k][3]);
-        fxh = fmaxf(fxh, (float)fold_s[k][4]);
+    if (alone) {
+        // (no written-through partials, no ticket round trip, no re-load; the same numbers as a fold of one split)
+        if (threadIdx.x != 0) return;
+        f0 += t0; f1 += t1; f2 += t2; f3 += t3;
+        fdz = fmaxf(fdz, (float)(double)mdz);
+        fxh = fmaxf(fxh, (float)(double)mxh);
+    } else {
+        if (threadIdx.x == 0) last_s = ticket_last(fin.tickets + ch, nsplit) ? 1 : 0;      // (thread 0 issued the stores above)
+        __syncthreads();
+        if (!last_s) return;
+        if ((int)threadIdx.x < nsplit) {
+            double* p = part + ((size_t)ch * kMaxSplit + threadIdx.x) * kPartStride;
+#pragma unroll
+            for (int k = 0; k < kBwdVals; ++k) fold_s[threadIdx.x][k] = __hip_atomic_load(p + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+        if (threadIdx.x != 0) return;
+        for (int k = 0; k < nsplit; ++k) {
+            f0 += fold_s[k][0]; f1 += fold_s[k][1]; f2 += fold_s[k][2]; f3 += fold_s[k][5];
+            fdz = fmaxf(fdz, (float)fold_s[k][3]);
+            fxh = fmaxf(fxh, (float)fold_s[k][4]);
+        }
     }
     if (fin.dbeta) fin.dbeta[ch] = (float)f0;
     if (fin.dgamma) fin.dgamma[ch] = (float)f1;
@@ -1496,6 +1515,7 @@ int pick_split(int n, int c, long hw) {
     long s = want < by_work ? want : by_work;
     if (s > n) s = n;
     if (s > kMaxSplit) s = kMaxSplit;
+    if ((long)n * hw <= 8192 && c >= 128) s = 1;       // (a channel's only workgroup finalises from registers: see bwd_partial_kernel)
     if (s < 1) s = 1;
     return (int)s;
 }
