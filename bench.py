@@ -492,12 +492,13 @@ def main():
         if w.get("mixup"):
             # on-device MixUp (ops/audio.py:32-52 semantics): partner = a batch permutation, rows are
             # mixed with probability p; equal lengths -> plain average, labels OR-ed
-            perm = torch.from_numpy(mix_rng.permutation(batch)).to(device)
-            take = torch.from_numpy(mix_rng.uniform(size=batch) < w["mixup"]).to(device)
-            partner = torch.where(take, perm, torch.arange(batch, device=device))
+            # (partner table: rows that do not draw MixUp pass through, no gathered copy of the partner rows)
+            perm = mix_rng.permutation(batch)
+            take = mix_rng.uniform(size=batch) < w["mixup"]
+            partner = __import__("numpy").where(take, perm, -1)
             t = w["samples"]
-            mixed, y = F.mixup_batch(signal.squeeze(-1), signal.squeeze(-1)[partner].contiguous(), [t] * batch, [t] * batch,
-                                     [0] * batch, mix_rng.uniform(0.4, 0.6, size=batch), labels, labels[partner].contiguous())
+            mixed, y = F.mixup_rows(signal.squeeze(-1), signal.squeeze(-1), partner, [t] * batch, [t] * batch, [0] * batch,
+                                    mix_rng.uniform(0.4, 0.6, size=batch), labels, labels)
             x = mixed.unsqueeze(-1)
         out = step_fn[0](x, y)
         if os.environ.get("FSC_BENCH_SYNC_ALL"):

@@ -1843,6 +1843,32 @@ def sigmoid(x):
 
 
 # ------------------------------------------------------------------------------ MixUp on device
+def mixup_rows(a, b, partner, len_a, len_b, start, alpha, labels_a=None, labels_b=None):
+    """mixup_batch with a partner table (fsc_mixup_rows): row n of `a` (N, Ta) is mixed with row partner[n] of `b` (M, Tb), whose
+    true length is len_b[n]; partner[n] < 0 passes row n (and its labels) through unchanged -- MixUp.p not drawn,
+    ops/transforms.py:57 -- without reading `b`.  No gathered copy of the partners.  Returns (mixed, labels)."""
+    _need_cuda(a, "mixup_rows")
+    a, b = a.contiguous(), b.contiguous()
+    n, ta = a.shape
+    tb = b.shape[1]
+    t_out = max(ta, tb)
+    out = _empty((n, t_out), a)
+    alpha64 = np.asarray(alpha, dtype=np.float64)
+    al = torch.from_numpy(alpha64.astype(np.float32)).to(a.device)
+    om = torch.from_numpy((1.0 - alpha64).astype(np.float32)).to(a.device)
+    dev = lambda v: torch.as_tensor(np.asarray(v, dtype=np.int32)).to(a.device)  # noqa: E731
+    pr, la, lb, st = dev(partner), dev(len_a), dev(len_b), dev(start)
+    lo = None
+    c = 0
+    if labels_a is not None:
+        labels_a, labels_b = labels_a.contiguous().float(), labels_b.contiguous().float()
+        lo = torch.empty_like(labels_a)
+        c = labels_a.shape[1]
+    call("fsc_mixup_rows", ptr(a), ptr(b), ptr(pr), ptr(la), ptr(lb), ptr(st), ptr(al), ptr(om), ptr(out), n, ta, tb, t_out,
+         ptr(labels_a), ptr(labels_b), ptr(lo), c, stream_ptr())
+    return out, lo
+
+
 def mixup_batch(a, b, len_a, len_b, start, alpha, labels_a=None, labels_b=None):
     """Batched ops/audio.py:32-52.  a (N, Ta), b (N, Tb) zero-padded rows with true lengths
     len_a / len_b (int32); `alpha` is the fp64 mixing draw per row.  Returns (mixed, labels)."""

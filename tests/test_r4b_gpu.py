@@ -201,3 +201,31 @@ def test_multi_pack_equals_single_pack_bit_for_bit():
     # a job that is not a bf16-limb tiling fails the call loudly
     bad = ConvDesc(128, 100, 100, 64, 215, 3, 3, 3)
     assert not lib.fsc_conv_pack_weights_multi_supported(C.byref(bad), 0)
+
+
+def test_mixup_rows_equals_mixup_batch_on_gathered_partners():
+    """The partner-table form (no gathered copy; undrawn rows pass through) against mixup_batch on explicitly gathered rows, bit for bit
+    (ops/audio.py:32-52; a row mixed with itself at equal length is (x + x) / 2 = x, what bench.py's cfg-3 loop used before)."""
+    import numpy as np
+    rng = np.random.RandomState(3)
+    n, t, c = 12, 4001, 80
+    a = torch.randn(n, t, device=DEV)
+    lens = rng.randint(t // 2, t + 1, size=n)
+    lens[:4] = t                                                   # some equal-length pairs
+    for i in range(n):
+        a[i, lens[i]:] = 0.0
+    labels = (torch.rand(n, c, device=DEV) < 0.05).float()
+    perm = rng.permutation(n)
+    take = rng.uniform(size=n) < 0.6
+    partner = np.where(take, perm, -1)
+    start = [int(rng.randint(0, max(1, abs(int(lens[i]) - int(lens[perm[i]])) + 1))) for i in range(n)]
+    alpha = rng.uniform(0.4, 0.6, size=n)
+    got, got_l = F.mixup_rows(a, a, partner, lens, lens[perm], start, alpha, labels, labels)
+    idx = torch.from_numpy(np.where(take, perm, np.arange(n))).to(DEV)
+    len_b = np.where(take, lens[perm], lens)
+    want, want_l = F.mixup_batch(a, a[idx].contiguous(), lens, len_b, start, alpha, labels, labels[idx].contiguous())
+    assert torch.equal(got, want)
+    assert torch.equal(got_l, want_l)
+    for i in range(n):
+        if not take[i]:
+            assert torch.equal(got[i], a[i])
