@@ -65,6 +65,8 @@ SIGNATURES = {
     "fsc_conv_default_arith": (_I, []),
     "fsc_conv_wgrad_workspace_bytes": (_SZ, [_D]),
     "fsc_conv_wgrad": (_I, [_D, _P, _P, _P, _P, _P, _P, _P]),
+    "fsc_conv_wgrad_partial": (_I, [_D, _P, _P, _P, _P, _P, _P]),
+    "fsc_conv_wgrad_reduce_multi": (_I, [_I, _P, _P, _P, _P]),
     "fsc_l16_bytes": (_SZ, [_I, _I, _L]),
     "fsc_l16_pack": (_I, [_P, _I, _I, _L, _P, _P, _P]),
     "fsc_l16_unpack": (_I, [_P, _I, _I, _L, _P, _P, _P]),

@@ -2003,6 +2003,44 @@ __global__ __launch_bounds__(kRedX * kRedY) void wgrad_reduce_kernel(const float
         dw[((long)co * c_in + ci) * taps + tap] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 
+// The reduces of several weight gradients in one launch (fsc_conv_wgrad_reduce_multi: the four convolutions of a block of the 1-d
+// model reduced their slices in four launches of ~8 us): job j owns the workgroups [block_start[j], block_start[j + 1]).
+constexpr int kRedJobs = 16;
+struct RedJob {
+    const float* part;
+    float* dw;
+    int c_out, c_in, taps, ci_pad, co_pad, nsplit, bx;      // bx = workgroups along co
+};
+struct RedJobs {
+    RedJob j[kRedJobs];
+    int block_start[kRedJobs + 1];
+    int n;
+};
+__global__ __launch_bounds__(kRedX * kRedY) void wgrad_reduce_multi_kernel(RedJobs jobs) {
+    __shared__ float red[kRedY][kRedX];
+    int ji = 0;
+    while (ji + 1 < jobs.n && (int)blockIdx.x >= jobs.block_start[ji + 1]) ++ji;
+    const RedJob q = jobs.j[ji];
+    const int b = (int)blockIdx.x - jobs.block_start[ji];
+    const int row = b / q.bx, co = (b - row * q.bx) * kRedX + threadIdx.x;       // row = (tap, ci)
+    const int tap = row / q.c_in, ci = row - tap * q.c_in;
+    const long slice = (long)q.taps * q.ci_pad * q.co_pad;
+    float s0 = 0.f, s1 = 0.f;
+    if (co < q.c_out) {
+        const float* p = q.part + ((long)tap * q.ci_pad + ci) * q.co_pad + co;
+        int sp = threadIdx.y;
+        for (; sp + kRedY < q.nsplit; sp += 2 * kRedY) {
+            s0 += p[(long)sp * slice];
+            s1 += p[(long)(sp + kRedY) * slice];
+        }
+        if (sp < q.nsplit) s0 += p[(long)sp * slice];
+    }
+    red[threadIdx.y][threadIdx.x] = s0 + s1;
+    __syncthreads();
+    if (threadIdx.y == 0 && co < q.c_out)
+        q.dw[((long)co * q.c_in + ci) * q.taps + tap] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
 // -------------------------------------------------------------------------------------------
 // host-side planning
 struct FwdPlan {
@@ -2885,35 +2923,77 @@ size_t fsc_conv_wgrad_workspace_bytes(const fsc_conv_desc* d) {
     return (size_t)p.part_splits * d->kh * d->kw * p.g.ci_pad * p.g.co_pad * sizeof(float);
 }
 
-int fsc_conv_wgrad(const fsc_conv_desc* d, const float* in, const float* dout, float* dweight, void* workspace,
-                   const float* in_amax, const float* dout_amax, fsc_stream_t stream) {
-    FSC_CHECK_ARG(valid_desc(d) && in && dout && dweight && workspace, "fsc_conv_wgrad: bad descriptor or null pointer");
-    hipStream_t st = fsc::as_stream(stream);
+// the split-K slices of a weight gradient into `workspace`; *ci_pad, *co_pad, *nsplit describe them for the reduce
+static int wgrad_partial(const fsc_conv_desc* d, const float* in, const float* dout, void* workspace, const float* in_amax,
+                         const float* dout_amax, hipStream_t st, int* ci_pad, int* co_pad, int* nsplit) {
     float* part = reinterpret_cast<float*>(workspace);
-    int rc;
     WgxPlan px;
     if (arith_of(*d) && plan_wgrad_x3(*d, arith_of(*d), &px)) {
         FSC_CHECK_ARG(px.nprod != 3 || (in_amax && dout_amax),
                       "fsc_conv_wgrad: the split-fp16 kernels need in_amax and dout_amax (fsc_amax of the operands)");
-        if (d->kh == 3) rc = launch_wgrad_x3<3, 3>(px, in, dout, part, in_amax, dout_amax, st);
-        else rc = launch_wgrad_x3<1, 3>(px, in, dout, part, in_amax, dout_amax, st);
-        if (rc) return rc;
-        const int taps = d->kh * d->kw;
-        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(fsc::ceil_div(d->c_out, kRedX), taps * d->c_in), dim3(kRedX, kRedY), 0, st,
-                           part, dweight, d->c_out, d->c_in, taps, px.g.ci_pad, px.g.co_pad, px.g.nsplit);
-        FSC_LAUNCH_CHECK("fsc_conv_wgrad(reduce)");
-        return 0;
+        *ci_pad = px.g.ci_pad; *co_pad = px.g.co_pad; *nsplit = px.g.nsplit;
+        if (!in) return 0;                                       // (geometry only)
+        if (d->kh == 3) return launch_wgrad_x3<3, 3>(px, in, dout, part, in_amax, dout_amax, st);
+        return launch_wgrad_x3<1, 3>(px, in, dout, part, in_amax, dout_amax, st);
     }
     WgPlan p;
     FSC_CHECK_ARG(plan_wgrad(*d, &p), "fsc_conv_wgrad: no tiling for this shape");
-    if (d->kh == 3) rc = launch_wgrad<3, 3>(p, in, dout, part, st);
-    else if (d->kw == 3) rc = launch_wgrad<1, 3>(p, in, dout, part, st);
-    else rc = launch_wgrad<1, 1>(p, in, dout, part, st);
+    *ci_pad = p.g.ci_pad; *co_pad = p.g.co_pad; *nsplit = p.part_splits;
+    if (!in) return 0;
+    if (d->kh == 3) return launch_wgrad<3, 3>(p, in, dout, part, st);
+    if (d->kw == 3) return launch_wgrad<1, 3>(p, in, dout, part, st);
+    return launch_wgrad<1, 1>(p, in, dout, part, st);
+}
+
+int fsc_conv_wgrad(const fsc_conv_desc* d, const float* in, const float* dout, float* dweight, void* workspace,
+                   const float* in_amax, const float* dout_amax, fsc_stream_t stream) {
+    FSC_CHECK_ARG(valid_desc(d) && in && dout && dweight && workspace, "fsc_conv_wgrad: bad descriptor or null pointer");
+    hipStream_t st = fsc::as_stream(stream);
+    int ci_pad, co_pad, nsplit;
+    const int rc = wgrad_partial(d, in, dout, workspace, in_amax, dout_amax, st, &ci_pad, &co_pad, &nsplit);
     if (rc) return rc;
     const int taps = d->kh * d->kw;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(fsc::ceil_div(d->c_out, kRedX), taps * d->c_in), dim3(kRedX, kRedY), 0, st,
-                       part, dweight, d->c_out, d->c_in, taps, p.g.ci_pad, p.g.co_pad, p.part_splits);
+                       reinterpret_cast<const float*>(workspace), dweight, d->c_out, d->c_in, taps, ci_pad, co_pad, nsplit);
     FSC_LAUNCH_CHECK("fsc_conv_wgrad(reduce)");
+    return 0;
+}
+
+int fsc_conv_wgrad_partial(const fsc_conv_desc* d, const float* in, const float* dout, void* workspace, const float* in_amax,
+                           const float* dout_amax, fsc_stream_t stream) {
+    FSC_CHECK_ARG(valid_desc(d) && in && dout && workspace, "fsc_conv_wgrad_partial: bad descriptor or null pointer");
+    int ci_pad, co_pad, nsplit;
+    const int rc = wgrad_partial(d, in, dout, workspace, in_amax, dout_amax, fsc::as_stream(stream), &ci_pad, &co_pad, &nsplit);
+    if (rc) return rc;
+    FSC_LAUNCH_CHECK("fsc_conv_wgrad_partial");
+    return 0;
+}
+
+int fsc_conv_wgrad_reduce_multi(int count, const fsc_conv_desc* descs, const void* const* workspaces, float* const* dweights,
+                                fsc_stream_t stream) {
+    FSC_CHECK_ARG(count > 0 && descs && workspaces && dweights, "fsc_conv_wgrad_reduce_multi: bad arguments");
+    hipStream_t st = fsc::as_stream(stream);
+    const float one = 1.f;                  // (any non-null amax: only the geometry is asked for)
+    for (int first = 0; first < count; first += kRedJobs) {
+        RedJobs jobs{};
+        jobs.n = count - first < kRedJobs ? count - first : kRedJobs;
+        int blocks = 0;
+        for (int i = 0; i < jobs.n; ++i) {
+            const fsc_conv_desc* d = descs + first + i;
+            FSC_CHECK_ARG(valid_desc(d) && workspaces[first + i] && dweights[first + i], "fsc_conv_wgrad_reduce_multi: job %d", first + i);
+            int ci_pad, co_pad, nsplit;
+            const int rc = wgrad_partial(d, nullptr, nullptr, nullptr, &one, &one, st, &ci_pad, &co_pad, &nsplit);
+            if (rc) return rc;
+            const int taps = d->kh * d->kw, bx = fsc::ceil_div(d->c_out, kRedX);
+            jobs.j[i] = RedJob{reinterpret_cast<const float*>(workspaces[first + i]), dweights[first + i], d->c_out, d->c_in, taps,
+                               ci_pad, co_pad, nsplit, bx};
+            jobs.block_start[i] = blocks;
+            blocks += bx * taps * d->c_in;
+        }
+        jobs.block_start[jobs.n] = blocks;
+        hipLaunchKernelGGL(wgrad_reduce_multi_kernel, dim3((unsigned)blocks), dim3(kRedX, kRedY), 0, st, jobs);
+        FSC_LAUNCH_CHECK("fsc_conv_wgrad_reduce_multi");
+    }
     return 0;
 }
 

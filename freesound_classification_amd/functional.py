@@ -825,7 +825,12 @@ def conv_wgrad(x, dout, weight_shape, on_side_stream=False, x_amax=None, dout_am
         dw = out if out is not None else _empty(tuple(weight_shape), x)
         xa, da = _operand_amax(x, x_amax), _operand_amax(dout, dout_amax)
         with _timed(d, 2):
-            call("fsc_conv_wgrad", C.byref(d), ptr(x), ptr(dout), ptr(dw), ptr(ws), ptr(xa), ptr(da), stream_ptr())
+            if _WGRAD_PENDING is not None and not (ASYNC_WGRAD and on_side_stream):
+                # the split-K slices now, their reduce with the block's other weight gradients (wgrad_flush)
+                call("fsc_conv_wgrad_partial", C.byref(d), ptr(x), ptr(dout), ptr(ws), ptr(xa), ptr(da), stream_ptr())
+                _WGRAD_PENDING.append((d, ws, dw))
+            else:
+                call("fsc_conv_wgrad", C.byref(d), ptr(x), ptr(dout), ptr(dw), ptr(ws), ptr(xa), ptr(da), stream_ptr())
         return dw
 
     if not (ASYNC_WGRAD and on_side_stream):
@@ -839,6 +844,41 @@ def conv_wgrad(x, dout, weight_shape, on_side_stream=False, x_amax=None, dout_am
     dout.record_stream(side)
     dw.record_stream(main)
     return dw
+
+
+# Weight gradients nobody reads before the block's backward returns: between wgrad_begin() and wgrad_flush() conv_wgrad leaves
+# its split-K slices in their workspaces, and the flush reduces all of them in one launch (fsc_conv_wgrad_reduce_multi; the four
+# reduces of a block of the 1-d model were four launches of ~8 us).  The tensors conv_wgrad returned are complete after the flush.
+_WGRAD_PENDING = None
+
+
+def wgrad_begin():
+    global _WGRAD_PENDING
+    _WGRAD_PENDING = []
+
+
+def wgrad_abort():
+    global _WGRAD_PENDING
+    _WGRAD_PENDING = None
+
+
+def wgrad_flush(end=True):
+    """Reduce what is pending (end: and stop deferring)."""
+    global _WGRAD_PENDING
+    pending = _WGRAD_PENDING
+    if end:
+        _WGRAD_PENDING = None
+    elif pending is not None:
+        _WGRAD_PENDING = []
+    if not pending:
+        return
+    count = len(pending)
+    descs = (ConvDesc * count)()
+    wsp, dwp = (C.c_void_p * count)(), (C.c_void_p * count)()
+    for i, (d, ws, dw) in enumerate(pending):
+        descs[i] = d
+        wsp[i], dwp[i] = ptr(ws), ptr(dw)
+    call("fsc_conv_wgrad_reduce_multi", count, descs, wsp, dwp, stream_ptr())
 
 
 # ------------------------------------------------------------------------------ BN + PReLU
@@ -1517,6 +1557,14 @@ class ConvBlockFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, d_out, d_feat):
+        wgrad_begin()                       # the block's weight gradients reduce their split-K slices together (wgrad_flush)
+        try:
+            return ConvBlockFn._backward(ctx, d_out, d_feat)
+        finally:
+            wgrad_abort()                   # (nothing is left pending on the normal path)
+
+    @staticmethod
+    def _backward(ctx, d_out, d_feat):
         k, mods, ph, sync = ctx.k, ctx.mods, ctx.ph, ctx.sync
         if k is None:
             raise RuntimeError("ConvBlockFn: backward through the block a second time -- its saved activations are "
@@ -1587,6 +1635,7 @@ class ConvBlockFn(torch.autograd.Function):
             if (STEM_BN_IDENTITY and not ctx.x_needs_grad and dc is not None and dc.dim() == 4 and tuple(wa.shape[2:]) == (3, 3)
                     and bn_a.weight is not None and h_w_min(dc) >= 2 and k.gamma_guard is not None and k.gamma_guard.ok()):
                 # the block input needs no gradient: bn_a's parameter gradients from the weight gradient (no dgrad, no BN backward)
+                wgrad_flush(end=False)                  # (dwa is read here)
                 dga, dbta = _stem_bn_grads(dc, dbias_a, wa, dwa, bn_a)
                 dx = None
                 del dc, dc_m
@@ -1598,6 +1647,7 @@ class ConvBlockFn(torch.autograd.Function):
         def like(param, g):
             return g.reshape(param.shape) if g is not None else None
 
+        wgrad_flush()
         join_side_stream(k.x.device)           # weight gradients computed on the side stream
         grads = [dga, dbta, like(conv_a.weight, dwa), dbias_a, dgb, dbtb, dalb,
                  like(res.conv1.weight, dw1), dbias1, dg1, dbt1, dal1,

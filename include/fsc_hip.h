@@ -155,6 +155,15 @@ size_t fsc_conv_wgrad_workspace_bytes(const fsc_conv_desc* d);
 int fsc_conv_wgrad(const fsc_conv_desc* d, const float* in, const float* dout,
                    float* dweight, void* workspace, const float* in_amax, const float* dout_amax,
                    fsc_stream_t stream);
+/* fsc_conv_wgrad in two halves, for callers that compute several weight gradients before anyone reads them (the four
+ * convolutions of a resnet block, classifiers.py:37-69 / 72-104): fsc_conv_wgrad_partial leaves the split-K slices in `workspace`
+ * (fsc_conv_wgrad_workspace_bytes, one workspace per pending gradient), fsc_conv_wgrad_reduce_multi sums the slices of `count`
+ * such gradients into their dweight tensors in ceil(count / 16) launches.  descs / workspaces / dweights are HOST arrays.  Same
+ * additions in the same order as fsc_conv_wgrad: bit-identical results. */
+int fsc_conv_wgrad_partial(const fsc_conv_desc* d, const float* in, const float* dout, void* workspace,
+                           const float* in_amax, const float* dout_amax, fsc_stream_t stream);
+int fsc_conv_wgrad_reduce_multi(int count, const fsc_conv_desc* descs, const void* const* workspaces,
+                                float* const* dweights, fsc_stream_t stream);
 
 /* ---- pre-split activations ("L16" tensors) for the split-fp16 arithmetic (arith 3).
  * The kernels behind fsc_conv_fwd split every fp32 activation into its two fp16 limbs beside the MFMAs, once per

@@ -229,3 +229,31 @@ def test_mixup_rows_equals_mixup_batch_on_gathered_partners():
     for i in range(n):
         if not take[i]:
             assert torch.equal(got[i], a[i])
+
+
+def test_deferred_weight_gradient_reduces_equal_the_immediate_ones():
+    """fsc_conv_wgrad_partial + fsc_conv_wgrad_reduce_multi (functional.wgrad_begin / wgrad_flush) against fsc_conv_wgrad: the same
+    additions in the same order, bit-identical -- on both weight-gradient kernels of the fp32-input path, more jobs than one launch's
+    table, and a deferral that an exception leaves behind does not outlive its block."""
+    cases = [("bf16", 128, 64, 64, 1, 1723, 3), ("bf16", 128, 476, 476, 1, 3, 1), ("bf16", 128, 305, 381, 1, 13, 3),
+             ("f16x3", 128, 759, 759, 2, 6, 3), ("f16x3", 128, 506, 506, 4, 13, 1)]
+    for arith, n, ci, co, h, w, k in cases:
+        F.set_conv_arith(arith)
+        try:
+            g = torch.Generator(device="cpu").manual_seed(ci + w)
+            x = torch.randn(n, ci, h, w, generator=g).to(DEV)
+            dy = torch.randn(n, co, h, w, generator=g).to(DEV)
+            shape = (co, ci, k if h > 1 else 1, k)
+            want = F.conv_wgrad(x, dy, shape)
+            F.wgrad_begin()
+            try:
+                got = [F.conv_wgrad(x, dy, shape) for _ in range(18)]       # 18 jobs: two launches
+                assert len(F._WGRAD_PENDING) == 18
+                F.wgrad_flush()
+            finally:
+                F.wgrad_abort()
+            assert F._WGRAD_PENDING is None
+            for t in got:
+                assert torch.equal(t, want), (arith, n, ci, co, h, w, k)
+        finally:
+            F.set_conv_arith(None)
