@@ -70,6 +70,9 @@ SIGNATURES = {
     "fsc_l16_bytes": (_SZ, [_I, _I, _L]),
     "fsc_l16_pack": (_I, [_P, _I, _I, _L, _P, _P, _P]),
     "fsc_l16_unpack": (_I, [_P, _I, _I, _L, _P, _P, _P]),
+    "fsc_l16_bytes_limbs": (_SZ, [_I, _I, _L, _I]),
+    "fsc_l16_pack_limbs": (_I, [_P, _I, _I, _L, _P, _I, _P, _P]),
+    "fsc_l16_unpack_limbs": (_I, [_P, _I, _I, _L, _P, _I, _P, _P]),
     "fsc_conv_l16_supported": (_I, [_D, _I]),
     "fsc_conv_l16_packed_floats": (_SZ, [_D, _I]),
     "fsc_conv_l16_pack_weights": (_I, [_D, _P, _I, _P, _P]),
@@ -95,6 +98,7 @@ SIGNATURES = {
     "fsc_bn_act_fwd_rec": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _L, _P, _P]),
     "fsc_bn_records_fold": (_I, [_P, _P, _I, _I, _L, _P, _P, _P, _P]),
     "fsc_bn_act_fwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _L, _P, _P, _P, _P]),
+    "fsc_bn_act_fwd_limbs": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _L, _P, _P, _P, _I, _P]),
     "fsc_bn_act_bwd": (_I, [_P] * 16 + [_I, _I, _L, _P, _P, _P, _I, _P, _P]),
     "fsc_bn_act_bwd_unpool": (_I, [_P] * 13 + [_I, _I, _I, _I, _I, _P, _P, _P, _I, _P, _P]),
     "fsc_maxpool_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),

@@ -27,6 +27,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef short v4s __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) void* lds_ptr;
 typedef __attribute__((address_space(3))) v4s* lds_v4s;
@@ -83,9 +84,20 @@ __device__ __forceinline__ void glds16(const void* src, void* lds_wave_base) {
     const unsigned m = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_ptr)lds_wave_base);
     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(m) : "memory", "m0");
 }
+template <int NL>
 __device__ __forceinline__ f32x4 mfma16(u32x4 a, u32x4 b, f32x4 c) {
-    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    if constexpr (NL == 2)
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    else
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
+// limb products (A limb, B limb), smallest first.  Two scaled fp16 limbs: l*h, h*l, h*h (l*l dropped: arith 3).  Three exact bf16
+// limbs (0 = h, 1 = m, 2 = l): all nine (arith 9), without l*l (8), without l*l, m*l, l*m (6).
+template <int NL, int NPROD> struct WProds;
+template <> struct WProds<2, 3> { static constexpr int la[3] = {1, 0, 0}; static constexpr int lb[3] = {0, 1, 0}; };
+template <> struct WProds<3, 9> { static constexpr int la[9] = {2, 1, 2, 0, 1, 2, 0, 1, 0}; static constexpr int lb[9] = {2, 2, 1, 2, 1, 0, 1, 0, 0}; };
+template <> struct WProds<3, 8> { static constexpr int la[8] = {1, 2, 0, 1, 2, 0, 1, 0}; static constexpr int lb[8] = {2, 1, 2, 1, 0, 1, 0, 0}; };
+template <> struct WProds<3, 6> { static constexpr int la[6] = {0, 1, 2, 0, 1, 0}; static constexpr int lb[6] = {2, 1, 0, 1, 0, 0}; };
 // two transpose reads = the 8 K values (positions p .. p + 7) of this lane's channel; `p` = byte address of the lane's piece
 __device__ __forceinline__ u32x4 tr_read8(const char* p) {
     const u32x2 lo = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s)(p)));
@@ -124,7 +136,7 @@ __device__ __forceinline__ void xcd_block_order(int* block, int* split) {
     *block = (int)(v - (unsigned)*split * bx);
 }
 
-template <int KH, int KW, int MT, int CT>
+template <int KH, int KW, int MT, int CT, int NL = 2, int NPROD = 3>
 __global__ __launch_bounds__(kWaves * 64) void conv_l16_wgrad_kernel(WGeom g, const uint4* __restrict__ in,
                                                                       const uint4* __restrict__ dout,
                                                                       float* __restrict__ part,
@@ -138,7 +150,7 @@ __global__ __launch_bounds__(kWaves * 64) void conv_l16_wgrad_kernel(WGeom g, co
 
     extern __shared__ __attribute__((aligned(16))) uint4 smem4[];
     const int co_oct = g.ng * g.tpg * 2, ci_oct = g.nt * CT * 2;             // octets staged per operand
-    const int stage_u4 = co_oct * 2 * g.du + ci_oct * 2 * g.plane;             // uint4 per stage: dOut units, then input units
+    const int stage_u4 = co_oct * NL * g.du + ci_oct * NL * g.plane;           // uint4 per stage: dOut units, then input units
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -160,8 +172,8 @@ __global__ __launch_bounds__(kWaves * 64) void conv_l16_wgrad_kernel(WGeom g, co
     }
 
     // ---- operand scales
-    float inv_ab;
-    {
+    float inv_ab = 1.f;
+    if constexpr (NL == 2) {
         float* red = reinterpret_cast<float*>(smem4);
         const float ma = fsc::wave_max(dout_amax[tid]), mb = fsc::wave_max(in_amax[tid]);
         if (lane == 0) { red[wid] = ma; red[kWaves + wid] = mb; }
@@ -178,10 +190,10 @@ __global__ __launch_bounds__(kWaves * 64) void conv_l16_wgrad_kernel(WGeom g, co
     const int co_oct_live = min(co_oct, g.oct_out - tile0 * 2), ci_oct_live = min(ci_oct, g.oct_in - cit0 * 2);
     for (int st = 0; st < 2; ++st) {
         uint4* dl = smem4 + st * stage_u4;
-        uint4* il = dl + co_oct * 2 * g.du;
+        uint4* il = dl + co_oct * NL * g.du;
         const uint4 z = make_uint4(0u, 0u, 0u, 0u);
-        for (int i = (co_oct_live > 0 ? co_oct_live : 0) * 2 * g.du + tid; i < co_oct * 2 * g.du; i += kWaves * 64) dl[i] = z;
-        for (int i = (ci_oct_live > 0 ? ci_oct_live : 0) * 2 * g.plane + tid; i < ci_oct * 2 * g.plane; i += kWaves * 64) il[i] = z;
+        for (int i = (co_oct_live > 0 ? co_oct_live : 0) * NL * g.du + tid; i < co_oct * NL * g.du; i += kWaves * 64) dl[i] = z;
+        for (int i = (ci_oct_live > 0 ? ci_oct_live : 0) * NL * g.plane + tid; i < ci_oct * NL * g.plane; i += kWaves * 64) il[i] = z;
     }
 
     // ---- unit-invariant DMA plans.  dOut: lane = pixel of the box in row-major (= run) order; input: lane + 64 j =
@@ -196,20 +208,20 @@ __global__ __launch_bounds__(kWaves * 64) void conv_l16_wgrad_kernel(WGeom g, co
         if (o >= g.npos) qr[j] = -1;
     }
     const uint4* const zero = reinterpret_cast<const uint4*>(g_zero16_w);
-    const long do_img = (long)g.oct_out * 2 * g.hw, in_img = (long)g.oct_in * 2 * g.hw;
+    const long do_img = (long)g.oct_out * NL * g.hw, in_img = (long)g.oct_in * NL * g.hw;
     auto issue_unit = [&](int u, int stage) {
         if (wid >= kCopyWaves) return;
         uint4* dl = smem4 + stage * stage_u4;
-        uint4* il = dl + co_oct * 2 * g.du;
+        uint4* il = dl + co_oct * NL * g.du;
         int t = u;
         const int twi = t % g.tiles_w; t /= g.tiles_w;
         const int thi = t % g.tiles_h; t /= g.tiles_h;
         const int n0 = t, h0 = thi * g.th, w0 = twi * g.tw;
         {
             const bool live = h0 + pr < g.h && w0 + pc < g.w;
-            const uint4* src = dout + (long)n0 * do_img + (long)(tile0 * 2) * 2 * g.hw + (long)(h0 + pr) * g.w + (w0 + pc);
+            const uint4* src = dout + (long)n0 * do_img + (long)(tile0 * 2) * NL * g.hw + (long)(h0 + pr) * g.w + (w0 + pc);
 #pragma unroll 1
-            for (int un = wid; un < co_oct_live * 2; un += kCopyWaves)        // unit = (octet, limb)
+            for (int un = wid; un < co_oct_live * NL; un += kCopyWaves)       // unit = (octet, limb)
                 glds16(live ? src + (long)un * g.hw : zero, dl + un * g.du);
         }
 #pragma unroll
@@ -217,9 +229,9 @@ __global__ __launch_bounds__(kWaves * 64) void conv_l16_wgrad_kernel(WGeom g, co
             if (j < g.xi && qr[j] >= 0) {
                 const int gh = h0 + qr[j] - PADH, gw = w0 + qc[j] - PADW;
                 const bool live = gh >= 0 && gh < g.h && gw >= 0 && gw < g.w;
-                const uint4* src = in + (long)n0 * in_img + (long)(cit0 * 2) * 2 * g.hw + (long)gh * g.w + gw;
+                const uint4* src = in + (long)n0 * in_img + (long)(cit0 * 2) * NL * g.hw + (long)gh * g.w + gw;
 #pragma unroll 1
-                for (int un = wid; un < ci_oct_live * 2; un += kCopyWaves)
+                for (int un = wid; un < ci_oct_live * NL; un += kCopyWaves)
                     glds16(live ? src + (long)un * g.hw : zero, il + un * g.plane + j * 64);
             }
         }
@@ -234,17 +246,17 @@ __global__ __launch_bounds__(kWaves * 64) void conv_l16_wgrad_kernel(WGeom g, co
     // ---- this lane's transpose-read pieces.  A (dOut) of tile i, limb l, k-step st:
     //      ((2 (g_start + i) + (c4 >> 1)) * 2 + l) * 64 positions + run * 8 + lj, + (c4 & 1) * 8 bytes;  run = 4 st + kq
     const int runs_shift = g.tw == 8 ? 0 : g.tw == 16 ? 1 : g.tw == 32 ? 2 : 3;      // log2(runs per box row)
-    const int a_lane = (((2 * g_start + (c4 >> 1)) * 2) * g.du + kq * 8 + lj) * 16 + (c4 & 1) * 8;
+    const int a_lane = (((2 * g_start + (c4 >> 1)) * NL) * g.du + kq * 8 + lj) * 16 + (c4 & 1) * 8;
     //      B (input) of slot (ci tile ct, tap), limb l: ((2 (cig * CT + ct) + (c4 >> 1)) * 2 + l) * plane + (r + ty) * cols + c0 + tx + lj
     int b_lane[2];
 #pragma unroll
     for (int st = 0; st < 2; ++st) {
         const int run = 4 * st + kq;
         const int r = run >> runs_shift, c0 = (run - (r << runs_shift)) * 8;
-        b_lane[st] = (((2 * cig * CT + (c4 >> 1)) * 2) * g.plane + r * g.cols + c0 + lj) * 16 + (c4 & 1) * 8;
+        b_lane[st] = (((2 * cig * CT + (c4 >> 1)) * NL) * g.plane + r * g.cols + c0 + lj) * 16 + (c4 & 1) * 8;
     }
     const int limb_b = g.plane * 16;
-    constexpr int kLa[3] = {1, 0, 0}, kLb[3] = {0, 1, 0};     // (A limb, B limb): l*h, h*l, h*h
+    using WP = WProds<NL, NPROD>;
 
     // The whole unit loop is specialised on the wave's live co tiles (dead tiles of a block's last group are skipped without
     // a branch per MFMA; a switch INSIDE the loop makes hipcc keep two copies of the accumulators).
@@ -264,24 +276,24 @@ __global__ __launch_bounds__(kWaves * 64) void conv_l16_wgrad_kernel(WGeom g, co
             if (u + g.nsplit < g.units) issue_unit(u + g.nsplit, stage ^ 1);
             WPROF_ADD(1);
             const char* dl = reinterpret_cast<const char*>(smem4 + stage * stage_u4);
-            const char* il = dl + (size_t)co_oct * 2 * g.du * 16;
+            const char* il = dl + (size_t)co_oct * NL * g.du * 16;
             if constexpr (LIVE > 0) {
 #pragma unroll 1
                 for (int st = 0; st < 2; ++st) {
                     const char* ap = dl + a_lane + st * (4 * 8 * 16);
                     const char* bp = il + b_lane[st];
-                    u32x4 af[LIVE][2];
+                    u32x4 af[LIVE][NL];
 #pragma unroll
                     for (int i = 0; i < LIVE; ++i)
 #pragma unroll
-                        for (int l = 0; l < 2; ++l) af[i][l] = tr_read8(ap + (i * 4 + l) * g.du * 16);
-                    u32x4 bf[kAhead + 1][2];                                   // [buffer][limb]
-                    auto read_slot = [&](int s, u32x4 (&dst)[2]) {
+                        for (int l = 0; l < NL; ++l) af[i][l] = tr_read8(ap + (i * 2 * NL + l) * g.du * 16);
+                    u32x4 bf[kAhead + 1][NL];                                  // [buffer][limb]
+                    auto read_slot = [&](int s, u32x4 (&dst)[NL]) {
                         const int ct = s / TAPS, tap = s - ct * TAPS;
                         const int ty = tap / KW, tx = tap - ty * KW;
-                        const char* p = bp + ct * 4 * limb_b + (ty * g.cols + tx) * 16;
-                        dst[0] = tr_read8(p);
-                        dst[1] = tr_read8(p + limb_b);
+                        const char* p = bp + ct * 2 * NL * limb_b + (ty * g.cols + tx) * 16;
+#pragma unroll
+                        for (int l = 0; l < NL; ++l) dst[l] = tr_read8(p + l * limb_b);
                     };
 #pragma unroll
                     for (int s = 0; s < kAhead && s < NB; ++s) read_slot(s, bf[s]);
@@ -289,14 +301,14 @@ __global__ __launch_bounds__(kWaves * 64) void conv_l16_wgrad_kernel(WGeom g, co
                         constexpr int s = decltype(s_c)::value;
                         if (s + kAhead < NB) read_slot(s + kAhead, bf[(s + kAhead) % (kAhead + 1)]);
 #pragma unroll
-                        for (int gq = 0; gq < 3; ++gq)
+                        for (int gq = 0; gq < NPROD; ++gq)
 #pragma unroll
                             for (int i = 0; i < LIVE; ++i)
-                                acc[s][i] = mfma16(af[i][kLa[gq]], bf[s % (kAhead + 1)][kLb[gq]], acc[s][i]);
-                        // the four reads of the slot kAhead ahead go behind the first MFMAs of this one; nothing else moves across
+                                acc[s][i] = mfma16<NL>(af[i][WP::la[gq]], bf[s % (kAhead + 1)][WP::lb[gq]], acc[s][i]);
+                        // the 2 * NL reads of the slot kAhead ahead go behind the first MFMAs of this one; nothing else moves across
                         // slots (unpinned, the scheduler hoists every slot's reads to the top of the k-step: +56 registers)
 #pragma unroll
-                        for (int k = 0; k < 4; ++k) {
+                        for (int k = 0; k < 2 * NL; ++k) {
                             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                             if (s + kAhead < NB) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
                         }
@@ -373,12 +385,15 @@ __global__ __launch_bounds__(kRedX * kRedY) void l16_wgrad_reduce_kernel(const f
 // -------------------------------------------------------------------------------------------
 struct WPlan {
     WGeom g;
-    int mt, ct;
+    int mt, ct, nl, nprod;
     size_t lds_bytes;
 };
 
 bool plan_l16_wgrad(const fsc_conv_desc& d, WPlan* out) {
-    if (d.arith != FSC_ARITH_DEFAULT && d.arith != 3) return false;
+    const bool bf3 = l16::is_bf3(d.arith);
+    if (d.arith != FSC_ARITH_DEFAULT && d.arith != 3 && !bf3) return false;
+    const int nl = bf3 ? 3 : 2;
+    const int max_tpg = bf3 ? 3 : 4;       // co tiles per wave: 9 taps x 4 tiles x 4 registers + three-limb fragments do not fit 256
     if (fsc::env().no_l16 || fsc::env().no_l16_wgrad) return false;
     const int taps = d.kh * d.kw;
     if (!((d.kh == 3 && d.kw == 3) || (d.kh == 1 && d.kw == 1))) return false;
@@ -392,7 +407,7 @@ bool plan_l16_wgrad(const fsc_conv_desc& d, WPlan* out) {
     }
     g.n = d.n; g.cin = d.c_in; g.cout = d.c_out; g.h = h; g.w = w; g.hw = (long)h * w;
     g.oct_in = (d.c_in + 7) / 8; g.oct_out = (d.c_out + 7) / 8;
-    if ((long)d.n * g.oct_in * 2 * g.hw >= (1L << 31) || (long)d.n * g.oct_out * 2 * g.hw >= (1L << 31)) return false;
+    if ((long)d.n * g.oct_in * nl * g.hw >= (1L << 31) || (long)d.n * g.oct_out * nl * g.hw >= (1L << 31)) return false;
     // box = th x tw = 64 pixels: the fewest padded pixels first; among boxes within 1 % of that, the smallest halo'd window
     // (8 x 8: 100 positions = two DMA instructions per plane; 2 x 32: 136 = three.  Measured on cfg 2 with the box pinned:
     // 64 x 215 planes +5 % with 8 x 8 over 2 x 32, 32 x 107 planes +6 % / -2.5 % over 4 x 16 at equal padding)
@@ -420,21 +435,27 @@ bool plan_l16_wgrad(const fsc_conv_desc& d, WPlan* out) {
     g.rows = g.th + d.kh - 1; g.cols = g.tw + d.kw - 1;
     g.npos = g.rows * g.cols;
     g.xi = fsc::ceil_div(g.npos, 64);
-    const int ct = taps == 1 ? 4 : 1;
-    p.ct = ct;
+    // ci tiles per wave.  1x1 on three limbs: 4, else 2, else 1 -- six bytes per element leave room for fewer staged octets
+    const int ct_opts[3] = {taps == 1 ? 4 : 1, 2, 1};
+    const int n_opts = (taps == 1 && bf3) ? 3 : 1;
+    int ct = ct_opts[0];
+    p.nl = nl;
+    p.nprod = bf3 ? (d.arith == 6 ? 6 : d.arith == 8 ? 8 : 9) : 3;
     const int tiles_co = fsc::ceil_div(d.c_out, 16), tiles_ci = fsc::ceil_div(d.c_in, 16);
     double best_eff = -1.0;
+    for (int opt = 0; opt < n_opts && best_eff < 0.4; ++opt)
     for (int pad = 1; pad >= 0 && best_eff < 0.4; --pad) {       // bank-conflict padding first; without it when nothing fits
+        ct = ct_opts[opt];
         int plane = g.npos;
         if (pad) while (plane % 8 != 2) ++plane;
         const int du = pad ? 66 : 64;
         for (int nt = 1; nt <= 8; nt *= 2) {
             const int ng = kWaves / nt;
             const int ci_blocks = fsc::ceil_div(tiles_ci, nt * ct);
-            const int co_blocks = fsc::ceil_div(tiles_co, ng * 4);
+            const int co_blocks = fsc::ceil_div(tiles_co, ng * max_tpg);
             const int tpb = fsc::ceil_div(tiles_co, co_blocks);
             const int tpg = fsc::ceil_div(tpb, ng);
-            const size_t lds = 2 * 16 * ((size_t)ng * tpg * 2 * 2 * du + (size_t)nt * ct * 2 * 2 * plane);
+            const size_t lds = 2 * 16 * ((size_t)ng * tpg * 2 * nl * du + (size_t)nt * ct * 2 * nl * plane);
             if (lds > 160 * 1024) continue;
             static const double kTileWeight[5] = {0.0, 0.6, 0.8, 0.93, 1.0};
             long busiest = 0;
@@ -466,6 +487,7 @@ bool plan_l16_wgrad(const fsc_conv_desc& d, WPlan* out) {
         }
     }
     if (best_eff < 0.4) return false;
+    p.ct = ct;
     p.mt = g.tpg;
     g.co_pad = g.co_blocks * g.tpb * 16;
     g.ci_pad = g.ci_blocks * g.nt * ct * 16;
@@ -480,10 +502,10 @@ bool plan_l16_wgrad(const fsc_conv_desc& d, WPlan* out) {
     return true;
 }
 
-template <int KH, int KW, int MT, int CT>
+template <int KH, int KW, int MT, int CT, int NL = 2, int NPROD = 3>
 void launch_k(const WPlan& p, const uint4* in, const uint4* dout, float* part, const float* in_amax, const float* dout_amax,
               hipStream_t st) {
-    auto kern = conv_l16_wgrad_kernel<KH, KW, MT, CT>;
+    auto kern = conv_l16_wgrad_kernel<KH, KW, MT, CT, NL, NPROD>;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes);
     dim3 grid(p.g.co_blocks * p.g.ci_blocks, p.g.nsplit);
     hipLaunchKernelGGL(kern, grid, dim3(kWaves * 64), p.lds_bytes, st, p.g, in, dout, part, in_amax, dout_amax);
@@ -513,8 +535,8 @@ size_t fsc_conv_l16_wgrad_workspace_bytes(const fsc_conv_desc* d) {
 int fsc_conv_l16_wgrad(const fsc_conv_desc* d, const void* in_l16, const float* in_amax, const void* dout_l16,
                        const float* dout_amax, float* dweight, void* workspace, fsc_stream_t stream) {
     WPlan p;
-    FSC_CHECK_ARG(valid_desc(d) && in_l16 && in_amax && dout_l16 && dout_amax && dweight && workspace,
-                  "fsc_conv_l16_wgrad: bad descriptor or null pointer");
+    FSC_CHECK_ARG(valid_desc(d) && in_l16 && dout_l16 && dweight && workspace, "fsc_conv_l16_wgrad: bad descriptor or null pointer");
+    FSC_CHECK_ARG(l16::is_bf3(d->arith) || (in_amax && dout_amax), "fsc_conv_l16_wgrad: the two-limb format needs both operand maxima");
     FSC_CHECK_ARG(plan_l16_wgrad(*d, &p), "fsc_conv_l16_wgrad: unsupported shape (see fsc_conv_l16_wgrad_supported)");
     hipStream_t st = fsc::as_stream(stream);
     const uint4* in = reinterpret_cast<const uint4*>(in_l16);
@@ -524,12 +546,31 @@ int fsc_conv_l16_wgrad(const fsc_conv_desc* d, const void* in_l16, const float* 
     if (d->kh == 3) launch_k<3, 3, MT_, 1>(p, in, dout, part, in_amax, dout_amax, st);            \
     else launch_k<1, 1, MT_, 4>(p, in, dout, part, in_amax, dout_amax, st);                       \
     break;
-    switch (p.mt) {
-        case 1: FSC_WL(1)
-        case 2: FSC_WL(2)
-        case 3: FSC_WL(3)
-        default: FSC_WL(4)
+#define FSC_WL3(MT_, NP_)                                                                                \
+    if (d->kh == 3) launch_k<3, 3, MT_, 1, 3, NP_>(p, in, dout, part, in_amax, dout_amax, st);           \
+    else if (p.ct == 4) launch_k<1, 1, MT_, 4, 3, NP_>(p, in, dout, part, in_amax, dout_amax, st);       \
+    else if (p.ct == 2) launch_k<1, 1, MT_, 2, 3, NP_>(p, in, dout, part, in_amax, dout_amax, st);       \
+    else launch_k<1, 1, MT_, 1, 3, NP_>(p, in, dout, part, in_amax, dout_amax, st);                      \
+    break;
+    if (p.nl == 3) {
+        if (p.nprod != 9) {
+            fsc::set_error("fsc_conv_l16_wgrad: this build has no bf16-limb kernels with %d products", p.nprod);
+            return 22;
+        }
+        switch (p.mt) {
+            case 1: FSC_WL3(1, 9)
+            case 2: FSC_WL3(2, 9)
+            default: FSC_WL3(3, 9)
+        }
+    } else {
+        switch (p.mt) {
+            case 1: FSC_WL(1)
+            case 2: FSC_WL(2)
+            case 3: FSC_WL(3)
+            default: FSC_WL(4)
+        }
     }
+#undef FSC_WL3
 #undef FSC_WL
     FSC_LAUNCH_CHECK("fsc_conv_l16_wgrad");
     const int taps = d->kh * d->kw;
@@ -542,10 +583,11 @@ int fsc_conv_l16_wgrad(const fsc_conv_desc* d, const void* in_l16, const float* 
 /* which = 0: the last fsc_conv_l16_fwd / _pool_fwd (_stats) launch, 1: the last fsc_conv_l16_wgrad launch.  Synchronises the
  * device (a measurement aid: bench.py reads it after re-running the dominant layer, outside any timed region). */
 int fsc_conv_l16_last_clock(int which, double* shader_mhz) {
-    FSC_CHECK_ARG(shader_mhz && (which == 0 || which == 1), "fsc_conv_l16_last_clock: bad arguments");
+    FSC_CHECK_ARG(shader_mhz && (which == 0 || which == 1 || which == 2), "fsc_conv_l16_last_clock: bad arguments");
     hipError_t e = hipDeviceSynchronize();
     if (e != hipSuccess) { fsc::set_error("fsc_conv_l16_last_clock: %s", hipGetErrorString(e)); return (int)e; }
     if (which == 0) return fsc::l16_fwd_clock(shader_mhz);
+    if (which == 2) return fsc::l3::last_clock(shader_mhz);
     unsigned long long v[2] = {0, 0};
     e = hipMemcpyFromSymbol(v, HIP_SYMBOL(g_l16w_clock), sizeof(v));
     if (e != hipSuccess) { fsc::set_error("fsc_conv_l16_last_clock: %s", hipGetErrorString(e)); return (int)e; }
@@ -566,9 +608,11 @@ int fsc_debug_l16w_prof(unsigned long long* out64) {
 int fsc_conv_l16_wgrad_plan_describe(const fsc_conv_desc* d, char* buf, size_t buf_len) {
     WPlan p;
     FSC_CHECK_ARG(valid_desc(d) && buf && buf_len > 0 && plan_l16_wgrad(*d, &p), "fsc_conv_l16_wgrad_plan_describe: unsupported shape");
-    snprintf(buf, buf_len, "conv_l16_wgrad_kernel<%d,%d,%d,%d> box=%dx%d groups=%dx%d tiles/block=%d units=%d split=%d grid=%dx%d lds=%zu",
-             d->kh, d->kw, p.mt, p.ct, p.g.th, p.g.tw, p.g.ng, p.g.nt, p.g.tpb, p.g.units, p.g.nsplit,
-             p.g.co_blocks * p.g.ci_blocks, p.g.nsplit, p.lds_bytes);
+    char name[64];
+    if (p.nl == 3) snprintf(name, sizeof(name), "conv_l3_wgrad_kernel<%d,%d,%d,%d,%d>", d->kh, d->kw, p.mt, p.ct, p.nprod);
+    else snprintf(name, sizeof(name), "conv_l16_wgrad_kernel<%d,%d,%d,%d>", d->kh, d->kw, p.mt, p.ct);
+    snprintf(buf, buf_len, "%s box=%dx%d groups=%dx%d tiles/block=%d units=%d split=%d grid=%dx%d lds=%zu", name, p.g.th, p.g.tw, p.g.ng,
+             p.g.nt, p.g.tpb, p.g.units, p.g.nsplit, p.g.co_blocks * p.g.ci_blocks, p.g.nsplit, p.lds_bytes);
     return 0;
 }
 

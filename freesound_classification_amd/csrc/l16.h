@@ -46,4 +46,56 @@ __device__ __forceinline__ void store_amax(float* amax, float value) {
     for (int i = threadIdx.x; i < fsc::kAmaxFloats; i += blockDim.x) amax[i] = i == 0 ? value : 0.f;
 }
 
+// ---- three exact bf16 limbs (arith 9 / 8 / 6): x = h + m + l with h = rne_bf16(x), m = rne_bf16(x - h), l = x - h - m (8 + 8 + 8
+// significand bits; bf16 has the fp32 exponent range, so there is no scale and no declared maximum).
+__host__ __device__ inline bool is_bf3(int arith) { return arith == 9 || arith == 8 || arith == 6; }
+typedef float f32x2_l16 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2_l16 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {      // v_cvt_pk_bf16_f32 (RNE)
+    return __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2_l16){lo, hi}, bf16x2_l16));
+}
+__device__ __forceinline__ float fsub1(float a, float b) {                 // one v_sub_f32 (hipcc pairs them into v_pk_add_f32 otherwise)
+    float r;
+    asm("v_sub_f32_e32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ void split3_pair(float x0, float x1, unsigned& h, unsigned& m, unsigned& l) {
+    const unsigned hp = cvt_pk_bf16(x0, x1);
+    const float r0 = fsub1(x0, __uint_as_float(hp << 16)), r1 = fsub1(x1, __uint_as_float(hp & 0xffff0000u));
+    const unsigned mp = cvt_pk_bf16(r0, r1);
+    const float s0 = fsub1(r0, __uint_as_float(mp << 16)), s1 = fsub1(r1, __uint_as_float(mp & 0xffff0000u));
+    h = hp;
+    m = mp;
+    l = cvt_pk_bf16(s0, s1);
+}
+// eight channels of one position -> the three 16-byte limb vectors
+__device__ __forceinline__ void split8_bf3(const float (&v)[8], uint4& h, uint4& m, uint4& l) {
+    split3_pair(v[0], v[1], h.x, m.x, l.x);
+    split3_pair(v[2], v[3], h.y, m.y, l.y);
+    split3_pair(v[4], v[5], h.z, m.z, l.z);
+    split3_pair(v[6], v[7], h.w, m.w, l.w);
+}
+
 }  // namespace l16
+
+// conv_l3.hip: the bf16-limb (three limbs, arith 9 / 8 / 6) kernels behind the fsc_conv_l16_* / fsc_l16_* entry points
+namespace fsc {
+namespace l3 {
+size_t tensor_bytes(int n, int c, long hw);
+int pack(const float* x, int n, int c, long hw, void* out, hipStream_t st);
+int unpack(const void* in, int n, int c, long hw, float* x, hipStream_t st);
+int supported(const fsc_conv_desc* d, int dgrad);
+int pool_supported(const fsc_conv_desc* d);
+size_t packed_floats(const fsc_conv_desc* d, int dgrad);
+int pack_weights_pair(const fsc_conv_desc* d, const float* weight, float* packed_fwd, float* packed_dgrad, hipStream_t st);
+int pack_weights_multi(int count, const fsc_conv_desc* descs, const float* const* weights, float* const* packed_fwd,
+                       float* const* packed_dgrad, hipStream_t st);
+int fwd(const fsc_conv_desc* d, const void* in_l16, const float* packed, const float* bias, int dgrad, int accumulate, float* out,
+        const float* stat_pivot, void* stat_rec, hipStream_t st);
+int pool_fwd(const fsc_conv_desc* d, const void* in_l16, const float* packed, const float* bias, float* pooled, uint8_t* idx,
+             const float* stat_pivot, void* stat_rec, hipStream_t st);
+int stats_layout(const fsc_conv_desc* d, int pool, int* out4);
+int plan_describe(const fsc_conv_desc* d, int dgrad, char* buf, size_t buf_len);
+int last_clock(double* shader_mhz);
+}  // namespace l3
+}  // namespace fsc

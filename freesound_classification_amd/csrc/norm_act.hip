@@ -765,15 +765,21 @@ __device__ __forceinline__ float block_max256(float m, float* red) {
 // lines, 4x the write requests.  Instead each wave transposes through its own LDS patch (80-byte lane pitch: conflict-free
 // 16-byte writes) so that instruction k stores positions 64 k + lane of the wave's 256 -- 1 KB contiguous.  Needs the wave's
 // lanes on consecutive quads (position lanes >= 64) and EVERY lane of the wave calling (dead lanes pass anything).
-__device__ __forceinline__ void l16_store_quads(uint4* __restrict__ out_hi, uint4* __restrict__ out_lo, long q, long hw,
-                                                const uint4 (&hi)[4], const uint4 (&lo)[4], uint4* wave_patch) {
+// NL limbs: 2 (scaled fp16 pairs) or 3 (exact bf16 triples); lv[p][limb]; limb planes hw apart from out0.
+template <int NL>
+__device__ __forceinline__ void l16_split(const float (&v8)[8], float s, uint4 (&out)[NL]) {
+    if constexpr (NL == 2) l16::split8(v8, s, out[0], out[1]);
+    else l16::split8_bf3(v8, out[0], out[1], out[2]);
+}
+template <int NL>
+__device__ __forceinline__ void l16_store_quads(uint4* __restrict__ out0, long q, long hw, const uint4 (&lv)[4][NL], uint4* wave_patch) {
     const int lane = threadIdx.x & 63;
     const long p0 = 4 * (q - lane);                          // first position of the wave's 256
 #pragma unroll
-    for (int limb = 0; limb < 2; ++limb) {
+    for (int limb = 0; limb < NL; ++limb) {
 #pragma unroll
-        for (int p = 0; p < 4; ++p) wave_patch[lane * 5 + p] = limb ? lo[p] : hi[p];
-        uint4* out = limb ? out_lo : out_hi;
+        for (int p = 0; p < 4; ++p) wave_patch[lane * 5 + p] = lv[p][limb];
+        uint4* out = out0 + limb * hw;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int pp = k * 64 + lane;
@@ -783,22 +789,25 @@ __device__ __forceinline__ void l16_store_quads(uint4* __restrict__ out_hi, uint
     }
 }
 
-template <int VEC, bool UNI>
+template <int VEC, bool UNI, int NL>
 __global__ __launch_bounds__(kThreads) void fwd_l16_kernel(
     const float* __restrict__ x, const float* __restrict__ scale, const float* __restrict__ shift,
     const float* __restrict__ alpha, const float* __restrict__ x_minmax, float* __restrict__ y,
     uint4* __restrict__ y16, float* __restrict__ y_amax, int n, int c, long hw, int hwp_log2) {
     __shared__ float red[kThreads / 64];
     const bool has_alpha = alpha != nullptr;
-    float m = 0.f;
-    for (int ch = threadIdx.x; ch < c; ch += kThreads) {
-        const float sc = scale[ch], sh = shift[ch], al = has_alpha ? alpha[ch] : 0.f;
-        const float lo = act(fmaf(x_minmax[2 * ch], sc, sh), al, has_alpha), hi = act(fmaf(x_minmax[2 * ch + 1], sc, sh), al, has_alpha);
-        m = fmaxf(m, fmaxf(fabsf(lo), fabsf(hi)));
+    float s = 1.f;
+    if constexpr (NL == 2) {                                 // (bf16 limbs carry the fp32 exponent: no scale, no declared maximum)
+        float m = 0.f;
+        for (int ch = threadIdx.x; ch < c; ch += kThreads) {
+            const float sc = scale[ch], sh = shift[ch], al = has_alpha ? alpha[ch] : 0.f;
+            const float lo = act(fmaf(x_minmax[2 * ch], sc, sh), al, has_alpha), hi = act(fmaf(x_minmax[2 * ch + 1], sc, sh), al, has_alpha);
+            m = fmaxf(m, fmaxf(fabsf(lo), fabsf(hi)));
+        }
+        m = block_max256(m, red);
+        if (blockIdx.x == 0 && blockIdx.y == 0) l16::store_amax(y_amax, m);
+        s = l16::field_to_float(l16::scale_field(m));
     }
-    m = block_max256(m, red);
-    if (blockIdx.x == 0 && blockIdx.y == 0) l16::store_amax(y_amax, m);
-    const float s = l16::field_to_float(l16::scale_field(m));
     const int oct = (c + 7) >> 3;
     const int hwp = UNI ? kThreads : 1 << hwp_log2, groups = UNI ? 1 : kThreads >> hwp_log2;
     const int tn = UNI ? 0 : threadIdx.x >> hwp_log2, ti = UNI ? threadIdx.x : threadIdx.x & (hwp - 1);
@@ -816,8 +825,7 @@ __global__ __launch_bounds__(kThreads) void fwd_l16_kernel(
     }
     const long nq = hw / VEC;
     const long xbase = ((long)img * c + o * 8) * hw;
-    uint4* const out_hi = y16 + (((long)img * oct + o) * 2) * hw;
-    uint4* const out_lo = out_hi + hw;
+    uint4* const out0 = y16 + (((long)img * oct + o) * NL) * hw;
     __shared__ uint4 patch[kThreads / 64][64 * 5];
     const bool transpose = VEC == 4 && hwp >= 64;            // (uniform)
     const int lane = threadIdx.x & 63;
@@ -842,23 +850,22 @@ __global__ __launch_bounds__(kThreads) void fwd_l16_kernel(
                 if (y && live) y[xbase + e * hw + q] = z[e][0];
             }
         }
-        uint4 hi[VEC], lo[VEC];
+        uint4 lv[VEC][NL];
 #pragma unroll
         for (int p = 0; p < VEC; ++p) {
             const float v8[8] = {z[0][p], z[1][p], z[2][p], z[3][p], z[4][p], z[5][p], z[6][p], z[7][p]};
-            l16::split8(v8, s, hi[p], lo[p]);
+            l16_split<NL>(v8, s, lv[p]);
         }
         if constexpr (VEC == 4) {
             if (transpose) {
-                l16_store_quads(out_hi, out_lo, q, hw, hi, lo, patch[threadIdx.x >> 6]);
+                l16_store_quads<NL>(out0, q, hw, lv, patch[threadIdx.x >> 6]);
                 continue;
             }
         }
 #pragma unroll
-        for (int p = 0; p < VEC; ++p) {
-            out_hi[q * VEC + p] = hi[p];
-            out_lo[q * VEC + p] = lo[p];
-        }
+        for (int p = 0; p < VEC; ++p)
+#pragma unroll
+            for (int l = 0; l < NL; ++l) out0[l * hw + q * VEC + p] = lv[p][l];
     }
 }
 
@@ -1301,17 +1308,20 @@ __global__ __launch_bounds__(kThreads) void bwd_apply_unpool_kernel(BwdArgs a, c
 
 // Backward apply pass writing dx as an L16 tensor (and, optionally, as fp32 planes too).  Same arithmetic as
 // bwd_apply_plane_kernel; thread layout of fwd_l16_kernel.  The scale comes from the per-channel bounds coef[2c + ch].
-template <int VEC, bool UNI>
+template <int VEC, bool UNI, int NL>
 __global__ __launch_bounds__(kThreads) void bwd_apply_l16_kernel(BwdArgs a, const float* __restrict__ coef,
                                                                   float* __restrict__ dx, uint4* __restrict__ dx16,
                                                                   float* __restrict__ dres,
                                                                   float* __restrict__ dx_amax, int hwp_log2) {
     __shared__ float red[kThreads / 64];
-    float m = 0.f;
-    for (int ch = threadIdx.x; ch < a.c; ch += kThreads) m = fmaxf(m, coef[2 * a.c + ch]);
-    m = block_max256(m, red);
-    if (blockIdx.x == 0 && blockIdx.y == 0) l16::store_amax(dx_amax, m);
-    const float s = l16::field_to_float(l16::scale_field(m));
+    float s = 1.f;
+    if (NL == 2 || dx_amax != nullptr) {                     // (bf16 limbs need no scale; the bound is still published when asked for)
+        float m = 0.f;
+        for (int ch = threadIdx.x; ch < a.c; ch += kThreads) m = fmaxf(m, coef[2 * a.c + ch]);
+        m = block_max256(m, red);
+        if (blockIdx.x == 0 && blockIdx.y == 0) l16::store_amax(dx_amax, m);
+        s = l16::field_to_float(l16::scale_field(m));
+    }
     const int c = a.c, oct = (c + 7) >> 3;
     const long hw = a.hw;
     const int hwp = UNI ? kThreads : 1 << hwp_log2, groups = UNI ? 1 : kThreads >> hwp_log2;
@@ -1322,8 +1332,7 @@ __global__ __launch_bounds__(kThreads) void bwd_apply_l16_kernel(BwdArgs a, cons
     const bool has_alpha = a.alpha != nullptr;
     const long nq = g_live ? hw / VEC : 0;
     const long xbase = ((long)img * c + o * 8) * hw;
-    uint4* const out_hi = dx16 + (((long)img * oct + o) * 2) * hw;
-    uint4* const out_lo = out_hi + hw;
+    uint4* const out0 = dx16 + (((long)img * oct + o) * NL) * hw;
     __shared__ uint4 patch[kThreads / 64][64 * 5];
     const bool transpose = VEC == 4 && hwp >= 64;            // (uniform; see l16_store_quads)
     const int lane = threadIdx.x & 63;
@@ -1377,40 +1386,43 @@ __global__ __launch_bounds__(kThreads) void bwd_apply_l16_kernel(BwdArgs a, cons
                 for (int p = 0; p < VEC; ++p) d[e][p] = 0.f;
             }
         }
-        uint4 hi[VEC], lo[VEC];
+        uint4 lv[VEC][NL];
 #pragma unroll
         for (int p = 0; p < VEC; ++p) {
             const float v8[8] = {d[0][p], d[1][p], d[2][p], d[3][p], d[4][p], d[5][p], d[6][p], d[7][p]};
-            l16::split8(v8, s, hi[p], lo[p]);
+            l16_split<NL>(v8, s, lv[p]);
         }
         if constexpr (VEC == 4) {
             if (transpose) {
-                l16_store_quads(out_hi, out_lo, q, hw, hi, lo, patch[threadIdx.x >> 6]);
+                l16_store_quads<NL>(out0, q, hw, lv, patch[threadIdx.x >> 6]);
                 continue;
             }
         }
 #pragma unroll
-        for (int p = 0; p < VEC; ++p) {
-            out_hi[q * VEC + p] = hi[p];
-            out_lo[q * VEC + p] = lo[p];
-        }
+        for (int p = 0; p < VEC; ++p)
+#pragma unroll
+            for (int l = 0; l < NL; ++l) out0[l * hw + q * VEC + p] = lv[p][l];
     }
 }
 
 // L16 form of bwd_apply_unpool_kernel: a thread owns one pooled position x the 8 channels of an (octet, image) and writes the
 // 2 x 2 (or 1 x 2) window of the full-resolution gradient dc -- each channel's gradient at ITS arg-max position, zeros
 // elsewhere -- as 16-byte limb vectors; the odd trailing row / column of dc is zero.
+template <int NL>
 __global__ __launch_bounds__(kThreads) void bwd_apply_unpool_l16_kernel(BwdArgs a, const float* __restrict__ coef,
                                                                          const uint8_t* __restrict__ pool_idx,
                                                                          float* __restrict__ dc, uint4* __restrict__ dc16,
                                                                          int h, int w, int ph, int oh, int ow,
                                                                          float* __restrict__ dc_amax, int hwp_log2) {
     __shared__ float red[kThreads / 64];
-    float m = 0.f;
-    for (int ch = threadIdx.x; ch < a.c; ch += kThreads) m = fmaxf(m, coef[2 * a.c + ch]);
-    m = block_max256(m, red);
-    if (blockIdx.x == 0 && blockIdx.y == 0) l16::store_amax(dc_amax, m);
-    const float s = l16::field_to_float(l16::scale_field(m));
+    float s = 1.f;
+    if (NL == 2 || dc_amax != nullptr) {
+        float m = 0.f;
+        for (int ch = threadIdx.x; ch < a.c; ch += kThreads) m = fmaxf(m, coef[2 * a.c + ch]);
+        m = block_max256(m, red);
+        if (blockIdx.x == 0 && blockIdx.y == 0) l16::store_amax(dc_amax, m);
+        s = l16::field_to_float(l16::scale_field(m));
+    }
     const int c = a.c, oct = (c + 7) >> 3;
     const long hw = a.hw, HW = (long)h * w;
     const int hwp = 1 << hwp_log2, groups = kThreads >> hwp_log2;
@@ -1420,8 +1432,7 @@ __global__ __launch_bounds__(kThreads) void bwd_apply_unpool_l16_kernel(BwdArgs 
     const int o = g_live ? (int)(g / a.n) : 0, img = g_live ? (int)(g - (long)o * a.n) : 0;
     const bool has_alpha = a.alpha != nullptr;
     const long xbase = ((long)img * c + o * 8) * hw;
-    uint4* const out_hi = dc16 + (((long)img * oct + o) * 2) * HW;
-    uint4* const out_lo = out_hi + HW;
+    uint4* const out0 = dc16 + (((long)img * oct + o) * NL) * HW;
     const uint4 zero4 = make_uint4(0u, 0u, 0u, 0u);
     const long nq = g_live ? hw : 0;
     for (long q = (long)blockIdx.y * hwp + ti; q < nq; q += (long)gridDim.y * hwp) {
@@ -1461,23 +1472,22 @@ __global__ __launch_bounds__(kThreads) void bwd_apply_unpool_l16_kernel(BwdArgs 
             float v8[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) v8[e] = pos[e] == wpos ? d[e] : 0.f;
-            uint4 hi, lo;
-            l16::split8(v8, s, hi, lo);
+            uint4 lv[NL];
+            l16_split<NL>(v8, s, lv);
             const long dst = (long)(oy * ph + (wpos >> 1)) * w + 2 * ox + (wpos & 1);
-            out_hi[dst] = hi;
-            out_lo[dst] = lo;
+#pragma unroll
+            for (int l = 0; l < NL; ++l) out0[l * HW + dst] = lv[l];
         }
         if ((w & 1) && ox == ow - 1) {                      // column floor-mode pooling never read
-            for (int r = 0; r < ph; ++r) {
-                out_hi[(long)(oy * ph + r) * w + w - 1] = zero4;
-                out_lo[(long)(oy * ph + r) * w + w - 1] = zero4;
-            }
+            for (int r = 0; r < ph; ++r)
+#pragma unroll
+                for (int l = 0; l < NL; ++l) out0[l * HW + (long)(oy * ph + r) * w + w - 1] = zero4;
         }
     }
     if (ph == 2 && (h & 1) && blockIdx.y == 0 && g_live) {  // trailing row
         for (int xx = ti; xx < w; xx += hwp) {
-            out_hi[(long)(h - 1) * w + xx] = zero4;
-            out_lo[(long)(h - 1) * w + xx] = zero4;
+#pragma unroll
+            for (int l = 0; l < NL; ++l) out0[l * HW + (long)(h - 1) * w + xx] = zero4;
             if (dc)
                 for (int e = 0; e < 8; ++e)
                     if (o * 8 + e < c) dc[((long)img * c + o * 8 + e) * HW + (long)(h - 1) * w + xx] = 0.f;
@@ -1691,16 +1701,31 @@ int fsc_bn_train_stats_conv(const void* records, int workers, int blocks, int co
 int fsc_bn_act_fwd(const float* x, const float* residual, const float* scale, const float* shift,
                    const float* alpha, float* y, int n, int c, long hw, float* y_amax, const float* x_minmax,
                    void* y_l16, fsc_stream_t stream) {
+    return fsc_bn_act_fwd_limbs(x, residual, scale, shift, alpha, y, n, c, hw, y_amax, x_minmax, y_l16, 2, stream);
+}
+
+int fsc_bn_act_fwd_limbs(const float* x, const float* residual, const float* scale, const float* shift,
+                         const float* alpha, float* y, int n, int c, long hw, float* y_amax, const float* x_minmax,
+                         void* y_l16, int limbs, fsc_stream_t stream) {
     FSC_CHECK_ARG(x && scale && shift && (y || y_l16), "fsc_bn_act_fwd: null pointer");
     FSC_CHECK_ARG(n > 0 && c > 0 && hw > 0, "fsc_bn_act_fwd: bad shape (%d, %d, %ld)", n, c, hw);
+    FSC_CHECK_ARG(limbs == 2 || limbs == 3, "fsc_bn_act_fwd_limbs: limbs must be 2 or 3");
     hipStream_t st = fsc::as_stream(stream);
     if (y_l16) {
-        FSC_CHECK_ARG(x_minmax && y_amax && !residual && hw > 1,
-                      "fsc_bn_act_fwd: the L16 output needs x_minmax (fsc_bn_train_stats) and y_amax, takes no residual, hw > 1");
+        FSC_CHECK_ARG(!residual && hw > 1, "fsc_bn_act_fwd: the L16 output takes no residual and needs hw > 1");
+        FSC_CHECK_ARG(limbs == 3 || (x_minmax && y_amax),
+                      "fsc_bn_act_fwd: the two-limb L16 output needs x_minmax (fsc_bn_train_stats) and y_amax");
         const L16Grid g = l16_grid(n, c, hw, true);
         uint4* y16 = reinterpret_cast<uint4*>(y_l16);
-#define FSC_FWD_L16(V_, U_) hipLaunchKernelGGL((fwd_l16_kernel<V_, U_>), g.grid, dim3(kThreads), 0, st, x, scale, shift, alpha, \
-                                               x_minmax, y, y16, y_amax, n, c, hw, g.hwp_log2)
+#define FSC_FWD_L16(V_, U_)                                                                                                          \
+    do {                                                                                                                             \
+        if (limbs == 2)                                                                                                              \
+            hipLaunchKernelGGL((fwd_l16_kernel<V_, U_, 2>), g.grid, dim3(kThreads), 0, st, x, scale, shift, alpha, x_minmax, y, y16, \
+                               y_amax, n, c, hw, g.hwp_log2);                                                                        \
+        else                                                                                                                         \
+            hipLaunchKernelGGL((fwd_l16_kernel<V_, U_, 3>), g.grid, dim3(kThreads), 0, st, x, scale, shift, alpha, x_minmax, y, y16, \
+                               y_amax, n, c, hw, g.hwp_log2);                                                                        \
+    } while (0)
         if (g.vec == 4) { if (g.uni) FSC_FWD_L16(4, true); else FSC_FWD_L16(4, false); }
         else { if (g.uni) FSC_FWD_L16(1, true); else FSC_FWD_L16(1, false); }
 #undef FSC_FWD_L16
@@ -1735,11 +1760,12 @@ int fsc_bn_act_bwd(const float* dy, const float* gmax_dy, const int* gmax_idx, c
                    const float* gamma, const float* beta, const float* alpha, float* dx, float* dresidual,
                    float* dgamma, float* dbeta, float* dalpha, float* dx_chan_sum, int n, int c, long hw,
                    void* workspace, float* dx_amax, double* sync, int phase, void* dx_l16, fsc_stream_t stream) {
-    FSC_CHECK_ARG(x && save_mean && save_invstd && (dx || dx_l16 || (phase & ~FSC_BN_TICKETS) == 1) && workspace,
+    FSC_CHECK_ARG(x && save_mean && save_invstd && (dx || dx_l16 || (phase & ~(FSC_BN_TICKETS | FSC_BN_L16_LIMBS3)) == 1) && workspace,
                   "fsc_bn_act_bwd: null pointer");
-    FSC_CHECK_ARG(!dx_l16 || (dx_amax && hw > 1), "fsc_bn_act_bwd: the L16 output needs dx_amax and hw > 1");
+    const bool limbs3 = (phase & FSC_BN_L16_LIMBS3) != 0;
+    FSC_CHECK_ARG(!dx_l16 || ((dx_amax || limbs3) && hw > 1), "fsc_bn_act_bwd: the L16 output needs dx_amax (two limbs) and hw > 1");
     const bool zero_tickets = (phase & FSC_BN_TICKETS) != 0;
-    phase &= ~FSC_BN_TICKETS;
+    phase &= ~(FSC_BN_TICKETS | FSC_BN_L16_LIMBS3);
     FSC_CHECK_ARG(phase == 0 || ((phase == 1 || phase == 2) && sync), "fsc_bn_act_bwd: phase 1 / 2 need `sync`");
     FSC_CHECK_ARG(dy || gmax_dy, "fsc_bn_act_bwd: no upstream gradient");
     FSC_CHECK_ARG((gmax_dy == nullptr) == (gmax_idx == nullptr), "fsc_bn_act_bwd: gmax_dy / gmax_idx must come in pairs");
@@ -1772,8 +1798,15 @@ int fsc_bn_act_bwd(const float* dy, const float* gmax_dy, const int* gmax_idx, c
     if (dx_l16) {
         const L16Grid g = l16_grid(n, c, hw, true);
         uint4* dx16 = reinterpret_cast<uint4*>(dx_l16);
-#define FSC_BWD_L16(V_, U_) hipLaunchKernelGGL((bwd_apply_l16_kernel<V_, U_>), g.grid, dim3(kThreads), 0, st, a, p.coef, dx, dx16, \
-                                               dresidual, dx_amax, g.hwp_log2)
+#define FSC_BWD_L16(V_, U_)                                                                                                    \
+    do {                                                                                                                       \
+        if (!limbs3)                                                                                                           \
+            hipLaunchKernelGGL((bwd_apply_l16_kernel<V_, U_, 2>), g.grid, dim3(kThreads), 0, st, a, p.coef, dx, dx16, dresidual, \
+                               dx_amax, g.hwp_log2);                                                                           \
+        else                                                                                                                   \
+            hipLaunchKernelGGL((bwd_apply_l16_kernel<V_, U_, 3>), g.grid, dim3(kThreads), 0, st, a, p.coef, dx, dx16, dresidual, \
+                               dx_amax, g.hwp_log2);                                                                           \
+    } while (0)
         if (g.vec == 4) { if (g.uni) FSC_BWD_L16(4, true); else FSC_BWD_L16(4, false); }
         else { if (g.uni) FSC_BWD_L16(1, true); else FSC_BWD_L16(1, false); }
 #undef FSC_BWD_L16
@@ -1805,9 +1838,10 @@ int fsc_bn_act_bwd_unpool(const float* dy, const float* x, const float* save_mea
                           int h, int w, int ph, void* workspace, float* dc_amax, double* sync, int phase,
                           void* dc_l16, fsc_stream_t stream) {
     FSC_CHECK_ARG(dy && x && save_mean && save_invstd && pool_idx && (dc || dc_l16) && workspace, "fsc_bn_act_bwd_unpool: null pointer");
-    FSC_CHECK_ARG(!dc_l16 || dc_amax, "fsc_bn_act_bwd_unpool: the L16 output needs dc_amax");
+    const bool limbs3 = (phase & FSC_BN_L16_LIMBS3) != 0;
+    FSC_CHECK_ARG(!dc_l16 || dc_amax || limbs3, "fsc_bn_act_bwd_unpool: the two-limb L16 output needs dc_amax");
     const bool zero_tickets = (phase & FSC_BN_TICKETS) != 0;
-    phase &= ~FSC_BN_TICKETS;
+    phase &= ~(FSC_BN_TICKETS | FSC_BN_L16_LIMBS3);
     FSC_CHECK_ARG(phase == 0 || ((phase == 1 || phase == 2) && sync), "fsc_bn_act_bwd_unpool: phase 1 / 2 need `sync`");
     FSC_CHECK_ARG((ph == 1 || ph == 2) && n > 0 && c > 0 && h >= ph && w >= 2, "fsc_bn_act_bwd_unpool: bad shape");
     const int oh = h / ph, ow = w / 2;
@@ -1833,8 +1867,12 @@ int fsc_bn_act_bwd_unpool(const float* dy, const float* x, const float* save_mea
     if (dc_l16) {
         L16Grid g = l16_grid(n, c, hw, false);
         if (g.uni) g.hwp_log2 = 8;
-        hipLaunchKernelGGL(bwd_apply_unpool_l16_kernel, g.grid, dim3(kThreads), 0, st, a, p.coef, pool_idx, dc,
-                           reinterpret_cast<uint4*>(dc_l16), h, w, ph, oh, ow, dc_amax, g.hwp_log2);
+        if (!limbs3)
+            hipLaunchKernelGGL(bwd_apply_unpool_l16_kernel<2>, g.grid, dim3(kThreads), 0, st, a, p.coef, pool_idx, dc,
+                               reinterpret_cast<uint4*>(dc_l16), h, w, ph, oh, ow, dc_amax, g.hwp_log2);
+        else
+            hipLaunchKernelGGL(bwd_apply_unpool_l16_kernel<3>, g.grid, dim3(kThreads), 0, st, a, p.coef, pool_idx, dc,
+                               reinterpret_cast<uint4*>(dc_l16), h, w, ph, oh, ow, dc_amax, g.hwp_log2);
         FSC_LAUNCH_CHECK("fsc_bn_act_bwd_unpool(l16)");
         return 0;
     }

@@ -372,35 +372,54 @@ def conv_dgrad(dout, weight, x_shape, accumulate_into=None, dout_amax=None):
 
 # ---- pre-split activations (include/fsc_hip.h "L16" tensors)
 class L16:
-    """An activation held as two scaled fp16 limbs in the MFMA operand layout, plus the maximum its scale derives from."""
-    __slots__ = ("data", "amax", "shape")
+    """An activation held as 16-bit limbs in the MFMA operand layout: two scaled fp16 limbs plus the maximum the scale derives
+    from (arith 3), or three exact bf16 limbs (arith 9: no scale, amax is None)."""
+    __slots__ = ("data", "amax", "shape", "limbs")
 
-    def __init__(self, data, amax, shape):
-        self.data, self.amax, self.shape = data, amax, tuple(shape)
+    def __init__(self, data, amax, shape, limbs=2):
+        self.data, self.amax, self.shape, self.limbs = data, amax, tuple(shape), limbs
 
 
-def l16_empty(shape, like):
+def _l16_arith():
+    """The arithmetic of the pre-split (L16) route under the current mode: 3 (two scaled fp16 limbs, three products), 9 (three
+    exact bf16 limbs, all nine products: fp32-exact), or None when the mode has no L16 kernels."""
+    a = get_conv_arith()
+    return a if a in (3, 9) else None
+
+
+def _l16_limbs(arith=None):
+    return 3 if (_l16_arith() if arith is None else arith) == 9 else 2
+
+
+BN_L16_LIMBS3 = 64        # include/fsc_hip.h FSC_BN_L16_LIMBS3
+
+
+def l16_empty(shape, like, limbs=None):
     n, c = shape[0], shape[1]
     hw = 1
     for v in shape[2:]:
         hw *= v
-    nbytes = _lib.load().fsc_l16_bytes(n, c, hw)
+    nbytes = _lib.load().fsc_l16_bytes_limbs(n, c, hw, _l16_limbs() if limbs is None else limbs)
     return torch.empty(nbytes // 4, device=like.device, dtype=torch.int32)
 
 
-def l16_pack(x, x_amax=None):
+def l16_pack(x, x_amax=None, limbs=None):
     """fp32 (N, C, ...) -> L16 (one read + one write; the fused producers write the format directly)."""
-    x_amax = amax(x) if x_amax is None else x_amax
+    limbs = _l16_limbs() if limbs is None else limbs
+    if limbs == 2:
+        x_amax = amax(x) if x_amax is None else x_amax
+    else:
+        x_amax = None
     n, c = x.shape[0], x.shape[1]
-    data = l16_empty(x.shape, x)
-    call("fsc_l16_pack", ptr(x), n, c, x.numel() // (n * c), ptr(x_amax), ptr(data), stream_ptr())
-    return L16(data, x_amax, x.shape)
+    data = l16_empty(x.shape, x, limbs)
+    call("fsc_l16_pack_limbs", ptr(x), n, c, x.numel() // (n * c), ptr(x_amax), limbs, ptr(data), stream_ptr())
+    return L16(data, x_amax, x.shape, limbs)
 
 
 def l16_unpack(t):
     n, c = t.shape[0], t.shape[1]
     x = torch.empty(t.shape, device=t.data.device, dtype=torch.float32)
-    call("fsc_l16_unpack", ptr(t.data), n, c, x.numel() // (n * c), ptr(t.amax), ptr(x), stream_ptr())
+    call("fsc_l16_unpack_limbs", ptr(t.data), n, c, x.numel() // (n * c), ptr(t.amax), t.limbs, ptr(x), stream_ptr())
     return x
 
 
@@ -453,7 +472,7 @@ def _l16_plan_sig(d):
 def conv_l16_pack(weight, n, h, w, dgrad):
     """Packed A fragments of `weight` for fsc_conv_l16_fwd on (n, ., h, w) activations: (descriptor, packed)."""
     c_out, c_in, kh, kw = weight.shape
-    d = _desc(n, c_in, c_out, h, w, kh, kw, 3)
+    d = _desc(n, c_in, c_out, h, w, kh, kw, _l16_arith())
     dg = 1 if dgrad else 0
     nfl = _lib.load().fsc_conv_l16_packed_floats(C.byref(d), dg)
     if nfl == 0:
@@ -488,7 +507,7 @@ def prepack_begin(key):
     _PREPACKED.clear()
     if MULTI_PACK:
         _xpack_begin(key)
-    if not MULTI_PACK or get_conv_arith() != 3 or not USE_L16:
+    if not MULTI_PACK or _l16_arith() is None or not USE_L16:
         return None
     plan = _PACK_PLAN.get(key)
     if plan is None:
@@ -501,7 +520,7 @@ def prepack_begin(key):
     made = []
     for i, (weight, n, h, w) in enumerate(plan):
         c_out, c_in, kh, kw = weight.shape
-        d = _desc(n, c_in, c_out, h, w, kh, kw, 3)
+        d = _desc(n, c_in, c_out, h, w, kh, kw, _l16_arith())
         nf, nd = lib.fsc_conv_l16_packed_floats(C.byref(d), 0), lib.fsc_conv_l16_packed_floats(C.byref(d), 1)
         pf = torch.empty(nf, device=weight.device, dtype=torch.float32) if nf else None
         pd = torch.empty(nd, device=weight.device, dtype=torch.float32) if nd else None
@@ -544,7 +563,7 @@ def conv_l16_pack_pair(weight, n, h, w):
     if hit is not None and hit[0] == (n, h, w):
         return hit[1], hit[2]
     c_out, c_in, kh, kw = weight.shape
-    d = _desc(n, c_in, c_out, h, w, kh, kw, 3)
+    d = _desc(n, c_in, c_out, h, w, kh, kw, _l16_arith())
     lib = _lib.load()
     nf, nd = lib.fsc_conv_l16_packed_floats(C.byref(d), 0), lib.fsc_conv_l16_packed_floats(C.byref(d), 1)
     if nf == 0 and nd == 0:
@@ -644,7 +663,7 @@ def conv_l16_pool(t, weight, bias, prepacked=None, stats_bn=None):
     shape), or None when the library has no fused tiling for the shape."""
     c_out, c_in, kh, kw = weight.shape
     n, _, h, w = t.shape
-    d = _desc(n, c_in, c_out, h, w, kh, kw, 3)
+    d = _desc(n, c_in, c_out, h, w, kh, kw, _l16_arith())
     if (kh, kw) != (3, 3) or not _lib.load().fsc_conv_l16_pool_supported(C.byref(d)):
         return None
     _, packed = prepacked if prepacked is not None else conv_l16_pack(weight, n, h, w, False)
@@ -685,7 +704,7 @@ def conv_l16_wgrad(x16, dout16, weight_shape, out=None):
     With L16_WGRAD_SIDE the kernel runs on the side stream (the caller joins it: ConvBlockFn.backward does)."""
     c_out, c_in, kh, kw = weight_shape
     n, _, h, w = x16.shape
-    d = _desc(n, c_in, c_out, h, w, kh, kw, 3)
+    d = _desc(n, c_in, c_out, h, w, kh, kw, _l16_arith())
     nbytes = _lib.load().fsc_conv_l16_wgrad_workspace_bytes(C.byref(d))
     if nbytes == 0:
         raise _lib.FscError("conv_l16_wgrad: unsupported shape %s" % [getattr(d, f) for f, _ in d._fields_])
@@ -742,7 +761,7 @@ def measure_l16_clock(shape, kind, iters=40):
             for _ in range(iters):
                 conv_l16(t, wt, None, dgrad=kind == "dgrad", prepacked=pp)
         mhz = C.c_double(0.0)
-        call("fsc_conv_l16_last_clock", 1 if kind == "wgrad" else 0, C.byref(mhz))
+        call("fsc_conv_l16_last_clock", 1 if kind == "wgrad" else (2 if _l16_limbs() == 3 else 0), C.byref(mhz))
     finally:
         globals()["TIMER"] = timer
     return mhz.value
@@ -760,11 +779,11 @@ USE_L16 = True        # route convolutions through the pre-split (L16) kernels w
 def l16_ok(n, c_in, c_out, h, w, kh, kw, dgrad):
     """True when the producer of this convolution's operand should write it as an L16 tensor (split-fp16 arithmetic and
     fsc_conv_l16_fwd has a tiling for the shape)."""
-    if not USE_L16 or get_conv_arith() != 3:
+    if not USE_L16 or _l16_arith() is None:
         return False
-    key = (n, c_in, c_out, h, w, kh, kw, bool(dgrad))
+    key = (n, c_in, c_out, h, w, kh, kw, bool(dgrad), _l16_arith())
     if key not in _L16_OK:
-        _L16_OK[key] = conv_l16_supported(_desc(n, c_in, c_out, h, w, kh, kw, 3), 1 if dgrad else 0)
+        _L16_OK[key] = conv_l16_supported(_desc(n, c_in, c_out, h, w, kh, kw, _l16_arith()), 1 if dgrad else 0)
     return _L16_OK[key]
 
 
@@ -778,12 +797,12 @@ def _l16_ok_for(x_shape, weight, dgrad):
 
 def _l16_wgrad_ok_for(x_shape, weight):
     """True when the weight gradient of this convolution runs on fsc_conv_l16_wgrad (both operands as L16 tensors)."""
-    if len(x_shape) != 4 or not USE_L16 or get_conv_arith() != 3:
+    if len(x_shape) != 4 or not USE_L16 or _l16_arith() is None:
         return False
     c_out, c_in, kh, kw = weight.shape
-    key = (x_shape[0], c_in, c_out, x_shape[2], x_shape[3], kh, kw, "wgrad")
+    key = (x_shape[0], c_in, c_out, x_shape[2], x_shape[3], kh, kw, "wgrad", _l16_arith())
     if key not in _L16_OK:
-        _L16_OK[key] = conv_l16_wgrad_supported(_desc(x_shape[0], c_in, c_out, x_shape[2], x_shape[3], kh, kw, 3))
+        _L16_OK[key] = conv_l16_wgrad_supported(_desc(x_shape[0], c_in, c_out, x_shape[2], x_shape[3], kh, kw, _l16_arith()))
     return _L16_OK[key]
 
 
@@ -1058,12 +1077,13 @@ def bn_act_forward(x, st, alpha=None, residual=None, with_amax=False, l16=False,
     conv_l16, when the unit has batch statistics (their min / max bound the output up front) and no residual."""
     n, c = x.shape[0], x.shape[1]
     hw = x.numel() // (n * c)
-    if l16 and st.minmax is not None and residual is None and hw > 1:
+    limbs = _l16_limbs()
+    if l16 and (st.minmax is not None or limbs == 3) and residual is None and hw > 1:
         y = torch.empty_like(x) if want_f32 else None
-        t = L16(l16_empty(x.shape, x), _empty((AMAX_FLOATS,), x), x.shape)
+        t = L16(l16_empty(x.shape, x, limbs), _empty((AMAX_FLOATS,), x) if limbs == 2 else None, x.shape, limbs)
         with _stage("bn_act_fwd", _nb(x, y, t)):
-            call("fsc_bn_act_fwd", ptr(x), None, ptr(st.scale), ptr(st.shift), ptr(alpha), ptr(y),
-                 n, c, hw, ptr(t.amax), ptr(st.minmax), ptr(t.data), stream_ptr())
+            call("fsc_bn_act_fwd_limbs", ptr(x), None, ptr(st.scale), ptr(st.shift), ptr(alpha), ptr(y),
+                 n, c, hw, ptr(t.amax), ptr(st.minmax) if limbs == 2 else None, ptr(t.data), limbs, stream_ptr())
         return y, t
     y = torch.empty_like(x)
     y_amax = _empty((AMAX_FLOATS,), x) if (with_amax or l16) and _want_amax() else None
@@ -1091,8 +1111,10 @@ def bn_act_backward(dy, x, st, bn, alpha=None, residual=None, gmax=None, want_dx
     dalpha = _empty((c,), x) if alpha is not None else None
     csum = _empty((c,), x) if want_chan_sum and want_dx else None
     gdy, gidx = gmax if gmax is not None else (None, None)
-    dx_amax = _empty((AMAX_FLOATS,), x) if with_amax and want_dx and (_want_amax() or l16) else None
-    t = L16(l16_empty(x.shape, x), dx_amax, x.shape) if l16 else None
+    limbs = _l16_limbs()
+    lflag = BN_L16_LIMBS3 if (l16 and limbs == 3) else 0
+    dx_amax = _empty((AMAX_FLOATS,), x) if with_amax and want_dx and (_want_amax() or (l16 and limbs == 2)) else None
+    t = L16(l16_empty(x.shape, x, limbs), dx_amax, x.shape, limbs) if l16 else None
     ws = _bn_ws(c, x)                                      # (kept alive across both phases)
     args = (ptr(dy), ptr(gdy), ptr(gidx), ptr(x), ptr(residual), ptr(st.mean),
             ptr(st.invstd), ptr(bn.weight), ptr(bn.bias), ptr(alpha), ptr(dx), ptr(dres), ptr(dgamma),
@@ -1106,12 +1128,12 @@ def bn_act_backward(dy, x, st, bn, alpha=None, residual=None, gmax=None, want_dx
     elif sync is None:
         # reduce pass reads dy, x, residual; apply pass reads them again and writes dx (fp32 and / or L16) and dresidual
         with _stage("bn_act_bwd", 2 * _nb(dy, x, residual) + _nb(dx, dres, t)):
-            call("fsc_bn_act_bwd", *args, None, BN_TICKETS, t_ptr, stream_ptr())
+            call("fsc_bn_act_bwd", *args, None, BN_TICKETS | lflag, t_ptr, stream_ptr())
     else:
         sums = _sync_buffer(c, x)                          # [sum dz, sum dz * xhat, count, 0] per channel
-        call("fsc_bn_act_bwd", *args, ptr(sums), 1, t_ptr, stream_ptr())
+        call("fsc_bn_act_bwd", *args, ptr(sums), 1 | lflag, t_ptr, stream_ptr())
         sync(sums)
-        call("fsc_bn_act_bwd", *args, ptr(sums), 2, t_ptr, stream_ptr())
+        call("fsc_bn_act_bwd", *args, ptr(sums), 2 | lflag, t_ptr, stream_ptr())
     if with_amax:
         return dx, dres, dgamma, dbeta, dalpha, csum, (t if l16 else dx_amax)
     return dx, dres, dgamma, dbeta, dalpha, csum
@@ -1127,8 +1149,10 @@ def bn_act_backward_unpool(dy, x, st, bn, alpha, pool_idx, c_shape, ph, sync=Non
     dbeta = _empty((c,), x)
     dalpha = _empty((c,), x) if alpha is not None else None
     csum = _empty((c,), x)
-    dc_amax = _empty((AMAX_FLOATS,), x) if (_want_amax() or l16) else None
-    t = L16(l16_empty(c_shape, x), dc_amax, c_shape) if l16 else None
+    limbs = _l16_limbs()
+    lflag = BN_L16_LIMBS3 if (l16 and limbs == 3) else 0
+    dc_amax = _empty((AMAX_FLOATS,), x) if (_want_amax() or (l16 and limbs == 2)) else None
+    t = L16(l16_empty(c_shape, x, limbs), dc_amax, c_shape, limbs) if l16 else None
     ws = _bn_ws(c, x)                                      # (kept alive across both phases)
     args = (ptr(dy), ptr(x), ptr(st.mean), ptr(st.invstd), ptr(bn.weight), ptr(bn.bias),
             ptr(alpha), ptr(pool_idx), ptr(dc), ptr(dgamma), ptr(dbeta), ptr(dalpha), ptr(csum), n, c, h, w, ph,
@@ -1136,12 +1160,12 @@ def bn_act_backward_unpool(dy, x, st, bn, alpha, pool_idx, c_shape, ph, sync=Non
     t_ptr = ptr(t.data) if l16 else None
     if sync is None:
         with _stage("bn_act_bwd", 2 * _nb(dy, x) + _nb(pool_idx, dc, t)):
-            call("fsc_bn_act_bwd_unpool", *args, None, BN_TICKETS, t_ptr, stream_ptr())
+            call("fsc_bn_act_bwd_unpool", *args, None, BN_TICKETS | lflag, t_ptr, stream_ptr())
     else:
         sums = _sync_buffer(c, x)
-        call("fsc_bn_act_bwd_unpool", *args, ptr(sums), 1, t_ptr, stream_ptr())
+        call("fsc_bn_act_bwd_unpool", *args, ptr(sums), 1 | lflag, t_ptr, stream_ptr())
         sync(sums)
-        call("fsc_bn_act_bwd_unpool", *args, ptr(sums), 2, t_ptr, stream_ptr())
+        call("fsc_bn_act_bwd_unpool", *args, ptr(sums), 2 | lflag, t_ptr, stream_ptr())
     return dc, dgamma, dbeta, dalpha, csum, (t if l16 else dc_amax)
 
 
@@ -1285,7 +1309,7 @@ def _bn_fwd_for_conv(x, st, alpha, weight, keep_f32=False, need_wgrad=True):
     The L16 form is written when the forward convolution or its weight gradient reads it; the fp32 form when one of the two
     does not (or the caller needs it: keep_f32)."""
     fw, wg = _l16_ok_for(x.shape, weight, False), need_wgrad and _l16_wgrad_ok_for(x.shape, weight)
-    if (fw or wg) and st.minmax is not None:
+    if (fw or wg) and (st.minmax is not None or _l16_limbs() == 3):
         y, t = bn_act_forward(x, st, alpha, l16=True, want_f32=keep_f32 or not (fw and (wg or not need_wgrad)))
         if t is not None:
             return y, t.amax, t
@@ -1350,7 +1374,7 @@ def _block_forward(x, mods, training, want_head, ph, keep, sync=None, next_bn=Fa
     w_a, b_a = _conv_params(conv_a)
 
     def mm(t, wt):           # inference: the BatchNorm in front of a convolution with an L16 tiling also reports the range of its input
-        return (not training) and EVAL_L16 and t.dim() == 4 and _l16_ok_for(t.shape, wt, False)
+        return (not training) and EVAL_L16 and _l16_limbs() == 2 and t.dim() == 4 and _l16_ok_for(t.shape, wt, False)   # (bf16 limbs: no scale, no range)
 
     st_a = bn_prepare(x, bn_a, training, sync, counters, want_minmax=mm(x, w_a))
     # Operands of convolutions that have an L16 tiling are written pre-split by the BN / PReLU kernel that produces them

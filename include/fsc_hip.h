@@ -177,6 +177,15 @@ size_t fsc_l16_bytes(int n, int c, long hw);
 int fsc_l16_pack(const float* x, int n, int c, long hw, const float* amax, void* out_l16, fsc_stream_t stream);
 /* (h + l) / scale back to fp32 NCHW (tests, debugging) */
 int fsc_l16_unpack(const void* in_l16, int n, int c, long hw, const float* amax, float* x, fsc_stream_t stream);
+/* Limb formats.  limbs = 2: the scaled fp16 pairs above (arith 3).  limbs = 3: three EXACT bf16 limbs, x = h + m + l
+ * (8 + 8 + 8 significand bits, fp32 exponent range: no scale, `amax` is neither read nor written and may be NULL), layout
+ * bf16[N][ceil(C / 8)][3 limbs][HW][8 channels], 6 bytes per element -- the operands of arith 9 (all nine limb products on
+ * v_mfma_f32_16x16x32_bf16: each product is the exact product of the fp32 operands, fp32 accumulation; 8 / 6 drop the terms
+ * below 2^-32 / 2^-23 |a*b|).  Every fsc_conv_l16_* entry point takes the format from fsc_conv_desc.arith (3 -> two limbs,
+ * 9 / 8 / 6 -> three) and the producers from their `limbs` argument (fsc_bn_act_*_limbs). */
+size_t fsc_l16_bytes_limbs(int n, int c, long hw, int limbs);
+int fsc_l16_pack_limbs(const float* x, int n, int c, long hw, const float* amax, int limbs, void* out_l16, fsc_stream_t stream);
+int fsc_l16_unpack_limbs(const void* in_l16, int n, int c, long hw, const float* amax, int limbs, float* x, fsc_stream_t stream);
 /* 1 when fsc_conv_l16_fwd has a tiling for this shape and direction (3x3 / 1x1, >= 32 input and >= 48 output
  * channels, enough work items to fill the chip without split-K; arith 3 or FSC_ARITH_DEFAULT) */
 int fsc_conv_l16_supported(const fsc_conv_desc* d, int dgrad);
@@ -228,6 +237,10 @@ size_t fsc_bn_workspace_bytes(int c);
  * Without the flag the workspace needs no initialisation and a separate finalisation kernel runs (same arithmetic, same order of
  * additions: bit-identical results). */
 #define FSC_BN_TICKETS 32
+/* fsc_bn_act_bwd / fsc_bn_act_bwd_unpool, OR-ed into `phase`: the L16 output (dx_l16 / dc_l16) is written as three exact bf16
+ * limbs (fsc_l16_bytes_limbs(.., 3) bytes; the operands of arith 9) instead of two scaled fp16 limbs; the `*_amax` bound is then
+ * optional (written when given). */
+#define FSC_BN_L16_LIMBS3 64
 size_t fsc_bn_workspace_ticket_offset(int c);
 int fsc_bn_workspace_reset(void* workspace, int c, fsc_stream_t stream);
 /* Cross-replica batch statistics (SyncBN for data parallelism; the reference is single-process so its
@@ -284,7 +297,8 @@ int fsc_bn_records_fold(const void* records, const float* y, int n, int c, long 
  * `stat_rec` holds workers * 8 * channels-per-block records of 16 bytes.  fsc_bn_records_fold_conv folds them into split 0 of a
  * BatchNorm workspace; then fsc_bn_train_stats(..., phase | FSC_BN_STATS_FOLDED | FSC_BN_STATS_PIVOT_RM, ...) with the SAME
  * running_mean pointer only finalises.  min / max are exact; mean / variance agree with the separate pass to rounding. */
-/* Shader clock (MHz) the chip ran the LAST L16 convolution launch at (which = 0: fsc_conv_l16_fwd family, 1: fsc_conv_l16_wgrad):
+/* Shader clock (MHz) the chip ran the LAST L16 convolution launch at (which = 0: fsc_conv_l16_fwd family on two-limb
+ * operands, 1: fsc_conv_l16_wgrad, 2: fsc_conv_l16_fwd family on three-limb operands):
  * workgroup 0 stamps the shader-cycle counter and the constant 100 MHz reference counter at both ends of the kernel.  The
  * MFMA-bound launches run well below the 2.4 GHz the peak figures assume (power limit); bench.py reports it next to `roofline`.
  * Synchronises the device: a measurement aid, not for the training path. */
@@ -317,6 +331,11 @@ int fsc_bn_eval_prepare(int c, const float* gamma, const float* beta, const floa
 int fsc_bn_act_fwd(const float* x, const float* residual, const float* scale,
                    const float* shift, const float* alpha, float* y, int n, int c, long hw,
                    float* y_amax, const float* x_minmax, void* y_l16, fsc_stream_t stream);
+/* fsc_bn_act_fwd with the limb format of the L16 output spelled out: limbs = 2 (as above) or 3 (exact bf16 triples: no scale, so
+ * x_minmax and y_amax are not needed and may be NULL). */
+int fsc_bn_act_fwd_limbs(const float* x, const float* residual, const float* scale,
+                         const float* shift, const float* alpha, float* y, int n, int c, long hw,
+                         float* y_amax, const float* x_minmax, void* y_l16, int limbs, fsc_stream_t stream);
 /* backward of the fused unit.  Upstream gradient = dy (may be NULL) plus, when the output also
  * feeds a global max-pool head, gmax_dy[n*c] scattered at position gmax_idx[n*c] of each plane
  * (both NULL otherwise).  Outputs: dx; dresidual (may be NULL; equals the gradient at the

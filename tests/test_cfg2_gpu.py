@@ -147,10 +147,14 @@ def cfg2_experiment(dropout=0.0):
                  scheduler="1cycle_0.0001_0.005", switch_off_augmentations_on=1000, _save_every=1000)))
 
 
-@pytest.fixture(scope="module")
-def cfg2_step(golden):
-    """One training forward / backward + eval forward of the product at cfg-2 width on the fixture's inputs."""
+@pytest.fixture(scope="module", params=["f16x3", "bf16x9"])
+def cfg2_step(golden, request):
+    """One training forward / backward + eval forward of the product at cfg-2 width on the fixture's inputs, in the shipped fast
+    arithmetic (f16x3: two fp16 limbs, three products) and in the fp32-exact one (bf16x9: three bf16 limbs, nine products -- the
+    arithmetic bench.py's headline runs); the tests that use the fixture run in the same mode."""
     g = golden("g12_cfg2_step.npz")
+    mode0 = F.get_conv_arith()
+    F.set_conv_arith(request.param)
     torch.manual_seed(int(g["seed"]))
     m = TwoDimensionalCNNClassificationModel(cfg2_experiment(), device="cuda:0")
     state = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
@@ -163,8 +167,9 @@ def cfg2_step(golden):
     m.eval()
     with torch.no_grad():
         ev = m(signal.to(DEV))["class_logits"].cpu()
-    return dict(g=g, state=state, signal=signal, labels=labels, logits=logits.detach().cpu(), per=per.detach().cpu(),
-                grads=grads, eval_logits=ev, model=m)
+    yield dict(g=g, state=state, signal=signal, labels=labels, logits=logits.detach().cpu(), per=per.detach().cpu(),
+               grads=grads, eval_logits=ev, model=m, arith=request.param)
+    F.set_conv_arith(mode0)
 
 
 def test_cfg2_model_forward_against_reference_golden(cfg2_step):

@@ -1,0 +1,286 @@
+"""The fp32-exact route (arith 9, "bf16x9") on PRE-SPLIT operands: three exact bf16 limbs per fp32 value, all nine limb
+products on v_mfma_f32_16x16x32_bf16, fp32 accumulation (csrc/conv_l3.hip, conv_l16_wgrad.hip<.., 3, 9>, the three-limb
+producers of norm_act.hip).  Replaces nn.Conv2d on fp32 tensors (reference networks/classifiers.py:526-531, 77-81) at the
+reference's own precision: every product is the exact product of the two fp32 operands.
+
+* the format: fp32 -> limbs -> fp32 is the identity, bit for bit;
+* known-answer products that need all nine limb terms (the six-product and the two-limb fp16 arithmetic round differently);
+* every convolution of the cfg-2 model that takes the route, forward / input gradient / accumulating input gradient / weight
+  gradient, with the kernel instantiation batch 128 selects (asserted), against PyTorch's fp64 convolution on the CPU;
+* the producers: what the BatchNorm / PReLU kernels write as limbs equals what they write as fp32, bit for bit
+  (forward, backward, backward + un-pooling);
+* the fused 2 x 2 max-pool and the BatchNorm statistics of the convolution epilogue against the separate passes.
+"""
+import ctypes as C
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+if not torch.cuda.is_available():
+    pytest.skip("needs an MI355X", allow_module_level=True)
+
+import torch.nn.functional as TF  # noqa: E402
+
+from freesound_classification_amd import functional as F  # noqa: E402
+from test_cfg2_gpu import LAYERS, _report  # noqa: E402
+
+DEV = torch.device("cuda:0")
+
+
+@pytest.fixture
+def bf16x9():
+    mode0 = F.get_conv_arith()
+    F.set_conv_arith(9)
+    yield
+    F.set_conv_arith(mode0)
+
+
+def test_three_limb_format_is_exact(bf16x9):
+    """x -> (h, m, l) -> h + (m + l) reproduces every finite normal fp32 value bit for bit, whatever its magnitude (no scale,
+    no declared maximum), for channel counts around the octet edges and odd plane sizes."""
+    gen = torch.Generator(device=DEV).manual_seed(5)
+    for n, c, hw in ((3, 8, 64), (2, 13, 77), (1, 100, 215), (4, 33, 5)):
+        x = torch.randn(n, c, hw, 1, device=DEV, generator=gen)
+        x = x * torch.exp2(torch.randint(-100, 100, x.shape, device=DEV, generator=gen).float())      # 2^-100 .. 2^100
+        t = F.l16_pack(x)
+        assert t.limbs == 3 and t.amax is None
+        assert t.data.numel() * 4 == n * ((c + 7) // 8) * 3 * hw * 16
+        back = F.l16_unpack(t)
+        assert torch.equal(back, x)
+
+
+def _single_product(a, b, arith):
+    """a * b through the 1x1 convolution kernels: 96 input channels of which one carries the operands."""
+    n, c, h, w = 32, 96, 16, 64
+    x = torch.zeros(n, c, h, w, device=DEV)
+    x[:, 5] = a
+    wt = torch.zeros(48, c, 1, 1, device=DEV)
+    wt[7, 5, 0, 0] = b
+    mode0 = F.get_conv_arith()
+    try:
+        F.set_conv_arith(arith)
+        if arith == 9:
+            assert F.conv_l16_supported(F._desc(n, c, 48, h, w, 1, 1, arith), 0)
+            y = F.conv_l16(F.l16_pack(x), wt, None)
+        else:
+            y = F.conv_forward(x, wt, None)
+    finally:
+        F.set_conv_arith(mode0)
+    vals = y[:, 7].flatten()
+    assert float((vals - vals[0]).abs().max()) == 0.0
+    return float(vals[0])
+
+
+def test_products_need_all_nine_limb_terms():
+    """a = 1 + 2^-8 + 2^-16 has the limbs (1, 2^-8, 2^-16); a * a = 1 + 2^-7 + 3 * 2^-16 + 2^-23 + 2^-32, whose fp32 rounding keeps
+    the 2^-23 that only the m * l + l * m terms supply: arith 9 returns the correctly rounded exact product (six products
+    would be one ulp short)."""
+    a = 1.0 + 2.0 ** -8 + 2.0 ** -16
+    exact = torch.tensor(a, dtype=torch.float64) ** 2
+    want = float(exact.float())
+    assert want == 1.0 + 2.0 ** -7 + 3 * 2.0 ** -16 + 2.0 ** -23
+    got9 = _single_product(a, a, 9)
+    assert got9 == want, (got9, want)
+    assert want != 1.0 + 2.0 ** -7 + 3 * 2.0 ** -16         # (what six products -- without m * l, l * m, l * l -- add up to)
+    # random operands with full 24-bit significands: the nine-product result is the fp32 sum of nine EXACT terms (small first),
+    # within one fp32 ulp of the exact product and never further than PyTorch's own fp32 multiply
+    gen = torch.Generator().manual_seed(3)
+    for _ in range(8):
+        u = float(1.0 + torch.rand(1, generator=gen, dtype=torch.float64).float())
+        v = float(1.0 + torch.rand(1, generator=gen, dtype=torch.float64).float())
+        got = _single_product(u, v, 9)
+        ex = u * v                                            # exact in fp64 (48 significant bits)
+        assert abs(got - ex) <= 2.0 ** -23 * ex, (u, v, got, ex)
+
+
+def _plans(n, layer):
+    c_in, c_out, h, w, k = layer
+    d = F._desc(n, c_in, c_out, h, w, k, k, 9)
+    return [F.l16_plan_name(d, 0), F.l16_plan_name(d, 1), F.l16_wgrad_plan_name(d)]
+
+
+def _batch_for(layer):
+    c_in, c_out, h, w, k = layer
+    if h * w <= 8 * 26:
+        return 128
+    full = _plans(128, layer)
+    for n in (2, 4, 8, 16, 32, 64):
+        d = F._desc(n, c_in, c_out, h, w, k, k, 9)
+        if all(F.conv_l16_supported(d, m) for m in (0, 1)) and F.conv_l16_wgrad_supported(d) and _plans(n, layer) == full:
+            return n
+    return 128
+
+
+L3_LAYERS = [l for l in LAYERS if l[0] >= 32 and l[2] * l[3] > 2 * 6]
+
+
+def test_the_cfg2_layers_take_the_three_limb_route(bf16x9):
+    """All 3 x 3 and 1 x 1 convolutions of the cfg-2 model from 100 channels @ 64 x 215 down to 759 @ 4 x 13 have a tiling in
+    every direction at batch 128 (the stem and the 2 x 6-pixel block stay on the fp32-input nine-product kernels)."""
+    for layer in L3_LAYERS:
+        c_in, c_out, h, w, k = layer
+        d = F._desc(128, c_in, c_out, h, w, k, k, 9)
+        assert F.conv_l16_supported(d, 0) and F.conv_l16_supported(d, 1) and F.conv_l16_wgrad_supported(d), layer
+        names = _plans(128, layer)
+        assert names[0].startswith("conv_l3_fwd_kernel<%d,%d," % (k, k)) and names[0].endswith(",9>"), names
+        assert names[2].startswith("conv_l3_wgrad_kernel<%d,%d," % (k, k)) and names[2].endswith(",9>"), names
+
+
+@pytest.mark.parametrize("layer", L3_LAYERS, ids=["%dto%d_%dx%d_k%d" % l for l in L3_LAYERS])
+def test_cfg2_layer_on_three_limbs_against_fp64(layer, bf16x9):
+    c_in, c_out, h, w, k = layer
+    n = _batch_for(layer)
+    names = _plans(n, layer)
+    assert names == _plans(128, layer), (names, _plans(128, layer))
+    torch.manual_seed(c_in * 7 + c_out + h)
+    pad = k // 2
+    x = torch.randn(n, c_in, h, w)
+    wt = torch.randn(c_out, c_in, k, k) / (c_in * k * k) ** 0.5
+    b = torch.randn(c_out)
+    gy = torch.randn(n, c_out, h, w)
+    y64 = TF.conv2d(x.double(), wt.double(), b.double(), padding=pad)
+    dx64 = torch.nn.grad.conv2d_input(x.shape, wt.double(), gy.double(), padding=pad)
+    dw64 = torch.nn.grad.conv2d_weight(x.double(), wt.shape, gy.double(), padding=pad)
+    e_y = float((TF.conv2d(x, wt, b, padding=pad).double() - y64).abs().max())
+    e_dx = float((torch.nn.grad.conv2d_input(x.shape, wt, gy, padding=pad).double() - dx64).abs().max())
+    e_dw = float((torch.nn.grad.conv2d_weight(x, wt.shape, gy, padding=pad).double() - dw64).abs().max())
+    xd, wd, bd, gd = x.to(DEV), wt.to(DEV), b.to(DEV), gy.to(DEV)
+    x16, g16 = F.l16_pack(xd), F.l16_pack(gd)
+    y = F.conv_l16(x16, wd, bd).cpu()
+    dx = F.conv_l16(g16, wd, None, dgrad=True).cpu()
+    base = torch.randn_like(x)
+    dxa = F.conv_l16(g16, wd, None, dgrad=True, accumulate_into=base.to(DEV)).cpu()
+    dw = F.conv_l16_wgrad(x16, g16, wt.shape).cpu()
+    g_y = float((y.double() - y64).abs().max())
+    g_dx = float((dx.double() - dx64).abs().max())
+    g_dxa = float((dxa.double() - (dx64 + base.double())).abs().max())
+    g_dw = float((dw.double() - dw64).abs().max())
+    _report("%-22s arith 9 (three limbs) n %3d  fwd %.2e (torch f32 %.2e, x%.2f) %s | dgrad %.2e (%.2e, x%.2f) %s | wgrad %.2e (%.2e, x%.2f) %s"
+            % ("%dto%d_%dx%d_k%d" % layer, n, g_y, e_y, g_y / e_y, names[0], g_dx, e_dx, g_dx / e_dx, names[1], g_dw, e_dw,
+               g_dw / e_dw, names[2]))
+    eps = 2.0 ** -23
+
+    def bound(e32, k_terms, ref):            # test_cfg2_gpu.py: 5x PyTorch's own fp32 error, or one serial fp32 chain of K / 32 blocks
+        return max(5.0 * e32, 2.0 * eps * (k_terms / 4.0) ** 0.5 * float(ref.abs().max())) + 1e-7
+
+    assert g_y < bound(e_y, c_in * k * k, y64), (g_y, e_y)
+    assert g_dx < bound(e_dx, c_out * k * k, dx64), (g_dx, e_dx)
+    assert g_dxa < bound(e_dx, c_out * k * k, dx64) + 1e-6, (g_dxa, e_dx)
+    assert g_dw < bound(e_dw, n * h * w, dw64), (g_dw, e_dw)
+    assert max(g_y, g_dx) < 5e-5
+
+
+@pytest.mark.parametrize("shape", [(48, 64, 10, 20, 3), (56, 100, 7, 33, 3), (100, 170, 9, 12, 3), (49, 81, 16, 16, 3), (136, 96, 5, 44, 1),
+                                   (100, 337, 8, 26, 3)])
+def test_three_limb_conv_odd_shapes_against_fp64(shape, bf16x9):
+    """Channel counts around every tile / octet / chunk edge (remainder chunks, half-empty wave groups, short last blocks),
+    odd planes, several images per box; at the smallest batch that has a persistent tiling (>= 128 work items) in both directions."""
+    c_in, c_out, h, w, k = shape
+    n = None
+    for cand in (8, 16, 32, 64, 128):
+        d = F._desc(cand, c_in, c_out, h, w, k, k, 9)
+        if F.conv_l16_supported(d, 0) and F.conv_l16_supported(d, 1):
+            n = cand
+            break
+    assert n is not None, shape
+    torch.manual_seed(sum(shape))
+    pad = k // 2
+    x = torch.randn(n, c_in, h, w)
+    wt = torch.randn(c_out, c_in, k, k) / (c_in * k * k) ** 0.5
+    b = torch.randn(c_out)
+    gy = torch.randn(n, c_out, h, w)
+    y64 = TF.conv2d(x.double(), wt.double(), b.double(), padding=pad)
+    dx64 = torch.nn.grad.conv2d_input(x.shape, wt.double(), gy.double(), padding=pad)
+    xd, wd, bd, gd = x.to(DEV), wt.to(DEV), b.to(DEV), gy.to(DEV)
+    y = F.conv_l16(F.l16_pack(xd), wd, bd).cpu()
+    dx = F.conv_l16(F.l16_pack(gd), wd, None, dgrad=True).cpu()
+    assert float((y.double() - y64).abs().max()) < 2e-5
+    assert float((dx.double() - dx64).abs().max()) < 2e-5
+    if F.conv_l16_wgrad_supported(d):
+        dw64 = torch.nn.grad.conv2d_weight(x.double(), wt.shape, gy.double(), padding=pad)
+        dw = F.conv_l16_wgrad(F.l16_pack(xd), F.l16_pack(gd), wt.shape).cpu()
+        assert float((dw.double() - dw64).abs().max()) < 3e-6 * float(dw64.abs().max()) + 1e-5
+
+
+def _BN(c, gen):
+    bn = torch.nn.BatchNorm2d(c).to(DEV)
+    with torch.no_grad():
+        bn.weight.copy_(1.0 + 0.3 * torch.randn(c, device=DEV, generator=gen))
+        bn.bias.copy_(0.2 * torch.randn(c, device=DEV, generator=gen))
+    return bn.train()
+
+
+@pytest.mark.parametrize("shape", [(4, 100, 16, 43), (3, 37, 9, 20), (2, 150, 32, 107), (5, 24, 1, 300), (128, 48, 3, 5)])
+def test_producers_write_the_limbs_of_what_they_write_as_fp32(shape, bf16x9):
+    """BatchNorm + PReLU forward, its backward and the backward fused with the max-pool un-pooling: the three-limb output,
+    recombined, equals the fp32 output of the same call bit for bit (the limbs are exact; nothing is scaled or bounded)."""
+    n, c, h, w = shape
+    gen = torch.Generator(device=DEV).manual_seed(n + c + h + w)
+    x = torch.randn(n, c, h, w, device=DEV, generator=gen)
+    bn = _BN(c, gen)
+    alpha = 0.25 + 0.1 * torch.rand(c, device=DEV, generator=gen)
+    st = F.bn_prepare(x, bn, True)
+    y, t = F.bn_act_forward(x, st, alpha, l16=True, want_f32=True)
+    assert t is not None and t.limbs == 3
+    assert torch.equal(F.l16_unpack(t), y)
+    y_plain = F.bn_act_forward(x, st, alpha)
+    assert torch.equal(y_plain, y)
+    # backward
+    dy = torch.randn(n, c, h, w, device=DEV, generator=gen) * torch.exp2(torch.randint(-30, 1, (n, 1, 1, 1), device=DEV, generator=gen).float())
+    res = F.bn_act_backward(dy, x, st, bn, alpha, want_dres=False, want_chan_sum=True, with_amax=True, l16=True, want_f32=True)
+    dx, t2 = res[0], res[-1]
+    assert isinstance(t2, F.L16) and t2.limbs == 3
+    assert torch.equal(F.l16_unpack(t2), dx)
+    ref = F.bn_act_backward(dy, x, st, bn, alpha, want_dres=False, want_chan_sum=True)
+    assert torch.equal(ref[0], dx)
+    for a, b in zip(ref[2:5], res[2:5]):
+        assert torch.equal(a, b)
+    # backward + un-pooling (2 x 2 windows; 1 x 2 on single rows)
+    ph = 2 if h >= 2 else 1
+    c_shape = (n, c, h * ph if ph == 2 else h, 2 * w + 1)
+    cfull = torch.randn(c_shape, device=DEV, generator=gen)
+    pooled, idx = F.maxpool_forward(cfull, ph)
+    assert pooled.shape[2:] == (h if ph == 2 else h, w)
+    stp = F.bn_prepare(pooled, bn, True)
+    out = F.bn_act_backward_unpool(dy, pooled, stp, bn, alpha, idx, c_shape, ph, l16=True, want_f32=True)
+    dc, t3 = out[0], out[-1]
+    assert isinstance(t3, F.L16) and t3.limbs == 3
+    assert torch.equal(F.l16_unpack(t3), dc)
+    ref = F.bn_act_backward_unpool(dy, pooled, stp, bn, alpha, idx, c_shape, ph)
+    # (the un-pooling kernel without limb output is a different kernel with a different thread layout; same arithmetic)
+    assert float((ref[0] - dc).abs().max()) <= 1e-6 * float(dc.abs().max())
+
+
+@pytest.mark.parametrize("shape", [(64, 100, 150, 16, 48), (8, 150, 225, 32, 107), (128, 64, 100, 8, 24)])
+def test_three_limb_conv_fused_with_maxpool_and_statistics(shape, bf16x9):
+    """fsc_conv_l16_pool_fwd(_stats) on three-limb operands: pooled values and window indices equal conv + fsc_maxpool_fwd bit
+    for bit; the statistics of the epilogue (plain and pooled) finalise to the mean / invstd of the separate pass."""
+    n, c_in, c_out, h, w = shape
+    gen = torch.Generator(device=DEV).manual_seed(sum(shape))
+    x = torch.randn(n, c_in, h, w, device=DEV, generator=gen)
+    wt = torch.randn(c_out, c_in, 3, 3, device=DEV, generator=gen) / (c_in * 9) ** 0.5
+    b = torch.randn(c_out, device=DEV, generator=gen)
+    t = F.l16_pack(x)
+    full = F.conv_l16(t, wt, b)
+    pooled_ref, idx_ref = F.maxpool_forward(full, 2)
+    got = F.conv_l16_pool(t, wt, b)
+    assert got is not None, shape
+    pooled, idx, cshape = got
+    assert tuple(cshape) == tuple(full.shape)
+    assert torch.equal(pooled, pooled_ref) and torch.equal(idx, idx_ref)
+    # epilogue statistics against the separate pass
+    bn = _BN(c_out, gen)
+    st_ref = F.bn_prepare(full, bn, True)
+    full2 = F.conv_l16(t, wt, b, stats_bn=(bn, True))
+    assert torch.equal(full2, full)
+    st = F.bn_prepare(full2, bn, True)
+    assert float(((st.mean - st_ref.mean).abs() * st_ref.invstd).max()) < 1e-5
+    assert float((st.invstd / st_ref.invstd - 1).abs().max()) < 1e-5
+    stp_ref = F.bn_prepare(pooled_ref, bn, True)
+    got2 = F.conv_l16_pool(t, wt, b, stats_bn=(bn, True))
+    stp = F.bn_prepare(got2[0], bn, True)
+    assert torch.equal(got2[0], pooled_ref)
+    assert float(((stp.mean - stp_ref.mean).abs() * stp_ref.invstd).max()) < 1e-5
+    assert float((stp.invstd / stp_ref.invstd - 1).abs().max()) < 1e-5
