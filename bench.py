@@ -9,9 +9,15 @@ mel_2048_1024_128, 6 blocks base 100 growth 1.5, deep supervision from block 1, 
 (reference README.md:200-214), fp32.  N > 1: one process per GPU (torch.distributed.run), the
 same per-GPU batch on every rank (weak scaling), value = clips of all ranks / max-over-ranks time.
 
+Arithmetic of `value` (cfg 2): fp32 with EXACT products -- every convolution operand is split exactly into three bf16 limbs by
+the kernel that produces it and all nine limb products run on v_mfma_f32_16x16x32_bf16 with fp32 accumulation ("bf16x9",
+fsc_conv_desc.arith = 9): no narrower than the reference's nn.Conv2d on fp32 tensors.  The library's shipped default, f16x3 (two
+scaled fp16 limbs, three products: 22-bit products), is the FAST mode and is timed beside it (`fast_mode`), as are the native
+fp32-MFMA kernels (`alt_f32`).
+
 Rank 0 prints one JSON line carrying `roofline` (dominant kernel = the conv kernel with the largest
-total time, FLOPs over HIP-event time measured inside the timed region), at N = 1 `alt_f32` (the same
-workload re-timed with the native fp32-MFMA conv kernels, outside the timed region of `value`) and
+total time, FLOPs over HIP-event time measured inside the timed region), at N = 1 `fast_mode` / `alt_f32` (the same
+workload re-timed in the other arithmetics, outside the timed region of `value`) and
 `cpu_baseline` (the CPU oracle = pure-PyTorch restatement of the reference path, timed on this
 box's host cores on a bounded sample: batch 8 of the same model and clip length, 1 + 3 steps).
 """
@@ -40,7 +46,7 @@ class NS(dict):
 WORKLOADS = {
     # BASELINE.json configs[1]
     "cfg2": dict(features="mel_2048_1024_128", blocks=6, base=100, growth=1.5, start=1, dropout=0.7,
-                 batch=128, samples=441000, sr=44100, n_mel=128),
+                 batch=128, samples=441000, sr=44100, n_mel=128, arith="bf16x9"),
     # BASELINE.json configs[2]: 1-d raw-STFT path (win 256), 10-block hierarchical CNN, LSEP + MixUp.
     # hop 128 / base 64 / growth 1.25 are SURVEY section 8d's assumptions.  bf16: conv operands rounded to one bf16
     # value, v_mfma_f32_16x16x32_bf16 with fp32 accumulation; weights / BN statistics / optimizer state fp32 masters
@@ -62,7 +68,7 @@ WORKLOADS = {
     # 4096 clips, lengths U(0.3 s, 30 s) @ 44.1 kHz seed 7, bucket edges every 2 s, <= 128 x 10 s of samples per
     # batch; the cfg-2 network).  A "step" is one length-grouped batch through all five resident fold models.
     "cfg5": dict(features="mel_2048_1024_128", blocks=6, base=100, growth=1.5, start=1, dropout=0.7,
-                 batch=128, samples=441000, sr=44100, n_mel=128, inference=dict(folds=5, clips=4096, seed=7,
+                 batch=128, samples=441000, sr=44100, n_mel=128, arith="bf16x9", inference=dict(folds=5, clips=4096, seed=7,
                                                                                  min_s=0.3, max_s=30.0, bucket_s=2.0)),
 }
 
@@ -148,6 +154,11 @@ def price_kernel(name):
     """(peak TFLOP/s, executed 16-bit MFMA flops per algorithmic fp32 flop, arithmetic) of a timed conv kernel, by its plan name.
     Split kernels (`..._x3_kernel<..., NPROD>`, `conv_l16_*`): every algorithmic fp32 flop costs NPROD 16-bit MFMA flops, so the
     achieved rate counts EXECUTED 16-bit flops and is priced against the dense fp16 / bf16 peak."""
+    if "conv_l3_" in name:             # pre-split operands, three exact bf16 limbs: NPROD (last template argument) limb products
+        per = int(name.rstrip(">").replace(",pool", "").split(",")[-1])
+        return PEAK_BF16_MFMA_TFLOPS, per, ("fp32 with exact products: every operand split exactly into three bf16 limbs by its producer "
+                                            "(L16 tensors, 6 B per element), %d bf16 MFMA products per fp32 product%s, fp32 accumulate"
+                                            % (per, " (all limb pairs: the product of the two fp32 operands is exact)" if per == 9 else ""))
     if "conv_l16_" in name:            # pre-split (L16) operands: the 2-limb fp16 arithmetic, 3 products
         return PEAK_BF16_MFMA_TFLOPS, 3, ("fp32 via 2-limb fp16 split with per-tensor power-of-two scaling (operands pre-split by their "
                                           "producers: L16 tensors), 3 fp16 MFMA products per fp32 product, fp32 accumulate")
@@ -160,6 +171,40 @@ def price_kernel(name):
             arith = "fp32 via 2-limb fp16 split with per-tensor power-of-two scaling, 3 fp16 MFMA products per fp32 product, fp32 accumulate"
         return PEAK_BF16_MFMA_TFLOPS, per, arith
     return PEAK_F32_MFMA_TFLOPS, 1, "native fp32 MFMA"
+
+
+ARITH_LABEL = {0: "f32", 1: "bf16", 3: "f16x3", 6: "bf16x6", 9: "bf16x9"}
+# significand bits a conv product keeps: 24 = the exact product of the fp32 operands (native fp32 MFMA; all nine bf16 limb products)
+ARITH_BITS = {0: 24, 1: 8, 3: 22, 6: 23, 9: 24}
+
+
+def roofline_of(summ, steps):
+    """`roofline` of a KernelTimer summary: the conv kernel with the largest total time, its algorithmic FLOPs over its HIP-event
+    time x the MFMA flops it executes per algorithmic flop, against the dense peak of the pipe it runs on."""
+    fam = {}
+    for name, r in summ.items():
+        f = fam.setdefault(name.split("<")[0], dict(flops=0.0, ms=0.0))
+        f["flops"] += r["flops"]
+        f["ms"] += r["ms"]
+    dom_name, dom = max(summ.items(), key=lambda kv: kv[1]["ms"])
+    achieved = dom["flops"] / dom["ms"] / 1e9          # TFLOP/s
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "roofline_traffic.json")
+    if os.path.exists(tpath):
+        with open(tpath) as f:
+            traffic = json.load(f).get(dom_name)
+    peak, executed_per_flop, arith = price_kernel(dom_name)
+    return {
+        "kernel": dom_name, "bound": "mfma", "achieved": achieved * executed_per_flop, "peak": peak,
+        "unit": "TFLOP/s", "frac": achieved * executed_per_flop / peak, "traffic": traffic,
+        "arithmetic": arith, "algorithmic_fp32_tflops": achieved,
+        "launches_per_step": dom["launches"] / steps,
+        "avg_launch_ms": dom["ms"] / dom["launches"],
+        "algorithmic_gflop_per_launch": dom["flops"] / dom["launches"] / 1e9,
+        "conv_ms_per_step": {k: v["ms"] / steps for k, v in fam.items()},
+        "conv_tflops": {k: v["flops"] / v["ms"] / 1e9 for k, v in fam.items()},
+        "conv_ms_total_per_step": sum(v["ms"] for v in fam.values()) / steps,
+    }
 
 
 def cpu_baseline_inference(w, batch=8, runs=2):
@@ -196,8 +241,8 @@ def run_other_workloads():
     them: their one-line results, trimmed, go into `other_workloads` of the cfg-2 line.  ~1 minute."""
     import subprocess
     out = {}
-    for name, extra in (("cfg3", ["--steps", "20", "--warmup", "5", "--graph"]), ("cfg5", ["--warmup", "2", "--no-alt"])):
-        cmd = [sys.executable, os.path.abspath(__file__), "--workload", name, "--no-cpu-baseline", "--no-other"] + extra
+    for name, extra in (("cfg3", ["--steps", "20", "--warmup", "5", "--graph", "--no-cpu-baseline"]), ("cfg5", ["--warmup", "2", "--no-alt"])):
+        cmd = [sys.executable, os.path.abspath(__file__), "--workload", name, "--no-other"] + extra
         try:
             r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600, cwd=ROOT)
             line = [l for l in r.stdout.decode().splitlines() if l.startswith("{")]
@@ -213,7 +258,7 @@ def run_other_workloads():
                      "dtype": d["dtype"], "scaling": d["scaling"], "workload": d["config"]["workload"],
                      "roofline": {k: roof.get(k) for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "launches_per_step",
                                                            "avg_launch_ms", "conv_ms_per_step", "stages") if k in roof}}
-        for k in ("final_loss", "audio_seconds_per_s", "abi_calls_per_step", "hip_graph"):
+        for k in ("final_loss", "audio_seconds_per_s", "abi_calls_per_step", "hip_graph", "cpu_baseline", "arith_bits", "fast_mode"):
             if k in d:
                 out[name][k] = d[k]
     return out
@@ -279,6 +324,22 @@ def run_inference(args, w, device, world, rank):
         dist.barrier()
     elapsed = time.perf_counter() - t0
     F.TIMER = None
+    fast = None
+    if world == 1 and F.get_conv_arith() != 3:              # the same pass in the library's default (fast) arithmetic, outside `value`
+        mode0 = F.get_conv_arith()
+        F.set_conv_arith(3)
+        try:
+            drv.ensemble_batch(models, padded[0])
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for x in padded[:n_steps]:
+                drv.ensemble_batch(models, x)
+            torch.cuda.synchronize()
+            e1 = time.perf_counter() - t1
+            fast = {"conv_arith": "f16x3", "arith_bits": ARITH_BITS[3], "value": clips / e1, "unit": "clips/s", "steps": n_steps,
+                    "ms_per_step": 1e3 * e1 / n_steps}
+        finally:
+            F.set_conv_arith(mode0)
     total = torch.tensor([float(clips), elapsed], device=device, dtype=torch.float64)
     if world > 1:
         both = total.clone()
@@ -294,14 +355,16 @@ def run_inference(args, w, device, world, rank):
             "metric": "inference clips/s (5-fold ensemble, length-grouped batches, GPU STFT+mel)",
             "value": clips_all / tmax, "unit": "clips/s", "n_gpus": world, "steps": n_steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * tmax / n_steps, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": {0: "f32", 3: "f32 (f16x3 products)", 6: "f32 (bf16x6 products)",
+                      9: "f32 (exact products: 3 bf16 limbs x 9 MFMA products, fp32 accumulate)"}.get(F.get_conv_arith(), "f32"),
+            "arith_bits": ARITH_BITS[F.get_conv_arith()], "data": "synthetic",
             "config": {"workload": "cfg5: %d clips of U(%.1f, %.0f) s @ %.1f kHz (%.0f s of audio), %d length-grouped batches "
                                    "(bucket edges every %.0f s, <= %d x %.0f s of samples), %d resident fold models of the "
                                    "cfg-2 network, sigmoid mean" % (
                                        inf["clips"], inf["min_s"], inf["max_s"], w["sr"] / 1e3, seconds, len(batches),
                                        inf["bucket_s"], w["batch"], w["samples"] / w["sr"], inf["folds"]),
                        "parallelism": "dp%d (batches round-robin)" % world,
-                       "conv_arith": {0: "f32", 1: "bf16", 3: "f16x3", 6: "bf16x6", 9: "bf16x9"}[F.get_conv_arith()]},
+                       "conv_arith": ARITH_LABEL[F.get_conv_arith()]},
             "audio_seconds_per_s": seconds * (clips_all / inf["clips"]) / tmax,
             "reference_claim": "README.md:37: stage-1 test set, 5 folds, 'only 1 minute' (hardware unspecified)",
         }
@@ -322,6 +385,8 @@ def run_inference(args, w, device, world, rank):
                                   "conv_ms_per_step": {k: v["ms"] / n_steps for k, v in fam.items()},
                                   "conv_tflops": {k: v["flops"] / v["ms"] / 1e9 for k, v in fam.items()},
                                   "conv_ms_total": sum(v["ms"] for v in summ.values()), "wall_ms": 1e3 * elapsed}
+        if fast is not None:
+            result["fast_mode"] = fast
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline_inference(w)
         _emit(json.dumps(result))
@@ -627,25 +692,37 @@ def main():
         h2d = {"value": batch * k_h / e_h, "unit": "clips/s", "steps": k_h, "ms_per_step": 1e3 * e_h / k_h,
                "h2d_bytes_per_step": pinned.numel() * 4,
                "note": "host->device copy of the waveform batch inside the timed region (pinned, double-buffered, copy stream)"}
-    # The same workload with the native fp32-MFMA conv kernels (FSC_CONV_ARITH=f32), for readers who want the
-    # number without the split-limb arithmetic; N = 1 only, outside the timed region of `value`.
-    alt = None
-    if world == 1 and not args.no_alt and F.get_conv_arith() not in (0, 1):
+    # The same workload in the other arithmetics, N = 1 only, outside the timed region of `value`: the library's shipped default
+    # (f16x3: two scaled fp16 limbs, three products -- the FAST mode, 22-bit products) with its own kernel table, and the native
+    # fp32-MFMA kernels (v_mfma_f32_16x16x4_f32).
+    def retime(mode, k, warm=2):
         mode0 = F.get_conv_arith()
-        F.set_conv_arith(0)
-        for _ in range(2):
-            one_step()
-        torch.cuda.synchronize()
-        k_alt = max(2, min(args.steps, 5))
-        F.TIMER = F.KernelTimer() if timer is not None else None      # same per-call event overhead as the timed region
-        t1 = time.perf_counter()
-        for _ in range(k_alt):
-            one_step()
-        torch.cuda.synchronize()
-        e_alt = time.perf_counter() - t1
-        F.TIMER = None
-        F.set_conv_arith(mode0)
-        alt = {"conv_arith": "f32", "value": batch * k_alt / e_alt, "unit": "clips/s", "steps": k_alt, "ms_per_step": 1e3 * e_alt / k_alt}
+        F.set_conv_arith(mode)
+        try:
+            for _ in range(warm):
+                one_step()
+            torch.cuda.synchronize()
+            tm = F.KernelTimer() if timer is not None else None      # same per-call event overhead as the timed region
+            F.TIMER = tm
+            t1 = time.perf_counter()
+            for _ in range(k):
+                one_step()
+            torch.cuda.synchronize()
+            e = time.perf_counter() - t1
+        finally:
+            F.TIMER = None
+            F.set_conv_arith(mode0)
+        r = {"conv_arith": ARITH_LABEL[mode], "arith_bits": ARITH_BITS[mode], "value": batch * k / e, "unit": "clips/s", "steps": k,
+             "ms_per_step": 1e3 * e / k}
+        if tm is not None:
+            r["roofline"] = roofline_of(tm.summary(), k)
+        return r
+
+    alt = fast = None
+    if world == 1 and not args.no_alt and F.get_conv_arith() not in (0, 1):
+        if F.get_conv_arith() != 3:
+            fast = retime(3, max(2, min(args.steps, 10)))
+        alt = retime(0, max(2, min(args.steps, 5)))
     if not torch.isfinite(torch.tensor(final_loss)):
         raise SystemExit("non-finite loss in the benchmark: %r" % final_loss)
     # The HBM-bound stages of BASELINE.md section 3 (front-end, BatchNorm / PReLU / pooling passes, optimizer): a few extra steps
@@ -707,15 +784,15 @@ def main():
             # bf16: conv operands rounded to bf16, fp32 accumulation / storage / master weights
             # (f16x3 products: every fp32 product is formed from two scaled fp16 limbs per operand, low x low dropped)
             "dtype": {0: "f32", 1: "bf16", 3: "f32 (f16x3 products)", 6: "f32 (bf16x6 products)",
-                      9: "f32 (bf16x9 products)"}[F.get_conv_arith()],
-            "arith_bits": {0: 24, 1: 8, 3: 22, 6: 23, 9: 24}[F.get_conv_arith()],   # significand bits a conv product keeps
+                      9: "f32 (exact products: 3 bf16 limbs x 9 MFMA products, fp32 accumulate)"}[F.get_conv_arith()],
+            "arith_bits": ARITH_BITS[F.get_conv_arith()],   # significand bits a conv product keeps (24: the exact fp32 product)
             "data": "synthetic",
             "config": {"workload": "%s: batch %d x %.0f s @ %.1f kHz, %s, %d-block %dd CNN base %d growth %g, "
                                    "LSEP, Adam-amsgrad, dropout %g" % (
                                        args.workload, batch, w["samples"] / w["sr"], w["sr"] / 1e3, w["features"],
                                        w["blocks"], w.get("dims", 2), w["base"], w["growth"], w["dropout"]),
                        "global_batch": world * batch, "parallelism": "dp%d" % world,
-                       "conv_arith": {0: "f32", 1: "bf16", 3: "f16x3", 6: "bf16x6", 9: "bf16x9"}[F.get_conv_arith()]},
+                       "conv_arith": ARITH_LABEL[F.get_conv_arith()]},
             "final_loss": final_loss,
             "abi_calls_per_step": abi_calls,           # entry-point calls of libfsc_hip.so per (eager) step (each enqueues one to three kernels)
         }
@@ -735,30 +812,16 @@ def main():
                 for name, r in sorted(summ.items(), key=lambda kv: -kv[1]["ms"]):
                     print("%-36s launches %5d  ms/step %8.3f  TFLOP/s %7.2f" % (
                         name, r["launches"], r["ms"] / timer_steps, r["flops"] / r["ms"] / 1e9), file=sys.stderr)
-            dom_name, dom = max(summ.items(), key=lambda kv: kv[1]["ms"])
-            achieved = dom["flops"] / dom["ms"] / 1e9          # TFLOP/s
-            traffic = None
-            tpath = os.path.join(ROOT, "profiles", "roofline_traffic.json")
-            if os.path.exists(tpath):
-                with open(tpath) as f:
-                    traffic = json.load(f).get(dom_name)
+            dom_name = max(summ.items(), key=lambda kv: kv[1]["ms"])[0]
+            result["roofline"] = roofline_of(summ, timer_steps)
             peak, executed_per_flop, arith = price_kernel(dom_name)
-            result["roofline"] = {
-                "kernel": dom_name, "bound": "mfma", "achieved": achieved * executed_per_flop, "peak": peak,
-                "unit": "TFLOP/s", "frac": achieved * executed_per_flop / peak, "traffic": traffic,
-                "arithmetic": arith, "algorithmic_fp32_tflops": achieved,
-                "launches_per_step": dom["launches"] / timer_steps,
-                "avg_launch_ms": dom["ms"] / dom["launches"],
-                "algorithmic_gflop_per_launch": dom["flops"] / dom["launches"] / 1e9,
-                "conv_ms_per_step": {k: v["ms"] / timer_steps for k, v in fam.items()},
-                "conv_tflops": {k: v["flops"] / v["ms"] / 1e9 for k, v in fam.items()},
-            }
+            achieved = result["roofline"]["algorithmic_fp32_tflops"]
             if stages:
                 result["roofline"]["stages"] = stages
             # The clock the chip actually sustains under the dominant kernel (its largest layer re-run back to back, outside the
             # timed region; the kernel stamps the shader-cycle and the 100 MHz reference counters itself): `peak` above is quoted at
             # the 2.4 GHz maximum, the MFMA-bound launches of this workload run power-limited well below it.
-            if world == 1 and dom_name in timer.shapes and "conv_l16_" in dom_name:
+            if world == 1 and dom_name in timer.shapes and ("conv_l16_" in dom_name or "conv_l3_" in dom_name):
                 _fl, shape, kind = timer.shapes[dom_name]
                 mhz = F.measure_l16_clock(shape, kind)
                 if mhz > 0:
@@ -769,9 +832,12 @@ def main():
         if per_rank is not None:
             result["per_rank_clips_per_s"] = per_rank
             result["allreduce"] = exchange
+        if fast is not None:
+            result["fast_mode"] = fast                                      # the shipped default arithmetic (22-bit products): an extra, not `value`
+            result["config"]["fast_mode_f16x3_clips_per_s"] = fast["value"]
         if alt is not None:
             result["alt_f32"] = alt
-            result["config"]["strict_f32_clips_per_s"] = alt["value"]      # the same step on the native fp32-MFMA kernels
+            result["config"]["native_f32_mfma_clips_per_s"] = alt["value"]  # the same step on the native fp32-MFMA kernels
         if h2d is not None:
             result["with_h2d"] = h2d
         if world == 1 and not args.no_cpu_baseline:
@@ -781,6 +847,18 @@ def main():
             F.forget_packed_weights()
             torch.cuda.empty_cache()
             result["other_workloads"] = run_other_workloads()
+        # the numbers of the line once more, compact and LAST (a log tail keeps them)
+        ow = result.get("other_workloads") or {}
+        roof = result.get("roofline") or {}
+        result["summary"] = {
+            "cfg2_clips_per_s": result["value"], "cfg2_ms_per_step": result["ms_per_step"], "cfg2_arith": result["config"]["conv_arith"],
+            "cfg2_arith_bits": result["arith_bits"], "cfg2_roofline_kernel": roof.get("kernel"), "cfg2_roofline_frac": roof.get("frac"),
+            "cfg2_fast_mode_f16x3_clips_per_s": fast["value"] if fast else None,
+            "cfg2_native_f32_mfma_clips_per_s": alt["value"] if alt else None,
+            "cfg3_clips_per_s": (ow.get("cfg3") or {}).get("value"), "cfg3_ms_per_step": (ow.get("cfg3") or {}).get("ms_per_step"),
+            "cfg5_clips_per_s": (ow.get("cfg5") or {}).get("value"),
+            "cfg5_fast_mode_f16x3_clips_per_s": ((ow.get("cfg5") or {}).get("fast_mode") or {}).get("value"),
+            "cpu_baseline_clips_per_s": (result.get("cpu_baseline") or {}).get("value")}
         _emit(json.dumps(result))
     if dist.is_initialized():
         dist.destroy_process_group()
