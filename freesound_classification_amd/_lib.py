@@ -188,6 +188,8 @@ def ptr(t):
 
 
 CALLS = [0]          # entry-point calls so far (bench.py reports calls per step: the launch-bound workloads are priced by it)
+ON_ERROR = []        # callables run when an entry point fails (functional.py drops its pooled BatchNorm workspaces: an aborted call
+                     # may have left their arrival counters non-zero)
 
 
 def call(name, *args):
@@ -195,4 +197,7 @@ def call(name, *args):
     CALLS[0] += 1
     rc = getattr(lib, name)(*args)
     if rc != 0:
-        raise FscError("%s failed (%d): %s" % (name, rc, lib.fsc_last_error_string().decode()))
+        msg = lib.fsc_last_error_string().decode()
+        for hook in ON_ERROR:
+            hook()
+        raise FscError("%s failed (%d): %s" % (name, rc, msg))

@@ -7,6 +7,8 @@ Layout: activations are NCHW fp32 like the reference; the 1-d model runs with H 
 import ctypes as C
 import os
 import sys
+import threading
+import weakref
 
 import numpy as np
 import torch
@@ -844,10 +846,10 @@ def conv_wgrad(x, dout, weight_shape, on_side_stream=False, x_amax=None, dout_am
         dw = out if out is not None else _empty(tuple(weight_shape), x)
         xa, da = _operand_amax(x, x_amax), _operand_amax(dout, dout_amax)
         with _timed(d, 2):
-            if _WGRAD_PENDING is not None and not (ASYNC_WGRAD and on_side_stream):
+            if _WGRAD.pending is not None and not (ASYNC_WGRAD and on_side_stream):
                 # the split-K slices now, their reduce with the block's other weight gradients (wgrad_flush)
                 call("fsc_conv_wgrad_partial", C.byref(d), ptr(x), ptr(dout), ptr(ws), ptr(xa), ptr(da), stream_ptr())
-                _WGRAD_PENDING.append((d, ws, dw))
+                _WGRAD.pending.append((d, ws, dw))
             else:
                 call("fsc_conv_wgrad", C.byref(d), ptr(x), ptr(dout), ptr(dw), ptr(ws), ptr(xa), ptr(da), stream_ptr())
         return dw
@@ -868,27 +870,30 @@ def conv_wgrad(x, dout, weight_shape, on_side_stream=False, x_amax=None, dout_am
 # Weight gradients nobody reads before the block's backward returns: between wgrad_begin() and wgrad_flush() conv_wgrad leaves
 # its split-K slices in their workspaces, and the flush reduces all of them in one launch (fsc_conv_wgrad_reduce_multi; the four
 # reduces of a block of the 1-d model were four launches of ~8 us).  The tensors conv_wgrad returned are complete after the flush.
-_WGRAD_PENDING = None
+# The pending list is per THREAD (autograd runs a backward on the thread that called it; two models training on two threads must
+# not mix their lists).
+class _WgradTLS(threading.local):
+    pending = None
+
+
+_WGRAD = _WgradTLS()
 
 
 def wgrad_begin():
-    global _WGRAD_PENDING
-    _WGRAD_PENDING = []
+    _WGRAD.pending = []
 
 
 def wgrad_abort():
-    global _WGRAD_PENDING
-    _WGRAD_PENDING = None
+    _WGRAD.pending = None
 
 
 def wgrad_flush(end=True):
     """Reduce what is pending (end: and stop deferring)."""
-    global _WGRAD_PENDING
-    pending = _WGRAD_PENDING
+    pending = _WGRAD.pending
     if end:
-        _WGRAD_PENDING = None
+        _WGRAD.pending = None
     elif pending is not None:
-        _WGRAD_PENDING = []
+        _WGRAD.pending = []
     if not pending:
         return
     count = len(pending)
@@ -904,11 +909,23 @@ def wgrad_flush(end=True):
 # BatchNorm workspaces.  With FSC_BN_TICKETS (include/fsc_hip.h) the reduce pass of a call also finalises and counts arrivals in
 # the workspace's ticket words, which must be zero when the call is enqueued and are zero again when it has run.  So workspaces
 # come from a pool of buffers that were zeroed ONCE, keyed by (device, stream, channels): calls on one stream are ordered, and a
-# buffer is handed out again only when nobody holds it any more (reference count) -- two calls that could overlap (different
-# streams: the side stream of the weight gradients, SyncBN's communication stream, a second model on its own stream) never share
-# one.  FSC_BN_NO_TICKETS=1 (read once, at import): plain torch.empty workspaces and the separate finalisation launches.
+# buffer is handed out again only when its previous holder has let go of it -- two calls that could overlap (different streams: the
+# side stream of the weight gradients, SyncBN's communication stream, a second model on its own stream) never share one.  A caller
+# gets a LEASE (a view of the pooled buffer); a finaliser on the lease puts the buffer back on the free list when the last reference
+# to the lease is gone (explicit check-out / return: no reliance on CPython's reference counts being readable).  The free lists are
+# capped; after a failed entry point (_lib.ON_ERROR) the pool is dropped, because an aborted call may have left ticket words non-zero.
+# FSC_BN_NO_TICKETS=1 (read once, at import): plain torch.empty workspaces and the separate finalisation launches.
 BN_TICKETS = 0 if os.environ.get("FSC_BN_NO_TICKETS") else 32          # FSC_BN_TICKETS
-_BN_WS_POOL = {}
+_BN_WS_POOL = {}           # (device, stream, channels) -> free list of zeroed buffers
+_BN_WS_GEN = [0]           # bumped by drop_bn_workspaces(): leases of an earlier generation do not come back
+_BN_WS_CAP = 16
+
+
+def _bn_ws_release(key, gen, base):
+    if gen == _BN_WS_GEN[0]:
+        free = _BN_WS_POOL.setdefault(key, [])
+        if len(free) < _BN_WS_CAP:
+            free.append(base)
 
 
 def _bn_ws(c, like):
@@ -916,20 +933,21 @@ def _bn_ws(c, like):
     if not BN_TICKETS:
         return torch.empty((nbytes + 7) // 8, device=like.device, dtype=torch.float64)
     key = (like.device.index, stream_ptr(), c)
-    pool = _BN_WS_POOL.get(key)
-    if pool is None:
-        pool = _BN_WS_POOL[key] = []
-    for ws in pool:
-        if sys.getrefcount(ws) == 3:                        # the pool's list, the loop variable, getrefcount's argument
-            return ws
-    ws = torch.zeros((nbytes + 7) // 8, device=like.device, dtype=torch.float64)
-    pool.append(ws)
-    return ws
+    free = _BN_WS_POOL.get(key)
+    base = free.pop() if free else torch.zeros((nbytes + 7) // 8, device=like.device, dtype=torch.float64)
+    lease = base.view(-1)                                    # what the caller holds (and may keep across both phases of a call)
+    weakref.finalize(lease, _bn_ws_release, key, _BN_WS_GEN[0], base)
+    return lease
 
 
 def drop_bn_workspaces():
-    """Forget the pooled BatchNorm workspaces (after a device error: their ticket words may be left non-zero)."""
+    """Forget the pooled BatchNorm workspaces (after a device error: their ticket words may be left non-zero).  Buffers that are
+    leased out at this moment are not taken back either."""
+    _BN_WS_GEN[0] += 1
     _BN_WS_POOL.clear()
+
+
+_lib.ON_ERROR.append(drop_bn_workspaces)
 
 
 class BNState:

@@ -44,7 +44,7 @@ def _checked_grad(p):
 
 
 class FusedAdam(Optimizer):
-    """torch.optim.Adam semantics (L2 weight decay, optional amsgrad) in one kernel per 24
+    """torch.optim.Adam semantics (L2 weight decay, optional amsgrad) in one kernel per 64
     tensors.  State keys match torch (step, exp_avg, exp_avg_sq, max_exp_avg_sq).
     `grad_scale` multiplies gradients first (1/world_size after a summing all-reduce)."""
 
@@ -268,9 +268,18 @@ class CapturedTrainingStep:
     def __call__(self, signal, labels):
         if torch.cuda.current_stream(self.signal.device) != self.stream:
             raise _lib.FscError("CapturedTrainingStep: replay on the stream the step was recorded on")
+        if tuple(signal.shape) != tuple(self.signal.shape) or tuple(labels.shape) != tuple(self.labels.shape):
+            raise _lib.FscError("CapturedTrainingStep: recorded for a batch of shape %s / %s, got %s / %s (copy_ would broadcast)"
+                                % (tuple(self.signal.shape), tuple(self.labels.shape), tuple(signal.shape), tuple(labels.shape)))
         self.signal.copy_(signal, non_blocking=True)
         self.labels.copy_(labels, non_blocking=True)
         self.step_count += 1
+        # the replay rewrites parameters and BatchNorm buffers through raw pointers (no torch version bump): the caches of an
+        # inference forward between replays (packed fragments, folded eval-mode BatchNorm) must not survive it
+        from .. import functional
+        functional.forget_packed_weights()
+        for st in self.opt.state.values():                # (a checkpoint saved mid-run resumes with the right bias correction)
+            st["step"] = self.step_count
         b1, b2 = self.group["betas"]
         _lib.load().fsc_adam_step_factors(float(self.group["lr"]), b1, b2, self.step_count, self._buf)
         # (by-value kernel arguments: no host buffer that a later call could overwrite before an earlier copy has run)

@@ -250,7 +250,8 @@ int fsc_bn_workspace_reset(void* workspace, int c, fsc_stream_t stream);
  *   1  reduce the local batch, write the local sums to `sync`, return (no outputs besides the parameter gradients: a backward
  *      call may pass dx = NULL -- also the way to get ONLY the parameter gradients when the input needs no gradient);
  *      the CALLER then sum-all-reduces `sync` over the replicas (RCCL; one small message per layer);
- *   2  finish from the reduced `sync` (statistics / input gradient use the global sums and count).
+ *   2  finish from the reduced `sync` (statistics / input gradient use the global sums and count).  Pass the SAME `workspace` as in
+ *      phase 1: the backward finalisation re-reads the replica's own partial sums from it (the closed-form per-channel sum of dx).
  * forward: [sum x, sum x^2, count] about zero; backward: [sum dz, sum dz*xhat, count].  dgamma / dbeta / dalpha are
  * always LOCAL sums (the gradient all-reduce adds the replicas). */
 #define FSC_BN_SYNC_DOUBLES(c) (4 * (size_t)(c))

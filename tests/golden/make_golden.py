@@ -140,6 +140,38 @@ def g1_frontend():
     save("g2_filterbanks.npz", **fbs)
 
 
+# ---------------------------------------------------------------------------------- G15
+def lcg_noise(n, seed):
+    """Deterministic noise in [-0.5, 0.5) from a 31-bit linear congruential generator in integer arithmetic: the tests rebuild the
+    waveform from (n, seed) instead of storing 1.7 MB of it (tests/test_oracle_cpu.py lcg_noise is the same function)."""
+    out = np.empty(n, dtype=np.float64)
+    state = np.uint64(seed)
+    a, c, mask = np.uint64(1103515245), np.uint64(12345), np.uint64((1 << 31) - 1)
+    for i in range(n):
+        state = (a * state + c) & mask
+        out[i] = float(state) / float(1 << 31) - 0.5
+    return out.astype(np.float32)
+
+
+G15_FRAMES = np.r_[0:4, 1000:1004, 1720:1728, 2340:2352, 3440:3446]
+
+
+def g15_frontend_10s():
+    """compute_torch_stft of the reference (ops/utils.py:110-127) with stft_256_128 on 10 s @ 44.1 kHz clips -- the cfg-3 front-end
+    shape: 441 000 samples -> 129 x 3446 frames.  Clip 1 has a zero tail from sample 300 000.  Stored: log(|stft| + 1e-4) at 34
+    frames and fp64 checksums of all frames."""
+    t = 441000
+    wav = np.stack([0.2 * lcg_noise(t, 15), 0.2 * lcg_noise(t, 16)])
+    wav[1, 300000:] = 0.0
+    mag = compute_torch_stft(torch.from_numpy(wav), "stft_256_128")
+    logmag = torch.log(mag + 1e-4)
+    assert tuple(logmag.shape) == (2, 129, 3446)
+    save("g15_frontend_10s.npz", seeds=np.array([15, 16]), t=np.int64(t), scale=np.float32(0.2), zero_from=np.int64(300000),
+         frames=G15_FRAMES.astype(np.int64), logmag=logmag[:, :, G15_FRAMES].numpy(),
+         sum=logmag.double().sum((1, 2)).numpy(), abs_sum=logmag.double().abs().sum((1, 2)).numpy(),
+         mag_sum=mag.double().sum((1, 2)).numpy())
+
+
 # ---------------------------------------------------------------------------------- G3/G9
 def _model_case(model, signal, labels, n_adam_steps, prefix, out, average=False):
     """state_dict, logits, per-sample LSEP, all param grads, BN stats after step 1, and the
@@ -584,3 +616,4 @@ if __name__ == "__main__":
     g12_cfg2_step()
     g13_input_pipeline()
     g14_rnn_head()
+    g15_frontend_10s()

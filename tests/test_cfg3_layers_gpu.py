@@ -1,0 +1,210 @@
+"""BASELINE.json configs[2] (1-d hierarchical model, reference networks/classifiers.py:107-217, 147-163, 42-50) layer by layer at
+the batch the benchmark runs: every convolution of the stated shape (10 blocks, 64 x 1.25^k channels, 3446 -> 3 frames) through
+forward / input gradient / weight gradient AT BATCH 128 -- the plans with 7 ... 32 pixel units per layer, one unit per workgroup,
+the deferred split-K reduce and the multi-tensor weight packing -- against PyTorch's fp64 convolution on the CPU, in bf16 (reference =
+fp64 on the bf16-ROUNDED operands: the arithmetic contract of arith 1) and in native fp32; plus whole-batch properties of the
+256-point front-end and the model (rows independent, zero tails = log 1e-4).  VERDICT r4 "weak" 1(a), 1(c).
+"""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+if not torch.cuda.is_available():
+    pytest.skip("needs an MI355X", allow_module_level=True)
+
+import torch.nn.functional as TF  # noqa: E402
+
+from freesound_classification_amd import functional as F  # noqa: E402
+from oracle import ref_torch as oref  # noqa: E402
+
+DEV = torch.device("cuda:0")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REPORT = os.path.join(ROOT, "gpurun_out", "cfg3_layer_parity.txt")
+
+
+def _report(line):
+    os.makedirs(os.path.dirname(REPORT), exist_ok=True)
+    with open(REPORT, "a") as f:
+        f.write(line + "\n")
+
+
+def cfg3_layers():
+    """(c_in, c_out, length, k) of the distinct convolutions of the stated cfg-3 model: per block the entry Conv1d(k = 3) at the
+    block's input length and the residual unit's Conv1d(k = 1) (conv1 == conv3) and Conv1d(k = 3) at half of it."""
+    out = []
+    length, c_in = 3446, 129
+    for depth in [int(1.25 ** k * 64) for k in range(10)]:
+        out.append((c_in, depth, length, 3))
+        length //= 2
+        out += [(depth, depth, length, 1), (depth, depth, length, 3)]
+        c_in = depth
+    return out
+
+
+LAYERS = cfg3_layers()
+N = 128
+
+
+def _bf16_round(t):
+    return t.to(torch.bfloat16).to(torch.float32)
+
+
+def _wgrad_plan(desc):
+    buf = C.create_string_buffer(512)
+    F.call("fsc_conv_plan_describe", C.byref(desc), 2, buf, 512)
+    return buf.value.decode()
+
+
+@pytest.mark.parametrize("arith", [1, 0], ids=["bf16", "f32"])
+@pytest.mark.parametrize("layer", LAYERS, ids=["%dto%d_L%d_k%d" % l for l in LAYERS])
+def test_cfg3_layer_at_batch_128_against_fp64(layer, arith):
+    c_in, c_out, length, k = layer
+    pad = k // 2
+    d = F._desc(N, c_in, c_out, 1, length, 1, k, arith)
+    plan = _wgrad_plan(d)
+    m = re.search(r"units=(\d+) split=(\d+)", plan)
+    assert m, plan
+    units, split = int(m.group(1)), int(m.group(2))
+    if "conv_wgrad_kernel" in plan and units < 64:
+        assert split == units, plan                     # the late blocks: one 64-pixel unit per workgroup (round 4)
+    gen = torch.Generator().manual_seed(c_in * 3 + c_out + length)
+    x = torch.randn(N, c_in, length, generator=gen)
+    wt = torch.randn(c_out, c_in, k, generator=gen) / (c_in * k) ** 0.5
+    b = torch.randn(c_out, generator=gen)
+    gy = torch.randn(N, c_out, length, generator=gen)
+    if arith == 1:                                      # the contract of arith 1: operands rounded once to bf16, exact products, fp32 sums
+        xr, wr, gr = _bf16_round(x), _bf16_round(wt), _bf16_round(gy)
+    else:
+        xr, wr, gr = x, wt, gy
+    y64 = TF.conv1d(xr.double(), wr.double(), b.double(), padding=pad)
+    dx64 = torch.nn.grad.conv1d_input(x.shape, wr.double(), gr.double(), padding=pad)
+    dw64 = torch.nn.grad.conv1d_weight(xr.double(), wt.shape, gr.double(), padding=pad)
+    # PyTorch's own fp32 convolution on the same (rounded) operands against fp64: the yard-stick
+    e_y = float((TF.conv1d(xr, wr, b, padding=pad).double() - y64).abs().max())
+    e_dx = float((torch.nn.grad.conv1d_input(x.shape, wr, gr, padding=pad).double() - dx64).abs().max())
+    e_dw = float((torch.nn.grad.conv1d_weight(xr, wt.shape, gr, padding=pad).double() - dw64).abs().max())
+    mode0 = F.get_conv_arith()
+    try:
+        F.set_conv_arith(arith)
+        xd, wd, bd, gd = x.to(DEV).unsqueeze(2), wt.to(DEV).unsqueeze(2), b.to(DEV), gy.to(DEV).unsqueeze(2)
+        y = F.conv_forward(xd, wd, bd).squeeze(2).cpu()
+        dx = F.conv_dgrad(gd, wd, xd.shape).squeeze(2).cpu()
+        dw = F.conv_wgrad(xd, gd, wd.shape).squeeze(2).cpu()
+        # the deferred form the training step uses: slices now, one multi-reduce for the block's gradients later
+        F.wgrad_begin()
+        dw_def = F.conv_wgrad(xd, gd, wd.shape)
+        F.wgrad_flush()
+        dw_def = dw_def.squeeze(2).cpu()
+    finally:
+        F.set_conv_arith(mode0)
+    g_y = float((y.double() - y64).abs().max())
+    g_dx = float((dx.double() - dx64).abs().max())
+    g_dw = float((dw.double() - dw64).abs().max())
+    _report("%-20s arith %d n %d  fwd %.2e (torch f32 %.2e) | dgrad %.2e (%.2e) | wgrad %.2e (%.2e) | %s"
+            % ("%dto%d_L%d_k%d" % layer, arith, N, g_y, e_y, g_dx, e_dx, g_dw, e_dw, plan.split(" lds")[0]))
+    assert torch.equal(dw_def, dw)
+    eps = 2.0 ** -23
+
+    def bound(e32, k_terms, ref):                       # tests/test_cfg2_gpu.py: 5x PyTorch's fp32 error, or one serial fp32 chain
+        return max(5.0 * e32, 2.0 * eps * (k_terms / 4.0) ** 0.5 * float(ref.abs().max())) + 1e-7
+
+    assert g_y < bound(e_y, c_in * k, y64), (g_y, e_y)
+    assert g_dx < bound(e_dx, c_out * k, dx64), (g_dx, e_dx)
+    assert g_dw < bound(e_dw, N * length, dw64), (g_dw, e_dw)
+
+
+def test_multi_tensor_pack_of_the_cfg3_weights_equals_the_single_calls():
+    """fsc_conv_pack_weights_multi (arith 1: what a cfg-3 training step uses from its second step on) on the weights of the last four
+    blocks at batch 128, forward and input-gradient fragments: bit for bit what fsc_conv_pack_weights writes."""
+    lib = F._lib.load()
+    jobs = [(l, dg) for l in LAYERS[-12:] for dg in (0, 1)]
+    count = len(jobs)
+    descs = (F.ConvDesc * count)()
+    wp, pp, dgs = (C.c_void_p * count)(), (C.c_void_p * count)(), (C.c_int * count)()
+    keep, single = [], []
+    gen = torch.Generator(device=DEV).manual_seed(11)
+    for i, ((c_in, c_out, length, k), dg) in enumerate(jobs):
+        d = F._desc(N, c_in, c_out, 1, length, 1, k, 1)
+        assert lib.fsc_conv_pack_weights_multi_supported(C.byref(d), dg), (c_in, c_out, length, k, dg)
+        w = torch.randn(c_out, c_in, 1, k, device=DEV, generator=gen)
+        nfl = lib.fsc_conv_packed_floats(C.byref(d), dg)
+        one = torch.zeros(nfl, device=DEV)
+        F.call("fsc_conv_pack_weights", C.byref(d), F.ptr(w), dg, F.ptr(one), F.stream_ptr())
+        many = torch.full((nfl,), float("nan"), device=DEV)
+        descs[i] = d
+        wp[i], pp[i], dgs[i] = F.ptr(w), F.ptr(many), dg
+        keep.append((w, many))
+        single.append(one)
+    F.call("fsc_conv_pack_weights_multi", count, descs, wp, dgs, pp, F.stream_ptr())
+    torch.cuda.synchronize()
+    for (w, many), one in zip(keep, single):
+        assert torch.equal(many.view(torch.int32), one.view(torch.int32))
+
+
+def test_frontend_256_on_ten_second_clips_against_the_reference_golden_and_the_cpu_oracle(golden):
+    """fsc_frontend_stft_fwd with n_fft 256 / hop 128 (the eight-frames-per-wave kernel) on 441 000-sample clips: against G15 (what
+    the imported reference produced: 34 frames + checksums of all 3446) and, on a different batch, against the CPU oracle's
+    torch.stft restatement (reference ops/utils.py:110-127 + classifiers.py:184-185).  Log-magnitudes within 1e-3 wherever the
+    magnitude is above 1e-3 (at near-silent bins the log amplifies the fp32 rounding of a cancelling sum: bounded in the LINEAR
+    domain there), zero tails exactly log(1e-4)."""
+    from test_oracle_cpu import g15_waveforms
+    g = golden("g15_frontend_10s.npz")
+    wav = g15_waveforms(g)
+    got = F.frontend_stft(wav.to(DEV), 256, 128, True).cpu()
+    assert tuple(got.shape) == (2, 129, 3446)
+    want = torch.from_numpy(g["logmag"]).double()
+    sub = got[:, :, torch.from_numpy(g["frames"])].double()
+    loud = want.exp() - 1e-4 > 1e-3
+    assert float((sub - want).abs()[loud].max()) < 1e-3
+    assert float((sub.exp() - want.exp()).abs().max()) < 2e-5
+    np.testing.assert_allclose(got.double().sum((1, 2)).numpy(), g["sum"], rtol=2e-6)
+    np.testing.assert_allclose((got.double().exp() - 1e-4).sum((1, 2)).numpy(), g["mag_sum"], rtol=2e-6)
+    assert float((got[1, :, 2350:] - float(np.log(1e-4))).abs().max()) < 1e-6
+    # the CPU oracle on seeded noise of several loudness levels
+    gen = torch.Generator().manual_seed(4)
+    sig = 0.1 * torch.randn(4, 441000, 1, generator=gen)
+    sig[1, 300000:] = 0.0
+    sig[3] *= 1e-3
+    want = oref.features_from_signal(sig, "stft_256_128", None).double()
+    got = F.frontend_stft(sig.squeeze(-1).to(DEV), 256, 128, True).cpu().double()
+    assert got.shape == want.shape
+    loud = want.exp() - 1e-4 > 1e-3
+    assert float((got - want).abs()[loud].max()) < 1e-3
+    assert float((got.exp() - want.exp()).abs().max()) < 2e-5
+    assert float((got[1, :, 2350:] - float(np.log(1e-4))).abs().max()) < 1e-6
+
+
+def test_cfg3_batch_128_properties():
+    """The stated cfg-3 model at batch 128 (the bench's batch, bf16): finite outputs, rows independent of their batch neighbours in
+    eval mode (running statistics), zero-tail frames of the front-end equal log 1e-4."""
+    from freesound_classification_amd.networks.classifiers import HierarchicalCNNClassificationModel
+    from test_parity_r3_gpu import cfg3_experiment
+    torch.manual_seed(5)
+    mode0 = F.get_conv_arith()
+    F.set_conv_arith("bf16")
+    try:
+        m = HierarchicalCNNClassificationModel(cfg3_experiment(), device="cuda:0")
+        gen = torch.Generator(device=DEV).manual_seed(8)
+        sig = 0.1 * torch.randn(N, 441000, 1, device=DEV, generator=gen)
+        m.train()
+        out = m(sig)["class_logits"]
+        assert out.shape == (N, 80) and bool(torch.isfinite(out).all())
+        m.eval()
+        with torch.no_grad():
+            full = m(sig)["class_logits"]
+            perm = torch.randperm(N, device=DEV, generator=gen)
+            shuffled = m(sig[perm])["class_logits"]
+            part = m(sig[:16])["class_logits"]
+        assert bool(torch.isfinite(full).all())
+        # bf16 operands, but every row sees the same arithmetic wherever it sits: the batch-128 plans pack several rows per box
+        assert float((shuffled - full[perm]).abs().max()) < 1e-4
+        # a 16-row batch takes different tilings (split-K, units per workgroup): same values up to fp32 summation order
+        assert float((part - full[:16]).abs().max()) < 2e-3
+    finally:
+        F.set_conv_arith(mode0)

@@ -51,6 +51,51 @@ def test_frontend(golden, desc):
     assert abs(float(out[-1, :, -2].max()) - np.log(1e-4)) < 1e-5
 
 
+def lcg_noise(n, seed):
+    """tests/golden/make_golden.py lcg_noise, vectorised: state_i = a^i s + c (a^i - 1) / (a - 1) mod 2^31 by repeated doubling."""
+    mask = (1 << 31) - 1
+    a, c = 1103515245, 12345
+    out = np.empty(n, dtype=np.int64)
+    out[0] = (a * seed + c) & mask
+    # affine maps x -> (A x + C) mod 2^31 compose; build the block [1 .. n) by doubling the filled prefix
+    filled, A, Cc = 1, a, c                     # (A, Cc) = the map that advances by `filled` steps
+    while filled < n:
+        m = min(filled, n - filled)
+        out[filled:filled + m] = (A * out[:m] + Cc) & mask
+        A, Cc = (A * A) & mask, (A * Cc + Cc) & mask
+        filled += m
+    return (out.astype(np.float64) / float(1 << 31) - 0.5).astype(np.float32)
+
+
+def g15_waveforms(g):
+    t = int(g["t"])
+    wav = np.stack([float(g["scale"]) * lcg_noise(t, int(s)) for s in g["seeds"]])
+    wav[1, int(g["zero_from"]):] = 0.0
+    return torch.from_numpy(wav)
+
+
+def test_lcg_noise_matches_the_generating_loop():
+    a, c, mask = 1103515245, 12345, (1 << 31) - 1
+    state, ref = 15, []
+    for _ in range(1000):
+        state = (a * state + c) & mask
+        ref.append(state / float(1 << 31) - 0.5)
+    np.testing.assert_array_equal(lcg_noise(1000, 15), np.array(ref, dtype=np.float32))
+
+
+def test_frontend_on_ten_second_clips(golden):
+    """G15: the reference's compute_torch_stft with stft_256_128 on 441 000-sample clips (the cfg-3 front-end shape, 3446 frames)
+    -- 34 stored frames and checksums of all of them."""
+    g = golden("g15_frontend_10s.npz")
+    wav = g15_waveforms(g)
+    out = oref.features_from_signal(wav[..., None], "stft_256_128")
+    assert tuple(out.shape) == (2, 129, 3446)
+    np.testing.assert_allclose(out[:, :, g["frames"]].numpy(), g["logmag"], atol=2e-5, rtol=0)
+    np.testing.assert_allclose(out.double().sum((1, 2)).numpy(), g["sum"], rtol=1e-6)
+    np.testing.assert_allclose(out.double().abs().sum((1, 2)).numpy(), g["abs_sum"], rtol=1e-6)
+    assert float((out[1, :, 2350:] - float(np.log(1e-4))).abs().max()) < 1e-6
+
+
 def _tiny2d():
     return oref.TagCNN2d("mel_1024_512_64", 2, 8, 1.5, 1, 80)
 

@@ -11,13 +11,15 @@ from freesound_classification_amd import functional as F  # noqa: E402
 from tools.conv_bench import SHAPES  # noqa: E402
 
 lib = F._lib.load()
-prof = lib.fsc_debug_l3_prof
-prof.argtypes = [C.c_void_p]
+HAVE_FWD = hasattr(lib, "fsc_debug_l3_prof")
+if HAVE_FWD:
+    prof = lib.fsc_debug_l3_prof
+    prof.argtypes = [C.c_void_p]
 buf = (C.c_ulonglong * 64)()
 F.set_conv_arith("bf16x9")
 dev = torch.device("cuda")
 names = sys.argv[1:] or ["b0c2", "b1e", "b1c2", "b2c2", "b3c2", "b0c1"]
-for name in names:
+for name in (names if HAVE_FWD else []):
     n, cin, cout, h, w, k = SHAPES[name]
     torch.manual_seed(1)
     x = torch.randn(n, cin, h, w, device=dev)
@@ -48,3 +50,38 @@ for name in names:
         print("   wave %d: kernel %.0f kcyc | per step: hand-over %.0f, MFMA steps %.0f | epilogue %.1f%%, first fragments %.1f%% of kernel, "
               "steps %.0f, accounted %.1f%%" % (wv, a[5] / 1e3, a[0] / steps, a[1] / steps, 100 * a[2] / a[5], 100 * a[3] / a[5], steps,
                                                100 * (a[0] + a[1] + a[2] + a[3]) / a[5]))
+
+
+# ---- weight gradient on three limbs (the same library build instruments conv_l16_wgrad_kernel)
+if hasattr(lib, "fsc_debug_l16w_prof"):
+    wprof = lib.fsc_debug_l16w_prof
+    wprof.argtypes = [C.c_void_p]
+    for name in names:
+        n, cin, cout, h, w, k = SHAPES[name]
+        d = F._desc(n, cin, cout, h, w, k, k, 9)
+        if not F.conv_l16_wgrad_supported(d):
+            continue
+        torch.manual_seed(1)
+        x = torch.randn(n, cin, h, w, device=dev)
+        gy = torch.randn(n, cout, h, w, device=dev)
+        x16, g16 = F.l16_pack(x), F.l16_pack(gy)
+        del x, gy
+        for _ in range(2):
+            F.conv_l16_wgrad(x16, g16, (cout, cin, k, k))
+        wprof(buf)
+        iters = 5
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            F.conv_l16_wgrad(x16, g16, (cout, cin, k, k))
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / iters
+        wprof(buf)
+        fl = 2.0 * n * h * w * cin * cout * k * k
+        print("%s wgrad %s: %.3f ms %.1f TF fp32-eq" % (name, F.l16_wgrad_plan_name(d), ms, fl / ms / 1e9))
+        for wv in range(8):
+            a = [buf[wv * 8 + i] / iters for i in range(5)]
+            units = max(a[3], 1)
+            print("   wave %d: kernel %.0f kcyc | per unit: wait + barrier %.0f, copy issue %.0f, MFMA k-steps %.0f | units %.0f, accounted %.1f%%"
+                  % (wv, a[4] / 1e3, a[0] / units, a[1] / units, a[2] / units, units, 100 * (a[0] + a[1] + a[2]) / max(a[4], 1)))
