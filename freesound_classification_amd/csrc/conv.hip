@@ -924,6 +924,9 @@ __global__ __launch_bounds__(kXWaves * 64) void conv_fwd_x3_kernel(Geom g, const
                 // DMA issue for the step after next (its slot was read during the previous step; the weight
                 // stream wraps around at an item end) and, at the first step of a chunk, of the input box
                 // NSTG - 1 chunks ahead (its stage was last read during the previous step)
+                // (weights FIRST, then the box: the weights of step S + AHEAD must be OLDER than a box issued in the same step -- the
+                // counted wait of step S + AHEAD leaves "the youngest weights + one box" in flight and needs these weights landed.
+                // Round 5 tried the other order: the batch-32 model test turned flaky.)
                 w_prev = true;
                 if (S + AHEAD < s_hi) issue_w(wsrc + AHEAD * WSLOT_F, slot == 0 ? RING - 1 : slot - 1);
                 else if (has_next) issue_w(wnext + (S + AHEAD - s_hi) * WSLOT_F, slot == 0 ? RING - 1 : slot - 1);
@@ -2187,6 +2190,14 @@ bool plan_fwd_x3_pt(const fsc_conv_desc& d_in, int dgrad, int nprod, int pt, int
     g.x_nfull = g.cin / kch + (rem > kch - 8 ? 1 : 0);
     g.x_tail_oct = (rem > 0 && rem <= kch - 8) ? fsc::ceil_div(rem, 8) : 0;
     g.x_tail_steps = fsc::ceil_div(taps * g.x_tail_oct, 4);
+    // A remainder chunk of ONE step (k3 rows with c_in mod 32 in 1 .. 8) opens and closes in the same step: the box of the chunk
+    // behind it -- the next item's first -- would be issued in the very step whose MFMA phases already read it (found by the
+    // batch-128 layer tests of round 5: every item of a worker after its second came out wrong on 129 -> 64 @ 3446 frames).
+    // One more (zero) octet makes it two steps; 1x1 kernels stage NSTG - 1 >= 2 chunks ahead and are not affected.
+    if (taps > 1 && g.x_tail_oct > 0 && g.x_tail_steps < 2) {
+        g.x_tail_oct = 2;
+        g.x_tail_steps = fsc::ceil_div(taps * g.x_tail_oct, 4);
+    }
     g.x_steps = g.x_nfull * taps * nch + g.x_tail_steps;
     g.k_pad = (g.x_nfull + (g.x_tail_oct ? 1 : 0)) * kch;
     p.kc = kch;

@@ -78,17 +78,23 @@ def test_cfg3_layer_at_batch_128_against_fp64(layer, arith):
     wt = torch.randn(c_out, c_in, k, generator=gen) / (c_in * k) ** 0.5
     b = torch.randn(c_out, generator=gen)
     gy = torch.randn(N, c_out, length, generator=gen)
-    if arith == 1:                                      # the contract of arith 1: operands rounded once to bf16, exact products, fp32 sums
-        xr, wr, gr = _bf16_round(x), _bf16_round(wt), _bf16_round(gy)
-    else:
-        xr, wr, gr = x, wt, gy
-    y64 = TF.conv1d(xr.double(), wr.double(), b.double(), padding=pad)
-    dx64 = torch.nn.grad.conv1d_input(x.shape, wr.double(), gr.double(), padding=pad)
-    dw64 = torch.nn.grad.conv1d_weight(xr.double(), wt.shape, gr.double(), padding=pad)
-    # PyTorch's own fp32 convolution on the same (rounded) operands against fp64: the yard-stick
-    e_y = float((TF.conv1d(xr, wr, b, padding=pad).double() - y64).abs().max())
-    e_dx = float((torch.nn.grad.conv1d_input(x.shape, wr, gr, padding=pad).double() - dx64).abs().max())
-    e_dw = float((torch.nn.grad.conv1d_weight(xr, wt.shape, gr, padding=pad).double() - dw64).abs().max())
+    def refs(xr, wr, gr):
+        y64 = TF.conv1d(xr.double(), wr.double(), b.double(), padding=pad)
+        dx64 = torch.nn.grad.conv1d_input(x.shape, wr.double(), gr.double(), padding=pad)
+        dw64 = torch.nn.grad.conv1d_weight(xr.double(), wt.shape, gr.double(), padding=pad)
+        # PyTorch's own fp32 convolution on the same operands against fp64: the yard-stick
+        e_y = float((TF.conv1d(xr, wr, b, padding=pad).double() - y64).abs().max())
+        e_dx = float((torch.nn.grad.conv1d_input(x.shape, wr, gr, padding=pad).double() - dx64).abs().max())
+        e_dw = float((torch.nn.grad.conv1d_weight(xr, wt.shape, gr, padding=pad).double() - dw64).abs().max())
+        return (y64, dx64, dw64), (e_y, e_dx, e_dw)
+
+    # The contract of arith 1: operands rounded ONCE to bf16, exact products, fp32 sums -- fp64 on the rounded operands is what the
+    # bf16 matrix-core kernels must reproduce to fp32 accuracy.  A direction the library runs on its native fp32 kernels instead
+    # (1x1 and late-block weight gradients) keeps the operands unrounded and must reproduce fp64 on the ORIGINAL operands: each
+    # direction has to meet ONE of the two references at fp32 accuracy -- never merely "bf16-close" to either.
+    (y64, dx64, dw64), (e_y, e_dx, e_dw) = refs(x, wt, gy)
+    if arith == 1:
+        (y64r, dx64r, dw64r), (e_yr, e_dxr, e_dwr) = refs(_bf16_round(x), _bf16_round(wt), _bf16_round(gy))
     mode0 = F.get_conv_arith()
     try:
         F.set_conv_arith(arith)
@@ -103,6 +109,13 @@ def test_cfg3_layer_at_batch_128_against_fp64(layer, arith):
         dw_def = dw_def.squeeze(2).cpu()
     finally:
         F.set_conv_arith(mode0)
+    if arith == 1:                                      # per direction: the reference (rounded / original operands) it is closer to
+        if float((y.double() - y64r).abs().max()) < float((y.double() - y64).abs().max()):
+            y64, e_y = y64r, e_yr
+        if float((dx.double() - dx64r).abs().max()) < float((dx.double() - dx64).abs().max()):
+            dx64, e_dx = dx64r, e_dxr
+        if float((dw.double() - dw64r).abs().max()) < float((dw.double() - dw64).abs().max()):
+            dw64, e_dw = dw64r, e_dwr
     g_y = float((y.double() - y64).abs().max())
     g_dx = float((dx.double() - dx64).abs().max())
     g_dw = float((dw.double() - dw64).abs().max())
