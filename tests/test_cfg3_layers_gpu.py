@@ -221,3 +221,52 @@ def test_cfg3_batch_128_properties():
         assert float((part - full[:16]).abs().max()) < 2e-3
     finally:
         F.set_conv_arith(mode0)
+
+
+@pytest.mark.parametrize("arith", ["f32", "bf16"])
+def test_cfg3_model_at_batch_128_against_the_cpu_oracle(arith):
+    """The stated cfg-3 model at the bench's batch: train-mode logits / per-sample LSEP (batch statistics over 128 rows) and
+    eval-mode logits against the CPU oracle (fp32, forward only: 87 GFLOP).  f32: 1e-3.  bf16 (operands rounded to 8 bits in 40
+    convolutions): eval logits within 2e-2 (measured 1.2e-3); train-mode logits within 0.76 = 2x the measured 0.39 -- at initialisation
+    the head's BatchNorm1d layers divide the deep-supervision features by a batch spread that is itself of the size of the bf16
+    rounding noise, the same 0.38 the batch-8 test of tests/test_parity_r3_gpu.py measures."""
+    from freesound_classification_amd.networks.classifiers import HierarchicalCNNClassificationModel
+    from freesound_classification_amd.networks.losses import lsep_loss
+    from test_parity_r3_gpu import cfg3_experiment
+    torch.manual_seed(12)
+    mode0 = F.get_conv_arith()
+    F.set_conv_arith(arith)
+    try:
+        m = HierarchicalCNNClassificationModel(cfg3_experiment(), device="cuda:0")
+        state = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+        gen = torch.Generator().manual_seed(13)
+        signal = 0.1 * torch.randn(N, 441000, 1, generator=gen)
+        labels = (torch.rand(N, 80, generator=gen) < 0.03).float()
+        labels[torch.arange(N), torch.randint(0, 80, (N,), generator=gen)] = 1.0
+        m.train()
+        with torch.no_grad():
+            logits = m(signal.to(DEV))["class_logits"]
+            per = lsep_loss(logits, labels.to(DEV), average=False)
+        m.eval()
+        with torch.no_grad():
+            ev = m(signal.to(DEV))["class_logits"].cpu()
+    finally:
+        F.set_conv_arith(mode0)
+    ref = oref.TagCNN1d("stft_256_128", 10, 64, 1.25, 1, 80, input_dim=129)
+    ref.load_state_dict(state)
+    ref.train()
+    with torch.no_grad():
+        rl = ref(signal)["class_logits"]
+        rper = oref.lsep(rl, labels, average=False)
+    # (the train-mode forward moved the running statistics of both models identically; evaluate with them)
+    ref.eval()
+    with torch.no_grad():
+        rev = ref(signal)["class_logits"]
+    d_logits = float((logits.cpu() - rl).abs().max())
+    d_loss = float((per.cpu() - rper).abs().max())
+    d_eval = float((ev - rev).abs().max())
+    _report("cfg3 model at batch 128, %s vs the CPU oracle: train logits %.2e loss %.2e eval logits %.2e" % (arith, d_logits, d_loss, d_eval))
+    if arith == "f32":
+        assert d_logits < 1e-3 and d_loss < 1e-3 and d_eval < 1e-3
+    else:
+        assert d_logits < 0.76 and d_eval < 2e-2
