@@ -178,6 +178,75 @@ ARITH_LABEL = {0: "f32", 1: "bf16", 3: "f16x3", 6: "bf16x6", 9: "bf16x9"}
 ARITH_BITS = {0: 24, 1: 8, 3: 22, 6: 23, 9: 24}
 
 
+def rocprof_name_to_timer_name(n):
+    """Kernel name as rocprofv3 prints it -> the name the KernelTimer uses (fsc_conv_*_plan_describe), or None."""
+    import re
+    m = re.search(r"(conv_\w+)<([^>]*)>", n)
+    if not m:
+        return None
+    base, a = m.group(1), [x.strip() for x in m.group(2).split(",")]
+    if base == "conv_l3_fwd_kernel":                    # <KH, KW, CT, PTW, NPROD, POOL, STATS>
+        return "conv_l3_fwd_kernel<%s>" % ",".join(a[:5] + (["pool"] if a[5:6] == ["true"] else []))
+    if base == "conv_l16_wgrad_kernel":                 # <KH, KW, MT, CT[, NL, NPROD]>
+        if len(a) >= 6 and a[4] == "3":
+            return "conv_l3_wgrad_kernel<%s>" % ",".join(a[:4] + [a[5]])
+        return "conv_l16_wgrad_kernel<%s>" % ",".join(a[:4])
+    if base == "conv_l16_fwd_kernel":                   # <KH, KW, COT, PT, POOL, STATS>
+        return "conv_l16_fwd_kernel<%s>" % ",".join(a[:4] + (["pool"] if a[4:5] == ["true"] else []))
+    if base == "conv_fwd_kernel":
+        return "conv_fwd_kernel<%s>" % ",".join(a[:4])
+    if base == "conv_wgrad_kernel":
+        return "conv_wgrad_kernel<%s>" % ",".join(a[:3] + (["packed"] if a[3:4] == ["true"] else []))
+    return "%s<%s>" % (base, ",".join(a))
+
+
+def measure_traffic(kernel, extra_args, timeout=150):
+    """HBM bytes per launch of `kernel` (a KernelTimer name) in this very workload, from rocprofv3 PMC counters: two separate passes
+    (FETCH_SIZE, WRITE_SIZE: they do not fit one pass) with --kernel-trace only over a 2-step run of this script in a child
+    process, averaged over all launches of the kernel -- as /opt/skills/guides/MI355X_MICROARCH.md prescribes: FETCH_SIZE counts
+    64 B per 128-B request of wide streaming reads on gfx950 (x 2; calibrated on fsc_axpy: 1 048 579 KiB reported for a 2 GiB read),
+    WRITE_SIZE x 1, both in KiB.  Returns (bytes or None, note)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, "rocprofv3 not found"
+    total, launches = 0.0, 0
+    tmp = tempfile.mkdtemp(prefix="fsc_traffic_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    try:
+        for counter, mult in (("FETCH_SIZE", 2.0), ("WRITE_SIZE", 1.0)):
+            out = os.path.join(tmp, counter)
+            cmd = [exe, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", out, "-o", "p", "--", sys.executable,
+                   os.path.abspath(__file__), "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-kernel-timer", "--no-alt",
+                   "--no-other"] + list(extra_args)
+            r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout, cwd="/tmp", env=env)
+            files = glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True)
+            if r.returncode != 0 or not files:
+                return None, "rocprofv3 --pmc %s failed (rc %d)" % (counter, r.returncode)
+            s, c = 0.0, 0
+            for f in files:
+                with open(f) as fh:
+                    for row in csv.DictReader(fh):
+                        if row.get("Counter_Name") == counter and rocprof_name_to_timer_name(row["Kernel_Name"]) == kernel:
+                            s += float(row["Counter_Value"]) * 1024.0 * mult
+                            c += 1
+            if c == 0:
+                return None, "kernel %s not in the %s pass" % (kernel, counter)
+            total += s / c
+            launches = c
+    except Exception as e:                                   # a failed side measurement must not take the line down
+        return None, repr(e)[:200]
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    return total, ("rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (two passes) over `bench.py --steps 2 --warmup 1` of this "
+                   "workload in a child process, mean of %d launches; FETCH_SIZE x 2 (gfx950 counts 64 B per 128-B request), WRITE_SIZE x 1"
+                   % launches)
+
+
 def roofline_of(summ, steps):
     """`roofline` of a KernelTimer summary: the conv kernel with the largest total time, its algorithmic FLOPs over its HIP-event
     time x the MFMA flops it executes per algorithmic flop, against the dense peak of the pipe it runs on."""
@@ -188,11 +257,7 @@ def roofline_of(summ, steps):
         f["ms"] += r["ms"]
     dom_name, dom = max(summ.items(), key=lambda kv: kv[1]["ms"])
     achieved = dom["flops"] / dom["ms"] / 1e9          # TFLOP/s
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "roofline_traffic.json")
-    if os.path.exists(tpath):
-        with open(tpath) as f:
-            traffic = json.load(f).get(dom_name)
+    traffic = None                                     # (measured by rocprofv3 PMC passes of this very run: measure_traffic)
     peak, executed_per_flop, arith = price_kernel(dom_name)
     return {
         "kernel": dom_name, "bound": "mfma", "achieved": achieved * executed_per_flop, "peak": peak,
@@ -470,6 +535,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-alt", action="store_true", help="skip the extra native-fp32-MFMA measurement (alt_f32)")
     ap.add_argument("--no-kernel-timer", action="store_true")
+    ap.add_argument("--no-traffic", action="store_true", help="skip the rocprofv3 PMC passes behind roofline.traffic (two child runs, ~1 min)")
     ap.add_argument("--no-kernel-timer-in-value", action="store_true",
                     help="time `value` without the per-kernel HIP events and take the per-kernel times behind `roofline` from a few extra "
                          "steps after it (launch-bound workloads: cfg 3 issues ~700 kernels per step, an event pair around each makes "
@@ -816,6 +882,17 @@ def main():
             result["roofline"] = roofline_of(summ, timer_steps)
             peak, executed_per_flop, arith = price_kernel(dom_name)
             achieved = result["roofline"]["algorithmic_fp32_tflops"]
+            if world == 1 and not args.no_alt and not args.no_traffic:
+                tb, note = measure_traffic(dom_name, ["--workload", args.workload, "--arith", ARITH_LABEL[F.get_conv_arith()]]
+                                           + (["--batch", str(args.batch)] if args.batch else []))
+                result["roofline"]["traffic"] = tb
+                result["roofline"]["traffic_source"] = note
+            if dom_name in timer.bytes and timer.bytes[dom_name][1]:
+                # algorithmic bytes of the same launches: both operands once + the result (three-limb operands 6 B, fp32 4 B per element)
+                ab = timer.bytes[dom_name][0] / timer.bytes[dom_name][1]
+                result["roofline"]["algorithmic_bytes_per_launch"] = ab
+                if result["roofline"].get("traffic"):
+                    result["roofline"]["traffic_over_algorithmic"] = result["roofline"]["traffic"] / ab
             if stages:
                 result["roofline"]["stages"] = stages
             # The clock the chip actually sustains under the dominant kernel (its largest layer re-run back to back, outside the

@@ -1044,8 +1044,10 @@ int stats_layout(const fsc_conv_desc* d, int pool, int* out4) {
 int plan_describe(const fsc_conv_desc* d, int dgrad, char* buf, size_t buf_len) {
     L3Plan p;
     FSC_CHECK_ARG(valid3(d) && buf && buf_len > 0 && plan_l3(*d, dgrad, &p), "fsc_conv_l16_plan_describe: unsupported shape");
-    snprintf(buf, buf_len, "conv_l3_fwd_kernel<%d,%d,%d,%d,%d> box=%dx%dx%d items=%ldx%d workers=%ld steps=%d lds=%zu wave=%dx%d", d->kh,
-             d->kw, p.g.cot, p.ptw, p.nprod, p.g.nb, p.g.th, p.g.tw, p.tiles, p.co_blocks, p.workers, p.g.steps, p.lds_bytes, p.ct, p.ptw);
+    // (the name is the kernel instantiation: <KH, KW, channel tiles per WAVE, pixel tiles per wave, limb products>; `cot` = channel
+    // tiles per block, halved between the two wave groups)
+    snprintf(buf, buf_len, "conv_l3_fwd_kernel<%d,%d,%d,%d,%d> cot=%d box=%dx%dx%d items=%ldx%d workers=%ld steps=%d lds=%zu", d->kh,
+             d->kw, p.ct, p.ptw, p.nprod, p.g.cot, p.g.nb, p.g.th, p.g.tw, p.tiles, p.co_blocks, p.workers, p.g.steps, p.lds_bytes);
     return 0;
 }
 

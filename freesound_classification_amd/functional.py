@@ -125,9 +125,25 @@ class KernelTimer:
         self.records = []      # (kernel name, algorithmic flops, start event, end event)
         self.shapes = {}       # kernel name -> (flops, (n, c_in, c_out, h, w, kh, kw), "fwd" | "dgrad" | "wgrad") of its largest call
 
+        self.bytes = {}        # kernel name -> [algorithmic HBM bytes of its noted calls, noted calls]
+
     def note(self, name, flops, shape, kind):
         if name not in self.shapes or flops > self.shapes[name][0]:
             self.shapes[name] = (flops, tuple(shape), kind)
+        # algorithmic bytes of the call: each operand read once, the result written once (three-limb operands 6 B, others 4 B
+        # per element; the fused max-pool writes a quarter of the plane plus one index byte)
+        n, c_in, c_out, h, w, kh, kw = shape
+        b_in = 6.0 if "conv_l3_" in name else 4.0
+        px = float(n) * h * w
+        if kind == "wgrad":
+            nb = px * (c_in + c_out) * b_in + 4.0 * c_out * c_in * kh * kw
+        elif kind == "dgrad":
+            nb = px * c_out * b_in + px * c_in * 4.0
+        else:
+            nb = px * c_in * b_in + (px / 4.0 * c_out * 5.0 if "pool" in name else px * c_out * 4.0)
+        acc = self.bytes.setdefault(name, [0.0, 0])
+        acc[0] += nb
+        acc[1] += 1
 
     def summary(self):
         """name -> dict(launches, flops, ms); call after a device synchronise."""
@@ -466,6 +482,8 @@ def _l16_plan_sig(d):
         call("fsc_conv_l16_plan_describe", C.byref(d), 0, buf, 256)
         txt = buf.value.decode()                     # conv_l16_fwd_kernel<kh,kw,cot,pt> box=... items=TILESxBLOCKS ...
         cot = int(txt.split("<")[1].split(">")[0].split(",")[2])
+        if " cot=" in txt:                           # conv_l3_fwd_kernel<kh,kw,ct,ptw,nprod> cot=... : tiles per block spelled out
+            cot = int(txt.split(" cot=")[1].split(" ")[0])
         blocks = int(txt.split("items=")[1].split(" ")[0].split("x")[1])
         _PLAN_SIG[key] = (cot, blocks)
     return _PLAN_SIG[key]
@@ -683,6 +701,7 @@ def conv_l16_pool(t, weight, bias, prepacked=None, stats_bn=None):
     if TIMER is not None:
         e1.record()
         TIMER.records.append((l16_plan_name(d, 0).replace(">", ",pool>"), 2.0 * n * h * w * c_in * c_out * kh * kw, e0, e1))
+        TIMER.note(l16_plan_name(d, 0).replace(">", ",pool>"), 2.0 * n * h * w * c_in * c_out * kh * kw, (n, c_in, c_out, h, w, kh, kw), "fwd")
     if lay is not None:
         _stats_end(lay, rec, y, c_out)
     return y, idx, (n, c_out, h, w)

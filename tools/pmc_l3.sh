@@ -21,7 +21,7 @@ cnt = collections.defaultdict(int)
 for f in glob.glob("$R/gpurun_out/$tag/p*/*counter_collection.csv"):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"][:70]
-        if "conv_l3_fwd" not in k and "conv_fwd_x3" not in k and "wgrad" not in k: continue
+        if "conv_l3_fwd" not in k and "conv_fwd_x3" not in k and "wgrad_kernel" not in k: continue
         agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
         cnt[(k, r["Counter_Name"])] += 1
 for k in agg:
