@@ -57,7 +57,7 @@ struct WGeom {
     int oct_in, oct_out;            // octets of the two L16 tensors
     int th, tw, tiles_h, tiles_w;   // 64-pixel box and boxes per image
     int rows, cols, plane, npos;    // staged input window incl. halo: npos = rows * cols positions, plane = unit pitch (npos padded)
-    int du;                         // dOut unit pitch: 66 (padded) or 64
+    int du;                         // dOut unit pitch: 66 / 68 (padded: two / three limbs) or 64
     int xi;                         // ceil(plane / 64)
     int units, nsplit;
     int ng, nt;                     // co groups x ci groups of a workgroup (ng * nt == 8)
@@ -446,9 +446,13 @@ bool plan_l16_wgrad(const fsc_conv_desc& d, WPlan* out) {
     for (int opt = 0; opt < n_opts && best_eff < 0.4; ++opt)
     for (int pad = 1; pad >= 0 && best_eff < 0.4; --pad) {       // bank-conflict padding first; without it when nothing fits
         ct = ct_opts[opt];
+        // (the two octets a transpose read touches must lie 64 or 192 bytes apart modulo 256: octet pitch = nl planes of 16-byte
+        // positions.  Two limbs: pitch == 2 (mod 8) positions; three limbs: 3 * pitch == 4 or 12 (mod 16), i.e. pitch == 4 (mod 8) --
+        // with the two-limb pitches half of the LDS cycles of the three-limb kernel were bank conflicts, profiles/r05_pmc_conv_l3_wgrad.txt)
+        const int want = nl == 3 ? 4 : 2;
         int plane = g.npos;
-        if (pad) while (plane % 8 != 2) ++plane;
-        const int du = pad ? 66 : 64;
+        if (pad) while (plane % 8 != want) ++plane;
+        const int du = pad ? 64 + want : 64;
         for (int nt = 1; nt <= 8; nt *= 2) {
             const int ng = kWaves / nt;
             const int ci_blocks = fsc::ceil_div(tiles_ci, nt * ct);
