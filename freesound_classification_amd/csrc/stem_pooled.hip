@@ -162,32 +162,36 @@ __global__ __launch_bounds__(kThreads) void stem_wgrad_pooled_kernel(const float
 
 // Sums the partial rows of one output channel over the blocks and finishes what can be finished per channel: the weight gradient
 // (xhat mode: dW = gamma dW' + beta T), the border sums, and this channel's terms of the BatchNorm parameter gradients, which it
-// leaves in pad floats 26 .. 26 + 2 CIN of its own row of block 0 ([sum_tap w T | sum_tap w dW(')] per input channel).
+// leaves as DOUBLES in floats 16 .. 16 + 4 CIN of its own row of block 0 ([sum_tap w T | sum_tap w dW(')] per input channel; the
+// row's own values are in shared memory by then).  Round 5: everything behind the per-block partial rows is summed in fp64 --
+// dgamma = sum_{co, tap} w dW' is a cancelling sum of 900 terms that are themselves sums over millions of positions, and the fp32
+// reductions here (2048 rows, then 9 taps, then 100 channels) left it 2.9e-3 of its scale from an fp64 evaluation against 4.6e-4 for
+// the CPU's direct fp32 sum (tests/test_cfg2_gpu.py, stage 0).
 template <int CIN>
 __global__ __launch_bounds__(256) void stem_grads_reduce_kernel(float* __restrict__ part, int blocks, int cout,
                                                                  const float* __restrict__ weight, const float* __restrict__ chan_sum,
                                                                  const float* __restrict__ gamma, const float* __restrict__ beta, int xhat,
                                                                  float* __restrict__ dweight, float* __restrict__ borders) {
-    __shared__ float red[8][32];
+    __shared__ double red[8][32];
     const int co = blockIdx.x, k = threadIdx.x & 31, g = threadIdx.x >> 5;
-    float acc = 0.f;
-    for (int b = g; b < blocks; b += 8) acc += part[((long)b * cout + co) * 32 + k];
+    double acc = 0.0;
+    for (int b = g; b < blocks; b += 8) acc += (double)part[((long)b * cout + co) * 32 + k];
     red[g][k] = acc;
     __syncthreads();
     if (threadIdx.x < 32) {
-        float t = 0.f;
+        double t = 0.0;
 #pragma unroll
         for (int i = 0; i < 8; ++i) t += red[i][k];
         red[0][k] = t;
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        const float* tot = red[0];
-        const float s = chan_sum[co];
-        float T[9];
+        const double* tot = red[0];
+        const double s = (double)chan_sum[co];
+        double T[9];
         for (int ty = 0; ty < 3; ++ty)
             for (int tx = 0; tx < 3; ++tx) {
-                float v = s;
+                double v = s;
                 if (ty == 0) v -= tot[18 + 0];
                 if (ty == 2) v -= tot[18 + 1];
                 if (tx == 0) v -= tot[18 + 2];
@@ -198,20 +202,20 @@ __global__ __launch_bounds__(256) void stem_grads_reduce_kernel(float* __restric
                 if (ty == 2 && tx == 2) v += tot[18 + 7];
                 T[ty * 3 + tx] = v;
             }
-        float* scratch = part + (long)co * 32 + 26;
+        double* scratch = reinterpret_cast<double*>(part + (long)co * 32 + 16);
         for (int ci = 0; ci < CIN; ++ci) {
-            float cb = 0.f, cs = 0.f;
+            double cb = 0.0, cs = 0.0;
             for (int tap = 0; tap < 9; ++tap) {
-                const float wv = weight[((long)co * CIN + ci) * 9 + tap], dwx = tot[ci * 9 + tap];
-                cb = fmaf(wv, T[tap], cb);
-                cs = fmaf(wv, dwx, cs);
-                dweight[((long)co * CIN + ci) * 9 + tap] = xhat ? fmaf(gamma[ci], dwx, beta[ci] * T[tap]) : dwx;
+                const double wv = (double)weight[((long)co * CIN + ci) * 9 + tap], dwx = tot[ci * 9 + tap];
+                cb += wv * T[tap];
+                cs += wv * dwx;
+                dweight[((long)co * CIN + ci) * 9 + tap] = (float)(xhat ? (double)gamma[ci] * dwx + (double)beta[ci] * T[tap] : dwx);
             }
             scratch[2 * ci] = cb;
             scratch[2 * ci + 1] = cs;
         }
         if (borders)
-            for (int i = 0; i < 8; ++i) borders[co * 8 + i] = tot[18 + i];
+            for (int i = 0; i < 8; ++i) borders[co * 8 + i] = (float)tot[18 + i];
     }
 }
 
@@ -221,20 +225,20 @@ template <int CIN>
 __global__ __launch_bounds__(256) void stem_bn_finish_kernel(const float* __restrict__ part, int cout, const float* __restrict__ gamma,
                                                               const float* __restrict__ beta, int xhat, float* __restrict__ dgamma,
                                                               float* __restrict__ dbeta) {
-    __shared__ float scratch[4];
-    float v[2 * CIN];
+    __shared__ double scratch[4];
+    double v[2 * CIN];
 #pragma unroll
-    for (int i = 0; i < 2 * CIN; ++i) v[i] = 0.f;
+    for (int i = 0; i < 2 * CIN; ++i) v[i] = 0.0;
     for (int co = threadIdx.x; co < cout; co += 256)
 #pragma unroll
-        for (int i = 0; i < 2 * CIN; ++i) v[i] += part[(long)co * 32 + 26 + i];
+        for (int i = 0; i < 2 * CIN; ++i) v[i] += reinterpret_cast<const double*>(part + (long)co * 32 + 16)[i];
 #pragma unroll
-    for (int i = 0; i < 2 * CIN; ++i) v[i] = fsc::block_sum<float, 4>(v[i], scratch);
+    for (int i = 0; i < 2 * CIN; ++i) v[i] = fsc::block_sum<double, 4>(v[i], scratch);
     if (threadIdx.x == 0)
         for (int ci = 0; ci < CIN; ++ci) {
-            const float db = v[2 * ci], x = v[2 * ci + 1];
-            dbeta[ci] = db;
-            dgamma[ci] = xhat ? x : (x - beta[ci] * db) / gamma[ci];
+            const double db = v[2 * ci], x = v[2 * ci + 1];
+            dbeta[ci] = (float)db;
+            dgamma[ci] = (float)(xhat ? x : (x - (double)beta[ci] * db) / (double)gamma[ci]);
         }
 }
 
