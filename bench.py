@@ -154,8 +154,14 @@ def price_kernel(name):
     """(peak TFLOP/s, executed 16-bit MFMA flops per algorithmic fp32 flop, arithmetic) of a timed conv kernel, by its plan name.
     Split kernels (`..._x3_kernel<..., NPROD>`, `conv_l16_*`): every algorithmic fp32 flop costs NPROD 16-bit MFMA flops, so the
     achieved rate counts EXECUTED 16-bit flops and is priced against the dense fp16 / bf16 peak."""
-    if "conv_l3_" in name:             # pre-split operands, three exact bf16 limbs: NPROD (last template argument) limb products
-        per = int(name.rstrip(">").replace(",pool", "").split(",")[-1])
+    if "conv_l3_" in name:             # pre-split operands, three limbs: <..., NPROD[,f16][,pool]> limb products
+        core = name.rstrip(">").replace(",pool", "")
+        f16 = core.endswith(",f16")
+        per = int(core.replace(",f16", "").split(",")[-1])
+        if f16:
+            return PEAK_BF16_MFMA_TFLOPS, per, ("fp32 via three SCALED fp16 limbs per operand, written once by the operand's producer (L16 tensors, 6 B per "
+                                                "element; exact for elements down to 2^-16 of the tensor maximum), %d fp16 MFMA products per fp32 product "
+                                                "(dropped limb pairs <= 2^-32 of the product), fp32 accumulate" % per)
         return PEAK_BF16_MFMA_TFLOPS, per, ("fp32 with exact products: every operand split exactly into three bf16 limbs by its producer "
                                             "(L16 tensors, 6 B per element), %d bf16 MFMA products per fp32 product%s, fp32 accumulate"
                                             % (per, " (all limb pairs: the product of the two fp32 operands is exact)" if per == 9 else ""))
@@ -173,9 +179,11 @@ def price_kernel(name):
     return PEAK_F32_MFMA_TFLOPS, 1, "native fp32 MFMA"
 
 
-ARITH_LABEL = {0: "f32", 1: "bf16", 3: "f16x3", 6: "bf16x6", 9: "bf16x9"}
-# significand bits a conv product keeps: 24 = the exact product of the fp32 operands (native fp32 MFMA; all nine bf16 limb products)
-ARITH_BITS = {0: 24, 1: 8, 3: 22, 6: 23, 9: 24}
+ARITH_LABEL = {0: "f32", 1: "bf16", 3: "f16x3", 6: "bf16x6", 9: "bf16x9", 10: "f16x6"}
+# significand bits a conv product keeps: 24 = the product of the fp32 operands before the accumulator's rounding (native fp32 MFMA; all
+# nine bf16 limb products: exact; f16x6: 24-bit operands, the dropped limb pairs are <= 2^-32 of the product -- 2^-8 of what the fp32
+# accumulator rounds away -- for operands down to 2^-16 of their tensor's maximum, include/fsc_hip.h)
+ARITH_BITS = {0: 24, 1: 8, 3: 22, 6: 23, 9: 24, 10: 24}
 
 
 def rocprof_name_to_timer_name(n):
@@ -185,11 +193,11 @@ def rocprof_name_to_timer_name(n):
     if not m:
         return None
     base, a = m.group(1), [x.strip() for x in m.group(2).split(",")]
-    if base == "conv_l3_fwd_kernel":                    # <KH, KW, CT, PTW, NPROD, POOL, STATS>
-        return "conv_l3_fwd_kernel<%s>" % ",".join(a[:5] + (["pool"] if a[5:6] == ["true"] else []))
-    if base == "conv_l16_wgrad_kernel":                 # <KH, KW, MT, CT[, NL, NPROD]>
+    if base == "conv_l3_fwd_kernel":                    # <KH, KW, CT, PTW, NPROD, F16, POOL, STATS>
+        return "conv_l3_fwd_kernel<%s>" % ",".join(a[:5] + (["f16"] if a[5:6] == ["true"] else []) + (["pool"] if a[6:7] == ["true"] else []))
+    if base == "conv_l16_wgrad_kernel":                 # <KH, KW, MT, CT[, NL, NPROD, F16]>
         if len(a) >= 6 and a[4] == "3":
-            return "conv_l3_wgrad_kernel<%s>" % ",".join(a[:4] + [a[5]])
+            return "conv_l3_wgrad_kernel<%s>" % ",".join(a[:4] + [a[5]] + (["f16"] if a[6:7] == ["true"] else []))
         return "conv_l16_wgrad_kernel<%s>" % ",".join(a[:4])
     if base == "conv_l16_fwd_kernel":                   # <KH, KW, COT, PT, POOL, STATS>
         return "conv_l16_fwd_kernel<%s>" % ",".join(a[:4] + (["pool"] if a[4:5] == ["true"] else []))
@@ -421,7 +429,8 @@ def run_inference(args, w, device, world, rank):
             "value": clips_all / tmax, "unit": "clips/s", "n_gpus": world, "steps": n_steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * tmax / n_steps, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": {0: "f32", 3: "f32 (f16x3 products)", 6: "f32 (bf16x6 products)",
-                      9: "f32 (exact products: 3 bf16 limbs x 9 MFMA products, fp32 accumulate)"}.get(F.get_conv_arith(), "f32"),
+                      9: "f32 (exact products: 3 bf16 limbs x 9 MFMA products, fp32 accumulate)",
+                      10: "f32 (3 scaled fp16 limbs x 6 MFMA products: products to 2^-32, fp32 accumulate)"}.get(F.get_conv_arith(), "f32"),
             "arith_bits": ARITH_BITS[F.get_conv_arith()], "data": "synthetic",
             "config": {"workload": "cfg5: %d clips of U(%.1f, %.0f) s @ %.1f kHz (%.0f s of audio), %d length-grouped batches "
                                    "(bucket edges every %.0f s, <= %d x %.0f s of samples), %d resident fold models of the "
@@ -545,7 +554,7 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="(default; kept for the profile scripts)")
     ap.add_argument("--no-other", action="store_true", help="skip the short cfg3 / cfg5 runs attached to the default cfg2 line (other_workloads)")
     ap.add_argument("--kernel-table", action="store_true", help="print per-kernel timing to stderr")
-    ap.add_argument("--arith", default=None, choices=["f32", "bf16", "f16x3", "bf16x6", "bf16x9"],
+    ap.add_argument("--arith", default=None, choices=["f32", "bf16", "f16x3", "bf16x6", "bf16x9", "f16x6"],
                     help="conv arithmetic (default: the workload's, else the library default f16x3)")
     ap.add_argument("--launch-check", action="store_true",
                     help="rendezvous + barrier + gradient-sized all-reduce only (no model); with --backend gloo it runs on CPU")
@@ -850,7 +859,8 @@ def main():
             # bf16: conv operands rounded to bf16, fp32 accumulation / storage / master weights
             # (f16x3 products: every fp32 product is formed from two scaled fp16 limbs per operand, low x low dropped)
             "dtype": {0: "f32", 1: "bf16", 3: "f32 (f16x3 products)", 6: "f32 (bf16x6 products)",
-                      9: "f32 (exact products: 3 bf16 limbs x 9 MFMA products, fp32 accumulate)"}[F.get_conv_arith()],
+                      9: "f32 (exact products: 3 bf16 limbs x 9 MFMA products, fp32 accumulate)",
+                      10: "f32 (3 scaled fp16 limbs x 6 MFMA products: products to 2^-32, fp32 accumulate)"}[F.get_conv_arith()],
             "arith_bits": ARITH_BITS[F.get_conv_arith()],   # significand bits a conv product keeps (24: the exact fp32 product)
             "data": "synthetic",
             "config": {"workload": "%s: batch %d x %.0f s @ %.1f kHz, %s, %d-block %dd CNN base %d growth %g, "

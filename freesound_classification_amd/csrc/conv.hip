@@ -2067,7 +2067,7 @@ size_t x3_limb_floats(const FwdPlan& p) {
 // Arithmetic of the conv kernels: 0 = native fp32 MFMA everywhere; 3 = scaled split-fp16 (two limbs, three
 // products; the default), 6 / 9 = split-bf16 (three limbs, that many products) wherever the x3 tilings fit.
 // A PER-CALL property: fsc_conv_desc.arith; FSC_ARITH_DEFAULT (-1) there means the process default, which is
-// read once from the environment (FSC_CONV_ARITH=f32|f16x3|bf16x6|bf16x9, else 3) and never changes afterwards.
+// read once from the environment (FSC_CONV_ARITH=f32|f16x3|bf16x6|bf16x9|f16x6, else 3) and never changes afterwards.
 int default_arith() {
     static const int mode = [] {
         const char* e = getenv("FSC_CONV_ARITH");
@@ -2075,11 +2075,17 @@ int default_arith() {
         if (e && !strcmp(e, "bf16")) return 1;
         if (e && !strcmp(e, "bf16x6")) return 6;
         if (e && !strcmp(e, "bf16x9")) return 9;
+        if (e && !strcmp(e, "f16x6")) return 10;
         return 3;
     }();
     return mode;
 }
-int arith_of(const fsc_conv_desc& d) { return d.arith < 0 ? default_arith() : d.arith; }
+// (10 -- three SCALED fp16 limbs, six products -- exists on pre-split L16 tensors only: the fp32-input kernels of this file, which
+// split beside the MFMAs, serve it with the exact nine-product bf16 split)
+int arith_of(const fsc_conv_desc& d) {
+    const int a = d.arith < 0 ? default_arith() : d.arith;
+    return a == 10 ? 9 : a;
+}
 
 int pad_plane(int floats, int want) {   // smallest p >= floats with p % 32 == want
     int p = floats;
@@ -2477,7 +2483,7 @@ bool stem_shape(const fsc_conv_desc& d) {
 
 bool valid_desc(const fsc_conv_desc* d) {
     if (!d || d->n <= 0 || d->c_in <= 0 || d->c_out <= 0 || d->h <= 0 || d->w <= 0) return false;
-    if (!(d->arith == FSC_ARITH_DEFAULT || d->arith == 0 || d->arith == 1 || d->arith == 3 || d->arith == 6 || d->arith == 9)) return false;
+    if (!(d->arith == FSC_ARITH_DEFAULT || d->arith == 0 || d->arith == 1 || d->arith == 3 || d->arith == 6 || d->arith == 9 || d->arith == 10)) return false;
     const bool k33 = d->kh == 3 && d->kw == 3, k11 = d->kh == 1 && d->kw == 1, k13 = d->kh == 1 && d->kw == 3;
     if (!(k33 || k11 || k13)) return false;
     const long big = 1L << 31;

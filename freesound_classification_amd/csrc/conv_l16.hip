@@ -1108,34 +1108,34 @@ int fsc_l16_unpack(const void* in, int n, int c, long hw, const float* amax, flo
     return 0;
 }
 
-/* the same three with the limb format spelled out: limbs = 2 (scaled fp16 pairs, arith 3) or 3 (exact bf16 triples, arith 9 / 8 / 6:
- * no scale, `amax` is not read and may be NULL) */
+/* the same three with the limb format spelled out: limbs = 2 (scaled fp16 pairs, arith 3), 3 (exact bf16 triples, arith 9 / 8 / 6:
+ * no scale, `amax` is not read and may be NULL) or 4 (FSC_L16_F16X3: scaled fp16 TRIPLES, arith 10) */
 size_t fsc_l16_bytes_limbs(int n, int c, long hw, int limbs) {
-    return limbs == 3 ? fsc::l3::tensor_bytes(n, c, hw) : fsc_l16_bytes(n, c, hw);
+    return limbs == 3 || limbs == 4 ? fsc::l3::tensor_bytes(n, c, hw) : fsc_l16_bytes(n, c, hw);
 }
 
 int fsc_l16_pack_limbs(const float* x, int n, int c, long hw, const float* amax, int limbs, void* out, fsc_stream_t stream) {
-    FSC_CHECK_ARG(limbs == 2 || limbs == 3, "fsc_l16_pack_limbs: limbs must be 2 or 3");
+    FSC_CHECK_ARG(limbs >= 2 && limbs <= 4, "fsc_l16_pack_limbs: limbs must be 2, 3 or 4 (three scaled fp16 limbs)");
     if (limbs == 2) return fsc_l16_pack(x, n, c, hw, amax, out, stream);
-    FSC_CHECK_ARG(x && out && n > 0 && c > 0 && hw > 0, "fsc_l16_pack_limbs: bad arguments");
-    return fsc::l3::pack(x, n, c, hw, out, fsc::as_stream(stream));
+    FSC_CHECK_ARG(x && out && n > 0 && c > 0 && hw > 0 && (limbs == 3 || amax), "fsc_l16_pack_limbs: bad arguments");
+    return fsc::l3::pack(x, n, c, hw, limbs == 4 ? amax : nullptr, out, fsc::as_stream(stream));
 }
 
 int fsc_l16_unpack_limbs(const void* in, int n, int c, long hw, const float* amax, int limbs, float* x, fsc_stream_t stream) {
-    FSC_CHECK_ARG(limbs == 2 || limbs == 3, "fsc_l16_unpack_limbs: limbs must be 2 or 3");
+    FSC_CHECK_ARG(limbs >= 2 && limbs <= 4, "fsc_l16_unpack_limbs: limbs must be 2, 3 or 4 (three scaled fp16 limbs)");
     if (limbs == 2) return fsc_l16_unpack(in, n, c, hw, amax, x, stream);
-    FSC_CHECK_ARG(x && in && n > 0 && c > 0 && hw > 0, "fsc_l16_unpack_limbs: bad arguments");
-    return fsc::l3::unpack(in, n, c, hw, x, fsc::as_stream(stream));
+    FSC_CHECK_ARG(x && in && n > 0 && c > 0 && hw > 0 && (limbs == 3 || amax), "fsc_l16_unpack_limbs: bad arguments");
+    return fsc::l3::unpack(in, n, c, hw, limbs == 4 ? amax : nullptr, x, fsc::as_stream(stream));
 }
 
 int fsc_conv_l16_supported(const fsc_conv_desc* d, int dgrad) {
-    if (d && l16::is_bf3(d->arith)) return fsc::l3::supported(d, dgrad);
+    if (d && l16::is_l3(d->arith)) return fsc::l3::supported(d, dgrad);
     LPlan p;
     return valid_l16_desc(d) && plan_l16(*d, dgrad, &p) ? 1 : 0;
 }
 
 size_t fsc_conv_l16_packed_floats(const fsc_conv_desc* d, int dgrad) {
-    if (d && l16::is_bf3(d->arith)) return fsc::l3::packed_floats(d, dgrad);
+    if (d && l16::is_l3(d->arith)) return fsc::l3::packed_floats(d, dgrad);
     LPlan p;
     if (!valid_l16_desc(d) || !plan_l16(*d, dgrad, &p)) return 0;
     return l16_limb_floats(p) + 4 + kWmaxBlocks;
@@ -1156,7 +1156,7 @@ static PackDir make_pack_dir(const LPlan& p, float* packed, int dgrad) {
 /* packs the forward (packed_fwd) and / or input-gradient (packed_dgrad) fragments of one weight in two launches total */
 int fsc_conv_l16_pack_weights_pair(const fsc_conv_desc* d, const float* weight, float* packed_fwd, float* packed_dgrad,
                                    fsc_stream_t stream) {
-    if (d && l16::is_bf3(d->arith)) return fsc::l3::pack_weights_pair(d, weight, packed_fwd, packed_dgrad, fsc::as_stream(stream));
+    if (d && l16::is_l3(d->arith)) return fsc::l3::pack_weights_pair(d, weight, packed_fwd, packed_dgrad, fsc::as_stream(stream));
     FSC_CHECK_ARG(valid_l16_desc(d) && weight && (packed_fwd || packed_dgrad), "fsc_conv_l16_pack_weights_pair: bad arguments");
     LPlan pf{}, pd{};
     FSC_CHECK_ARG(!packed_fwd || plan_l16(*d, 0, &pf), "fsc_conv_l16_pack_weights_pair: no forward tiling for this shape");
@@ -1184,9 +1184,9 @@ int fsc_conv_l16_pack_weights_multi(int count, const fsc_conv_desc* descs, const
                                     float* const* packed_dgrad, fsc_stream_t stream) {
     FSC_CHECK_ARG(count > 0 && descs && weights && packed_fwd && packed_dgrad, "fsc_conv_l16_pack_weights_multi: bad arguments");
     hipStream_t st = fsc::as_stream(stream);
-    if (l16::is_bf3(descs[0].arith)) {                       // (one arithmetic per call)
+    if (l16::is_l3(descs[0].arith)) {                        // (one arithmetic per call)
         for (int k = 1; k < count; ++k)
-            FSC_CHECK_ARG(l16::is_bf3(descs[k].arith), "fsc_conv_l16_pack_weights_multi: entry %d mixes limb formats", k);
+            FSC_CHECK_ARG(descs[k].arith == descs[0].arith, "fsc_conv_l16_pack_weights_multi: entry %d mixes limb formats", k);
         return fsc::l3::pack_weights_multi(count, descs, weights, packed_fwd, packed_dgrad, st);
     }
     for (int base = 0; base < count; base += kMultiPack) {
@@ -1223,8 +1223,8 @@ int fsc_conv_l16_pack_weights_multi(int count, const fsc_conv_desc* descs, const
 
 int fsc_conv_l16_fwd(const fsc_conv_desc* d, const void* in_l16, const float* in_amax, const float* packed,
                      const float* bias, int dgrad, int accumulate, float* out, fsc_stream_t stream) {
-    if (d && l16::is_bf3(d->arith))
-        return fsc::l3::fwd(d, in_l16, packed, bias, dgrad, accumulate, out, nullptr, nullptr, fsc::as_stream(stream));
+    if (d && l16::is_l3(d->arith))
+        return fsc::l3::fwd(d, in_l16, in_amax, packed, bias, dgrad, accumulate, out, nullptr, nullptr, fsc::as_stream(stream));
     LPlan p;
     FSC_CHECK_ARG(valid_l16_desc(d) && in_l16 && in_amax && packed && out, "fsc_conv_l16_fwd: bad descriptor or null pointer");
     FSC_CHECK_ARG(!(dgrad && bias), "fsc_conv_l16_fwd: dgrad takes no bias");
@@ -1239,7 +1239,7 @@ int fsc_conv_l16_fwd(const fsc_conv_desc* d, const void* in_l16, const float* in
  * workers * 8 * channels-per-block float4 {sum (y - pivot), sum (y - pivot)^2, min, max}; worker w holds channel block
  * w % blocks (order 0) or (w / 8) % blocks (order 1: XCD-aware item order) */
 int fsc_conv_l16_stats_layout(const fsc_conv_desc* d, int pool, int* out3) {
-    if (d && l16::is_bf3(d->arith)) return fsc::l3::stats_layout(d, pool, out3);
+    if (d && l16::is_l3(d->arith)) return fsc::l3::stats_layout(d, pool, out3);
     LPlan p;
     if (!valid_l16_desc(d) || !out3) return 0;
     if (!(pool ? plan_l16_pool(*d, &p) : plan_l16(*d, 0, &p)) || !stats_ok(p)) return 0;
@@ -1249,9 +1249,9 @@ int fsc_conv_l16_stats_layout(const fsc_conv_desc* d, int pool, int* out3) {
 
 int fsc_conv_l16_fwd_stats(const fsc_conv_desc* d, const void* in_l16, const float* in_amax, const float* packed,
                            const float* bias, float* out, const float* stat_pivot, void* stat_rec, fsc_stream_t stream) {
-    if (d && l16::is_bf3(d->arith)) {
+    if (d && l16::is_l3(d->arith)) {
         FSC_CHECK_ARG(stat_rec, "fsc_conv_l16_fwd_stats: null records");
-        return fsc::l3::fwd(d, in_l16, packed, bias, 0, 0, out, stat_pivot, stat_rec, fsc::as_stream(stream));
+        return fsc::l3::fwd(d, in_l16, in_amax, packed, bias, 0, 0, out, stat_pivot, stat_rec, fsc::as_stream(stream));
     }
     LPlan p;
     FSC_CHECK_ARG(valid_l16_desc(d) && in_l16 && in_amax && packed && out && stat_rec, "fsc_conv_l16_fwd_stats: bad descriptor or null pointer");
@@ -1264,15 +1264,15 @@ int fsc_conv_l16_fwd_stats(const fsc_conv_desc* d, const void* in_l16, const flo
 }
 
 int fsc_conv_l16_pool_supported(const fsc_conv_desc* d) {
-    if (d && l16::is_bf3(d->arith)) return fsc::l3::pool_supported(d);
+    if (d && l16::is_l3(d->arith)) return fsc::l3::pool_supported(d);
     LPlan p;
     return valid_l16_desc(d) && plan_l16_pool(*d, &p) ? 1 : 0;
 }
 
 static int pool_fwd_impl(const fsc_conv_desc* d, const void* in_l16, const float* in_amax, const float* packed, const float* bias,
                          float* pooled, uint8_t* idx, StatArgs sa, fsc_stream_t stream) {
-    if (d && l16::is_bf3(d->arith))
-        return fsc::l3::pool_fwd(d, in_l16, packed, bias, pooled, idx, sa.pivot, sa.rec, fsc::as_stream(stream));
+    if (d && l16::is_l3(d->arith))
+        return fsc::l3::pool_fwd(d, in_l16, in_amax, packed, bias, pooled, idx, sa.pivot, sa.rec, fsc::as_stream(stream));
     LPlan p;
     FSC_CHECK_ARG(valid_l16_desc(d) && in_l16 && in_amax && packed && pooled && idx, "fsc_conv_l16_pool_fwd: bad descriptor or null pointer");
     FSC_CHECK_ARG(plan_l16_pool(*d, &p), "fsc_conv_l16_pool_fwd: unsupported shape (see fsc_conv_l16_pool_supported)");
@@ -1314,7 +1314,7 @@ int fsc_debug_l16_prof(unsigned long long* out64) {
 #endif
 
 int fsc_conv_l16_plan_describe(const fsc_conv_desc* d, int dgrad, char* buf, size_t buf_len) {
-    if (d && l16::is_bf3(d->arith)) return fsc::l3::plan_describe(d, dgrad, buf, buf_len);
+    if (d && l16::is_l3(d->arith)) return fsc::l3::plan_describe(d, dgrad, buf, buf_len);
     LPlan p;
     FSC_CHECK_ARG(valid_l16_desc(d) && buf && buf_len > 0 && plan_l16(*d, dgrad, &p), "fsc_conv_l16_plan_describe: unsupported shape");
     snprintf(buf, buf_len, "conv_l16_fwd_kernel<%d,%d,%d,%d> box=%dx%dx%d items=%ldx%d workers=%ld steps=%d lds=%zu", d->kh, d->kw,

@@ -84,9 +84,9 @@ __device__ __forceinline__ void glds16(const void* src, void* lds_wave_base) {
     const unsigned m = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_ptr)lds_wave_base);
     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(m) : "memory", "m0");
 }
-template <int NL>
+template <bool F16>
 __device__ __forceinline__ f32x4 mfma16(u32x4 a, u32x4 b, f32x4 c) {
-    if constexpr (NL == 2)
+    if constexpr (F16)
         return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
     else
         return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
@@ -136,7 +136,8 @@ __device__ __forceinline__ void xcd_block_order(int* block, int* split) {
     *block = (int)(v - (unsigned)*split * bx);
 }
 
-template <int KH, int KW, int MT, int CT, int NL = 2, int NPROD = 3>
+// F16: scaled fp16 limbs (two: arith 3; three: arith 10, l16.h) -- else three exact bf16 limbs
+template <int KH, int KW, int MT, int CT, int NL = 2, int NPROD = 3, bool F16 = (NL == 2)>
 __global__ __launch_bounds__(kWaves * 64) void conv_l16_wgrad_kernel(WGeom g, const uint4* __restrict__ in,
                                                                       const uint4* __restrict__ dout,
                                                                       float* __restrict__ part,
@@ -173,7 +174,7 @@ __global__ __launch_bounds__(kWaves * 64) void conv_l16_wgrad_kernel(WGeom g, co
 
     // ---- operand scales
     float inv_ab = 1.f;
-    if constexpr (NL == 2) {
+    if constexpr (F16) {
         float* red = reinterpret_cast<float*>(smem4);
         const float ma = fsc::wave_max(dout_amax[tid]), mb = fsc::wave_max(in_amax[tid]);
         if (lane == 0) { red[wid] = ma; red[kWaves + wid] = mb; }
@@ -304,7 +305,7 @@ __global__ __launch_bounds__(kWaves * 64) void conv_l16_wgrad_kernel(WGeom g, co
                         for (int gq = 0; gq < NPROD; ++gq)
 #pragma unroll
                             for (int i = 0; i < LIVE; ++i)
-                                acc[s][i] = mfma16<NL>(af[i][WP::la[gq]], bf[s % (kAhead + 1)][WP::lb[gq]], acc[s][i]);
+                                acc[s][i] = mfma16<F16>(af[i][WP::la[gq]], bf[s % (kAhead + 1)][WP::lb[gq]], acc[s][i]);
                         // the 2 * NL reads of the slot kAhead ahead go behind the first MFMAs of this one; nothing else moves across
                         // slots (unpinned, the scheduler hoists every slot's reads to the top of the k-step: +56 registers)
 #pragma unroll
@@ -386,11 +387,12 @@ __global__ __launch_bounds__(kRedX * kRedY) void l16_wgrad_reduce_kernel(const f
 struct WPlan {
     WGeom g;
     int mt, ct, nl, nprod;
+    bool f16;
     size_t lds_bytes;
 };
 
 bool plan_l16_wgrad(const fsc_conv_desc& d, WPlan* out) {
-    const bool bf3 = l16::is_bf3(d.arith);
+    const bool bf3 = l16::is_l3(d.arith);                   // (three limbs: bf16, or scaled fp16)
     if (d.arith != FSC_ARITH_DEFAULT && d.arith != 3 && !bf3) return false;
     const int nl = bf3 ? 3 : 2;
     const int max_tpg = bf3 ? 3 : 4;       // co tiles per wave: 9 taps x 4 tiles x 4 registers + three-limb fragments do not fit 256
@@ -440,7 +442,8 @@ bool plan_l16_wgrad(const fsc_conv_desc& d, WPlan* out) {
     const int n_opts = (taps == 1 && bf3) ? 3 : 1;
     int ct = ct_opts[0];
     p.nl = nl;
-    p.nprod = bf3 ? (d.arith == 6 ? 6 : d.arith == 8 ? 8 : 9) : 3;
+    p.nprod = bf3 ? (d.arith == 6 || l16::is_f3(d.arith) ? 6 : d.arith == 8 ? 8 : 9) : 3;
+    p.f16 = !l16::is_bf3(d.arith);
     const int tiles_co = fsc::ceil_div(d.c_out, 16), tiles_ci = fsc::ceil_div(d.c_in, 16);
     double best_eff = -1.0;
     for (int opt = 0; opt < n_opts && best_eff < 0.4; ++opt)
@@ -506,10 +509,10 @@ bool plan_l16_wgrad(const fsc_conv_desc& d, WPlan* out) {
     return true;
 }
 
-template <int KH, int KW, int MT, int CT, int NL = 2, int NPROD = 3>
+template <int KH, int KW, int MT, int CT, int NL = 2, int NPROD = 3, bool F16 = (NL == 2)>
 void launch_k(const WPlan& p, const uint4* in, const uint4* dout, float* part, const float* in_amax, const float* dout_amax,
               hipStream_t st) {
-    auto kern = conv_l16_wgrad_kernel<KH, KW, MT, CT, NL, NPROD>;
+    auto kern = conv_l16_wgrad_kernel<KH, KW, MT, CT, NL, NPROD, F16>;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes);
     dim3 grid(p.g.co_blocks * p.g.ci_blocks, p.g.nsplit);
     hipLaunchKernelGGL(kern, grid, dim3(kWaves * 64), p.lds_bytes, st, p.g, in, dout, part, in_amax, dout_amax);
@@ -540,7 +543,7 @@ int fsc_conv_l16_wgrad(const fsc_conv_desc* d, const void* in_l16, const float* 
                        const float* dout_amax, float* dweight, void* workspace, fsc_stream_t stream) {
     WPlan p;
     FSC_CHECK_ARG(valid_desc(d) && in_l16 && dout_l16 && dweight && workspace, "fsc_conv_l16_wgrad: bad descriptor or null pointer");
-    FSC_CHECK_ARG(l16::is_bf3(d->arith) || (in_amax && dout_amax), "fsc_conv_l16_wgrad: the two-limb format needs both operand maxima");
+    FSC_CHECK_ARG(l16::is_bf3(d->arith) || (in_amax && dout_amax), "fsc_conv_l16_wgrad: the scaled fp16 formats need both operand maxima");
     FSC_CHECK_ARG(plan_l16_wgrad(*d, &p), "fsc_conv_l16_wgrad: unsupported shape (see fsc_conv_l16_wgrad_supported)");
     hipStream_t st = fsc::as_stream(stream);
     const uint4* in = reinterpret_cast<const uint4*>(in_l16);
@@ -550,21 +553,27 @@ int fsc_conv_l16_wgrad(const fsc_conv_desc* d, const void* in_l16, const float* 
     if (d->kh == 3) launch_k<3, 3, MT_, 1>(p, in, dout, part, in_amax, dout_amax, st);            \
     else launch_k<1, 1, MT_, 4>(p, in, dout, part, in_amax, dout_amax, st);                       \
     break;
-#define FSC_WL3(MT_, NP_)                                                                                \
-    if (d->kh == 3) launch_k<3, 3, MT_, 1, 3, NP_>(p, in, dout, part, in_amax, dout_amax, st);           \
-    else if (p.ct == 4) launch_k<1, 1, MT_, 4, 3, NP_>(p, in, dout, part, in_amax, dout_amax, st);       \
-    else if (p.ct == 2) launch_k<1, 1, MT_, 2, 3, NP_>(p, in, dout, part, in_amax, dout_amax, st);       \
-    else launch_k<1, 1, MT_, 1, 3, NP_>(p, in, dout, part, in_amax, dout_amax, st);                      \
+#define FSC_WL3(MT_, NP_, F16_)                                                                                \
+    if (d->kh == 3) launch_k<3, 3, MT_, 1, 3, NP_, F16_>(p, in, dout, part, in_amax, dout_amax, st);           \
+    else if (p.ct == 4) launch_k<1, 1, MT_, 4, 3, NP_, F16_>(p, in, dout, part, in_amax, dout_amax, st);       \
+    else if (p.ct == 2) launch_k<1, 1, MT_, 2, 3, NP_, F16_>(p, in, dout, part, in_amax, dout_amax, st);       \
+    else launch_k<1, 1, MT_, 1, 3, NP_, F16_>(p, in, dout, part, in_amax, dout_amax, st);                      \
     break;
-    if (p.nl == 3) {
+    if (p.nl == 3 && p.f16) {
+        switch (p.mt) {
+            case 1: FSC_WL3(1, 6, true)
+            case 2: FSC_WL3(2, 6, true)
+            default: FSC_WL3(3, 6, true)
+        }
+    } else if (p.nl == 3) {
         if (p.nprod != 9) {
             fsc::set_error("fsc_conv_l16_wgrad: this build has no bf16-limb kernels with %d products", p.nprod);
             return 22;
         }
         switch (p.mt) {
-            case 1: FSC_WL3(1, 9)
-            case 2: FSC_WL3(2, 9)
-            default: FSC_WL3(3, 9)
+            case 1: FSC_WL3(1, 9, false)
+            case 2: FSC_WL3(2, 9, false)
+            default: FSC_WL3(3, 9, false)
         }
     } else {
         switch (p.mt) {
@@ -613,7 +622,7 @@ int fsc_conv_l16_wgrad_plan_describe(const fsc_conv_desc* d, char* buf, size_t b
     WPlan p;
     FSC_CHECK_ARG(valid_desc(d) && buf && buf_len > 0 && plan_l16_wgrad(*d, &p), "fsc_conv_l16_wgrad_plan_describe: unsupported shape");
     char name[64];
-    if (p.nl == 3) snprintf(name, sizeof(name), "conv_l3_wgrad_kernel<%d,%d,%d,%d,%d>", d->kh, d->kw, p.mt, p.ct, p.nprod);
+    if (p.nl == 3) snprintf(name, sizeof(name), "conv_l3_wgrad_kernel<%d,%d,%d,%d,%d%s>", d->kh, d->kw, p.mt, p.ct, p.nprod, p.f16 ? ",f16" : "");
     else snprintf(name, sizeof(name), "conv_l16_wgrad_kernel<%d,%d,%d,%d>", d->kh, d->kw, p.mt, p.ct);
     snprintf(buf, buf_len, "%s box=%dx%d groups=%dx%d tiles/block=%d units=%d split=%d grid=%dx%d lds=%zu", name, p.g.th, p.g.tw, p.g.ng,
              p.g.nt, p.g.tpb, p.g.units, p.g.nsplit, p.g.co_blocks * p.g.ci_blocks, p.g.nsplit, p.lds_bytes);

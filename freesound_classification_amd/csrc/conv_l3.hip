@@ -37,6 +37,7 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef __attribute__((address_space(3))) void* lds_ptr;
 
 constexpr int kWaves = 8;
@@ -87,6 +88,19 @@ __device__ __forceinline__ void glds16(const void* src, void* lds_wave_base) {  
 __device__ __forceinline__ f32x4 mfma_bf(u32x4 a, u32x4 b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
+template <bool F16>
+__device__ __forceinline__ f32x4 mfma_l(u32x4 a, u32x4 b, f32x4 c) {
+    if constexpr (F16) return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    else return mfma_bf(a, b, c);
+}
+constexpr int kWmaxBlocks3 = 64;     // partial maxima of a weight tensor (scaled fp16 limbs)
+// maximum over an FSC_AMAX_FLOATS buffer, by one wave (uniform result)
+__device__ __forceinline__ float wave_amax512(const float* __restrict__ amax) {
+    float m = 0.f;
+#pragma unroll
+    for (int i = 0; i < fsc::kAmaxFloats / 64; ++i) m = fmaxf(m, amax[(threadIdx.x & 63) + 64 * i]);
+    return fsc::wave_max(m);
+}
 __device__ __forceinline__ float dpp_xor1(float v) {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true));
 }
@@ -115,7 +129,11 @@ template <> struct Prods<6> { static constexpr int la[6] = {0, 1, 0, 2, 1, 0}; s
 
 // -------------------------------------------------------------------------------------------
 // fp32 NCHW <-> three bf16 limbs (stand-alone producer / inverse: tests, and tensors no fused producer writes)
-__global__ __launch_bounds__(256) void l3_pack_kernel(const float* __restrict__ x, int n, int c, long hw, uint4* __restrict__ out) {
+// (amax != nullptr: three SCALED fp16 limbs, l16.h)
+__global__ __launch_bounds__(256) void l3_pack_kernel(const float* __restrict__ x, int n, int c, long hw, const float* __restrict__ amax,
+                                                      uint4* __restrict__ out) {
+    float sc = 0.f;
+    if (amax != nullptr) sc = l16::field_to_float(l16::scale_field(wave_amax512(amax)));
     const int oct = (c + 7) / 8;
     const long total = (long)n * oct * hw;
     for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
@@ -130,14 +148,21 @@ __global__ __launch_bounds__(256) void l3_pack_kernel(const float* __restrict__ 
             v[e] = ch < c ? x[(img * c + ch) * hw + p] : 0.f;
         }
         uint4 h, m, l;
-        l16::split8_bf3(v, h, m, l);
+        if (amax != nullptr) l16::split8_f3(v, sc, h, m, l);
+        else l16::split8_bf3(v, h, m, l);
         out[(no * 3) * hw + p] = h;
         out[(no * 3 + 1) * hw + p] = m;
         out[(no * 3 + 2) * hw + p] = l;
     }
 }
 
-__global__ __launch_bounds__(256) void l3_unpack_kernel(const uint4* __restrict__ in, int n, int c, long hw, float* __restrict__ x) {
+__global__ __launch_bounds__(256) void l3_unpack_kernel(const uint4* __restrict__ in, int n, int c, long hw,
+                                                        const float* __restrict__ amax, float* __restrict__ x) {
+    float inv = 1.f;
+    if (amax != nullptr) {
+        const float mx = wave_amax512(amax);
+        inv = l16::inv_scale(l16::scale_field(mx), mx);
+    }
     const int oct = (c + 7) / 8;
     const long total = (long)n * oct * hw;
     for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
@@ -152,6 +177,13 @@ __global__ __launch_bounds__(256) void l3_unpack_kernel(const uint4* __restrict_
             const int ch = o * 8 + e;
             if (ch >= c) continue;
             const int sh = (e & 1) * 16;
+            if (amax != nullptr) {
+                const float hv = (float)__builtin_bit_cast(_Float16, (unsigned short)(hh[e >> 1] >> sh)),
+                            mv = (float)__builtin_bit_cast(_Float16, (unsigned short)(mm[e >> 1] >> sh)),
+                            lv = (float)__builtin_bit_cast(_Float16, (unsigned short)(ll[e >> 1] >> sh));
+                x[(img * c + ch) * hw + p] = (hv + (mv + lv)) * inv;  // (m + l is exact: 22 significant bits)
+                continue;
+            }
             const float hv = __uint_as_float((hh[e >> 1] >> sh) << 16), mv = __uint_as_float((mm[e >> 1] >> sh) << 16),
                         lv = __uint_as_float((ll[e >> 1] >> sh) << 16);
             x[(img * c + ch) * hw + p] = hv + (mv + lv);              // (m + l is exact: 16 significant bits)
@@ -164,11 +196,20 @@ __global__ __launch_bounds__(256) void l3_unpack_kernel(const uint4* __restrict_
 // step structure of conv_l16.hip, three exact bf16 limbs instead of two scaled fp16 ones (no weight maximum, one launch).
 struct PackDir3 {
     uint4* packed;
+    float* w_amax;           // scaled fp16 limbs: receives max |w| (behind the fragments; read by the conv kernel), else nullptr
     int cot, co_blocks, nfull, tail_oct, steps, dgrad;
     long frags;              // (fragment, lane) pairs: co_blocks * steps * cot * 64
     int blocks;
 };
-__device__ __forceinline__ void pack3_block(const float* __restrict__ w, int c_out, int c_in, int taps, const PackDir3& dir, int blk) {
+__device__ __forceinline__ void pack3_block(const float* __restrict__ w, int c_out, int c_in, int taps, const PackDir3& dir, int blk,
+                                            const float* __restrict__ wmax_part) {
+    float sw = 0.f;
+    if (dir.w_amax != nullptr) {                           // every block folds the partial maxima of l3_wmax_kernel
+        float wm = 0.f;
+        for (int i = 0; i < kWmaxBlocks3; ++i) wm = fmaxf(wm, wmax_part[i]);
+        if (blk == 0 && threadIdx.x == 0) dir.w_amax[0] = wm;
+        sw = l16::field_to_float(l16::scale_field(wm));
+    }
     const int cot = dir.cot, steps = dir.steps, nfull = dir.nfull;
     for (long idx = (long)blk * blockDim.x + threadIdx.x; idx < dir.frags; idx += (long)dir.blocks * blockDim.x) {
         const int lane = (int)(idx & 63);
@@ -194,20 +235,19 @@ __device__ __forceinline__ void pack3_block(const float* __restrict__ w, int c_o
             }
         }
         uint4 h, m, l;
-        l16::split8_bf3(v, h, m, l);
+        if (dir.w_amax != nullptr) l16::split8_f3(v, sw, h, m, l);
+        else l16::split8_bf3(v, h, m, l);
         uint4* o = dir.packed + ((((long)cb * steps + S) * cot + i) * 3) * 64 + lane;
         o[0] = h;
         o[64] = m;
         o[128] = l;
     }
 }
-__global__ void l3_pack_w_kernel(const float* __restrict__ w, int c_out, int c_in, int taps, PackDir3 a, PackDir3 b) {
-    const bool second = (int)blockIdx.x >= a.blocks;
-    pack3_block(w, c_out, c_in, taps, second ? b : a, second ? blockIdx.x - a.blocks : blockIdx.x);
-}
 constexpr int kMultiPack3 = 12;
 struct PackJob3 {
     const float* w;
+    float* part;             // scaled fp16 limbs: kWmaxBlocks3 partial maxima (behind the first direction's fragments)
+    long count;              // elements of w
     int c_out, c_in, taps;
     PackDir3 a, b;
     int first_block;
@@ -221,21 +261,43 @@ __global__ void l3_pack_w_multi_kernel(PackJobs3 jobs) {
     const PackJob3& pj = jobs.j[job];
     const int rel = (int)blockIdx.x - pj.first_block;
     const bool second = rel >= pj.a.blocks;
-    pack3_block(pj.w, pj.c_out, pj.c_in, pj.taps, second ? pj.b : pj.a, second ? rel - pj.a.blocks : rel);
+    pack3_block(pj.w, pj.c_out, pj.c_in, pj.taps, second ? pj.b : pj.a, second ? rel - pj.a.blocks : rel, pj.part);
+}
+// max |w| of up to kMultiPack3 weight tensors: kWmaxBlocks3 partial maxima each (no clear needed)
+__global__ __launch_bounds__(256) void l3_wmax_multi_kernel(PackJobs3 jobs) {
+    __shared__ float sm[4];
+    const int job = blockIdx.x / kWmaxBlocks3, blk = blockIdx.x - job * kWmaxBlocks3;
+    const PackJob3& pj = jobs.j[job];
+    float m = 0.f;
+    for (long i = (long)blk * 256 + threadIdx.x; i < pj.count; i += (long)kWmaxBlocks3 * 256) m = fmaxf(m, fabsf(pj.w[i]));
+    m = fsc::wave_max(m);
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) pj.part[blk] = fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3]));
 }
 
 // -------------------------------------------------------------------------------------------
 // Forward / dgrad.  See the head of the file.  POOL / STATS as in conv_l16_fwd_kernel.
-template <int KH, int KW, int CT, int PTW, int NPROD, bool POOL = false, bool STATS = false>
+// F16: the limbs are scaled fp16 (arith 10, l16.h) -- v_mfma_f32_16x16x32_f16, and the accumulators leave through
+// 1 / (input scale * weight scale) (powers of two: exact), from the declared maxima `in_amax` (FSC_AMAX_FLOATS) and `w_amax`.
+template <int KH, int KW, int CT, int PTW, int NPROD, bool F16 = false, bool POOL = false, bool STATS = false>
 __global__ __launch_bounds__(kWaves * 64) void conv_l3_fwd_kernel(L3Geom g, const uint4* __restrict__ in,
                                                                    const uint4* __restrict__ packed,
                                                                    const float* __restrict__ bias, float* __restrict__ out,
                                                                    int accumulate, uint8_t* __restrict__ pool_idx,
                                                                    const float* __restrict__ stat_pivot,
-                                                                   float4* __restrict__ stat_rec) {
+                                                                   float4* __restrict__ stat_rec,
+                                                                   const float* __restrict__ in_amax,
+                                                                   const float* __restrict__ w_amax) {
     constexpr int TAPS = KH * KW;
     constexpr int PADH = KH / 2, PADW = KW / 2;
     using P = Prods<NPROD>;
+    float oscale = 1.f;
+    if constexpr (F16) {
+        const float ax = wave_amax512(in_amax), aw = *w_amax;
+        oscale = l16::inv_scale(l16::scale_field(ax), ax) * l16::inv_scale(l16::scale_field(aw), aw);
+        oscale = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, oscale)));
+    }
 
     extern __shared__ __attribute__((aligned(16))) uint4 smem4[];
     uint4* const ibase = smem4;
@@ -335,12 +397,20 @@ __global__ __launch_bounds__(kWaves * 64) void conv_l3_fwd_kernel(L3Geom g, cons
 
     // ---- input DMA: chunk c into `stage`; wave wid copies units wid and wid + 8 (unit = octet * 3 + limb)
     const uint4* const zero = reinterpret_cast<const uint4*>(g_zero16_3);
+#ifndef FSC_L3_COPYGRP
+#define FSC_L3_COPYGRP 1
+#endif
+    // FSC_L3_COPYGRP: the copies of a chunk are issued by the waves of channel group 1 alone (three planes each; the group with the
+    // smaller half of an odd block).  Its partner on the SIMD (same pixel group, channel group 0) goes straight from the barrier into
+    // its MFMAs, so the matrix pipe works through the ~0.6 k cycles of address arithmetic and copy issue instead of standing still
+    // while all eight waves issue (cycle stamps: 630 - 1900 cycles per step of hand-over, independent of the number of products).
     auto issue_i = [&](int stage, int c, int tile) {
+        if (FSC_L3_COPYGRP && cw == 0) return;
         int pos_off[kNptMax];
         plan_input(tile, pos_off);
 #pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            const int u = wid + 8 * k;
+        for (int k = 0; k < (FSC_L3_COPYGRP ? 3 : 2); ++k) {
+            const int u = FSC_L3_COPYGRP ? pw + 4 * k : wid + 8 * k;
             if (u < kUnits) {
                 const int ol = u / 3;
                 const int oct = c * 4 + ol;
@@ -488,8 +558,8 @@ __global__ __launch_bounds__(kWaves * 64) void conv_l3_fwd_kernel(L3Geom g, cons
                 constexpr int p = decltype(p_c)::value;
 #pragma unroll
                 for (int j = 0; j < PTW; ++j) {
-                    if (FSC_L3_TMPACC) tmp[j] = mfma_bf(A[i][P::la[p]], B[j][P::lb[p]], p == 0 ? (f32x4){0.f, 0.f, 0.f, 0.f} : tmp[j]);
-                    else acc[i][j] = mfma_bf(A[i][P::la[p]], B[j][P::lb[p]], acc[i][j]);
+                    if (FSC_L3_TMPACC) tmp[j] = mfma_l<F16>(A[i][P::la[p]], B[j][P::lb[p]], p == 0 ? (f32x4){0.f, 0.f, 0.f, 0.f} : tmp[j]);
+                    else acc[i][j] = mfma_l<F16>(A[i][P::la[p]], B[j][P::lb[p]], acc[i][j]);
                 }
                 if constexpr (last && (p + 1 == NPROD || P::lb[p + 1 < NPROD ? p + 1 : p] != P::lb[p])) {
                     // this B limb is done for the step: the next step's fragments of it go behind these MFMAs
@@ -581,7 +651,7 @@ __global__ __launch_bounds__(kWaves * 64) void conv_l3_fwd_kernel(L3Geom g, cons
                     for (int j = 0; j < PTW; ++j) {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
-                            const float v0 = acc[i][j][r] + bv[r];
+                            const float v0 = F16 ? fmaf(acc[i][j][r], oscale, bv[r]) : acc[i][j][r] + bv[r];
                             const float v1 = dpp_xor1(v0);
                             const float v2 = dpp_xor8(v0);
                             const float v3 = dpp_xor8(v1);
@@ -651,7 +721,8 @@ __global__ __launch_bounds__(kWaves * 64) void conv_l3_fwd_kernel(L3Geom g, cons
 #pragma unroll
                     for (int j = 0; j < PTW; ++j) {
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) scratch[(kq_e * 4 + r) * kScr + lm_e] = acc[i][j][r] + bv[r];
+                        for (int r = 0; r < 4; ++r)
+                            scratch[(kq_e * 4 + r) * kScr + lm_e] = F16 ? fmaf(acc[i][j][r], oscale, bv[r]) : acc[i][j][r] + bv[r];
                         const f32x4 v = *reinterpret_cast<const f32x4*>(scratch + ch * kScr + (lane_e & 3) * 4);
                         if (STATS && co < g.cout && quad_ok[j]) {
                             if (quad_ok[j] == 15) {
@@ -728,6 +799,7 @@ __global__ __launch_bounds__(kWaves * 64) void conv_l3_fwd_kernel(L3Geom g, cons
 struct L3Plan {
     L3Geom g;
     int ct, ptw, co_blocks, nprod;
+    bool f16;                 // scaled fp16 limbs (arith 10)
     size_t lds_bytes;
     long tiles, workers;
 };
@@ -832,70 +904,76 @@ bool plan_l3_pt(const fsc_conv_desc& d_in, int dgrad, int ptw, L3Plan* out, bool
     return true;
 }
 
-int nprod_of(int arith) { return arith == 6 ? 6 : arith == 8 ? 8 : 9; }
+int nprod_of(int arith) { return arith == 6 || l16::is_f3(arith) ? 6 : arith == 8 ? 8 : 9; }
 
 bool plan_l3(const fsc_conv_desc& d, int dgrad, L3Plan* out) {
-    if (!l16::is_bf3(d.arith)) return false;
+    if (!l16::is_l3(d.arith)) return false;
     if (fsc::env().no_l16) return false;
     const int force_pt = fsc::env().l16_pt;                 // development (FSC_L16_PT = 2 | 1): 256- / 128-pixel tiles
     bool ok = false;
     if ((!force_pt || force_pt == 2) && plan_l3_pt(d, dgrad, 4, out)) ok = true;
     else if (force_pt != 2 && plan_l3_pt(d, dgrad, 2, out)) ok = true;
-    if (ok) out->nprod = nprod_of(d.arith);
+    if (ok) {
+        out->nprod = nprod_of(d.arith);
+        out->f16 = l16::is_f3(d.arith);
+    }
     return ok;
 }
 
 bool plan_l3_pool(const fsc_conv_desc& d, L3Plan* out) {
-    if (!l16::is_bf3(d.arith)) return false;
+    if (!l16::is_l3(d.arith)) return false;
     if (fsc::env().no_l16 || fsc::env().no_l16_pool) return false;
     if (d.kh != 3 || d.kw != 3 || d.h < 2 || d.w < 8) return false;
     L3Plan plain;
     if (!plan_l3(d, 0, &plain) || plain.ptw != 4) return false;
     if (!plan_l3_pt(d, 0, 4, out, true)) return false;
     out->nprod = nprod_of(d.arith);
+    out->f16 = l16::is_f3(d.arith);
     return out->g.cot == plain.g.cot && out->co_blocks == plain.co_blocks && out->g.steps == plain.g.steps;
 }
 
 size_t l3_packed_u4(const L3Plan& p) { return (size_t)p.co_blocks * p.g.steps * p.g.cot * 3 * 64; }
+// scaled fp16 limbs: behind the fragments, max |w| (4 floats: 16-byte alignment) and the partial maxima of the pack
+constexpr size_t kWTailFloats = 4 + kWmaxBlocks3;
 
 bool stats_ok3(const L3Plan& p) { return p.workers >= p.co_blocks; }
 
 struct StatArgs3 { const float* pivot; float4* rec; };
-struct PoolArgs3 { uint8_t* idx; };
+struct ScaleArgs3 { const float* in_amax; const float* w_amax; };
 
-template <int KH, int KW, int CT, int PTW, int NPROD, bool POOL, bool STATS>
+template <int KH, int KW, int CT, int PTW, int NPROD, bool F16, bool POOL, bool STATS>
 int launch3(const L3Plan& p, const uint4* in, const uint4* packed, const float* bias, float* out, int accumulate, uint8_t* idx,
-            StatArgs3 sa, hipStream_t st) {
-    auto kern = conv_l3_fwd_kernel<KH, KW, CT, PTW, NPROD, POOL, STATS>;
+            StatArgs3 sa, ScaleArgs3 sc, hipStream_t st) {
+    auto kern = conv_l3_fwd_kernel<KH, KW, CT, PTW, NPROD, F16, POOL, STATS>;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes);
     hipLaunchKernelGGL(kern, dim3((unsigned)p.workers), dim3(kWaves * 64), p.lds_bytes, st, p.g, in, packed, bias, out, accumulate, idx,
-                       sa.pivot, sa.rec);
-    FSC_LAUNCH_CHECK("fsc_conv_l16_fwd(bf16 limbs)");
+                       sa.pivot, sa.rec, sc.in_amax, sc.w_amax);
+    FSC_LAUNCH_CHECK("fsc_conv_l16_fwd(three limbs)");
     return 0;
 }
 
-template <int KH, int KW, int CT, int PTW, int NPROD>
+template <int KH, int KW, int CT, int PTW, int NPROD, bool F16>
 int launch3_var(const L3Plan& p, const uint4* in, const uint4* packed, const float* bias, float* out, int accumulate, uint8_t* idx,
-                StatArgs3 sa, hipStream_t st) {
+                StatArgs3 sa, ScaleArgs3 sc, hipStream_t st) {
     if (idx) {
         if constexpr (KH == 3 && PTW == 4) {
-            if (sa.rec) return launch3<KH, KW, CT, PTW, NPROD, true, true>(p, in, packed, bias, out, 0, idx, sa, st);
-            return launch3<KH, KW, CT, PTW, NPROD, true, false>(p, in, packed, bias, out, 0, idx, sa, st);
+            if (sa.rec) return launch3<KH, KW, CT, PTW, NPROD, F16, true, true>(p, in, packed, bias, out, 0, idx, sa, sc, st);
+            return launch3<KH, KW, CT, PTW, NPROD, F16, true, false>(p, in, packed, bias, out, 0, idx, sa, sc, st);
         }
         fsc::set_error("fsc_conv_l16_pool_fwd: internal: no pooled instantiation");
         return 22;
     }
-    if (sa.rec) return launch3<KH, KW, CT, PTW, NPROD, false, true>(p, in, packed, bias, out, 0, nullptr, sa, st);
-    return launch3<KH, KW, CT, PTW, NPROD, false, false>(p, in, packed, bias, out, accumulate, nullptr, sa, st);
+    if (sa.rec) return launch3<KH, KW, CT, PTW, NPROD, F16, false, true>(p, in, packed, bias, out, 0, nullptr, sa, sc, st);
+    return launch3<KH, KW, CT, PTW, NPROD, F16, false, false>(p, in, packed, bias, out, accumulate, nullptr, sa, sc, st);
 }
 
-template <int KH, int KW, int NPROD>
+template <int KH, int KW, int NPROD, bool F16>
 int launch3_ct(const L3Plan& p, const uint4* in, const uint4* packed, const float* bias, float* out, int accumulate, uint8_t* idx,
-               StatArgs3 sa, hipStream_t st) {
-#define FSC_L3_CASE(CT_)                                                                                                   \
-    case CT_:                                                                                                              \
-        if (p.ptw == 4) return launch3_var<KH, KW, CT_, 4, NPROD>(p, in, packed, bias, out, accumulate, idx, sa, st);     \
-        return launch3_var<KH, KW, CT_, 2, NPROD>(p, in, packed, bias, out, accumulate, idx, sa, st);
+               StatArgs3 sa, ScaleArgs3 sc, hipStream_t st) {
+#define FSC_L3_CASE(CT_)                                                                                                        \
+    case CT_:                                                                                                                   \
+        if (p.ptw == 4) return launch3_var<KH, KW, CT_, 4, NPROD, F16>(p, in, packed, bias, out, accumulate, idx, sa, sc, st); \
+        return launch3_var<KH, KW, CT_, 2, NPROD, F16>(p, in, packed, bias, out, accumulate, idx, sa, sc, st);
     switch (p.ct) {
 #ifndef FSC_L16_DEV
         FSC_L3_CASE(2)
@@ -906,27 +984,38 @@ int launch3_ct(const L3Plan& p, const uint4* in, const uint4* packed, const floa
         default: break;
     }
 #undef FSC_L3_CASE
-    fsc::set_error("fsc_conv_l16_fwd: internal: no bf16-limb instantiation for %d channel tiles per wave", p.ct);
+    fsc::set_error("fsc_conv_l16_fwd: internal: no three-limb instantiation for %d channel tiles per wave", p.ct);
     return 22;
 }
 
 int launch3_any(const L3Plan& p, int taps, const uint4* in, const uint4* packed, const float* bias, float* out, int accumulate,
-                uint8_t* idx, StatArgs3 sa, hipStream_t st) {
+                uint8_t* idx, StatArgs3 sa, const float* in_amax, hipStream_t st) {
+    ScaleArgs3 sc{nullptr, nullptr};
+    if (p.f16) {
+        sc.in_amax = in_amax;
+        sc.w_amax = reinterpret_cast<const float*>(packed + l3_packed_u4(p));
+#ifndef FSC_L3_NO_F16
+        if (taps == 9) return launch3_ct<3, 3, 6, true>(p, in, packed, bias, out, accumulate, idx, sa, sc, st);
+        return launch3_ct<1, 1, 6, true>(p, in, packed, bias, out, accumulate, idx, sa, sc, st);
+#endif
+    }
+#ifndef FSC_L3_NO_BF16
     if (p.nprod == 9) {
-        if (taps == 9) return launch3_ct<3, 3, 9>(p, in, packed, bias, out, accumulate, idx, sa, st);
-        return launch3_ct<1, 1, 9>(p, in, packed, bias, out, accumulate, idx, sa, st);
-    }
-#ifdef FSC_L3_ALL_PRODS
-    if (p.nprod == 8) {
-        if (taps == 9) return launch3_ct<3, 3, 8>(p, in, packed, bias, out, accumulate, idx, sa, st);
-        return launch3_ct<1, 1, 8>(p, in, packed, bias, out, accumulate, idx, sa, st);
-    }
-    if (p.nprod == 6) {
-        if (taps == 9) return launch3_ct<3, 3, 6>(p, in, packed, bias, out, accumulate, idx, sa, st);
-        return launch3_ct<1, 1, 6>(p, in, packed, bias, out, accumulate, idx, sa, st);
+        if (taps == 9) return launch3_ct<3, 3, 9, false>(p, in, packed, bias, out, accumulate, idx, sa, sc, st);
+        return launch3_ct<1, 1, 9, false>(p, in, packed, bias, out, accumulate, idx, sa, sc, st);
     }
 #endif
-    fsc::set_error("fsc_conv_l16_fwd: this build has no bf16-limb kernels with %d products", p.nprod);
+#ifdef FSC_L3_ALL_PRODS
+    if (p.nprod == 8) {
+        if (taps == 9) return launch3_ct<3, 3, 8, false>(p, in, packed, bias, out, accumulate, idx, sa, sc, st);
+        return launch3_ct<1, 1, 8, false>(p, in, packed, bias, out, accumulate, idx, sa, sc, st);
+    }
+    if (p.nprod == 6) {
+        if (taps == 9) return launch3_ct<3, 3, 6, false>(p, in, packed, bias, out, accumulate, idx, sa, sc, st);
+        return launch3_ct<1, 1, 6, false>(p, in, packed, bias, out, accumulate, idx, sa, sc, st);
+    }
+#endif
+    fsc::set_error("fsc_conv_l16_fwd: this build has no three-limb kernels with %d products%s", p.nprod, p.f16 ? " (fp16)" : "");
     return 22;
 }
 
@@ -939,6 +1028,7 @@ bool valid3(const fsc_conv_desc* d) {
 PackDir3 make_dir3(const L3Plan& p, float* packed, int dgrad) {
     PackDir3 r{};
     r.packed = reinterpret_cast<uint4*>(packed);
+    r.w_amax = p.f16 ? packed + l3_packed_u4(p) * 4 : nullptr;
     r.cot = p.g.cot; r.co_blocks = p.co_blocks; r.nfull = p.g.nfull; r.tail_oct = p.g.tail_oct; r.steps = p.g.steps;
     r.dgrad = dgrad;
     r.frags = (long)p.co_blocks * p.g.steps * p.g.cot * 64;
@@ -955,21 +1045,21 @@ namespace l3 {
 
 size_t tensor_bytes(int n, int c, long hw) { return (size_t)n * ((c + 7) / 8) * 3 * (size_t)hw * 16; }
 
-int pack(const float* x, int n, int c, long hw, void* out, hipStream_t st) {
+int pack(const float* x, int n, int c, long hw, const float* amax, void* out, hipStream_t st) {
     const long total = (long)n * ((c + 7) / 8) * hw;
     long blocks = (total + 255) / 256;
     if (blocks > 16384) blocks = 16384;
-    hipLaunchKernelGGL(l3_pack_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, n, c, hw, reinterpret_cast<uint4*>(out));
-    FSC_LAUNCH_CHECK("fsc_l16_pack(bf16 limbs)");
+    hipLaunchKernelGGL(l3_pack_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, n, c, hw, amax, reinterpret_cast<uint4*>(out));
+    FSC_LAUNCH_CHECK("fsc_l16_pack(three limbs)");
     return 0;
 }
 
-int unpack(const void* in, int n, int c, long hw, float* x, hipStream_t st) {
+int unpack(const void* in, int n, int c, long hw, const float* amax, float* x, hipStream_t st) {
     const long total = (long)n * ((c + 7) / 8) * hw;
     long blocks = (total + 255) / 256;
     if (blocks > 16384) blocks = 16384;
-    hipLaunchKernelGGL(l3_unpack_kernel, dim3((unsigned)blocks), dim3(256), 0, st, reinterpret_cast<const uint4*>(in), n, c, hw, x);
-    FSC_LAUNCH_CHECK("fsc_l16_unpack(bf16 limbs)");
+    hipLaunchKernelGGL(l3_unpack_kernel, dim3((unsigned)blocks), dim3(256), 0, st, reinterpret_cast<const uint4*>(in), n, c, hw, amax, x);
+    FSC_LAUNCH_CHECK("fsc_l16_unpack(three limbs)");
     return 0;
 }
 
@@ -986,22 +1076,14 @@ int pool_supported(const fsc_conv_desc* d) {
 size_t packed_floats(const fsc_conv_desc* d, int dgrad) {
     L3Plan p;
     if (!valid3(d) || !plan_l3(*d, dgrad, &p)) return 0;
-    return l3_packed_u4(p) * 4;
+    return l3_packed_u4(p) * 4 + (p.f16 ? kWTailFloats : 0);
 }
 
+int pack_weights_multi(int count, const fsc_conv_desc* descs, const float* const* weights, float* const* packed_fwd,
+                       float* const* packed_dgrad, hipStream_t st);
 int pack_weights_pair(const fsc_conv_desc* d, const float* weight, float* packed_fwd, float* packed_dgrad, hipStream_t st) {
     FSC_CHECK_ARG(valid3(d) && weight && (packed_fwd || packed_dgrad), "fsc_conv_l16_pack_weights_pair: bad arguments");
-    L3Plan pf{}, pd{};
-    FSC_CHECK_ARG(!packed_fwd || plan_l3(*d, 0, &pf), "fsc_conv_l16_pack_weights_pair: no forward tiling for this shape");
-    FSC_CHECK_ARG(!packed_dgrad || plan_l3(*d, 1, &pd), "fsc_conv_l16_pack_weights_pair: no dgrad tiling for this shape");
-    PackDir3 a{}, b{};
-    if (packed_fwd) a = make_dir3(pf, packed_fwd, 0);
-    if (packed_dgrad) b = make_dir3(pd, packed_dgrad, 1);
-    if (!packed_fwd) { a = b; b = PackDir3{}; }
-    hipLaunchKernelGGL(l3_pack_w_kernel, dim3((unsigned)(a.blocks + b.blocks)), dim3(256), 0, st, weight, d->c_out, d->c_in, d->kh * d->kw,
-                       a, b);
-    FSC_LAUNCH_CHECK("fsc_conv_l16_pack_weights(bf16 limbs)");
-    return 0;
+    return pack_weights_multi(1, d, &weight, &packed_fwd, &packed_dgrad, st);
 }
 
 int pack_weights_multi(int count, const fsc_conv_desc* descs, const float* const* weights, float* const* packed_fwd,
@@ -1010,6 +1092,7 @@ int pack_weights_multi(int count, const fsc_conv_desc* descs, const float* const
         PackJobs3 jobs{};
         jobs.n = count - base < kMultiPack3 ? count - base : kMultiPack3;
         int blocks = 0;
+        bool f16 = false;
         for (int k = 0; k < jobs.n; ++k) {
             const fsc_conv_desc* d = descs + base + k;
             float* pf_out = packed_fwd[base + k];
@@ -1021,39 +1104,45 @@ int pack_weights_multi(int count, const fsc_conv_desc* descs, const float* const
             PackJob3& pj = jobs.j[k];
             pj.w = weights[base + k];
             pj.c_out = d->c_out; pj.c_in = d->c_in; pj.taps = d->kh * d->kw;
+            pj.count = (long)d->c_out * d->c_in * pj.taps;
+            f16 = f16 || l16::is_f3(d->arith);
             PackDir3 a{}, b{};
             if (pf_out) a = make_dir3(pf, pf_out, 0);
             if (pd_out) b = make_dir3(pd, pd_out, 1);
             if (!pf_out) { a = b; b = PackDir3{}; }
             pj.a = a; pj.b = b;
+            pj.part = a.w_amax ? a.w_amax + 4 : nullptr;
             pj.first_block = blocks;
             blocks += a.blocks + b.blocks;
         }
+        if (f16) hipLaunchKernelGGL(l3_wmax_multi_kernel, dim3((unsigned)(jobs.n * kWmaxBlocks3)), dim3(256), 0, st, jobs);
         hipLaunchKernelGGL(l3_pack_w_multi_kernel, dim3((unsigned)blocks), dim3(256), 0, st, jobs);
     }
-    FSC_LAUNCH_CHECK("fsc_conv_l16_pack_weights_multi(bf16 limbs)");
+    FSC_LAUNCH_CHECK("fsc_conv_l16_pack_weights_multi(three limbs)");
     return 0;
 }
 
-int fwd(const fsc_conv_desc* d, const void* in_l16, const float* packed, const float* bias, int dgrad, int accumulate, float* out,
-        const float* stat_pivot, void* stat_rec, hipStream_t st) {
+int fwd(const fsc_conv_desc* d, const void* in_l16, const float* in_amax, const float* packed, const float* bias, int dgrad,
+        int accumulate, float* out, const float* stat_pivot, void* stat_rec, hipStream_t st) {
     L3Plan p;
     FSC_CHECK_ARG(valid3(d) && in_l16 && packed && out, "fsc_conv_l16_fwd: bad descriptor or null pointer");
+    FSC_CHECK_ARG(!l16::is_f3(d->arith) || in_amax, "fsc_conv_l16_fwd: scaled fp16 limbs need the input's declared maximum");
     FSC_CHECK_ARG(!(dgrad && bias), "fsc_conv_l16_fwd: dgrad takes no bias");
     FSC_CHECK_ARG(plan_l3(*d, dgrad, &p), "fsc_conv_l16_fwd: unsupported shape (see fsc_conv_l16_supported)");
     FSC_CHECK_ARG(!stat_rec || stats_ok3(p), "fsc_conv_l16_fwd_stats: unsupported shape (see fsc_conv_l16_stats_layout)");
     return launch3_any(p, d->kh * d->kw, reinterpret_cast<const uint4*>(in_l16), reinterpret_cast<const uint4*>(packed), bias, out,
-                       accumulate, nullptr, StatArgs3{stat_pivot, reinterpret_cast<float4*>(stat_rec)}, st);
+                       accumulate, nullptr, StatArgs3{stat_pivot, reinterpret_cast<float4*>(stat_rec)}, in_amax, st);
 }
 
-int pool_fwd(const fsc_conv_desc* d, const void* in_l16, const float* packed, const float* bias, float* pooled, uint8_t* idx,
-             const float* stat_pivot, void* stat_rec, hipStream_t st) {
+int pool_fwd(const fsc_conv_desc* d, const void* in_l16, const float* in_amax, const float* packed, const float* bias, float* pooled,
+             uint8_t* idx, const float* stat_pivot, void* stat_rec, hipStream_t st) {
     L3Plan p;
     FSC_CHECK_ARG(valid3(d) && in_l16 && packed && pooled && idx, "fsc_conv_l16_pool_fwd: bad descriptor or null pointer");
+    FSC_CHECK_ARG(!l16::is_f3(d->arith) || in_amax, "fsc_conv_l16_pool_fwd: scaled fp16 limbs need the input's declared maximum");
     FSC_CHECK_ARG(plan_l3_pool(*d, &p), "fsc_conv_l16_pool_fwd: unsupported shape (see fsc_conv_l16_pool_supported)");
     FSC_CHECK_ARG(!stat_rec || stats_ok3(p), "fsc_conv_l16_pool_fwd_stats: unsupported shape (see fsc_conv_l16_stats_layout)");
     return launch3_any(p, 9, reinterpret_cast<const uint4*>(in_l16), reinterpret_cast<const uint4*>(packed), bias, pooled, 0, idx,
-                       StatArgs3{stat_pivot, reinterpret_cast<float4*>(stat_rec)}, st);
+                       StatArgs3{stat_pivot, reinterpret_cast<float4*>(stat_rec)}, in_amax, st);
 }
 
 int stats_layout(const fsc_conv_desc* d, int pool, int* out4) {
@@ -1069,8 +1158,8 @@ int plan_describe(const fsc_conv_desc* d, int dgrad, char* buf, size_t buf_len) 
     FSC_CHECK_ARG(valid3(d) && buf && buf_len > 0 && plan_l3(*d, dgrad, &p), "fsc_conv_l16_plan_describe: unsupported shape");
     // (the name is the kernel instantiation: <KH, KW, channel tiles per WAVE, pixel tiles per wave, limb products>; `cot` = channel
     // tiles per block, halved between the two wave groups)
-    snprintf(buf, buf_len, "conv_l3_fwd_kernel<%d,%d,%d,%d,%d> cot=%d box=%dx%dx%d items=%ldx%d workers=%ld steps=%d lds=%zu", d->kh,
-             d->kw, p.ct, p.ptw, p.nprod, p.g.cot, p.g.nb, p.g.th, p.g.tw, p.tiles, p.co_blocks, p.workers, p.g.steps, p.lds_bytes);
+    snprintf(buf, buf_len, "conv_l3_fwd_kernel<%d,%d,%d,%d,%d%s> cot=%d box=%dx%dx%d items=%ldx%d workers=%ld steps=%d lds=%zu", d->kh,
+             d->kw, p.ct, p.ptw, p.nprod, p.f16 ? ",f16" : "", p.g.cot, p.g.nb, p.g.th, p.g.tw, p.tiles, p.co_blocks, p.workers, p.g.steps, p.lds_bytes);
     return 0;
 }
 

@@ -76,24 +76,57 @@ __device__ __forceinline__ void split8_bf3(const float (&v)[8], uint4& h, uint4&
     split3_pair(v[6], v[7], h.w, m.w, l.w);
 }
 
+
+// ---- three SCALED fp16 limbs (arith 10, "f16x6"): with the power-of-two scale s of the two-limb format, x * s = h + m + l with
+// h = rne_f16(x s), m = rne_f16(x s - h), l = rne_f16(x s - h - m): 11 + 11 + 11 significand bits -- the 24 bits of x exactly
+// while the last bit of x s is >= 2^-24 (the fp16 subnormal step), i.e. |x| >= 2^-16 max|tensor|; smaller elements keep an
+// ABSOLUTE error <= 2^-25 / s <= 2^-39 max|tensor| (an fp32 accumulation of such a tensor rounds at 2^-24 of its partial sums).
+// Six of the nine limb products (all but m*l, l*m, l*l <= 2^-32 |a b|) form the product of two fp32 operands to 2^-32: as exact,
+// for an fp32 accumulator, as all nine of the unscaled bf16 limbs, at 6 / 9 of the MFMA work.
+__host__ __device__ inline bool is_f3(int arith) { return arith == 10; }
+__host__ __device__ inline bool is_l3(int arith) { return is_bf3(arith) || is_f3(arith); }
+// L16 format codes of the `limbs` arguments of include/fsc_hip.h
+constexpr int kFmtF16x2 = 2, kFmtBf16x3 = 3, kFmtF16x3 = 4;
+__host__ __device__ constexpr int fmt_limbs(int fmt) { return fmt == kFmtF16x2 ? 2 : 3; }
+__host__ __device__ constexpr bool fmt_scaled(int fmt) { return fmt != kFmtBf16x3; }
+typedef _Float16 f16x2_l16 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void split3s_pair(float x0, float x1, float s, unsigned& h, unsigned& m, unsigned& l) {
+    const float t0 = x0 * s, t1 = x1 * s;                                   // (exact: s is a power of two)
+    const f16x2_l16 hp = {(_Float16)t0, (_Float16)t1};
+    const float r0 = fsub1(t0, (float)hp[0]), r1 = fsub1(t1, (float)hp[1]);  // exact
+    const f16x2_l16 mp = {(_Float16)r0, (_Float16)r1};
+    const float q0 = fsub1(r0, (float)mp[0]), q1 = fsub1(r1, (float)mp[1]);  // exact
+    const f16x2_l16 lp = {(_Float16)q0, (_Float16)q1};
+    h = __builtin_bit_cast(unsigned, hp);
+    m = __builtin_bit_cast(unsigned, mp);
+    l = __builtin_bit_cast(unsigned, lp);
+}
+__device__ __forceinline__ void split8_f3(const float (&v)[8], float s, uint4& h, uint4& m, uint4& l) {
+    split3s_pair(v[0], v[1], s, h.x, m.x, l.x);
+    split3s_pair(v[2], v[3], s, h.y, m.y, l.y);
+    split3s_pair(v[4], v[5], s, h.z, m.z, l.z);
+    split3s_pair(v[6], v[7], s, h.w, m.w, l.w);
+}
+
 }  // namespace l16
 
-// conv_l3.hip: the bf16-limb (three limbs, arith 9 / 8 / 6) kernels behind the fsc_conv_l16_* / fsc_l16_* entry points
+// conv_l3.hip: the three-limb (bf16: arith 9 / 8 / 6; scaled fp16: arith 10) kernels behind the fsc_conv_l16_* / fsc_l16_* entry points
 namespace fsc {
 namespace l3 {
 size_t tensor_bytes(int n, int c, long hw);
-int pack(const float* x, int n, int c, long hw, void* out, hipStream_t st);
-int unpack(const void* in, int n, int c, long hw, float* x, hipStream_t st);
+// (amax / in_amax: the FSC_AMAX_FLOATS buffer of the scaled fp16 format, NULL for bf16 limbs)
+int pack(const float* x, int n, int c, long hw, const float* amax, void* out, hipStream_t st);
+int unpack(const void* in, int n, int c, long hw, const float* amax, float* x, hipStream_t st);
 int supported(const fsc_conv_desc* d, int dgrad);
 int pool_supported(const fsc_conv_desc* d);
 size_t packed_floats(const fsc_conv_desc* d, int dgrad);
 int pack_weights_pair(const fsc_conv_desc* d, const float* weight, float* packed_fwd, float* packed_dgrad, hipStream_t st);
 int pack_weights_multi(int count, const fsc_conv_desc* descs, const float* const* weights, float* const* packed_fwd,
                        float* const* packed_dgrad, hipStream_t st);
-int fwd(const fsc_conv_desc* d, const void* in_l16, const float* packed, const float* bias, int dgrad, int accumulate, float* out,
-        const float* stat_pivot, void* stat_rec, hipStream_t st);
-int pool_fwd(const fsc_conv_desc* d, const void* in_l16, const float* packed, const float* bias, float* pooled, uint8_t* idx,
-             const float* stat_pivot, void* stat_rec, hipStream_t st);
+int fwd(const fsc_conv_desc* d, const void* in_l16, const float* in_amax, const float* packed, const float* bias, int dgrad,
+        int accumulate, float* out, const float* stat_pivot, void* stat_rec, hipStream_t st);
+int pool_fwd(const fsc_conv_desc* d, const void* in_l16, const float* in_amax, const float* packed, const float* bias, float* pooled,
+             uint8_t* idx, const float* stat_pivot, void* stat_rec, hipStream_t st);
 int stats_layout(const fsc_conv_desc* d, int pool, int* out4);
 int plan_describe(const fsc_conv_desc* d, int dgrad, char* buf, size_t buf_len);
 int last_clock(double* shader_mhz);

@@ -765,18 +765,21 @@ __device__ __forceinline__ float block_max256(float m, float* red) {
 // lines, 4x the write requests.  Instead each wave transposes through its own LDS patch (80-byte lane pitch: conflict-free
 // 16-byte writes) so that instruction k stores positions 64 k + lane of the wave's 256 -- 1 KB contiguous.  Needs the wave's
 // lanes on consecutive quads (position lanes >= 64) and EVERY lane of the wave calling (dead lanes pass anything).
-// NL limbs: 2 (scaled fp16 pairs) or 3 (exact bf16 triples); lv[p][limb]; limb planes hw apart from out0.
+// NL = the L16 format code (l16.h): 2 (scaled fp16 pairs), 3 (exact bf16 triples) or 4 (scaled fp16 triples); lv[p][limb]; limb
+// planes hw apart from out0.
+#define FSC_NLIMBS(NL) l16::fmt_limbs(NL)
 template <int NL>
-__device__ __forceinline__ void l16_split(const float (&v8)[8], float s, uint4 (&out)[NL]) {
+__device__ __forceinline__ void l16_split(const float (&v8)[8], float s, uint4 (&out)[FSC_NLIMBS(NL)]) {
     if constexpr (NL == 2) l16::split8(v8, s, out[0], out[1]);
+    else if constexpr (NL == 4) l16::split8_f3(v8, s, out[0], out[1], out[2]);
     else l16::split8_bf3(v8, out[0], out[1], out[2]);
 }
 template <int NL>
-__device__ __forceinline__ void l16_store_quads(uint4* __restrict__ out0, long q, long hw, const uint4 (&lv)[4][NL], uint4* wave_patch) {
+__device__ __forceinline__ void l16_store_quads(uint4* __restrict__ out0, long q, long hw, const uint4 (&lv)[4][FSC_NLIMBS(NL)], uint4* wave_patch) {
     const int lane = threadIdx.x & 63;
     const long p0 = 4 * (q - lane);                          // first position of the wave's 256
 #pragma unroll
-    for (int limb = 0; limb < NL; ++limb) {
+    for (int limb = 0; limb < FSC_NLIMBS(NL); ++limb) {
 #pragma unroll
         for (int p = 0; p < 4; ++p) wave_patch[lane * 5 + p] = lv[p][limb];
         uint4* out = out0 + limb * hw;
@@ -797,7 +800,7 @@ __global__ __launch_bounds__(kThreads) void fwd_l16_kernel(
     __shared__ float red[kThreads / 64];
     const bool has_alpha = alpha != nullptr;
     float s = 1.f;
-    if constexpr (NL == 2) {                                 // (bf16 limbs carry the fp32 exponent: no scale, no declared maximum)
+    if constexpr (l16::fmt_scaled(NL)) {                                 // (bf16 limbs carry the fp32 exponent: no scale, no declared maximum)
         float m = 0.f;
         for (int ch = threadIdx.x; ch < c; ch += kThreads) {
             const float sc = scale[ch], sh = shift[ch], al = has_alpha ? alpha[ch] : 0.f;
@@ -825,7 +828,7 @@ __global__ __launch_bounds__(kThreads) void fwd_l16_kernel(
     }
     const long nq = hw / VEC;
     const long xbase = ((long)img * c + o * 8) * hw;
-    uint4* const out0 = y16 + (((long)img * oct + o) * NL) * hw;
+    uint4* const out0 = y16 + (((long)img * oct + o) * FSC_NLIMBS(NL)) * hw;
     __shared__ uint4 patch[kThreads / 64][64 * 5];
     const bool transpose = VEC == 4 && hwp >= 64;            // (uniform)
     const int lane = threadIdx.x & 63;
@@ -850,7 +853,7 @@ __global__ __launch_bounds__(kThreads) void fwd_l16_kernel(
                 if (y && live) y[xbase + e * hw + q] = z[e][0];
             }
         }
-        uint4 lv[VEC][NL];
+        uint4 lv[VEC][FSC_NLIMBS(NL)];
 #pragma unroll
         for (int p = 0; p < VEC; ++p) {
             const float v8[8] = {z[0][p], z[1][p], z[2][p], z[3][p], z[4][p], z[5][p], z[6][p], z[7][p]};
@@ -865,7 +868,7 @@ __global__ __launch_bounds__(kThreads) void fwd_l16_kernel(
 #pragma unroll
         for (int p = 0; p < VEC; ++p)
 #pragma unroll
-            for (int l = 0; l < NL; ++l) out0[l * hw + q * VEC + p] = lv[p][l];
+            for (int l = 0; l < FSC_NLIMBS(NL); ++l) out0[l * hw + q * VEC + p] = lv[p][l];
     }
 }
 
@@ -1315,7 +1318,7 @@ __global__ __launch_bounds__(kThreads) void bwd_apply_l16_kernel(BwdArgs a, cons
                                                                   float* __restrict__ dx_amax, int hwp_log2) {
     __shared__ float red[kThreads / 64];
     float s = 1.f;
-    if (NL == 2 || dx_amax != nullptr) {                     // (bf16 limbs need no scale; the bound is still published when asked for)
+    if (l16::fmt_scaled(NL) || dx_amax != nullptr) {                     // (bf16 limbs need no scale; the bound is still published when asked for)
         float m = 0.f;
         for (int ch = threadIdx.x; ch < a.c; ch += kThreads) m = fmaxf(m, coef[2 * a.c + ch]);
         m = block_max256(m, red);
@@ -1332,7 +1335,7 @@ __global__ __launch_bounds__(kThreads) void bwd_apply_l16_kernel(BwdArgs a, cons
     const bool has_alpha = a.alpha != nullptr;
     const long nq = g_live ? hw / VEC : 0;
     const long xbase = ((long)img * c + o * 8) * hw;
-    uint4* const out0 = dx16 + (((long)img * oct + o) * NL) * hw;
+    uint4* const out0 = dx16 + (((long)img * oct + o) * FSC_NLIMBS(NL)) * hw;
     __shared__ uint4 patch[kThreads / 64][64 * 5];
     const bool transpose = VEC == 4 && hwp >= 64;            // (uniform; see l16_store_quads)
     const int lane = threadIdx.x & 63;
@@ -1386,7 +1389,7 @@ __global__ __launch_bounds__(kThreads) void bwd_apply_l16_kernel(BwdArgs a, cons
                 for (int p = 0; p < VEC; ++p) d[e][p] = 0.f;
             }
         }
-        uint4 lv[VEC][NL];
+        uint4 lv[VEC][FSC_NLIMBS(NL)];
 #pragma unroll
         for (int p = 0; p < VEC; ++p) {
             const float v8[8] = {d[0][p], d[1][p], d[2][p], d[3][p], d[4][p], d[5][p], d[6][p], d[7][p]};
@@ -1401,7 +1404,7 @@ __global__ __launch_bounds__(kThreads) void bwd_apply_l16_kernel(BwdArgs a, cons
 #pragma unroll
         for (int p = 0; p < VEC; ++p)
 #pragma unroll
-            for (int l = 0; l < NL; ++l) out0[l * hw + q * VEC + p] = lv[p][l];
+            for (int l = 0; l < FSC_NLIMBS(NL); ++l) out0[l * hw + q * VEC + p] = lv[p][l];
     }
 }
 
@@ -1416,7 +1419,7 @@ __global__ __launch_bounds__(kThreads) void bwd_apply_unpool_l16_kernel(BwdArgs 
                                                                          float* __restrict__ dc_amax, int hwp_log2) {
     __shared__ float red[kThreads / 64];
     float s = 1.f;
-    if (NL == 2 || dc_amax != nullptr) {
+    if (l16::fmt_scaled(NL) || dc_amax != nullptr) {
         float m = 0.f;
         for (int ch = threadIdx.x; ch < a.c; ch += kThreads) m = fmaxf(m, coef[2 * a.c + ch]);
         m = block_max256(m, red);
@@ -1432,7 +1435,7 @@ __global__ __launch_bounds__(kThreads) void bwd_apply_unpool_l16_kernel(BwdArgs 
     const int o = g_live ? (int)(g / a.n) : 0, img = g_live ? (int)(g - (long)o * a.n) : 0;
     const bool has_alpha = a.alpha != nullptr;
     const long xbase = ((long)img * c + o * 8) * hw;
-    uint4* const out0 = dc16 + (((long)img * oct + o) * NL) * HW;
+    uint4* const out0 = dc16 + (((long)img * oct + o) * FSC_NLIMBS(NL)) * HW;
     const uint4 zero4 = make_uint4(0u, 0u, 0u, 0u);
     const long nq = g_live ? hw : 0;
     for (long q = (long)blockIdx.y * hwp + ti; q < nq; q += (long)gridDim.y * hwp) {
@@ -1472,22 +1475,22 @@ __global__ __launch_bounds__(kThreads) void bwd_apply_unpool_l16_kernel(BwdArgs 
             float v8[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) v8[e] = pos[e] == wpos ? d[e] : 0.f;
-            uint4 lv[NL];
+            uint4 lv[FSC_NLIMBS(NL)];
             l16_split<NL>(v8, s, lv);
             const long dst = (long)(oy * ph + (wpos >> 1)) * w + 2 * ox + (wpos & 1);
 #pragma unroll
-            for (int l = 0; l < NL; ++l) out0[l * HW + dst] = lv[l];
+            for (int l = 0; l < FSC_NLIMBS(NL); ++l) out0[l * HW + dst] = lv[l];
         }
         if ((w & 1) && ox == ow - 1) {                      // column floor-mode pooling never read
             for (int r = 0; r < ph; ++r)
 #pragma unroll
-                for (int l = 0; l < NL; ++l) out0[l * HW + (long)(oy * ph + r) * w + w - 1] = zero4;
+                for (int l = 0; l < FSC_NLIMBS(NL); ++l) out0[l * HW + (long)(oy * ph + r) * w + w - 1] = zero4;
         }
     }
     if (ph == 2 && (h & 1) && blockIdx.y == 0 && g_live) {  // trailing row
         for (int xx = ti; xx < w; xx += hwp) {
 #pragma unroll
-            for (int l = 0; l < NL; ++l) out0[l * HW + (long)(h - 1) * w + xx] = zero4;
+            for (int l = 0; l < FSC_NLIMBS(NL); ++l) out0[l * HW + (long)(h - 1) * w + xx] = zero4;
             if (dc)
                 for (int e = 0; e < 8; ++e)
                     if (o * 8 + e < c) dc[((long)img * c + o * 8 + e) * HW + (long)(h - 1) * w + xx] = 0.f;
@@ -1709,18 +1712,21 @@ int fsc_bn_act_fwd_limbs(const float* x, const float* residual, const float* sca
                          void* y_l16, int limbs, fsc_stream_t stream) {
     FSC_CHECK_ARG(x && scale && shift && (y || y_l16), "fsc_bn_act_fwd: null pointer");
     FSC_CHECK_ARG(n > 0 && c > 0 && hw > 0, "fsc_bn_act_fwd: bad shape (%d, %d, %ld)", n, c, hw);
-    FSC_CHECK_ARG(limbs == 2 || limbs == 3, "fsc_bn_act_fwd_limbs: limbs must be 2 or 3");
+    FSC_CHECK_ARG(limbs >= 2 && limbs <= 4, "fsc_bn_act_fwd_limbs: limbs must be 2, 3 or 4 (three scaled fp16 limbs)");
     hipStream_t st = fsc::as_stream(stream);
     if (y_l16) {
         FSC_CHECK_ARG(!residual && hw > 1, "fsc_bn_act_fwd: the L16 output takes no residual and needs hw > 1");
         FSC_CHECK_ARG(limbs == 3 || (x_minmax && y_amax),
-                      "fsc_bn_act_fwd: the two-limb L16 output needs x_minmax (fsc_bn_train_stats) and y_amax");
+                      "fsc_bn_act_fwd: the scaled fp16 L16 outputs need x_minmax (fsc_bn_train_stats) and y_amax");
         const L16Grid g = l16_grid(n, c, hw, true);
         uint4* y16 = reinterpret_cast<uint4*>(y_l16);
 #define FSC_FWD_L16(V_, U_)                                                                                                          \
     do {                                                                                                                             \
         if (limbs == 2)                                                                                                              \
             hipLaunchKernelGGL((fwd_l16_kernel<V_, U_, 2>), g.grid, dim3(kThreads), 0, st, x, scale, shift, alpha, x_minmax, y, y16, \
+                               y_amax, n, c, hw, g.hwp_log2);                                                                        \
+        else if (limbs == 4)                                                                                                         \
+            hipLaunchKernelGGL((fwd_l16_kernel<V_, U_, 4>), g.grid, dim3(kThreads), 0, st, x, scale, shift, alpha, x_minmax, y, y16, \
                                y_amax, n, c, hw, g.hwp_log2);                                                                        \
         else                                                                                                                         \
             hipLaunchKernelGGL((fwd_l16_kernel<V_, U_, 3>), g.grid, dim3(kThreads), 0, st, x, scale, shift, alpha, x_minmax, y, y16, \
@@ -1760,12 +1766,13 @@ int fsc_bn_act_bwd(const float* dy, const float* gmax_dy, const int* gmax_idx, c
                    const float* gamma, const float* beta, const float* alpha, float* dx, float* dresidual,
                    float* dgamma, float* dbeta, float* dalpha, float* dx_chan_sum, int n, int c, long hw,
                    void* workspace, float* dx_amax, double* sync, int phase, void* dx_l16, fsc_stream_t stream) {
-    FSC_CHECK_ARG(x && save_mean && save_invstd && (dx || dx_l16 || (phase & ~(FSC_BN_TICKETS | FSC_BN_L16_LIMBS3)) == 1) && workspace,
+    FSC_CHECK_ARG(x && save_mean && save_invstd && (dx || dx_l16 || (phase & ~(FSC_BN_TICKETS | FSC_BN_L16_LIMBS3 | FSC_BN_L16_F16X3)) == 1) && workspace,
                   "fsc_bn_act_bwd: null pointer");
-    const bool limbs3 = (phase & FSC_BN_L16_LIMBS3) != 0;
-    FSC_CHECK_ARG(!dx_l16 || ((dx_amax || limbs3) && hw > 1), "fsc_bn_act_bwd: the L16 output needs dx_amax (two limbs) and hw > 1");
+    const bool limbs3 = (phase & FSC_BN_L16_LIMBS3) != 0, f16x3 = (phase & FSC_BN_L16_F16X3) != 0;
+    FSC_CHECK_ARG(!(limbs3 && f16x3), "fsc_bn_act_bwd: FSC_BN_L16_LIMBS3 and FSC_BN_L16_F16X3 exclude each other");
+    FSC_CHECK_ARG(!dx_l16 || ((dx_amax || limbs3) && hw > 1), "fsc_bn_act_bwd: the L16 output needs dx_amax (scaled fp16 limbs) and hw > 1");
     const bool zero_tickets = (phase & FSC_BN_TICKETS) != 0;
-    phase &= ~(FSC_BN_TICKETS | FSC_BN_L16_LIMBS3);
+    phase &= ~(FSC_BN_TICKETS | FSC_BN_L16_LIMBS3 | FSC_BN_L16_F16X3);
     FSC_CHECK_ARG(phase == 0 || ((phase == 1 || phase == 2) && sync), "fsc_bn_act_bwd: phase 1 / 2 need `sync`");
     FSC_CHECK_ARG(dy || gmax_dy, "fsc_bn_act_bwd: no upstream gradient");
     FSC_CHECK_ARG((gmax_dy == nullptr) == (gmax_idx == nullptr), "fsc_bn_act_bwd: gmax_dy / gmax_idx must come in pairs");
@@ -1800,7 +1807,10 @@ int fsc_bn_act_bwd(const float* dy, const float* gmax_dy, const int* gmax_idx, c
         uint4* dx16 = reinterpret_cast<uint4*>(dx_l16);
 #define FSC_BWD_L16(V_, U_)                                                                                                    \
     do {                                                                                                                       \
-        if (!limbs3)                                                                                                           \
+        if (f16x3)                                                                                                             \
+            hipLaunchKernelGGL((bwd_apply_l16_kernel<V_, U_, 4>), g.grid, dim3(kThreads), 0, st, a, p.coef, dx, dx16, dresidual, \
+                               dx_amax, g.hwp_log2);                                                                           \
+        else if (!limbs3)                                                                                                      \
             hipLaunchKernelGGL((bwd_apply_l16_kernel<V_, U_, 2>), g.grid, dim3(kThreads), 0, st, a, p.coef, dx, dx16, dresidual, \
                                dx_amax, g.hwp_log2);                                                                           \
         else                                                                                                                   \
@@ -1838,10 +1848,11 @@ int fsc_bn_act_bwd_unpool(const float* dy, const float* x, const float* save_mea
                           int h, int w, int ph, void* workspace, float* dc_amax, double* sync, int phase,
                           void* dc_l16, fsc_stream_t stream) {
     FSC_CHECK_ARG(dy && x && save_mean && save_invstd && pool_idx && (dc || dc_l16) && workspace, "fsc_bn_act_bwd_unpool: null pointer");
-    const bool limbs3 = (phase & FSC_BN_L16_LIMBS3) != 0;
-    FSC_CHECK_ARG(!dc_l16 || dc_amax || limbs3, "fsc_bn_act_bwd_unpool: the two-limb L16 output needs dc_amax");
+    const bool limbs3 = (phase & FSC_BN_L16_LIMBS3) != 0, f16x3 = (phase & FSC_BN_L16_F16X3) != 0;
+    FSC_CHECK_ARG(!(limbs3 && f16x3), "fsc_bn_act_bwd_unpool: FSC_BN_L16_LIMBS3 and FSC_BN_L16_F16X3 exclude each other");
+    FSC_CHECK_ARG(!dc_l16 || dc_amax || limbs3, "fsc_bn_act_bwd_unpool: the scaled fp16 L16 outputs need dc_amax");
     const bool zero_tickets = (phase & FSC_BN_TICKETS) != 0;
-    phase &= ~(FSC_BN_TICKETS | FSC_BN_L16_LIMBS3);
+    phase &= ~(FSC_BN_TICKETS | FSC_BN_L16_LIMBS3 | FSC_BN_L16_F16X3);
     FSC_CHECK_ARG(phase == 0 || ((phase == 1 || phase == 2) && sync), "fsc_bn_act_bwd_unpool: phase 1 / 2 need `sync`");
     FSC_CHECK_ARG((ph == 1 || ph == 2) && n > 0 && c > 0 && h >= ph && w >= 2, "fsc_bn_act_bwd_unpool: bad shape");
     const int oh = h / ph, ow = w / 2;
@@ -1867,7 +1878,10 @@ int fsc_bn_act_bwd_unpool(const float* dy, const float* x, const float* save_mea
     if (dc_l16) {
         L16Grid g = l16_grid(n, c, hw, false);
         if (g.uni) g.hwp_log2 = 8;
-        if (!limbs3)
+        if (f16x3)
+            hipLaunchKernelGGL(bwd_apply_unpool_l16_kernel<4>, g.grid, dim3(kThreads), 0, st, a, p.coef, pool_idx, dc,
+                               reinterpret_cast<uint4*>(dc_l16), h, w, ph, oh, ow, dc_amax, g.hwp_log2);
+        else if (!limbs3)
             hipLaunchKernelGGL(bwd_apply_unpool_l16_kernel<2>, g.grid, dim3(kThreads), 0, st, a, p.coef, pool_idx, dc,
                                reinterpret_cast<uint4*>(dc_l16), h, w, ph, oh, ow, dc_amax, g.hwp_log2);
         else

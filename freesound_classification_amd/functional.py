@@ -240,19 +240,20 @@ class _timed:
             TIMER.records.append((self.name, self.flops, self.e0, self.e1))
 
 
-ARITH_NAMES = {"f32": 0, "bf16": 1, "f16x3": 3, "bf16x6": 6, "bf16x9": 9}
+ARITH_NAMES = {"f32": 0, "bf16": 1, "f16x3": 3, "bf16x6": 6, "bf16x9": 9, "f16x6": 10}
 
 
 def set_conv_arith(mode):
     """Arithmetic the descriptors built by this module ask for (fsc_conv_desc.arith, include/fsc_hip.h).
     0 / "f32": native fp32 MFMA; 3 / "f16x3" (the default): fp32 via two fp16 limbs with exact power-of-two
     operand scaling, three limb products; 6, 9 / "bf16x6", "bf16x9": fp32 via exact three-limb bf16 split with
-    that many limb products; 1 / "bf16": plain bf16 operands, fp32 accumulation (mixed precision, cfg 3); None: back to the library default (FSC_CONV_ARITH or 3).  Host-side convenience only:
+    that many limb products; 10 / "f16x6": three SCALED fp16 limbs, six products, on the pre-split (L16) route -- fp32-equivalent
+    (products to 2^-32) at two thirds of bf16x9's matrix work, bf16x9 wherever a layer has no L16 kernel; 1 / "bf16": plain bf16 operands, fp32 accumulation (mixed precision, cfg 3); None: back to the library default (FSC_CONV_ARITH or 3).  Host-side convenience only:
     the C ABI takes the mode per call."""
     global _ARITH
     mode = ARITH_NAMES.get(mode, mode)
-    if mode is not None and int(mode) not in (0, 1, 3, 6, 9):
-        raise _lib.FscError("conv arithmetic must be 0 (f32), 1 (bf16), 3 (f16x3), 6 (bf16x6) or 9 (bf16x9); got %r" % (mode,))
+    if mode is not None and int(mode) not in (0, 1, 3, 6, 9, 10):
+        raise _lib.FscError("conv arithmetic must be 0 (f32), 1 (bf16), 3 (f16x3), 6 (bf16x6), 9 (bf16x9) or 10 (f16x6); got %r" % (mode,))
     _ARITH = None if mode is None else int(mode)
 
 
@@ -391,7 +392,8 @@ def conv_dgrad(dout, weight, x_shape, accumulate_into=None, dout_amax=None):
 # ---- pre-split activations (include/fsc_hip.h "L16" tensors)
 class L16:
     """An activation held as 16-bit limbs in the MFMA operand layout: two scaled fp16 limbs plus the maximum the scale derives
-    from (arith 3), or three exact bf16 limbs (arith 9: no scale, amax is None)."""
+    from (arith 3; limbs = 2), three exact bf16 limbs (arith 9: no scale, amax is None; limbs = 3) or three scaled fp16 limbs
+    (arith 10; limbs = 4, the format code FSC_L16_F16X3 of include/fsc_hip.h)."""
     __slots__ = ("data", "amax", "shape", "limbs")
 
     def __init__(self, data, amax, shape, limbs=2):
@@ -400,16 +402,20 @@ class L16:
 
 def _l16_arith():
     """The arithmetic of the pre-split (L16) route under the current mode: 3 (two scaled fp16 limbs, three products), 9 (three
-    exact bf16 limbs, all nine products: fp32-exact), or None when the mode has no L16 kernels."""
+    exact bf16 limbs, all nine products: fp32-exact), 10 (three scaled fp16 limbs, six products), or None when the mode has no
+    L16 kernels."""
     a = get_conv_arith()
-    return a if a in (3, 9) else None
+    return a if a in (3, 9, 10) else None
 
 
 def _l16_limbs(arith=None):
-    return 3 if (_l16_arith() if arith is None else arith) == 9 else 2
+    """The L16 format code (the `limbs` argument of include/fsc_hip.h) of an arithmetic: 2, 3, or 4 (three scaled fp16 limbs)."""
+    return {9: 3, 10: 4}.get(_l16_arith() if arith is None else arith, 2)
 
 
 BN_L16_LIMBS3 = 64        # include/fsc_hip.h FSC_BN_L16_LIMBS3
+BN_L16_F16X3 = 128        # include/fsc_hip.h FSC_BN_L16_F16X3
+_BN_L16_FLAG = {3: BN_L16_LIMBS3, 4: BN_L16_F16X3}
 
 
 def l16_empty(shape, like, limbs=None):
@@ -424,7 +430,7 @@ def l16_empty(shape, like, limbs=None):
 def l16_pack(x, x_amax=None, limbs=None):
     """fp32 (N, C, ...) -> L16 (one read + one write; the fused producers write the format directly)."""
     limbs = _l16_limbs() if limbs is None else limbs
-    if limbs == 2:
+    if limbs != 3:
         x_amax = amax(x) if x_amax is None else x_amax
     else:
         x_amax = None
@@ -782,7 +788,7 @@ def measure_l16_clock(shape, kind, iters=40):
             for _ in range(iters):
                 conv_l16(t, wt, None, dgrad=kind == "dgrad", prepacked=pp)
         mhz = C.c_double(0.0)
-        call("fsc_conv_l16_last_clock", 1 if kind == "wgrad" else (2 if _l16_limbs() == 3 else 0), C.byref(mhz))
+        call("fsc_conv_l16_last_clock", 1 if kind == "wgrad" else (2 if _l16_limbs() in (3, 4) else 0), C.byref(mhz))
     finally:
         globals()["TIMER"] = timer
     return mhz.value
@@ -1117,10 +1123,10 @@ def bn_act_forward(x, st, alpha=None, residual=None, with_amax=False, l16=False,
     limbs = _l16_limbs()
     if l16 and (st.minmax is not None or limbs == 3) and residual is None and hw > 1:
         y = torch.empty_like(x) if want_f32 else None
-        t = L16(l16_empty(x.shape, x, limbs), _empty((AMAX_FLOATS,), x) if limbs == 2 else None, x.shape, limbs)
+        t = L16(l16_empty(x.shape, x, limbs), _empty((AMAX_FLOATS,), x) if limbs != 3 else None, x.shape, limbs)
         with _stage("bn_act_fwd", _nb(x, y, t)):
             call("fsc_bn_act_fwd_limbs", ptr(x), None, ptr(st.scale), ptr(st.shift), ptr(alpha), ptr(y),
-                 n, c, hw, ptr(t.amax), ptr(st.minmax) if limbs == 2 else None, ptr(t.data), limbs, stream_ptr())
+                 n, c, hw, ptr(t.amax), ptr(st.minmax) if limbs != 3 else None, ptr(t.data), limbs, stream_ptr())
         return y, t
     y = torch.empty_like(x)
     y_amax = _empty((AMAX_FLOATS,), x) if (with_amax or l16) and _want_amax() else None
@@ -1149,8 +1155,8 @@ def bn_act_backward(dy, x, st, bn, alpha=None, residual=None, gmax=None, want_dx
     csum = _empty((c,), x) if want_chan_sum and want_dx else None
     gdy, gidx = gmax if gmax is not None else (None, None)
     limbs = _l16_limbs()
-    lflag = BN_L16_LIMBS3 if (l16 and limbs == 3) else 0
-    dx_amax = _empty((AMAX_FLOATS,), x) if with_amax and want_dx and (_want_amax() or (l16 and limbs == 2)) else None
+    lflag = _BN_L16_FLAG.get(limbs, 0) if l16 else 0
+    dx_amax = _empty((AMAX_FLOATS,), x) if with_amax and want_dx and (_want_amax() or (l16 and limbs != 3)) else None
     t = L16(l16_empty(x.shape, x, limbs), dx_amax, x.shape, limbs) if l16 else None
     ws = _bn_ws(c, x)                                      # (kept alive across both phases)
     args = (ptr(dy), ptr(gdy), ptr(gidx), ptr(x), ptr(residual), ptr(st.mean),
@@ -1187,8 +1193,8 @@ def bn_act_backward_unpool(dy, x, st, bn, alpha, pool_idx, c_shape, ph, sync=Non
     dalpha = _empty((c,), x) if alpha is not None else None
     csum = _empty((c,), x)
     limbs = _l16_limbs()
-    lflag = BN_L16_LIMBS3 if (l16 and limbs == 3) else 0
-    dc_amax = _empty((AMAX_FLOATS,), x) if (_want_amax() or (l16 and limbs == 2)) else None
+    lflag = _BN_L16_FLAG.get(limbs, 0) if l16 else 0
+    dc_amax = _empty((AMAX_FLOATS,), x) if (_want_amax() or (l16 and limbs != 3)) else None
     t = L16(l16_empty(c_shape, x, limbs), dc_amax, c_shape, limbs) if l16 else None
     ws = _bn_ws(c, x)                                      # (kept alive across both phases)
     args = (ptr(dy), ptr(x), ptr(st.mean), ptr(st.invstd), ptr(bn.weight), ptr(bn.bias),
@@ -1411,7 +1417,7 @@ def _block_forward(x, mods, training, want_head, ph, keep, sync=None, next_bn=Fa
     w_a, b_a = _conv_params(conv_a)
 
     def mm(t, wt):           # inference: the BatchNorm in front of a convolution with an L16 tiling also reports the range of its input
-        return (not training) and EVAL_L16 and _l16_limbs() == 2 and t.dim() == 4 and _l16_ok_for(t.shape, wt, False)   # (bf16 limbs: no scale, no range)
+        return (not training) and EVAL_L16 and _l16_limbs() != 3 and t.dim() == 4 and _l16_ok_for(t.shape, wt, False)   # (bf16 limbs: no scale, no range)
 
     st_a = bn_prepare(x, bn_a, training, sync, counters, want_minmax=mm(x, w_a))
     # Operands of convolutions that have an L16 tiling are written pre-split by the BN / PReLU kernel that produces them

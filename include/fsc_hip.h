@@ -144,9 +144,16 @@ int fsc_conv_plan_describe(const fsc_conv_desc* d, int mode, char* buf, size_t b
  * master weights; relative operand error 2^-9, NOT fp32-accurate.
  * 6 / 9: every fp32 operand is split exactly into three bf16 limbs and the product is formed from 6 / 9
  * limb products on v_mfma_f32_16x16x32_bf16 with fp32 accumulation (9 = all terms: the product is exact
- * before accumulation; 6 drops terms below 2^-23 |a*b|).  Inputs, outputs and accumulators are fp32
+ * before accumulation; 6 drops terms below 2^-23 |a*b|).
+ * 10 ("f16x6", pre-split L16 tensors only -- fsc_conv_l16_*; the fp32-input entry points serve it as 9): every operand is scaled
+ * as in mode 3 and split into THREE fp16 limbs, x*s = h + m + l (11 + 11 + 11 significand bits: EXACT for every element down to
+ * 2^-16 of the tensor's declared maximum, an absolute error <= 2^-39 of that maximum below), and the product is formed from the
+ * six limb products hh + hm + mh + mm + hl + lh on v_mfma_f32_16x16x32_f16 (dropped: ml + lm + ll <= 2^-32 |a*b|), fp32
+ * accumulation, unscaled exactly.  For an fp32 accumulator -- which rounds every partial sum at 2^-24 -- that is the same
+ * arithmetic as mode 9 at two thirds of the matrix work; what it gives up is mode 9's independence of the operands' range.
+ * Inputs, outputs and accumulators are fp32
  * in every mode.  FSC_ARITH_DEFAULT selects the process default: 3, or the environment variable
- * FSC_CONV_ARITH = f32 | bf16 | f16x3 | bf16x6 | bf16x9, read once.  The packed-weight format depends on the mode:
+ * FSC_CONV_ARITH = f32 | bf16 | f16x3 | bf16x6 | bf16x9 | f16x6, read once.  The packed-weight format depends on the mode:
  * pack with the descriptor (same `arith`) the weights are used with. */
 int fsc_conv_default_arith(void);
 /* bytes of split-K workspace for the weight gradient */
@@ -181,8 +188,11 @@ int fsc_l16_unpack(const void* in_l16, int n, int c, long hw, const float* amax,
  * (8 + 8 + 8 significand bits, fp32 exponent range: no scale, `amax` is neither read nor written and may be NULL), layout
  * bf16[N][ceil(C / 8)][3 limbs][HW][8 channels], 6 bytes per element -- the operands of arith 9 (all nine limb products on
  * v_mfma_f32_16x16x32_bf16: each product is the exact product of the fp32 operands, fp32 accumulation; 8 / 6 drop the terms
- * below 2^-32 / 2^-23 |a*b|).  Every fsc_conv_l16_* entry point takes the format from fsc_conv_desc.arith (3 -> two limbs,
- * 9 / 8 / 6 -> three) and the producers from their `limbs` argument (fsc_bn_act_*_limbs). */
+ * below 2^-32 / 2^-23 |a*b|).  limbs = 4 (FSC_L16_F16X3): three SCALED fp16 limbs, x * s = h + m + l with the scale of the
+ * two-limb format (`amax` as there), same layout and size as limbs = 3 -- the operands of arith 10.  Every fsc_conv_l16_* entry
+ * point takes the format from fsc_conv_desc.arith (3 -> two fp16 limbs, 9 / 8 / 6 -> three bf16 limbs, 10 -> three fp16 limbs)
+ * and the producers from their `limbs` argument (fsc_bn_act_*_limbs) or phase flag. */
+#define FSC_L16_F16X3 4
 size_t fsc_l16_bytes_limbs(int n, int c, long hw, int limbs);
 int fsc_l16_pack_limbs(const float* x, int n, int c, long hw, const float* amax, int limbs, void* out_l16, fsc_stream_t stream);
 int fsc_l16_unpack_limbs(const void* in_l16, int n, int c, long hw, const float* amax, int limbs, float* x, fsc_stream_t stream);
@@ -241,6 +251,9 @@ size_t fsc_bn_workspace_bytes(int c);
  * limbs (fsc_l16_bytes_limbs(.., 3) bytes; the operands of arith 9) instead of two scaled fp16 limbs; the `*_amax` bound is then
  * optional (written when given). */
 #define FSC_BN_L16_LIMBS3 64
+/* the same for three SCALED fp16 limbs (fsc_l16_bytes_limbs(.., FSC_L16_F16X3); the operands of arith 10): `*_amax` is required
+ * as for two limbs.  Excludes FSC_BN_L16_LIMBS3. */
+#define FSC_BN_L16_F16X3 128
 size_t fsc_bn_workspace_ticket_offset(int c);
 int fsc_bn_workspace_reset(void* workspace, int c, fsc_stream_t stream);
 /* Cross-replica batch statistics (SyncBN for data parallelism; the reference is single-process so its
@@ -332,8 +345,8 @@ int fsc_bn_eval_prepare(int c, const float* gamma, const float* beta, const floa
 int fsc_bn_act_fwd(const float* x, const float* residual, const float* scale,
                    const float* shift, const float* alpha, float* y, int n, int c, long hw,
                    float* y_amax, const float* x_minmax, void* y_l16, fsc_stream_t stream);
-/* fsc_bn_act_fwd with the limb format of the L16 output spelled out: limbs = 2 (as above) or 3 (exact bf16 triples: no scale, so
- * x_minmax and y_amax are not needed and may be NULL). */
+/* fsc_bn_act_fwd with the limb format of the L16 output spelled out: limbs = 2 (as above), 3 (exact bf16 triples: no scale, so
+ * x_minmax and y_amax are not needed and may be NULL) or 4 (FSC_L16_F16X3, scaled fp16 triples: x_minmax and y_amax as for 2). */
 int fsc_bn_act_fwd_limbs(const float* x, const float* residual, const float* scale,
                          const float* shift, const float* alpha, float* y, int n, int c, long hw,
                          float* y_amax, const float* x_minmax, void* y_l16, int limbs, fsc_stream_t stream);

@@ -147,11 +147,11 @@ def cfg2_experiment(dropout=0.0):
                  scheduler="1cycle_0.0001_0.005", switch_off_augmentations_on=1000, _save_every=1000)))
 
 
-@pytest.fixture(scope="module", params=["f16x3", "bf16x9"])
+@pytest.fixture(scope="module", params=["f16x3", "bf16x9", "f16x6"])
 def cfg2_step(golden, request):
     """One training forward / backward + eval forward of the product at cfg-2 width on the fixture's inputs, in the shipped fast
     arithmetic (f16x3: two fp16 limbs, three products) and in the fp32-exact one (bf16x9: three bf16 limbs, nine products -- the
-    arithmetic bench.py's headline runs); the tests that use the fixture run in the same mode."""
+    arithmetic bench.py's headline runs; f16x6: three scaled fp16 limbs, six products); the tests that use the fixture run in the same mode."""
     g = golden("g12_cfg2_step.npz")
     mode0 = F.get_conv_arith()
     F.set_conv_arith(request.param)

@@ -1,7 +1,9 @@
 """The fp32-exact route (arith 9, "bf16x9") on PRE-SPLIT operands: three exact bf16 limbs per fp32 value, all nine limb
 products on v_mfma_f32_16x16x32_bf16, fp32 accumulation (csrc/conv_l3.hip, conv_l16_wgrad.hip<.., 3, 9>, the three-limb
 producers of norm_act.hip).  Replaces nn.Conv2d on fp32 tensors (reference networks/classifiers.py:526-531, 77-81) at the
-reference's own precision: every product is the exact product of the two fp32 operands.
+reference's own precision: every product is the exact product of the two fp32 operands.  And the same kernels on three SCALED
+fp16 limbs with six products (arith 10, "f16x6": products to 2^-32, operands exact down to 2^-16 of their tensor's maximum):
+every test of the route runs in both arithmetics, against the same bounds.
 
 * the format: fp32 -> limbs -> fp32 is the identity, bit for bit;
 * known-answer products that need all nine limb terms (the six-product and the two-limb fp16 arithmetic round differently);
@@ -37,6 +39,19 @@ def bf16x9():
     F.set_conv_arith(mode0)
 
 
+@pytest.fixture(params=[9, 10], ids=["bf16x9", "f16x6"])
+def l3(request):
+    """The three-limb arithmetics: yields fsc_conv_desc.arith."""
+    mode0 = F.get_conv_arith()
+    F.set_conv_arith(request.param)
+    yield request.param
+    F.set_conv_arith(mode0)
+
+
+SUFFIX = {9: ",9>", 10: ",6,f16>"}
+FMT = {9: 3, 10: 4}
+
+
 def test_three_limb_format_is_exact(bf16x9):
     """x -> (h, m, l) -> h + (m + l) reproduces every finite normal fp32 value bit for bit, whatever its magnitude (no scale,
     no declared maximum), for channel counts around the octet edges and odd plane sizes."""
@@ -51,6 +66,30 @@ def test_three_limb_format_is_exact(bf16x9):
         assert torch.equal(back, x)
 
 
+def test_scaled_fp16_three_limb_format():
+    """arith 10: x * s = h + m + l in fp16 with the tensor's power-of-two scale.  Elements within 2^-16 of the tensor's maximum come
+    back bit for bit; smaller ones within 2^-39 of the maximum (the fp16 subnormal step under the scale)."""
+    mode0 = F.get_conv_arith()
+    F.set_conv_arith(10)
+    try:
+        gen = torch.Generator(device=DEV).manual_seed(6)
+        for n, c, hw in ((3, 8, 64), (2, 13, 77), (1, 100, 215), (4, 33, 5)):
+            for top in (-60, 0, 50):
+                x = torch.randn(n, c, hw, 1, device=DEV, generator=gen).clamp_(-3.9, 3.9)
+                x = x * torch.exp2(torch.randint(-30, 1, x.shape, device=DEV, generator=gen).float() + top)
+                t = F.l16_pack(x)
+                assert t.limbs == 4 and t.amax is not None
+                assert t.data.numel() * 4 == n * ((c + 7) // 8) * 3 * hw * 16
+                back = F.l16_unpack(t)
+                amax = float(x.abs().max())
+                big = x.abs() >= 2.0 ** -15 * amax              # (2^-16 of the power of two above the maximum)
+                assert torch.equal(back[big], x[big])
+                assert float((back - x).abs().max()) <= 2.0 ** -39 * amax
+                assert int(big.sum()) > x.numel() // 4 and int((~big).sum()) > x.numel() // 4
+    finally:
+        F.set_conv_arith(mode0)
+
+
 def _single_product(a, b, arith):
     """a * b through the 1x1 convolution kernels: 96 input channels of which one carries the operands."""
     n, c, h, w = 32, 96, 16, 64
@@ -61,7 +100,7 @@ def _single_product(a, b, arith):
     mode0 = F.get_conv_arith()
     try:
         F.set_conv_arith(arith)
-        if arith == 9:
+        if arith in (9, 10):
             assert F.conv_l16_supported(F._desc(n, c, 48, h, w, 1, 1, arith), 0)
             y = F.conv_l16(F.l16_pack(x), wt, None)
         else:
@@ -95,20 +134,34 @@ def test_products_need_all_nine_limb_terms():
         assert abs(got - ex) <= 2.0 ** -23 * ex, (u, v, got, ex)
 
 
-def _plans(n, layer):
+def test_six_scaled_fp16_products_carry_24_bit_operands():
+    """a = 1 + 2^-12 + 2^-23 needs 24 significand bits: two fp16 limbs hold 1 + 2^-12 (arith 3 loses the last bit of a * 1), three hold
+    a exactly (arith 10); random 24-bit operands: within one fp32 ulp of the exact product (the dropped limb pairs are <= 2^-32)."""
+    a = 1.0 + 2.0 ** -12 + 2.0 ** -23
+    assert _single_product(a, 1.0, 10) == a
+    assert _single_product(a, 1.0, 3) == 1.0 + 2.0 ** -12
+    gen = torch.Generator().manual_seed(4)
+    for _ in range(8):
+        u = float(1.0 + torch.rand(1, generator=gen, dtype=torch.float64).float())
+        v = float(1.0 + torch.rand(1, generator=gen, dtype=torch.float64).float())
+        got = _single_product(u, v, 10)
+        assert abs(got - u * v) <= 2.0 ** -23 * u * v, (u, v, got, u * v)
+
+
+def _plans(n, layer, arith=9):
     c_in, c_out, h, w, k = layer
-    d = F._desc(n, c_in, c_out, h, w, k, k, 9)
+    d = F._desc(n, c_in, c_out, h, w, k, k, arith)
     return [F.l16_plan_name(d, 0), F.l16_plan_name(d, 1), F.l16_wgrad_plan_name(d)]
 
 
-def _batch_for(layer):
+def _batch_for(layer, arith=9):
     c_in, c_out, h, w, k = layer
     if h * w <= 8 * 26:
         return 128
-    full = _plans(128, layer)
+    full = _plans(128, layer, arith)
     for n in (2, 4, 8, 16, 32, 64):
-        d = F._desc(n, c_in, c_out, h, w, k, k, 9)
-        if all(F.conv_l16_supported(d, m) for m in (0, 1)) and F.conv_l16_wgrad_supported(d) and _plans(n, layer) == full:
+        d = F._desc(n, c_in, c_out, h, w, k, k, arith)
+        if all(F.conv_l16_supported(d, m) for m in (0, 1)) and F.conv_l16_wgrad_supported(d) and _plans(n, layer, arith) == full:
             return n
     return 128
 
@@ -116,24 +169,24 @@ def _batch_for(layer):
 L3_LAYERS = [l for l in LAYERS if l[0] >= 32 and l[2] * l[3] > 2 * 6]
 
 
-def test_the_cfg2_layers_take_the_three_limb_route(bf16x9):
+def test_the_cfg2_layers_take_the_three_limb_route(l3):
     """All 3 x 3 and 1 x 1 convolutions of the cfg-2 model from 100 channels @ 64 x 215 down to 759 @ 4 x 13 have a tiling in
     every direction at batch 128 (the stem and the 2 x 6-pixel block stay on the fp32-input nine-product kernels)."""
     for layer in L3_LAYERS:
         c_in, c_out, h, w, k = layer
-        d = F._desc(128, c_in, c_out, h, w, k, k, 9)
+        d = F._desc(128, c_in, c_out, h, w, k, k, l3)
         assert F.conv_l16_supported(d, 0) and F.conv_l16_supported(d, 1) and F.conv_l16_wgrad_supported(d), layer
-        names = _plans(128, layer)
-        assert names[0].startswith("conv_l3_fwd_kernel<%d,%d," % (k, k)) and names[0].endswith(",9>"), names
-        assert names[2].startswith("conv_l3_wgrad_kernel<%d,%d," % (k, k)) and names[2].endswith(",9>"), names
+        names = _plans(128, layer, l3)
+        assert names[0].startswith("conv_l3_fwd_kernel<%d,%d," % (k, k)) and names[0].split(" ")[0].endswith(SUFFIX[l3]), names
+        assert names[2].startswith("conv_l3_wgrad_kernel<%d,%d," % (k, k)) and names[2].split(" ")[0].endswith(SUFFIX[l3]), names
 
 
 @pytest.mark.parametrize("layer", L3_LAYERS, ids=["%dto%d_%dx%d_k%d" % l for l in L3_LAYERS])
-def test_cfg2_layer_on_three_limbs_against_fp64(layer, bf16x9):
+def test_cfg2_layer_on_three_limbs_against_fp64(layer, l3):
     c_in, c_out, h, w, k = layer
-    n = _batch_for(layer)
-    names = _plans(n, layer)
-    assert names == _plans(128, layer), (names, _plans(128, layer))
+    n = _batch_for(layer, l3)
+    names = _plans(n, layer, l3)
+    assert names == _plans(128, layer, l3), (names, _plans(128, layer, l3))
     torch.manual_seed(c_in * 7 + c_out + h)
     pad = k // 2
     x = torch.randn(n, c_in, h, w)
@@ -157,8 +210,8 @@ def test_cfg2_layer_on_three_limbs_against_fp64(layer, bf16x9):
     g_dx = float((dx.double() - dx64).abs().max())
     g_dxa = float((dxa.double() - (dx64 + base.double())).abs().max())
     g_dw = float((dw.double() - dw64).abs().max())
-    _report("%-22s arith 9 (three limbs) n %3d  fwd %.2e (torch f32 %.2e, x%.2f) %s | dgrad %.2e (%.2e, x%.2f) %s | wgrad %.2e (%.2e, x%.2f) %s"
-            % ("%dto%d_%dx%d_k%d" % layer, n, g_y, e_y, g_y / e_y, names[0], g_dx, e_dx, g_dx / e_dx, names[1], g_dw, e_dw,
+    _report("%-22s arith %2d (three limbs) n %3d  fwd %.2e (torch f32 %.2e, x%.2f) %s | dgrad %.2e (%.2e, x%.2f) %s | wgrad %.2e (%.2e, x%.2f) %s"
+            % ("%dto%d_%dx%d_k%d" % layer, l3, n, g_y, e_y, g_y / e_y, names[0], g_dx, e_dx, g_dx / e_dx, names[1], g_dw, e_dw,
                g_dw / e_dw, names[2]))
     eps = 2.0 ** -23
 
@@ -179,13 +232,13 @@ def test_cfg2_layer_on_three_limbs_against_fp64(layer, bf16x9):
 
 @pytest.mark.parametrize("shape", [(48, 64, 10, 20, 3), (56, 100, 7, 33, 3), (100, 170, 9, 12, 3), (49, 81, 16, 16, 3), (136, 96, 5, 44, 1),
                                    (100, 337, 8, 26, 3)])
-def test_three_limb_conv_odd_shapes_against_fp64(shape, bf16x9):
+def test_three_limb_conv_odd_shapes_against_fp64(shape, l3):
     """Channel counts around every tile / octet / chunk edge (remainder chunks, half-empty wave groups, short last blocks),
     odd planes, several images per box; at the smallest batch that has a persistent tiling (>= 128 work items) in both directions."""
     c_in, c_out, h, w, k = shape
     n = None
     for cand in (8, 16, 32, 64, 128):
-        d = F._desc(cand, c_in, c_out, h, w, k, k, 9)
+        d = F._desc(cand, c_in, c_out, h, w, k, k, l3)
         if F.conv_l16_supported(d, 0) and F.conv_l16_supported(d, 1):
             n = cand
             break
@@ -218,26 +271,36 @@ def _BN(c, gen):
 
 
 @pytest.mark.parametrize("shape", [(4, 100, 16, 43), (3, 37, 9, 20), (2, 150, 32, 107), (5, 24, 1, 300), (128, 48, 3, 5)])
-def test_producers_write_the_limbs_of_what_they_write_as_fp32(shape, bf16x9):
+def test_producers_write_the_limbs_of_what_they_write_as_fp32(shape, l3):
     """BatchNorm + PReLU forward, its backward and the backward fused with the max-pool un-pooling: the three-limb output,
-    recombined, equals the fp32 output of the same call bit for bit (the limbs are exact; nothing is scaled or bounded)."""
+    recombined, equals the fp32 output of the same call bit for bit (bf16 limbs are exact; nothing is scaled or bounded) -- with
+    scaled fp16 limbs, bit for bit for every element within 2^-16 of the declared maximum and to 2^-39 of that maximum below."""
     n, c, h, w = shape
+
+    def same(t, ref):
+        assert t.limbs == FMT[l3]
+        back = F.l16_unpack(t)
+        if l3 == 9:
+            return torch.equal(back, ref)
+        top = float(t.amax.max())                              # the declared bound (>= the largest element)
+        assert top >= float(ref.abs().max()) and top <= 4.0 * float(ref.abs().max()) + 1e-30
+        big = ref.abs() >= 2.0 ** -15 * top
+        return torch.equal(back[big], ref[big]) and float((back - ref).abs().max()) <= 2.0 ** -39 * top
+
     gen = torch.Generator(device=DEV).manual_seed(n + c + h + w)
     x = torch.randn(n, c, h, w, device=DEV, generator=gen)
     bn = _BN(c, gen)
     alpha = 0.25 + 0.1 * torch.rand(c, device=DEV, generator=gen)
     st = F.bn_prepare(x, bn, True)
     y, t = F.bn_act_forward(x, st, alpha, l16=True, want_f32=True)
-    assert t is not None and t.limbs == 3
-    assert torch.equal(F.l16_unpack(t), y)
+    assert t is not None and same(t, y)
     y_plain = F.bn_act_forward(x, st, alpha)
     assert torch.equal(y_plain, y)
     # backward
     dy = torch.randn(n, c, h, w, device=DEV, generator=gen) * torch.exp2(torch.randint(-30, 1, (n, 1, 1, 1), device=DEV, generator=gen).float())
     res = F.bn_act_backward(dy, x, st, bn, alpha, want_dres=False, want_chan_sum=True, with_amax=True, l16=True, want_f32=True)
     dx, t2 = res[0], res[-1]
-    assert isinstance(t2, F.L16) and t2.limbs == 3
-    assert torch.equal(F.l16_unpack(t2), dx)
+    assert isinstance(t2, F.L16) and same(t2, dx)
     ref = F.bn_act_backward(dy, x, st, bn, alpha, want_dres=False, want_chan_sum=True)
     assert torch.equal(ref[0], dx)
     for a, b in zip(ref[2:5], res[2:5]):
@@ -251,15 +314,14 @@ def test_producers_write_the_limbs_of_what_they_write_as_fp32(shape, bf16x9):
     stp = F.bn_prepare(pooled, bn, True)
     out = F.bn_act_backward_unpool(dy, pooled, stp, bn, alpha, idx, c_shape, ph, l16=True, want_f32=True)
     dc, t3 = out[0], out[-1]
-    assert isinstance(t3, F.L16) and t3.limbs == 3
-    assert torch.equal(F.l16_unpack(t3), dc)
+    assert isinstance(t3, F.L16) and same(t3, dc)
     ref = F.bn_act_backward_unpool(dy, pooled, stp, bn, alpha, idx, c_shape, ph)
     # (the un-pooling kernel without limb output is a different kernel with a different thread layout; same arithmetic)
     assert float((ref[0] - dc).abs().max()) <= 1e-6 * float(dc.abs().max())
 
 
 @pytest.mark.parametrize("shape", [(64, 100, 150, 16, 48), (8, 150, 225, 32, 107), (128, 64, 100, 8, 24)])
-def test_three_limb_conv_fused_with_maxpool_and_statistics(shape, bf16x9):
+def test_three_limb_conv_fused_with_maxpool_and_statistics(shape, l3):
     """fsc_conv_l16_pool_fwd(_stats) on three-limb operands: pooled values and window indices equal conv + fsc_maxpool_fwd bit
     for bit; the statistics of the epilogue (plain and pooled) finalise to the mean / invstd of the separate pass."""
     n, c_in, c_out, h, w = shape

@@ -21,8 +21,12 @@ def main():
     ap.add_argument("--n", type=int, default=None)
     ap.add_argument("--wgrad", action="store_true")
     ap.add_argument("--f64", action="store_true", help="also compare with an fp64 convolution on the CPU (use a small --n)")
+    ap.add_argument("--arith", type=int, default=9, help="9 (default), 8 / 6 (development builds with -DFSC_L3_ALL_PRODS), 10 (f16x6)")
     a = ap.parse_args()
-    F.set_conv_arith("bf16x9")
+    F.set_conv_arith("f16x6" if a.arith == 10 else "bf16x9")
+    if a.arith not in (9, 10):
+        F._l16_arith = lambda: a.arith
+        F._l16_limbs = lambda arith=None: 3
     dev = torch.device("cuda")
     names = a.names or [k for k in SHAPES if k != "b0e"]
     for name in names:
@@ -34,7 +38,7 @@ def main():
         wt = torch.randn(cout, cin, k, k, device=dev) / (cin * k * k) ** 0.5
         bias = torch.randn(cout, device=dev)
         gy = torch.randn(n, cout, h, w, device=dev)
-        d = F._desc(n, cin, cout, h, w, k, k, 9)
+        d = F._desc(n, cin, cout, h, w, k, k, a.arith)
         fl = 2.0 * n * h * w * cin * cout * k * k
         if a.wgrad:
             if not F.conv_l16_wgrad_supported(d):

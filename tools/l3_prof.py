@@ -16,7 +16,8 @@ if HAVE_FWD:
     prof = lib.fsc_debug_l3_prof
     prof.argtypes = [C.c_void_p]
 buf = (C.c_ulonglong * 64)()
-F.set_conv_arith("bf16x9")
+ARITH = int(os.environ.get("L3_ARITH", "9"))        # 9 (bf16x9) or 10 (f16x6)
+F.set_conv_arith(ARITH)
 dev = torch.device("cuda")
 names = sys.argv[1:] or ["b0c2", "b1e", "b1c2", "b2c2", "b3c2", "b0c1"]
 for name in (names if HAVE_FWD else []):
@@ -27,7 +28,7 @@ for name in (names if HAVE_FWD else []):
     bias = torch.randn(cout, device=dev)
     t = F.l16_pack(x)
     pp = F.conv_l16_pack(wt, n, h, w, False)
-    d = F._desc(n, cin, cout, h, w, k, k, 9)
+    d = F._desc(n, cin, cout, h, w, k, k, ARITH)
     for _ in range(2):
         F.conv_l16(t, wt, bias, prepacked=pp)
     prof(buf)
@@ -58,7 +59,7 @@ if hasattr(lib, "fsc_debug_l16w_prof"):
     wprof.argtypes = [C.c_void_p]
     for name in names:
         n, cin, cout, h, w, k = SHAPES[name]
-        d = F._desc(n, cin, cout, h, w, k, k, 9)
+        d = F._desc(n, cin, cout, h, w, k, k, ARITH)
         if not F.conv_l16_wgrad_supported(d):
             continue
         torch.manual_seed(1)
