@@ -245,30 +245,18 @@ def cfg2_experiment():
 BATCH32_TOL = 1e-3
 
 
-def test_cfg2_model_batch32_gradients_against_the_oracle_in_fp64():
-    """One training forward / backward of the real 21.5 M-parameter cfg-2 model at batch 32 x 10 s (the head's BatchNorm1d layers
-    normalise over 32 rows, not the 4 of fixture g12) against the CPU oracle evaluated in fp64 on the same weights and inputs.
-    North star: logits and loss within 1e-3; gradients: every tensor within 1e-3 rms of its scale max(1, |g|max) and >= 99.9 % of
-    all elements within 1e-3 of that scale.  What exceeds it is counted (max-pool / global-max winners that differ between an
-    fp32 and an fp64 evaluation: one flipped window moves the weight gradients of one output channel), and the same census is
-    taken for the CPU oracle run in fp32 -- the reference's own arithmetic -- against the same fp64 evaluation."""
+@pytest.fixture(scope="module")
+def batch32_oracle():
+    """Weights, inputs and the CPU oracle's batch-32 step in fp64 and in fp32 (computed once for every arithmetic tested)."""
     torch.manual_seed(20)
     m = TwoDimensionalCNNClassificationModel(cfg2_experiment(), device="cuda:0")
     state = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+    del m
     n = 32
     gen = torch.Generator().manual_seed(5)
     signal = 0.1 * torch.randn(n, 441000, 1, generator=gen)
     labels = (torch.rand(n, 80, generator=gen) < 0.02).float()
     labels[torch.arange(n), torch.randint(0, 80, (n,), generator=gen)] = 1.0
-    m.train()
-    logits = m(signal.to(DEV))["class_logits"]
-    per = lsep_loss(logits, labels.to(DEV), average=False)
-    F.mean(per).backward()
-    grads = {k: p.grad.detach().cpu() for k, p in m.named_parameters()}
-    logits, per = logits.detach().cpu(), per.detach().cpu()
-    del m
-    torch.cuda.empty_cache()
-
     torch.set_num_threads(min(64, os.cpu_count() or 1))
 
     def oracle(dtype):
@@ -284,6 +272,36 @@ def test_cfg2_model_batch32_gradients_against_the_oracle_in_fp64():
 
     rl, rper, g64 = oracle(torch.float64)
     _, _, g32 = oracle(torch.float32)                      # the reference's own arithmetic: the yard-stick
+    return dict(state=state, signal=signal, labels=labels, rl=rl, rper=rper, g64=g64, g32=g32)
+
+
+@pytest.mark.parametrize("arith", ["f16x3", "f16x6"])
+def test_cfg2_model_batch32_gradients_against_the_oracle_in_fp64(batch32_oracle, arith):
+    """One training forward / backward of the real 21.5 M-parameter cfg-2 model at batch 32 x 10 s (the head's BatchNorm1d layers
+    normalise over 32 rows, not the 4 of fixture g12) against the CPU oracle evaluated in fp64 on the same weights and inputs, in
+    the library's default arithmetic (f16x3) and in the one bench.py's headline runs (f16x6).
+    North star: logits and loss within 1e-3; gradients: every tensor within 1e-3 rms of its scale max(1, |g|max) and >= 99.9 % of
+    all elements within 1e-3 of that scale.  What exceeds it is counted (max-pool / global-max winners that differ between an
+    fp32 and an fp64 evaluation: one flipped window moves the weight gradients of one output channel), and the same census is
+    taken for the CPU oracle run in fp32 -- the reference's own arithmetic -- against the same fp64 evaluation."""
+    o = batch32_oracle
+    rl, rper, g64, g32 = o["rl"], o["rper"], o["g64"], o["g32"]
+    mode0 = F.get_conv_arith()
+    F.set_conv_arith(arith)
+    try:
+        m = TwoDimensionalCNNClassificationModel(cfg2_experiment(), device="cuda:0")
+        m.load_state_dict(o["state"])
+        m.train()
+        logits = m(o["signal"].to(DEV))["class_logits"]
+        per = lsep_loss(logits, o["labels"].to(DEV), average=False)
+        F.mean(per).backward()
+        grads = {k: p.grad.detach().cpu() for k, p in m.named_parameters()}
+        logits, per = logits.detach().cpu(), per.detach().cpu()
+        del m
+    finally:
+        F.set_conv_arith(mode0)
+        F.forget_packed_weights()
+    torch.cuda.empty_cache()
 
     def census(got):
         total = beyond = 0
@@ -303,10 +321,10 @@ def test_cfg2_model_batch32_gradients_against_the_oracle_in_fp64():
     d_logits = float((logits.double() - rl).abs().max())
     d_loss = float((per.double() - rper).abs().max())
     ours, cpu = census(grads), census(g32)
-    for who, (w_rms, w_max, beyond, total) in (("accelerated", ours), ("CPU oracle fp32", cpu)):
+    for who, (w_rms, w_max, beyond, total) in (("accelerated (%s)" % arith, ours), ("CPU oracle fp32", cpu)):
         _report("cfg2 batch 32 vs fp64 oracle, %s: %sworst per-tensor rms %.2e (%s), worst element %.2e (%s); %d of %d elements "
                 "(%.4f %%) beyond 1e-3 of their tensor's scale" % (
-                    who, ("logits %.2e loss %.2e; " % (d_logits, d_loss)) if who == "accelerated" else "", w_rms[1], w_rms[0],
+                    who, ("logits %.2e loss %.2e; " % (d_logits, d_loss)) if who.startswith("accelerated") else "", w_rms[1], w_rms[0],
                     w_max[1], w_max[0], beyond, total, 100.0 * beyond / total))
     assert d_logits < BATCH32_TOL and d_loss < BATCH32_TOL
     # Gradients: within 1e-3 (rms per tensor on its scale, 99.9 % of all elements) -- or, where the reference's own fp32 arithmetic
