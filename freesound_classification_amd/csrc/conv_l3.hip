@@ -69,10 +69,10 @@ __device__ unsigned long long g_l3_clock[2];
 
 // Development (-DFSC_L16_PROFILE): shader-clock stamps, summed per wave of workgroup 0 into g_l3_prof[wave][phase]; read and cleared
 // by fsc_debug_l3_prof.  Phases: 0 chunk hand-over (wait, barrier, copy issue), 1 the MFMA steps, 2 epilogue, 3 first fragments of an
-// item, 4 steps counted, 5 whole kernel, 6 the same in 100 MHz reference ticks.
+// item, 4 steps counted, 5 whole kernel, 6 the same in 100 MHz reference ticks, 7 the wait + barrier part of the hand-over (0 = its copy issue).
 #ifdef FSC_L16_PROFILE
 __device__ unsigned long long g_l3_prof[8][8];
-#define P3_DECL unsigned long long pf_t = __builtin_readcyclecounter(), pf_acc[7] = {0, 0, 0, 0, 0, 0, 0}; const unsigned long long pf_k0 = pf_t, pf_r0 = __builtin_amdgcn_s_memrealtime();
+#define P3_DECL unsigned long long pf_t = __builtin_readcyclecounter(), pf_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; const unsigned long long pf_k0 = pf_t, pf_r0 = __builtin_amdgcn_s_memrealtime();
 #define P3_ADD(i) do { const unsigned long long n_ = __builtin_readcyclecounter(); pf_acc[i] += n_ - pf_t; pf_t = n_; } while (0)
 #else
 #define P3_DECL
@@ -473,6 +473,11 @@ __global__ __launch_bounds__(kWaves * 64) void conv_l3_fwd_kernel(L3Geom g, cons
     }
 
     P3_DECL
+#if defined(FSC_L3_PRIO) && (FSC_L3_PRIO == 3 || FSC_L3_PRIO == 4)
+    // development: a fixed priority for one channel group (3: the copying group, 4: the other)
+    if ((FSC_L3_PRIO == 3) == (cw == 1)) __builtin_amdgcn_s_setprio(1);
+    else __builtin_amdgcn_s_setprio(0);
+#endif
     int item = t0;
     // consumer position (all uniform): step S of the item, chunk c, step sc of nst inside it, input stage stg
     int S = 0, c = 0, sc = 0, nst = g.nfull > 0 ? TAPS : g.tail_steps, stg = 0;
@@ -508,6 +513,7 @@ __global__ __launch_bounds__(kWaves * 64) void conv_l3_fwd_kernel(L3Geom g, cons
             else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * LIVE) : "memory");
             drain = false;
             raw_barrier();
+            P3_ADD(7);
             produce_i();           // (issued piecewise between the channel tiles of the step instead: +2.6 % cycles -- DESIGN 4.3)
             P3_ADD(0);
         }
@@ -766,7 +772,7 @@ __global__ __launch_bounds__(kWaves * 64) void conv_l3_fwd_kernel(L3Geom g, cons
     if (blockIdx.x == 0 && lane == 0) {
         pf_acc[5] = __builtin_readcyclecounter() - pf_k0;
         pf_acc[6] = __builtin_amdgcn_s_memrealtime() - pf_r0;
-        for (int i = 0; i < 7; ++i) atomicAdd(&g_l3_prof[wid][i], pf_acc[i]);
+        for (int i = 0; i < 8; ++i) atomicAdd(&g_l3_prof[wid][i], pf_acc[i]);
     }
 #endif
     if (blockIdx.x == 0 && tid == 0) {

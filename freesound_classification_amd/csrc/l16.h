@@ -89,17 +89,22 @@ __host__ __device__ inline bool is_l3(int arith) { return is_bf3(arith) || is_f3
 constexpr int kFmtF16x2 = 2, kFmtBf16x3 = 3, kFmtF16x3 = 4;
 __host__ __device__ constexpr int fmt_limbs(int fmt) { return fmt == kFmtF16x2 ? 2 : 3; }
 __host__ __device__ constexpr bool fmt_scaled(int fmt) { return fmt != kFmtBf16x3; }
-typedef _Float16 f16x2_l16 __attribute__((ext_vector_type(2)));
+// (eight mixed-precision FMAs per pair of values: h = rne16(x s), m = rne16(x s - h) in one rounding each, r = x s - h exactly in
+// fp32, l = rne16(r - m))
 __device__ __forceinline__ void split3s_pair(float x0, float x1, float s, unsigned& h, unsigned& m, unsigned& l) {
-    const float t0 = x0 * s, t1 = x1 * s;                                   // (exact: s is a power of two)
-    const f16x2_l16 hp = {(_Float16)t0, (_Float16)t1};
-    const float r0 = fsub1(t0, (float)hp[0]), r1 = fsub1(t1, (float)hp[1]);  // exact
-    const f16x2_l16 mp = {(_Float16)r0, (_Float16)r1};
-    const float q0 = fsub1(r0, (float)mp[0]), q1 = fsub1(r1, (float)mp[1]);  // exact
-    const f16x2_l16 lp = {(_Float16)q0, (_Float16)q1};
-    h = __builtin_bit_cast(unsigned, hp);
-    m = __builtin_bit_cast(unsigned, mp);
-    l = __builtin_bit_cast(unsigned, lp);
+    unsigned hp, mp, lp;
+    float r0, r1;
+    asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(hp) : "v"(x0), "v"(s));
+    asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(hp) : "v"(x1), "v"(s));
+    asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(mp) : "v"(x0), "v"(s), "v"(hp));
+    asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(mp) : "v"(x1), "v"(s), "v"(hp));
+    asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(r0) : "v"(x0), "v"(s), "v"(hp));
+    asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(r1) : "v"(x1), "v"(s), "v"(hp));
+    asm("v_fma_mixlo_f16 %0, %1, 1.0, -%2 op_sel_hi:[0,0,1]" : "=v"(lp) : "v"(r0), "v"(mp));
+    asm("v_fma_mixhi_f16 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(lp) : "v"(r1), "v"(mp));
+    h = hp;
+    m = mp;
+    l = lp;
 }
 __device__ __forceinline__ void split8_f3(const float (&v)[8], float s, uint4& h, uint4& m, uint4& l) {
     split3s_pair(v[0], v[1], s, h.x, m.x, l.x);

@@ -41,16 +41,16 @@ for name in (names if HAVE_FWD else []):
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / iters
     prof(buf)
-    v = [[buf[wv * 8 + i] / iters for i in range(7)] for wv in range(8)]
+    v = [[buf[wv * 8 + i] / iters for i in range(8)] for wv in range(8)]
     fl = 2.0 * n * h * w * cin * cout * k * k
     print("%s %s %s: %.3f ms %.1f TF fp32-eq; shader clock %.0f MHz" % (
         name, SHAPES[name], F.l16_plan_name(d, 0), ms, fl / ms / 1e9, 100.0 * v[0][5] / max(v[0][6], 1)))
     for wv in range(8):
         a = v[wv]
         steps = max(a[4], 1)
-        print("   wave %d: kernel %.0f kcyc | per step: hand-over %.0f, MFMA steps %.0f | epilogue %.1f%%, first fragments %.1f%% of kernel, "
-              "steps %.0f, accounted %.1f%%" % (wv, a[5] / 1e3, a[0] / steps, a[1] / steps, 100 * a[2] / a[5], 100 * a[3] / a[5], steps,
-                                               100 * (a[0] + a[1] + a[2] + a[3]) / a[5]))
+        print("   wave %d: kernel %.0f kcyc | per step: wait+barrier %.0f, copy issue %.0f, MFMA steps %.0f | epilogue %.1f%%, first fragments %.1f%% of kernel, "
+              "steps %.0f, accounted %.1f%%" % (wv, a[5] / 1e3, a[7] / steps, a[0] / steps, a[1] / steps, 100 * a[2] / a[5], 100 * a[3] / a[5], steps,
+                                               100 * (a[0] + a[1] + a[2] + a[3] + a[7]) / a[5]))
 
 
 # ---- weight gradient on three limbs (the same library build instruments conv_l16_wgrad_kernel)
