@@ -351,3 +351,36 @@ def test_three_limb_conv_fused_with_maxpool_and_statistics(shape, l3):
     assert torch.equal(got2[0], pooled_ref)
     assert float(((stp.mean - stp_ref.mean).abs() * stp_ref.invstd).max()) < 1e-5
     assert float((stp.invstd / stp_ref.invstd - 1).abs().max()) < 1e-5
+
+
+def test_what_the_scaled_limbs_give_up_operand_range():
+    """The honest difference between the two three-limb arithmetics.  Images of one batch scaled by 2^0 ... 2^-24: with bf16 limbs
+    (no scale) every image's output is as accurate as the first's; with scaled fp16 limbs an image keeps full fp32 accuracy while its
+    elements stay within ~2^-16 of the TENSOR's maximum and degrades linearly below (absolute error <= 2^-39 of the tensor maximum per
+    operand element) -- the per-tensor scale of the shipped two-limb mode, 2^11 further down."""
+    n, c_in, c_out, h, w = 32, 64, 64, 16, 64
+    torch.manual_seed(11)
+    x = torch.randn(n, c_in, h, w)
+    shifts = torch.arange(n).clamp(max=24).float()
+    x = x * torch.exp2(-shifts).view(n, 1, 1, 1)
+    wt = torch.randn(c_out, c_in, 3, 3) / (c_in * 9) ** 0.5
+    y64 = TF.conv2d(x.double(), wt.double(), None, padding=1)
+    rms64 = y64.pow(2).mean(dim=(1, 2, 3)).sqrt()
+    mode0 = F.get_conv_arith()
+    rel = {}
+    try:
+        for arith in (9, 10):
+            F.set_conv_arith(arith)
+            assert F.conv_l16_supported(F._desc(n, c_in, c_out, h, w, 3, 3, arith), 0)
+            y = F.conv_l16(F.l16_pack(x.to(DEV)), wt.to(DEV), None).cpu().double()
+            rel[arith] = ((y - y64).pow(2).mean(dim=(1, 2, 3)).sqrt() / rms64)
+    finally:
+        F.set_conv_arith(mode0)
+    _report("operand range: per-image relative rms error of a 64 -> 64 3x3 convolution, image i scaled by 2^-i: "
+            + "; ".join("2^-%d: bf16x9 %.1e f16x6 %.1e" % (i, float(rel[9][i]), float(rel[10][i])) for i in (0, 8, 12, 16, 20, 24)))
+    assert float(rel[9].max()) < 3e-7                                     # exact limbs: no dependence on the range
+    assert float(rel[10][:13].max()) < 3e-7                               # within 2^-12 of the maximum: indistinguishable
+    for i in range(13, n):
+        k = int(shifts[i])
+        # |x| of image i ~ 2^-k |x|max / 4: operand error <= 2^-39 |x|max each => relative <= 2^-37 2^k; measured ~10x below
+        assert float(rel[10][i]) < max(3e-7, 2.0 ** (k - 37)), (i, float(rel[10][i]))
