@@ -751,17 +751,57 @@ def conv_l16_wgrad(x16, dout16, weight_shape, out=None):
             TIMER.note(l16_wgrad_plan_name(d), 2.0 * n * h * w * c_in * c_out * kh * kw, (n, c_in, c_out, h, w, kh, kw), "wgrad")
         return dw
 
-    if not L16_WGRAD_SIDE:
+    if not L16_WGRAD_SIDE or torch.cuda.is_current_stream_capturing():
         return run()
+    if L16_WGRAD_SIDE == 2:
+        # beside the BatchNorm passes only: launched on the side stream by the NEXT input-gradient convolution of the backward pass,
+        # behind it (l16_wgrad_fork), and joined before the one after that (l16_wgrad_join)
+        dw = out if out is not None else torch.empty(tuple(weight_shape), device=dev, dtype=torch.float32)
+        pend = _WGRAD.l16_pending
+
+        def deferred(dw=dw):
+            side = torch.cuda.current_stream(dev)
+            nonlocal out
+            out = dw
+            run()
+            for t in (x16.data, x16.amax, dout16.data, dout16.amax, dw):
+                if t is not None:
+                    t.record_stream(side)             # keep the allocator from recycling them under the kernel
+        pend.append(deferred)
+        return dw
     main = torch.cuda.current_stream(dev)
     side = _side_stream(dev)
     side.wait_stream(main)                    # operands were produced on the main stream
     with torch.cuda.stream(side):
         dw = run()
     for t in (x16.data, x16.amax, dout16.data, dout16.amax):
-        t.record_stream(side)                 # keep the allocator from recycling them under the kernel
+        if t is not None:
+            t.record_stream(side)             # keep the allocator from recycling them under the kernel
     dw.record_stream(main)
     return dw
+
+
+def l16_wgrad_join(dev):
+    """FSC_L16_WGRAD_SIDE=2: the main stream waits for the weight gradients in flight on the side stream (before a convolution is
+    launched on the main stream: two matrix-bound kernels never share the chip)."""
+    if _WGRAD.l16_inflight:
+        torch.cuda.current_stream(dev).wait_stream(_side_stream(dev))
+        _WGRAD.l16_inflight = False
+
+
+def l16_wgrad_fork(dev):
+    """FSC_L16_WGRAD_SIDE=2: launch the deferred weight gradients on the side stream, behind everything the main stream holds."""
+    pend = _WGRAD.l16_pending
+    if not pend:
+        return
+    main = torch.cuda.current_stream(dev)
+    side = _side_stream(dev)
+    side.wait_stream(main)
+    with torch.cuda.stream(side):
+        for fn in pend:
+            fn()
+    pend.clear()
+    _WGRAD.l16_inflight = True
 
 
 def measure_l16_clock(shape, kind, iters=40):
@@ -794,11 +834,13 @@ def measure_l16_clock(shape, kind, iters=40):
     return mhz.value
 
 
-# FSC_L16_WGRAD_SIDE=1: the L16 weight-gradient kernels run on the side stream beside the BatchNorm backward passes of the next
-# layer (measured at cfg 2, same box: 36.92 -> 36.36 ms per step).  Off by default: with two kernels sharing the CUs the per-kernel
-# durations that bench.py's roofline and the rocprof tables attribute are no longer those of the kernel alone (the weight-gradient
-# launches read 2.2x longer while the step gets shorter).
-L16_WGRAD_SIDE = os.environ.get("FSC_L16_WGRAD_SIDE", "0") == "1"
+# FSC_L16_WGRAD_SIDE: where the L16 weight-gradient kernels of the backward pass run.  0: in line.  1: on the side stream as soon as
+# their operands exist (round 2, cfg 2, same box: 36.92 -> 36.36 ms per step; two matrix-bound kernels then share the CUs and the
+# per-kernel durations that bench.py's roofline and the rocprof tables attribute are no longer those of a kernel alone).  2 (round 5):
+# on the side stream BESIDE THE BatchNorm PASSES ONLY -- the gradient of layer k is launched behind layer k's input-gradient
+# convolution and joined before layer k-1's, so it overlaps the HBM-bound reduce / apply passes between the two and no two
+# convolutions ever run together.
+L16_WGRAD_SIDE = int(os.environ.get("FSC_L16_WGRAD_SIDE", "0"))
 _L16_OK = {}
 USE_L16 = True        # route convolutions through the pre-split (L16) kernels where the library has a tiling for them
 
@@ -898,7 +940,10 @@ def conv_wgrad(x, dout, weight_shape, on_side_stream=False, x_amax=None, dout_am
 # The pending list is per THREAD (autograd runs a backward on the thread that called it; two models training on two threads must
 # not mix their lists).
 class _WgradTLS(threading.local):
-    pending = None
+    def __init__(self):
+        self.pending = None
+        self.l16_pending = []          # FSC_L16_WGRAD_SIDE=2: weight gradients waiting for the next input-gradient convolution
+        self.l16_inflight = False      # ... and whether the side stream holds some the main stream has not joined
 
 
 _WGRAD = _WgradTLS()
@@ -910,6 +955,7 @@ def wgrad_begin():
 
 def wgrad_abort():
     _WGRAD.pending = None
+    _WGRAD.l16_pending.clear()
 
 
 def wgrad_flush(end=True):
@@ -1376,9 +1422,16 @@ def _conv_fwd_any(x, x_16, weight, bias, x_amax, packs=None, stats_bn=None):
 
 
 def _conv_dgrad_any(dout, dout_16, weight, x_shape, dout_amax, accumulate_into=None, prepacked=None):
+    side2 = L16_WGRAD_SIDE == 2 and (_WGRAD.l16_inflight or _WGRAD.l16_pending)
+    if side2:
+        l16_wgrad_join(dout.device if dout is not None else dout_16.data.device)
     if dout_16 is not None and _l16_ok_for(x_shape, weight, True):
-        return conv_l16(dout_16, weight, None, dgrad=True, accumulate_into=accumulate_into, prepacked=prepacked)
-    return conv_dgrad(dout, weight, x_shape, accumulate_into=accumulate_into, dout_amax=dout_amax)
+        r = conv_l16(dout_16, weight, None, dgrad=True, accumulate_into=accumulate_into, prepacked=prepacked)
+    else:
+        r = conv_dgrad(dout, weight, x_shape, accumulate_into=accumulate_into, dout_amax=dout_amax)
+    if side2:
+        l16_wgrad_fork(r.device)
+    return r
 
 
 GRAD_OUT = None       # callable(weight) -> tensor to write that weight's gradient into, or None (parallel.BucketedGradReducer.grad_view)
@@ -1703,6 +1756,9 @@ class ConvBlockFn(torch.autograd.Function):
                     and bn_a.weight is not None and h_w_min(dc) >= 2 and k.gamma_guard is not None and k.gamma_guard.ok()):
                 # the block input needs no gradient: bn_a's parameter gradients from the weight gradient (no dgrad, no BN backward)
                 wgrad_flush(end=False)                  # (dwa is read here)
+                if L16_WGRAD_SIDE == 2:
+                    l16_wgrad_fork(dc.device)
+                    l16_wgrad_join(dc.device)
                 dga, dbta = _stem_bn_grads(dc, dbias_a, wa, dwa, bn_a)
                 dx = None
                 del dc, dc_m
@@ -1715,6 +1771,9 @@ class ConvBlockFn(torch.autograd.Function):
             return g.reshape(param.shape) if g is not None else None
 
         wgrad_flush()
+        if L16_WGRAD_SIDE == 2:
+            l16_wgrad_fork(k.x.device)
+            _WGRAD.l16_inflight = False
         join_side_stream(k.x.device)           # weight gradients computed on the side stream
         grads = [dga, dbta, like(conv_a.weight, dwa), dbias_a, dgb, dbtb, dalb,
                  like(res.conv1.weight, dw1), dbias1, dg1, dbt1, dal1,
