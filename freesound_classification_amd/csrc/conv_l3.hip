@@ -62,6 +62,7 @@ struct L3Geom {
     int tiles_total;          // channel tiles of the layer
     long img_stride;          // 16-byte units between images of the input: oct_in * 3 * hw
     int xcd;
+    int spat;                 // item index v -> tile of XCD (v mod 8)'s contiguous eighth (see tile_of)
 };
 
 __device__ __attribute__((aligned(16))) float g_zero16_3[4] = {0.f, 0.f, 0.f, 0.f};
@@ -345,6 +346,19 @@ __global__ __launch_bounds__(kWaves * 64) void conv_l3_fwd_kernel(L3Geom g, cons
         cb_w = (int)blockIdx.x % g.coblk;
         t0 = (int)blockIdx.x / g.coblk;
     }
+#ifndef FSC_L3_XCDSPAT
+#define FSC_L3_XCDSPAT 1
+#endif
+    // XCD-aware form, second half: the item index v (v mod 8 = the XCD of the worker that takes it) names tile base(v mod 8) + v / 8,
+    // base(x) = the start of XCD x's CONTIGUOUS eighth of the tiles -- the 32 workers of an XCD work on 32 adjacent boxes at any
+    // time, so the halo rows and columns two boxes share are fetched into that XCD's L2 once (with tile = v, an XCD's boxes were 8
+    // apart and every halo came from HBM twice)
+    const int tq = ntiles >> 3, tr = ntiles & 7;
+    auto tile_of = [&](int v) -> int {
+        if (!FSC_L3_XCDSPAT || !g.spat) return v;
+        const int x = v & 7, j = v >> 3;
+        return x * tq + (x < tr ? x : tr) + j;
+    };
     const int nchunks = g.nfull + (g.tail_oct ? 1 : 0);
     // this wave's channel tiles inside the block: the live tiles of the block are halved between the two channel groups
     int blk_live = g.tiles_total - cb_w * g.cot;
@@ -430,7 +444,7 @@ __global__ __launch_bounds__(kWaves * 64) void conv_l3_fwd_kernel(L3Geom g, cons
     int ip_item = t0, ip_c = 0, ip_stg = 0;
     auto produce_i = [&]() -> bool {
         if (ip_item >= ntiles) return false;
-        issue_i(ip_stg, ip_c, ip_item);
+        issue_i(ip_stg, ip_c, tile_of(ip_item));
         ip_stg ^= 1;
         if (++ip_c == nchunks) {
             ip_c = 0;
@@ -601,7 +615,7 @@ __global__ __launch_bounds__(kWaves * 64) void conv_l3_fwd_kernel(L3Geom g, cons
     auto run = [&](auto live_c) {
         constexpr int LIVE = decltype(live_c)::value;
         for (; item < ntiles; item += ts) {
-            const int tile = item;
+            const int tile = tile_of(item);
             const int co0 = cb_w * CO_BLK + tile0 * 16;
             load_first();
             P3_ADD(3);
@@ -906,6 +920,8 @@ bool plan_l3_pt(const fsc_conv_desc& d_in, int dgrad, int ptw, L3Plan* out, bool
     if (items > 256 && items <= 512) p.workers = (items + 1) / 2;
     p.workers -= p.workers % p.co_blocks;
     g.xcd = (p.co_blocks > 1 && p.workers % (8 * p.co_blocks) == 0 && !fsc::env().l16_no_xcd) ? 1 : 0;
+    // (one channel block: item v = worker + workers * k, and worker mod 8 is the worker's XCD when the grid is a multiple of 8)
+    g.spat = (g.xcd || (p.co_blocks == 1 && p.workers % 8 == 0 && !fsc::env().l16_no_xcd)) ? 1 : 0;
     *out = p;
     return true;
 }
