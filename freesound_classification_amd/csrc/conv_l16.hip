@@ -51,6 +51,7 @@ struct LGeom {
     int coblk;
     long img_stride;          // 16-byte units between images of the input: oct_in * 2 * hw
     int xcd;                  // item order: the channel blocks of a tile on workers of one XCD (see the kernel)
+    int spat;                 // item index v -> tile of XCD (v mod 8)'s contiguous eighth of the tiles (tile_of in the kernel)
 };
 
 __device__ __attribute__((aligned(16))) float g_zero16_l[4] = {0.f, 0.f, 0.f, 0.f};
@@ -399,6 +400,14 @@ __global__ __launch_bounds__(kWaves * 64) void conv_l16_fwd_kernel(LGeom g, cons
         cb_w = (int)blockIdx.x % g.coblk;
         t0 = (int)blockIdx.x / g.coblk;
     }
+    // g.spat: the item index v (v mod 8 = the XCD of its worker) names tile base(v mod 8) + v / 8 -- an XCD's 32 workers take 32
+    // ADJACENT boxes at any time, whose shared halo rows and columns reach that XCD's L2 once (conv_l3.hip: -1 % kernel time)
+    const int tq = ntiles >> 3, tr = ntiles & 7;
+    auto tile_of = [&](int v) -> int {
+        if (!g.spat) return v;
+        const int x = v & 7, j = v >> 3;
+        return x * tq + (x < tr ? x : tr) + j;
+    };
     const int nchunks = g.nfull + (g.tail_oct ? 1 : 0);
 
     int pos_off[kNptMax];        // source offset (16-byte units, relative to unit 0 of image 0) of staged positions; -1 = zeros
@@ -491,7 +500,7 @@ __global__ __launch_bounds__(kWaves * 64) void conv_l16_fwd_kernel(LGeom g, cons
         if (++ip_c == nchunks) {
             ip_c = 0;
             ip_item += ts;
-            if (ip_item < ntiles) plan_input(ip_item);
+            if (ip_item < ntiles) plan_input(tile_of(ip_item));
         }
         return true;
     };
@@ -539,7 +548,7 @@ __global__ __launch_bounds__(kWaves * 64) void conv_l16_fwd_kernel(LGeom g, cons
     int item = t0;                 // (the tile of the current item)
     int slot = 0;
     if (item < ntiles) {
-        plan_input(item);
+        plan_input(tile_of(item));
         wp_set_item();
 #pragma unroll
         for (int d = 0; d < DAHEAD; ++d) produce_i();
@@ -675,7 +684,7 @@ __global__ __launch_bounds__(kWaves * 64) void conv_l16_fwd_kernel(LGeom g, cons
 
     const bool add_bias = bias != nullptr;
     for (; item < ntiles; item += ts) {
-        const int tile = item;
+        const int tile = tile_of(item);
         const int co0 = cb_w * CO_BLK;
 #pragma unroll 1
         for (int S = 0; S + 1 < g.steps; S += 2) {
@@ -970,6 +979,7 @@ bool plan_l16_pt(const fsc_conv_desc& d_in, int dgrad, int pt, int max_cot, LPla
     if (items > 256 && items <= 512) p.workers = (items + 1) / 2;     // two items each instead of 256 + a short second wave
     p.workers -= p.workers % p.co_blocks;           // a worker keeps one channel block
     g.xcd = (p.co_blocks > 1 && p.workers % (8 * p.co_blocks) == 0 && !fsc::env().l16_no_xcd) ? 1 : 0;
+    g.spat = (g.xcd || (p.co_blocks == 1 && p.workers % 8 == 0 && !fsc::env().l16_no_xcd)) ? 1 : 0;
     *out = p;
     return true;
 }
