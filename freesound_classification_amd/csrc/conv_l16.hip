@@ -1323,6 +1323,18 @@ int fsc_debug_l16_prof(unsigned long long* out64) {
 }
 #endif
 
+/* include/fsc_hip.h: inference -- convolution + per-channel affine + PReLU, written as the L16 operand of the next convolution */
+int fsc_conv_l16_fwd_act_supported(const fsc_conv_desc* d) {
+    return d && l16::is_l3(d->arith) ? fsc::l3::supported(d, 0) : 0;
+}
+
+int fsc_conv_l16_fwd_act(const fsc_conv_desc* d, const void* in_l16, const float* in_amax, const float* packed, const float* bias,
+                         const float* scale, const float* shift, const float* alpha, void* out_l16, const float* out_amax,
+                         float* seen_max, fsc_stream_t stream) {
+    FSC_CHECK_ARG(d && l16::is_l3(d->arith), "fsc_conv_l16_fwd_act: three-limb arithmetics only (arith 9 / 10)");
+    return fsc::l3::fwd_act(d, in_l16, in_amax, packed, bias, scale, shift, alpha, out_l16, out_amax, seen_max, fsc::as_stream(stream));
+}
+
 int fsc_conv_l16_plan_describe(const fsc_conv_desc* d, int dgrad, char* buf, size_t buf_len) {
     if (d && l16::is_l3(d->arith)) return fsc::l3::plan_describe(d, dgrad, buf, buf_len);
     LPlan p;

@@ -281,7 +281,20 @@ __global__ __launch_bounds__(256) void l3_wmax_multi_kernel(PackJobs3 jobs) {
 // Forward / dgrad.  See the head of the file.  POOL / STATS as in conv_l16_fwd_kernel.
 // F16: the limbs are scaled fp16 (arith 10, l16.h) -- v_mfma_f32_16x16x32_f16, and the accumulators leave through
 // 1 / (input scale * weight scale) (powers of two: exact), from the declared maxima `in_amax` (FSC_AMAX_FLOATS) and `w_amax`.
-template <int KH, int KW, int CT, int PTW, int NPROD, bool F16 = false, bool POOL = false, bool STATS = false>
+// ACT16 (inference, fsc_conv_l16_fwd_act): the epilogue applies a per-channel affine (an eval-mode BatchNorm: y = z scale + shift)
+// and PReLU to the convolution output z and writes y as the three-limb L16 tensor the NEXT convolution reads -- straight from the
+// accumulators, 6 bytes per element instead of 4 written + 4 read + 6 written by the separate pass.  Same expressions as the
+// two-pass route (fwd_l16_kernel of norm_act.hip): bit-identical limbs.  Scaled fp16 limbs take the DECLARED maximum `out_amax`
+// (a calibrated bound); the largest |y| actually written is max-ed into `seen` for the caller's saturation check.
+struct ActArgs3 {
+    const float* scale;       // per output channel, or nullptr (identity)
+    const float* shift;
+    const float* alpha;       // PReLU slopes, or nullptr (no activation)
+    uint2* out16;             // the L16 output in 8-byte units; nullptr = not an ACT16 launch
+    const float* out_amax;    // scaled fp16 limbs: FSC_AMAX_FLOATS declared maximum of y
+    unsigned* seen;           // receives max |y| as its fp32 bit pattern (atomicMax; zeroed by the caller), or nullptr
+};
+template <int KH, int KW, int CT, int PTW, int NPROD, bool F16 = false, bool POOL = false, bool STATS = false, bool ACT16 = false>
 __global__ __launch_bounds__(kWaves * 64) void conv_l3_fwd_kernel(L3Geom g, const uint4* __restrict__ in,
                                                                    const uint4* __restrict__ packed,
                                                                    const float* __restrict__ bias, float* __restrict__ out,
@@ -289,7 +302,8 @@ __global__ __launch_bounds__(kWaves * 64) void conv_l3_fwd_kernel(L3Geom g, cons
                                                                    const float* __restrict__ stat_pivot,
                                                                    float4* __restrict__ stat_rec,
                                                                    const float* __restrict__ in_amax,
-                                                                   const float* __restrict__ w_amax) {
+                                                                   const float* __restrict__ w_amax, ActArgs3 act) {
+    static_assert(!ACT16 || (!POOL && !STATS), "ACT16 replaces the plain epilogue");
     constexpr int TAPS = KH * KW;
     constexpr int PADH = KH / 2, PADW = KW / 2;
     using P = Prods<NPROD>;
@@ -298,6 +312,11 @@ __global__ __launch_bounds__(kWaves * 64) void conv_l3_fwd_kernel(L3Geom g, cons
         const float ax = wave_amax512(in_amax), aw = *w_amax;
         oscale = l16::inv_scale(l16::scale_field(ax), ax) * l16::inv_scale(l16::scale_field(aw), aw);
         oscale = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, oscale)));
+    }
+    float s_out = 1.f, seen_mx = 0.f;
+    if constexpr (F16 && ACT16) {
+        s_out = l16::field_to_float(l16::scale_field(wave_amax512(act.out_amax)));
+        s_out = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, s_out)));
     }
 
     extern __shared__ __attribute__((aligned(16))) uint4 smem4[];
@@ -631,7 +650,79 @@ __global__ __launch_bounds__(kWaves * 64) void conv_l3_fwd_kernel(L3Geom g, cons
             int lane_e = lane;
             asm volatile("" : "+v"(lane_e));
             const int lm_e = lane_e & 15, kq_e = lane_e >> 4;
-            if constexpr (POOL) {
+            if constexpr (ACT16) {
+                // ---- affine + PReLU + limb split: lane (kq, lm) holds channels kq * 4 + r of pixel lm -- four channels = one 8-byte
+                //      half of the (octet, limb) vector of that pixel; lanes kq, kq ^ 1 complete the 16 bytes, 16 pixels make 256
+                long gpix[PTW];                           // 16-byte unit of the pixel in limb 0 of octet 0 of its image, or -1
+                {
+                    int t = tile;
+                    const int twi = t % g.tiles_w; t /= g.tiles_w;
+                    const int thi = t % g.tiles_h; t /= g.tiles_h;
+                    const int n0 = t * g.nb, h0 = thi * g.th, w0 = twi * g.tw;
+                    const long img_u = (long)((g.cout + 7) >> 3) * 3 * g.hw;
+#pragma unroll
+                    for (int pt = 0; pt < PTW; ++pt) {
+                        const int p = (pw * PTW + pt) * 16 + lm_e;
+                        gpix[pt] = -1;
+                        if (p < g.npix) {
+                            const int per = g.th * g.tw;
+                            const int b = fdiv(p, inv_thw), rem = p - b * per;
+                            const int r = fdiv(rem, inv_tw), cq = rem - r * g.tw;
+                            if (n0 + b < g.n && h0 + r < g.h && w0 + cq < g.w)
+                                gpix[pt] = (long)(n0 + b) * img_u + (long)(h0 + r) * g.w + (w0 + cq);
+                        }
+                    }
+                }
+                long hw_t = g.hw;
+                const float* bias_t = bias;
+                asm volatile("" : "+s"(hw_t), "+s"(bias_t));
+                const int oct_out = (g.cout + 7) >> 3;
+                const bool has_aff = act.scale != nullptr, has_alpha = act.alpha != nullptr;
+#pragma unroll
+                for (int i = 0; i < LIVE; ++i) {
+                    if (i >= live) continue;
+                    float bv[4], sc[4], sh[4], al[4];
+                    bool okc[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int cob = co0 + i * 16 + kq_e * 4 + r;
+                        okc[r] = cob < g.cout;
+                        bv[r] = (add_bias && okc[r]) ? bias_t[cob] : 0.f;
+                        sc[r] = (has_aff && okc[r]) ? act.scale[cob] : 1.f;
+                        sh[r] = (has_aff && okc[r]) ? act.shift[cob] : 0.f;
+                        al[r] = (has_alpha && okc[r]) ? act.alpha[cob] : 0.f;
+                    }
+                    const int oct = ((co0 + i * 16) >> 3) + (kq_e >> 1);
+                    if (oct < oct_out) {
+#pragma unroll
+                        for (int j = 0; j < PTW; ++j) {
+                            if (gpix[j] < 0) continue;
+                            float y[4];
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                const float z = F16 ? fmaf(acc[i][j][r], oscale, bv[r]) : acc[i][j][r] + bv[r];
+                                const float t = has_aff ? fmaf(z, sc[r], sh[r]) : z;
+                                const float v = (has_alpha && !(t > 0.f)) ? al[r] * t : t;
+                                y[r] = okc[r] ? v : 0.f;
+                                seen_mx = fmaxf(seen_mx, fabsf(y[r]));
+                            }
+                            unsigned h0, m0, l0, h1, m1, l1;
+                            if constexpr (F16) {
+                                l16::split3s_pair(y[0], y[1], s_out, h0, m0, l0);
+                                l16::split3s_pair(y[2], y[3], s_out, h1, m1, l1);
+                            } else {
+                                l16::split3_pair(y[0], y[1], h0, m0, l0);
+                                l16::split3_pair(y[2], y[3], h1, m1, l1);
+                            }
+                            uint2* o = act.out16 + (gpix[j] + (long)oct * 3 * hw_t) * 2 + (kq_e & 1);
+                            o[0] = make_uint2(h0, h1);
+                            o[2 * hw_t] = make_uint2(m0, m1);
+                            o[4 * hw_t] = make_uint2(l0, l1);
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            } else if constexpr (POOL) {
                 // ---- pooled epilogue (conv_l16.hip): the four pixels of a pooling window sit in lanes lm, lm + 1, lm + 8, lm + 9
                 int t = tile;
                 const int twi = t % g.tiles_w; t /= g.tiles_w;
@@ -792,6 +883,10 @@ __global__ __launch_bounds__(kWaves * 64) void conv_l3_fwd_kernel(L3Geom g, cons
     if (blockIdx.x == 0 && tid == 0) {
         g_l3_clock[0] = __builtin_readcyclecounter() - ck0;
         g_l3_clock[1] = __builtin_amdgcn_s_memrealtime() - cr0;
+    }
+    if constexpr (ACT16) {
+        seen_mx = fsc::wave_max(seen_mx);
+        if (act.seen != nullptr && lane == 0) atomicMax(act.seen, __float_as_uint(seen_mx));
     }
     if constexpr (STATS) {
         // records [(worker * 8 + wave) * CO_BLK + channel in block]: this wave's tiles carry its sums, the block's other
@@ -963,39 +1058,40 @@ bool stats_ok3(const L3Plan& p) { return p.workers >= p.co_blocks; }
 struct StatArgs3 { const float* pivot; float4* rec; };
 struct ScaleArgs3 { const float* in_amax; const float* w_amax; };
 
-template <int KH, int KW, int CT, int PTW, int NPROD, bool F16, bool POOL, bool STATS>
+template <int KH, int KW, int CT, int PTW, int NPROD, bool F16, bool POOL, bool STATS, bool ACT16 = false>
 int launch3(const L3Plan& p, const uint4* in, const uint4* packed, const float* bias, float* out, int accumulate, uint8_t* idx,
-            StatArgs3 sa, ScaleArgs3 sc, hipStream_t st) {
-    auto kern = conv_l3_fwd_kernel<KH, KW, CT, PTW, NPROD, F16, POOL, STATS>;
+            StatArgs3 sa, ScaleArgs3 sc, ActArgs3 act, hipStream_t st) {
+    auto kern = conv_l3_fwd_kernel<KH, KW, CT, PTW, NPROD, F16, POOL, STATS, ACT16>;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes);
     hipLaunchKernelGGL(kern, dim3((unsigned)p.workers), dim3(kWaves * 64), p.lds_bytes, st, p.g, in, packed, bias, out, accumulate, idx,
-                       sa.pivot, sa.rec, sc.in_amax, sc.w_amax);
+                       sa.pivot, sa.rec, sc.in_amax, sc.w_amax, act);
     FSC_LAUNCH_CHECK("fsc_conv_l16_fwd(three limbs)");
     return 0;
 }
 
 template <int KH, int KW, int CT, int PTW, int NPROD, bool F16>
 int launch3_var(const L3Plan& p, const uint4* in, const uint4* packed, const float* bias, float* out, int accumulate, uint8_t* idx,
-                StatArgs3 sa, ScaleArgs3 sc, hipStream_t st) {
+                StatArgs3 sa, ScaleArgs3 sc, ActArgs3 act, hipStream_t st) {
+    if (act.out16) return launch3<KH, KW, CT, PTW, NPROD, F16, false, false, true>(p, in, packed, bias, nullptr, 0, nullptr, sa, sc, act, st);
     if (idx) {
         if constexpr (KH == 3 && PTW == 4) {
-            if (sa.rec) return launch3<KH, KW, CT, PTW, NPROD, F16, true, true>(p, in, packed, bias, out, 0, idx, sa, sc, st);
-            return launch3<KH, KW, CT, PTW, NPROD, F16, true, false>(p, in, packed, bias, out, 0, idx, sa, sc, st);
+            if (sa.rec) return launch3<KH, KW, CT, PTW, NPROD, F16, true, true>(p, in, packed, bias, out, 0, idx, sa, sc, act, st);
+            return launch3<KH, KW, CT, PTW, NPROD, F16, true, false>(p, in, packed, bias, out, 0, idx, sa, sc, act, st);
         }
         fsc::set_error("fsc_conv_l16_pool_fwd: internal: no pooled instantiation");
         return 22;
     }
-    if (sa.rec) return launch3<KH, KW, CT, PTW, NPROD, F16, false, true>(p, in, packed, bias, out, 0, nullptr, sa, sc, st);
-    return launch3<KH, KW, CT, PTW, NPROD, F16, false, false>(p, in, packed, bias, out, accumulate, nullptr, sa, sc, st);
+    if (sa.rec) return launch3<KH, KW, CT, PTW, NPROD, F16, false, true>(p, in, packed, bias, out, 0, nullptr, sa, sc, act, st);
+    return launch3<KH, KW, CT, PTW, NPROD, F16, false, false>(p, in, packed, bias, out, accumulate, nullptr, sa, sc, act, st);
 }
 
 template <int KH, int KW, int NPROD, bool F16>
 int launch3_ct(const L3Plan& p, const uint4* in, const uint4* packed, const float* bias, float* out, int accumulate, uint8_t* idx,
-               StatArgs3 sa, ScaleArgs3 sc, hipStream_t st) {
-#define FSC_L3_CASE(CT_)                                                                                                        \
-    case CT_:                                                                                                                   \
-        if (p.ptw == 4) return launch3_var<KH, KW, CT_, 4, NPROD, F16>(p, in, packed, bias, out, accumulate, idx, sa, sc, st); \
-        return launch3_var<KH, KW, CT_, 2, NPROD, F16>(p, in, packed, bias, out, accumulate, idx, sa, sc, st);
+               StatArgs3 sa, ScaleArgs3 sc, ActArgs3 act, hipStream_t st) {
+#define FSC_L3_CASE(CT_)                                                                                                             \
+    case CT_:                                                                                                                        \
+        if (p.ptw == 4) return launch3_var<KH, KW, CT_, 4, NPROD, F16>(p, in, packed, bias, out, accumulate, idx, sa, sc, act, st); \
+        return launch3_var<KH, KW, CT_, 2, NPROD, F16>(p, in, packed, bias, out, accumulate, idx, sa, sc, act, st);
     switch (p.ct) {
 #ifndef FSC_L16_DEV
         FSC_L3_CASE(2)
@@ -1011,30 +1107,30 @@ int launch3_ct(const L3Plan& p, const uint4* in, const uint4* packed, const floa
 }
 
 int launch3_any(const L3Plan& p, int taps, const uint4* in, const uint4* packed, const float* bias, float* out, int accumulate,
-                uint8_t* idx, StatArgs3 sa, const float* in_amax, hipStream_t st) {
+                uint8_t* idx, StatArgs3 sa, const float* in_amax, hipStream_t st, ActArgs3 act = ActArgs3{}) {
     ScaleArgs3 sc{nullptr, nullptr};
     if (p.f16) {
         sc.in_amax = in_amax;
         sc.w_amax = reinterpret_cast<const float*>(packed + l3_packed_u4(p));
 #ifndef FSC_L3_NO_F16
-        if (taps == 9) return launch3_ct<3, 3, 6, true>(p, in, packed, bias, out, accumulate, idx, sa, sc, st);
-        return launch3_ct<1, 1, 6, true>(p, in, packed, bias, out, accumulate, idx, sa, sc, st);
+        if (taps == 9) return launch3_ct<3, 3, 6, true>(p, in, packed, bias, out, accumulate, idx, sa, sc, act, st);
+        return launch3_ct<1, 1, 6, true>(p, in, packed, bias, out, accumulate, idx, sa, sc, act, st);
 #endif
     }
 #ifndef FSC_L3_NO_BF16
     if (p.nprod == 9) {
-        if (taps == 9) return launch3_ct<3, 3, 9, false>(p, in, packed, bias, out, accumulate, idx, sa, sc, st);
-        return launch3_ct<1, 1, 9, false>(p, in, packed, bias, out, accumulate, idx, sa, sc, st);
+        if (taps == 9) return launch3_ct<3, 3, 9, false>(p, in, packed, bias, out, accumulate, idx, sa, sc, act, st);
+        return launch3_ct<1, 1, 9, false>(p, in, packed, bias, out, accumulate, idx, sa, sc, act, st);
     }
 #endif
 #ifdef FSC_L3_ALL_PRODS
     if (p.nprod == 8) {
-        if (taps == 9) return launch3_ct<3, 3, 8, false>(p, in, packed, bias, out, accumulate, idx, sa, sc, st);
-        return launch3_ct<1, 1, 8, false>(p, in, packed, bias, out, accumulate, idx, sa, sc, st);
+        if (taps == 9) return launch3_ct<3, 3, 8, false>(p, in, packed, bias, out, accumulate, idx, sa, sc, act, st);
+        return launch3_ct<1, 1, 8, false>(p, in, packed, bias, out, accumulate, idx, sa, sc, act, st);
     }
     if (p.nprod == 6) {
-        if (taps == 9) return launch3_ct<3, 3, 6, false>(p, in, packed, bias, out, accumulate, idx, sa, sc, st);
-        return launch3_ct<1, 1, 6, false>(p, in, packed, bias, out, accumulate, idx, sa, sc, st);
+        if (taps == 9) return launch3_ct<3, 3, 6, false>(p, in, packed, bias, out, accumulate, idx, sa, sc, act, st);
+        return launch3_ct<1, 1, 6, false>(p, in, packed, bias, out, accumulate, idx, sa, sc, act, st);
     }
 #endif
     fsc::set_error("fsc_conv_l16_fwd: this build has no three-limb kernels with %d products%s", p.nprod, p.f16 ? " (fp16)" : "");
@@ -1154,6 +1250,19 @@ int fwd(const fsc_conv_desc* d, const void* in_l16, const float* in_amax, const 
     FSC_CHECK_ARG(!stat_rec || stats_ok3(p), "fsc_conv_l16_fwd_stats: unsupported shape (see fsc_conv_l16_stats_layout)");
     return launch3_any(p, d->kh * d->kw, reinterpret_cast<const uint4*>(in_l16), reinterpret_cast<const uint4*>(packed), bias, out,
                        accumulate, nullptr, StatArgs3{stat_pivot, reinterpret_cast<float4*>(stat_rec)}, in_amax, st);
+}
+
+int fwd_act(const fsc_conv_desc* d, const void* in_l16, const float* in_amax, const float* packed, const float* bias,
+            const float* scale, const float* shift, const float* alpha, void* out_l16, const float* out_amax, float* seen_max,
+            hipStream_t st) {
+    L3Plan p;
+    FSC_CHECK_ARG(valid3(d) && in_l16 && packed && out_l16, "fsc_conv_l16_fwd_act: bad descriptor or null pointer");
+    FSC_CHECK_ARG((scale == nullptr) == (shift == nullptr), "fsc_conv_l16_fwd_act: scale and shift come together");
+    FSC_CHECK_ARG(!l16::is_f3(d->arith) || (in_amax && out_amax), "fsc_conv_l16_fwd_act: scaled fp16 limbs need both declared maxima");
+    FSC_CHECK_ARG(plan_l3(*d, 0, &p), "fsc_conv_l16_fwd_act: unsupported shape (see fsc_conv_l16_supported)");
+    ActArgs3 act{scale, shift, alpha, reinterpret_cast<uint2*>(out_l16), out_amax, reinterpret_cast<unsigned*>(seen_max)};
+    return launch3_any(p, d->kh * d->kw, reinterpret_cast<const uint4*>(in_l16), reinterpret_cast<const uint4*>(packed), bias, nullptr,
+                       0, nullptr, StatArgs3{nullptr, nullptr}, in_amax, st, act);
 }
 
 int pool_fwd(const fsc_conv_desc* d, const void* in_l16, const float* in_amax, const float* packed, const float* bias, float* pooled,

@@ -684,6 +684,102 @@ def conv_l16(t, weight, bias, dgrad=False, accumulate_into=None, prepacked=None,
     return out
 
 
+# ---- inference: convolution + eval-mode BatchNorm + PReLU written straight as the next convolution's L16 operand
+# (fsc_conv_l16_fwd_act, three-limb arithmetics).  bf16 limbs (arith 9) carry no scale: the fold is unconditional.  Scaled fp16
+# limbs (arith 10) need the DECLARED maximum of the output before it exists: a calibrated bound -- what the two-pass route derived
+# for this layer on an earlier batch, doubled -- and a check that nothing outgrew it.  The check reads device memory, so it belongs
+# to the caller's own synchronisation point: the fold with a calibrated scale only runs inside an `act_fold_scope()`, whose
+# `ok()` the caller asks once the results are on their way to the host anyway (predict_2d_cnn.ensemble_batch / predict_folds);
+# a scope that is not ok() has dropped the calibrations that overflowed and the caller recomputes the batch.
+EVAL_ACT_FOLD = os.environ.get("FSC_EVAL_ACT_FOLD", "1") == "1"
+_ACT_CAL = {}
+
+
+class _ActFoldTLS(threading.local):
+    def __init__(self):
+        self.scope = None
+
+
+_ACT_TLS = _ActFoldTLS()
+
+
+class ActFoldScope:
+    """Collects (largest |y| written, limit) of every calibrated fold launched while it is the current scope."""
+
+    def __init__(self):
+        self.seen = None
+        self.limits = []
+        self.keys = []
+        self._prev = None
+
+    def __enter__(self):
+        self._prev = _ACT_TLS.scope
+        _ACT_TLS.scope = self
+        return self
+
+    def __exit__(self, *exc):
+        _ACT_TLS.scope = self._prev
+        return False
+
+    def slot(self, like, limit, key):
+        if self.seen is None or len(self.keys) >= self.seen.numel():
+            grown = torch.zeros(256 if self.seen is None else 2 * self.seen.numel(), device=like.device, dtype=torch.float32)
+            if self.seen is not None:
+                grown[:self.seen.numel()] = self.seen
+            self.seen = grown
+        i = len(self.keys)
+        self.limits.append(limit)
+        self.keys.append(key)
+        return self.seen[i:i + 1]
+
+    def ok(self):
+        """True when no calibrated scale was outgrown (synchronises: reads the flags).  Otherwise the calibrations concerned are
+        dropped -- the next forward takes the two-pass route for those layers and calibrates afresh -- and the caller recomputes."""
+        if not self.keys:
+            return True
+        bad = (self.seen[:len(self.keys)] > torch.cat(self.limits)).cpu()
+        if not bool(bad.any()):
+            return True
+        for i in torch.nonzero(bad).flatten().tolist():
+            _ACT_CAL.pop(self.keys[i], None)
+        return False
+
+
+def act_fold_scope():
+    return ActFoldScope()
+
+
+def conv_l16_act_supported(t_shape, weight):
+    if not EVAL_ACT_FOLD or _l16_arith() not in (9, 10) or len(t_shape) != 4:
+        return False
+    c_out, c_in, kh, kw = weight.shape
+    n, _, h, w = t_shape
+    key = (n, c_in, c_out, h, w, kh, kw, "act", _l16_arith())
+    if key not in _L16_OK:
+        _L16_OK[key] = bool(_lib.load().fsc_conv_l16_fwd_act_supported(C.byref(_desc(n, c_in, c_out, h, w, kh, kw, _l16_arith()))))
+    return _L16_OK[key]
+
+
+def conv_l16_act(t, weight, bias, scale, shift, alpha, decl_amax=None, seen=None, prepacked=None):
+    """L16 operand of the next convolution = prelu(conv(t) * scale + shift) (fsc_conv_l16_fwd_act).  decl_amax: the declared
+    maximum of the result (scaled fp16 limbs only); seen: 1-element tensor that receives max |result| (atomic max; zero it first)."""
+    c_out, c_in, kh, kw = weight.shape
+    n, _, h, w = t.shape
+    d, packed = prepacked if prepacked is not None else conv_l16_pack(weight, n, h, w, False)
+    limbs = _l16_limbs()
+    out = L16(l16_empty((n, c_out, h, w), weight, limbs), decl_amax if limbs != 3 else None, (n, c_out, h, w), limbs)
+    if TIMER is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    call("fsc_conv_l16_fwd_act", C.byref(d), ptr(t.data), ptr(t.amax), ptr(packed), ptr(bias), ptr(scale), ptr(shift), ptr(alpha),
+         ptr(out.data), ptr(out.amax), ptr(seen), stream_ptr())
+    if TIMER is not None:
+        e1.record()
+        TIMER.records.append((l16_plan_name(d, 0), 2.0 * n * h * w * c_in * c_out * kh * kw, e0, e1))
+        TIMER.note(l16_plan_name(d, 0), 2.0 * n * h * w * c_in * c_out * kh * kw, (n, c_in, c_out, h, w, kh, kw), "fwd")
+    return out
+
+
 def conv_l16_pool(t, weight, bias, prepacked=None, stats_bn=None):
     """3x3 convolution on an L16 operand fused with MaxPool2d(2) (fsc_conv_l16_pool_fwd): (pooled, window index, conv output
     shape), or None when the library has no fused tiling for the shape."""
@@ -1066,6 +1162,28 @@ def bn_act_forward_rec(x, st, alpha, residual, want_stats, want_gmax):
     return y, feat, fidx
 
 
+def _bn_eval_key(bn, gamma, beta):
+    return tuple((t.data_ptr(), t._version) if t is not None else None
+                 for t in (gamma, beta, bn.running_mean, bn.running_var)) + (bn.eps,)
+
+
+def _bn_eval_scale_shift(bn, gamma, beta, scale=None, shift=None):
+    """Folded scale / shift of an eval-mode BatchNorm into (or instead of) the given buffers; cached across batches under no_grad."""
+    key = _bn_eval_key(bn, gamma, beta) if not torch.is_grad_enabled() else None
+    hit = _EVAL_BN.get(key) if key is not None else None
+    if hit is not None:
+        return hit[0], hit[1]
+    if scale is None:
+        scale, shift = _empty((bn.running_mean.numel(),), bn.running_mean), _empty((bn.running_mean.numel(),), bn.running_mean)
+    call("fsc_bn_eval_prepare", scale.numel(), ptr(gamma), ptr(beta), ptr(bn.running_mean), ptr(bn.running_var),
+         bn.eps, ptr(scale), ptr(shift), stream_ptr())
+    if key is not None:
+        if len(_EVAL_BN) > 4096:
+            _EVAL_BN.clear()
+        _EVAL_BN[key] = (scale, shift, bn)          # (the module is kept alive: its addresses cannot be reused)
+    return scale, shift
+
+
 def bn_prepare(x, bn, training, sync=None, defer=None, want_minmax=False):
     """Batch statistics (training; also updates the running stats, once) or running statistics
     (eval) -> per-channel scale/shift.  `sync` (a callable that sum-all-reduces a device tensor in place over the
@@ -1122,20 +1240,7 @@ def bn_prepare(x, bn, training, sync=None, defer=None, want_minmax=False):
         st.invstd = None
         # the folded scale / shift of an eval-mode BatchNorm are reused across batches (keyed like the packed weights: addresses
         # and versions; a training forward or an optimizer step of this library drops the cache)
-        key = None
-        if not torch.is_grad_enabled():
-            key = tuple((t.data_ptr(), t._version) if t is not None else None
-                        for t in (gamma, beta, bn.running_mean, bn.running_var)) + (bn.eps,)
-            hit = _EVAL_BN.get(key)
-        if key is not None and hit is not None:
-            st.scale, st.shift = hit[0], hit[1]
-        else:
-            call("fsc_bn_eval_prepare", c, ptr(gamma), ptr(beta), ptr(bn.running_mean), ptr(bn.running_var),
-                 bn.eps, ptr(st.scale), ptr(st.shift), stream_ptr())
-            if key is not None:
-                if len(_EVAL_BN) > 4096:
-                    _EVAL_BN.clear()
-                _EVAL_BN[key] = (st.scale, st.shift, bn)          # (the module is kept alive: its addresses cannot be reused)
+        st.scale, st.shift = _bn_eval_scale_shift(bn, gamma, beta, st.scale, st.shift)
         pre = _take_prestats(x)
         if pre is not None and (pre[1] & _STATS_CONV_REC):
             if want_minmax and EVAL_L16 and hw > 1:          # min / max straight from the conv epilogue's records, one launch
@@ -1460,6 +1565,46 @@ def _l16_of(m):
     return m if isinstance(m, L16) else None
 
 
+def _act_key(bn, weight):
+    return _bn_eval_key(bn, bn.weight, bn.bias) + (weight.data_ptr(), weight._version)
+
+
+def _eval_conv_act(t16, weight, bias, bn, alpha, next_weight):
+    """Inference: conv -> eval-mode BatchNorm -> PReLU in ONE launch that writes the next convolution's L16 operand
+    (conv_l16_act), or None when the layer takes the two-pass route (no tiling, the next convolution reads fp32, or -- scaled
+    fp16 limbs -- no scope / no calibration yet)."""
+    if not EVAL_ACT_FOLD or t16 is None or torch.is_grad_enabled() or bn.running_mean is None or len(t16.shape) != 4:
+        return None
+    n, _, h, w = t16.shape
+    if not conv_l16_act_supported(t16.shape, weight) or not _l16_ok_for((n, weight.shape[0], h, w), next_weight, False):
+        return None
+    decl = seen = None
+    if _l16_arith() == 10:
+        scope = _ACT_TLS.scope
+        cal = _ACT_CAL.get(_act_key(bn, weight)) if scope is not None else None
+        if cal is None:
+            return None
+        decl = cal[0]
+        seen = scope.slot(weight, cal[1], _act_key(bn, weight))
+    scale, shift = _bn_eval_scale_shift(bn, bn.weight, bn.bias)
+    return conv_l16_act(t16, weight, bias, scale, shift, alpha, decl, seen)
+
+
+def _act_calibrate(bn, weight, t16):
+    """Scaled fp16 limbs, inference on the two-pass route: remember TWICE the bound this batch declared for the layer's output as
+    the scale of the folded launches to come (the fp16 high limb itself holds another factor 1.99 above the declared maximum:
+    `limit`, what ActFoldScope.ok() compares the largest value written with)."""
+    if not EVAL_ACT_FOLD or _l16_arith() != 10 or t16 is None or t16.amax is None or torch.is_grad_enabled():
+        return
+    key = _act_key(bn, weight)
+    if key in _ACT_CAL:
+        return
+    if len(_ACT_CAL) > 4096:
+        _ACT_CAL.clear()
+    decl = t16.amax * 2.0
+    _ACT_CAL[key] = (decl, (decl.max() * 1.99).reshape(1), bn, weight)
+
+
 def _block_forward(x, mods, training, want_head, ph, keep, sync=None, next_bn=False):
     """BN -> conv3 -> maxpool -> BN+PReLU -> residual unit (-> global max).  `mods` is the
     reference's nn.Sequential of parameter holders.  Returns (out, feat, ctx)."""
@@ -1505,14 +1650,31 @@ def _block_forward(x, mods, training, want_head, ph, keep, sync=None, next_bn=Fa
     w1, b1 = _conv_params(res.conv1)
     st_b = bn_prepare(p, bn_b, training, sync, counters, want_minmax=mm(p, w1))
     b, b_max, b_16 = _bn_fwd_for_conv(p, st_b, prelu_b.weight, w1, keep_f32=True, need_wgrad=keep)      # (the residual reads it)
-    r1 = _conv_fwd_any(b, b_16, w1, b1, b_max, packs, (res.bn1, training))
     w2, b2 = _conv_params(res.conv2)
-    st1 = bn_prepare(r1, res.bn1, training, sync, counters, want_minmax=mm(r1, w2))
-    s1, s1_max, s1_16 = _bn_fwd_for_conv(r1, st1, res.prelu1.weight, w2, need_wgrad=keep)
-    r2 = _conv_fwd_any(s1, s1_16, w2, b2, s1_max, packs, (res.bn2, training))
     w3, b3 = _conv_params(res.conv3)
-    st2 = bn_prepare(r2, res.bn2, training, sync, counters, want_minmax=mm(r2, w3))
-    s2, s2_max, s2_16 = _bn_fwd_for_conv(r2, st2, res.prelu2.weight, w3, need_wgrad=keep)
+    # inference: conv1 -> bn1 -> PReLU and conv2 -> bn2 -> PReLU as one launch each (the epilogue writes the next convolution's
+    # limbs); training, or a layer the fold does not cover: convolution, statistics / range, apply pass
+    fold = (not training) and not keep
+    s1_16 = _eval_conv_act(b_16, w1, b1, res.bn1, res.prelu1.weight, w2) if fold else None
+    if s1_16 is not None:
+        r1 = s1 = st1 = None
+        s1_max = s1_16.amax
+    else:
+        r1 = _conv_fwd_any(b, b_16, w1, b1, b_max, packs, (res.bn1, training))
+        st1 = bn_prepare(r1, res.bn1, training, sync, counters, want_minmax=mm(r1, w2))
+        s1, s1_max, s1_16 = _bn_fwd_for_conv(r1, st1, res.prelu1.weight, w2, need_wgrad=keep)
+        if fold:
+            _act_calibrate(res.bn1, w1, s1_16)
+    s2_16 = _eval_conv_act(s1_16, w2, b2, res.bn2, res.prelu2.weight, w3) if fold else None
+    if s2_16 is not None:
+        r2 = s2 = st2 = None
+        s2_max = s2_16.amax
+    else:
+        r2 = _conv_fwd_any(s1, s1_16, w2, b2, s1_max, packs, (res.bn2, training))
+        st2 = bn_prepare(r2, res.bn2, training, sync, counters, want_minmax=mm(r2, w3))
+        s2, s2_max, s2_16 = _bn_fwd_for_conv(r2, st2, res.prelu2.weight, w3, need_wgrad=keep)
+        if fold:
+            _act_calibrate(res.bn2, w2, s2_16)
     r3 = _conv_fwd_any(s2, s2_16, w3, b3, s2_max, packs, (res.bn3, training))
     st3 = bn_prepare(r3, res.bn3, training, sync, counters)
     feat, fidx = (None, None)

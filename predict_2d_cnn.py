@@ -73,17 +73,31 @@ def load_fold_models(experiment, folds, device, model_cls):
     return models
 
 
-def ensemble_batch(models, signal):
+def ensemble_batch(models, signal, scope=None):
     """Mean over the fold models of sigmoid(logits) for one device batch.  The front-end (STFT -> mel -> log) has no
-    trained parameters, so it runs once and its output feeds every fold's conv stack."""
+    trained parameters, so it runs once and its output feeds every fold's conv stack.
+    scope (functional.act_fold_scope()): the residual units run conv -> BatchNorm -> PReLU as one launch with calibrated operand
+    scales where the arithmetic has scales (f16x6); the caller asks `scope.ok()` once the result is on its way to the host and
+    calls again WITHOUT a scope if it is not (a scale was outgrown: never seen on the synthetic or the golden inputs)."""
     from freesound_classification_amd import functional as F
-    with torch.no_grad():
+    import contextlib
+    with torch.no_grad(), (scope if scope is not None else contextlib.nullcontext()):
         feats = models[0].features(signal)
         total = None
         for model in models:
             probs = F.sigmoid(model.forward_features(feats)["class_logits"])
             total = probs if total is None else total.add_(probs)
     return total.div_(len(models))
+
+
+def ensemble_batch_checked(models, signal):
+    """ensemble_batch on the folded route, verified: the result as a host array (the check rides on the copy's synchronisation)."""
+    from freesound_classification_amd import functional as F
+    scope = F.act_fold_scope()
+    out = ensemble_batch(models, signal, scope).cpu()
+    if not scope.ok():
+        out = ensemble_batch(models, signal).cpu()
+    return out
 
 
 def predict_folds(experiment, folds, dataset, batches, collate, device, model_cls, models=None):
@@ -100,7 +114,7 @@ def predict_folds(experiment, folds, dataset, batches, collate, device, model_cl
     if order:
         loader = torch.utils.data.DataLoader(dataset, batch_sampler=mine, collate_fn=collate)
         for sample in loader:
-            chunks.append(ensemble_batch(models, sample["signal"].to(device)).cpu().numpy())
+            chunks.append(ensemble_batch_checked(models, sample["signal"].to(device)).numpy())
     local = np.concatenate(chunks).astype(np.float32) if chunks else np.zeros((0, n_classes), np.float32)
     out = np.zeros((len(dataset), n_classes), np.float32)
     if world == 1:

@@ -384,3 +384,99 @@ def test_what_the_scaled_limbs_give_up_operand_range():
         k = int(shifts[i])
         # |x| of image i ~ 2^-k |x|max / 4: operand error <= 2^-39 |x|max each => relative <= 2^-37 2^k; measured ~10x below
         assert float(rel[10][i]) < max(3e-7, 2.0 ** (k - 37)), (i, float(rel[10][i]))
+
+
+@pytest.mark.parametrize("shape", [(64, 100, 100, 16, 53, 3), (16, 150, 150, 32, 107, 1), (128, 337, 337, 8, 26, 3), (128, 96, 170, 9, 20, 3)])
+def test_conv_with_the_batchnorm_and_prelu_in_its_epilogue_equals_the_two_pass_route(shape, l3):
+    """fsc_conv_l16_fwd_act (inference): the limbs the epilogue writes are, bit for bit, those of convolution -> eval-mode
+    BatchNorm + PReLU pass -> limb split with the same declared maximum; pad channels are zero; the largest value written is
+    reported exactly."""
+    n, c_in, c_out, h, w, k = shape
+    gen = torch.Generator(device=DEV).manual_seed(sum(shape))
+    x = torch.randn(n, c_in, h, w, device=DEV, generator=gen)
+    wt = torch.randn(c_out, c_in, k, k, device=DEV, generator=gen) / (c_in * k * k) ** 0.5
+    b = torch.randn(c_out, device=DEV, generator=gen)
+    bn = _BN(c_out, gen).eval()
+    with torch.no_grad():
+        bn.running_mean.normal_(0, 0.3, generator=gen)
+        bn.running_var.uniform_(0.5, 1.5, generator=gen)
+    alpha = 0.25 + 0.1 * torch.rand(c_out, device=DEV, generator=gen)
+    with torch.no_grad():
+        assert F.conv_l16_act_supported(x.shape, wt)
+        t = F.l16_pack(x)
+        r = F.conv_l16(t, wt, b)
+        st = F.bn_prepare(r, bn, False)
+        y = F.bn_act_forward(r, st, alpha)
+        decl = F.amax(y) * 2.0 if l3 == 10 else None
+        want = F.l16_pack(y, x_amax=decl)
+        seen = torch.zeros(1, device=DEV)
+        got = F.conv_l16_act(t, wt, b, st.scale, st.shift, alpha, decl, seen)
+    assert got.limbs == want.limbs and torch.equal(got.data, want.data)
+    assert float(seen) == float(y.abs().max())
+    # without the affine and without the activation: the plain convolution as limbs
+    with torch.no_grad():
+        decl2 = F.amax(r) if l3 == 10 else None
+        got2 = F.conv_l16_act(t, wt, b, None, None, None, decl2, None)
+        assert torch.equal(got2.data, F.l16_pack(r, x_amax=decl2).data)
+
+
+@pytest.mark.parametrize("arith", ["bf16x9", "f16x6"])
+def test_inference_with_folded_residual_units_against_the_two_pass_route(arith):
+    """Eval-mode forward of the cfg-2 network (batch 32 x 10 s: the first two blocks have three-limb tilings) with conv -> BatchNorm -> PReLU of the residual units as one launch:
+    bf16 limbs -- the same logits (to the 1e-7 run-to-run noise of the head's reductions; the limbs themselves are bit-identical: the
+    test above), no scope needed; scaled fp16 limbs -- the first batch calibrates on the two-pass route, the
+    second runs folded inside a scope that is ok(), logits within 1e-5; a calibration that is too small is caught by ok(), dropped,
+    and the next forward is two-pass again."""
+    from freesound_classification_amd.networks.classifiers import TwoDimensionalCNNClassificationModel
+    from test_cfg2_gpu import cfg2_experiment
+    mode0 = F.get_conv_arith()
+    F.set_conv_arith(arith)
+    fold0 = F.EVAL_ACT_FOLD
+
+    def same(a, b):
+        return float((a - b).abs().max()) < 1e-6
+    try:
+        torch.manual_seed(3)
+        m = TwoDimensionalCNNClassificationModel(cfg2_experiment(), device="cuda:0").eval()
+        for mod in m.modules():
+            if isinstance(mod, torch.nn.modules.batchnorm._BatchNorm):
+                mod.running_mean.normal_(0, 0.1)
+                mod.running_var.uniform_(0.5, 1.5)
+        x = 0.1 * torch.randn(32, 441000, 1, device=DEV)
+        with torch.no_grad():
+            F.EVAL_ACT_FOLD = False
+            ref = m(x)["class_logits"].clone()
+            F.EVAL_ACT_FOLD = True
+            F._ACT_CAL.clear()
+            calls = []
+            orig = F.conv_l16_act
+            F.conv_l16_act = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+            try:
+                if arith == "bf16x9":
+                    out = m(x)["class_logits"]
+                    assert len(calls) >= 4 and same(out, ref)
+                else:
+                    first = m(x)["class_logits"]                 # calibrates (no scope: two-pass)
+                    assert not calls and same(first, ref) and len(F._ACT_CAL) >= 4
+                    scope = F.act_fold_scope()
+                    with scope:
+                        out = m(x)["class_logits"]
+                    assert len(calls) >= 4 and scope.ok()
+                    assert float((out - ref).abs().max()) < 1e-5 * max(1.0, float(ref.abs().max()))
+                    # a calibration that is too small: caught, dropped, two-pass again
+                    key = next(iter(F._ACT_CAL))
+                    decl, limit, bn, wt = F._ACT_CAL[key]
+                    F._ACT_CAL[key] = (decl * 2.0 ** -8, limit * 2.0 ** -8, bn, wt)
+                    scope = F.act_fold_scope()
+                    with scope:
+                        m(x)
+                    assert not scope.ok() and key not in F._ACT_CAL
+                    del calls[:]
+                    again = m(x)["class_logits"]
+                    assert not calls and same(again, ref)
+            finally:
+                F.conv_l16_act = orig
+    finally:
+        F.EVAL_ACT_FOLD = fold0
+        F.set_conv_arith(mode0)
+        F._ACT_CAL.clear()
