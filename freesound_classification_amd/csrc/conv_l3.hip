@@ -198,6 +198,7 @@ __global__ __launch_bounds__(256) void l3_unpack_kernel(const uint4* __restrict_
 struct PackDir3 {
     uint4* packed;
     float* w_amax;           // scaled fp16 limbs: receives max |w| (behind the fragments; read by the conv kernel), else nullptr
+    int part_home;           // the partial maxima of the pack live behind THIS direction's w_amax (else: those words are zeroed)
     int cot, co_blocks, nfull, tail_oct, steps, dgrad;
     long frags;              // (fragment, lane) pairs: co_blocks * steps * cot * 64
     int blocks;
@@ -208,7 +209,11 @@ __device__ __forceinline__ void pack3_block(const float* __restrict__ w, int c_o
     if (dir.w_amax != nullptr) {                           // every block folds the partial maxima of l3_wmax_kernel
         float wm = 0.f;
         for (int i = 0; i < kWmaxBlocks3; ++i) wm = fmaxf(wm, wmax_part[i]);
-        if (blk == 0 && threadIdx.x == 0) dir.w_amax[0] = wm;
+        if (blk == 0) {                                    // (every word of the tail defined: packed buffers compare bit for bit)
+            if (threadIdx.x == 0) dir.w_amax[0] = wm;
+            if (threadIdx.x >= 1 && threadIdx.x < 4) dir.w_amax[threadIdx.x] = 0.f;
+            if (!dir.part_home && threadIdx.x < kWmaxBlocks3) dir.w_amax[4 + threadIdx.x] = 0.f;
+        }
         sw = l16::field_to_float(l16::scale_field(wm));
     }
     const int cot = dir.cot, steps = dir.steps, nfull = dir.nfull;
@@ -1228,6 +1233,7 @@ int pack_weights_multi(int count, const fsc_conv_desc* descs, const float* const
             if (pf_out) a = make_dir3(pf, pf_out, 0);
             if (pd_out) b = make_dir3(pd, pd_out, 1);
             if (!pf_out) { a = b; b = PackDir3{}; }
+            a.part_home = 1;
             pj.a = a; pj.b = b;
             pj.part = a.w_amax ? a.w_amax + 4 : nullptr;
             pj.first_block = blocks;

@@ -474,12 +474,14 @@ def test_cfg3_stated_shape_against_the_oracle(arith):
 
 
 # ------------------------------------------------------------------------------ all weight fragments of a step in one go
-def test_multi_tensor_weight_packing_equals_the_per_layer_calls():
+def test_multi_tensor_weight_packing_equals_the_per_layer_calls(request):
     """fsc_conv_l16_pack_weights_multi (what a training forward uses from its second step on) writes bit for bit what the
     per-layer fsc_conv_l16_pack_weights_pair calls write -- 11 weights: two launch chunks, forward-only and both-direction entries."""
     import ctypes as C
     lib = F._lib.load()
     torch.manual_seed(9)
+    F.set_conv_arith(3)                                    # (the two-limb format, whatever the process default)
+    request.addfinalizer(lambda: F.set_conv_arith(None))
     shapes = [c for c, v in T.CONV_CASES.items() if v != (None, None)][:11]         # (n, c_in, c_out, h, w, k) with an L16 tiling
     count = len(shapes)
     assert count == 11

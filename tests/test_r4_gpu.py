@@ -54,7 +54,7 @@ def _bwd(x, dy, res, mean, invstd, gamma, beta, alpha, ws, flag, l16=False):
     dx = torch.empty_like(x)
     dres = torch.empty_like(x) if res is not None else None
     amax = torch.empty(F.AMAX_FLOATS, device=DEV)
-    d16 = F.l16_empty(x.shape, x) if l16 else None
+    d16 = F.l16_empty(x.shape, x, limbs=2) if l16 else None      # (no limb flag in `flag`: the two-limb format, whatever the default arithmetic)
     call("fsc_bn_act_bwd", ptr(dy), None, None, ptr(x), ptr(res), ptr(mean), ptr(invstd), ptr(gamma), ptr(beta), ptr(alpha),
          ptr(dx), ptr(dres), ptr(out["dgamma"]), ptr(out["dbeta"]), ptr(out["dalpha"]), ptr(out["csum"]), n, c, hw, ptr(ws),
          ptr(amax), None, flag, ptr(d16), stream_ptr())
