@@ -17,6 +17,7 @@ SHAPES = {
     "b2c2": (128, 225, 225, 16, 53, 3), "b3e": (128, 225, 337, 16, 53, 3), "b3c2": (128, 337, 337, 8, 26, 3),
     "b4e": (128, 337, 506, 8, 26, 3), "b4c2": (128, 506, 506, 4, 13, 3), "b5e": (128, 506, 759, 4, 13, 3),
     "b5c2": (128, 759, 759, 2, 6, 3), "b5c1": (128, 759, 759, 2, 6, 1),
+    "t128": (128, 128, 128, 64, 215, 3), "t96": (128, 96, 96, 64, 215, 3),      # (development: 8 + 8 and 6 + 6 tiles -- balanced blocks)
 }
 
 
