@@ -721,6 +721,11 @@ class ActFoldScope:
         _ACT_TLS.scope = self._prev
         return False
 
+    def prepare(self, like, slots=256):
+        """Allocate the flag words now, on the current stream (callers that fold on several streams: before they fork)."""
+        if self.seen is None:
+            self.seen = torch.zeros(slots, device=like.device, dtype=torch.float32)
+
     def slot(self, like, limit, key):
         if self.seen is None or len(self.keys) >= self.seen.numel():
             grown = torch.zeros(256 if self.seen is None else 2 * self.seen.numel(), device=like.device, dtype=torch.float32)

@@ -480,3 +480,39 @@ def test_inference_with_folded_residual_units_against_the_two_pass_route(arith):
         F.EVAL_ACT_FOLD = fold0
         F.set_conv_arith(mode0)
         F._ACT_CAL.clear()
+
+
+def test_fold_models_on_several_streams_give_the_single_stream_ensemble():
+    """predict_2d_cnn.ensemble_batch runs the fold models of a batch on FOLD_STREAMS streams (the few-item kernels of one model's late
+    blocks leave most of the chip to the other streams): same probabilities as on one stream, the folded route's scope ok() on both."""
+    import predict_2d_cnn as drv
+    from freesound_classification_amd.networks.classifiers import TwoDimensionalCNNClassificationModel
+    from test_cfg2_gpu import cfg2_experiment
+    mode0 = F.get_conv_arith()
+    streams0 = drv.FOLD_STREAMS
+    F.set_conv_arith("f16x6")
+    try:
+        models = []
+        for i in range(3):
+            torch.manual_seed(10 + i)
+            m = TwoDimensionalCNNClassificationModel(cfg2_experiment(), device="cuda:0").eval()
+            for mod in m.modules():
+                if isinstance(mod, torch.nn.modules.batchnorm._BatchNorm):
+                    mod.running_mean.normal_(0, 0.1)
+                    mod.running_var.uniform_(0.5, 1.5)
+            models.append(m)
+        x = 0.1 * torch.randn(32, 441000, 1, device=DEV)
+        F._ACT_CAL.clear()
+        drv.FOLD_STREAMS = 1
+        ref = drv.ensemble_batch(models, x).clone()               # (calibrates)
+        for n in (1, 2, 3):
+            drv.FOLD_STREAMS = n
+            for _ in range(2):
+                scope = F.act_fold_scope()
+                out = drv.ensemble_batch(models, x, scope).clone()
+                assert scope.ok() and len(scope.keys) >= 12
+                assert float((out - ref).abs().max()) < 1e-6
+    finally:
+        drv.FOLD_STREAMS = streams0
+        F.set_conv_arith(mode0)
+        F._ACT_CAL.clear()
