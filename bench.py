@@ -332,7 +332,7 @@ def run_other_workloads():
         out[name] = {"metric": d["metric"], "value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"], "steps": d["steps"],
                      "dtype": d["dtype"], "scaling": d["scaling"], "workload": d["config"]["workload"],
                      "roofline": {k: roof.get(k) for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "launches_per_step",
-                                                           "avg_launch_ms", "conv_ms_per_step", "stages") if k in roof}}
+                                                           "avg_launch_ms", "conv_ms_per_step", "stages", "streams", "note") if k in roof}}
         for k in ("final_loss", "audio_seconds_per_s", "abi_calls_per_step", "hip_graph", "cpu_baseline", "arith_bits", "fast_mode", "exact_mode", "act_fold"):
             if k in d:
                 out[name][k] = d[k]
@@ -477,7 +477,12 @@ def run_inference(args, w, device, world, rank):
                                   "algorithmic_gflop_per_launch": dom["flops"] / dom["launches"] / 1e9,
                                   "conv_ms_per_step": {k: v["ms"] / n_steps for k, v in fam.items()},
                                   "conv_tflops": {k: v["flops"] / v["ms"] / 1e9 for k, v in fam.items()},
-                                  "conv_ms_total": sum(v["ms"] for v in summ.values()), "wall_ms": 1e3 * elapsed}
+                                  "conv_ms_total": sum(v["ms"] for v in summ.values()), "wall_ms": 1e3 * elapsed,
+                                  "streams": drv.FOLD_STREAMS,
+                                  "note": ("the fold models of a batch run on %d streams: a launch's HIP-event duration includes the share of "
+                                           "the chip the other streams' kernels took while it ran, so `achieved` / `frac` are lower bounds "
+                                           "(one stream, FSC_FOLD_STREAMS=1: frac 0.42 at 1040 clips/s)" % drv.FOLD_STREAMS)
+                                          if drv.FOLD_STREAMS > 1 else None}
         if fast is not None:
             result["fast_mode"] = fast
         if exact is not None:
