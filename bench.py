@@ -394,17 +394,20 @@ def run_inference(args, w, device, world, rank):
     # (the residual units' conv -> BatchNorm -> PReLU run as one launch with calibrated operand scales -- the warm-up batch calibrated
     # them on the two-pass route; whether a scale was outgrown is read once, behind the last batch, and such a batch is recomputed
     # without the fold inside the timed region: what predict_2d_cnn.predict_folds does per batch behind its device-to-host copy)
-    scopes = []
-    for x in padded[:n_steps]:
-        scope = F.act_fold_scope()
-        probs = drv.ensemble_batch(models, x, scope)
-        scopes.append((scope, x))
-        clips += x.shape[0]
-    refolded = 0
-    for scope, x in scopes:
-        if not scope.ok():
-            probs = drv.ensemble_batch(models, x)
-            refolded += 1
+    def run_batches(xs):
+        scopes, redone, last = [], 0, None
+        for x in xs:
+            scope = F.act_fold_scope()
+            last = drv.ensemble_batch(models, x, scope)
+            scopes.append((scope, x))
+        for scope, x in scopes:
+            if not scope.ok():
+                last = drv.ensemble_batch(models, x)
+                redone += 1
+        return redone, last
+
+    refolded, probs = run_batches(padded[:n_steps])
+    clips = sum(x.shape[0] for x in padded[:n_steps])
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -416,11 +419,10 @@ def run_inference(args, w, device, world, rank):
         mode0 = F.get_conv_arith()
         F.set_conv_arith(mode)
         try:
-            drv.ensemble_batch(models, padded[0])
+            drv.ensemble_batch(models, padded[0])             # (calibrates the folded launches of this arithmetic)
             torch.cuda.synchronize()
             t1 = time.perf_counter()
-            for x in padded[:n_steps]:
-                drv.ensemble_batch(models, x)
+            run_batches(padded[:n_steps])
             torch.cuda.synchronize()
             e1 = time.perf_counter() - t1
             return {"conv_arith": ARITH_LABEL[mode], "arith_bits": ARITH_BITS[mode], "value": clips / e1, "unit": "clips/s",

@@ -317,7 +317,18 @@ __global__ void l16_pack_w_multi_kernel(PackJobs jobs) {
 // block for all its items (the host makes the worker count a multiple of the channel blocks), so the sums stay in registers
 // until the end of the kernel: one float4 record per (worker, wave, channel) in `stat_rec`, folded by
 // fsc_bn_records_fold_conv.  pivot = stat_pivot[channel] (the BatchNorm's running mean: close to the batch mean) or 0.
-template <int KH, int KW, int COT, int PT, bool POOL = false, bool STATS = false>
+// ACT16 (inference, fsc_conv_l16_fwd_act; conv_l3.hip has the three-limb twin): the epilogue applies an eval-mode BatchNorm's scale /
+// shift and PReLU and writes the result as the two-limb L16 operand of the next convolution, scaled by the DECLARED maximum the caller
+// brings; same expressions as the two-pass route: bit-identical limbs.
+struct ActArgs2 {
+    const float* scale;
+    const float* shift;
+    const float* alpha;
+    uint2* out16;
+    const float* out_amax;
+    unsigned* seen;
+};
+template <int KH, int KW, int COT, int PT, bool POOL = false, bool STATS = false, bool ACT16 = false>
 __global__ __launch_bounds__(kWaves * 64) void conv_l16_fwd_kernel(LGeom g, const uint4* __restrict__ in,
                                                                     const float* __restrict__ packed,
                                                                     const float* __restrict__ bias,
@@ -326,7 +337,9 @@ __global__ __launch_bounds__(kWaves * 64) void conv_l16_fwd_kernel(LGeom g, cons
                                                                     const float* __restrict__ w_amax,
                                                                     uint8_t* __restrict__ pool_idx = nullptr,
                                                                     const float* __restrict__ stat_pivot = nullptr,
-                                                                    float4* __restrict__ stat_rec = nullptr) {
+                                                                    float4* __restrict__ stat_rec = nullptr,
+                                                                    ActArgs2 act = ActArgs2{}) {
+    static_assert(!ACT16 || (!POOL && !STATS), "ACT16 replaces the plain epilogue");
     constexpr int TAPS = KH * KW;
     constexpr int CO_BLK = COT * 16;
     constexpr int PADH = KH / 2, PADW = KW / 2;
@@ -361,6 +374,8 @@ __global__ __launch_bounds__(kWaves * 64) void conv_l16_fwd_kernel(LGeom g, cons
     const float aw = *w_amax;
     const int fx = scale_field(ax), fw = scale_field(aw);
     const float inv_x = inv_scale(fx, ax), inv_w = inv_scale(fw, aw);
+    float act_s = 1.f, act_seen = 0.f;
+    if constexpr (ACT16) act_s = field_to_float(scale_field(block_amax512(act.out_amax, smem)));
 
     const float inv_per = 1.0f / (float)(g.rows * g.cols), inv_cols = 1.0f / (float)g.cols;
     const float inv_tw = 1.0f / (float)g.tw, inv_thw = 1.0f / (float)(g.th * g.tw);
@@ -771,6 +786,79 @@ __global__ __launch_bounds__(kWaves * 64) void conv_l16_fwd_kernel(LGeom g, cons
             PROF_ADD(3);
             continue;
         }
+        if constexpr (ACT16) {
+            // ---- affine + PReLU + limb split (conv_l3.hip): lane (kq, lm) holds channels kq * 4 + r of pixel lm = one 8-byte half of
+            //      the (octet, limb) vector of that pixel
+            long gpix[PT];
+            {
+                int t = tile;
+                const int twi = t % g.tiles_w; t /= g.tiles_w;
+                const int thi = t % g.tiles_h; t /= g.tiles_h;
+                const int n0 = t * g.nb, h0 = thi * g.th, w0 = twi * g.tw;
+                const long img_u = (long)((g.cout + 7) >> 3) * 2 * g.hw;
+#pragma unroll
+                for (int pt = 0; pt < PT; ++pt) {
+                    const int p = (wid * PT + pt) * 16 + lm;
+                    gpix[pt] = -1;
+                    if (p < g.npix) {
+                        const int per = g.th * g.tw;
+                        const int b = fdiv(p, inv_thw), rem = p - b * per;
+                        const int r = fdiv(rem, inv_tw), cq = rem - r * g.tw;
+                        if (n0 + b < g.n && h0 + r < g.h && w0 + cq < g.w)
+                            gpix[pt] = (long)(n0 + b) * img_u + (long)(h0 + r) * g.w + (w0 + cq);
+                    }
+                }
+            }
+            long hw_a = g.hw;
+            const float* bias_a = bias;
+            asm volatile("" : "+s"(hw_a), "+s"(bias_a));
+            const int oct_out = (g.cout + 7) >> 3;
+            const bool has_aff = act.scale != nullptr, has_alpha = act.alpha != nullptr;
+#pragma unroll
+            for (int i = 0; i < COT; ++i) {
+                float bv[4], sc[4], sh[4], al[4];
+                bool okc[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int cob = co0 + i * 16 + kq * 4 + r;
+                    okc[r] = cob < g.cout;
+                    bv[r] = (add_bias && okc[r]) ? bias_a[cob] : 0.f;
+                    sc[r] = (has_aff && okc[r]) ? act.scale[cob] : 1.f;
+                    sh[r] = (has_aff && okc[r]) ? act.shift[cob] : 0.f;
+                    al[r] = (has_alpha && okc[r]) ? act.alpha[cob] : 0.f;
+                }
+                const int oct = ((co0 + i * 16) >> 3) + (kq >> 1);
+                if (oct < oct_out) {
+#pragma unroll
+                    for (int j = 0; j < PT; ++j) {
+                        if (gpix[j] < 0) continue;
+                        float y[4];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float z = fmaf(acc[i][j][r] * inv_x, inv_w, bv[r]);
+                            const float t = has_aff ? fmaf(z, sc[r], sh[r]) : z;
+                            const float v = (has_alpha && !(t > 0.f)) ? al[r] * t : t;
+                            y[r] = okc[r] ? v : 0.f;
+                            act_seen = fmaxf(act_seen, fabsf(y[r]));
+                        }
+                        unsigned h0, l0, h1, l1;
+                        split2_pair(y[0], y[1], act_s, h0, l0);
+                        split2_pair(y[2], y[3], act_s, h1, l1);
+                        uint2* o = act.out16 + (gpix[j] + (long)oct * 2 * hw_a) * 2 + (kq & 1);
+                        o[0] = make_uint2(h0, h1);
+                        o[2 * hw_a] = make_uint2(l0, l1);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int i = 0; i < COT; ++i)
+#pragma unroll
+                for (int j = 0; j < PT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            drain = true;
+            PROF_ADD(3);
+            continue;
+        }
         // ---- epilogue: D row = channel (kq*4 + r), column = pixel (lm) -> scratch[ch][px] -> lane = (channel, quad).
         //      This lane's quads (four consecutive pixels of a box row) are decoded here, once per item.
         long quad_g[PT];
@@ -861,6 +949,10 @@ __global__ __launch_bounds__(kWaves * 64) void conv_l16_fwd_kernel(LGeom g, cons
     if (blockIdx.x == 0 && tid == 0) {
         g_l16_clock[0] = __builtin_readcyclecounter() - ck0;
         g_l16_clock[1] = __builtin_amdgcn_s_memrealtime() - cr0;
+    }
+    if constexpr (ACT16) {
+        act_seen = fsc::wave_max(act_seen);
+        if (act.seen != nullptr && lane == 0) atomicMax(act.seen, __float_as_uint(act_seen));
     }
     if constexpr (STATS) {
         // the four lanes of a quad hold the same channel: fold them, lane (lane & 3) == 0 writes the record
@@ -1017,14 +1109,22 @@ bool stats_ok(const LPlan& p) { return p.cot <= 8 && p.workers >= p.co_blocks; }
 
 template <int KH, int KW, int COT, int PT>
 int launch_l16(const LPlan& p, const uint4* in, const float* packed, const float* bias, float* out, int accumulate,
-               const float* in_amax, hipStream_t st, StatArgs sa = StatArgs{nullptr, nullptr}) {
+               const float* in_amax, hipStream_t st, StatArgs sa = StatArgs{nullptr, nullptr}, ActArgs2 act = ActArgs2{}) {
     const float* w_amax = packed + l16_limb_floats(p);
+    if (act.out16) {
+        auto kern = conv_l16_fwd_kernel<KH, KW, COT, PT, false, false, true>;
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes);
+        hipLaunchKernelGGL(kern, dim3((unsigned)p.workers), dim3(kWaves * 64), p.lds_bytes, st, p.g, in, packed, bias, (float*)nullptr, 0,
+                           in_amax, w_amax, (uint8_t*)nullptr, (const float*)nullptr, (float4*)nullptr, act);
+        FSC_LAUNCH_CHECK("fsc_conv_l16_fwd_act");
+        return 0;
+    }
     if constexpr (COT <= 8) {
         if (sa.rec) {
             auto kern = conv_l16_fwd_kernel<KH, KW, COT, PT, false, true>;
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes);
             hipLaunchKernelGGL(kern, dim3(stat_workers(p)), dim3(kWaves * 64), p.lds_bytes, st, p.g, in, packed, bias, out, 0, in_amax,
-                               w_amax, (uint8_t*)nullptr, sa.pivot, sa.rec);
+                               w_amax, (uint8_t*)nullptr, sa.pivot, sa.rec, ActArgs2{});
             FSC_LAUNCH_CHECK("fsc_conv_l16_fwd_stats");
             return 0;
         }
@@ -1032,7 +1132,7 @@ int launch_l16(const LPlan& p, const uint4* in, const float* packed, const float
     auto kern = conv_l16_fwd_kernel<KH, KW, COT, PT, false>;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes);
     hipLaunchKernelGGL(kern, dim3((unsigned)p.workers), dim3(kWaves * 64), p.lds_bytes, st, p.g, in, packed, bias, out,
-                       accumulate, in_amax, w_amax, (uint8_t*)nullptr, (const float*)nullptr, (float4*)nullptr);
+                       accumulate, in_amax, w_amax, (uint8_t*)nullptr, (const float*)nullptr, (float4*)nullptr, ActArgs2{});
     FSC_LAUNCH_CHECK("fsc_conv_l16_fwd");
     return 0;
 }
@@ -1045,39 +1145,39 @@ int launch_l16_pool(const LPlan& p, const uint4* in, const float* packed, const 
         auto kern = conv_l16_fwd_kernel<3, 3, COT, 2, true, true>;
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes);
         hipLaunchKernelGGL(kern, dim3(stat_workers(p)), dim3(kWaves * 64), p.lds_bytes, st, p.g, in, packed, bias, pooled, 0, in_amax,
-                           w_amax, idx, sa.pivot, sa.rec);
+                           w_amax, idx, sa.pivot, sa.rec, ActArgs2{});
         FSC_LAUNCH_CHECK("fsc_conv_l16_pool_fwd_stats");
         return 0;
     }
     auto kern = conv_l16_fwd_kernel<3, 3, COT, 2, true>;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes);
     hipLaunchKernelGGL(kern, dim3((unsigned)p.workers), dim3(kWaves * 64), p.lds_bytes, st, p.g, in, packed, bias, pooled, 0,
-                       in_amax, w_amax, idx, (const float*)nullptr, (float4*)nullptr);
+                       in_amax, w_amax, idx, (const float*)nullptr, (float4*)nullptr, ActArgs2{});
     FSC_LAUNCH_CHECK("fsc_conv_l16_pool_fwd");
     return 0;
 }
 
 template <int KH, int KW, int COT>
 int launch_l16_pt(const LPlan& p, const uint4* in, const float* packed, const float* bias, float* out, int accumulate,
-                  const float* in_amax, hipStream_t st, StatArgs sa = StatArgs{nullptr, nullptr}) {
-    if (p.pt == 2) return launch_l16<KH, KW, COT, 2>(p, in, packed, bias, out, accumulate, in_amax, st, sa);
-    return launch_l16<KH, KW, COT, 1>(p, in, packed, bias, out, accumulate, in_amax, st, sa);
+                  const float* in_amax, hipStream_t st, StatArgs sa = StatArgs{nullptr, nullptr}, ActArgs2 act = ActArgs2{}) {
+    if (p.pt == 2) return launch_l16<KH, KW, COT, 2>(p, in, packed, bias, out, accumulate, in_amax, st, sa, act);
+    return launch_l16<KH, KW, COT, 1>(p, in, packed, bias, out, accumulate, in_amax, st, sa, act);
 }
 
 template <int KH, int KW>
 int launch_l16_cot(const LPlan& p, const uint4* in, const float* packed, const float* bias, float* out, int accumulate,
-                   const float* in_amax, hipStream_t st, StatArgs sa = StatArgs{nullptr, nullptr}) {
+                   const float* in_amax, hipStream_t st, StatArgs sa = StatArgs{nullptr, nullptr}, ActArgs2 act = ActArgs2{}) {
     switch (p.cot) {
 #ifndef FSC_L16_DEV          // (development builds: only the instantiations of the cfg-2 layers, a third of the compile time)
-        case 3: return launch_l16_pt<KH, KW, 3>(p, in, packed, bias, out, accumulate, in_amax, st, sa);
-        case 4: return launch_l16_pt<KH, KW, 4>(p, in, packed, bias, out, accumulate, in_amax, st, sa);
-        case 6: return launch_l16_pt<KH, KW, 6>(p, in, packed, bias, out, accumulate, in_amax, st, sa);
-        case 9: if constexpr (KH * KW > 1) return launch_l16_pt<KH, KW, 9>(p, in, packed, bias, out, accumulate, in_amax, st, sa); break;
-        case 10: if constexpr (KH * KW > 1) return launch_l16_pt<KH, KW, 10>(p, in, packed, bias, out, accumulate, in_amax, st, sa); break;
+        case 3: return launch_l16_pt<KH, KW, 3>(p, in, packed, bias, out, accumulate, in_amax, st, sa, act);
+        case 4: return launch_l16_pt<KH, KW, 4>(p, in, packed, bias, out, accumulate, in_amax, st, sa, act);
+        case 6: return launch_l16_pt<KH, KW, 6>(p, in, packed, bias, out, accumulate, in_amax, st, sa, act);
+        case 9: if constexpr (KH * KW > 1) return launch_l16_pt<KH, KW, 9>(p, in, packed, bias, out, accumulate, in_amax, st, sa, act); break;
+        case 10: if constexpr (KH * KW > 1) return launch_l16_pt<KH, KW, 10>(p, in, packed, bias, out, accumulate, in_amax, st, sa, act); break;
 #endif
-        case 5: return launch_l16_pt<KH, KW, 5>(p, in, packed, bias, out, accumulate, in_amax, st, sa);
-        case 7: return launch_l16_pt<KH, KW, 7>(p, in, packed, bias, out, accumulate, in_amax, st, sa);
-        case 8: return launch_l16_pt<KH, KW, 8>(p, in, packed, bias, out, accumulate, in_amax, st, sa);
+        case 5: return launch_l16_pt<KH, KW, 5>(p, in, packed, bias, out, accumulate, in_amax, st, sa, act);
+        case 7: return launch_l16_pt<KH, KW, 7>(p, in, packed, bias, out, accumulate, in_amax, st, sa, act);
+        case 8: return launch_l16_pt<KH, KW, 8>(p, in, packed, bias, out, accumulate, in_amax, st, sa, act);
         default: break;
     }
     fsc::set_error("fsc_conv_l16_fwd: internal: no instantiation for %d channel tiles", p.cot);
@@ -1324,15 +1424,22 @@ int fsc_debug_l16_prof(unsigned long long* out64) {
 #endif
 
 /* include/fsc_hip.h: inference -- convolution + per-channel affine + PReLU, written as the L16 operand of the next convolution */
-int fsc_conv_l16_fwd_act_supported(const fsc_conv_desc* d) {
-    return d && l16::is_l3(d->arith) ? fsc::l3::supported(d, 0) : 0;
-}
+int fsc_conv_l16_fwd_act_supported(const fsc_conv_desc* d) { return fsc_conv_l16_supported(d, 0); }
 
 int fsc_conv_l16_fwd_act(const fsc_conv_desc* d, const void* in_l16, const float* in_amax, const float* packed, const float* bias,
                          const float* scale, const float* shift, const float* alpha, void* out_l16, const float* out_amax,
                          float* seen_max, fsc_stream_t stream) {
-    FSC_CHECK_ARG(d && l16::is_l3(d->arith), "fsc_conv_l16_fwd_act: three-limb arithmetics only (arith 9 / 10)");
-    return fsc::l3::fwd_act(d, in_l16, in_amax, packed, bias, scale, shift, alpha, out_l16, out_amax, seen_max, fsc::as_stream(stream));
+    if (d && l16::is_l3(d->arith))
+        return fsc::l3::fwd_act(d, in_l16, in_amax, packed, bias, scale, shift, alpha, out_l16, out_amax, seen_max, fsc::as_stream(stream));
+    LPlan p;
+    FSC_CHECK_ARG(valid_l16_desc(d) && in_l16 && in_amax && packed && out_l16 && out_amax, "fsc_conv_l16_fwd_act: bad descriptor or null pointer");
+    FSC_CHECK_ARG((scale == nullptr) == (shift == nullptr), "fsc_conv_l16_fwd_act: scale and shift come together");
+    FSC_CHECK_ARG(plan_l16(*d, 0, &p), "fsc_conv_l16_fwd_act: unsupported shape (see fsc_conv_l16_supported)");
+    hipStream_t st = fsc::as_stream(stream);
+    const uint4* in = reinterpret_cast<const uint4*>(in_l16);
+    ActArgs2 act{scale, shift, alpha, reinterpret_cast<uint2*>(out_l16), out_amax, reinterpret_cast<unsigned*>(seen_max)};
+    if (d->kh == 3) return launch_l16_cot<3, 3>(p, in, packed, bias, nullptr, 0, in_amax, st, StatArgs{nullptr, nullptr}, act);
+    return launch_l16_cot<1, 1>(p, in, packed, bias, nullptr, 0, in_amax, st, StatArgs{nullptr, nullptr}, act);
 }
 
 int fsc_conv_l16_plan_describe(const fsc_conv_desc* d, int dgrad, char* buf, size_t buf_len) {

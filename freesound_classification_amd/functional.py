@@ -685,8 +685,8 @@ def conv_l16(t, weight, bias, dgrad=False, accumulate_into=None, prepacked=None,
 
 
 # ---- inference: convolution + eval-mode BatchNorm + PReLU written straight as the next convolution's L16 operand
-# (fsc_conv_l16_fwd_act, three-limb arithmetics).  bf16 limbs (arith 9) carry no scale: the fold is unconditional.  Scaled fp16
-# limbs (arith 10) need the DECLARED maximum of the output before it exists: a calibrated bound -- what the two-pass route derived
+# (fsc_conv_l16_fwd_act).  bf16 limbs (arith 9) carry no scale: the fold is unconditional.  Scaled fp16
+# limbs (arith 3, 10) need the DECLARED maximum of the output before it exists: a calibrated bound -- what the two-pass route derived
 # for this layer on an earlier batch, doubled -- and a check that nothing outgrew it.  The check reads device memory, so it belongs
 # to the caller's own synchronisation point: the fold with a calibrated scale only runs inside an `act_fold_scope()`, whose
 # `ok()` the caller asks once the results are on their way to the host anyway (predict_2d_cnn.ensemble_batch / predict_folds);
@@ -755,7 +755,7 @@ def act_fold_scope():
 
 
 def conv_l16_act_supported(t_shape, weight):
-    if not EVAL_ACT_FOLD or _l16_arith() not in (9, 10) or len(t_shape) != 4:
+    if not EVAL_ACT_FOLD or _l16_arith() is None or len(t_shape) != 4:
         return False
     c_out, c_in, kh, kw = weight.shape
     n, _, h, w = t_shape
@@ -1584,7 +1584,7 @@ def _eval_conv_act(t16, weight, bias, bn, alpha, next_weight):
     if not conv_l16_act_supported(t16.shape, weight) or not _l16_ok_for((n, weight.shape[0], h, w), next_weight, False):
         return None
     decl = seen = None
-    if _l16_arith() == 10:
+    if _l16_limbs() != 3:                                    # (scaled fp16 limbs: f16x3, f16x6)
         scope = _ACT_TLS.scope
         cal = _ACT_CAL.get(_act_key(bn, weight)) if scope is not None else None
         if cal is None:
@@ -1599,7 +1599,7 @@ def _act_calibrate(bn, weight, t16):
     """Scaled fp16 limbs, inference on the two-pass route: remember TWICE the bound this batch declared for the layer's output as
     the scale of the folded launches to come (the fp16 high limb itself holds another factor 1.99 above the declared maximum:
     `limit`, what ActFoldScope.ok() compares the largest value written with)."""
-    if not EVAL_ACT_FOLD or _l16_arith() != 10 or t16 is None or t16.amax is None or torch.is_grad_enabled():
+    if not EVAL_ACT_FOLD or _l16_arith() is None or _l16_limbs() == 3 or t16 is None or t16.amax is None or torch.is_grad_enabled():
         return
     key = _act_key(bn, weight)
     if key in _ACT_CAL:

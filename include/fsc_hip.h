@@ -214,16 +214,16 @@ int fsc_conv_l16_pack_weights_multi(int count, const fsc_conv_desc* descs, const
 int fsc_conv_l16_fwd(const fsc_conv_desc* d, const void* in_l16, const float* in_amax, const float* packed,
                      const float* bias, int dgrad, int accumulate, float* out, fsc_stream_t stream);
 int fsc_conv_l16_plan_describe(const fsc_conv_desc* d, int dgrad, char* buf, size_t buf_len);
-/* Inference (three-limb arithmetics, arith 9 / 10): convolution whose epilogue applies an eval-mode BatchNorm and PReLU and writes
+/* Inference (the L16 arithmetics: 3, 9, 10): convolution whose epilogue applies an eval-mode BatchNorm and PReLU and writes
  * the result as the L16 operand of the NEXT convolution -- nn.Conv2d -> nn.BatchNorm2d (eval) -> nn.PReLU of a residual unit
  * (reference classifiers.py:77-101) in one launch, 6 bytes per element leaving the kernel instead of 4 + 4 + 6 through the separate
  * pass.  y = prelu(fma(conv(x) + bias, scale[c], shift[c]), alpha[c]); scale / shift = fsc_bn_eval_prepare's (both NULL: identity),
  * alpha NULL: no activation.  Same expressions as fsc_conv_l16_fwd followed by fsc_bn_act_fwd_limbs: bit-identical limbs.
- * out_l16: fsc_l16_bytes_limbs(n, c_out, h * w, 3 | FSC_L16_F16X3) bytes.  arith 10: `out_amax` (FSC_AMAX_FLOATS floats) is the
+ * out_l16: fsc_l16_bytes_limbs(n, c_out, h * w, 2 | 3 | FSC_L16_F16X3) bytes.  arith 3 / 10 (scaled fp16 limbs): `out_amax` (FSC_AMAX_FLOATS floats) is the
  * DECLARED maximum of |y| the limbs are scaled by -- a calibrated bound the caller brings (e.g. the bound the two-pass route derived
  * on an earlier batch, with headroom); elements beyond it saturate, so the kernel max-es the largest |y| it wrote into
  * `seen_max[0]` (atomic; the caller zeroes it before the launch and compares afterwards; may be NULL).  arith 9: no scale, out_amax
- * unused.  _supported: 1 when the shape has a three-limb forward tiling. */
+ * unused.  _supported: 1 when the shape has an L16 forward tiling in the descriptor's arithmetic. */
 int fsc_conv_l16_fwd_act_supported(const fsc_conv_desc* d);
 int fsc_conv_l16_fwd_act(const fsc_conv_desc* d, const void* in_l16, const float* in_amax, const float* packed, const float* bias,
                          const float* scale, const float* shift, const float* alpha, void* out_l16, const float* out_amax,
