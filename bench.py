@@ -11,11 +11,12 @@ same per-GPU batch on every rank (weak scaling), value = clips of all ranks / ma
 
 Arithmetic of `value` (cfg 2): fp32 tensors and accumulators, every convolution product formed to 2^-32 -- each operand is split by
 the kernel that produces it into three scaled fp16 limbs (24-bit operands, exact for every element within 2^-16 of its tensor's
-maximum) and six limb products run on v_mfma_f32_16x16x32_f16 with fp32 accumulation ("f16x6", fsc_conv_desc.arith = 10): for an
+maximum) and six limb products run on v_mfma_f32_16x16x32_f16 with fp32 accumulation ("f16x6", fsc_conv_desc.arith = 10 -- the
+LIBRARY DEFAULT since round 6: `value` is measured with no arithmetic selected anywhere): for an
 fp32 accumulator the arithmetic of the reference's nn.Conv2d on fp32 tensors (per-layer errors against fp64 0.1 - 1.4x those of
 PyTorch's own fp32 convolution, tests/test_l3_gpu.py).  Timed beside it, outside `value`: `exact_mode` (bf16x9: three exact
-bf16 limbs, all nine products -- the product of the two fp32 operands is EXACT whatever their range), `fast_mode` (the library's
-shipped default f16x3: two scaled fp16 limbs, three products, 22-bit products) and `alt_f32` (the native fp32-MFMA kernels).
+bf16 limbs, all nine products -- the product of the two fp32 operands is EXACT whatever their range), `fast_mode` (the opt-in
+f16x3: two scaled fp16 limbs, three products, 22-bit products) and `alt_f32` (the native fp32-MFMA kernels).
 
 Rank 0 prints one JSON line carrying `roofline` (dominant kernel = the conv kernel with the largest
 total time, FLOPs over HIP-event time measured inside the timed region), at N = 1 `fast_mode` / `alt_f32` (the same
@@ -48,7 +49,7 @@ class NS(dict):
 WORKLOADS = {
     # BASELINE.json configs[1]
     "cfg2": dict(features="mel_2048_1024_128", blocks=6, base=100, growth=1.5, start=1, dropout=0.7,
-                 batch=128, samples=441000, sr=44100, n_mel=128, arith="f16x6"),
+                 batch=128, samples=441000, sr=44100, n_mel=128),    # (arithmetic: the library default, f16x6)
     # BASELINE.json configs[2]: 1-d raw-STFT path (win 256), 10-block hierarchical CNN, LSEP + MixUp.
     # hop 128 / base 64 / growth 1.25 are SURVEY section 8d's assumptions.  bf16: conv operands rounded to one bf16
     # value, v_mfma_f32_16x16x32_bf16 with fp32 accumulation; weights / BN statistics / optimizer state fp32 masters
@@ -70,7 +71,7 @@ WORKLOADS = {
     # 4096 clips, lengths U(0.3 s, 30 s) @ 44.1 kHz seed 7, bucket edges every 2 s, <= 128 x 10 s of samples per
     # batch; the cfg-2 network).  A "step" is one length-grouped batch through all five resident fold models.
     "cfg5": dict(features="mel_2048_1024_128", blocks=6, base=100, growth=1.5, start=1, dropout=0.7,
-                 batch=128, samples=441000, sr=44100, n_mel=128, arith="f16x6", inference=dict(folds=5, clips=4096, seed=7,
+                 batch=128, samples=441000, sr=44100, n_mel=128, inference=dict(folds=5, clips=4096, seed=7,
                                                                                  min_s=0.3, max_s=30.0, bucket_s=2.0)),
 }
 
@@ -433,7 +434,7 @@ def run_inference(args, w, device, world, rank):
         finally:
             F.set_conv_arith(mode0)
 
-    if world == 1 and F.get_conv_arith() != 3:              # the library's default (fast) arithmetic
+    if world == 1 and F.get_conv_arith() != 3:              # the opt-in fast arithmetic (22-bit products)
         fast = repass(3)
     if world == 1 and F.get_conv_arith() == 10:             # exact products (bf16x9)
         exact = repass(9)
@@ -588,7 +589,7 @@ def main():
     ap.add_argument("--no-other", action="store_true", help="skip the short cfg3 / cfg5 runs attached to the default cfg2 line (other_workloads)")
     ap.add_argument("--kernel-table", action="store_true", help="print per-kernel timing to stderr")
     ap.add_argument("--arith", default=None, choices=["f32", "bf16", "f16x3", "bf16x6", "bf16x9", "f16x6"],
-                    help="conv arithmetic (default: the workload's, else the library default f16x3)")
+                    help="conv arithmetic (default: the workload's (cfg3: bf16), else the library default = f16x6)")
     ap.add_argument("--launch-check", action="store_true",
                     help="rendezvous + barrier + gradient-sized all-reduce only (no model); with --backend gloo it runs on CPU")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="process-group backend (gloo: --launch-check only)")

@@ -2065,9 +2065,11 @@ size_t x3_limb_floats(const FwdPlan& p) {
 }
 
 // Arithmetic of the conv kernels: 0 = native fp32 MFMA everywhere; 3 = scaled split-fp16 (two limbs, three
-// products; the default), 6 / 9 = split-bf16 (three limbs, that many products) wherever the x3 tilings fit.
+// products: 22-bit products, the opt-in FAST mode), 6 / 9 = split-bf16 (three limbs, that many products) wherever the x3
+// tilings fit, 10 = three scaled fp16 limbs, six products (products to 2^-32: the reference's fp32 nn.Conv2d precision,
+// classifiers.py:526-531, 77-81 -- THE DEFAULT since round 6: what bench.py measures is what the library ships).
 // A PER-CALL property: fsc_conv_desc.arith; FSC_ARITH_DEFAULT (-1) there means the process default, which is
-// read once from the environment (FSC_CONV_ARITH=f32|f16x3|bf16x6|bf16x9|f16x6, else 3) and never changes afterwards.
+// read once from the environment (FSC_CONV_ARITH=f32|f16x3|bf16x6|bf16x9|f16x6, else 10) and never changes afterwards.
 int default_arith() {
     static const int mode = [] {
         const char* e = getenv("FSC_CONV_ARITH");
@@ -2075,8 +2077,9 @@ int default_arith() {
         if (e && !strcmp(e, "bf16")) return 1;
         if (e && !strcmp(e, "bf16x6")) return 6;
         if (e && !strcmp(e, "bf16x9")) return 9;
-        if (e && !strcmp(e, "f16x6")) return 10;
-        return 3;
+        if (e && !strcmp(e, "f16x3")) return 3;
+        if (e && *e && strcmp(e, "f16x6")) fprintf(stderr, "libfsc_hip: unknown FSC_CONV_ARITH=%s, using f16x6\n", e);
+        return 10;
     }();
     return mode;
 }

@@ -109,7 +109,7 @@ def frontend_stft(wave, n_fft, hop, apply_log, freq_channel=False):
 
 
 # ------------------------------------------------------------------------------ convolution
-_ARITH = None        # host-side default for the descriptors built here (None: the library's FSC_CONV_ARITH default)
+_ARITH = None        # host-side default for the descriptors built here (None: the library's default -- FSC_CONV_ARITH, else f16x6)
 
 
 def _desc(n, c_in, c_out, h, w, kh, kw, arith=None):
@@ -245,10 +245,12 @@ ARITH_NAMES = {"f32": 0, "bf16": 1, "f16x3": 3, "bf16x6": 6, "bf16x9": 9, "f16x6
 
 def set_conv_arith(mode):
     """Arithmetic the descriptors built by this module ask for (fsc_conv_desc.arith, include/fsc_hip.h).
-    0 / "f32": native fp32 MFMA; 3 / "f16x3" (the default): fp32 via two fp16 limbs with exact power-of-two
-    operand scaling, three limb products; 6, 9 / "bf16x6", "bf16x9": fp32 via exact three-limb bf16 split with
+    0 / "f32": native fp32 MFMA; 3 / "f16x3" (the opt-in FAST mode: 22-bit products): fp32 via two fp16 limbs with exact
+    power-of-two operand scaling, three limb products; 6, 9 / "bf16x6", "bf16x9": fp32 via exact three-limb bf16 split with
     that many limb products; 10 / "f16x6": three SCALED fp16 limbs, six products, on the pre-split (L16) route -- fp32-equivalent
-    (products to 2^-32) at two thirds of bf16x9's matrix work, bf16x9 wherever a layer has no L16 kernel; 1 / "bf16": plain bf16 operands, fp32 accumulation (mixed precision, cfg 3); None: back to the library default (FSC_CONV_ARITH or 3).  Host-side convenience only:
+    (products to 2^-32) at two thirds of bf16x9's matrix work, bf16x9 wherever a layer has no L16 kernel -- THE LIBRARY DEFAULT
+    (round 6: the arithmetic bench.py's `value` is measured in is the one that ships); 1 / "bf16": plain bf16 operands, fp32
+    accumulation (mixed precision, cfg 3); None: back to the library default (FSC_CONV_ARITH or 10).  Host-side convenience only:
     the C ABI takes the mode per call."""
     global _ARITH
     mode = ARITH_NAMES.get(mode, mode)

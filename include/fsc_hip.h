@@ -152,7 +152,8 @@ int fsc_conv_plan_describe(const fsc_conv_desc* d, int mode, char* buf, size_t b
  * accumulation, unscaled exactly.  For an fp32 accumulator -- which rounds every partial sum at 2^-24 -- that is the same
  * arithmetic as mode 9 at two thirds of the matrix work; what it gives up is mode 9's independence of the operands' range.
  * Inputs, outputs and accumulators are fp32
- * in every mode.  FSC_ARITH_DEFAULT selects the process default: 3, or the environment variable
+ * in every mode.  FSC_ARITH_DEFAULT selects the process default: 10 (the reference's fp32 nn.Conv2d precision,
+ * classifiers.py:526-531, 77-81; mode 3 is the opt-in fast mode with 22-bit products), or the environment variable
  * FSC_CONV_ARITH = f32 | bf16 | f16x3 | bf16x6 | bf16x9 | f16x6, read once.  The packed-weight format depends on the mode:
  * pack with the descriptor (same `arith`) the weights are used with. */
 int fsc_conv_default_arith(void);

@@ -82,6 +82,11 @@ def build_parser(default_label="2d_cnn"):
     p.add_argument("--synthetic_sr", type=int, default=16000)
     p.add_argument("--loss", default="lsep", choices=["lsep", "bce"])
     p.add_argument("--experiments_dir", default="experiments")
+    p.add_argument("--conv_arith", default=None, choices=("f16x6", "bf16x9", "f16x3", "f32", "bf16"),
+                   help="arithmetic of the convolutions.  Default (the library's): f16x6 -- three scaled fp16 limbs, six MFMA "
+                        "products, products to 2^-32: the reference's fp32 nn.Conv2d precision; bf16x9: exact fp32 products "
+                        "whatever the operands' range; f16x3: the opt-in FAST mode (22-bit products); f32: native fp32 MFMA; "
+                        "bf16: mixed precision (cfg 3)")
     return p
 
 
@@ -154,6 +159,9 @@ def main(model_cls=TwoDimensionalCNNClassificationModel, default_label="2d_cnn",
         torch.cuda.set_device(local)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
         args.device = "cuda:%d" % local
+    if args.conv_arith is not None:
+        from freesound_classification_amd import functional as F
+        F.set_conv_arith(args.conv_arith)
     if args.p_aug > 0:
         raise NotImplementedError("--p_aug: the sox AudioAugmentation (pysndfx) is outside the accelerated path")
     is_main = parallel.rank() == 0
