@@ -227,6 +227,9 @@ class _timed:
         if self.on:
             self.name = plan_name(desc, mode)
             self.flops = 2.0 * desc.n * desc.h * desc.w * desc.c_in * desc.c_out * desc.kh * desc.kw
+            # (algorithmic bytes of the call: fp32 operands once + the result once)
+            TIMER.note(self.name, self.flops, (desc.n, desc.c_in, desc.c_out, desc.h, desc.w, desc.kh, desc.kw),
+                       ("fwd", "dgrad", "wgrad")[mode] if mode in (0, 1, 2) else "fwd")
 
     def __enter__(self):
         if self.on:
@@ -471,7 +474,8 @@ _EVAL_BN = {}
 
 
 def forget_packed_weights():
-    """THE invalidation hook of the inference caches (packed weight fragments, folded eval-mode BatchNorm scale / shift).  The
+    """THE invalidation hook of the inference caches (packed weight fragments, folded eval-mode BatchNorm scale / shift, the
+    calibrated operand ranges of the folded conv -> BatchNorm -> PReLU launches).  The
     caches are keyed by address and torch version counter, so every in-place torch op invalidates them by itself; anything that
     writes parameters or BatchNorm buffers through raw pointers (this library's optimizers do, an external EMA / SWA kernel would)
     must call this.  Called by the Fused* optimizers' step(), a training-mode bn_prepare, and the model's train() /
@@ -479,6 +483,7 @@ def forget_packed_weights():
     global _XPACK_RECORD
     _EVAL_PACKS.clear()
     _EVAL_BN.clear()
+    _ACT_CAL.clear()          # (calibrated output ranges of the folded inference launches: they depend on every parameter in front)
     _XPACKED.clear()          # (fragments packed up front for a step are that step's)
     _XPACK_RECORD = None      # (and the recording of a first step ends with its optimizer step)
 
@@ -507,7 +512,7 @@ def conv_l16_pack(weight, n, h, w, dgrad):
         raise _lib.FscError("conv_l16: unsupported shape %s" % [getattr(d, f) for f, _ in d._fields_])
     key = None
     if not dgrad and not torch.is_grad_enabled():
-        key = (weight.data_ptr(), weight._version, tuple(weight.shape), nfl) + _l16_plan_sig(d)
+        key = (weight.data_ptr(), weight._version, tuple(weight.shape), nfl, _l16_arith()) + _l16_plan_sig(d)
         hit = _EVAL_PACKS.get(key)
         if hit is not None:
             return d, hit[0]
@@ -706,50 +711,90 @@ _ACT_TLS = _ActFoldTLS()
 
 
 class ActFoldScope:
-    """Collects (largest |y| written, limit) of every calibrated fold launched while it is the current scope."""
+    """Collects (largest |y| written, limit) of every calibrated fold launched while it is the current scope.  The flag words
+    live in fixed chunks of SLOTS floats that are NEVER reallocated: a view handed to a launched kernel stays the word `ok()`
+    reads, on whatever stream the kernel runs (a grown-and-copied buffer lost the maxima of kernels on other streams)."""
+    SLOTS = 256
 
     def __init__(self):
-        self.seen = None
+        self.chunks = []
         self.limits = []
         self.keys = []
         self._prev = None
+        self._depth = 0
 
     def __enter__(self):
-        self._prev = _ACT_TLS.scope
-        _ACT_TLS.scope = self
+        if self._depth == 0:                  # (re-entrant: eval_checked enters the scope and hands it to a callee that enters it too)
+            self._prev = _ACT_TLS.scope
+            _ACT_TLS.scope = self
+        self._depth += 1
         return self
 
     def __exit__(self, *exc):
-        _ACT_TLS.scope = self._prev
+        self._depth -= 1
+        if self._depth == 0:
+            _ACT_TLS.scope = self._prev
+            self._prev = None
         return False
 
     def prepare(self, like, slots=256):
-        """Allocate the flag words now, on the current stream (callers that fold on several streams: before they fork)."""
-        if self.seen is None:
-            self.seen = torch.zeros(slots, device=like.device, dtype=torch.float32)
+        """Allocate flag words for `slots` folded launches now, on the current stream (callers that fold on several streams:
+        before they fork, sized models x folded layers, so that no chunk is first touched on a side stream)."""
+        while len(self.chunks) * self.SLOTS < slots:
+            self.chunks.append(torch.zeros(self.SLOTS, device=like.device, dtype=torch.float32))
 
     def slot(self, like, limit, key):
-        if self.seen is None or len(self.keys) >= self.seen.numel():
-            grown = torch.zeros(256 if self.seen is None else 2 * self.seen.numel(), device=like.device, dtype=torch.float32)
-            if self.seen is not None:
-                grown[:self.seen.numel()] = self.seen
-            self.seen = grown
         i = len(self.keys)
+        if i >= len(self.chunks) * self.SLOTS:       # (a further chunk: zeroed on the stream of the launch that uses it first)
+            self.chunks.append(torch.zeros(self.SLOTS, device=like.device, dtype=torch.float32))
         self.limits.append(limit)
         self.keys.append(key)
-        return self.seen[i:i + 1]
+        return self.chunks[i // self.SLOTS][i % self.SLOTS:i % self.SLOTS + 1]
 
-    def ok(self):
-        """True when no calibrated scale was outgrown (synchronises: reads the flags).  Otherwise the calibrations concerned are
-        dropped -- the next forward takes the two-pass route for those layers and calibrates afresh -- and the caller recomputes."""
+    def bad_mask(self):
+        """Device float tensor, one entry per folded launch: 1.0 where the largest value written outgrew the calibrated limit
+        (None when nothing was folded).  Callers append it to the result they copy to the host anyway -- ONE device-to-host
+        copy and one synchronisation per batch -- and hand the host copy to ok()."""
+        if not self.keys:
+            return None
+        n = len(self.keys)
+        seen = self.chunks[0][:n] if n <= self.SLOTS else torch.cat(self.chunks)[:n]
+        return (seen > torch.cat(self.limits)).to(torch.float32)
+
+    def ok(self, bad_host=None):
+        """True when no calibrated scale was outgrown (without `bad_host` -- the host copy of bad_mask() -- it synchronises:
+        reads the flags).  Otherwise the calibrations concerned are dropped -- the next forward takes the two-pass route for
+        those layers and calibrates afresh -- and the caller recomputes."""
         if not self.keys:
             return True
-        bad = (self.seen[:len(self.keys)] > torch.cat(self.limits)).cpu()
+        bad = (self.bad_mask().cpu() if bad_host is None else bad_host) > 0
         if not bool(bad.any()):
             return True
         for i in torch.nonzero(bad).flatten().tolist():
             _ACT_CAL.pop(self.keys[i], None)
         return False
+
+
+EVAL_RECOMPUTES = 0      # batches recomputed on the two-pass route because a calibrated scale was outgrown (diagnostic counter)
+
+
+def eval_checked(fn):
+    """Run `fn()` -- an inference forward returning a device tensor -- inside an act_fold_scope and return its result on the
+    HOST, verified: the overflow flags of the calibrated folds ride on the same device-to-host copy; if a calibrated scale was
+    outgrown the forward is repeated on the two-pass route (no scope).  The contract of the folded route in one place, for
+    model.predict() / model.evaluate() (networks/classifiers.py) and predict_2d_cnn.ensemble_batch_checked."""
+    scope = act_fold_scope()
+    with scope:
+        out = fn(scope)
+    bad = scope.bad_mask()
+    if bad is None:
+        return out.cpu()
+    host = torch.cat([out.reshape(-1).to(torch.float32), bad]).cpu()
+    if scope.ok(host[out.numel():]):
+        return host[:out.numel()].reshape(out.shape).to(out.dtype)
+    global EVAL_RECOMPUTES
+    EVAL_RECOMPUTES += 1
+    return fn(None).cpu()
 
 
 def act_fold_scope():
@@ -1572,8 +1617,11 @@ def _l16_of(m):
     return m if isinstance(m, L16) else None
 
 
-def _act_key(bn, weight):
-    return _bn_eval_key(bn, bn.weight, bn.bias) + (weight.data_ptr(), weight._version)
+def _act_key(bn, weight, bias=None, alpha=None):
+    """Everything the output range of conv -> eval BatchNorm -> PReLU depends on besides the input: (address, version) of the
+    BatchNorm's parameters / buffers, the convolution's weight and bias and the PReLU slope."""
+    extra = tuple((t.data_ptr(), t._version) if t is not None else (0, 0) for t in (weight, bias, alpha))
+    return _bn_eval_key(bn, bn.weight, bn.bias) + extra
 
 
 def _eval_conv_act(t16, weight, bias, bn, alpha, next_weight):
@@ -1588,28 +1636,29 @@ def _eval_conv_act(t16, weight, bias, bn, alpha, next_weight):
     decl = seen = None
     if _l16_limbs() != 3:                                    # (scaled fp16 limbs: f16x3, f16x6)
         scope = _ACT_TLS.scope
-        cal = _ACT_CAL.get(_act_key(bn, weight)) if scope is not None else None
+        key = _act_key(bn, weight, bias, alpha)
+        cal = _ACT_CAL.get(key) if scope is not None else None
         if cal is None:
             return None
         decl = cal[0]
-        seen = scope.slot(weight, cal[1], _act_key(bn, weight))
+        seen = scope.slot(weight, cal[1], key)
     scale, shift = _bn_eval_scale_shift(bn, bn.weight, bn.bias)
     return conv_l16_act(t16, weight, bias, scale, shift, alpha, decl, seen)
 
 
-def _act_calibrate(bn, weight, t16):
+def _act_calibrate(bn, weight, t16, bias=None, alpha=None):
     """Scaled fp16 limbs, inference on the two-pass route: remember TWICE the bound this batch declared for the layer's output as
     the scale of the folded launches to come (the fp16 high limb itself holds another factor 1.99 above the declared maximum:
     `limit`, what ActFoldScope.ok() compares the largest value written with)."""
     if not EVAL_ACT_FOLD or _l16_arith() is None or _l16_limbs() == 3 or t16 is None or t16.amax is None or torch.is_grad_enabled():
         return
-    key = _act_key(bn, weight)
+    key = _act_key(bn, weight, bias, alpha)
     if key in _ACT_CAL:
         return
     if len(_ACT_CAL) > 4096:
         _ACT_CAL.clear()
     decl = t16.amax * 2.0
-    _ACT_CAL[key] = (decl, (decl.max() * 1.99).reshape(1), bn, weight)
+    _ACT_CAL[key] = (decl, (decl.max() * 1.99).reshape(1), bn, weight, bias, alpha)   # (kept alive: their addresses cannot be reused)
 
 
 def _block_forward(x, mods, training, want_head, ph, keep, sync=None, next_bn=False):
@@ -1671,7 +1720,7 @@ def _block_forward(x, mods, training, want_head, ph, keep, sync=None, next_bn=Fa
         st1 = bn_prepare(r1, res.bn1, training, sync, counters, want_minmax=mm(r1, w2))
         s1, s1_max, s1_16 = _bn_fwd_for_conv(r1, st1, res.prelu1.weight, w2, need_wgrad=keep)
         if fold:
-            _act_calibrate(res.bn1, w1, s1_16)
+            _act_calibrate(res.bn1, w1, s1_16, b1, res.prelu1.weight)
     s2_16 = _eval_conv_act(s1_16, w2, b2, res.bn2, res.prelu2.weight, w3) if fold else None
     if s2_16 is not None:
         r2 = s2 = st2 = None
@@ -1681,7 +1730,7 @@ def _block_forward(x, mods, training, want_head, ph, keep, sync=None, next_bn=Fa
         st2 = bn_prepare(r2, res.bn2, training, sync, counters, want_minmax=mm(r2, w3))
         s2, s2_max, s2_16 = _bn_fwd_for_conv(r2, st2, res.prelu2.weight, w3, need_wgrad=keep)
         if fold:
-            _act_calibrate(res.bn2, w2, s2_16)
+            _act_calibrate(res.bn2, w2, s2_16, b2, res.prelu2.weight)
     r3 = _conv_fwd_any(s2, s2_16, w3, b3, s2_max, packs, (res.bn3, training))
     st3 = bn_prepare(r3, res.bn3, training, sync, counters)
     feat, fidx = (None, None)

@@ -105,6 +105,40 @@ def shard_range(total, world=None, index=None):
     return lo, lo + base + (1 if index < extra else 0)
 
 
+def gather_rows(order, local, width, device=None, dst=0, group=None):
+    """Sharded inference (SURVEY 8e "Inference (cfg5)"): every rank holds `local` = (len(order), width) fp32 rows and their
+    dataset indices `order`; rank `dst` receives [(indices, rows)] of every rank (the others an empty list).  ONE tensor
+    all-gather of the padded (rows | index) blocks -- no pickling; counts differ per rank and may be zero.  Over RCCL ("nccl")
+    the blocks are device tensors, over gloo host tensors."""
+    import numpy as np
+    world = dist.get_world_size(group)
+    staged = _staged(group)
+    dev = torch.device("cpu") if staged else torch.device(device if device is not None else "cuda")
+    counts = torch.zeros(world, dtype=torch.int64, device=dev)
+    counts[dist.get_rank(group)] = len(order)
+    dist.all_reduce(counts, op=dist.ReduceOp.SUM, group=group)
+    counts = counts.cpu().tolist()
+    cap = max(1, max(counts))
+    # the index column travels as two fp32 halves of 2^20 each (exact for up to 2^40 rows): one dtype, one collective
+    block = torch.zeros(cap, width + 2, dtype=torch.float32)
+    if len(order):
+        idx = np.asarray(order, dtype=np.int64)
+        block[:len(order), :width] = torch.from_numpy(np.ascontiguousarray(local, dtype=np.float32))
+        block[:len(order), width] = torch.from_numpy((idx >> 20).astype(np.float32))
+        block[:len(order), width + 1] = torch.from_numpy((idx & ((1 << 20) - 1)).astype(np.float32))
+    block = block.to(dev)
+    blocks = [torch.empty_like(block) for _ in range(world)]
+    dist.all_gather(blocks, block, group=group)
+    if dist.get_rank(group) != dst:
+        return []
+    out = []
+    for r in range(world):
+        b = blocks[r][:counts[r]].cpu().numpy()
+        idx = (b[:, width].astype(np.int64) << 20) | b[:, width + 1].astype(np.int64)
+        out.append((idx, b[:, :width]))
+    return out
+
+
 class BucketedGradReducer:
     """Sum-all-reduce of parameter gradients in flat buckets, overlapped with backward."""
 

@@ -108,7 +108,7 @@ def ensemble_batch(models, signal, scope=None):
         main = torch.cuda.current_stream(signal.device)
         parts = []
         if scope is not None:
-            scope.prepare(signal)             # (the flag words exist, zeroed, before any side stream touches them)
+            scope.prepare(signal, slots=64 * len(models))      # (the flag words exist, zeroed, before any side stream touches them)
         for s in streams:
             s.wait_stream(main)
         for i, model in enumerate(models):
@@ -128,17 +128,50 @@ def ensemble_batch(models, signal, scope=None):
 def ensemble_batch_checked(models, signal):
     """ensemble_batch on the folded route, verified: the result as a host array (the check rides on the copy's synchronisation)."""
     from freesound_classification_amd import functional as F
-    scope = F.act_fold_scope()
-    out = ensemble_batch(models, signal, scope).cpu()
-    if not scope.ok():
-        out = ensemble_batch(models, signal).cpu()
-    return out
+    # (ONE device-to-host copy and one synchronisation per batch: the overflow flags of the calibrated folds travel with the result)
+    return F.eval_checked(lambda scope: ensemble_batch(models, signal, scope))
+
+
+def ensemble_batches(models, signals, depth=2):
+    """Generator over device batches: yields each batch's verified host probabilities, in order.  Batch i + 1 is enqueued BEFORE
+    batch i's result is waited for (its probabilities and the overflow flags of its calibrated folds go to a pinned buffer in one
+    asynchronous copy behind its kernels), so the GPU never idles on the host's per-batch synchronisation.  A batch whose flags
+    say a calibrated scale was outgrown is recomputed on the two-pass route when its turn comes."""
+    from collections import deque
+    from freesound_classification_amd import functional as F
+    pending = deque()
+
+    def finish(item):
+        x, scope, host, event, shape, n = item
+        event.synchronize()
+        if not scope.ok(host[n:]):
+            F.EVAL_RECOMPUTES += 1
+            return ensemble_batch(models, x).cpu()
+        return host[:n].reshape(shape).clone()
+
+    for x in signals:
+        scope = F.act_fold_scope()
+        out = ensemble_batch(models, x, scope)
+        bad = scope.bad_mask()
+        flat = out.reshape(-1) if bad is None else torch.cat([out.reshape(-1), bad])
+        host = torch.empty(flat.numel(), dtype=torch.float32, pin_memory=True)
+        host.copy_(flat, non_blocking=True)
+        event = torch.cuda.Event()
+        event.record()
+        pending.append((x, scope, host, event, tuple(out.shape), out.numel()))
+        if len(pending) >= depth:
+            yield finish(pending.popleft())
+    while pending:
+        yield finish(pending.popleft())
 
 
 def predict_folds(experiment, folds, dataset, batches, collate, device, model_cls, models=None):
-    """Mean over folds of sigmoid(logits); rows follow the dataset order.  Returns rank 0's array.
+    """Mean over folds of sigmoid(logits); rows follow the dataset order.  Returns rank 0's array (the other ranks: zeros).
     (Reference predict_2d_cnn.py:72-125 loops folds outermost and reloads the data per fold; here every batch is
-    uploaded once and goes through all resident fold models -- the same numbers, since eval-mode batches are independent.)"""
+    uploaded once and goes through all resident fold models -- the same numbers, since eval-mode batches are independent.)
+    N ranks: the length-grouped batches go round-robin (batch composition equals the single-process sampler's: padding is
+    unmasked), every rank averages its folds locally, and ONE gather of (rows, n_classes) fp32 + the row indices brings
+    them to rank 0 (parallel.gather_rows: tensors, no pickling)."""
     world, rank = parallel.world_size(), parallel.rank()
     mine = batches[rank::world]
     order = [i for b in mine for i in b]
@@ -148,16 +181,14 @@ def predict_folds(experiment, folds, dataset, batches, collate, device, model_cl
     chunks = []
     if order:
         loader = torch.utils.data.DataLoader(dataset, batch_sampler=mine, collate_fn=collate)
-        for sample in loader:
-            chunks.append(ensemble_batch_checked(models, sample["signal"].to(device)).numpy())
+        for host in ensemble_batches(models, (sample["signal"].to(device) for sample in loader)):
+            chunks.append(host.numpy())
     local = np.concatenate(chunks).astype(np.float32) if chunks else np.zeros((0, n_classes), np.float32)
     out = np.zeros((len(dataset), n_classes), np.float32)
     if world == 1:
         out[order] = local
         return out
-    gathered = [None] * world
-    dist.all_gather_object(gathered, (order, local))
-    for idx, block in gathered:
+    for idx, block in parallel.gather_rows(order, local, n_classes, device):
         out[idx] = block
     return out
 

@@ -79,7 +79,16 @@ def test_conv_l16_forward_and_dgrad(case):
         F.set_conv_arith(None)
 
 
-def test_l16_pack_scale_and_pad_channels():
+@pytest.fixture
+def two_limbs():
+    """The two-limb (f16x3, the opt-in fast arithmetic) format and kernels this module tests; the library default is f16x6."""
+    mode0 = F.get_conv_arith()
+    F.set_conv_arith("f16x3")
+    yield
+    F.set_conv_arith(mode0)
+
+
+def test_l16_pack_scale_and_pad_channels(two_limbs):
     """Pad channels of the last octet are zero, the scale is the power of two that brings the maximum to [2^14, 2^15)."""
     x = torch.randn(3, 13, 5, 7, device=DEV) * 1e-7
     t = F.l16_pack(x)
@@ -179,7 +188,7 @@ def test_bn_backward_unpool_writes_l16(case):
     assert only[0] is None and torch.equal(only[-1].data, t.data)
 
 
-def test_block_with_and_without_l16_agree():
+def test_block_with_and_without_l16_agree(two_limbs):
     """One residual block at a shape whose convolutions take the L16 kernels: outputs and every gradient equal the fp32-input
     path's within the rounding of the operand scales (the backward bounds over-estimate the maxima)."""
     from freesound_classification_amd.networks.classifiers import TwoDimensionalCNNClassificationModel

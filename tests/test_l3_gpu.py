@@ -475,8 +475,8 @@ def test_inference_with_folded_residual_units_against_the_two_pass_route(arith):
                     assert float((out - ref).abs().max()) < 1e-5 * max(1.0, float(ref.abs().max()))
                     # a calibration that is too small: caught, dropped, two-pass again
                     key = next(iter(F._ACT_CAL))
-                    decl, limit, bn, wt = F._ACT_CAL[key]
-                    F._ACT_CAL[key] = (decl * 2.0 ** -8, limit * 2.0 ** -8, bn, wt)
+                    ent = F._ACT_CAL[key]
+                    F._ACT_CAL[key] = (ent[0] * 2.0 ** -8, ent[1] * 2.0 ** -8) + tuple(ent[2:])
                     scope = F.act_fold_scope()
                     with scope:
                         m(x)

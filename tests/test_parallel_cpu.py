@@ -171,3 +171,39 @@ def test_bench_launches_its_own_ranks():
     bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--launch-check", "--backend", "gloo"],
                          env=env, capture_output=True, text=True, timeout=120)
     assert bad.returncode != 0 and "WORLD_SIZE=3" in bad.stderr
+
+
+def _gather_worker(rank, world, port, outdir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        total, width = 23, 80
+        rng = np.random.RandomState(5)
+        perm = rng.permutation(total) + (1 << 21)            # (indices beyond 2^20: both halves of the index column in use)
+        full = rng.rand(total, width).astype(np.float32)
+        # rank 0: 14 rows, rank 1: 9 rows, rank 2: none (a rank without a batch)
+        cuts = [0, 14, 23, 23]
+        order = perm[cuts[rank]:cuts[rank + 1]].tolist()
+        local = full[cuts[rank]:cuts[rank + 1]]
+        got = parallel.gather_rows(order, local, width)
+        if rank == 0:
+            assert len(got) == world and [len(i) for i, _ in got] == [14, 9, 0]
+            idx = np.concatenate([i for i, _ in got])
+            rows = np.concatenate([b for _, b in got])
+            assert np.array_equal(idx, perm) and np.array_equal(rows, full)          # bit for bit, order preserved
+            open(os.path.join(outdir, "ok"), "w").write("1")
+        else:
+            assert got == []
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_gather_rows_of_the_sharded_inference_over_three_ranks_with_an_empty_one():
+    """parallel.gather_rows (predict_2d_cnn.predict_folds' one exchange, SURVEY 8e "Inference (cfg5)"): uneven row counts, a rank
+    with zero rows, indices and fp32 rows unchanged bit for bit at rank 0."""
+    world = 3
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_gather_worker, args=(world, _free_port(), d), nprocs=world, join=True)
+        assert os.path.exists(os.path.join(d, "ok"))
