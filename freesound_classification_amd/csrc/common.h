@@ -93,3 +93,13 @@ inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }
 inline long round_up(long a, long b) { return (a + b - 1) / b * b; }
 
 }  // namespace fsc
+
+// fsc_conv_desc.arith == FSC_ARITH_DEFAULT means the PROCESS default (fsc_conv_default_arith(): f16x6 unless FSC_CONV_ARITH says
+// otherwise) at EVERY entry point, the pre-split (L16) ones included: the descriptor is resolved once, at the boundary.
+#define FSC_RESOLVE_DESC(d)                                                                      \
+    fsc_conv_desc d##_resolved_;                                                                 \
+    if ((d) != nullptr && (d)->arith == FSC_ARITH_DEFAULT) {                                     \
+        d##_resolved_ = *(d);                                                                    \
+        d##_resolved_.arith = fsc_conv_default_arith();                                          \
+        (d) = &d##_resolved_;                                                                    \
+    }

@@ -21,6 +21,7 @@
 // Replaces nn.Conv2d 3x3 / 1x1 forward and input gradient (reference networks/classifiers.py:526-531, 77-81).
 #include "common.h"
 #include "l16.h"
+#include <vector>
 #include <stdlib.h>
 #include <string.h>
 
@@ -1077,7 +1078,7 @@ bool plan_l16_pt(const fsc_conv_desc& d_in, int dgrad, int pt, int max_cot, LPla
 }
 
 bool plan_l16(const fsc_conv_desc& d, int dgrad, LPlan* out) {
-    if (d.arith != FSC_ARITH_DEFAULT && d.arith != 3) return false;
+    if (d.arith != 3) return false;                          // (the entry points resolve FSC_ARITH_DEFAULT: FSC_RESOLVE_DESC)
     if (fsc::env().no_l16) return false;
     const int taps = d.kh * d.kw;
     const int force_pt = fsc::env().l16_pt;                 // development (FSC_L16_PT): force the pixel tiles per wave
@@ -1090,7 +1091,7 @@ bool plan_l16(const fsc_conv_desc& d, int dgrad, LPlan* out) {
 // forward convolution fused with the 2 x 2 max-pool behind it: the same channel tiling as plan_l16 (the packed weights are
 // shared), a box of 2 x 8 blocks
 bool plan_l16_pool(const fsc_conv_desc& d, LPlan* out) {
-    if (d.arith != FSC_ARITH_DEFAULT && d.arith != 3) return false;
+    if (d.arith != 3) return false;
     if (fsc::env().no_l16 || fsc::env().no_l16_pool) return false;
     if (d.kh != 3 || d.kw != 3 || d.h < 2 || d.w < 8) return false;
     LPlan plain;
@@ -1239,12 +1240,14 @@ int fsc_l16_unpack_limbs(const void* in, int n, int c, long hw, const float* ama
 }
 
 int fsc_conv_l16_supported(const fsc_conv_desc* d, int dgrad) {
+    FSC_RESOLVE_DESC(d)
     if (d && l16::is_l3(d->arith)) return fsc::l3::supported(d, dgrad);
     LPlan p;
     return valid_l16_desc(d) && plan_l16(*d, dgrad, &p) ? 1 : 0;
 }
 
 size_t fsc_conv_l16_packed_floats(const fsc_conv_desc* d, int dgrad) {
+    FSC_RESOLVE_DESC(d)
     if (d && l16::is_l3(d->arith)) return fsc::l3::packed_floats(d, dgrad);
     LPlan p;
     if (!valid_l16_desc(d) || !plan_l16(*d, dgrad, &p)) return 0;
@@ -1266,6 +1269,7 @@ static PackDir make_pack_dir(const LPlan& p, float* packed, int dgrad) {
 /* packs the forward (packed_fwd) and / or input-gradient (packed_dgrad) fragments of one weight in two launches total */
 int fsc_conv_l16_pack_weights_pair(const fsc_conv_desc* d, const float* weight, float* packed_fwd, float* packed_dgrad,
                                    fsc_stream_t stream) {
+    FSC_RESOLVE_DESC(d)
     if (d && l16::is_l3(d->arith)) return fsc::l3::pack_weights_pair(d, weight, packed_fwd, packed_dgrad, fsc::as_stream(stream));
     FSC_CHECK_ARG(valid_l16_desc(d) && weight && (packed_fwd || packed_dgrad), "fsc_conv_l16_pack_weights_pair: bad arguments");
     LPlan pf{}, pd{};
@@ -1294,6 +1298,10 @@ int fsc_conv_l16_pack_weights_multi(int count, const fsc_conv_desc* descs, const
                                     float* const* packed_dgrad, fsc_stream_t stream) {
     FSC_CHECK_ARG(count > 0 && descs && weights && packed_fwd && packed_dgrad, "fsc_conv_l16_pack_weights_multi: bad arguments");
     hipStream_t st = fsc::as_stream(stream);
+    std::vector<fsc_conv_desc> resolved(descs, descs + count);       // (FSC_ARITH_DEFAULT -> the process default, entry by entry)
+    for (auto& r : resolved)
+        if (r.arith == FSC_ARITH_DEFAULT) r.arith = fsc_conv_default_arith();
+    descs = resolved.data();
     if (l16::is_l3(descs[0].arith)) {                        // (one arithmetic per call)
         for (int k = 1; k < count; ++k)
             FSC_CHECK_ARG(descs[k].arith == descs[0].arith, "fsc_conv_l16_pack_weights_multi: entry %d mixes limb formats", k);
@@ -1333,6 +1341,7 @@ int fsc_conv_l16_pack_weights_multi(int count, const fsc_conv_desc* descs, const
 
 int fsc_conv_l16_fwd(const fsc_conv_desc* d, const void* in_l16, const float* in_amax, const float* packed,
                      const float* bias, int dgrad, int accumulate, float* out, fsc_stream_t stream) {
+    FSC_RESOLVE_DESC(d)
     if (d && l16::is_l3(d->arith))
         return fsc::l3::fwd(d, in_l16, in_amax, packed, bias, dgrad, accumulate, out, nullptr, nullptr, fsc::as_stream(stream));
     LPlan p;
@@ -1349,6 +1358,7 @@ int fsc_conv_l16_fwd(const fsc_conv_desc* d, const void* in_l16, const float* in
  * workers * 8 * channels-per-block float4 {sum (y - pivot), sum (y - pivot)^2, min, max}; worker w holds channel block
  * w % blocks (order 0) or (w / 8) % blocks (order 1: XCD-aware item order) */
 int fsc_conv_l16_stats_layout(const fsc_conv_desc* d, int pool, int* out3) {
+    FSC_RESOLVE_DESC(d)
     if (d && l16::is_l3(d->arith)) return fsc::l3::stats_layout(d, pool, out3);
     LPlan p;
     if (!valid_l16_desc(d) || !out3) return 0;
@@ -1359,6 +1369,7 @@ int fsc_conv_l16_stats_layout(const fsc_conv_desc* d, int pool, int* out3) {
 
 int fsc_conv_l16_fwd_stats(const fsc_conv_desc* d, const void* in_l16, const float* in_amax, const float* packed,
                            const float* bias, float* out, const float* stat_pivot, void* stat_rec, fsc_stream_t stream) {
+    FSC_RESOLVE_DESC(d)
     if (d && l16::is_l3(d->arith)) {
         FSC_CHECK_ARG(stat_rec, "fsc_conv_l16_fwd_stats: null records");
         return fsc::l3::fwd(d, in_l16, in_amax, packed, bias, 0, 0, out, stat_pivot, stat_rec, fsc::as_stream(stream));
@@ -1374,6 +1385,7 @@ int fsc_conv_l16_fwd_stats(const fsc_conv_desc* d, const void* in_l16, const flo
 }
 
 int fsc_conv_l16_pool_supported(const fsc_conv_desc* d) {
+    FSC_RESOLVE_DESC(d)
     if (d && l16::is_l3(d->arith)) return fsc::l3::pool_supported(d);
     LPlan p;
     return valid_l16_desc(d) && plan_l16_pool(*d, &p) ? 1 : 0;
@@ -1408,6 +1420,7 @@ int fsc_conv_l16_pool_fwd(const fsc_conv_desc* d, const void* in_l16, const floa
 int fsc_conv_l16_pool_fwd_stats(const fsc_conv_desc* d, const void* in_l16, const float* in_amax, const float* packed,
                                 const float* bias, float* pooled, uint8_t* idx, const float* stat_pivot, void* stat_rec,
                                 fsc_stream_t stream) {
+    FSC_RESOLVE_DESC(d)
     FSC_CHECK_ARG(stat_rec, "fsc_conv_l16_pool_fwd_stats: null records");
     return pool_fwd_impl(d, in_l16, in_amax, packed, bias, pooled, idx, StatArgs{stat_pivot, reinterpret_cast<float4*>(stat_rec)}, stream);
 }
@@ -1429,6 +1442,7 @@ int fsc_conv_l16_fwd_act_supported(const fsc_conv_desc* d) { return fsc_conv_l16
 int fsc_conv_l16_fwd_act(const fsc_conv_desc* d, const void* in_l16, const float* in_amax, const float* packed, const float* bias,
                          const float* scale, const float* shift, const float* alpha, void* out_l16, const float* out_amax,
                          float* seen_max, fsc_stream_t stream) {
+    FSC_RESOLVE_DESC(d)
     if (d && l16::is_l3(d->arith))
         return fsc::l3::fwd_act(d, in_l16, in_amax, packed, bias, scale, shift, alpha, out_l16, out_amax, seen_max, fsc::as_stream(stream));
     LPlan p;
@@ -1443,6 +1457,7 @@ int fsc_conv_l16_fwd_act(const fsc_conv_desc* d, const void* in_l16, const float
 }
 
 int fsc_conv_l16_plan_describe(const fsc_conv_desc* d, int dgrad, char* buf, size_t buf_len) {
+    FSC_RESOLVE_DESC(d)
     if (d && l16::is_l3(d->arith)) return fsc::l3::plan_describe(d, dgrad, buf, buf_len);
     LPlan p;
     FSC_CHECK_ARG(valid_l16_desc(d) && buf && buf_len > 0 && plan_l16(*d, dgrad, &p), "fsc_conv_l16_plan_describe: unsupported shape");

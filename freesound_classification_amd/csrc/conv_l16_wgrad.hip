@@ -393,7 +393,7 @@ struct WPlan {
 
 bool plan_l16_wgrad(const fsc_conv_desc& d, WPlan* out) {
     const bool bf3 = l16::is_l3(d.arith);                   // (three limbs: bf16, or scaled fp16)
-    if (d.arith != FSC_ARITH_DEFAULT && d.arith != 3 && !bf3) return false;
+    if (d.arith != 3 && !bf3) return false;                  // (the entry points resolve FSC_ARITH_DEFAULT: FSC_RESOLVE_DESC)
     const int nl = bf3 ? 3 : 2;
     const int max_tpg = bf3 ? 3 : 4;       // co tiles per wave: 9 taps x 4 tiles x 4 registers + three-limb fragments do not fit 256
     if (fsc::env().no_l16 || fsc::env().no_l16_wgrad) return false;
@@ -529,11 +529,13 @@ bool valid_desc(const fsc_conv_desc* d) {
 extern "C" {
 
 int fsc_conv_l16_wgrad_supported(const fsc_conv_desc* d) {
+    FSC_RESOLVE_DESC(d)
     WPlan p;
     return valid_desc(d) && plan_l16_wgrad(*d, &p) ? 1 : 0;
 }
 
 size_t fsc_conv_l16_wgrad_workspace_bytes(const fsc_conv_desc* d) {
+    FSC_RESOLVE_DESC(d)
     WPlan p;
     if (!valid_desc(d) || !plan_l16_wgrad(*d, &p)) return 0;
     return (size_t)p.g.nsplit * d->kh * d->kw * p.g.ci_pad * p.g.co_pad * sizeof(float);
@@ -541,6 +543,7 @@ size_t fsc_conv_l16_wgrad_workspace_bytes(const fsc_conv_desc* d) {
 
 int fsc_conv_l16_wgrad(const fsc_conv_desc* d, const void* in_l16, const float* in_amax, const void* dout_l16,
                        const float* dout_amax, float* dweight, void* workspace, fsc_stream_t stream) {
+    FSC_RESOLVE_DESC(d)
     WPlan p;
     FSC_CHECK_ARG(valid_desc(d) && in_l16 && dout_l16 && dweight && workspace, "fsc_conv_l16_wgrad: bad descriptor or null pointer");
     FSC_CHECK_ARG(l16::is_bf3(d->arith) || (in_amax && dout_amax), "fsc_conv_l16_wgrad: the scaled fp16 formats need both operand maxima");
@@ -619,6 +622,7 @@ int fsc_debug_l16w_prof(unsigned long long* out64) {
 #endif
 
 int fsc_conv_l16_wgrad_plan_describe(const fsc_conv_desc* d, char* buf, size_t buf_len) {
+    FSC_RESOLVE_DESC(d)
     WPlan p;
     FSC_CHECK_ARG(valid_desc(d) && buf && buf_len > 0 && plan_l16_wgrad(*d, &p), "fsc_conv_l16_wgrad_plan_describe: unsupported shape");
     char name[64];

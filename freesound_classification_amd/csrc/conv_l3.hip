@@ -1028,8 +1028,20 @@ bool plan_l3_pt(const fsc_conv_desc& d_in, int dgrad, int ptw, L3Plan* out, bool
 
 int nprod_of(int arith) { return arith == 6 || l16::is_f3(arith) ? 6 : arith == 8 ? 8 : 9; }
 
+// the three-limb arithmetics THIS BUILD has kernels for: 9 (bf16, nine products) and 10 (scaled fp16, six products); the six- and
+// eight-product bf16 variants exist under -DFSC_L3_ALL_PRODS only, so without it their descriptors have NO pre-split tiling
+// (supported / packed_floats / pack_weights say so up front instead of failing with rc 22 at launch time: ADVICE r5) and the
+// caller's fp32-input route (fsc_conv_fwd, arith 6) serves them
+bool l3_built(int arith) {
+#ifdef FSC_L3_ALL_PRODS
+    return l16::is_l3(arith);
+#else
+    return arith == 9 || l16::is_f3(arith);
+#endif
+}
+
 bool plan_l3(const fsc_conv_desc& d, int dgrad, L3Plan* out) {
-    if (!l16::is_l3(d.arith)) return false;
+    if (!l3_built(d.arith)) return false;
     if (fsc::env().no_l16) return false;
     const int force_pt = fsc::env().l16_pt;                 // development (FSC_L16_PT = 2 | 1): 256- / 128-pixel tiles
     bool ok = false;
@@ -1043,7 +1055,7 @@ bool plan_l3(const fsc_conv_desc& d, int dgrad, L3Plan* out) {
 }
 
 bool plan_l3_pool(const fsc_conv_desc& d, L3Plan* out) {
-    if (!l16::is_l3(d.arith)) return false;
+    if (!l3_built(d.arith)) return false;
     if (fsc::env().no_l16 || fsc::env().no_l16_pool) return false;
     if (d.kh != 3 || d.kw != 3 || d.h < 2 || d.w < 8) return false;
     L3Plan plain;

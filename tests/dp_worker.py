@@ -26,10 +26,12 @@ def make_experiment(sync_bn):
                  scheduler="1cycle_0.0001_0.005", sync_bn=sync_bn)))
 
 
-def global_batch():
+def global_batch(tail=None):
+    """Seeded global batch of 8 clips; `tail` (default: FSC_DP_TEST_TAIL, on): clip 3 ends in a zero-padded tail, as collated
+    batches do (ops/padding.py:11-31) -- its frames are live data at log(1e-4)."""
     g = torch.Generator().manual_seed(77)
     x = 0.1 * torch.randn(8, 24000, 1, generator=g)
-    if os.environ.get("FSC_DP_TEST_TAIL", "1") == "1":          # (development switch of tools/dbg_dp_syncbn.py)
+    if (os.environ.get("FSC_DP_TEST_TAIL", "1") == "1") if tail is None else tail:
         x[3, 15000:] = 0.0
     y = torch.zeros(8, 80)
     y[torch.arange(8), torch.randint(0, 80, (8,), generator=g)] = 1.0
@@ -45,6 +47,10 @@ def main():
     from freesound_classification_amd import parallel
     from freesound_classification_amd.networks.classifiers import TwoDimensionalCNNClassificationModel
     from freesound_classification_amd.networks.losses import lsep_loss
+    if os.environ.get("FSC_DP_DUMP"):                 # (development: tools/dbg_dp_syncbn.py compares the discrete decisions)
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import dp_dump
+        dp_dump.install()
     torch.manual_seed(5 + rank)                       # replicas start DIFFERENT: the broadcast must fix it
     model = TwoDimensionalCNNClassificationModel(make_experiment(sync_bn), device="cuda:0")
     model.train()
@@ -59,6 +65,8 @@ def main():
     model._reducer.prepare(sync=True)
     loss.backward()
     model._reducer.finish()
+    if os.environ.get("FSC_DP_DUMP"):
+        dp_dump.save(os.environ["FSC_DP_DUMP"] + ".rank%d.npz" % rank)
     out = {"logits": logits.detach().cpu().numpy(), "per": per.detach().cpu().numpy(),
            "bn_sync_calls": np.int64(model._bn_sync.calls if sync_bn else 0),
            "bucket_sizes": np.asarray(model._reducer.bucket_sizes(), np.int64)}

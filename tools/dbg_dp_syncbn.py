@@ -10,10 +10,36 @@ import dp_worker
 from freesound_classification_amd import functional as F
 
 print("arith", F.get_conv_arith())
+dump = os.path.join(ROOT, "gpurun_out", "dp_dump")
+os.environ["FSC_DP_DUMP"] = dump
 with tempfile.TemporaryDirectory() as d:
     r0, r1 = T._run_two_replicas(d, sync_bn=True)
+del os.environ["FSC_DP_DUMP"]
 x, y = dp_worker.global_batch()
+import dp_dump
+dp_dump.install()
 logits, per, grads, state = T._single_process(x, y, seed=5)
+single = list(dp_dump.REC)
+dp_dump.save(dump + ".single.npz")
+z0, z1 = np.load(dump + ".rank0.npz"), np.load(dump + ".rank1.npz")
+keys = sorted(z0.files)
+print("decisions recorded: single %d, replicas %d" % (len(single), len(keys)))
+for (name, a), k in zip(single, keys):
+    if "bn_prepare" in k:
+        print("  %-28s statistics: replica 0 vs single %.2e (relative), replica 1 vs single %.2e" % (
+            k, float(np.abs(z0[k] / a - 1).max()), float(np.abs(z1[k] / a - 1).max())))
+        continue
+    both = np.concatenate([z0[k], z1[k]])
+    if both.dtype.kind == "f":
+        both = both / 2.0                                   # (a replica's loss is the mean over ITS four clips)
+        d = np.abs(both - a).reshape(a.shape[0], -1).max(1) / max(1e-30, float(np.abs(a).max()))
+        print("  %-28s %s: max |replicas / 2 - single| / max|single| per clip: %s" % (k, tuple(a.shape), ", ".join("%.1e" % v for v in d)))
+        continue
+    if both.shape != a.shape:
+        print("  %-28s shapes differ %s %s" % (k, a.shape, both.shape)); continue
+    ne = both != a
+    per_clip = ne.reshape(ne.shape[0], -1).sum(1)
+    print("  %-28s %s: %d of %d decisions differ; per clip %s" % (k, tuple(a.shape), int(ne.sum()), ne.size, per_clip.tolist()))
 print("logits", float(np.abs(np.concatenate([r0["logits"], r1["logits"]]) - logits).max()))
 rows = []
 for k, g in grads.items():
