@@ -19,6 +19,7 @@
 //   * split-K over pixel tiles; partials [split][tap][ci][co] reduced by a second kernel that
 //     also transposes into the (c_out, c_in, kh, kw) layout of the state dict.
 #include "common.h"
+#include "s1d.h"
 #include <stdlib.h>
 #include <string.h>
 
@@ -2056,6 +2057,8 @@ struct FwdPlan {
     int x3;           // 0: native fp32 MFMA kernel; 6 / 9: conv_fwd_x3_kernel with that many limb products
     int pt;           // pixel tiles per wave
     long launch_x;    // x3: persistent workgroups per (channel block, K slice)
+    int s1d;          // 1: the small 1-d bf16 kernels of conv_s1d.hip (x3 = 1: same packed fragments, cot / co_blocks / x_* describe them)
+    fsc::s1d::Plan sp;
 };
 
 // floats of the packed limb fragments of an x3 plan (fp16 limbs: followed by 4 floats holding the weights' amax)
@@ -2276,6 +2279,21 @@ bool plan_fwd_f32(const fsc_conv_desc& d, int dgrad, FwdPlan* out);
 
 bool plan_fwd(const fsc_conv_desc& d, int dgrad, FwdPlan* out) {
     const int arith = arith_of(d);
+    if (arith == 1) {                                    // bf16, few positions (the late blocks of the 1-d model): conv_s1d.hip
+        fsc_conv_desc dd = d;
+        dd.arith = 1;
+        fsc::s1d::Plan sp;
+        if (fsc::s1d::plan_fwd(dd, dgrad, &sp)) {
+            FwdPlan p{};
+            p.x3 = 1; p.s1d = 1; p.sp = sp;
+            p.cot = fsc::s1d::kCot; p.co_blocks = sp.co_blocks; p.pt = fsc::s1d::kPt;
+            p.g.n = d.n; p.g.h = d.h; p.g.w = d.w; p.g.hw = (long)d.h * d.w; p.g.cin = sp.cin; p.g.cout = sp.cout;
+            p.g.x_nfull = sp.nfull; p.g.x_tail_oct = sp.tail_oct; p.g.x_steps = sp.steps; p.g.ksplit = 1;
+            p.grid_x = sp.px_groups; p.launch_x = sp.px_groups;
+            *out = p;
+            return true;
+        }
+    }
     if (arith && plan_fwd_x3(d, dgrad, arith, out)) return true;
     return plan_fwd_f32(d, dgrad, out);
 }
@@ -2757,6 +2775,14 @@ int launch_wgrad(const WgPlan& p, const float* in, const float* dout, float* par
     }
 }
 
+// the weight gradient of a small 1-d layer in the bf16 arithmetic (conv_s1d.hip), or false
+bool s1d_wgrad_plan(const fsc_conv_desc& d, fsc::s1d::WPlan* out) {
+    if (arith_of(d) != 1) return false;
+    fsc_conv_desc dd = d;
+    dd.arith = 1;
+    return fsc::s1d::plan_wgrad(dd, out);
+}
+
 }  // namespace
 
 extern "C" {
@@ -2844,6 +2870,7 @@ int fsc_conv_fwd(const fsc_conv_desc* d, const float* in, const float* packed, c
     FSC_CHECK_ARG(plan_fwd(*d, dgrad, &p), "fsc_conv_fwd: no tiling for this shape");
     FSC_CHECK_ARG(p.x3 != 3 || in_amax, "fsc_conv_fwd: the split-fp16 kernels need in_amax (fsc_amax of `in`)");
     hipStream_t st = fsc::as_stream(stream);
+    if (p.s1d) return fsc::s1d::launch_fwd(p.sp, in, reinterpret_cast<const unsigned short*>(packed), bias, out, accumulate, st);
     if (stem_shape(*d) && !p.x3) {
         // stem layer: direct kernels organised around the wide tensor (see conv_stem_*_kernel)
         const int qpr = (d->w + 3) / 4;
@@ -2903,6 +2930,12 @@ int fsc_conv_pool_fwd(const fsc_conv_desc* d, const float* in, const float* pack
 int fsc_conv_plan_describe(const fsc_conv_desc* d, int mode, char* buf, size_t buf_len) {
     FSC_CHECK_ARG(valid_desc(d) && buf && buf_len > 0, "fsc_conv_plan_describe: bad arguments");
     if (mode == 2) {
+        fsc::s1d::WPlan ws;
+        if (s1d_wgrad_plan(*d, &ws)) {
+            snprintf(buf, buf_len, "conv_s1d_wgrad_kernel<%d,%d> units=%d split=%d grid=%dx%dx%d", d->kh, d->kw, ws.ksteps, ws.nsplit,
+                     ws.ci_blocks, ws.co_blocks, ws.nsplit);
+            return 0;
+        }
         WgxPlan px;
         if (arith_of(*d) && plan_wgrad_x3(*d, arith_of(*d), &px)) {
             snprintf(buf, buf_len, "conv_wgrad_x3_kernel<%d,%d,%d,%d> box=%dx%d groups=%dx%d tiles/block=%d units=%d split=%d grid=%dx%d lds=%zu",
@@ -2918,7 +2951,10 @@ int fsc_conv_plan_describe(const fsc_conv_desc* d, int mode, char* buf, size_t b
     } else {
         FwdPlan p;
         FSC_CHECK_ARG(plan_fwd(*d, mode, &p), "fsc_conv_plan_describe: no tiling for this shape");
-        if (stem_shape(*d) && !p.x3)
+        if (p.s1d)
+            snprintf(buf, buf_len, "conv_s1d_fwd_kernel<%d,%d> tile=%dx%d grid=%dx%d steps=%d waves=%d", d->kh, d->kw, fsc::s1d::kCot * 16,
+                     fsc::s1d::kPt * 16, p.sp.px_groups, p.sp.co_blocks, p.sp.steps, fsc::s1d::kWaves);
+        else if (stem_shape(*d) && !p.x3)
             snprintf(buf, buf_len, "%s<%d> quads=%d", mode ? "conv_stem_dgrad_kernel" : "conv_stem_fwd_kernel", d->c_in,
                      d->h * ((d->w + 3) / 4));
         else if (p.x3)
@@ -2935,6 +2971,8 @@ int fsc_conv_plan_describe(const fsc_conv_desc* d, int mode, char* buf, size_t b
 
 size_t fsc_conv_wgrad_workspace_bytes(const fsc_conv_desc* d) {
     if (!valid_desc(d)) return 0;
+    fsc::s1d::WPlan ws;
+    if (s1d_wgrad_plan(*d, &ws)) return (size_t)ws.nsplit * d->kh * d->kw * ws.ci_pad * ws.co_pad * sizeof(float);
     WgxPlan px;
     if (arith_of(*d) && plan_wgrad_x3(*d, arith_of(*d), &px))
         return (size_t)px.g.nsplit * d->kh * d->kw * px.g.ci_pad * px.g.co_pad * sizeof(float);
@@ -2947,6 +2985,12 @@ size_t fsc_conv_wgrad_workspace_bytes(const fsc_conv_desc* d) {
 static int wgrad_partial(const fsc_conv_desc* d, const float* in, const float* dout, void* workspace, const float* in_amax,
                          const float* dout_amax, hipStream_t st, int* ci_pad, int* co_pad, int* nsplit) {
     float* part = reinterpret_cast<float*>(workspace);
+    fsc::s1d::WPlan ws;
+    if (s1d_wgrad_plan(*d, &ws)) {                              // bf16, few positions: conv_s1d.hip
+        *ci_pad = ws.ci_pad; *co_pad = ws.co_pad; *nsplit = ws.nsplit;
+        if (!in) return 0;
+        return fsc::s1d::launch_wgrad(ws, in, dout, part, st);
+    }
     WgxPlan px;
     if (arith_of(*d) && plan_wgrad_x3(*d, arith_of(*d), &px)) {
         FSC_CHECK_ARG(px.nprod != 3 || (in_amax && dout_amax),

@@ -1,0 +1,424 @@
+// Small 1-d convolutions in the bf16 arithmetic (arith 1) for gfx950 -- the LATE blocks of the hierarchical model of
+// BASELINE.json configs[2] (reference networks/classifiers.py:147-163, 37-69: Conv1d k = 3 / k = 1 on 156 ... 476 channels over
+// rows of 107 ... 3 frames, batch 128: 13.7 k ... 384 positions per layer, tensors of 8 MB ... 0.7 MB).
+//
+// conv_fwd_x3_kernel (conv.hip) is built for layers that fill the chip with 128-position x 128-channel tiles and walks K in
+// barrier-paced steps behind an LDS ring: on these layers it launches 12 ... 100 workgroups of 36 ... 45 serial steps at ~0.9 us a
+// step -- 20 ... 50 us per convolution, 1.9 ms of the 8.5 ms cfg-3 step (profiles/r06_step_timeline_cfg3.txt).  They are tiny GEMMs
+// (M = output channels, N = positions, K = taps x input channels; <= 0.9 GFLOP), so the kernels here are organised for LATENCY:
+//   * forward / input gradient: a workgroup owns 32 channels x 32 positions and ALL of K; its 8 waves take every 8th K step
+//     (one step = one tap x 32 channels = one v_mfma_f32_16x16x32_bf16 per 16 x 16 tile) and add their partial tiles through LDS
+//     at the end: 5 - 6 steps per wave instead of 45 in a row, hundreds to thousands of workgroups instead of a dozen;
+//   * no LDS staging, no barrier inside the K loop: a wave loads its A fragments (the packed bf16 weight fragments of
+//     fsc_conv_pack_weights, conv.hip pack_x3_items: 1 KB per tile and step, L2-resident) and gathers its B fragments straight from
+//     the fp32 NCL activation (8 dwords per lane: the 8 channels of its octet at its position and tap; rounded to bf16 with
+//     v_cvt_pk_bf16_f32 -- round to nearest even, the contract of arith 1), the loads of step s + 8 in flight behind the MFMAs of s;
+//   * weight gradient: D[ci][co] per tap, K = positions: a workgroup owns 32 x 32 (ci, co) x taps, its 4 waves every 4th
+//     32-position K step of its split; the three taps of a k = 3 layer share ONE window of 10 positions per lane.  Slices go to
+//     the caller's workspace in the [split][tap][ci][co] layout of conv.hip, reduced by the library's wgrad_reduce kernels.
+// Same arithmetic contract as the matrix-core path of arith 1 (operands rounded once to bf16, exact products, fp32 sums).
+#include "s1d.h"
+
+#include <stdlib.h>
+
+namespace {
+
+using fsc::s1d::kCot;
+using fsc::s1d::kPt;
+using fsc::s1d::kWaves;
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+
+__device__ float g_zero_s1d[4] = {0.f, 0.f, 0.f, 0.f};
+
+__device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {      // v_cvt_pk_bf16_f32 (RNE)
+    return __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){lo, hi}, bf16x2));
+}
+__device__ __forceinline__ f32x4 mfma_bf(u32x4 a, u32x4 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ u32x4 pack8(const float (&v)[8]) {
+    return (u32x4){cvt_pk_bf16(v[0], v[1]), cvt_pk_bf16(v[2], v[3]), cvt_pk_bf16(v[4], v[5]), cvt_pk_bf16(v[6], v[7])};
+}
+
+struct FwdArgs {
+    const float* in;
+    const u32x4* packed;
+    const float* bias;
+    float* out;
+    int cin, cout, len, n;
+    long npix;
+    int nfull, tail_oct, steps, accumulate;
+};
+
+// grid: x = groups of kPt * 16 positions of the flattened (image, position) sequence, y = blocks of kCot * 16 output channels
+template <int TAPS>
+__global__ __launch_bounds__(kWaves * 64) void s1d_fwd_kernel(FwdArgs a) {
+    constexpr int PAD = TAPS / 2;
+    constexpr int NT = kCot * kPt;
+    __shared__ f32x4 red[kWaves][NT][64];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lm = lane & 15, kq = lane >> 4;
+    const long p0 = (long)blockIdx.x * (kPt * 16);
+    const int cb = blockIdx.y;
+
+    long base[kPt];               // element offset of (image, channel 0, position) of this lane's position in tile j
+    int pos[kPt];
+    bool live[kPt];
+#pragma unroll
+    for (int j = 0; j < kPt; ++j) {
+        const long p = p0 + j * 16 + lm;
+        live[j] = p < a.npix;
+        const long pc = live[j] ? p : 0;
+        const int img = (int)(pc / a.len);
+        pos[j] = (int)(pc - (long)img * a.len);
+        base[j] = (long)img * a.cin * a.len + pos[j];
+    }
+    f32x4 acc[kCot][kPt];
+#pragma unroll
+    for (int i = 0; i < kCot; ++i)
+#pragma unroll
+        for (int j = 0; j < kPt; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const u32x4* const a_base = a.packed + (long)cb * a.steps * (kCot * 64) + lane;
+    const float* const zero = g_zero_s1d;
+
+    // operands of one K step: A fragments of the block's tiles, raw B values of this lane's two positions
+    struct Ops {
+        u32x4 A[kCot];
+        float v[kPt][8];
+    };
+    auto load = [&](int S, Ops& o) {
+        int c, s;
+        if (S < a.nfull * TAPS) {
+            c = S / TAPS;
+            s = S - c * TAPS;
+        } else {
+            c = a.nfull;
+            s = S - a.nfull * TAPS;
+        }
+        int tap, ch0;
+        bool kvalid = true;
+        if (c < a.nfull) {                     // a full chunk: step = tap, lane group = octet
+            tap = s;
+            ch0 = c * 32 + kq * 8;
+        } else {                               // the remainder chunk: (tap, octet) flattened over the lane groups
+            const int gi = 4 * s + kq;
+            kvalid = gi < TAPS * a.tail_oct;
+            tap = kvalid ? gi / a.tail_oct : 0;
+            ch0 = c * 32 + (kvalid ? gi - tap * a.tail_oct : 0) * 8;
+        }
+#pragma unroll
+        for (int i = 0; i < kCot; ++i) o.A[i] = a_base[((long)S * kCot + i) * 64];
+#pragma unroll
+        for (int j = 0; j < kPt; ++j) {
+            const int ls = pos[j] + tap - PAD;
+            const bool ok = live[j] && kvalid && ls >= 0 && ls < a.len;
+            const float* src = a.in + base[j] + (long)ch0 * a.len + (tap - PAD);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float* q = (ok && ch0 + e < a.cin) ? src + (long)e * a.len : zero;
+                o.v[j][e] = *q;
+            }
+        }
+    };
+    auto compute = [&](const Ops& o) {
+        u32x4 B[kPt];
+#pragma unroll
+        for (int j = 0; j < kPt; ++j) B[j] = pack8(o.v[j]);
+#pragma unroll
+        for (int i = 0; i < kCot; ++i)
+#pragma unroll
+            for (int j = 0; j < kPt; ++j) acc[i][j] = mfma_bf(o.A[i], B[j], acc[i][j]);
+    };
+
+    // this wave's steps: wid, wid + 8, ...; the loads of the next one are issued before the MFMAs of the current one.  (Two steps
+    // ahead -- pairs of steps, 136 registers -- measured SLOWER: 15.4 -> 21.3 us on 156 -> 156 @ 107 frames; the loop is bound by the
+    // cache lines its gathers touch, not by the latency of one step.)
+    int S = wid;
+    if (S < a.steps) {
+        Ops cur;
+        load(S, cur);
+        for (S += kWaves; S < a.steps; S += kWaves) {
+            Ops nxt;
+            load(S, nxt);
+            compute(cur);
+            cur = nxt;
+        }
+        compute(cur);
+    }
+#pragma unroll
+    for (int i = 0; i < kCot; ++i)
+#pragma unroll
+        for (int j = 0; j < kPt; ++j) red[wid][i * kPt + j][lane] = acc[i][j];
+    __syncthreads();
+    if (wid < NT) {
+        const int t = wid, i = t / kPt, j = t - i * kPt;
+        f32x4 s = red[0][t][lane];
+#pragma unroll
+        for (int w = 1; w < kWaves; ++w) s += red[w][t][lane];
+        const long p = p0 + j * 16 + lm;
+        if (p < a.npix) {
+            const int img = (int)(p / a.len);
+            const int l = (int)(p - (long)img * a.len);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int co = (cb * kCot + i) * 16 + kq * 4 + r;
+                if (co < a.cout) {
+                    const long idx = ((long)img * a.cout + co) * a.len + l;
+                    float v = s[r];
+                    if (a.bias != nullptr) v += a.bias[co];
+                    if (a.accumulate) v += a.out[idx];
+                    a.out[idx] = v;
+                }
+            }
+        }
+    }
+}
+
+// -------------------------------------------------------------------------------------------
+// weight gradient: part[split][tap][ci][co] = sum over the split's positions of x[ci][p + tap - pad] * dout[co][p]
+struct WArgs {
+    const float* in;
+    const float* dout;
+    float* part;
+    int cin, cout, len, n;
+    long npix;
+    int ksteps, nsplit, ci_pad, co_pad;
+};
+constexpr int kWWaves = 4;
+
+// grid: x = 32-channel blocks of ci, y = 32-channel blocks of co, z = split.  D[M = ci][N = co]: the A operand is the input window
+// (lane (kq, m): 8 consecutive positions of channel m), the B operand the output gradient (lane (kq, n): the same 8 positions of
+// channel n): an accumulator row is 4 consecutive ci of one co, so a lane group stores 16 consecutive co of a ci row.
+template <int TAPS>
+__global__ __launch_bounds__(kWWaves * 64) void s1d_wgrad_kernel(WArgs a) {
+    constexpr int PAD = TAPS / 2;
+    constexpr int NW = 8 + 2 * PAD;            // window positions per lane
+    constexpr int NT = 2 * 2 * TAPS;
+    __shared__ f32x4 red[kWWaves][NT][64];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lm = lane & 15, kq = lane >> 4;
+    const int cib = blockIdx.x, cob = blockIdx.y, z = blockIdx.z;
+    f32x4 acc[2][2][TAPS];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int t = 0; t < TAPS; ++t) acc[i][j][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const float* const zero = g_zero_s1d;
+
+    struct Ops {
+        float x[2][NW];           // input window of this lane's ci (two ci tiles)
+        float g[2][8];            // output gradient of this lane's co (two co tiles)
+        unsigned first, last;     // bit e: position e of the lane's 8 is the first / last of its row
+    };
+    auto load = [&](int ks, Ops& o) {
+        const long pk = (long)ks * 32 + kq * 8;                   // this lane group's first position
+        // walk the window pk - PAD ... pk + 7 + PAD of the flattened (image, position) sequence
+        long ps = pk - PAD;
+        const bool neg = ps < 0;
+        if (neg) ps = 0;
+        int img = (int)(ps / a.len);
+        int l = (int)(ps - (long)img * a.len);
+        o.first = 0;
+        o.last = 0;
+        long off_x[2], off_g[2];
+        bool ci_ok[2], co_ok[2];
+#pragma unroll
+        for (int t2 = 0; t2 < 2; ++t2) {
+            const int ci = (cib * 2 + t2) * 16 + lm, co = (cob * 2 + t2) * 16 + lm;
+            ci_ok[t2] = ci < a.cin;
+            co_ok[t2] = co < a.cout;
+            off_x[t2] = ((long)img * a.cin + (ci_ok[t2] ? ci : 0)) * a.len + l;
+            off_g[t2] = ((long)img * a.cout + (co_ok[t2] ? co : 0)) * a.len + l;
+        }
+        long p = pk - PAD;
+#pragma unroll
+        for (int q = 0; q < NW; ++q, ++p) {
+            const bool in_range = p >= 0 && p < a.npix;
+#pragma unroll
+            for (int t2 = 0; t2 < 2; ++t2) {
+                const float* px = (in_range && ci_ok[t2]) ? a.in + off_x[t2] : zero;
+                o.x[t2][q] = *px;
+            }
+            const int e = q - PAD;
+            if (e >= 0 && e < 8) {
+#pragma unroll
+                for (int t2 = 0; t2 < 2; ++t2) {
+                    const float* pg = (in_range && co_ok[t2]) ? a.dout + off_g[t2] : zero;
+                    o.g[t2][e] = *pg;
+                }
+                if (l == 0) o.first |= 1u << e;
+                if (l == a.len - 1) o.last |= 1u << e;
+            }
+            if (p >= 0) {                                          // advance (p < 0: the walk has not started: ps was clamped to 0)
+                ++l;
+#pragma unroll
+                for (int t2 = 0; t2 < 2; ++t2) { ++off_x[t2]; ++off_g[t2]; }
+                if (l == a.len) {
+                    l = 0;
+#pragma unroll
+                    for (int t2 = 0; t2 < 2; ++t2) {
+                        off_x[t2] += (long)(a.cin - 1) * a.len;
+                        off_g[t2] += (long)(a.cout - 1) * a.len;
+                    }
+                }
+            }
+        }
+    };
+    auto compute = [&](const Ops& o) {
+        u32x4 B[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) B[j] = pack8(o.g[j]);
+#pragma unroll
+        for (int t = 0; t < TAPS; ++t) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                float v[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    float xv = o.x[i][e + t];
+                    if (TAPS == 3) {
+                        // the tap's neighbour lies in another row (the flattened sequence continues into the next image): zero padding
+                        if (t == 0 && ((o.first >> e) & 1u)) xv = 0.f;
+                        if (t == 2 && ((o.last >> e) & 1u)) xv = 0.f;
+                    }
+                    v[e] = xv;
+                }
+                const u32x4 A = pack8(v);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j][t] = mfma_bf(A, B[j], acc[i][j][t]);
+            }
+        }
+    };
+    const int stride = a.nsplit * kWWaves;
+    int ks = z * kWWaves + wid;
+    if (ks < a.ksteps) {
+        Ops cur;
+        load(ks, cur);
+        for (ks += stride; ks < a.ksteps; ks += stride) {
+            Ops nxt;
+            load(ks, nxt);
+            compute(cur);
+            cur = nxt;
+        }
+        compute(cur);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int t = 0; t < TAPS; ++t) red[wid][(i * 2 + j) * TAPS + t][lane] = acc[i][j][t];
+    __syncthreads();
+    for (int tt = wid; tt < NT; tt += kWWaves) {
+        f32x4 s = red[0][tt][lane];
+#pragma unroll
+        for (int w = 1; w < kWWaves; ++w) s += red[w][tt][lane];
+        const int t = tt % TAPS, ij = tt / TAPS, i = ij >> 1, j = ij & 1;
+        const int co = (cob * 2 + j) * 16 + lm;
+        float* dst = a.part + ((long)z * TAPS + t) * a.ci_pad * a.co_pad + co;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int ci = (cib * 2 + i) * 16 + kq * 4 + r;
+            dst[(long)ci * a.co_pad] = s[r];
+        }
+    }
+}
+
+// positions (n * length) up to which these kernels take a layer (development: FSC_S1D_MAXPX / FSC_S1D_WMAXPX).  Measured per layer
+// of cfg 3 at batch 128 (tools/s1d_bench.py, profiles/r06_s1d_layers.txt): forward / input gradient win from rows of 107 frames
+// down (13.7 k positions: 27 -> 20 us, 35 -> 7.6 us on the last block) and lose above (27.5 k positions: gathered loads, the
+// activation re-read by every channel block); the weight gradient -- lane = channel, so a wave's gathers touch 64 lines per
+// instruction -- wins from rows of 26 frames down.
+int max_px() {
+    static const int v = [] {
+        const char* e = getenv("FSC_S1D_MAXPX");
+        return e ? atoi(e) : 16384;
+    }();
+    return v;
+}
+int max_px_wgrad() {
+    static const int v = [] {
+        const char* e = getenv("FSC_S1D_WMAXPX");
+        return e ? atoi(e) : 4096;
+    }();
+    return v;
+}
+
+}  // namespace
+
+namespace fsc {
+namespace s1d {
+
+bool plan_fwd(const fsc_conv_desc& d, int dgrad, Plan* out) {
+    if (d.arith != 1 || d.h != 1 || d.kh != 1 || !(d.kw == 1 || d.kw == 3)) return false;
+    Plan p{};
+    p.n = d.n; p.len = d.w; p.taps = d.kw;
+    p.cin = dgrad ? d.c_out : d.c_in;
+    p.cout = dgrad ? d.c_in : d.c_out;
+    p.npix = (long)d.n * d.w;
+    if (p.npix > max_px() || p.cin < 32 || p.cout < 48) return false;
+    const int rem = p.cin % 32;
+    p.nfull = p.cin / 32 + (rem > 24 ? 1 : 0);
+    p.tail_oct = (rem > 0 && rem <= 24) ? ceil_div(rem, 8) : 0;
+    p.steps = p.nfull * p.taps + ceil_div(p.taps * p.tail_oct, 4);
+    p.co_blocks = ceil_div(ceil_div(p.cout, 16), kCot);
+    p.px_groups = ceil_div(p.npix, kPt * 16);
+    *out = p;
+    return true;
+}
+
+int launch_fwd(const Plan& p, const float* in, const unsigned short* packed, const float* bias, float* out, int accumulate,
+               hipStream_t st) {
+    FwdArgs a{in, reinterpret_cast<const u32x4*>(packed), bias, out, p.cin, p.cout, p.len, p.n, p.npix, p.nfull, p.tail_oct, p.steps,
+              accumulate};
+    const dim3 grid((unsigned)p.px_groups, (unsigned)p.co_blocks);
+    if (p.taps == 3) hipLaunchKernelGGL(s1d_fwd_kernel<3>, grid, dim3(kWaves * 64), 0, st, a);
+    else hipLaunchKernelGGL(s1d_fwd_kernel<1>, grid, dim3(kWaves * 64), 0, st, a);
+    FSC_LAUNCH_CHECK("fsc_conv_fwd(s1d)");
+    return 0;
+}
+
+bool plan_wgrad(const fsc_conv_desc& d, WPlan* out) {
+    if (d.arith != 1 || d.h != 1 || d.kh != 1 || !(d.kw == 1 || d.kw == 3)) return false;
+    WPlan p{};
+    p.n = d.n; p.len = d.w; p.taps = d.kw; p.cin = d.c_in; p.cout = d.c_out;
+    p.npix = (long)d.n * d.w;
+    if (p.npix > max_px_wgrad() || p.cin < 32 || p.cout < 32) return false;
+    p.ksteps = ceil_div(p.npix, 32);
+    p.ci_blocks = ceil_div(p.cin, 32);
+    p.co_blocks = ceil_div(p.cout, 32);
+    p.ci_pad = p.ci_blocks * 32;
+    p.co_pad = p.co_blocks * 32;
+    // split K until the grid has ~2 workgroups per CU, with >= 2 K steps per wave
+    const long blocks = (long)p.ci_blocks * p.co_blocks;
+    long ns = (512 + blocks - 1) / blocks;
+    const long cap = p.ksteps / (2 * kWWaves);
+    if (ns > cap) ns = cap;
+    if (ns > 64) ns = 64;
+    if (ns < 1) ns = 1;
+    p.nsplit = (int)ns;
+    *out = p;
+    return true;
+}
+
+int launch_wgrad(const WPlan& p, const float* in, const float* dout, float* part, hipStream_t st) {
+    WArgs a{in, dout, part, p.cin, p.cout, p.len, p.n, p.npix, p.ksteps, p.nsplit, p.ci_pad, p.co_pad};
+    const dim3 grid((unsigned)p.ci_blocks, (unsigned)p.co_blocks, (unsigned)p.nsplit);
+    if (p.taps == 3) hipLaunchKernelGGL(s1d_wgrad_kernel<3>, grid, dim3(kWWaves * 64), 0, st, a);
+    else hipLaunchKernelGGL(s1d_wgrad_kernel<1>, grid, dim3(kWWaves * 64), 0, st, a);
+    FSC_LAUNCH_CHECK("fsc_conv_wgrad(s1d)");
+    return 0;
+}
+
+}  // namespace s1d
+}  // namespace fsc
