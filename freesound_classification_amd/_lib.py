@@ -81,6 +81,8 @@ SIGNATURES = {
     "fsc_conv_l16_plan_describe": (_I, [_D, _I, C.c_char_p, _SZ]),
     "fsc_conv_l16_fwd_act_supported": (_I, [_D]),
     "fsc_conv_l16_fwd_act": (_I, [_D, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "fsc_conv_l16_pool_fwd_act_supported": (_I, [_D]),
+    "fsc_conv_l16_pool_fwd_act": (_I, [_D, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "fsc_conv_l16_pool_supported": (_I, [_D]),
     "fsc_conv_l16_pool_fwd": (_I, [_D, _P, _P, _P, _P, _P, _P, _P]),
     "fsc_conv_l16_wgrad_supported": (_I, [_D]),

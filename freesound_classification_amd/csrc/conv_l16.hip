@@ -1436,6 +1436,21 @@ int fsc_debug_l16_prof(unsigned long long* out64) {
 }
 #endif
 
+/* include/fsc_hip.h: inference -- 3x3 convolution + MaxPool2d(2) + eval-mode BatchNorm + PReLU in one launch (three-limb arithmetics) */
+int fsc_conv_l16_pool_fwd_act_supported(const fsc_conv_desc* d) {
+    FSC_RESOLVE_DESC(d)
+    return d && l16::is_l3(d->arith) ? fsc::l3::pool_supported(d) : 0;
+}
+
+int fsc_conv_l16_pool_fwd_act(const fsc_conv_desc* d, const void* in_l16, const float* in_amax, const float* packed, const float* bias,
+                              const float* scale, const float* shift, const float* alpha, float* out, void* out_l16,
+                              const float* out_amax, float* seen_max, fsc_stream_t stream) {
+    FSC_RESOLVE_DESC(d)
+    FSC_CHECK_ARG(d && l16::is_l3(d->arith), "fsc_conv_l16_pool_fwd_act: the three-limb arithmetics only (arith 9, 10)");
+    return fsc::l3::pool_fwd_act(d, in_l16, in_amax, packed, bias, scale, shift, alpha, out, out_l16, out_amax, seen_max,
+                                 fsc::as_stream(stream));
+}
+
 /* include/fsc_hip.h: inference -- convolution + per-channel affine + PReLU, written as the L16 operand of the next convolution */
 int fsc_conv_l16_fwd_act_supported(const fsc_conv_desc* d) { return fsc_conv_l16_supported(d, 0); }
 

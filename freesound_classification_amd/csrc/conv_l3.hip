@@ -298,6 +298,7 @@ struct ActArgs3 {
     uint2* out16;             // the L16 output in 8-byte units; nullptr = not an ACT16 launch
     const float* out_amax;    // scaled fp16 limbs: FSC_AMAX_FLOATS declared maximum of y
     unsigned* seen;           // receives max |y| as its fp32 bit pattern (atomicMax; zeroed by the caller), or nullptr
+    int pooled;               // 1: the POOL variant -- y = act(maxpool2x2(conv)), written as fp32 to `out` (if non-null) AND as limbs
 };
 template <int KH, int KW, int CT, int PTW, int NPROD, bool F16 = false, bool POOL = false, bool STATS = false, bool ACT16 = false>
 __global__ __launch_bounds__(kWaves * 64) void conv_l3_fwd_kernel(L3Geom g, const uint4* __restrict__ in,
@@ -308,7 +309,7 @@ __global__ __launch_bounds__(kWaves * 64) void conv_l3_fwd_kernel(L3Geom g, cons
                                                                    float4* __restrict__ stat_rec,
                                                                    const float* __restrict__ in_amax,
                                                                    const float* __restrict__ w_amax, ActArgs3 act) {
-    static_assert(!ACT16 || (!POOL && !STATS), "ACT16 replaces the plain epilogue");
+    static_assert(!ACT16 || !STATS, "ACT16 (inference) has no statistics epilogue");
     constexpr int TAPS = KH * KW;
     constexpr int PADH = KH / 2, PADW = KW / 2;
     using P = Prods<NPROD>;
@@ -655,7 +656,7 @@ __global__ __launch_bounds__(kWaves * 64) void conv_l3_fwd_kernel(L3Geom g, cons
             int lane_e = lane;
             asm volatile("" : "+v"(lane_e));
             const int lm_e = lane_e & 15, kq_e = lane_e >> 4;
-            if constexpr (ACT16) {
+            if constexpr (ACT16 && !POOL) {
                 // ---- affine + PReLU + limb split: lane (kq, lm) holds channels kq * 4 + r of pixel lm -- four channels = one 8-byte
                 //      half of the (octet, limb) vector of that pixel; lanes kq, kq ^ 1 complete the 16 bytes, 16 pixels make 256
                 long gpix[PTW];                           // 16-byte unit of the pixel in limb 0 of octet 0 of its image, or -1
@@ -736,15 +737,20 @@ __global__ __launch_bounds__(kWaves * 64) void conv_l3_fwd_kernel(L3Geom g, cons
                 const int oh = g.h >> 1, ow = g.w >> 1;
                 const int tpr = g.tw >> 3, tpi = (g.th >> 1) * tpr;
                 long pool_g[PTW];
+                long pool_u[PTW];                            // (ACT16) 16-byte unit of the pooled pixel in limb 0 of octet 0 of its image
 #pragma unroll
                 for (int pt = 0; pt < PTW; ++pt) {
                     const int tt = pw * PTW + pt;
                     pool_g[pt] = -1;
+                    pool_u[pt] = -1;
                     if (tt * 16 < g.npix) {
                         const int b = tt / tpi, rem = tt - b * tpi;
                         const int tr = rem / tpr, tc = rem - tr * tpr;
                         const int pr = (h0 >> 1) + tr, pc = (w0 >> 1) + 4 * tc + (lane_e & 3);
-                        if (n0 + b < g.n && pr < oh && pc < ow) pool_g[pt] = ((long)(n0 + b) * g.cout * oh + pr) * ow + pc;
+                        if (n0 + b < g.n && pr < oh && pc < ow) {
+                            pool_g[pt] = ((long)(n0 + b) * g.cout * oh + pr) * ow + pc;
+                            pool_u[pt] = (long)(n0 + b) * ((g.cout + 7) >> 3) * 3 * ((long)oh * ow) + (long)pr * ow + pc;
+                        }
                     }
                 }
                 const long ohw = (long)oh * ow;
@@ -782,11 +788,48 @@ __global__ __launch_bounds__(kWaves * 64) void conv_l3_fwd_kernel(L3Geom g, cons
                             }
                         }
                         const float val = scratch[chp * kScr + (lane_e & 3)];
-                        const int bidx = __float_as_int(scratch[chp * kScr + 8 + (lane_e & 3)]);
-                        if (co < g.cout && pool_g[j] >= 0) {
-                            out[pool_g[j] + (long)co * ohw] = val;
-                            pool_idx[pool_g[j] + (long)co * ohw] = (uint8_t)bidx;
-                            if (STATS) stat_add(i, val, pv);
+                        if constexpr (ACT16) {
+                            // ---- inference (fsc_conv_l16_pool_fwd_act): the POOLED value goes through the eval-mode BatchNorm and PReLU
+                            //      behind the pool (classifiers.py:532-534) and leaves as fp32 (the residual reads it) AND as the limbs the
+                            //      next convolution reads; the pooled pre-activation itself is never written
+                            float yv = 0.f;
+                            if (co < g.cout) {
+                                const float tt = act.scale != nullptr ? fmaf(val, act.scale[co], act.shift[co]) : val;
+                                yv = (act.alpha != nullptr && !(tt > 0.f)) ? act.alpha[co] * tt : tt;
+                            }
+                            if (co < g.cout && pool_g[j] >= 0) {
+                                if (out != nullptr) out[pool_g[j] + (long)co * ohw] = yv;
+                                seen_mx = fmaxf(seen_mx, fabsf(yv));
+                            }
+                            scratch[chp * kScr + (lane_e & 3)] = yv;           // (its own slot) -> lanes 0..15 = (channel quad, pooled pixel)
+                            if (lane_e < 16) {
+                                const int kq2 = lane_e >> 2;
+                                float y[4];
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) y[r] = scratch[(kq2 * 4 + r) * kScr + (lane_e & 3)];
+                                const int oct = ((co0 + i * 16) >> 3) + (kq2 >> 1);
+                                if (oct < ((g.cout + 7) >> 3) && pool_u[j] >= 0) {
+                                    unsigned h0, m0, l0, h1, m1, l1;
+                                    if constexpr (F16) {
+                                        l16::split3s_pair(y[0], y[1], s_out, h0, m0, l0);
+                                        l16::split3s_pair(y[2], y[3], s_out, h1, m1, l1);
+                                    } else {
+                                        l16::split3_pair(y[0], y[1], h0, m0, l0);
+                                        l16::split3_pair(y[2], y[3], h1, m1, l1);
+                                    }
+                                    uint2* o = act.out16 + (pool_u[j] + (long)oct * 3 * ohw) * 2 + (kq2 & 1);
+                                    o[0] = make_uint2(h0, h1);
+                                    o[2 * ohw] = make_uint2(m0, m1);
+                                    o[4 * ohw] = make_uint2(l0, l1);
+                                }
+                            }
+                        } else {
+                            const int bidx = __float_as_int(scratch[chp * kScr + 8 + (lane_e & 3)]);
+                            if (co < g.cout && pool_g[j] >= 0) {
+                                out[pool_g[j] + (long)co * ohw] = val;
+                                pool_idx[pool_g[j] + (long)co * ohw] = (uint8_t)bidx;
+                                if (STATS) stat_add(i, val, pv);
+                            }
                         }
                     }
                     __builtin_amdgcn_sched_barrier(0);
@@ -1089,6 +1132,12 @@ int launch3(const L3Plan& p, const uint4* in, const uint4* packed, const float* 
 template <int KH, int KW, int CT, int PTW, int NPROD, bool F16>
 int launch3_var(const L3Plan& p, const uint4* in, const uint4* packed, const float* bias, float* out, int accumulate, uint8_t* idx,
                 StatArgs3 sa, ScaleArgs3 sc, ActArgs3 act, hipStream_t st) {
+    if (act.out16 && act.pooled) {
+        if constexpr (KH == 3 && PTW == 4)
+            return launch3<KH, KW, CT, PTW, NPROD, F16, true, false, true>(p, in, packed, bias, out, 0, nullptr, sa, sc, act, st);
+        fsc::set_error("fsc_conv_l16_pool_fwd_act: internal: no pooled instantiation");
+        return 22;
+    }
     if (act.out16) return launch3<KH, KW, CT, PTW, NPROD, F16, false, false, true>(p, in, packed, bias, nullptr, 0, nullptr, sa, sc, act, st);
     if (idx) {
         if constexpr (KH == 3 && PTW == 4) {
@@ -1278,9 +1327,24 @@ int fwd_act(const fsc_conv_desc* d, const void* in_l16, const float* in_amax, co
     FSC_CHECK_ARG((scale == nullptr) == (shift == nullptr), "fsc_conv_l16_fwd_act: scale and shift come together");
     FSC_CHECK_ARG(!l16::is_f3(d->arith) || (in_amax && out_amax), "fsc_conv_l16_fwd_act: scaled fp16 limbs need both declared maxima");
     FSC_CHECK_ARG(plan_l3(*d, 0, &p), "fsc_conv_l16_fwd_act: unsupported shape (see fsc_conv_l16_supported)");
-    ActArgs3 act{scale, shift, alpha, reinterpret_cast<uint2*>(out_l16), out_amax, reinterpret_cast<unsigned*>(seen_max)};
+    ActArgs3 act{scale, shift, alpha, reinterpret_cast<uint2*>(out_l16), out_amax, reinterpret_cast<unsigned*>(seen_max), 0};
     return launch3_any(p, d->kh * d->kw, reinterpret_cast<const uint4*>(in_l16), reinterpret_cast<const uint4*>(packed), bias, nullptr,
                        0, nullptr, StatArgs3{nullptr, nullptr}, in_amax, st, act);
+}
+
+// conv 3x3 -> MaxPool2d(2) -> eval-mode BatchNorm -> PReLU in one launch (reference networks/classifiers.py:526-534): `out` (may be
+// NULL) receives the result as fp32 (N, c_out, H / 2, W / 2), `out_l16` as the three-limb L16 tensor of that shape
+int pool_fwd_act(const fsc_conv_desc* d, const void* in_l16, const float* in_amax, const float* packed, const float* bias,
+                 const float* scale, const float* shift, const float* alpha, float* out, void* out_l16, const float* out_amax,
+                 float* seen_max, hipStream_t st) {
+    L3Plan p;
+    FSC_CHECK_ARG(valid3(d) && in_l16 && packed && out_l16, "fsc_conv_l16_pool_fwd_act: bad descriptor or null pointer");
+    FSC_CHECK_ARG((scale == nullptr) == (shift == nullptr), "fsc_conv_l16_pool_fwd_act: scale and shift come together");
+    FSC_CHECK_ARG(!l16::is_f3(d->arith) || (in_amax && out_amax), "fsc_conv_l16_pool_fwd_act: scaled fp16 limbs need both declared maxima");
+    FSC_CHECK_ARG(plan_l3_pool(*d, &p), "fsc_conv_l16_pool_fwd_act: unsupported shape (see fsc_conv_l16_pool_supported)");
+    ActArgs3 act{scale, shift, alpha, reinterpret_cast<uint2*>(out_l16), out_amax, reinterpret_cast<unsigned*>(seen_max), 1};
+    return launch3_any(p, 9, reinterpret_cast<const uint4*>(in_l16), reinterpret_cast<const uint4*>(packed), bias, out, 0, nullptr,
+                       StatArgs3{nullptr, nullptr}, in_amax, st, act);
 }
 
 int pool_fwd(const fsc_conv_desc* d, const void* in_l16, const float* in_amax, const float* packed, const float* bias, float* pooled,

@@ -135,6 +135,9 @@ int pool_fwd(const fsc_conv_desc* d, const void* in_l16, const float* in_amax, c
 int fwd_act(const fsc_conv_desc* d, const void* in_l16, const float* in_amax, const float* packed, const float* bias,
             const float* scale, const float* shift, const float* alpha, void* out_l16, const float* out_amax, float* seen_max,
             hipStream_t st);
+int pool_fwd_act(const fsc_conv_desc* d, const void* in_l16, const float* in_amax, const float* packed, const float* bias,
+                 const float* scale, const float* shift, const float* alpha, float* out, void* out_l16, const float* out_amax,
+                 float* seen_max, hipStream_t st);
 int stats_layout(const fsc_conv_desc* d, int pool, int* out4);
 int plan_describe(const fsc_conv_desc* d, int dgrad, char* buf, size_t buf_len);
 int last_clock(double* shader_mhz);

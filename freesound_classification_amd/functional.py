@@ -861,6 +861,48 @@ def conv_l16_pool(t, weight, bias, prepacked=None, stats_bn=None):
     return y, idx, (n, c_out, h, w)
 
 
+# conv -> max-pool -> BatchNorm -> PReLU in one launch (inference, fsc_conv_l16_pool_fwd_act): built and bit-identical to the three-pass
+# route (tests/test_l3_gpu.py), but OFF by default -- measured on cfg 5 (five fold models on three streams, same box, alternating runs):
+# 1151.7 / 1150.8 clips/s without, 1144.5 / 1144.0 with.  The pooled pass and the BatchNorm pass it removes are HBM-bound kernels that
+# already hide behind the other streams' matrix-bound convolutions, while the longer epilogue sits on the critical path of this one.
+EVAL_POOL_FOLD = os.environ.get("FSC_EVAL_POOL_FOLD", "0") == "1"
+
+
+def conv_l16_pool_act_supported(t_shape, weight):
+    if not EVAL_ACT_FOLD or not EVAL_POOL_FOLD or _l16_arith() not in (9, 10) or len(t_shape) != 4 or tuple(weight.shape[2:]) != (3, 3):
+        return False
+    c_out, c_in, kh, kw = weight.shape
+    n, _, h, w = t_shape
+    key = (n, c_in, c_out, h, w, kh, kw, "pool_act", _l16_arith())
+    if key not in _L16_OK:
+        _L16_OK[key] = bool(_lib.load().fsc_conv_l16_pool_fwd_act_supported(C.byref(_desc(n, c_in, c_out, h, w, kh, kw, _l16_arith()))))
+    return _L16_OK[key]
+
+
+def conv_l16_pool_act(t, weight, bias, scale, shift, alpha, decl_amax=None, seen=None, want_f32=True):
+    """Inference: 3x3 convolution -> MaxPool2d(2) -> eval-mode BatchNorm -> PReLU in one launch (fsc_conv_l16_pool_fwd_act,
+    reference classifiers.py:526-534): (result as fp32 (N, c_out, H/2, W/2) or None, result as the L16 operand of the next
+    convolution).  Neither the convolution output nor the pooled pre-activation is written."""
+    c_out, c_in, kh, kw = weight.shape
+    n, _, h, w = t.shape
+    d, packed = conv_l16_pack(weight, n, h, w, False)
+    limbs = _l16_limbs()
+    shape = (n, c_out, h // 2, w // 2)
+    out = torch.empty(shape, device=weight.device, dtype=torch.float32) if want_f32 else None
+    out16 = L16(l16_empty(shape, weight, limbs), decl_amax if limbs != 3 else None, shape, limbs)
+    if TIMER is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    call("fsc_conv_l16_pool_fwd_act", C.byref(d), ptr(t.data), ptr(t.amax), ptr(packed), ptr(bias), ptr(scale), ptr(shift), ptr(alpha),
+         ptr(out), ptr(out16.data), ptr(out16.amax), ptr(seen), stream_ptr())
+    if TIMER is not None:
+        e1.record()
+        name = l16_plan_name(d, 0).replace(">", ",pool>")
+        TIMER.records.append((name, 2.0 * n * h * w * c_in * c_out * kh * kw, e0, e1))
+        TIMER.note(name, 2.0 * n * h * w * c_in * c_out * kh * kw, (n, c_in, c_out, h, w, kh, kw), "fwd")
+    return out, out16
+
+
 POOL_FUSION = True
 
 
@@ -1646,6 +1688,29 @@ def _eval_conv_act(t16, weight, bias, bn, alpha, next_weight):
     return conv_l16_act(t16, weight, bias, scale, shift, alpha, decl, seen)
 
 
+def _eval_conv_pool_act(a16, weight, bias, bn, alpha, next_weight):
+    """Inference: conv3x3 -> max-pool -> eval-mode BatchNorm -> PReLU as ONE launch writing fp32 (for the residual) and the next
+    convolution's limbs (conv_l16_pool_act), or None (two-pass route: no tiling, the unit's first convolution reads fp32, or --
+    scaled fp16 limbs -- no scope / no calibration yet)."""
+    if (not EVAL_ACT_FOLD or a16 is None or torch.is_grad_enabled() or bn.running_mean is None or len(a16.shape) != 4
+            or not POOL_FUSION):
+        return None
+    n, _, h, w = a16.shape
+    if not conv_l16_pool_act_supported(a16.shape, weight) or not _l16_ok_for((n, weight.shape[0], h // 2, w // 2), next_weight, False):
+        return None
+    decl = seen = None
+    if _l16_limbs() != 3:
+        scope = _ACT_TLS.scope
+        key = _act_key(bn, weight, bias, alpha)
+        cal = _ACT_CAL.get(key) if scope is not None else None
+        if cal is None:
+            return None
+        decl = cal[0]
+        seen = scope.slot(weight, cal[1], key)
+    scale, shift = _bn_eval_scale_shift(bn, bn.weight, bn.bias)
+    return conv_l16_pool_act(a16, weight, bias, scale, shift, alpha, decl, seen)
+
+
 def _act_calibrate(bn, weight, t16, bias=None, alpha=None):
     """Scaled fp16 limbs, inference on the two-pass route: remember TWICE the bound this batch declared for the layer's output as
     the scale of the folded launches to come (the fp16 high limb itself holds another factor 1.99 above the declared maximum:
@@ -1678,12 +1743,20 @@ def _block_forward(x, mods, training, want_head, ph, keep, sync=None, next_bn=Fa
     # (`*_16`); the fp32 copy stays for the weight gradient (and, for b, the residual).
     a, a_max, a_16 = _bn_fwd_for_conv(x, st_a, None, w_a, need_wgrad=keep)
     packs = [] if keep else None          # input-gradient weight fragments packed along with the forward ones
-    fused = conv_pool_forward(a, w_a, b_a) if (ph == 2 and a is not None) else None
+    w1, b1 = _conv_params(res.conv1)
+    # inference: conv_a -> max-pool -> bn_b -> PReLU in one launch (the pooled pre-activation never exists); else the steps below
+    pool_act = _eval_conv_pool_act(a_16, w_a, b_a, bn_b, prelu_b.weight, w1) if (ph == 2 and not training and not keep) else None
+    if pool_act is not None:
+        b, b_16 = pool_act
+        b_max = b_16.amax
+        st_b = None
+        k.c_shape = (a_16.shape[0], w_a.shape[0], a_16.shape[2], a_16.shape[3])
+    fused = conv_pool_forward(a, w_a, b_a) if (ph == 2 and a is not None and pool_act is None) else None
     if fused is not None:
         p, pidx, k.c_shape = fused
         if keep:
             packs.append(None)
-    else:
+    elif pool_act is None:
         pooled = None
         if POOL_FUSION and ph == 2 and a_16 is not None and _l16_ok_for(a_16.shape, w_a, False):
             n_, _, h_, w_ = a_16.shape
@@ -1703,9 +1776,12 @@ def _block_forward(x, mods, training, want_head, ph, keep, sync=None, next_bn=Fa
             p, pidx = maxpool_forward(c, ph)
             k.c_shape = tuple(c.shape)
             del c
-    w1, b1 = _conv_params(res.conv1)
-    st_b = bn_prepare(p, bn_b, training, sync, counters, want_minmax=mm(p, w1))
-    b, b_max, b_16 = _bn_fwd_for_conv(p, st_b, prelu_b.weight, w1, keep_f32=True, need_wgrad=keep)      # (the residual reads it)
+    if pool_act is None:
+        st_b = bn_prepare(p, bn_b, training, sync, counters, want_minmax=mm(p, w1))
+        b, b_max, b_16 = _bn_fwd_for_conv(p, st_b, prelu_b.weight, w1, keep_f32=True, need_wgrad=keep)      # (the residual reads it)
+        if (ph == 2 and not training and not keep and a_16 is not None and b_16 is not None
+                and conv_l16_pool_act_supported(a_16.shape, w_a)):
+            _act_calibrate(bn_b, w_a, b_16, b_a, prelu_b.weight)                 # (scaled limbs: the folded launch's scale next time)
     w2, b2 = _conv_params(res.conv2)
     w3, b3 = _conv_params(res.conv3)
     # inference: conv1 -> bn1 -> PReLU and conv2 -> bn2 -> PReLU as one launch each (the epilogue writes the next convolution's

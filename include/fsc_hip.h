@@ -229,6 +229,15 @@ int fsc_conv_l16_fwd_act_supported(const fsc_conv_desc* d);
 int fsc_conv_l16_fwd_act(const fsc_conv_desc* d, const void* in_l16, const float* in_amax, const float* packed, const float* bias,
                          const float* scale, const float* shift, const float* alpha, void* out_l16, const float* out_amax,
                          float* seen_max, fsc_stream_t stream);
+/* Inference, the entry convolution of a block (classifiers.py:526-534): 3x3 convolution -> MaxPool2d(2) -> eval-mode BatchNorm
+ * (scale / shift of fsc_bn_eval_prepare) -> PReLU in ONE launch.  The result (N, c_out, H/2, W/2) leaves as fp32 in `out` (the
+ * residual unit adds it back; may be NULL) AND as the three-limb L16 tensor `out_l16` the unit's first convolution reads; the
+ * convolution output and the pooled pre-activation are never written.  Same expressions as fsc_conv_l16_pool_fwd followed by
+ * fsc_bn_act_fwd_limbs: bit-identical fp32 and limbs.  Arith 9 / 10 only; out_amax / seen_max as fsc_conv_l16_fwd_act. */
+int fsc_conv_l16_pool_fwd_act_supported(const fsc_conv_desc* d);
+int fsc_conv_l16_pool_fwd_act(const fsc_conv_desc* d, const void* in_l16, const float* in_amax, const float* packed, const float* bias,
+                              const float* scale, const float* shift, const float* alpha, float* out, void* out_l16,
+                              const float* out_amax, float* seen_max, fsc_stream_t stream);
 /* Forward 3x3 convolution fused with the MaxPool2d(2) behind it (classifiers.py:526-532, the blocks after the stem): writes
  * the pooled tensor (N, c_out, H/2, W/2) and the uint8 window indices of fsc_maxpool_fwd (same first-maximum / NaN rule);
  * the full-resolution output is never materialised.  `packed` from fsc_conv_l16_pack_weights(dgrad = 0). */

@@ -430,6 +430,51 @@ def test_conv_with_the_batchnorm_and_prelu_in_its_epilogue_equals_the_two_pass_r
         assert torch.equal(got2.data, F.l16_pack(r, x_amax=decl2).data)
 
 
+@pytest.mark.parametrize("shape", [(64, 100, 150, 16, 48), (8, 150, 225, 32, 107), (128, 64, 100, 8, 24), (16, 100, 150, 31, 107), (16, 100, 150, 33, 105)])
+def test_conv_pool_batchnorm_prelu_in_one_launch_equals_the_three_pass_route(shape, l3):
+    """fsc_conv_l16_pool_fwd_act (inference, the entry convolution of a block: reference classifiers.py:526-534): conv 3x3 ->
+    MaxPool2d(2) -> eval-mode BatchNorm -> PReLU.  The fp32 result and the limbs are, bit for bit, those of fsc_conv_l16_pool_fwd
+    -> fsc_bn_act_fwd -> limb split with the same declared maximum (odd H / W: floor-mode pooling); pad channels zero; the
+    largest value written is reported exactly; the fp32 output is optional."""
+    n, c_in, c_out, h, w = shape
+    gen = torch.Generator(device=DEV).manual_seed(sum(shape))
+    x = torch.randn(n, c_in, h, w, device=DEV, generator=gen)
+    wt = torch.randn(c_out, c_in, 3, 3, device=DEV, generator=gen) / (c_in * 9) ** 0.5
+    b = torch.randn(c_out, device=DEV, generator=gen)
+    bn = _BN(c_out, gen).eval()
+    with torch.no_grad():
+        bn.running_mean.normal_(0, 0.3, generator=gen)
+        bn.running_var.uniform_(0.5, 1.5, generator=gen)
+    alpha = 0.25 + 0.1 * torch.rand(c_out, device=DEV, generator=gen)
+    fold0, F.EVAL_POOL_FOLD = F.EVAL_POOL_FOLD, True              # (off by default: functional.EVAL_POOL_FOLD says why)
+    F._L16_OK.clear()
+    try:
+        _pool_act_case(shape, l3, x, wt, b, bn, alpha)
+    finally:
+        F.EVAL_POOL_FOLD = fold0
+        F._L16_OK.clear()
+
+
+def _pool_act_case(shape, l3, x, wt, b, bn, alpha):
+    n, c_in, c_out, h, w = shape
+    with torch.no_grad():
+        assert F.conv_l16_pool_act_supported(x.shape, wt), shape
+        t = F.l16_pack(x)
+        pooled = F.conv_l16_pool(t, wt, b)
+        assert pooled is not None
+        st = F.bn_prepare(pooled[0], bn, False)
+        y = F.bn_act_forward(pooled[0], st, alpha)
+        decl = F.amax(y) * 2.0 if l3 != 9 else None
+        want = F.l16_pack(y, x_amax=decl)
+        seen = torch.zeros(1, device=DEV)
+        out, got = F.conv_l16_pool_act(t, wt, b, st.scale, st.shift, alpha, decl, seen)
+        assert tuple(out.shape) == (n, c_out, h // 2, w // 2) and torch.equal(out, y)
+        assert got.limbs == want.limbs and torch.equal(got.data, want.data)
+        assert float(seen) == float(y.abs().max())
+        none, got2 = F.conv_l16_pool_act(t, wt, b, st.scale, st.shift, alpha, decl, None, want_f32=False)
+        assert none is None and torch.equal(got2.data, want.data)
+
+
 @pytest.mark.parametrize("arith", ["bf16x9", "f16x6", "f16x3"])
 def test_inference_with_folded_residual_units_against_the_two_pass_route(arith):
     """Eval-mode forward of the cfg-2 network (batch 32 x 10 s: the first two blocks have three-limb tilings) with conv -> BatchNorm -> PReLU of the residual units as one launch:
