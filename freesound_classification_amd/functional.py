@@ -1939,6 +1939,40 @@ def _stem_bn_grads(dc, dc_chan_sum, weight, dweight, bn, borders=None):
     return dgamma, dbeta
 
 
+FIRST_BLOCK_1D_IDENTITY = os.environ.get("FSC_FIRST_BLOCK_1D_IDENTITY", "1") == "1"
+
+
+def _first_block_grads_1d(x, st, dc, dc_chan_sum, weight, bn):
+    """First block of the 1-d model (reference classifiers.py:147-154: BatchNorm1d -> Conv1d(k = 3) on the spectrogram, which needs no
+    gradient): the convolution's weight gradient AND the BatchNorm's dgamma / dbeta from ONE weight-gradient pass over the RAW input x
+    of the BatchNorm -- no input-gradient convolution (a 228 MB tensor at cfg 3 that was only ever summed), no BatchNorm backward
+    pass over it, and NO DIVISION by gamma (the quotient form of _stem_bn_grads needs a host-side guard on min |gamma|, which a
+    recorded HIP graph cannot evaluate).  With a = gamma xhat + beta inside the row and 0 in the padding, xhat = (x - mean) invstd:
+        dWx[co][ci][t] = sum_p dc[co][p] x[ci][p + t - 1]        (x zero-extended: the same zero padding as the convolution)
+        T[co][t]       = sum of dc[co] over the positions whose tap-t neighbour lies inside the row (total - first / last column)
+        C = invstd (dWx - mean T) = sum dc xhat                   dW = gamma C + beta T
+        dgamma[ci] = sum_p da xhat = sum_{co,t} w C               dbeta[ci] = sum_p da = sum_{co,t} w T
+    (da = the input gradient nobody computes any more.)  Exact in exact arithmetic; in fp32 the difference dWx - mean T costs about
+    log2(|mean| / std) bits of the correlation (log-magnitudes: one or two).  Returns (dW, dgamma, dbeta)."""
+    c_out, c_in = weight.shape[0], weight.shape[1]
+    dwx = conv_wgrad(x, dc, weight.shape, False)
+    wgrad_flush(end=False)                                   # (read here)
+    tot = dc_chan_sum
+    t = torch.stack([tot - dc[:, :, 0, 0].sum(0), tot, tot - dc[:, :, 0, -1].sum(0)], 1)          # (c_out, 3)
+    mu, istd = st.mean, st.invstd
+    g, b = bn.weight.detach(), bn.bias.detach()
+    core = (dwx.reshape(c_out, c_in, 3) - mu[None, :, None] * t[:, None, :]) * istd[None, :, None]
+    w3 = weight.detach().reshape(c_out, c_in, 3)
+    dgamma = (w3 * core).sum((0, 2))
+    dbeta = (w3 * t[:, None, :]).sum((0, 2))
+    dw = core * g[None, :, None] + b[None, :, None] * t[:, None, :]
+    out = GRAD_OUT(weight) if GRAD_OUT is not None else None
+    if out is not None:                                      # data-parallel: the gradient lives in the all-reduce bucket
+        out.view(c_out, c_in, 3).copy_(dw)
+        dw = out
+    return dw.reshape(weight.shape), dgamma, dbeta
+
+
 class ConvBlockFn(torch.autograd.Function):
     """One `conv_modules[k]` block of the reference (networks/classifiers.py:524-536 with
     ResnetBlock2d :72-104, or the 1-d pair :147-161 / :37-69) and its deep-supervision head
@@ -2045,8 +2079,19 @@ class ConvBlockFn(torch.autograd.Function):
             dc, dgb, dbtb, dalb, dbias_a, dc_m = bn_act_backward_unpool(db.contiguous(), k.p, k.st_b, bn_b, prelu_b.weight,
                                                                         k.pidx, k.c_shape, ph, sync=sync, l16=w16, want_f32=w32)
             del db
-            dwa = _conv_wgrad_any(k.a, a_16, a_max, dc, _l16_of(dc_m), _amax_of(dc_m), wa)
-            if (STEM_BN_IDENTITY and not ctx.x_needs_grad and dc is not None and dc.dim() == 4 and tuple(wa.shape[2:]) == (3, 3)
+            first_1d = (FIRST_BLOCK_1D_IDENTITY and not ctx.x_needs_grad and dc is not None and dc.dim() == 4 and dc.shape[2] == 1
+                        and tuple(wa.shape[2:]) == (1, 3) and dc.shape[3] >= 2 and bn_a.weight is not None and k.st_a.mean is not None
+                        and sync is None)
+            if first_1d:
+                # first block of the 1-d model: everything from one weight-gradient pass over bn_a's raw input (no dgrad, no BN backward)
+                dwa, dga, dbta = _first_block_grads_1d(k.x, k.st_a, dc, dbias_a, wa, bn_a)
+                dx = None
+                del dc, dc_m
+            else:
+                dwa = _conv_wgrad_any(k.a, a_16, a_max, dc, _l16_of(dc_m), _amax_of(dc_m), wa)
+            if first_1d:
+                pass
+            elif (STEM_BN_IDENTITY and not ctx.x_needs_grad and dc is not None and dc.dim() == 4 and tuple(wa.shape[2:]) == (3, 3)
                     and bn_a.weight is not None and h_w_min(dc) >= 2 and k.gamma_guard is not None and k.gamma_guard.ok()):
                 # the block input needs no gradient: bn_a's parameter gradients from the weight gradient (no dgrad, no BN backward)
                 wgrad_flush(end=False)                  # (dwa is read here)

@@ -275,7 +275,7 @@ def batch32_oracle():
     return dict(state=state, signal=signal, labels=labels, rl=rl, rper=rper, g64=g64, g32=g32)
 
 
-@pytest.mark.parametrize("arith", ["f16x3", "f16x6"])
+@pytest.mark.parametrize("arith", ["f16x3", "f16x6", "bf16x9"])
 def test_cfg2_model_batch32_gradients_against_the_oracle_in_fp64(batch32_oracle, arith):
     """One training forward / backward of the real 21.5 M-parameter cfg-2 model at batch 32 x 10 s (the head's BatchNorm1d layers
     normalise over 32 rows, not the 4 of fixture g12) against the CPU oracle evaluated in fp64 on the same weights and inputs, in
