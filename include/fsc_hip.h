@@ -198,7 +198,8 @@ size_t fsc_l16_bytes_limbs(int n, int c, long hw, int limbs);
 int fsc_l16_pack_limbs(const float* x, int n, int c, long hw, const float* amax, int limbs, void* out_l16, fsc_stream_t stream);
 int fsc_l16_unpack_limbs(const void* in_l16, int n, int c, long hw, const float* amax, int limbs, float* x, fsc_stream_t stream);
 /* 1 when fsc_conv_l16_fwd has a tiling for this shape and direction (3x3 / 1x1, >= 32 input and >= 48 output
- * channels, enough work items to fill the chip without split-K; arith 3 or FSC_ARITH_DEFAULT) */
+ * channels, enough work items to fill the chip without split-K) in the descriptor's arithmetic: 3 (two limbs), 9 / 10 (three limbs);
+ * FSC_ARITH_DEFAULT resolves to the process default (fsc_conv_default_arith) at every entry point */
 int fsc_conv_l16_supported(const fsc_conv_desc* d, int dgrad);
 size_t fsc_conv_l16_packed_floats(const fsc_conv_desc* d, int dgrad);
 int fsc_conv_l16_pack_weights(const fsc_conv_desc* d, const float* weight, int dgrad, float* packed,
