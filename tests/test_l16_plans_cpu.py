@@ -48,12 +48,26 @@ def _describe(d, mode):
 
 def test_cfg3_late_blocks_weight_gradients_run_one_unit_per_workgroup():
     """The 1-d model's last blocks (128 x 3 ... 13 positions: 7 - 32 boxes of 64 pixels) split their weight gradients down to one
-    unit per workgroup; layers of 64 units and more keep at least four units per split (conv.hip plan_wgrad)."""
+    unit per workgroup on the native kernels (fp32 arithmetic); layers of 64 units and more keep at least four units per split
+    (conv.hip plan_wgrad).  In bf16 (arith 1, cfg 3) these layers take conv_s1d.hip since round 6: 32-position K steps, split so
+    that a wave keeps at least two steps."""
     want = {(476, 476, 3, 1): (7, 7), (476, 476, 3, 3): (7, 7), (381, 381, 6, 3): (13, 13), (305, 305, 13, 1): (32, 32),
             (244, 244, 26, 1): (64, 16)}
     for (ci, co, length, k), (units, split) in want.items():
-        txt = _describe(F._desc(128, ci, co, 1, length, 1, k, 1), 2)
-        assert "units=%d split=%d " % (units, split) in txt, txt
+        txt = _describe(F._desc(128, ci, co, 1, length, 1, k, 0), 2)
+        assert txt.startswith("conv_wgrad_kernel") and "units=%d split=%d " % (units, split) in txt, txt
+    s1d = {(476, 476, 3, 1): (12, 1), (476, 476, 3, 3): (12, 1), (381, 381, 6, 3): (24, 3), (305, 305, 13, 1): (52, 6),
+           (244, 244, 26, 1): (104, 8)}
+    for (ci, co, length, k), (units, split) in s1d.items():
+        d = F._desc(128, ci, co, 1, length, 1, k, 1)
+        txt = _describe(d, 2)
+        assert txt.startswith("conv_s1d_wgrad_kernel<1,%d>" % k) and "units=%d split=%d " % (units, split) in txt, txt
+        assert _describe(d, 0).startswith("conv_s1d_fwd_kernel<1,%d>" % k) and _describe(d, 1).startswith("conv_s1d_fwd_kernel")
+    # rows above the small-layer ranges keep the round-1 kernels: forward / input gradient beyond 16 384 positions, weight gradient beyond 4096
+    d = F._desc(128, 125, 156, 1, 215, 1, 3, 1)
+    assert _describe(d, 0).startswith("conv_fwd_x3_kernel") and _describe(d, 2).startswith("conv_wgrad_x3_kernel")
+    d = F._desc(128, 195, 195, 1, 53, 1, 3, 1)
+    assert _describe(d, 0).startswith("conv_s1d_fwd_kernel") and not _describe(d, 2).startswith("conv_s1d")
 
 
 def test_multi_pack_covers_the_bf16_limb_tilings_only():
