@@ -106,3 +106,36 @@ def test_train_driver_cli_has_the_reference_flags():
     assert args.folds == [0, 1, 2, 3, 4] and args.conv_base_depth == 100 and args.share_noisy and args.resume
     assert drv.build_parser("1d_cnn").parse_args([]).label == "1d_cnn"
     import train_hierarchical_cnn  # noqa: F401  (imports the shared driver with the 1-d model class)
+
+
+def test_default_conv_arithmetic_is_the_headline_one_and_the_drivers_can_change_it():
+    """Round 6 ("ship what you measure"): with no environment variable the library's default convolution arithmetic is f16x6
+    (arith 10, products to 2^-32: the reference's fp32 nn.Conv2d precision, classifiers.py:526-531) -- what bench.py's `value` is
+    measured in; `--conv_arith` on both drivers selects the others; a descriptor's FSC_ARITH_DEFAULT means that default."""
+    import ctypes as C
+    import subprocess
+    import sys
+    import train_2d_cnn as drv
+    from freesound_classification_amd import functional as F
+    lib = F._lib.load()
+    env = {k: v for k, v in os.environ.items() if k != "FSC_CONV_ARITH"}
+    code = "from freesound_classification_amd import functional as F; print(F._lib.load().fsc_conv_default_arith())"
+    assert subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, cwd=ROOT).stdout.strip() == "10"
+    for name, want in (("f16x3", "3"), ("bf16x9", "9"), ("f32", "0")):
+        out = subprocess.run([sys.executable, "-c", code], env=dict(env, FSC_CONV_ARITH=name), capture_output=True, text=True, cwd=ROOT)
+        assert out.stdout.strip() == want, (name, out.stdout, out.stderr)
+    if "FSC_CONV_ARITH" not in os.environ:
+        assert lib.fsc_conv_default_arith() == 10 and F.get_conv_arith() == 10
+    args = drv.build_parser().parse_args("--synthetic 8 --conv_arith bf16x9".split())
+    assert args.conv_arith == "bf16x9" and drv.build_parser().parse_args([]).conv_arith is None
+    src = open(os.path.join(ROOT, "predict_2d_cnn.py")).read()
+    assert "--conv_arith" in src and "set_conv_arith(args.conv_arith)" in src
+    # FSC_ARITH_DEFAULT resolves to the process default at the pre-split entry points too: the same tiling as arith = default
+    d_def = F.ConvDesc(128, 100, 100, 64, 215, 3, 3, -1)
+    d_exp = F.ConvDesc(128, 100, 100, 64, 215, 3, 3, lib.fsc_conv_default_arith())
+    assert lib.fsc_conv_l16_supported(C.byref(d_def), 0) == lib.fsc_conv_l16_supported(C.byref(d_exp), 0) == 1
+    assert lib.fsc_conv_l16_packed_floats(C.byref(d_def), 0) == lib.fsc_conv_l16_packed_floats(C.byref(d_exp), 0)
+    assert lib.fsc_conv_l16_wgrad_workspace_bytes(C.byref(d_def)) == lib.fsc_conv_l16_wgrad_workspace_bytes(C.byref(d_exp))
+    buf_a, buf_b = C.create_string_buffer(256), C.create_string_buffer(256)
+    assert lib.fsc_conv_l16_plan_describe(C.byref(d_def), 0, buf_a, 256) == 0 and lib.fsc_conv_l16_plan_describe(C.byref(d_exp), 0, buf_b, 256) == 0
+    assert buf_a.value == buf_b.value
