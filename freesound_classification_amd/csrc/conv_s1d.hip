@@ -334,14 +334,149 @@ __global__ __launch_bounds__(kWWaves * 64) void s1d_wgrad_kernel(WArgs a) {
     }
 }
 
+// -------------------------------------------------------------------------------------------
+// weight gradient, SEGMENT form (rows of >= 8 positions): the K dimension runs over segments of 8 consecutive positions of ONE row
+// (a row of L positions has ceil(L / 8) segments, the last one masked), four segments per K step, one per lane group.  A lane's
+// operand values are then contiguous in memory -- the window l0 - 1 ... l0 + 8 of its input channel, the 8 positions of its output
+// channel -- and arrive as three / two vector loads instead of ten / eight gathered dwords (lane = channel: every load instruction
+// of the flattened form touched 64 cache lines); positions outside the row are masked to zero, which IS the convolution's padding.
+struct f4u { float v[4]; } __attribute__((packed, aligned(4)));
+struct f2u { float v[2]; } __attribute__((packed, aligned(4)));
+
+template <int TAPS>
+__global__ __launch_bounds__(kWWaves * 64) void s1d_wgrad_seg_kernel(WArgs a, int spr, long nseg, long total_x, long total_g) {
+    constexpr int PAD = TAPS / 2;
+    constexpr int NW = 8 + 2 * PAD;
+    constexpr int NT = 2 * 2 * TAPS;
+    __shared__ f32x4 red[kWWaves][NT][64];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lm = lane & 15, kq = lane >> 4;
+    const int cib = blockIdx.x, cob = blockIdx.y, z = blockIdx.z;
+    f32x4 acc[2][2][TAPS];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int t = 0; t < TAPS; ++t) acc[i][j][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    struct Ops {
+        float x[2][NW];
+        float g[2][8];
+    };
+    auto load = [&](int ks, Ops& o) {
+        const long seg = (long)ks * 4 + kq;
+        const bool seg_ok = seg < nseg;
+        const long sc = seg_ok ? seg : 0;
+        const int img = (int)(sc / spr);
+        const int l0 = (int)(sc - (long)img * spr) * 8;
+#pragma unroll
+        for (int t2 = 0; t2 < 2; ++t2) {
+            const int ci = (cib * 2 + t2) * 16 + lm, co = (cob * 2 + t2) * 16 + lm;
+            const bool ci_ok = seg_ok && ci < a.cin, co_ok = seg_ok && co < a.cout;
+            // ---- input window l0 - PAD ... l0 + 7 + PAD of channel ci
+            const long bx = ((long)img * a.cin + (ci_ok ? ci : 0)) * a.len + l0 - PAD;
+            float xv[NW];
+            if (bx >= 0 && bx + NW <= total_x) {              // (all but the first / last rows of the tensor: vector loads)
+                const f4u q0 = *reinterpret_cast<const f4u*>(a.in + bx), q1 = *reinterpret_cast<const f4u*>(a.in + bx + 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { xv[e] = q0.v[e]; xv[4 + e] = q1.v[e]; }
+                if (PAD) {
+                    const f2u q2 = *reinterpret_cast<const f2u*>(a.in + bx + 8);
+                    xv[8] = q2.v[0]; xv[NW - 1] = q2.v[1];
+                }
+            } else {
+#pragma unroll
+                for (int q = 0; q < NW; ++q) xv[q] = (bx + q >= 0 && bx + q < total_x) ? a.in[bx + q] : 0.f;
+            }
+#pragma unroll
+            for (int q = 0; q < NW; ++q) {
+                const int l = l0 - PAD + q;
+                o.x[t2][q] = (ci_ok && l >= 0 && l < a.len) ? xv[q] : 0.f;
+            }
+            // ---- output gradient l0 ... l0 + 7 of channel co
+            const long bg = ((long)img * a.cout + (co_ok ? co : 0)) * a.len + l0;
+            float gv[8];
+            if (bg + 8 <= total_g) {
+                const f4u q0 = *reinterpret_cast<const f4u*>(a.dout + bg), q1 = *reinterpret_cast<const f4u*>(a.dout + bg + 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { gv[e] = q0.v[e]; gv[4 + e] = q1.v[e]; }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) gv[e] = bg + e < total_g ? a.dout[bg + e] : 0.f;
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o.g[t2][e] = (co_ok && l0 + e < a.len) ? gv[e] : 0.f;
+        }
+    };
+    auto compute = [&](const Ops& o) {
+        u32x4 B[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) B[j] = pack8(o.g[j]);
+#pragma unroll
+        for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                float v[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = o.x[i][e + t];
+                const u32x4 A = pack8(v);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j][t] = mfma_bf(A, B[j], acc[i][j][t]);
+            }
+    };
+    const int stride = a.nsplit * kWWaves;
+    int ks = z * kWWaves + wid;
+    if (ks < a.ksteps) {
+        Ops cur;
+        load(ks, cur);
+        for (ks += stride; ks < a.ksteps; ks += stride) {
+            Ops nxt;
+            load(ks, nxt);
+            compute(cur);
+            cur = nxt;
+        }
+        compute(cur);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int t = 0; t < TAPS; ++t) red[wid][(i * 2 + j) * TAPS + t][lane] = acc[i][j][t];
+    __syncthreads();
+    for (int tt = wid; tt < NT; tt += kWWaves) {
+        f32x4 s = red[0][tt][lane];
+#pragma unroll
+        for (int w = 1; w < kWWaves; ++w) s += red[w][tt][lane];
+        const int t = tt % TAPS, ij = tt / TAPS, i = ij >> 1, j = ij & 1;
+        const int co = (cob * 2 + j) * 16 + lm;
+        float* dst = a.part + ((long)z * TAPS + t) * a.ci_pad * a.co_pad + co;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int ci = (cib * 2 + i) * 16 + kq * 4 + r;
+            dst[(long)ci * a.co_pad] = s[r];
+        }
+    }
+}
+
 // positions (n * length) up to which these kernels take a layer (development: FSC_S1D_MAXPX / FSC_S1D_WMAXPX).  Measured per layer
 // of cfg 3 at batch 128 (tools/s1d_bench.py, profiles/r06_s1d_layers.txt): forward / input gradient win from rows of 107 frames
 // down (13.7 k positions: 27 -> 20 us, 35 -> 7.6 us on the last block) and lose above (27.5 k positions: gathered loads, the
-// activation re-read by every channel block); the weight gradient -- lane = channel, so a wave's gathers touch 64 lines per
-// instruction -- wins from rows of 26 frames down.
+// activation re-read by every channel block); the weight gradient in its flattened form -- lane = channel, so a wave's gathers
+// touch 64 lines per instruction -- wins from rows of 26 frames down (4096 positions), in its segment form (rows of >= 13 frames)
+// over the whole range: 445 -> 358 us over blocks 4 - 9 (30 -> 21 us on 195 -> 195 k1 @ 53, 38 -> 17 on 244 -> 305 @ 26).
 int max_px() {
     static const int v = [] {
         const char* e = getenv("FSC_S1D_MAXPX");
+        return e ? atoi(e) : 16384;
+    }();
+    return v;
+}
+int max_px_wgrad_seg() {
+    static const int v = [] {
+        const char* e = getenv("FSC_S1D_WSEGMAXPX");
         return e ? atoi(e) : 16384;
     }();
     return v;
@@ -393,8 +528,12 @@ bool plan_wgrad(const fsc_conv_desc& d, WPlan* out) {
     WPlan p{};
     p.n = d.n; p.len = d.w; p.taps = d.kw; p.cin = d.c_in; p.cout = d.c_out;
     p.npix = (long)d.n * d.w;
-    if (p.npix > max_px_wgrad() || p.cin < 32 || p.cout < 32) return false;
-    p.ksteps = ceil_div(p.npix, 32);
+    // rows of >= 13 positions: the segment form (K step = four 8-position segments of single rows: vector loads); shorter rows
+    // (6 and 3 frames fill 75 % / 37 % of a segment) keep the flattened form
+    p.seg = d.w >= 13 ? 1 : 0;
+    if (p.npix > (p.seg ? max_px_wgrad_seg() : max_px_wgrad()) || p.cin < 32 || p.cout < 32) return false;
+    p.spr = ceil_div(d.w, 8);
+    p.ksteps = p.seg ? ceil_div((long)d.n * p.spr, 4) : ceil_div(p.npix, 32);
     p.ci_blocks = ceil_div(p.cin, 32);
     p.co_blocks = ceil_div(p.cout, 32);
     p.ci_pad = p.ci_blocks * 32;
@@ -414,6 +553,13 @@ bool plan_wgrad(const fsc_conv_desc& d, WPlan* out) {
 int launch_wgrad(const WPlan& p, const float* in, const float* dout, float* part, hipStream_t st) {
     WArgs a{in, dout, part, p.cin, p.cout, p.len, p.n, p.npix, p.ksteps, p.nsplit, p.ci_pad, p.co_pad};
     const dim3 grid((unsigned)p.ci_blocks, (unsigned)p.co_blocks, (unsigned)p.nsplit);
+    if (p.seg) {
+        const long nseg = (long)p.n * p.spr, tx = p.npix * p.cin, tg = p.npix * p.cout;
+        if (p.taps == 3) hipLaunchKernelGGL(s1d_wgrad_seg_kernel<3>, grid, dim3(kWWaves * 64), 0, st, a, p.spr, nseg, tx, tg);
+        else hipLaunchKernelGGL(s1d_wgrad_seg_kernel<1>, grid, dim3(kWWaves * 64), 0, st, a, p.spr, nseg, tx, tg);
+        FSC_LAUNCH_CHECK("fsc_conv_wgrad(s1d, segments)");
+        return 0;
+    }
     if (p.taps == 3) hipLaunchKernelGGL(s1d_wgrad_kernel<3>, grid, dim3(kWWaves * 64), 0, st, a);
     else hipLaunchKernelGGL(s1d_wgrad_kernel<1>, grid, dim3(kWWaves * 64), 0, st, a);
     FSC_LAUNCH_CHECK("fsc_conv_wgrad(s1d)");

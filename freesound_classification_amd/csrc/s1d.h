@@ -25,7 +25,8 @@ int launch_fwd(const Plan& p, const float* in, const unsigned short* packed, con
 struct WPlan {
     int n, cin, cout, len, taps;
     long npix;
-    int ksteps;                        // 32-pixel K steps over n * len
+    int seg, spr;                      // seg = 1: K steps of four 8-position segments of single rows (spr segments per row)
+    int ksteps;                        // K steps (32 positions, or four segments)
     int nsplit;                        // split-K slices written to the workspace (grid.z)
     int ci_blocks, co_blocks;          // 32 x 32 (ci, co) blocks
     int ci_pad, co_pad;
