@@ -467,17 +467,20 @@ __global__ __launch_bounds__(kWWaves * 64) void s1d_wgrad_seg_kernel(WArgs a, in
 // activation re-read by every channel block); the weight gradient in its flattened form -- lane = channel, so a wave's gathers
 // touch 64 lines per instruction -- wins from rows of 26 frames down (4096 positions), in its segment form (rows of >= 13 frames)
 // over the whole range: 445 -> 358 us over blocks 4 - 9 (30 -> 21 us on 195 -> 195 k1 @ 53, 38 -> 17 on 244 -> 305 @ 26).
-int max_px() {
+// (re-measured with 64-channel workgroups, profiles/r06_s1d_layers.txt last table: k = 3 wins up to rows of 215 frames (27.5 k
+// positions: 27 -> 19 us) and loses at 430 (29 against 27 us); k = 1 -- a third of the gathers -- still wins there (27 -> 24 us)
+// and loses at 861; the weight gradient's segment form wins or ties up to 55 k positions (38 -> 28 us on 100 -> 100 k1 @ 430))
+int max_px(int taps) {
     static const int v = [] {
         const char* e = getenv("FSC_S1D_MAXPX");
-        return e ? atoi(e) : 16384;
+        return e ? atoi(e) : -1;
     }();
-    return v;
+    return v >= 0 ? v : (taps == 1 ? 65536 : 32768);
 }
 int max_px_wgrad_seg() {
     static const int v = [] {
         const char* e = getenv("FSC_S1D_WSEGMAXPX");
-        return e ? atoi(e) : 16384;
+        return e ? atoi(e) : 65536;
     }();
     return v;
 }
@@ -501,7 +504,7 @@ bool plan_fwd(const fsc_conv_desc& d, int dgrad, Plan* out) {
     p.cin = dgrad ? d.c_out : d.c_in;
     p.cout = dgrad ? d.c_in : d.c_out;
     p.npix = (long)d.n * d.w;
-    if (p.npix > max_px() || p.cin < 32 || p.cout < 48) return false;
+    if (p.npix > max_px(p.taps) || p.cin < 32 || p.cout < 48) return false;
     const int rem = p.cin % 32;
     p.nfull = p.cin / 32 + (rem > 24 ? 1 : 0);
     p.tail_oct = (rem > 0 && rem <= 24) ? ceil_div(rem, 8) : 0;

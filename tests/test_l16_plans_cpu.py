@@ -65,9 +65,16 @@ def test_cfg3_late_blocks_weight_gradients_run_one_unit_per_workgroup():
         txt = _describe(d, 2)
         assert txt.startswith("conv_s1d_wgrad_kernel<1,%d>" % k) and "units=%d split=%d " % (units, split) in txt, txt
         assert _describe(d, 0).startswith("conv_s1d_fwd_kernel<1,%d>" % k) and _describe(d, 1).startswith("conv_s1d_fwd_kernel")
-    # rows above the small-layer range (16 384 positions) keep the round-1 kernels in every direction
+    # the ranges: k = 3 forward / input gradient up to 32 768 positions, k = 1 and the weight gradient's segment form up to 65 536;
+    # rows above keep the round-1 kernels in every direction
     d = F._desc(128, 125, 156, 1, 215, 1, 3, 1)
-    assert _describe(d, 0).startswith("conv_fwd_x3_kernel") and _describe(d, 2).startswith("conv_wgrad_x3_kernel")
+    assert _describe(d, 0).startswith("conv_s1d_fwd_kernel") and _describe(d, 2).startswith("conv_s1d_wgrad_kernel")
+    d = F._desc(128, 100, 100, 1, 430, 1, 3, 1)
+    assert _describe(d, 0).startswith("conv_fwd_x3_kernel") and _describe(d, 2).startswith("conv_s1d_wgrad_kernel")
+    d = F._desc(128, 100, 100, 1, 430, 1, 1, 1)
+    assert _describe(d, 0).startswith("conv_s1d_fwd_kernel") and _describe(d, 2).startswith("conv_s1d_wgrad_kernel")
+    d = F._desc(128, 80, 80, 1, 861, 1, 1, 1)
+    assert _describe(d, 0).startswith("conv_fwd_x3_kernel") and _describe(d, 2).startswith("conv_wgrad_kernel")
 
 
 def test_multi_pack_covers_the_bf16_limb_tilings_only():
