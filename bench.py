@@ -854,8 +854,33 @@ def main():
         # no pre-split (L16) route, so its convolutions run the fp32-input kernels with exact products (three bf16 limbs, nine
         # MFMA products): the number VERDICT r5 item 5 asked to see on the driver line
         f32_mode = retime(F._lib.load().fsc_conv_default_arith(), max(2, min(args.steps, 5)))
-        f32_mode["note"] = ("the same step with fp32-exact convolution products (library default arithmetic; fp32-input kernels, "
-                            "no pre-split route for the 1-d model), eager")
+        f32_mode["note"] = ("the same step at the library default arithmetic (f16x6 on the layers with a pre-split tiling, fp32-exact "
+                            "nine-product kernels on the others), eager: host-bound on boxes with a slow host")
+        if use_graph:
+            # ... and replayed from a HIP graph like `value` (the eager figure above depends on the box's host: 13 - 17 ms)
+            from freesound_classification_amd.ops.training import CapturedTrainingStep
+            mode0 = F.get_conv_arith()
+            F.set_conv_arith(F._lib.load().fsc_conv_default_arith())
+            try:
+                one_step()
+                cap2 = CapturedTrainingStep(model, signal, labels)
+                step_fn[0] = cap2
+                for _ in range(2):
+                    one_step()
+                torch.cuda.synchronize()
+                k2 = max(2, min(args.steps, 10))
+                t1 = time.perf_counter()
+                for _ in range(k2):
+                    one_step()
+                torch.cuda.synchronize()
+                e2 = time.perf_counter() - t1
+                cap2.sync_state()
+                f32_mode["eager"] = {"value": f32_mode["value"], "ms_per_step": f32_mode["ms_per_step"]}
+                f32_mode["value"], f32_mode["ms_per_step"], f32_mode["steps"] = batch * k2 / e2, 1e3 * e2 / k2, k2
+                f32_mode["hip_graph"] = True
+            finally:
+                step_fn[0] = model.training_step
+                F.set_conv_arith(mode0)
     if not torch.isfinite(torch.tensor(final_loss)):
         raise SystemExit("non-finite loss in the benchmark: %r" % final_loss)
     # The HBM-bound stages of BASELINE.md section 3 (front-end, BatchNorm / PReLU / pooling passes, optimizer): a few extra steps
