@@ -2277,16 +2277,18 @@ bool plan_fwd_x3(const fsc_conv_desc& d, int dgrad, int nprod, FwdPlan* out) {
 
 bool plan_fwd_f32(const fsc_conv_desc& d, int dgrad, FwdPlan* out);
 
+bool stem_like(const fsc_conv_desc& d) { return d.c_in <= 4; }
+
 bool plan_fwd(const fsc_conv_desc& d, int dgrad, FwdPlan* out) {
     const int arith = arith_of(d);
-    if (arith == 1) {                                    // bf16, few positions (the late blocks of the 1-d model): conv_s1d.hip
+    if (arith == 1 || arith == 9) {                      // few positions (the late blocks of the 1-d model; cfg 2's 2 x 6-pixel block): conv_s1d.hip
         fsc_conv_desc dd = d;
-        dd.arith = 1;
+        dd.arith = arith;
         fsc::s1d::Plan sp;
-        if (fsc::s1d::plan_fwd(dd, dgrad, &sp)) {
+        if (!stem_like(d) && fsc::s1d::plan_fwd(dd, dgrad, &sp)) {
             FwdPlan p{};
-            p.x3 = 1; p.s1d = 1; p.sp = sp;
-            p.cot = fsc::s1d::kCot; p.co_blocks = sp.co_blocks; p.pt = fsc::s1d::kPt;
+            p.x3 = arith; p.s1d = 1; p.sp = sp;
+            p.cot = sp.cot; p.co_blocks = sp.co_blocks; p.pt = fsc::s1d::kPt;
             p.g.n = d.n; p.g.h = d.h; p.g.w = d.w; p.g.hw = (long)d.h * d.w; p.g.cin = sp.cin; p.g.cout = sp.cout;
             p.g.x_nfull = sp.nfull; p.g.x_tail_oct = sp.tail_oct; p.g.x_steps = sp.steps; p.g.ksplit = 1;
             p.grid_x = sp.px_groups; p.launch_x = sp.px_groups;
@@ -2952,8 +2954,9 @@ int fsc_conv_plan_describe(const fsc_conv_desc* d, int mode, char* buf, size_t b
         FwdPlan p;
         FSC_CHECK_ARG(plan_fwd(*d, mode, &p), "fsc_conv_plan_describe: no tiling for this shape");
         if (p.s1d)
-            snprintf(buf, buf_len, "conv_s1d_fwd_kernel<%d,%d> tile=%dx%d grid=%dx%d steps=%d waves=%d", d->kh, d->kw, fsc::s1d::kCot * 16,
-                     fsc::s1d::kPt * 16, p.sp.px_groups, p.sp.co_blocks, p.sp.steps, fsc::s1d::kWaves);
+            snprintf(buf, buf_len, "conv_s1d_fwd_kernel<%d,%d%s> tile=%dx%d grid=%dx%d steps=%d waves=%d", d->kh, d->kw,
+                     p.sp.nprod == 9 ? ",9" : "", p.sp.cot * 16, fsc::s1d::kPt * 16, p.sp.px_groups, p.sp.co_blocks, p.sp.steps,
+                     fsc::s1d::kWaves);
         else if (stem_shape(*d) && !p.x3)
             snprintf(buf, buf_len, "%s<%d> quads=%d", mode ? "conv_stem_dgrad_kernel" : "conv_stem_fwd_kernel", d->c_in,
                      d->h * ((d->w + 3) / 4));

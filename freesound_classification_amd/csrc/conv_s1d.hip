@@ -50,16 +50,36 @@ struct FwdArgs {
     const u32x4* packed;
     const float* bias;
     float* out;
-    int cin, cout, len, n;
-    long npix;
+    int cin, cout, h, w, n;       // plane = h x w positions (1-d: h = 1)
+    long hw, npix;
     int nfull, tail_oct, steps, accumulate;
 };
 
-// grid: x = groups of kPt * 16 positions of the flattened (image, position) sequence, y = blocks of kCot * 16 output channels
-template <int TAPS>
+// the three exact bf16 limbs of two fp32 values (l16.h split3_pair): x = h + m + l
+__device__ __forceinline__ void split3(float x0, float x1, unsigned& h, unsigned& m, unsigned& l) {
+    const unsigned hp = cvt_pk_bf16(x0, x1);
+    float r0, r1;
+    asm("v_sub_f32_e32 %0, %1, %2" : "=v"(r0) : "v"(x0), "v"(__uint_as_float(hp << 16)));
+    asm("v_sub_f32_e32 %0, %1, %2" : "=v"(r1) : "v"(x1), "v"(__uint_as_float(hp & 0xffff0000u)));
+    const unsigned mp = cvt_pk_bf16(r0, r1);
+    float s0, s1;
+    asm("v_sub_f32_e32 %0, %1, %2" : "=v"(s0) : "v"(r0), "v"(__uint_as_float(mp << 16)));
+    asm("v_sub_f32_e32 %0, %1, %2" : "=v"(s1) : "v"(r1), "v"(__uint_as_float(mp & 0xffff0000u)));
+    h = hp;
+    m = mp;
+    l = cvt_pk_bf16(s0, s1);
+}
+
+// grid: x = groups of kPt * 16 positions of the flattened (image, row, column) sequence, y = blocks of COT * 16 output channels.
+// NP = 1: operands rounded once to bf16 (arith 1); NP = 9: three exact bf16 limbs per operand, all nine limb products summed in a
+// step accumulator (smallest terms first) that reaches the running sum with ONE fp32 addition (arith 9; conv_l3.hip FSC_L3_TMPACC:
+// the product of the two fp32 operands is exact, one rounding per 32-channel tap).  The A fragments are those of
+// fsc_conv_pack_weights (conv.hip pack_x3_items: [block][step][tile][limb][lane]).
+template <int KH, int KW, int NP, int COT>
 __global__ __launch_bounds__(kWaves * 64) void s1d_fwd_kernel(FwdArgs a) {
-    constexpr int PAD = TAPS / 2;
-    constexpr int NT = kCot * kPt;
+    constexpr int TAPS = KH * KW, PH = KH / 2, PW = KW / 2;
+    constexpr int NL = NP == 1 ? 1 : 3;
+    constexpr int NT = COT * kPt;
     __shared__ f32x4 red[kWaves][NT][64];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -67,30 +87,32 @@ __global__ __launch_bounds__(kWaves * 64) void s1d_fwd_kernel(FwdArgs a) {
     const long p0 = (long)blockIdx.x * (kPt * 16);
     const int cb = blockIdx.y;
 
-    long base[kPt];               // element offset of (image, channel 0, position) of this lane's position in tile j
-    int pos[kPt];
+    long base[kPt];               // element offset of (image, channel 0, row, column) of this lane's position in tile j
+    int py[kPt], px[kPt];
     bool live[kPt];
 #pragma unroll
     for (int j = 0; j < kPt; ++j) {
         const long p = p0 + j * 16 + lm;
         live[j] = p < a.npix;
         const long pc = live[j] ? p : 0;
-        const int img = (int)(pc / a.len);
-        pos[j] = (int)(pc - (long)img * a.len);
-        base[j] = (long)img * a.cin * a.len + pos[j];
+        const int img = (int)(pc / a.hw);
+        const int rem = (int)(pc - (long)img * a.hw);
+        py[j] = KH == 1 ? 0 : rem / a.w;
+        px[j] = rem - py[j] * a.w;
+        base[j] = (long)img * a.cin * a.hw + rem;
     }
-    f32x4 acc[kCot][kPt];
+    f32x4 acc[COT][kPt];
 #pragma unroll
-    for (int i = 0; i < kCot; ++i)
+    for (int i = 0; i < COT; ++i)
 #pragma unroll
         for (int j = 0; j < kPt; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    const u32x4* const a_base = a.packed + (long)cb * a.steps * (kCot * 64) + lane;
+    const u32x4* const a_base = a.packed + (long)cb * a.steps * (COT * NL * 64) + lane;
     const float* const zero = g_zero_s1d;
 
     // operands of one K step: A fragments of the block's tiles, raw B values of this lane's two positions
     struct Ops {
-        u32x4 A[kCot];
+        u32x4 A[COT][NL];
         float v[kPt][8];
     };
     auto load = [&](int S, Ops& o) {
@@ -113,28 +135,56 @@ __global__ __launch_bounds__(kWaves * 64) void s1d_fwd_kernel(FwdArgs a) {
             tap = kvalid ? gi / a.tail_oct : 0;
             ch0 = c * 32 + (kvalid ? gi - tap * a.tail_oct : 0) * 8;
         }
+        const int ty = KW == 1 ? 0 : tap / KW, tx = tap - ty * KW;
+        const int dy = ty - PH, dx = tx - PW;
 #pragma unroll
-        for (int i = 0; i < kCot; ++i) o.A[i] = a_base[((long)S * kCot + i) * 64];
+        for (int i = 0; i < COT; ++i)
+#pragma unroll
+            for (int l = 0; l < NL; ++l) o.A[i][l] = a_base[(((long)S * COT + i) * NL + l) * 64];
 #pragma unroll
         for (int j = 0; j < kPt; ++j) {
-            const int ls = pos[j] + tap - PAD;
-            const bool ok = live[j] && kvalid && ls >= 0 && ls < a.len;
-            const float* src = a.in + base[j] + (long)ch0 * a.len + (tap - PAD);
+            const int ys = py[j] + dy, xs = px[j] + dx;
+            const bool ok = live[j] && kvalid && ys >= 0 && ys < a.h && xs >= 0 && xs < a.w;
+            const float* src = a.in + base[j] + (long)ch0 * a.hw + dy * a.w + dx;
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                const float* q = (ok && ch0 + e < a.cin) ? src + (long)e * a.len : zero;
+                const float* q = (ok && ch0 + e < a.cin) ? src + (long)e * a.hw : zero;
                 o.v[j][e] = *q;
             }
         }
     };
     auto compute = [&](const Ops& o) {
-        u32x4 B[kPt];
+        if constexpr (NP == 1) {
+            u32x4 B[kPt];
 #pragma unroll
-        for (int j = 0; j < kPt; ++j) B[j] = pack8(o.v[j]);
+            for (int j = 0; j < kPt; ++j) B[j] = pack8(o.v[j]);
 #pragma unroll
-        for (int i = 0; i < kCot; ++i)
+            for (int i = 0; i < COT; ++i)
 #pragma unroll
-            for (int j = 0; j < kPt; ++j) acc[i][j] = mfma_bf(o.A[i], B[j], acc[i][j]);
+                for (int j = 0; j < kPt; ++j) acc[i][j] = mfma_bf(o.A[i][0], B[j], acc[i][j]);
+        } else {
+            u32x4 B[kPt][3];
+#pragma unroll
+            for (int j = 0; j < kPt; ++j) {
+                unsigned h[4], m[4], l[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) split3(o.v[j][2 * q], o.v[j][2 * q + 1], h[q], m[q], l[q]);
+                B[j][0] = (u32x4){h[0], h[1], h[2], h[3]};
+                B[j][1] = (u32x4){m[0], m[1], m[2], m[3]};
+                B[j][2] = (u32x4){l[0], l[1], l[2], l[3]};
+            }
+            // (A limb, B limb) smallest terms first: l l, m l, l m, h l, m m, l h, h m, m h, h h
+            constexpr int la[9] = {2, 1, 2, 0, 1, 2, 0, 1, 0}, lb[9] = {2, 2, 1, 2, 1, 0, 1, 0, 0};
+#pragma unroll
+            for (int i = 0; i < COT; ++i)
+#pragma unroll
+                for (int j = 0; j < kPt; ++j) {
+                    f32x4 t = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int q = 0; q < 9; ++q) t = mfma_bf(o.A[i][la[q]], B[j][lb[q]], t);
+                    acc[i][j] += t;
+                }
+        }
     };
 
     // this wave's steps: wid, wid + 8, ...; the loads of the next one are issued before the MFMAs of the current one.  (Two steps
@@ -153,24 +203,24 @@ __global__ __launch_bounds__(kWaves * 64) void s1d_fwd_kernel(FwdArgs a) {
         compute(cur);
     }
 #pragma unroll
-    for (int i = 0; i < kCot; ++i)
+    for (int i = 0; i < COT; ++i)
 #pragma unroll
         for (int j = 0; j < kPt; ++j) red[wid][i * kPt + j][lane] = acc[i][j];
     __syncthreads();
-    if (wid < NT) {
-        const int t = wid, i = t / kPt, j = t - i * kPt;
+    for (int t = wid; t < NT; t += kWaves) {
+        const int i = t / kPt, j = t - i * kPt;
         f32x4 s = red[0][t][lane];
 #pragma unroll
         for (int w = 1; w < kWaves; ++w) s += red[w][t][lane];
         const long p = p0 + j * 16 + lm;
         if (p < a.npix) {
-            const int img = (int)(p / a.len);
-            const int l = (int)(p - (long)img * a.len);
+            const int img = (int)(p / a.hw);
+            const long rem = p - (long)img * a.hw;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int co = (cb * kCot + i) * 16 + kq * 4 + r;
+                const int co = (cb * COT + i) * 16 + kq * 4 + r;
                 if (co < a.cout) {
-                    const long idx = ((long)img * a.cout + co) * a.len + l;
+                    const long idx = ((long)img * a.cout + co) * a.hw + rem;
                     float v = s[r];
                     if (a.bias != nullptr) v += a.bias[co];
                     if (a.accumulate) v += a.out[idx];
@@ -477,6 +527,13 @@ int max_px(int taps) {
     }();
     return v >= 0 ? v : (taps == 1 ? 65536 : 32768);
 }
+int max_px_small() {
+    static const int v = [] {
+        const char* e = getenv("FSC_S1D_SMALLPX");         // 2-d planes / nine products: positions up to which these kernels take a layer
+        return e ? atoi(e) : 4096;
+    }();
+    return v;
+}
 int max_px_wgrad_seg() {
     static const int v = [] {
         const char* e = getenv("FSC_S1D_WSEGMAXPX");
@@ -498,18 +555,32 @@ namespace fsc {
 namespace s1d {
 
 bool plan_fwd(const fsc_conv_desc& d, int dgrad, Plan* out) {
-    if (d.arith != 1 || d.h != 1 || d.kh != 1 || !(d.kw == 1 || d.kw == 3)) return false;
+    const bool k11 = d.kh == 1 && d.kw == 1, k13 = d.kh == 1 && d.kw == 3, k33 = d.kh == 3 && d.kw == 3;
+    if (!(d.arith == 1 || d.arith == 9) || !(k11 || k13 || k33)) return false;
+    if (k13 && d.h != 1) return false;
+    // Shipped: the bf16 arithmetic on 1-d rows (cfg 3).  The kernel itself is general -- 2-d planes, 3 x 3 taps, nine exact limb
+    // products (arith 9) -- and was measured on cfg 2's last block (759 channels on 2 x 6 pixels, batch 128, bf16x9): 1 x 1 layers
+    // 70 -> 42 us, 3 x 3 layers 288 -> 269 us (a 32-channel x 32-position workgroup re-reads 1.3 MB of weight fragments: 0.7 GB of
+    // L2 traffic per launch): 0.15 ms of a 46 ms step.  Not worth a second route through the fp32-exact arithmetics;
+    // FSC_S1D_GENERAL=1 enables it (development).
+    static const bool general = [] { const char* e = getenv("FSC_S1D_GENERAL"); return e && e[0] == '1'; }();
+    if (!general && (d.arith != 1 || d.h != 1)) return false;
     Plan p{};
-    p.n = d.n; p.len = d.w; p.taps = d.kw;
+    p.n = d.n; p.h = d.h; p.w = d.w; p.kh = d.kh; p.kw = d.kw; p.taps = d.kh * d.kw;
+    p.nprod = d.arith == 9 ? 9 : 1;
+    p.cot = p.nprod == 9 ? 2 : kCot;            // (nine products: three limb fragments per tile -- 32 channels per workgroup)
     p.cin = dgrad ? d.c_out : d.c_in;
     p.cout = dgrad ? d.c_in : d.c_out;
-    p.npix = (long)d.n * d.w;
-    if (p.npix > max_px(p.taps) || p.cin < 32 || p.cout < 48) return false;
+    p.npix = (long)d.n * d.h * d.w;
+    // ranges: the bf16 kernels on 1-d rows as measured (max_px); 2-d planes and the nine-product arithmetic take the layers the
+    // persistent kernels cannot fill (cfg 2's last block: 759 channels on 2 x 6 pixels, 1536 positions at batch 128)
+    const long cap = (p.nprod == 1 && d.h == 1) ? max_px(p.taps) : max_px_small();
+    if (p.npix > cap || p.cin < 32 || p.cout < 48) return false;
     const int rem = p.cin % 32;
     p.nfull = p.cin / 32 + (rem > 24 ? 1 : 0);
     p.tail_oct = (rem > 0 && rem <= 24) ? ceil_div(rem, 8) : 0;
     p.steps = p.nfull * p.taps + ceil_div(p.taps * p.tail_oct, 4);
-    p.co_blocks = ceil_div(ceil_div(p.cout, 16), kCot);
+    p.co_blocks = ceil_div(ceil_div(p.cout, 16), p.cot);
     p.px_groups = ceil_div(p.npix, kPt * 16);
     *out = p;
     return true;
@@ -517,11 +588,18 @@ bool plan_fwd(const fsc_conv_desc& d, int dgrad, Plan* out) {
 
 int launch_fwd(const Plan& p, const float* in, const unsigned short* packed, const float* bias, float* out, int accumulate,
                hipStream_t st) {
-    FwdArgs a{in, reinterpret_cast<const u32x4*>(packed), bias, out, p.cin, p.cout, p.len, p.n, p.npix, p.nfull, p.tail_oct, p.steps,
-              accumulate};
-    const dim3 grid((unsigned)p.px_groups, (unsigned)p.co_blocks);
-    if (p.taps == 3) hipLaunchKernelGGL(s1d_fwd_kernel<3>, grid, dim3(kWaves * 64), 0, st, a);
-    else hipLaunchKernelGGL(s1d_fwd_kernel<1>, grid, dim3(kWaves * 64), 0, st, a);
+    FwdArgs a{in, reinterpret_cast<const u32x4*>(packed), bias, out, p.cin, p.cout, p.h, p.w, p.n, (long)p.h * p.w, p.npix, p.nfull,
+              p.tail_oct, p.steps, accumulate};
+    const dim3 grid((unsigned)p.px_groups, (unsigned)p.co_blocks), block(kWaves * 64);
+#define FSC_S1D_LAUNCH(KH_, KW_)                                                                              \
+    do {                                                                                                      \
+        if (p.nprod == 9) hipLaunchKernelGGL((s1d_fwd_kernel<KH_, KW_, 9, 2>), grid, block, 0, st, a);        \
+        else hipLaunchKernelGGL((s1d_fwd_kernel<KH_, KW_, 1, kCot>), grid, block, 0, st, a);                  \
+    } while (0)
+    if (p.kh == 3) FSC_S1D_LAUNCH(3, 3);
+    else if (p.kw == 3) FSC_S1D_LAUNCH(1, 3);
+    else FSC_S1D_LAUNCH(1, 1);
+#undef FSC_S1D_LAUNCH
     FSC_LAUNCH_CHECK("fsc_conv_fwd(s1d)");
     return 0;
 }

@@ -7,7 +7,8 @@ namespace fsc {
 namespace s1d {
 
 struct Plan {
-    int n, cin, cout, len, taps;       // cin / cout as the KERNEL sees them (dgrad: swapped)
+    int n, cin, cout, h, w, kh, kw, taps;   // cin / cout as the KERNEL sees them (dgrad: swapped); 1-d rows: h = 1
+    int nprod, cot;                    // 1 (bf16 operands) / 9 (three exact bf16 limbs, nine products); channel tiles per workgroup
     int nfull, tail_oct, steps;        // K steps of 32 channels x one tap (conv.hip pack_x3_items: the A-fragment order)
     int co_blocks;                     // blocks of kCot output-channel tiles
     long npix;                         // n * len
