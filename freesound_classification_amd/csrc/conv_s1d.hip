@@ -144,7 +144,7 @@ __global__ __launch_bounds__(kWaves * 64) void s1d_fwd_kernel(FwdArgs a) {
 #pragma unroll
         for (int j = 0; j < kPt; ++j) {
             const int ys = py[j] + dy, xs = px[j] + dx;
-            const bool ok = live[j] && kvalid && ys >= 0 && ys < a.h && xs >= 0 && xs < a.w;
+            const bool ok = live[j] && kvalid && ys >= 0 && ys < a.h && xs >= 0 && xs < (KH == 1 && KW == 1 ? a.hw : a.w);   // 1 x 1: the plane is one row
             const float* src = a.in + base[j] + (long)ch0 * a.hw + dy * a.w + dx;
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
