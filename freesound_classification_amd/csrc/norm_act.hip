@@ -69,7 +69,9 @@ struct FinalizeArgs {
 };
 
 // (s1, s2): the channel's sums of (x - pivot), (x - pivot)^2 over `count` elements (unused in phase 2)
-__device__ __forceinline__ void finalize_channel(const FinalizeArgs& a, int ch, double s1, double s2, double pivot) {
+// `store` false: only the returned scale / shift (every thread of a one-workgroup unit evaluates them, thread 0 stores)
+__device__ __forceinline__ void finalize_channel(const FinalizeArgs& a, int ch, double s1, double s2, double pivot,
+                                                 bool store = true, float* sc_out = nullptr, float* sh_out = nullptr) {
     double count = a.count;
     if (a.phase == 2) {
         s1 = a.sync[ch * 4];
@@ -88,6 +90,11 @@ __device__ __forceinline__ void finalize_channel(const FinalizeArgs& a, int ch, 
     double var = s2 / count - m1 * m1;
     if (var < 0.0) var = 0.0;
     const double invstd = 1.0 / sqrt(var + (double)a.eps);
+    const float g = a.gamma ? a.gamma[ch] : 1.f, b = a.beta ? a.beta[ch] : 0.f;
+    const float sc = g * (float)invstd;
+    const float sh = b - (float)mean * sc;
+    if (sc_out) { *sc_out = sc; *sh_out = sh; }
+    if (!store) return;
     if (a.running_mean) {
         const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
         a.running_mean[ch] = (float)((1.0 - a.momentum) * a.running_mean[ch] + a.momentum * mean);
@@ -95,10 +102,8 @@ __device__ __forceinline__ void finalize_channel(const FinalizeArgs& a, int ch, 
     }
     a.save_mean[ch] = (float)mean;
     a.save_invstd[ch] = (float)invstd;
-    const float g = a.gamma ? a.gamma[ch] : 1.f, b = a.beta ? a.beta[ch] : 0.f;
-    const float sc = g * (float)invstd;
     a.scale[ch] = sc;
-    a.shift[ch] = b - (float)mean * sc;
+    a.shift[ch] = sh;
 }
 
 // Small planes in the two reduce passes: a lane owns ONE quad of a plane, 256 / 2^l4 planes side by side, several such groups in
@@ -124,6 +129,13 @@ __device__ __forceinline__ float4 load_quad(const float* plane, QuadPos q, float
     if (q.count > 1) r.y = plane[q.base + 1];
     if (q.count > 2) r.z = plane[q.base + 2];
     return r;
+}
+
+__device__ __forceinline__ void store_quad(float* plane, QuadPos q, const float4& v) {
+    if (q.count == 4) { *reinterpret_cast<float4*>(plane + q.base) = v; return; }
+    if (q.count > 0) plane[q.base] = v.x;
+    if (q.count > 1) plane[q.base + 1] = v.y;
+    if (q.count > 2) plane[q.base + 2] = v.z;
 }
 
 // Larger planes: one plane at a time per workgroup, 16-byte loads behind an alignment peel.
@@ -1073,6 +1085,210 @@ __global__ __launch_bounds__(kThreads) void bwd_partial_kernel(BwdArgs a, int ns
     if (fin.want_bound) fin.coef[2 * a.c + ch] = fabsf(g * invstd) * (fdz + fabsf(c1) + fxh * fabsf(c2));
 }
 
+// ---------------------------------------------------------------- units whose channel is ONE workgroup
+// The 1-d model's late blocks (195 ... 476 channels on rows of 53 ... 3 frames at batch 128: tensors of <= 1.3 MB) pay per LAUNCH, not
+// per byte: a reduce pass takes 7 - 12 us, its apply pass 4 - 6, each a chain of dependent round trips -- parameters, two rounds of
+// loads, six block reductions of two barriers each, one thread's finalisation, the stores.  Running the apply pass inside the
+// reduce pass's launch as a second loop over memory bought nothing (measured: the apply phase cost what its launch had cost).
+// These kernels hold the channel in registers instead: a thread owns at most TRIPS quads (all loads in flight at once), every
+// reduction of the unit goes through ONE LDS exchange, every thread finalises (fp64, redundantly: no hand-over), and the apply
+// pass is arithmetic on registers plus the stores.  Same additions in the same order as stats_partial_kernel / bwd_partial_kernel
+// with one split and the same element arithmetic as fwd_wave_kernel / bwd_apply_wave_kernel / bwd_apply_unpool_kernel: bit-identical
+// results (tests/test_bn_fused_gpu.py).
+struct UnitGeom {
+    int l4, g4, tn4, ti4;
+    __device__ __forceinline__ UnitGeom(long hw) {
+        const int q4 = small_plane_lanes(hw);
+        l4 = 0;
+        while ((1 << l4) < q4) ++l4;
+        g4 = kThreads >> l4;
+        tn4 = threadIdx.x >> l4;
+        ti4 = threadIdx.x & ((1 << l4) - 1);
+    }
+};
+inline int unit_trips(int n, long hw) {
+    const int q4 = small_plane_lanes(hw);
+    int l4 = 0;
+    while ((1 << l4) < q4) ++l4;
+    const int g4 = kThreads >> l4;
+    return (n + g4 - 1) / g4;
+}
+
+struct FwdApply { const float* res; const float* alpha; float* y; };
+
+template <int TRIPS>
+__global__ __launch_bounds__(kThreads) void unit_fwd_kernel(const float* __restrict__ x, int n, int c, long hw, FinalizeArgs fa,
+                                                             FwdApply ap) {
+    __shared__ double sd[2][kThreads / 64];
+    __shared__ float sm[2][kThreads / 64];
+    const int ch = blockIdx.x;
+    const UnitGeom u(hw);
+    const float pivot = x[(long)ch * hw];
+    float4 v[TRIPS];
+    QuadPos q[TRIPS];
+    long off[TRIPS];
+#pragma unroll
+    for (int t = 0; t < TRIPS; ++t) {
+        const int b = u.tn4 + t * u.g4;
+        off[t] = ((long)(b < n ? b : 0) * c + ch) * hw;
+        q[t] = quad_pos(off[t], (int)hw, u.ti4);
+        if (b >= n) q[t].count = 0;
+        v[t] = load_quad(x + off[t], q[t], pivot);      // (missing elements read as the pivot: they add nothing to the shifted sums
+    }                                                   //  and lie inside [min, max])
+    float s1 = 0.f, s2 = 0.f, mn = pivot, mx = pivot;
+#pragma unroll
+    for (int t = 0; t < TRIPS; ++t) {
+        const float a0 = v[t].x - pivot, a1 = v[t].y - pivot, a2 = v[t].z - pivot, a3 = v[t].w - pivot;
+        s1 += (a0 + a1) + (a2 + a3);
+        s2 += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
+        mn = fminf(fminf(mn, fminf(v[t].x, v[t].y)), fminf(v[t].z, v[t].w));
+        mx = fmaxf(fmaxf(mx, fmaxf(v[t].x, v[t].y)), fmaxf(v[t].z, v[t].w));
+    }
+    const double w1 = fsc::wave_sum((double)s1), w2 = fsc::wave_sum((double)s2);
+    mx = fsc::wave_max(mx);
+    mn = -fsc::wave_max(-mn);
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    if (lane == 0) { sd[0][wid] = w1; sd[1][wid] = w2; sm[0][wid] = mn; sm[1][wid] = mx; }
+    __syncthreads();
+    double t1 = sd[0][0], t2 = sd[1][0];
+#pragma unroll
+    for (int i = 1; i < kThreads / 64; ++i) { t1 += sd[0][i]; t2 += sd[1][i]; }
+    if (threadIdx.x == 0 && fa.x_minmax) {
+        mn = sm[0][0]; mx = sm[1][0];
+        for (int i = 1; i < kThreads / 64; ++i) { mn = fminf(mn, sm[0][i]); mx = fmaxf(mx, sm[1][i]); }
+        fa.x_minmax[2 * ch] = mn;
+        fa.x_minmax[2 * ch + 1] = mx;
+    }
+    float sc, sh;
+    finalize_channel(fa, ch, 0.0 + t1, 0.0 + t2, (double)pivot, threadIdx.x == 0, &sc, &sh);
+    const bool has_alpha = ap.alpha != nullptr;
+    const float al = has_alpha ? ap.alpha[ch] : 0.f;
+#pragma unroll
+    for (int t = 0; t < TRIPS; ++t) {
+        if (q[t].count == 0) continue;
+        float4 z = make_float4(fmaf(v[t].x, sc, sh), fmaf(v[t].y, sc, sh), fmaf(v[t].z, sc, sh), fmaf(v[t].w, sc, sh));
+        if (ap.res) {
+            const float4 r = load_quad(ap.res + off[t], q[t], 0.f);
+            z.x += r.x; z.y += r.y; z.z += r.z; z.w += r.w;
+        }
+        z.x = act(z.x, al, has_alpha); z.y = act(z.y, al, has_alpha);
+        z.z = act(z.z, al, has_alpha); z.w = act(z.w, al, has_alpha);
+        store_quad(ap.y + off[t], q[t], z);
+    }
+}
+
+// dx / dresidual as bwd_apply_wave_kernel writes them, or -- pool_idx given -- the gradient scattered through a (1, 2) max-pool
+// as bwd_apply_unpool_kernel does for single-row planes (dc: rows of w = 2 * hw or 2 * hw + 1 values)
+struct BwdApply { float* dx; float* dres; const uint8_t* pool_idx; float* dc; int w; };
+
+template <int TRIPS>
+__global__ __launch_bounds__(kThreads) void unit_bwd_kernel(BwdArgs a, BwdFinish fin, BwdApply ap) {
+    __shared__ double sd[4][kThreads / 64];
+    __shared__ float sm[2][kThreads / 64];
+    const int ch = blockIdx.x;
+    const UnitGeom u(a.hw);
+    const float mean = a.mean[ch], invstd = a.invstd[ch];
+    const float g = a.gamma ? a.gamma[ch] : 1.f, b = a.beta ? a.beta[ch] : 0.f;
+    const bool has_alpha = a.alpha != nullptr;
+    const float al = has_alpha ? a.alpha[ch] : 1.f;
+    float4 xv[TRIPS], rv[TRIPS], uv[TRIPS];
+    QuadPos q[TRIPS];
+    long off[TRIPS];
+    unsigned pi[TRIPS];
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int t = 0; t < TRIPS; ++t) {
+        const int bb = u.tn4 + t * u.g4;
+        const bool ok = bb < a.n;
+        const long plane = (long)(ok ? bb : 0) * a.c + ch;
+        off[t] = plane * a.hw;
+        q[t] = quad_pos(off[t], (int)a.hw, u.ti4);
+        if (!ok) q[t].count = 0;
+        xv[t] = load_quad(a.x + off[t], q[t], mean);
+        rv[t] = a.res ? load_quad(a.res + off[t], q[t], 0.f) : zero4;
+        uv[t] = a.dy ? load_quad(a.dy + off[t], q[t], 0.f) : zero4;
+        if (q[t].count > 0 && a.gmax_dy) {
+            const int d = a.gmax_idx[plane] - q[t].base;
+            const float gval = a.gmax_dy[plane];
+            if (d >= 0 && d < q[t].count) { if (d == 0) uv[t].x += gval; else if (d == 1) uv[t].y += gval; else if (d == 2) uv[t].z += gval; else uv[t].w += gval; }
+        }
+        pi[t] = 0u;
+        if (ap.pool_idx)
+            for (int e = 0; e < q[t].count; ++e) pi[t] |= (unsigned)ap.pool_idx[off[t] + q[t].base + e] << (8 * e);
+    }
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f, mdz = 0.f, mxh = 0.f;
+    // (xv / uv become xhat / dz in place: what the apply pass needs)
+#pragma unroll
+    for (int t = 0; t < TRIPS; ++t) {
+        float xs[4] = {xv[t].x, xv[t].y, xv[t].z, xv[t].w}, us[4] = {uv[t].x, uv[t].y, uv[t].z, uv[t].w};
+        const float rs[4] = {rv[t].x, rv[t].y, rv[t].z, rv[t].w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float xh = (xs[e] - mean) * invstd;
+            const float z = fmaf(xh, g, b) + rs[e];
+            const bool neg = has_alpha && !(z > 0.f);
+            const float dz = neg ? al * us[e] : us[e];
+            s0 += dz;
+            s1 += dz * xh;
+            s2 += us[e] * (neg ? z : 0.f);
+            s3 += xh;
+            mdz = fmaxf(mdz, fabsf(dz));
+            mxh = fmaxf(mxh, fabsf(xh));
+            xs[e] = xh;
+            us[e] = dz;
+        }
+        xv[t] = make_float4(xs[0], xs[1], xs[2], xs[3]);
+        uv[t] = make_float4(us[0], us[1], us[2], us[3]);
+    }
+    const double w0 = fsc::wave_sum((double)s0), w1 = fsc::wave_sum((double)s1), w2 = fsc::wave_sum((double)s2),
+                 w3 = fsc::wave_sum((double)s3);
+    mdz = fsc::wave_max(mdz);
+    mxh = fsc::wave_max(mxh);
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    if (lane == 0) { sd[0][wid] = w0; sd[1][wid] = w1; sd[2][wid] = w2; sd[3][wid] = w3; sm[0][wid] = mdz; sm[1][wid] = mxh; }
+    __syncthreads();
+    double t0 = sd[0][0], t1 = sd[1][0], t2 = sd[2][0], t3 = sd[3][0];
+    mdz = sm[0][0]; mxh = sm[1][0];
+#pragma unroll
+    for (int i = 1; i < kThreads / 64; ++i) {
+        t0 += sd[0][i]; t1 += sd[1][i]; t2 += sd[2][i]; t3 += sd[3][i];
+        mdz = fmaxf(mdz, sm[0][i]); mxh = fmaxf(mxh, sm[1][i]);
+    }
+    // (the fold of one split, as bwd_partial_kernel's `alone` path)
+    double f0 = 0.0, f1 = 0.0, f2 = 0.0, f3 = 0.0;
+    f0 += t0; f1 += t1; f2 += t2; f3 += t3;
+    const float c1 = (float)(f0 / fin.count), c2 = (float)(f1 / fin.count);
+    if (threadIdx.x == 0) {
+        if (fin.dbeta) fin.dbeta[ch] = (float)f0;
+        if (fin.dgamma) fin.dgamma[ch] = (float)f1;
+        if (fin.dalpha) fin.dalpha[ch] = (float)f2;
+        fin.coef[ch * 2] = c1;
+        fin.coef[ch * 2 + 1] = c2;
+        if (fin.dx_chan_sum) fin.dx_chan_sum[ch] = chan_sum_of_dx(g * invstd, f0, f3, fin.count, c1, c2);
+    }
+    const float k = g * invstd;
+#pragma unroll
+    for (int t = 0; t < TRIPS; ++t) {
+        if (q[t].count == 0) continue;
+        const float xh[4] = {xv[t].x, xv[t].y, xv[t].z, xv[t].w}, dz[4] = {uv[t].x, uv[t].y, uv[t].z, uv[t].w};
+        float dv[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) dv[e] = k * (dz[e] - c1 - xh[e] * c2);
+        if (ap.dc) {
+            typedef float f32x2 __attribute__((ext_vector_type(2)));
+            float* r0 = ap.dc + (off[t] / a.hw) * ap.w;
+            for (int e = 0; e < q[t].count; ++e) {
+                const int pos = (int)((pi[t] >> (8 * e)) & 0xFFu);
+                *reinterpret_cast<f32x2*>(r0 + 2 * (q[t].base + e)) = (f32x2){pos == 0 ? dv[e] : 0.f, pos == 1 ? dv[e] : 0.f};
+            }
+            if ((ap.w & 1) && q[t].base + q[t].count == (int)a.hw) r0[ap.w - 1] = 0.f;      // the column the pool never read
+        } else {
+            store_quad(ap.dx + off[t], q[t], make_float4(dv[0], dv[1], dv[2], dv[3]));
+            if (ap.dres) store_quad(ap.dres + off[t], q[t], uv[t]);
+        }
+    }
+}
+
 // HW == 1 version: thread per channel
 __global__ void bwd_rows_kernel(BwdArgs a, double* __restrict__ part) {
     const int ch = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1624,6 +1840,37 @@ int fsc_bn_train_stats(const float* x, int n, int c, long hw, const float* gamma
     return 0;
 }
 
+// a unit whose channel is one workgroup that holds it in registers (unit_fwd_kernel / unit_bwd_kernel)
+static bool fused_unit(int n, int c, long hw) {
+    static const bool off = [] { const char* e = getenv("FSC_BN_FUSED"); return e && e[0] == '0'; }();
+    return !off && hw > 1 && small_planes(hw) && pick_split(n, c, hw) == 1 && unit_trips(n, hw) <= 8;
+}
+#define FSC_UNIT_LAUNCH(KERNEL_, TRIPS_, ...)                                                                        \
+    do {                                                                                                             \
+        if ((TRIPS_) <= 1) hipLaunchKernelGGL(KERNEL_<1>, dim3(c), dim3(kThreads), 0, st, __VA_ARGS__);              \
+        else if ((TRIPS_) <= 2) hipLaunchKernelGGL(KERNEL_<2>, dim3(c), dim3(kThreads), 0, st, __VA_ARGS__);         \
+        else if ((TRIPS_) <= 4) hipLaunchKernelGGL(KERNEL_<4>, dim3(c), dim3(kThreads), 0, st, __VA_ARGS__);         \
+        else hipLaunchKernelGGL(KERNEL_<8>, dim3(c), dim3(kThreads), 0, st, __VA_ARGS__);                            \
+    } while (0)
+
+int fsc_bn_train_act_fwd_supported(int n, int c, long hw) { return (n > 0 && c > 0 && fused_unit(n, c, hw)) ? 1 : 0; }
+
+int fsc_bn_train_act_fwd(const float* x, const float* residual, int n, int c, long hw, const float* gamma, const float* beta, float eps,
+                         float momentum, float* running_mean, float* running_var, float* save_mean, float* save_invstd, float* scale,
+                         float* shift, float* x_minmax, const float* alpha, float* y, fsc_stream_t stream) {
+    FSC_CHECK_ARG(x && save_mean && save_invstd && scale && shift && y, "fsc_bn_train_act_fwd: null pointer");
+    FSC_CHECK_ARG(n > 0 && c > 0 && hw > 0, "fsc_bn_train_act_fwd: bad shape (%d, %d, %ld)", n, c, hw);
+    FSC_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr), "fsc_bn_train_act_fwd: running stats must come in pairs");
+    FSC_CHECK_ARG(fused_unit(n, c, hw), "fsc_bn_train_act_fwd: (%d, %d, %ld) is not a one-workgroup-per-channel shape "
+                  "(fsc_bn_train_act_fwd_supported)", n, c, hw);
+    hipStream_t st = fsc::as_stream(stream);
+    FinalizeArgs fa{x, c, hw, (double)n * (double)hw, 1, nullptr, gamma, beta, eps, momentum, running_mean, running_var,
+                    save_mean, save_invstd, scale, shift, nullptr, 0, x_minmax, 0, 0};
+    FSC_UNIT_LAUNCH(unit_fwd_kernel, unit_trips(n, hw), x, n, c, hw, fa, FwdApply{residual, alpha, y});
+    FSC_LAUNCH_CHECK("fsc_bn_train_act_fwd");
+    return 0;
+}
+
 int fsc_bn_eval_prepare(int c, const float* gamma, const float* beta, const float* running_mean,
                         const float* running_var, float eps, float* scale, float* shift, fsc_stream_t stream) {
     FSC_CHECK_ARG(running_mean && running_var && scale && shift && c > 0, "fsc_bn_eval_prepare: bad arguments");
@@ -1786,6 +2033,12 @@ int fsc_bn_act_bwd(const float* dy, const float* gmax_dy, const int* gmax_idx, c
     if (phase == 0 && hw > 1 && zero_tickets) {
         fin = BwdFinish{p.tickets, (double)n * (double)hw, dgamma, dbeta, dalpha, p.coef, dx_chan_sum, dx_amax, dx_l16 ? 1 : 0};
     }
+    if (fin.tickets != nullptr && dx && !dx_l16 && !dx_amax && fused_unit(n, c, hw)) {
+        // a channel that is one workgroup: reduce, finalise and apply from registers in one launch
+        FSC_UNIT_LAUNCH(unit_bwd_kernel, unit_trips(n, hw), a, fin, BwdApply{dx, dresidual, nullptr, nullptr, 0});
+        FSC_LAUNCH_CHECK("fsc_bn_act_bwd(unit)");
+        return 0;
+    }
     if (phase != 2) {
         if (hw == 1) {
             FSC_CHECK_ARG(gmax_dy == nullptr, "fsc_bn_act_bwd: global-max gradient needs hw > 1");
@@ -1864,6 +2117,11 @@ int fsc_bn_act_bwd_unpool(const float* dy, const float* x, const float* save_mea
     BwdFinish fin{};
     if (phase == 0 && zero_tickets) {
         fin = BwdFinish{p.tickets, (double)n * (double)hw, dgamma, dbeta, dalpha, p.coef, dx_chan_sum, dc_amax, dc_l16 ? 1 : 0};
+    }
+    if (fin.tickets != nullptr && dc && !dc_l16 && !dc_amax && h == 1 && ph == 1 && fused_unit(n, c, hw)) {
+        FSC_UNIT_LAUNCH(unit_bwd_kernel, unit_trips(n, hw), a, fin, BwdApply{nullptr, nullptr, pool_idx, dc, w});
+        FSC_LAUNCH_CHECK("fsc_bn_act_bwd_unpool(unit)");
+        return 0;
     }
     if (phase != 2)
         hipLaunchKernelGGL(bwd_partial_kernel, dim3(c, nsplit), dim3(kThreads), 0, st, a, nsplit, p.part, fin);

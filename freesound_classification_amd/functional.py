@@ -1213,7 +1213,10 @@ _lib.ON_ERROR.append(drop_bn_workspaces)
 
 class BNState:
     """What one fused BN(+residual)(+PReLU) unit keeps between forward and backward."""
-    __slots__ = ("mean", "invstd", "scale", "shift", "minmax")
+    __slots__ = ("mean", "invstd", "scale", "shift", "minmax", "pending")
+
+    def __init__(self):
+        self.pending = None         # bn_prepare(lazy=True): the statistics call, not issued yet (see _bn_realize)
 
 
 def _sync_buffer(c, like):
@@ -1241,6 +1244,7 @@ def bn_act_forward_rec(x, st, alpha, residual, want_stats, want_gmax):
     Returns (y, feat or None, feat_idx or None)."""
     n, c = x.shape[0], x.shape[1]
     hw = x.numel() // (n * c)
+    _bn_realize(st)
     y = torch.empty_like(x)
     rec = torch.empty((_lib.load().fsc_bn_records_bytes(n, c, hw) + 7) // 8, device=x.device, dtype=torch.float64)
     with _stage("bn_act_fwd", _nb(x, residual, y)):
@@ -1278,10 +1282,24 @@ def _bn_eval_scale_shift(bn, gamma, beta, scale=None, shift=None):
     return scale, shift
 
 
-def bn_prepare(x, bn, training, sync=None, defer=None, want_minmax=False):
+BN_FUSED = os.environ.get("FSC_BN_FUSED", "1") != "0"
+
+
+def _bn_realize(st):
+    """Issue the statistics call a lazy bn_prepare held back (a consumer other than the plain apply pass needs them)."""
+    pend, st.pending = st.pending, None
+    if pend is not None:
+        x, args = pend
+        with _stage("bn_stats", _nb(x)):
+            call("fsc_bn_train_stats", *args, ptr(_bn_ws(x.shape[1], x)), None, BN_TICKETS, ptr(st.minmax), stream_ptr())
+
+
+def bn_prepare(x, bn, training, sync=None, defer=None, want_minmax=False, lazy=False):
     """Batch statistics (training; also updates the running stats, once) or running statistics
     (eval) -> per-channel scale/shift.  `sync` (a callable that sum-all-reduces a device tensor in place over the
-    data-parallel replicas, see parallel.SyncBN) turns the batch statistics into cross-replica statistics."""
+    data-parallel replicas, see parallel.SyncBN) turns the batch statistics into cross-replica statistics.
+    lazy: the caller hands `st` to bn_act_forward / bn_act_forward_rec next -- where the library runs statistics and apply pass
+    of such a shape in one launch (fsc_bn_train_act_fwd: a channel is one workgroup) the statistics are left to that call."""
     n, c = x.shape[0], x.shape[1]
     hw = x.numel() // (n * c)
     st = BNState()
@@ -1317,6 +1335,12 @@ def bn_prepare(x, bn, training, sync=None, defer=None, want_minmax=False):
                          ptr(st.mean), ptr(st.invstd), ptr(st.scale), ptr(st.shift), ptr(st.minmax), stream_ptr())
                 return st
             pre = (_fold_conv_records(pre[0], x), pre[1] & ~_STATS_CONV_REC)
+        if (lazy and BN_FUSED and pre is None and sync is None and hw > 1
+                and _lib.load().fsc_bn_train_act_fwd_supported(n, c, hw)):
+            st.pending = (x, (ptr(x), n, c, hw, ptr(gamma), ptr(beta), bn.eps, momentum,
+                              ptr(bn.running_mean) if track else None, ptr(bn.running_var) if track else None,
+                              ptr(st.mean), ptr(st.invstd), ptr(st.scale), ptr(st.shift)))
+            return st
         ws, folded = pre if pre is not None else (_bn_ws(c, x), 0)      # (kept alive across both phases)
         args = (ptr(x), n, c, hw, ptr(gamma), ptr(beta), bn.eps, momentum,
                 ptr(bn.running_mean) if track else None, ptr(bn.running_var) if track else None,
@@ -1366,7 +1390,19 @@ def bn_act_forward(x, st, alpha=None, residual=None, with_amax=False, l16=False,
     n, c = x.shape[0], x.shape[1]
     hw = x.numel() // (n * c)
     limbs = _l16_limbs()
-    if l16 and (st.minmax is not None or limbs == 3) and residual is None and hw > 1:
+    to_l16 = l16 and (st.minmax is not None or limbs == 3) and residual is None and hw > 1
+    if st.pending is not None:
+        if not to_l16 and not ((with_amax or l16) and _want_amax()) and st.pending[0] is x:
+            # statistics + apply in one launch (a channel is one workgroup)
+            (_x, a), st.pending = st.pending, None
+            y = torch.empty_like(x)
+            with _stage("bn_act_fwd", 2 * _nb(x) + _nb(residual, y)):
+                call("fsc_bn_train_act_fwd", a[0], ptr(residual), *a[1:], ptr(st.minmax), ptr(alpha), ptr(y), stream_ptr())
+            if l16:
+                return y, None
+            return (y, None) if with_amax else y
+        _bn_realize(st)
+    if to_l16:
         y = torch.empty_like(x) if want_f32 else None
         t = L16(l16_empty(x.shape, x, limbs), _empty((AMAX_FLOATS,), x) if limbs != 3 else None, x.shape, limbs)
         with _stage("bn_act_fwd", _nb(x, y, t)):
@@ -1738,7 +1774,7 @@ def _block_forward(x, mods, training, want_head, ph, keep, sync=None, next_bn=Fa
     def mm(t, wt):           # inference: the BatchNorm in front of a convolution with an L16 tiling also reports the range of its input
         return (not training) and EVAL_L16 and _l16_limbs() != 3 and t.dim() == 4 and _l16_ok_for(t.shape, wt, False)   # (bf16 limbs: no scale, no range)
 
-    st_a = bn_prepare(x, bn_a, training, sync, counters, want_minmax=mm(x, w_a))
+    st_a = bn_prepare(x, bn_a, training, sync, counters, want_minmax=mm(x, w_a), lazy=True)
     # Operands of convolutions that have an L16 tiling are written pre-split by the BN / PReLU kernel that produces them
     # (`*_16`); the fp32 copy stays for the weight gradient (and, for b, the residual).
     a, a_max, a_16 = _bn_fwd_for_conv(x, st_a, None, w_a, need_wgrad=keep)
@@ -1777,7 +1813,7 @@ def _block_forward(x, mods, training, want_head, ph, keep, sync=None, next_bn=Fa
             k.c_shape = tuple(c.shape)
             del c
     if pool_act is None:
-        st_b = bn_prepare(p, bn_b, training, sync, counters, want_minmax=mm(p, w1))
+        st_b = bn_prepare(p, bn_b, training, sync, counters, want_minmax=mm(p, w1), lazy=True)
         b, b_max, b_16 = _bn_fwd_for_conv(p, st_b, prelu_b.weight, w1, keep_f32=True, need_wgrad=keep)      # (the residual reads it)
         if (ph == 2 and not training and not keep and a_16 is not None and b_16 is not None
                 and conv_l16_pool_act_supported(a_16.shape, w_a)):
@@ -1793,7 +1829,7 @@ def _block_forward(x, mods, training, want_head, ph, keep, sync=None, next_bn=Fa
         s1_max = s1_16.amax
     else:
         r1 = _conv_fwd_any(b, b_16, w1, b1, b_max, packs, (res.bn1, training))
-        st1 = bn_prepare(r1, res.bn1, training, sync, counters, want_minmax=mm(r1, w2))
+        st1 = bn_prepare(r1, res.bn1, training, sync, counters, want_minmax=mm(r1, w2), lazy=True)
         s1, s1_max, s1_16 = _bn_fwd_for_conv(r1, st1, res.prelu1.weight, w2, need_wgrad=keep)
         if fold:
             _act_calibrate(res.bn1, w1, s1_16, b1, res.prelu1.weight)
@@ -1803,12 +1839,12 @@ def _block_forward(x, mods, training, want_head, ph, keep, sync=None, next_bn=Fa
         s2_max = s2_16.amax
     else:
         r2 = _conv_fwd_any(s1, s1_16, w2, b2, s1_max, packs, (res.bn2, training))
-        st2 = bn_prepare(r2, res.bn2, training, sync, counters, want_minmax=mm(r2, w3))
+        st2 = bn_prepare(r2, res.bn2, training, sync, counters, want_minmax=mm(r2, w3), lazy=True)
         s2, s2_max, s2_16 = _bn_fwd_for_conv(r2, st2, res.prelu2.weight, w3, need_wgrad=keep)
         if fold:
             _act_calibrate(res.bn2, w2, s2_16, b2, res.prelu2.weight)
     r3 = _conv_fwd_any(s2, s2_16, w3, b3, s2_max, packs, (res.bn3, training))
-    st3 = bn_prepare(r3, res.bn3, training, sync, counters)
+    st3 = bn_prepare(r3, res.bn3, training, sync, counters, lazy=True)
     feat, fidx = (None, None)
     next_stats = next_bn and (training or EVAL_L16)          # (inference: the next block's input BatchNorm wants the range)
     if FUSE_OUT_STATS and h_w_min(r3) * max(r3.shape[2], r3.shape[3]) > 1 and (want_head or next_stats):
@@ -2143,7 +2179,7 @@ class BNActFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, bn, prelu, training, sync, gamma, beta, alpha):
         x = x.contiguous()
-        st = bn_prepare(x, bn, training, sync if training else None)
+        st = bn_prepare(x, bn, training, sync if training else None, lazy=True)
         y = bn_act_forward(x, st, alpha)
         ctx.save_for_backward(x)
         ctx.st, ctx.bn, ctx.prelu, ctx.sync = st, bn, prelu, (sync if training else None)

@@ -301,6 +301,18 @@ int fsc_bn_train_stats(const float* x, int n, int c, long hw, const float* gamma
                        float* running_var, float* save_mean, float* save_invstd,
                        float* scale, float* shift, void* workspace, double* sync, int phase,
                        float* x_minmax, fsc_stream_t stream);
+/* Statistics AND apply pass of one training-mode unit in ONE launch (classifiers.py:78-82, 92-93, 96-97, 100-104: BatchNorm in
+ * training mode, [+ residual], PReLU): where a channel's n x hw values are the work of one workgroup (single replica, planes of
+ * 2 ... ~1000 values, n * hw <= 8192 with >= 128 channels: the 1-d model's blocks from 53 frames down at batch 128 -- tensors of
+ * <= 1.3 MB on which each launch costs more than its bytes) that workgroup finalises and applies: everything fsc_bn_train_stats
+ * (phase 0) writes, then y = act(x * scale + shift [+ residual]) exactly as fsc_bn_act_fwd computes it (bit-identical: the
+ * same instruction sequence).  `_supported` says whether (n, c, hw) is such a shape; the call fails otherwise.  The backward
+ * entry points below make the same decision on their own (their apply pass runs in the reduce pass's launch), nothing to ask for. */
+int fsc_bn_train_act_fwd_supported(int n, int c, long hw);
+int fsc_bn_train_act_fwd(const float* x, const float* residual, int n, int c, long hw, const float* gamma, const float* beta,
+                         float eps, float momentum, float* running_mean, float* running_var, float* save_mean,
+                         float* save_invstd, float* scale, float* shift, float* x_minmax, const float* alpha, float* y,
+                         fsc_stream_t stream);
 /* x_minmax (2*C floats, may be NULL): per channel [min x, max x] of the local batch -- what fsc_bn_act_fwd needs to
  * bound its output before it writes an L16 tensor.
  * phase | FSC_BN_STATS_FOLDED: the reduction over x was done by the kernel that WROTE x (fsc_bn_act_fwd_rec +

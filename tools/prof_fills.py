@@ -1,0 +1,51 @@
+"""development: which Python lines of a cfg-3 training step launch torch's own fill / copy kernels (FillFunctor, copyBuffer).
+   python tools/prof_fills.py [cfg3|cfg2]"""
+import collections, os, sys
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench
+from freesound_classification_amd import functional as F
+from freesound_classification_amd.networks.classifiers import HierarchicalCNNClassificationModel, TwoDimensionalCNNClassificationModel
+from freesound_classification_amd.ops.training import make_step
+
+name = sys.argv[1] if len(sys.argv) > 1 else "cfg3"
+w = bench.WORKLOADS[name]
+if w.get("arith"):
+    F.set_conv_arith(w["arith"])
+dev = torch.device("cuda", 0)
+torch.manual_seed(42)
+cls = HierarchicalCNNClassificationModel if w.get("dims") == 1 else TwoDimensionalCNNClassificationModel
+model = cls(bench.make_experiment(w), device=str(dev))
+model.train(); model.global_step = 0
+model.make_optimizer(max_steps=40)
+signal, labels = bench.synthetic_batch(w, int(os.environ.get("BATCH", w["batch"])), dev, 1234)
+def step():
+    model.global_step += 1
+    make_step(model.scheduler, step=model.global_step)
+    return model.training_step(signal, labels)
+for _ in range(3):
+    step()
+torch.cuda.synchronize()
+from torch.profiler import profile, ProfilerActivity
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
+    step()
+    torch.cuda.synchronize()
+groups = collections.Counter()
+names = collections.Counter()
+for ev in prof.events():
+    if ev.name in ("aten::fill_", "aten::zero_", "aten::copy_", "aten::clone", "aten::zeros", "aten::zeros_like", "aten::add_", "aten::add",
+                   "aten::mul", "aten::sum", "aten::contiguous", "aten::_to_copy"):
+        if ev.cpu_parent is not None and ev.cpu_parent.name.startswith("aten::"):
+            continue
+        stack = [s for s in (ev.stack or []) if "freesound_classification_amd" in s or "bench.py" in s or "autograd" in s]
+        groups[(ev.name, tuple(stack[:3]))] += 1
+        names[ev.name] += 1
+print(names)
+for (n, st), k in groups.most_common(60):
+    print("%4d  %-18s %s" % (k, n, " <- ".join(s.split("/")[-1] for s in st)))
+kern = collections.Counter()
+for ev in prof.events():
+    if ev.device_type is not None and str(ev.device_type).endswith("CUDA"):
+        kern[ev.name[:60]] += 1
+for n, k in kern.most_common(12):
+    print("%4d  %s" % (k, n))
