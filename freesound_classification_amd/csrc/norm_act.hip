@@ -1095,45 +1095,62 @@ __global__ __launch_bounds__(kThreads) void bwd_partial_kernel(BwdArgs a, int ns
 // pass is arithmetic on registers plus the stores.  Same additions in the same order as stats_partial_kernel / bwd_partial_kernel
 // with one split and the same element arithmetic as fwd_wave_kernel / bwd_apply_wave_kernel / bwd_apply_unpool_kernel: bit-identical
 // results (tests/test_bn_fused_gpu.py).
+template <int THREADS>
 struct UnitGeom {
     int l4, g4, tn4, ti4;
     __device__ __forceinline__ UnitGeom(long hw) {
         const int q4 = small_plane_lanes(hw);
         l4 = 0;
         while ((1 << l4) < q4) ++l4;
-        g4 = kThreads >> l4;
+        g4 = THREADS >> l4;
         tn4 = threadIdx.x >> l4;
         ti4 = threadIdx.x & ((1 << l4) - 1);
     }
 };
-inline int unit_trips(int n, long hw) {
+inline int unit_trips(int n, long hw, int threads) {
     const int q4 = small_plane_lanes(hw);
     int l4 = 0;
     while ((1 << l4) < q4) ++l4;
-    const int g4 = kThreads >> l4;
+    const int g4 = threads >> l4;
     return (n + g4 - 1) / g4;
+}
+// workgroup size and quads per thread of a unit: 256 threads while <= 8 quads each hold the channel, else 1024 (the 1-d model's
+// blocks 3 and 4 at batch 128: 125 / 156 channels of 27.5 k / 13.7 k values); 0 threads: not a unit
+struct UnitShape { int threads, trips; };
+inline UnitShape unit_shape(int n, long hw) {
+    if (hw < 2 || !small_planes(hw)) return UnitShape{0, 0};
+    int t = unit_trips(n, hw, 256);
+    if (t <= 8) return UnitShape{256, t};
+    t = unit_trips(n, hw, 1024);
+    if (t <= 8) return UnitShape{1024, t};
+    return UnitShape{0, 0};
 }
 
 struct FwdApply { const float* res; const float* alpha; float* y; };
 
-template <int TRIPS>
-__global__ __launch_bounds__(kThreads) void unit_fwd_kernel(const float* __restrict__ x, int n, int c, long hw, FinalizeArgs fa,
-                                                             FwdApply ap) {
-    __shared__ double sd[2][kThreads / 64];
-    __shared__ float sm[2][kThreads / 64];
+template <int THREADS, int TRIPS>
+__global__ __launch_bounds__(THREADS) void unit_fwd_kernel(const float* __restrict__ x, int n, int c, long hw, FinalizeArgs fa,
+                                                            FwdApply ap) {
+    constexpr int NW = THREADS / 64;
+    __shared__ double sd[2][NW];
+    __shared__ float sm[2][NW];
     const int ch = blockIdx.x;
-    const UnitGeom u(hw);
+    const UnitGeom<THREADS> u(hw);
     const float pivot = x[(long)ch * hw];
     float4 v[TRIPS];
-    QuadPos q[TRIPS];
-    long off[TRIPS];
+    // (positions are recomputed where they are needed again: 4 registers per quad that 1024 threads x 8 quads do not have)
+    auto where = [&](int t, long& off) {
+        const int b = u.tn4 + t * u.g4;
+        off = ((long)(b < n ? b : 0) * c + ch) * hw;
+        QuadPos q = quad_pos(off, (int)hw, u.ti4);
+        if (b >= n) q.count = 0;
+        return q;
+    };
 #pragma unroll
     for (int t = 0; t < TRIPS; ++t) {
-        const int b = u.tn4 + t * u.g4;
-        off[t] = ((long)(b < n ? b : 0) * c + ch) * hw;
-        q[t] = quad_pos(off[t], (int)hw, u.ti4);
-        if (b >= n) q[t].count = 0;
-        v[t] = load_quad(x + off[t], q[t], pivot);      // (missing elements read as the pivot: they add nothing to the shifted sums
+        long off;
+        const QuadPos q = where(t, off);
+        v[t] = load_quad(x + off, q, pivot);            // (missing elements read as the pivot: they add nothing to the shifted sums
     }                                                   //  and lie inside [min, max])
     float s1 = 0.f, s2 = 0.f, mn = pivot, mx = pivot;
 #pragma unroll
@@ -1151,11 +1168,11 @@ __global__ __launch_bounds__(kThreads) void unit_fwd_kernel(const float* __restr
     if (lane == 0) { sd[0][wid] = w1; sd[1][wid] = w2; sm[0][wid] = mn; sm[1][wid] = mx; }
     __syncthreads();
     double t1 = sd[0][0], t2 = sd[1][0];
-#pragma unroll
-    for (int i = 1; i < kThreads / 64; ++i) { t1 += sd[0][i]; t2 += sd[1][i]; }
+#pragma unroll 4
+    for (int i = 1; i < NW; ++i) { t1 += sd[0][i]; t2 += sd[1][i]; }
     if (threadIdx.x == 0 && fa.x_minmax) {
         mn = sm[0][0]; mx = sm[1][0];
-        for (int i = 1; i < kThreads / 64; ++i) { mn = fminf(mn, sm[0][i]); mx = fmaxf(mx, sm[1][i]); }
+        for (int i = 1; i < NW; ++i) { mn = fminf(mn, sm[0][i]); mx = fmaxf(mx, sm[1][i]); }
         fa.x_minmax[2 * ch] = mn;
         fa.x_minmax[2 * ch + 1] = mx;
     }
@@ -1165,15 +1182,17 @@ __global__ __launch_bounds__(kThreads) void unit_fwd_kernel(const float* __restr
     const float al = has_alpha ? ap.alpha[ch] : 0.f;
 #pragma unroll
     for (int t = 0; t < TRIPS; ++t) {
-        if (q[t].count == 0) continue;
+        long off;
+        const QuadPos q = where(t, off);
+        if (q.count == 0) continue;
         float4 z = make_float4(fmaf(v[t].x, sc, sh), fmaf(v[t].y, sc, sh), fmaf(v[t].z, sc, sh), fmaf(v[t].w, sc, sh));
         if (ap.res) {
-            const float4 r = load_quad(ap.res + off[t], q[t], 0.f);
+            const float4 r = load_quad(ap.res + off, q, 0.f);
             z.x += r.x; z.y += r.y; z.z += r.z; z.w += r.w;
         }
         z.x = act(z.x, al, has_alpha); z.y = act(z.y, al, has_alpha);
         z.z = act(z.z, al, has_alpha); z.w = act(z.w, al, has_alpha);
-        store_quad(ap.y + off[t], q[t], z);
+        store_quad(ap.y + off, q, z);
     }
 }
 
@@ -1181,47 +1200,53 @@ __global__ __launch_bounds__(kThreads) void unit_fwd_kernel(const float* __restr
 // as bwd_apply_unpool_kernel does for single-row planes (dc: rows of w = 2 * hw or 2 * hw + 1 values)
 struct BwdApply { float* dx; float* dres; const uint8_t* pool_idx; float* dc; int w; };
 
-template <int TRIPS>
-__global__ __launch_bounds__(kThreads) void unit_bwd_kernel(BwdArgs a, BwdFinish fin, BwdApply ap) {
-    __shared__ double sd[4][kThreads / 64];
-    __shared__ float sm[2][kThreads / 64];
+// RES false: the unit has no residual (four of a block's five: 8 instead of 12 registers per quad)
+template <int THREADS, int TRIPS, bool RES>
+__global__ __launch_bounds__(THREADS) void unit_bwd_kernel(BwdArgs a, BwdFinish fin, BwdApply ap) {
+    constexpr int NW = THREADS / 64;
+    __shared__ double sd[4][NW];
+    __shared__ float sm[2][NW];
     const int ch = blockIdx.x;
-    const UnitGeom u(a.hw);
+    const UnitGeom<THREADS> u(a.hw);
     const float mean = a.mean[ch], invstd = a.invstd[ch];
     const float g = a.gamma ? a.gamma[ch] : 1.f, b = a.beta ? a.beta[ch] : 0.f;
     const bool has_alpha = a.alpha != nullptr;
     const float al = has_alpha ? a.alpha[ch] : 1.f;
-    float4 xv[TRIPS], rv[TRIPS], uv[TRIPS];
-    QuadPos q[TRIPS];
-    long off[TRIPS];
+    float4 xv[TRIPS], rv[RES ? TRIPS : 1], uv[TRIPS];
     unsigned pi[TRIPS];
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-    for (int t = 0; t < TRIPS; ++t) {
+    auto where = [&](int t, long& plane) {           // (recomputed in the apply loop, see unit_fwd_kernel)
         const int bb = u.tn4 + t * u.g4;
         const bool ok = bb < a.n;
-        const long plane = (long)(ok ? bb : 0) * a.c + ch;
-        off[t] = plane * a.hw;
-        q[t] = quad_pos(off[t], (int)a.hw, u.ti4);
-        if (!ok) q[t].count = 0;
-        xv[t] = load_quad(a.x + off[t], q[t], mean);
-        rv[t] = a.res ? load_quad(a.res + off[t], q[t], 0.f) : zero4;
-        uv[t] = a.dy ? load_quad(a.dy + off[t], q[t], 0.f) : zero4;
-        if (q[t].count > 0 && a.gmax_dy) {
-            const int d = a.gmax_idx[plane] - q[t].base;
+        plane = (long)(ok ? bb : 0) * a.c + ch;
+        QuadPos q = quad_pos(plane * a.hw, (int)a.hw, u.ti4);
+        if (!ok) q.count = 0;
+        return q;
+    };
+#pragma unroll
+    for (int t = 0; t < TRIPS; ++t) {
+        long plane;
+        const QuadPos q = where(t, plane);
+        const long off = plane * a.hw;
+        xv[t] = load_quad(a.x + off, q, mean);
+        if constexpr (RES) rv[t] = load_quad(a.res + off, q, 0.f);
+        uv[t] = a.dy ? load_quad(a.dy + off, q, 0.f) : zero4;
+        if (q.count > 0 && a.gmax_dy) {
+            const int d = a.gmax_idx[plane] - q.base;
             const float gval = a.gmax_dy[plane];
-            if (d >= 0 && d < q[t].count) { if (d == 0) uv[t].x += gval; else if (d == 1) uv[t].y += gval; else if (d == 2) uv[t].z += gval; else uv[t].w += gval; }
+            if (d >= 0 && d < q.count) { if (d == 0) uv[t].x += gval; else if (d == 1) uv[t].y += gval; else if (d == 2) uv[t].z += gval; else uv[t].w += gval; }
         }
         pi[t] = 0u;
         if (ap.pool_idx)
-            for (int e = 0; e < q[t].count; ++e) pi[t] |= (unsigned)ap.pool_idx[off[t] + q[t].base + e] << (8 * e);
+            for (int e = 0; e < q.count; ++e) pi[t] |= (unsigned)ap.pool_idx[off + q.base + e] << (8 * e);
     }
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f, mdz = 0.f, mxh = 0.f;
     // (xv / uv become xhat / dz in place: what the apply pass needs)
 #pragma unroll
     for (int t = 0; t < TRIPS; ++t) {
         float xs[4] = {xv[t].x, xv[t].y, xv[t].z, xv[t].w}, us[4] = {uv[t].x, uv[t].y, uv[t].z, uv[t].w};
-        const float rs[4] = {rv[t].x, rv[t].y, rv[t].z, rv[t].w};
+        const float4 r4 = RES ? rv[RES ? t : 0] : zero4;
+        const float rs[4] = {r4.x, r4.y, r4.z, r4.w};
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const float xh = (xs[e] - mean) * invstd;
@@ -1248,12 +1273,8 @@ __global__ __launch_bounds__(kThreads) void unit_bwd_kernel(BwdArgs a, BwdFinish
     if (lane == 0) { sd[0][wid] = w0; sd[1][wid] = w1; sd[2][wid] = w2; sd[3][wid] = w3; sm[0][wid] = mdz; sm[1][wid] = mxh; }
     __syncthreads();
     double t0 = sd[0][0], t1 = sd[1][0], t2 = sd[2][0], t3 = sd[3][0];
-    mdz = sm[0][0]; mxh = sm[1][0];
-#pragma unroll
-    for (int i = 1; i < kThreads / 64; ++i) {
-        t0 += sd[0][i]; t1 += sd[1][i]; t2 += sd[2][i]; t3 += sd[3][i];
-        mdz = fmaxf(mdz, sm[0][i]); mxh = fmaxf(mxh, sm[1][i]);
-    }
+#pragma unroll 4
+    for (int i = 1; i < NW; ++i) { t0 += sd[0][i]; t1 += sd[1][i]; t2 += sd[2][i]; t3 += sd[3][i]; }
     // (the fold of one split, as bwd_partial_kernel's `alone` path)
     double f0 = 0.0, f1 = 0.0, f2 = 0.0, f3 = 0.0;
     f0 += t0; f1 += t1; f2 += t2; f3 += t3;
@@ -1269,22 +1290,24 @@ __global__ __launch_bounds__(kThreads) void unit_bwd_kernel(BwdArgs a, BwdFinish
     const float k = g * invstd;
 #pragma unroll
     for (int t = 0; t < TRIPS; ++t) {
-        if (q[t].count == 0) continue;
+        long plane;
+        const QuadPos q = where(t, plane);
+        if (q.count == 0) continue;
         const float xh[4] = {xv[t].x, xv[t].y, xv[t].z, xv[t].w}, dz[4] = {uv[t].x, uv[t].y, uv[t].z, uv[t].w};
         float dv[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) dv[e] = k * (dz[e] - c1 - xh[e] * c2);
         if (ap.dc) {
             typedef float f32x2 __attribute__((ext_vector_type(2)));
-            float* r0 = ap.dc + (off[t] / a.hw) * ap.w;
-            for (int e = 0; e < q[t].count; ++e) {
+            float* r0 = ap.dc + plane * ap.w;
+            for (int e = 0; e < q.count; ++e) {
                 const int pos = (int)((pi[t] >> (8 * e)) & 0xFFu);
-                *reinterpret_cast<f32x2*>(r0 + 2 * (q[t].base + e)) = (f32x2){pos == 0 ? dv[e] : 0.f, pos == 1 ? dv[e] : 0.f};
+                *reinterpret_cast<f32x2*>(r0 + 2 * (q.base + e)) = (f32x2){pos == 0 ? dv[e] : 0.f, pos == 1 ? dv[e] : 0.f};
             }
-            if ((ap.w & 1) && q[t].base + q[t].count == (int)a.hw) r0[ap.w - 1] = 0.f;      // the column the pool never read
+            if ((ap.w & 1) && q.base + q.count == (int)a.hw) r0[ap.w - 1] = 0.f;      // the column the pool never read
         } else {
-            store_quad(ap.dx + off[t], q[t], make_float4(dv[0], dv[1], dv[2], dv[3]));
-            if (ap.dres) store_quad(ap.dres + off[t], q[t], uv[t]);
+            store_quad(ap.dx + plane * a.hw, q, make_float4(dv[0], dv[1], dv[2], dv[3]));
+            if (ap.dres) store_quad(ap.dres + plane * a.hw, q, uv[t]);
         }
     }
 }
@@ -1840,20 +1863,28 @@ int fsc_bn_train_stats(const float* x, int n, int c, long hw, const float* gamma
     return 0;
 }
 
-// a unit whose channel is one workgroup that holds it in registers (unit_fwd_kernel / unit_bwd_kernel)
-static bool fused_unit(int n, int c, long hw) {
-    static const bool off = [] { const char* e = getenv("FSC_BN_FUSED"); return e && e[0] == '0'; }();
-    return !off && hw > 1 && small_planes(hw) && pick_split(n, c, hw) == 1 && unit_trips(n, hw) <= 8;
+// a unit whose channel is one workgroup that holds it in registers (unit_fwd_kernel / unit_bwd_kernel).  The backward keeps 8 - 12
+// registers per quad: 8 quads x 1024 threads do not fit (`bwd`: at most 4 there)
+static UnitShape fused_unit(int n, int c, long hw, bool bwd = false) {
+    static const int mode = [] { const char* e = getenv("FSC_BN_FUSED"); return e ? atoi(e) : 1; }();   // 0: off; 2: 256 threads only (A/B)
+    UnitShape u = unit_shape(n, hw);
+    if (mode == 0 || n <= 0 || c <= 0 || (mode == 2 && u.threads != 256) || (bwd && u.threads == 1024 && u.trips > 4)) u.threads = 0;
+    return u;
 }
-#define FSC_UNIT_LAUNCH(KERNEL_, TRIPS_, ...)                                                                        \
-    do {                                                                                                             \
-        if ((TRIPS_) <= 1) hipLaunchKernelGGL(KERNEL_<1>, dim3(c), dim3(kThreads), 0, st, __VA_ARGS__);              \
-        else if ((TRIPS_) <= 2) hipLaunchKernelGGL(KERNEL_<2>, dim3(c), dim3(kThreads), 0, st, __VA_ARGS__);         \
-        else if ((TRIPS_) <= 4) hipLaunchKernelGGL(KERNEL_<4>, dim3(c), dim3(kThreads), 0, st, __VA_ARGS__);         \
-        else hipLaunchKernelGGL(KERNEL_<8>, dim3(c), dim3(kThreads), 0, st, __VA_ARGS__);                            \
+#define FSC_UNIT_TRIPS(KERNEL_, THREADS_, TRIPS_, ...)                                                                           \
+    do {                                                                                                                         \
+        if ((TRIPS_) <= 1) hipLaunchKernelGGL((KERNEL_<THREADS_, 1 FSC_UNIT_EXTRA>), dim3(c), dim3(THREADS_), 0, st, __VA_ARGS__);      \
+        else if ((TRIPS_) <= 2) hipLaunchKernelGGL((KERNEL_<THREADS_, 2 FSC_UNIT_EXTRA>), dim3(c), dim3(THREADS_), 0, st, __VA_ARGS__); \
+        else if ((TRIPS_) <= 4) hipLaunchKernelGGL((KERNEL_<THREADS_, 4 FSC_UNIT_EXTRA>), dim3(c), dim3(THREADS_), 0, st, __VA_ARGS__); \
+        else hipLaunchKernelGGL((KERNEL_<THREADS_, 8 FSC_UNIT_EXTRA>), dim3(c), dim3(THREADS_), 0, st, __VA_ARGS__);                    \
+    } while (0)
+#define FSC_UNIT_LAUNCH(KERNEL_, U_, ...)                                                \
+    do {                                                                                 \
+        if ((U_).threads == 256) FSC_UNIT_TRIPS(KERNEL_, 256, (U_).trips, __VA_ARGS__);  \
+        else FSC_UNIT_TRIPS(KERNEL_, 1024, (U_).trips, __VA_ARGS__);                     \
     } while (0)
 
-int fsc_bn_train_act_fwd_supported(int n, int c, long hw) { return (n > 0 && c > 0 && fused_unit(n, c, hw)) ? 1 : 0; }
+int fsc_bn_train_act_fwd_supported(int n, int c, long hw) { return fused_unit(n, c, hw).threads ? 1 : 0; }
 
 int fsc_bn_train_act_fwd(const float* x, const float* residual, int n, int c, long hw, const float* gamma, const float* beta, float eps,
                          float momentum, float* running_mean, float* running_var, float* save_mean, float* save_invstd, float* scale,
@@ -1861,12 +1892,15 @@ int fsc_bn_train_act_fwd(const float* x, const float* residual, int n, int c, lo
     FSC_CHECK_ARG(x && save_mean && save_invstd && scale && shift && y, "fsc_bn_train_act_fwd: null pointer");
     FSC_CHECK_ARG(n > 0 && c > 0 && hw > 0, "fsc_bn_train_act_fwd: bad shape (%d, %d, %ld)", n, c, hw);
     FSC_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr), "fsc_bn_train_act_fwd: running stats must come in pairs");
-    FSC_CHECK_ARG(fused_unit(n, c, hw), "fsc_bn_train_act_fwd: (%d, %d, %ld) is not a one-workgroup-per-channel shape "
+    const UnitShape us = fused_unit(n, c, hw);
+    FSC_CHECK_ARG(us.threads != 0, "fsc_bn_train_act_fwd: (%d, %d, %ld) is not a one-workgroup-per-channel shape "
                   "(fsc_bn_train_act_fwd_supported)", n, c, hw);
     hipStream_t st = fsc::as_stream(stream);
     FinalizeArgs fa{x, c, hw, (double)n * (double)hw, 1, nullptr, gamma, beta, eps, momentum, running_mean, running_var,
                     save_mean, save_invstd, scale, shift, nullptr, 0, x_minmax, 0, 0};
-    FSC_UNIT_LAUNCH(unit_fwd_kernel, unit_trips(n, hw), x, n, c, hw, fa, FwdApply{residual, alpha, y});
+#define FSC_UNIT_EXTRA
+    FSC_UNIT_LAUNCH(unit_fwd_kernel, us, x, n, c, hw, fa, FwdApply{residual, alpha, y});
+#undef FSC_UNIT_EXTRA
     FSC_LAUNCH_CHECK("fsc_bn_train_act_fwd");
     return 0;
 }
@@ -2033,9 +2067,19 @@ int fsc_bn_act_bwd(const float* dy, const float* gmax_dy, const int* gmax_idx, c
     if (phase == 0 && hw > 1 && zero_tickets) {
         fin = BwdFinish{p.tickets, (double)n * (double)hw, dgamma, dbeta, dalpha, p.coef, dx_chan_sum, dx_amax, dx_l16 ? 1 : 0};
     }
-    if (fin.tickets != nullptr && dx && !dx_l16 && !dx_amax && fused_unit(n, c, hw)) {
+    const UnitShape us = fused_unit(n, c, hw, true);
+    if (fin.tickets != nullptr && dx && !dx_l16 && !dx_amax && us.threads) {
         // a channel that is one workgroup: reduce, finalise and apply from registers in one launch
-        FSC_UNIT_LAUNCH(unit_bwd_kernel, unit_trips(n, hw), a, fin, BwdApply{dx, dresidual, nullptr, nullptr, 0});
+        const BwdApply ap{dx, dresidual, nullptr, nullptr, 0};
+        if (residual) {
+#define FSC_UNIT_EXTRA , true
+            FSC_UNIT_LAUNCH(unit_bwd_kernel, us, a, fin, ap);
+#undef FSC_UNIT_EXTRA
+        } else {
+#define FSC_UNIT_EXTRA , false
+            FSC_UNIT_LAUNCH(unit_bwd_kernel, us, a, fin, ap);
+#undef FSC_UNIT_EXTRA
+        }
         FSC_LAUNCH_CHECK("fsc_bn_act_bwd(unit)");
         return 0;
     }
@@ -2118,8 +2162,12 @@ int fsc_bn_act_bwd_unpool(const float* dy, const float* x, const float* save_mea
     if (phase == 0 && zero_tickets) {
         fin = BwdFinish{p.tickets, (double)n * (double)hw, dgamma, dbeta, dalpha, p.coef, dx_chan_sum, dc_amax, dc_l16 ? 1 : 0};
     }
-    if (fin.tickets != nullptr && dc && !dc_l16 && !dc_amax && h == 1 && ph == 1 && fused_unit(n, c, hw)) {
-        FSC_UNIT_LAUNCH(unit_bwd_kernel, unit_trips(n, hw), a, fin, BwdApply{nullptr, nullptr, pool_idx, dc, w});
+    const UnitShape us = fused_unit(n, c, hw, true);
+    if (fin.tickets != nullptr && dc && !dc_l16 && !dc_amax && h == 1 && ph == 1 && us.threads) {
+        const BwdApply ap{nullptr, nullptr, pool_idx, dc, w};
+#define FSC_UNIT_EXTRA , false
+        FSC_UNIT_LAUNCH(unit_bwd_kernel, us, a, fin, ap);
+#undef FSC_UNIT_EXTRA
         FSC_LAUNCH_CHECK("fsc_bn_act_bwd_unpool(unit)");
         return 0;
     }

@@ -302,12 +302,15 @@ int fsc_bn_train_stats(const float* x, int n, int c, long hw, const float* gamma
                        float* scale, float* shift, void* workspace, double* sync, int phase,
                        float* x_minmax, fsc_stream_t stream);
 /* Statistics AND apply pass of one training-mode unit in ONE launch (classifiers.py:78-82, 92-93, 96-97, 100-104: BatchNorm in
- * training mode, [+ residual], PReLU): where a channel's n x hw values are the work of one workgroup (single replica, planes of
- * 2 ... ~1000 values, n * hw <= 8192 with >= 128 channels: the 1-d model's blocks from 53 frames down at batch 128 -- tensors of
- * <= 1.3 MB on which each launch costs more than its bytes) that workgroup finalises and applies: everything fsc_bn_train_stats
- * (phase 0) writes, then y = act(x * scale + shift [+ residual]) exactly as fsc_bn_act_fwd computes it (bit-identical: the
- * same instruction sequence).  `_supported` says whether (n, c, hw) is such a shape; the call fails otherwise.  The backward
- * entry points below make the same decision on their own (their apply pass runs in the reduce pass's launch), nothing to ask for. */
+ * training mode, [+ residual], PReLU) where a channel's n x hw values fit the registers of one workgroup (single replica, planes
+ * of 2 ... 1024 values, <= 8 16-byte quads per thread of 256 or 1024 threads: the 1-d model's blocks from 215 frames down at batch
+ * 128 -- tensors of <= 14 MB on which a launch costs more than its bytes): all loads in flight at once, every reduction of the
+ * unit through one LDS exchange, every thread finalises, the apply pass is arithmetic on registers.  Writes everything
+ * fsc_bn_train_stats (phase 0) writes, then y = act(x * scale + shift [+ residual]) with fsc_bn_act_fwd's element arithmetic;
+ * against the two-launch route the statistics agree to an ulp of invstd (same additions in the same order where that route runs
+ * one split; the products are contracted into other fused multiply-adds).  `_supported` says whether (n, c, hw) is such a shape;
+ * the call fails otherwise.  fsc_bn_act_bwd / fsc_bn_act_bwd_unpool (single row, (1, 2) windows) make the same decision on their
+ * own -- no L16 output, no amax, single replica, FSC_BN_TICKETS: reduce, finalise and apply in one launch -- nothing to ask for. */
 int fsc_bn_train_act_fwd_supported(int n, int c, long hw);
 int fsc_bn_train_act_fwd(const float* x, const float* residual, int n, int c, long hw, const float* gamma, const float* beta,
                          float eps, float momentum, float* running_mean, float* running_var, float* save_mean,
