@@ -1126,7 +1126,9 @@ inline UnitShape unit_shape(int n, long hw) {
     return UnitShape{0, 0};
 }
 
-struct FwdApply { const float* res; const float* alpha; float* y; };
+// gmax / gmax_idx (may be null; planes of <= 64 lanes): the (n, c) global max of y and its position, the rule of
+// fsc_global_maxpool_fwd (first maximum; NaN wins) -- what the hierarchical head reads of a block output (classifiers.py:586-590)
+struct FwdApply { const float* res; const float* alpha; float* y; float* gmax; int* gmax_idx; };
 
 template <int THREADS, int TRIPS>
 __global__ __launch_bounds__(THREADS) void unit_fwd_kernel(const float* __restrict__ x, int n, int c, long hw, FinalizeArgs fa,
@@ -1184,7 +1186,7 @@ __global__ __launch_bounds__(THREADS) void unit_fwd_kernel(const float* __restri
     for (int t = 0; t < TRIPS; ++t) {
         long off;
         const QuadPos q = where(t, off);
-        if (q.count == 0) continue;
+        if (q.count == 0 && !ap.gmax) continue;        // (with gmax every lane of a plane's group takes part in the shuffles)
         float4 z = make_float4(fmaf(v[t].x, sc, sh), fmaf(v[t].y, sc, sh), fmaf(v[t].z, sc, sh), fmaf(v[t].w, sc, sh));
         if (ap.res) {
             const float4 r = load_quad(ap.res + off, q, 0.f);
@@ -1193,6 +1195,28 @@ __global__ __launch_bounds__(THREADS) void unit_fwd_kernel(const float* __restri
         z.x = act(z.x, al, has_alpha); z.y = act(z.y, al, has_alpha);
         z.z = act(z.z, al, has_alpha); z.w = act(z.w, al, has_alpha);
         store_quad(ap.y + off, q, z);
+        if (ap.gmax) {
+            // the plane's 2^l4 <= 64 lanes sit in one wave: (value, first index) keys folded with shuffles; the lane that holds
+            // the winner writes it (its own bits: the sign of a zero, the payload of a NaN)
+            const float zs[4] = {z.x, z.y, z.z, z.w};
+            unsigned long long key = 0ull;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const unsigned long long k2 = e < q.count ? rec_key(zs[e], (unsigned)(q.base + e)) : 0ull;
+                key = k2 > key ? k2 : key;
+            }
+            for (int o = (1 << u.l4) >> 1; o > 0; o >>= 1) {
+                const unsigned long long other = __shfl_xor(key, o, 64);
+                key = other > key ? other : key;
+            }
+            const int ii = (int)(0xFFFFFFFFu - (unsigned)(key & 0xFFFFFFFFull));
+            if (ii >= q.base && ii < q.base + q.count) {
+                const long plane = off / hw;
+                const int d = ii - q.base;
+                ap.gmax[plane] = d == 0 ? z.x : d == 1 ? z.y : d == 2 ? z.z : z.w;
+                ap.gmax_idx[plane] = ii;
+            }
+        }
     }
 }
 
@@ -1884,12 +1908,17 @@ static UnitShape fused_unit(int n, int c, long hw, bool bwd = false) {
         else FSC_UNIT_TRIPS(KERNEL_, 1024, (U_).trips, __VA_ARGS__);                     \
     } while (0)
 
-int fsc_bn_train_act_fwd_supported(int n, int c, long hw) { return fused_unit(n, c, hw).threads ? 1 : 0; }
+int fsc_bn_train_act_fwd_supported(int n, int c, long hw) {
+    if (!fused_unit(n, c, hw).threads) return 0;
+    return small_plane_lanes(hw) <= 64 ? 3 : 1;          // bit 1: gmax / gmax_idx can be asked for
+}
 
 int fsc_bn_train_act_fwd(const float* x, const float* residual, int n, int c, long hw, const float* gamma, const float* beta, float eps,
                          float momentum, float* running_mean, float* running_var, float* save_mean, float* save_invstd, float* scale,
-                         float* shift, float* x_minmax, const float* alpha, float* y, fsc_stream_t stream) {
+                         float* shift, float* x_minmax, const float* alpha, float* y, float* gmax, int* gmax_idx, fsc_stream_t stream) {
     FSC_CHECK_ARG(x && save_mean && save_invstd && scale && shift && y, "fsc_bn_train_act_fwd: null pointer");
+    FSC_CHECK_ARG((gmax == nullptr) == (gmax_idx == nullptr), "fsc_bn_train_act_fwd: gmax / gmax_idx must come in pairs");
+    FSC_CHECK_ARG(!gmax || small_plane_lanes(hw) <= 64, "fsc_bn_train_act_fwd: the global max needs planes of <= 64 lanes (hw <= ~250)");
     FSC_CHECK_ARG(n > 0 && c > 0 && hw > 0, "fsc_bn_train_act_fwd: bad shape (%d, %d, %ld)", n, c, hw);
     FSC_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr), "fsc_bn_train_act_fwd: running stats must come in pairs");
     const UnitShape us = fused_unit(n, c, hw);
@@ -1899,7 +1928,7 @@ int fsc_bn_train_act_fwd(const float* x, const float* residual, int n, int c, lo
     FinalizeArgs fa{x, c, hw, (double)n * (double)hw, 1, nullptr, gamma, beta, eps, momentum, running_mean, running_var,
                     save_mean, save_invstd, scale, shift, nullptr, 0, x_minmax, 0, 0};
 #define FSC_UNIT_EXTRA
-    FSC_UNIT_LAUNCH(unit_fwd_kernel, us, x, n, c, hw, fa, FwdApply{residual, alpha, y});
+    FSC_UNIT_LAUNCH(unit_fwd_kernel, us, x, n, c, hw, fa, FwdApply{residual, alpha, y, gmax, gmax_idx});
 #undef FSC_UNIT_EXTRA
     FSC_LAUNCH_CHECK("fsc_bn_train_act_fwd");
     return 0;

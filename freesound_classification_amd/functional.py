@@ -1238,6 +1238,27 @@ def _take_prestats(x):
     return None
 
 
+def bn_act_forward_unit(x, st, alpha, residual, want_gmax):
+    """A lazily prepared unit whose channel is one workgroup (bn_prepare(lazy=True) left st.pending): statistics, apply pass and --
+    where the planes allow -- the global max-pool of the output in ONE launch.  Returns (y, feat, fidx), or None when this
+    shape cannot serve the global max that way (the caller then takes bn_act_forward_rec)."""
+    pend = st.pending
+    if pend is None or pend[0] is not x:
+        return None
+    n, c = x.shape[0], x.shape[1]
+    hw = x.numel() // (n * c)
+    if want_gmax and not (_lib.load().fsc_bn_train_act_fwd_supported(n, c, hw) & 2):
+        return None
+    (_x, a), st.pending = pend, None
+    y = torch.empty_like(x)
+    feat = _empty((n, c), x) if want_gmax else None
+    fidx = _empty((n, c), x, torch.int32) if want_gmax else None
+    with _stage("bn_act_fwd", 2 * _nb(x) + _nb(residual, y)):
+        call("fsc_bn_train_act_fwd", a[0], ptr(residual), *a[1:], ptr(st.minmax), ptr(alpha), ptr(y), ptr(feat), ptr(fidx),
+             stream_ptr())
+    return y, feat, fidx
+
+
 def bn_act_forward_rec(x, st, alpha, residual, want_stats, want_gmax):
     """bn_act_forward (fp32 output) that also reduces, while it writes y, what the next readers of y need: the statistics
     partials of the BatchNorm that follows (kept for the bn_prepare call on this very tensor) and the global max-pool.
@@ -1397,7 +1418,7 @@ def bn_act_forward(x, st, alpha=None, residual=None, with_amax=False, l16=False,
             (_x, a), st.pending = st.pending, None
             y = torch.empty_like(x)
             with _stage("bn_act_fwd", 2 * _nb(x) + _nb(residual, y)):
-                call("fsc_bn_train_act_fwd", a[0], ptr(residual), *a[1:], ptr(st.minmax), ptr(alpha), ptr(y), stream_ptr())
+                call("fsc_bn_train_act_fwd", a[0], ptr(residual), *a[1:], ptr(st.minmax), ptr(alpha), ptr(y), None, None, stream_ptr())
             if l16:
                 return y, None
             return (y, None) if with_amax else y
@@ -1847,7 +1868,12 @@ def _block_forward(x, mods, training, want_head, ph, keep, sync=None, next_bn=Fa
     st3 = bn_prepare(r3, res.bn3, training, sync, counters, lazy=True)
     feat, fidx = (None, None)
     next_stats = next_bn and (training or EVAL_L16)          # (inference: the next block's input BatchNorm wants the range)
-    if FUSE_OUT_STATS and h_w_min(r3) * max(r3.shape[2], r3.shape[3]) > 1 and (want_head or next_stats):
+    # small tensors (a channel is one workgroup): the output's statistics are not reduced here -- the next block's input BatchNorm
+    # is such a unit itself (statistics + apply in one launch: cheaper than records, fold and finalisation launches)
+    unit = bn_act_forward_unit(r3, st3, res.prelu3.weight, b, want_head) if st3.pending is not None else None
+    if unit is not None:
+        out, feat, fidx = unit
+    elif FUSE_OUT_STATS and h_w_min(r3) * max(r3.shape[2], r3.shape[3]) > 1 and (want_head or next_stats):
         out, feat, fidx = bn_act_forward_rec(r3, st3, res.prelu3.weight, b, next_stats, want_head)
     else:
         out = bn_act_forward(r3, st3, res.prelu3.weight, residual=b)

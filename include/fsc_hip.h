@@ -310,12 +310,15 @@ int fsc_bn_train_stats(const float* x, int n, int c, long hw, const float* gamma
  * against the two-launch route the statistics agree to an ulp of invstd (same additions in the same order where that route runs
  * one split; the products are contracted into other fused multiply-adds).  `_supported` says whether (n, c, hw) is such a shape;
  * the call fails otherwise.  fsc_bn_act_bwd / fsc_bn_act_bwd_unpool (single row, (1, 2) windows) make the same decision on their
- * own -- no L16 output, no amax, single replica, FSC_BN_TICKETS: reduce, finalise and apply in one launch -- nothing to ask for. */
+ * own -- no L16 output, no amax, single replica, FSC_BN_TICKETS: reduce, finalise and apply in one launch -- nothing to ask for.
+ * gmax / gmax_idx (may be NULL; `_supported` bit 1: planes of <= 64 lanes, hw <= ~250): the (n, c) global max of y and its
+ * position under fsc_global_maxpool_fwd's rule -- the block output's second reader (classifiers.py:586-590) served by the launch
+ * that writes it.  `_supported`: 0 no; 1 yes; 3 yes, and the global max can be asked for. */
 int fsc_bn_train_act_fwd_supported(int n, int c, long hw);
 int fsc_bn_train_act_fwd(const float* x, const float* residual, int n, int c, long hw, const float* gamma, const float* beta,
                          float eps, float momentum, float* running_mean, float* running_var, float* save_mean,
                          float* save_invstd, float* scale, float* shift, float* x_minmax, const float* alpha, float* y,
-                         fsc_stream_t stream);
+                         float* gmax, int* gmax_idx, fsc_stream_t stream);
 /* x_minmax (2*C floats, may be NULL): per channel [min x, max x] of the local batch -- what fsc_bn_act_fwd needs to
  * bound its output before it writes an L16 tensor.
  * phase | FSC_BN_STATS_FOLDED: the reduction over x was done by the kernel that WROTE x (fsc_bn_act_fwd_rec +

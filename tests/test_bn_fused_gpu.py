@@ -44,15 +44,15 @@ def _close(a, b, rel=2e-6):
 def test_supported_shapes():
     lib = _lib.load()
     for n, c, w in SHAPES:
-        assert lib.fsc_bn_train_act_fwd_supported(n, c, w) == 1, (n, c, w)
-    assert lib.fsc_bn_train_act_fwd_supported(128, 125, 215) == 1          # (block 3, forward only: 1024 threads x 8 quads)
+        assert lib.fsc_bn_train_act_fwd_supported(n, c, w) & 1, (n, c, w)
+    assert lib.fsc_bn_train_act_fwd_supported(128, 125, 215) == 3          # (block 3, forward only: 1024 threads x 8 quads)
     for n, c, w in [(128, 64, 3446), (128, 100, 430), (128, 476, 1)]:      # big; > 8 quads per thread; hw == 1
         assert lib.fsc_bn_train_act_fwd_supported(n, c, w) == 0, (n, c, w)
     x = torch.randn(128, 100, 1, 430, device=DEV)
     f = torch.empty(100, device=DEV)
     with pytest.raises(_lib.FscError):
         F.call("fsc_bn_train_act_fwd", F.ptr(x), None, 128, 100, 430, None, None, 1e-5, 0.1, None, None, F.ptr(f), F.ptr(f), F.ptr(f),
-               F.ptr(f), None, None, F.ptr(torch.empty_like(x)), F.stream_ptr())
+               F.ptr(f), None, None, F.ptr(torch.empty_like(x)), None, None, F.stream_ptr())
 
 
 @pytest.mark.parametrize("shape", SHAPES + [(128, 125, 215)])
@@ -104,6 +104,45 @@ def test_lazy_statistics_reach_other_consumers(restore_conv_arith):
     st2 = F.bn_prepare(x, bn2, True)
     y2 = F.bn_act_forward(x, st2, alpha, res)
     assert torch.equal(y, y2) and torch.equal(st.mean, st2.mean) and torch.equal(feat, y2.amax(dim=(2, 3)))      # (both: the two-launch statistics)
+
+
+@pytest.mark.parametrize("shape", SHAPES[:8] + [(128, 125, 215), (2, 9, 248)])
+def test_forward_with_the_global_max(shape, restore_conv_arith):
+    """The block-end unit (bn3 + residual + PReLU) that also serves the head's global max-pool: values and FIRST positions as
+    fsc_global_maxpool_fwd finds them on the stored output (ties: a constant channel, a clamped one; a NaN wins)."""
+    F.set_conv_arith("bf16")
+    n, c, w = shape
+    assert _lib.load().fsc_bn_train_act_fwd_supported(n, c, w) == 3
+    torch.manual_seed(n + c + 3 * w)
+    x = torch.randn(n, c, 1, w)
+    x[:, 1] = 2.0                                       # constant channel: every position ties, index 0 wins
+    res = torch.randn(n, c, 1, w)
+    res[:, 1] = 0.0
+    x[0, 2, 0, w // 2] = float("nan")                   # (poisons channel 2's statistics: every value of it is NaN, index 0 wins)
+    alpha = (torch.rand(c) * 0.3 + 0.1).to(DEV)
+    xd, rd = x.to(DEV), res.to(DEV)
+    bn = _bn(c, 5).to(DEV).train()
+    st = F.bn_prepare(xd, bn, True, lazy=True)
+    y, feat, fidx = F.bn_act_forward_unit(xd, st, alpha, rd, True)
+    assert st.pending is None
+    ref_feat, ref_idx = F.global_maxpool_forward(y)
+    assert torch.equal(fidx, ref_idx)
+    assert torch.equal(feat.view(torch.int32), ref_feat.view(torch.int32))          # (bit for bit: NaNs and zeros included)
+    bn2 = _bn(c, 5).to(DEV).train()
+    y2 = F.bn_act_forward(xd, F.bn_prepare(xd, bn2, True), alpha, rd)
+    ok = ~torch.isnan(y2)
+    assert torch.equal(torch.isnan(y), torch.isnan(y2)) and _close(y[ok], y2[ok])
+    assert int(fidx[0, 1, ]) == 0 and int(fidx[0, 2]) == 0
+
+
+def test_long_planes_leave_the_global_max_to_the_record_route(restore_conv_arith):
+    F.set_conv_arith("bf16")
+    x = torch.randn(3, 7, 1, 1000, device=DEV)
+    assert _lib.load().fsc_bn_train_act_fwd_supported(3, 7, 1000) == 1
+    st = F.bn_prepare(x, _bn(7, 1).to(DEV).train(), True, lazy=True)
+    assert F.bn_act_forward_unit(x, st, None, None, True) is None and st.pending is not None
+    y, feat, fidx = F.bn_act_forward_unit(x, st, None, None, False)
+    assert feat is None and st.pending is None and torch.isfinite(y).all()
 
 
 @pytest.mark.parametrize("shape", SHAPES)
@@ -166,7 +205,7 @@ def test_backward_through_the_pool_one_launch_equals_two(shape, restore_conv_ari
     y.backward(gy)
     dbn = _bn(c, 11).to(DEV).train()
     pd, pidx = F.maxpool_forward(full.detach().to(DEV), 1)
-    assert _lib.load().fsc_bn_train_act_fwd_supported(n, c, w // 2) == 1
+    assert _lib.load().fsc_bn_train_act_fwd_supported(n, c, w // 2) & 1
     got = {}
     for arith in ("f16x3", "bf16"):
         F.set_conv_arith(arith)
