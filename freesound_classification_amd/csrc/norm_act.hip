@@ -1786,7 +1786,8 @@ __global__ void bwd_apply_flat_kernel(BwdArgs a, const float* __restrict__ coef,
 int pick_split(int n, int c, long hw) {
     // enough blocks to fill 256 CUs a few times over, bounded by the batch and the workspace
     long want = (256L * 8 + c - 1) / c;
-    const long per_block = small_planes(hw) ? 4096 : 16384;        // (small planes are latency-bound: more, shorter blocks)
+    static const long big = [] { const char* e = getenv("FSC_BN_PER_BLOCK"); return e ? atol(e) : 16384L; }();
+    const long per_block = small_planes(hw) ? 4096 : big;          // (small planes are latency-bound: more, shorter blocks)
     long by_work = ((long)n * hw + per_block - 1) / per_block;
     long s = want < by_work ? want : by_work;
     if (s > n) s = n;

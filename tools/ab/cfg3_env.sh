@@ -1,5 +1,6 @@
-# same-box A/B of an environment switch on the cfg-3 step:  tools/ab/cfg3_env.sh VAR=off_value   (development tool)
-for r in 1 2 3; do for v in off on; do
-if [ $v = off ]; then export $1; else unset ${1%%=*}; fi
-python bench.py --workload cfg3 --steps 20 --warmup 5 --graph --no-cpu-baseline --no-other 2>/dev/null | python -c "import json,sys; d=json.load(sys.stdin); print('cfg3 $1 $v', round(d['value'],1), round(d['ms_per_step'],3))"
+# development: cfg 3 (HIP-graph replay) under settings of one environment variable:  tools/ab/cfg3_env.sh NAME v1 v2 ...
+NAME=$1; shift
+for i in 1 2; do for v in "$@"; do
+env $NAME=$v python bench.py --workload cfg3 --steps 20 --warmup 5 --graph --no-cpu-baseline --no-other 2> /dev/null | python -c "
+import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$NAME=$v', d['value'], d['ms_per_step'], d['final_loss'])"
 done; done
