@@ -302,9 +302,11 @@ def test_producers_write_the_limbs_of_what_they_write_as_fp32(shape, l3):
     dx, t2 = res[0], res[-1]
     assert isinstance(t2, F.L16) and same(t2, dx)
     ref = F.bn_act_backward(dy, x, st, bn, alpha, want_dres=False, want_chan_sum=True)
-    assert torch.equal(ref[0], dx)
-    for a, b in zip(ref[2:5], res[2:5]):
-        assert torch.equal(a, b)
+    # (small tensors: the call without limb output is the one-workgroup-per-channel kernel -- the same sums in the same order, the
+    # products contracted into other fused multiply-adds: an ulp; tests/test_bn_fused_gpu.py)
+    unit = F._lib.load().fsc_bn_train_act_fwd_supported(n, c, h * w) != 0
+    for a, b in zip((ref[0],) + tuple(ref[2:5]), (dx,) + tuple(res[2:5])):
+        assert torch.equal(a, b) or (unit and float((a - b).abs().max()) <= 2e-6 * float(b.abs().max()))
     # backward + un-pooling (2 x 2 windows; 1 x 2 on single rows)
     ph = 2 if h >= 2 else 1
     c_shape = (n, c, h * ph if ph == 2 else h, 2 * w + 1)
