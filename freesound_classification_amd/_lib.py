@@ -97,6 +97,8 @@ SIGNATURES = {
     "fsc_bn_train_act_fwd": (_I, [_P, _P, _I, _I, _L, _P, _P, _F, _F, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "fsc_bn_eval_prepare": (_I, [_I, _P, _P, _P, _P, _F, _P, _P, _P]),
     "fsc_conv_l16_stats_layout": (_I, [_D, _I, _P]),
+    "fsc_conv_fwd_stats_layout": (_I, [_D, _P]),
+    "fsc_conv_fwd_stats": (_I, [_D, _P, _P, _P, _P, _P, _P, _P]),
     "fsc_conv_l16_fwd_stats": (_I, [_D, _P, _P, _P, _P, _P, _P, _P, _P]),
     "fsc_conv_l16_pool_fwd_stats": (_I, [_D, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "fsc_bn_records_fold_conv": (_I, [_P, _I, _I, _I, _I, _I, _P, _P]),

@@ -422,13 +422,21 @@ __device__ __forceinline__ f32x4 mfma_k32(u32x4 a, u32x4 b, f32x4 c) {
 // workgroup barrier that neither drains the DMAs in flight nor lets the compiler move LDS accesses across it
 __device__ __forceinline__ void raw_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-template <int KH, int KW, int COT, int PT, int NPROD>
+// STATS (plain bf16 arithmetic on 1-d rows: the 1-d model's early blocks; the pre-split kernels of conv_l16.hip / conv_l3.hip have
+// had it since round 3): the forward of a convolution whose output goes into a BatchNorm (classifiers.py:78-101) also accumulates,
+// per lane and output channel, sum (y - pivot), sum (y - pivot)^2, min y, max y of what it stores; one float4 record per (worker,
+// wave, channel) at the end -- conv_l16.hip's record format, folded and finalised by fsc_bn_train_stats_conv: the statistics pass
+// over the output (21 - 25 us per convolution on cfg 3's 14 - 56 MB tensors) disappears.  The host launches it only where a
+// worker keeps ONE channel block (one block in all, or a worker count that is a multiple), no K split, no accumulation.
+template <int KH, int KW, int COT, int PT, int NPROD, bool STATS = false>
 __global__ __launch_bounds__(kXWaves * 64) void conv_fwd_x3_kernel(Geom g, const float* __restrict__ in,
                                                                const float* __restrict__ packed,
                                                                const float* __restrict__ bias,
                                                                float* __restrict__ out, int accumulate,
                                                                const float* __restrict__ in_amax,
-                                                               const float* __restrict__ w_amax) {
+                                                               const float* __restrict__ w_amax,
+                                                               const float* __restrict__ stat_pivot = nullptr,
+                                                               float4* __restrict__ stat_rec = nullptr) {
     constexpr int TAPS = KH * KW;
     constexpr int CO_BLK = COT * 16;
     constexpr int PADH = KH / 2, PADW = KW / 2;
@@ -568,6 +576,10 @@ __global__ __launch_bounds__(kXWaves * 64) void conv_fwd_x3_kernel(Geom g, const
     for (int i = 0; i < COT; ++i)
 #pragma unroll
         for (int j = 0; j < PT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    constexpr int NST = STATS ? COT : 1;
+    float st_s1[NST], st_s2[NST], st_mn[NST], st_mx[NST];
+#pragma unroll
+    for (int i = 0; i < NST; ++i) { st_s1[i] = 0.f; st_s2[i] = 0.f; st_mn[i] = INFINITY; st_mx[i] = -INFINITY; }
 
     // ---- fp16 limbs: activations are scaled to [2^14, 2^15) by a power of two from the tensor's largest magnitude
     //      (the weights were scaled the same way when they were packed); the epilogue undoes both exactly
@@ -996,12 +1008,27 @@ __global__ __launch_bounds__(kXWaves * 64) void conv_fwd_x3_kernel(Geom g, const
                 bv[r] = (add_bias && cob < g.cout) ? bias_t[cob] : 0.f;
             }
             const int co = co0 + i * 16 + ch;
+            float pv = 0.f;
+            if (STATS && stat_pivot != nullptr && co < g.cout) pv = stat_pivot[co];
 #pragma unroll
             for (int j = 0; j < PT; ++j) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
                     scratch[(kq * 4 + r) * SCR + lm] = F16 ? fmaf(acc[i][j][r] * inv_x, inv_w, bv[r]) : acc[i][j][r] + bv[r];
                 const f32x4 v = *reinterpret_cast<const f32x4*>(scratch + ch * SCR + (lane & 3) * 4);
+                if constexpr (STATS) {
+                    if (co < g.cout && quad_ok[j]) {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k)
+                            if (quad_ok[j] & (1 << k)) {
+                                const float a = v[k] - pv;
+                                st_s1[i] += a;
+                                st_s2[i] = fmaf(a, a, st_s2[i]);
+                                st_mn[i] = fminf(st_mn[i], v[k]);
+                                st_mx[i] = fmaxf(st_mx[i], v[k]);
+                            }
+                    }
+                }
                 if (co < g.cout && quad_ok[j]) {
                     float* o = out + quad_g[j] + (long)co * hw_t;
                     if (plain && quad_ok[j] == 15) {
@@ -1026,6 +1053,20 @@ __global__ __launch_bounds__(kXWaves * 64) void conv_fwd_x3_kernel(Geom g, const
 #pragma unroll
             for (int j = 0; j < PT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
         stores_pending = true;
+    }
+    if constexpr (STATS) {
+        // the four lanes of a quad hold the same channel: fold them, lane (lane & 3) == 0 writes the record
+        constexpr int CO_BLK_ = COT * 16;
+#pragma unroll
+        for (int i = 0; i < COT; ++i) {
+            float a = st_s1[i], b = st_s2[i], mn = st_mn[i], mx = st_mx[i];
+            a += __shfl_xor(a, 1, 64); a += __shfl_xor(a, 2, 64);
+            b += __shfl_xor(b, 1, 64); b += __shfl_xor(b, 2, 64);
+            mn = fminf(mn, __shfl_xor(mn, 1, 64)); mn = fminf(mn, __shfl_xor(mn, 2, 64));
+            mx = fmaxf(mx, __shfl_xor(mx, 1, 64)); mx = fmaxf(mx, __shfl_xor(mx, 2, 64));
+            if ((lane & 3) == 0)
+                stat_rec[((long)blockIdx.x * kXWaves + wid) * CO_BLK_ + i * 16 + (lane >> 2)] = make_float4(a, b, mn, mx);
+        }
     }
 }
 
@@ -2390,27 +2431,44 @@ bool plan_fwd_f32(const fsc_conv_desc& d, int dgrad, FwdPlan* out) {
     return true;
 }
 
+struct XStat { const float* pivot; float4* rec; };       // statistics records of a STATS forward (null: none)
+// where the STATS instantiations exist and a worker keeps one channel block
+bool x3_stats_ok(const FwdPlan& p, const fsc_conv_desc& d) {
+    return p.x3 == 1 && !p.s1d && d.kh == 1 && p.cot <= 8 && p.g.ksplit == 1 && p.launch_x > 0 &&
+           (p.co_blocks == 1 || p.launch_x % p.co_blocks == 0);
+}
+
 template <int KH, int KW, int COT, int PT, int NPROD>
 void launch_x3_pt(const FwdPlan& p, dim3 grid, const float* in, const float* packed, const float* bias, float* out,
-                  int accumulate, const float* in_amax, hipStream_t st) {
+                  int accumulate, const float* in_amax, hipStream_t st, XStat sa = XStat{nullptr, nullptr}) {
+    const float* w_amax = packed + x3_limb_floats(p);      // fp16 limbs: the weights' largest magnitude follows the fragments
+    if constexpr (NPROD == 1 && KH == 1 && COT <= 8) {
+        if (sa.rec) {
+            auto kern = conv_fwd_x3_kernel<KH, KW, COT, PT, NPROD, true>;
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes);
+            hipLaunchKernelGGL(kern, grid, dim3(kXWaves * 64), p.lds_bytes, st, p.g, in, packed, bias, out, accumulate, in_amax, w_amax,
+                               sa.pivot, sa.rec);
+            return;
+        }
+    }
     auto kern = conv_fwd_x3_kernel<KH, KW, COT, PT, NPROD>;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes);
-    const float* w_amax = packed + x3_limb_floats(p);      // fp16 limbs: the weights' largest magnitude follows the fragments
-    hipLaunchKernelGGL(kern, grid, dim3(kXWaves * 64), p.lds_bytes, st, p.g, in, packed, bias, out, accumulate, in_amax, w_amax);
+    hipLaunchKernelGGL(kern, grid, dim3(kXWaves * 64), p.lds_bytes, st, p.g, in, packed, bias, out, accumulate, in_amax, w_amax,
+                       (const float*)nullptr, (float4*)nullptr);
 }
 
 template <int KH, int KW, int COT, int PT>
 void launch_x3_arith(const FwdPlan& p, dim3 grid, const float* in, const float* packed, const float* bias, float* out,
-                     int accumulate, const float* in_amax, hipStream_t st) {
+                     int accumulate, const float* in_amax, hipStream_t st, XStat sa = XStat{nullptr, nullptr}) {
     if (p.x3 == 3) launch_x3_pt<KH, KW, COT, PT, 3>(p, grid, in, packed, bias, out, accumulate, in_amax, st);
-    else if (p.x3 == 1) launch_x3_pt<KH, KW, COT, PT, 1>(p, grid, in, packed, bias, out, accumulate, in_amax, st);
+    else if (p.x3 == 1) launch_x3_pt<KH, KW, COT, PT, 1>(p, grid, in, packed, bias, out, accumulate, in_amax, st, sa);
     else if (p.x3 == 6) launch_x3_pt<KH, KW, COT, PT, 6>(p, grid, in, packed, bias, out, accumulate, in_amax, st);
     else launch_x3_pt<KH, KW, COT, PT, 9>(p, grid, in, packed, bias, out, accumulate, in_amax, st);
 }
 
 template <int KH, int KW, int COT>
 int launch_fwd_cot(const FwdPlan& p, const float* in, const float* packed, const float* bias, float* out,
-                   int accumulate, const float* in_amax, hipStream_t st) {
+                   int accumulate, const float* in_amax, hipStream_t st, XStat sa = XStat{nullptr, nullptr}) {
     dim3 grid((unsigned)p.grid_x, p.co_blocks, p.g.ksplit);
     if (p.g.ksplit > 1 && !accumulate) {
         const size_t bytes = sizeof(float) * (size_t)p.g.n * p.g.cout * p.g.hw;
@@ -2420,8 +2478,8 @@ int launch_fwd_cot(const FwdPlan& p, const float* in, const float* packed, const
     if (p.x3) {
         grid.x = (unsigned)p.launch_x;
         grid.y = 1;
-        if (p.pt == 2) launch_x3_arith<KH, KW, COT, 2>(p, grid, in, packed, bias, out, accumulate, in_amax, st);
-        else launch_x3_arith<KH, KW, COT, 1>(p, grid, in, packed, bias, out, accumulate, in_amax, st);
+        if (p.pt == 2) launch_x3_arith<KH, KW, COT, 2>(p, grid, in, packed, bias, out, accumulate, in_amax, st, sa);
+        else launch_x3_arith<KH, KW, COT, 1>(p, grid, in, packed, bias, out, accumulate, in_amax, st, sa);
         FSC_LAUNCH_CHECK("fsc_conv_fwd(x3)");
         return 0;
     }
@@ -2467,18 +2525,18 @@ int launch_fwd_wide(const FwdPlan& p, const float* in, const float* packed, cons
 
 template <int KH, int KW>
 int launch_fwd(const FwdPlan& p, const float* in, const float* packed, const float* bias, float* out, int accumulate,
-               const float* in_amax, hipStream_t st) {
+               const float* in_amax, hipStream_t st, XStat sa = XStat{nullptr, nullptr}) {
     if (p.cot == 10) return launch_fwd_wide<KH, KW, 10>(p, in, packed, bias, out, accumulate, in_amax, st);
     if (p.cot == 15) return launch_fwd_wide<KH, KW, 15>(p, in, packed, bias, out, accumulate, in_amax, st);
     switch (p.cot) {
-        case 1: return launch_fwd_cot<KH, KW, 1>(p, in, packed, bias, out, accumulate, in_amax, st);
-        case 2: return launch_fwd_cot<KH, KW, 2>(p, in, packed, bias, out, accumulate, in_amax, st);
-        case 3: return launch_fwd_cot<KH, KW, 3>(p, in, packed, bias, out, accumulate, in_amax, st);
-        case 4: return launch_fwd_cot<KH, KW, 4>(p, in, packed, bias, out, accumulate, in_amax, st);
-        case 5: return launch_fwd_cot<KH, KW, 5>(p, in, packed, bias, out, accumulate, in_amax, st);
-        case 6: return launch_fwd_cot<KH, KW, 6>(p, in, packed, bias, out, accumulate, in_amax, st);
-        case 7: return launch_fwd_cot<KH, KW, 7>(p, in, packed, bias, out, accumulate, in_amax, st);
-        default: return launch_fwd_cot<KH, KW, 8>(p, in, packed, bias, out, accumulate, in_amax, st);
+        case 1: return launch_fwd_cot<KH, KW, 1>(p, in, packed, bias, out, accumulate, in_amax, st, sa);
+        case 2: return launch_fwd_cot<KH, KW, 2>(p, in, packed, bias, out, accumulate, in_amax, st, sa);
+        case 3: return launch_fwd_cot<KH, KW, 3>(p, in, packed, bias, out, accumulate, in_amax, st, sa);
+        case 4: return launch_fwd_cot<KH, KW, 4>(p, in, packed, bias, out, accumulate, in_amax, st, sa);
+        case 5: return launch_fwd_cot<KH, KW, 5>(p, in, packed, bias, out, accumulate, in_amax, st, sa);
+        case 6: return launch_fwd_cot<KH, KW, 6>(p, in, packed, bias, out, accumulate, in_amax, st, sa);
+        case 7: return launch_fwd_cot<KH, KW, 7>(p, in, packed, bias, out, accumulate, in_amax, st, sa);
+        default: return launch_fwd_cot<KH, KW, 8>(p, in, packed, bias, out, accumulate, in_amax, st, sa);
     }
 }
 
@@ -2898,6 +2956,27 @@ int fsc_conv_fwd(const fsc_conv_desc* d, const float* in, const float* packed, c
     if (d->kh == 3) return launch_fwd<3, 3>(p, in, packed, bias, out, accumulate, in_amax, st);
     if (d->kw == 3) return launch_fwd<1, 3>(p, in, packed, bias, out, accumulate, in_amax, st);
     return launch_fwd<1, 1>(p, in, packed, bias, out, accumulate, in_amax, st);
+}
+
+/* statistics records of fsc_conv_fwd_stats: out4 = {workers, channel blocks, channels per block, order (0)}; workers * 8 * channels-per-
+ * block float4 {sum (y - pivot), sum (y - pivot)^2, min, max} -- the record format of fsc_conv_l16_stats_layout.  0: no such kernel
+ * for this layer (anything but plain bf16 arithmetic on 1-d rows with a ring-kernel tiling). */
+int fsc_conv_fwd_stats_layout(const fsc_conv_desc* d, int* out4) {
+    FwdPlan p;
+    if (!valid_desc(d) || !out4 || !plan_fwd(*d, 0, &p) || !x3_stats_ok(p, *d)) return 0;
+    out4[0] = (int)p.launch_x; out4[1] = p.co_blocks; out4[2] = p.cot * 16; out4[3] = 0;
+    return 1;
+}
+
+int fsc_conv_fwd_stats(const fsc_conv_desc* d, const float* in, const float* packed, const float* bias, float* out,
+                       const float* stat_pivot, void* stat_rec, fsc_stream_t stream) {
+    FSC_CHECK_ARG(valid_desc(d) && in && packed && out && stat_rec, "fsc_conv_fwd_stats: bad descriptor or null pointer");
+    FwdPlan p;
+    FSC_CHECK_ARG(plan_fwd(*d, 0, &p) && x3_stats_ok(p, *d), "fsc_conv_fwd_stats: unsupported layer (see fsc_conv_fwd_stats_layout)");
+    const XStat sa{stat_pivot, reinterpret_cast<float4*>(stat_rec)};
+    hipStream_t st = fsc::as_stream(stream);
+    if (d->kw == 3) return launch_fwd<1, 3>(p, in, packed, bias, out, 0, nullptr, st, sa);
+    return launch_fwd<1, 1>(p, in, packed, bias, out, 0, nullptr, st, sa);
 }
 
 int fsc_amax(const float* x, long n, float* out, fsc_stream_t stream) {

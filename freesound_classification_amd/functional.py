@@ -347,13 +347,33 @@ def _xpack_begin(key):
     return False
 
 
-def conv_forward(x, weight, bias, x_amax=None):
-    """x (N, Cin, H, W), weight (Cout, Cin, kh, kw) -> (N, Cout, H, W); stride 1, same pad."""
+_X3_STATS_LAYOUT = {}
+
+
+def conv_forward(x, weight, bias, x_amax=None, stats_bn=None):
+    """x (N, Cin, H, W), weight (Cout, Cin, kh, kw) -> (N, Cout, H, W); stride 1, same pad.
+    stats_bn = (BatchNorm module, training): where the layer has such a kernel (plain bf16 on 1-d rows, ring-kernel tiling:
+    fsc_conv_fwd_stats) the epilogue also reduces that BatchNorm's statistics of the output, picked up by bn_prepare on this
+    very tensor."""
     n, c_in, h, w = x.shape
     c_out, _, kh, kw = weight.shape
     d = _desc(n, c_in, c_out, h, w, kh, kw)
     packed = conv_pack(d, weight, 0)
     out = _empty((n, c_out, h, w), x)
+    if stats_bn is not None and CONV_STATS and d.arith == 1 and h == 1 and stats_bn[1]:
+        key = _desc_key(d)
+        if key not in _X3_STATS_LAYOUT:
+            out4 = (C.c_int * 4)()
+            _X3_STATS_LAYOUT[key] = tuple(out4) if _lib.load().fsc_conv_fwd_stats_layout(C.byref(d), out4) else None
+        lay = _X3_STATS_LAYOUT[key]
+        if lay is not None:
+            bn, training = stats_bn
+            rec = torch.empty(lay[0] * 8 * lay[2] * 4, device=x.device, dtype=torch.float32)
+            pivot = bn.running_mean if bn_tracks(bn, training) else None
+            with _timed(d, 0):
+                call("fsc_conv_fwd_stats", C.byref(d), ptr(x), ptr(packed), ptr(bias), ptr(out), ptr(pivot), ptr(rec), stream_ptr())
+            _stats_end(lay, rec, out, c_out)
+            return out
     x_amax = _operand_amax(x, x_amax)
     with _timed(d, 0):
         call("fsc_conv_fwd", C.byref(d), ptr(x), ptr(packed), ptr(bias), 0, 0, ptr(out), ptr(x_amax), stream_ptr())
@@ -1674,7 +1694,7 @@ def _conv_fwd_any(x, x_16, weight, bias, x_amax, packs=None, stats_bn=None):
         return conv_l16(x_16, weight, bias, stats_bn=stats_bn)
     if packs is not None:
         packs.append(None)
-    return conv_forward(x, weight, bias, x_amax=x_amax)
+    return conv_forward(x, weight, bias, x_amax=x_amax, stats_bn=stats_bn)
 
 
 def _conv_dgrad_any(dout, dout_16, weight, x_shape, dout_amax, accumulate_into=None, prepacked=None):

@@ -354,6 +354,14 @@ int fsc_bn_records_fold(const void* records, const float* y, int n, int c, long 
  * `stat_rec` holds workers * 8 * channels-per-block records of 16 bytes.  fsc_bn_records_fold_conv folds them into split 0 of a
  * BatchNorm workspace; then fsc_bn_train_stats(..., phase | FSC_BN_STATS_FOLDED | FSC_BN_STATS_PIVOT_RM, ...) with the SAME
  * running_mean pointer only finalises.  min / max are exact; mean / variance agree with the separate pass to rounding. */
+/* The same statistics epilogue on the fp32-input ring kernels in plain bf16 arithmetic (arith 1) on 1-d rows -- the 1-d model's
+ * early blocks (classifiers.py:147-163, 78-101: every Conv1d of a ResnetBlock feeds a BatchNorm): fsc_conv_fwd (forward, no
+ * accumulation) that also leaves the record format of fsc_conv_l16_stats_layout for fsc_bn_train_stats_conv (sums about `stat_pivot`
+ * = that BatchNorm's running mean, or NULL = 0).  `_layout` returns 0 where the layer has no such kernel (other arithmetics, 2-d
+ * planes, the small-layer kernels of conv_s1d.hip, split-K plans). */
+int fsc_conv_fwd_stats_layout(const fsc_conv_desc* d, int* out4);
+int fsc_conv_fwd_stats(const fsc_conv_desc* d, const float* in, const float* packed, const float* bias, float* out,
+                       const float* stat_pivot, void* stat_rec, fsc_stream_t stream);
 /* Shader clock (MHz) the chip ran the LAST L16 convolution launch at (which = 0: fsc_conv_l16_fwd family on two-limb
  * operands, 1: fsc_conv_l16_wgrad, 2: fsc_conv_l16_fwd family on three-limb operands):
  * workgroup 0 stamps the shader-cycle counter and the constant 100 MHz reference counter at both ends of the kernel.  The
