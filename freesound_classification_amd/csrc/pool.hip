@@ -42,6 +42,23 @@ __global__ __launch_bounds__(kThreads) void maxpool_fwd_kernel(const float* __re
     }
 }
 
+// Single-row planes with few windows (the 1-d model's late blocks: 61 k planes of 3 ... 215 windows): a thread per window over ALL
+// planes.  (A workgroup per plane ran 3 ... 215 of its 256 threads: 8 - 19 us for 1.5 - 14 MB tensors, the smallest the slowest.)
+__global__ __launch_bounds__(kThreads) void maxpool_rows_flat_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                                     uint8_t* __restrict__ idx, int w, int ow, long total) {
+    const long i = (long)blockIdx.x * kThreads + threadIdx.x;
+    if (i >= total) return;
+    const long pl = i / ow;
+    const int ox = (int)(i - pl * ow);
+    const float* p = x + pl * w + 2 * ox;
+    float best = p[0];
+    int bi = 0;
+    const float v = p[1];
+    if (v > best || v != v) { best = v; bi = 1; }
+    y[i] = best;
+    idx[i] = (uint8_t)bi;
+}
+
 // gather form: every input element is written exactly once
 __global__ __launch_bounds__(kThreads) void maxpool_bwd_kernel(const float* __restrict__ dy,
                                                                const uint8_t* __restrict__ idx,
@@ -153,6 +170,13 @@ int fsc_maxpool_fwd(const float* x, float* y, uint8_t* idx, int nc, int h, int w
     FSC_CHECK_ARG(x && y && idx, "fsc_maxpool_fwd: null pointer");
     FSC_CHECK_ARG((ph == 1 || ph == 2) && nc > 0 && h >= ph && w >= 2, "fsc_maxpool_fwd: bad shape nc=%d h=%d w=%d ph=%d", nc, h, w, ph);
     const int oh = h / ph, ow = w / 2;
+    if (h == 1 && ph == 1 && ow <= 256) {
+        const long total = (long)nc * ow;
+        hipLaunchKernelGGL(maxpool_rows_flat_kernel, dim3((unsigned)((total + kThreads - 1) / kThreads)), dim3(kThreads), 0,
+                           fsc::as_stream(stream), x, y, idx, w, ow, total);
+        FSC_LAUNCH_CHECK("fsc_maxpool_fwd(rows)");
+        return 0;
+    }
     const int cl = col_log2(ow);
     hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(nc, row_grid(oh, cl)), dim3(kThreads), 0, fsc::as_stream(stream), x, y,
                        idx, h, w, ph, oh, ow, cl);

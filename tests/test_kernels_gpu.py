@@ -481,19 +481,23 @@ def test_bn_act_bwd_with_global_max_head():
 
 
 # ------------------------------------------------------------------------------ pooling
-@pytest.mark.parametrize("shape,ph", [((2, 3, 13, 21), 2), ((2, 5, 8, 8), 2), ((3, 4, 1, 17), 1), ((1, 2, 2, 2), 2)])
+@pytest.mark.parametrize("shape,ph", [((2, 3, 13, 21), 2), ((2, 5, 8, 8), 2), ((3, 4, 1, 17), 1), ((1, 2, 2, 2), 2),
+                                      ((128, 476, 1, 6), 1), ((128, 244, 1, 53), 1), ((7, 5, 1, 431), 1), ((3, 4, 1, 1001), 1)])
 def test_maxpool(shape, ph):
+    # (single rows of <= 256 windows: the thread-per-window kernel over all planes; longer rows and 2-d planes: a workgroup per plane)
     torch.manual_seed(sum(shape))
     x = torch.randn(shape)
     x[0, 0, 0, :4] = 1.5          # ties: the first maximum must win
+    x[-1, -1, 0, 1] = float("nan")   # NaN wins (ATen)
     xr = x.clone().requires_grad_()
     y = TF.max_pool2d(xr, (ph, 2), (ph, 2))
     gy = torch.randn_like(y)
     y.backward(gy)
     yd, idx = F.maxpool_forward(x.to(DEV), ph)
-    assert maxdiff(yd, y) == 0.0
+    assert torch.equal(torch.isnan(yd.cpu()), torch.isnan(y))
+    assert maxdiff(torch.nan_to_num(yd), torch.nan_to_num(y.detach())) == 0.0
     dx = F.maxpool_backward(gy.to(DEV), idx, x.shape, ph)
-    assert maxdiff(dx, xr.grad) == 0.0
+    assert maxdiff(torch.nan_to_num(dx), torch.nan_to_num(xr.grad)) == 0.0
 
 
 @pytest.mark.parametrize("shape", [(3, 5, 7, 9), (2, 130, 2, 6), (4, 3, 1, 1000)])
