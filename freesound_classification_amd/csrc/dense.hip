@@ -147,7 +147,10 @@ int run_gemm(const GemmArgs& g_in, hipStream_t st, const char* name) {
     const long tiles = (long)grid.x * grid.y;
     const int kchunks = (g.k + BK - 1) / BK;
     if (tiles < 128 && kchunks >= 16 && g.ldc == g.n) {
-        long ks = 256 / tiles;
+        // (512 workgroups: 6.672 -> 6.649 ms per cfg-3 step against 256, the same at 1024 -- beyond that the K slices' atomics cost
+        // what the shorter loops save)
+        static const long target = [] { const char* e = getenv("FSC_GEMM_WORKGROUPS"); return e ? atol(e) : 512L; }();
+        long ks = target / tiles;
         if (ks > kchunks / 4) ks = kchunks / 4;
         if (ks > 16) ks = 16;
         if (ks > 1) {
