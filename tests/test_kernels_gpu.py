@@ -511,8 +511,10 @@ def test_global_maxpool(shape):
 
 
 # ------------------------------------------------------------------------------ head ops
-@pytest.mark.parametrize("m,k,n", [(4, 20, 80), (128, 1977, 80), (16, 300, 300), (3, 7, 5)])
+@pytest.mark.parametrize("m,k,n", [(4, 20, 80), (128, 1977, 80), (16, 300, 300), (3, 7, 5), (128, 1977, 1977), (37, 131, 67),
+                                   (128, 64, 33), (65, 33, 129)])
 def test_linear(m, k, n):
+    # (odd row lengths: the 16-byte loads of the tiles are 4-byte aligned; edges in every direction; the head's own sizes)
     torch.manual_seed(m + k + n)
     x = torch.randn(m, k, requires_grad=True)
     w = (torch.randn(n, k) / k ** 0.5).requires_grad_()
