@@ -99,6 +99,8 @@ SIGNATURES = {
     "fsc_conv_l16_stats_layout": (_I, [_D, _I, _P]),
     "fsc_conv_fwd_stats_layout": (_I, [_D, _P]),
     "fsc_conv_fwd_stats": (_I, [_D, _P, _P, _P, _P, _P, _P, _P]),
+    "fsc_conv_fwd_pool_stats_supported": (_I, [_D]),
+    "fsc_conv_fwd_pool_stats": (_I, [_D, _P, _P, _P, _P, _P, _P, _P, _P]),
     "fsc_conv_l16_fwd_stats": (_I, [_D, _P, _P, _P, _P, _P, _P, _P, _P]),
     "fsc_conv_l16_pool_fwd_stats": (_I, [_D, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "fsc_bn_records_fold_conv": (_I, [_P, _I, _I, _I, _I, _I, _P, _P]),

@@ -428,7 +428,11 @@ __device__ __forceinline__ void raw_barrier() { asm volatile("s_waitcnt lgkmcnt(
 // wave, channel) at the end -- conv_l16.hip's record format, folded and finalised by fsc_bn_train_stats_conv: the statistics pass
 // over the output (21 - 25 us per convolution on cfg 3's 14 - 56 MB tensors) disappears.  The host launches it only where a
 // worker keeps ONE channel block (one block in all, or a worker count that is a multiple), no K split, no accumulation.
-template <int KH, int KW, int COT, int PT, int NPROD, bool STATS = false>
+// POOL (with STATS, single rows): the block's entry convolution followed by MaxPool1d(2) (classifiers.py:149-155): a lane's four
+// consecutive positions are two pooling windows -- `out` receives the POOLED tensor (n, c_out, w / 2), `pool_idx` the window
+// positions (fsc_maxpool_fwd's format and tie / NaN rule), the statistics are those of the pooled values; the full-resolution
+// output is never written (113 MB at cfg 3's first block) and the max-pool launch and the statistics pass behind it disappear.
+template <int KH, int KW, int COT, int PT, int NPROD, bool STATS = false, bool POOL = false>
 __global__ __launch_bounds__(kXWaves * 64) void conv_fwd_x3_kernel(Geom g, const float* __restrict__ in,
                                                                const float* __restrict__ packed,
                                                                const float* __restrict__ bias,
@@ -436,7 +440,9 @@ __global__ __launch_bounds__(kXWaves * 64) void conv_fwd_x3_kernel(Geom g, const
                                                                const float* __restrict__ in_amax,
                                                                const float* __restrict__ w_amax,
                                                                const float* __restrict__ stat_pivot = nullptr,
-                                                               float4* __restrict__ stat_rec = nullptr) {
+                                                               float4* __restrict__ stat_rec = nullptr,
+                                                               uint8_t* __restrict__ pool_idx = nullptr) {
+    static_assert(!POOL || (STATS && KH == 1), "POOL: single rows, with the statistics epilogue");
     constexpr int TAPS = KH * KW;
     constexpr int CO_BLK = COT * 16;
     constexpr int PADH = KH / 2, PADW = KW / 2;
@@ -550,6 +556,7 @@ __global__ __launch_bounds__(kXWaves * 64) void conv_fwd_x3_kernel(Geom g, const
     }
     long quad_g[PT];                              // offset of the quad's first pixel in the output tensor (channel 0)
     int quad_ok[PT];                              // bit k: pixel k of the quad lies inside the image
+    const int pool_ow = g.w >> 1;                 // (POOL) windows per row
     auto plan_output = [&](int tile) {
         int t = tile;
         const int twi = t % g.tiles_w; t /= g.tiles_w;
@@ -562,7 +569,8 @@ __global__ __launch_bounds__(kXWaves * 64) void conv_fwd_x3_kernel(Geom g, const
             if (quad_dec[pt] >= 0) {
                 const int b = quad_dec[pt] >> 20, r = (quad_dec[pt] >> 10) & 1023, c = quad_dec[pt] & 1023;
                 if (n0 + b < g.n && h0 + r < g.h) {
-                    quad_g[pt] = (long)(n0 + b) * g.cout * g.hw + (long)(h0 + r) * g.w + (w0 + c);
+                    quad_g[pt] = POOL ? (long)(n0 + b) * g.cout * pool_ow + ((w0 + c) >> 1)        // (columns are multiples of 4)
+                                      : (long)(n0 + b) * g.cout * g.hw + (long)(h0 + r) * g.w + (w0 + c);
                     const int left = g.w - (w0 + c), inbox = g.npix - ((wid * PT + pt) * 16 + (lane & 3) * 4);
                     const int nv = left < inbox ? left : inbox;       // valid pixels of the quad
                     quad_ok[pt] = nv >= 4 ? 15 : nv <= 0 ? 0 : (1 << nv) - 1;
@@ -1016,6 +1024,28 @@ __global__ __launch_bounds__(kXWaves * 64) void conv_fwd_x3_kernel(Geom g, const
                 for (int r = 0; r < 4; ++r)
                     scratch[(kq * 4 + r) * SCR + lm] = F16 ? fmaf(acc[i][j][r] * inv_x, inv_w, bv[r]) : acc[i][j][r] + bv[r];
                 const f32x4 v = *reinterpret_cast<const f32x4*>(scratch + ch * SCR + (lane & 3) * 4);
+                if constexpr (POOL) {
+                    if (co < g.cout) {
+                        float* o = out + quad_g[j] + (long)co * pool_ow;
+                        uint8_t* oi = pool_idx + quad_g[j] + (long)co * pool_ow;
+#pragma unroll
+                        for (int wdw = 0; wdw < 2; ++wdw) {
+                            if ((quad_ok[j] & (3 << (2 * wdw))) != (3 << (2 * wdw))) continue;     // both positions inside the row
+                            float best = v[2 * wdw];
+                            int bi = 0;
+                            const float u = v[2 * wdw + 1];
+                            if (u > best || u != u) { best = u; bi = 1; }
+                            o[wdw] = best;
+                            oi[wdw] = (uint8_t)bi;
+                            const float a = best - pv;
+                            st_s1[i] += a;
+                            st_s2[i] = fmaf(a, a, st_s2[i]);
+                            st_mn[i] = fminf(st_mn[i], best);
+                            st_mx[i] = fmaxf(st_mx[i], best);
+                        }
+                    }
+                    continue;
+                }
                 if constexpr (STATS) {
                     if (co < g.cout && quad_ok[j]) {
 #pragma unroll
@@ -2431,7 +2461,7 @@ bool plan_fwd_f32(const fsc_conv_desc& d, int dgrad, FwdPlan* out) {
     return true;
 }
 
-struct XStat { const float* pivot; float4* rec; };       // statistics records of a STATS forward (null: none)
+struct XStat { const float* pivot; float4* rec; uint8_t* pidx; };       // statistics records of a STATS forward (null: none); POOL
 // where the STATS instantiations exist and a worker keeps one channel block
 bool x3_stats_ok(const FwdPlan& p, const fsc_conv_desc& d) {
     return p.x3 == 1 && !p.s1d && d.kh == 1 && p.cot <= 8 && p.g.ksplit == 1 && p.launch_x > 0 &&
@@ -2440,26 +2470,35 @@ bool x3_stats_ok(const FwdPlan& p, const fsc_conv_desc& d) {
 
 template <int KH, int KW, int COT, int PT, int NPROD>
 void launch_x3_pt(const FwdPlan& p, dim3 grid, const float* in, const float* packed, const float* bias, float* out,
-                  int accumulate, const float* in_amax, hipStream_t st, XStat sa = XStat{nullptr, nullptr}) {
+                  int accumulate, const float* in_amax, hipStream_t st, XStat sa = XStat{nullptr, nullptr, nullptr}) {
     const float* w_amax = packed + x3_limb_floats(p);      // fp16 limbs: the weights' largest magnitude follows the fragments
     if constexpr (NPROD == 1 && KH == 1 && COT <= 8) {
+        if (sa.rec && sa.pidx) {
+            if constexpr (KW == 3) {
+                auto kern = conv_fwd_x3_kernel<KH, KW, COT, PT, NPROD, true, true>;
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes);
+                hipLaunchKernelGGL(kern, grid, dim3(kXWaves * 64), p.lds_bytes, st, p.g, in, packed, bias, out, accumulate, in_amax, w_amax,
+                                   sa.pivot, sa.rec, sa.pidx);
+            }
+            return;
+        }
         if (sa.rec) {
             auto kern = conv_fwd_x3_kernel<KH, KW, COT, PT, NPROD, true>;
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes);
             hipLaunchKernelGGL(kern, grid, dim3(kXWaves * 64), p.lds_bytes, st, p.g, in, packed, bias, out, accumulate, in_amax, w_amax,
-                               sa.pivot, sa.rec);
+                               sa.pivot, sa.rec, (uint8_t*)nullptr);
             return;
         }
     }
     auto kern = conv_fwd_x3_kernel<KH, KW, COT, PT, NPROD>;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes);
     hipLaunchKernelGGL(kern, grid, dim3(kXWaves * 64), p.lds_bytes, st, p.g, in, packed, bias, out, accumulate, in_amax, w_amax,
-                       (const float*)nullptr, (float4*)nullptr);
+                       (const float*)nullptr, (float4*)nullptr, (uint8_t*)nullptr);
 }
 
 template <int KH, int KW, int COT, int PT>
 void launch_x3_arith(const FwdPlan& p, dim3 grid, const float* in, const float* packed, const float* bias, float* out,
-                     int accumulate, const float* in_amax, hipStream_t st, XStat sa = XStat{nullptr, nullptr}) {
+                     int accumulate, const float* in_amax, hipStream_t st, XStat sa = XStat{nullptr, nullptr, nullptr}) {
     if (p.x3 == 3) launch_x3_pt<KH, KW, COT, PT, 3>(p, grid, in, packed, bias, out, accumulate, in_amax, st);
     else if (p.x3 == 1) launch_x3_pt<KH, KW, COT, PT, 1>(p, grid, in, packed, bias, out, accumulate, in_amax, st, sa);
     else if (p.x3 == 6) launch_x3_pt<KH, KW, COT, PT, 6>(p, grid, in, packed, bias, out, accumulate, in_amax, st);
@@ -2468,7 +2507,7 @@ void launch_x3_arith(const FwdPlan& p, dim3 grid, const float* in, const float* 
 
 template <int KH, int KW, int COT>
 int launch_fwd_cot(const FwdPlan& p, const float* in, const float* packed, const float* bias, float* out,
-                   int accumulate, const float* in_amax, hipStream_t st, XStat sa = XStat{nullptr, nullptr}) {
+                   int accumulate, const float* in_amax, hipStream_t st, XStat sa = XStat{nullptr, nullptr, nullptr}) {
     dim3 grid((unsigned)p.grid_x, p.co_blocks, p.g.ksplit);
     if (p.g.ksplit > 1 && !accumulate) {
         const size_t bytes = sizeof(float) * (size_t)p.g.n * p.g.cout * p.g.hw;
@@ -2525,7 +2564,7 @@ int launch_fwd_wide(const FwdPlan& p, const float* in, const float* packed, cons
 
 template <int KH, int KW>
 int launch_fwd(const FwdPlan& p, const float* in, const float* packed, const float* bias, float* out, int accumulate,
-               const float* in_amax, hipStream_t st, XStat sa = XStat{nullptr, nullptr}) {
+               const float* in_amax, hipStream_t st, XStat sa = XStat{nullptr, nullptr, nullptr}) {
     if (p.cot == 10) return launch_fwd_wide<KH, KW, 10>(p, in, packed, bias, out, accumulate, in_amax, st);
     if (p.cot == 15) return launch_fwd_wide<KH, KW, 15>(p, in, packed, bias, out, accumulate, in_amax, st);
     switch (p.cot) {
@@ -2973,10 +3012,28 @@ int fsc_conv_fwd_stats(const fsc_conv_desc* d, const float* in, const float* pac
     FSC_CHECK_ARG(valid_desc(d) && in && packed && out && stat_rec, "fsc_conv_fwd_stats: bad descriptor or null pointer");
     FwdPlan p;
     FSC_CHECK_ARG(plan_fwd(*d, 0, &p) && x3_stats_ok(p, *d), "fsc_conv_fwd_stats: unsupported layer (see fsc_conv_fwd_stats_layout)");
-    const XStat sa{stat_pivot, reinterpret_cast<float4*>(stat_rec)};
+    const XStat sa{stat_pivot, reinterpret_cast<float4*>(stat_rec), nullptr};
     hipStream_t st = fsc::as_stream(stream);
     if (d->kw == 3) return launch_fwd<1, 3>(p, in, packed, bias, out, 0, nullptr, st, sa);
     return launch_fwd<1, 1>(p, in, packed, bias, out, 0, nullptr, st, sa);
+}
+
+/* fsc_conv_fwd_stats of a k3 Conv1d followed by MaxPool1d(2) in one launch: `pooled` (n, c_out, 1, w / 2) and `pool_idx` (same
+ * shape, bytes) are what fsc_maxpool_fwd would give on the convolution's output -- which is never written --, the records are the
+ * statistics of the POOLED tensor (layout: fsc_conv_fwd_stats_layout of the same descriptor). */
+int fsc_conv_fwd_pool_stats_supported(const fsc_conv_desc* d) {
+    FwdPlan p;
+    return (valid_desc(d) && d->kh == 1 && d->kw == 3 && d->h == 1 && d->w >= 2 && plan_fwd(*d, 0, &p) && x3_stats_ok(p, *d)) ? 1 : 0;
+}
+
+int fsc_conv_fwd_pool_stats(const fsc_conv_desc* d, const float* in, const float* packed, const float* bias, float* pooled,
+                            uint8_t* pool_idx, const float* stat_pivot, void* stat_rec, fsc_stream_t stream) {
+    FSC_CHECK_ARG(valid_desc(d) && in && packed && pooled && pool_idx && stat_rec, "fsc_conv_fwd_pool_stats: bad descriptor or null pointer");
+    FSC_CHECK_ARG(fsc_conv_fwd_pool_stats_supported(d), "fsc_conv_fwd_pool_stats: unsupported layer (see fsc_conv_fwd_pool_stats_supported)");
+    FwdPlan p;
+    plan_fwd(*d, 0, &p);
+    const XStat sa{stat_pivot, reinterpret_cast<float4*>(stat_rec), pool_idx};
+    return launch_fwd<1, 3>(p, in, packed, bias, pooled, 0, nullptr, fsc::as_stream(stream), sa);
 }
 
 int fsc_amax(const float* x, long n, float* out, fsc_stream_t stream) {

@@ -396,6 +396,41 @@ def conv_pool_forward(x, weight, bias):
     return y, idx, (n, c_out, h, w)
 
 
+CONV_POOL_1D = os.environ.get("FSC_CONV_POOL_1D", "1") != "0"
+_POOL1D_OK = {}
+
+
+def conv_pool1d_forward(x, weight, bias, stats_bn):
+    """k3 Conv1d fused with MaxPool1d(2) and the statistics of the BatchNorm behind the pool (classifiers.py:149-156; plain bf16,
+    ring-kernel tiling: fsc_conv_fwd_pool_stats): (pooled, window index, conv output shape) with the records left for bn_prepare on
+    the pooled tensor, or None (the caller then runs the convolution, the pool and the statistics pass)."""
+    n, c_in, h, w = x.shape
+    c_out, _, kh, kw = weight.shape
+    if not (CONV_POOL_1D and CONV_STATS and h == 1 and kh == 1 and kw == 3 and stats_bn is not None and stats_bn[1]):
+        return None
+    d = _desc(n, c_in, c_out, h, w, kh, kw)
+    if d.arith != 1:
+        return None
+    key = _desc_key(d)
+    if key not in _POOL1D_OK:
+        out4 = (C.c_int * 4)()
+        ok = _lib.load().fsc_conv_fwd_pool_stats_supported(C.byref(d)) and _lib.load().fsc_conv_fwd_stats_layout(C.byref(d), out4)
+        _POOL1D_OK[key] = tuple(out4) if ok else None
+    lay = _POOL1D_OK[key]
+    if lay is None:
+        return None
+    bn, training = stats_bn
+    packed = conv_pack(d, weight, 0)
+    y = _empty((n, c_out, 1, w // 2), x)
+    idx = _empty((n, c_out, 1, w // 2), x, torch.uint8)
+    rec = torch.empty(lay[0] * 8 * lay[2] * 4, device=x.device, dtype=torch.float32)
+    pivot = bn.running_mean if bn_tracks(bn, training) else None
+    with _timed(d, 0):
+        call("fsc_conv_fwd_pool_stats", C.byref(d), ptr(x), ptr(packed), ptr(bias), ptr(y), ptr(idx), ptr(pivot), ptr(rec), stream_ptr())
+    _stats_end(lay, rec, y, c_out)
+    return y, idx, (n, c_out, h, w)
+
+
 def conv_dgrad(dout, weight, x_shape, accumulate_into=None, dout_amax=None):
     """Gradient w.r.t. the conv input.  With `accumulate_into` the result is added in place."""
     n, c_in, h, w = x_shape
@@ -1829,6 +1864,8 @@ def _block_forward(x, mods, training, want_head, ph, keep, sync=None, next_bn=Fa
         st_b = None
         k.c_shape = (a_16.shape[0], w_a.shape[0], a_16.shape[2], a_16.shape[3])
     fused = conv_pool_forward(a, w_a, b_a) if (ph == 2 and a is not None and pool_act is None) else None
+    if fused is None and ph == 1 and a is not None and pool_act is None and training:
+        fused = conv_pool1d_forward(a, w_a, b_a, (bn_b, training))
     if fused is not None:
         p, pidx, k.c_shape = fused
         if keep:

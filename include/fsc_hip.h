@@ -360,6 +360,12 @@ int fsc_bn_records_fold(const void* records, const float* y, int n, int c, long 
  * = that BatchNorm's running mean, or NULL = 0).  `_layout` returns 0 where the layer has no such kernel (other arithmetics, 2-d
  * planes, the small-layer kernels of conv_s1d.hip, split-K plans). */
 int fsc_conv_fwd_stats_layout(const fsc_conv_desc* d, int* out4);
+/* ... and of a k3 Conv1d followed by MaxPool1d(2) (the entry convolution of a block of the 1-d model, classifiers.py:149-155) in one
+ * launch: `pooled` (n, c_out, 1, w / 2) and `pool_idx` (bytes, same shape) are what fsc_maxpool_fwd gives on the convolution's
+ * output -- which is never written --, the records are the statistics of the POOLED tensor (same layout query). */
+int fsc_conv_fwd_pool_stats_supported(const fsc_conv_desc* d);
+int fsc_conv_fwd_pool_stats(const fsc_conv_desc* d, const float* in, const float* packed, const float* bias, float* pooled,
+                            uint8_t* pool_idx, const float* stat_pivot, void* stat_rec, fsc_stream_t stream);
 int fsc_conv_fwd_stats(const fsc_conv_desc* d, const float* in, const float* packed, const float* bias, float* out,
                        const float* stat_pivot, void* stat_rec, fsc_stream_t stream);
 /* Shader clock (MHz) the chip ran the LAST L16 convolution launch at (which = 0: fsc_conv_l16_fwd family on two-limb

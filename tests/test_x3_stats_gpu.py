@@ -78,3 +78,46 @@ def test_layers_without_such_a_kernel(bf16):
     with pytest.raises(_lib.FscError):
         d = F._desc(128, 476, 476, 1, 3, 1, 3)
         F.call("fsc_conv_fwd_stats", C.byref(d), F.ptr(x), F.ptr(x), None, F.ptr(x), None, F.ptr(rec), F.stream_ptr())
+
+
+# the entry convolutions of cfg 3's blocks 0 - 2 at batch 128, odd rows (a last position without a window), a partly filled batch
+POOL_CASES = [(128, 129, 64, 3446), (128, 64, 80, 1723), (128, 80, 100, 861), (64, 64, 64, 1001), (32, 48, 64, 2050)]
+
+
+@pytest.mark.parametrize("case", POOL_CASES)
+def test_convolution_max_pool_and_statistics_in_one_launch(case, bf16):
+    n, ci, co, length = case
+    torch.manual_seed(sum(case))
+    x = torch.randn(n, ci, 1, length, device=DEV)
+    w = torch.randn(co, ci, 1, 3, device=DEV) / (ci * 3) ** 0.5
+    b = torch.randn(co, device=DEV) * 2.0
+    x[0, :, 0, 4:8] = 0.0                                      # (equal neighbours: the first position of a window wins)
+    d = F._desc(n, ci, co, 1, length, 1, 3)
+    assert _lib.load().fsc_conv_fwd_pool_stats_supported(C.byref(d)) == 1, F.plan_name(d, 0)
+    full = F.conv_forward(x, w, b)
+    p_ref, idx_ref = F.maxpool_forward(full, 1)
+    bn1, bn2 = (torch.nn.BatchNorm2d(co).to(DEV).train() for _ in range(2))
+    for bn in (bn1, bn2):
+        with torch.no_grad():
+            bn.running_mean.copy_(b + 0.5)
+    F._PRESTATS.clear()
+    got = F.conv_pool1d_forward(x, w, b, (bn1, True))
+    assert got is not None and F._PRESTATS
+    p, idx, c_shape = got
+    assert c_shape == (n, co, 1, length) and tuple(p.shape) == (n, co, 1, length // 2)
+    assert torch.equal(p, p_ref) and torch.equal(idx, idx_ref)
+    st1 = F.bn_prepare(p, bn1, True)
+    assert not F._PRESTATS
+    st2 = F.bn_prepare(p_ref, bn2, True)
+    assert torch.equal(st1.minmax, st2.minmax)
+    assert float((st1.mean - st2.mean).abs().max()) < 2e-6 * float(st2.mean.abs().max())
+    assert float((st1.invstd / st2.invstd - 1).abs().max()) < 1e-5
+    assert float((bn1.running_var / bn2.running_var - 1).abs().max()) < 1e-5
+
+
+def test_no_pool_fusion_where_the_layer_has_no_such_kernel(bf16):
+    assert _lib.load().fsc_conv_fwd_pool_stats_supported(C.byref(F._desc(128, 381, 476, 1, 6, 1, 3))) == 0       # conv_s1d
+    assert _lib.load().fsc_conv_fwd_pool_stats_supported(C.byref(F._desc(128, 64, 64, 1, 1723, 1, 1))) == 0      # 1 x 1
+    x = torch.randn(128, 381, 1, 6, device=DEV)
+    w = torch.randn(476, 381, 1, 3, device=DEV) * 0.03
+    assert F.conv_pool1d_forward(x, w, None, (torch.nn.BatchNorm2d(476).to(DEV).train(), True)) is None
