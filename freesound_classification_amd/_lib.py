@@ -140,6 +140,7 @@ SIGNATURES = {
     "fsc_adam_amsgrad_step_dev": (_I, [C.POINTER(OptTensor), _I, _P, _F, _F, _F, _F, _F, _P]),
     "fsc_sgd_nesterov_step": (_I, [C.POINTER(OptTensor), _I, _F, _F, _F, _I, _F, _P]),
     "fsc_plane_border_sums": (_I, [_P, _I, _I, _I, _I, _P, _P]),
+    "fsc_first_block_1d_finish": (_I, [_P] * 8 + [_I, _I, _I, _I, _P, _P, _P, _P]),
     "fsc_fill": (_I, [_P, _F, _L, _P]),
     "fsc_axpy": (_I, [_P, _F, _P, _L, _P]),
 }

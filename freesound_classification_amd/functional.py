@@ -2061,6 +2061,9 @@ def _stem_bn_grads(dc, dc_chan_sum, weight, dweight, bn, borders=None):
 FIRST_BLOCK_1D_IDENTITY = os.environ.get("FSC_FIRST_BLOCK_1D_IDENTITY", "1") == "1"
 
 
+FIRST_BLOCK_1D_KERNEL = os.environ.get("FSC_FIRST_BLOCK_1D_KERNEL", "1") != "0"
+
+
 def _first_block_grads_1d(x, st, dc, dc_chan_sum, weight, bn):
     """First block of the 1-d model (reference classifiers.py:147-154: BatchNorm1d -> Conv1d(k = 3) on the spectrogram, which needs no
     gradient): the convolution's weight gradient AND the BatchNorm's dgamma / dbeta from ONE weight-gradient pass over the RAW input x
@@ -2076,6 +2079,14 @@ def _first_block_grads_1d(x, st, dc, dc_chan_sum, weight, bn):
     c_out, c_in = weight.shape[0], weight.shape[1]
     dwx = conv_wgrad(x, dc, weight.shape, False)
     wgrad_flush(end=False)                                   # (read here)
+    if FIRST_BLOCK_1D_KERNEL and bn.weight is not None and bn.bias is not None and c_out <= 2048:
+        # the same arithmetic in one launch (fsc_first_block_1d_finish) instead of ~15 broadcast / reduction launches of torch
+        out = GRAD_OUT(weight) if GRAD_OUT is not None else None
+        dw = out if out is not None else torch.empty_like(weight)
+        dgamma, dbeta = _empty((c_in,), x), _empty((c_in,), x)
+        call("fsc_first_block_1d_finish", ptr(dwx), ptr(dc), ptr(dc_chan_sum), ptr(st.mean), ptr(st.invstd), ptr(bn.weight),
+             ptr(bn.bias), ptr(weight), x.shape[0], c_in, c_out, dc.shape[3], ptr(dw), ptr(dgamma), ptr(dbeta), stream_ptr())
+        return dw, dgamma, dbeta
     tot = dc_chan_sum
     t = torch.stack([tot - dc[:, :, 0, 0].sum(0), tot, tot - dc[:, :, 0, -1].sum(0)], 1)          # (c_out, 3)
     mu, istd = st.mean, st.invstd

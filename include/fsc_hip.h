@@ -579,6 +579,14 @@ int fsc_sgd_nesterov_step(const fsc_opt_tensor* tensors_host, int n_tensors, flo
  * last column and the four corner elements.  Used to obtain the first block's input-BN parameter gradients from the stem
  * convolution's weight gradient instead of its input gradient (classifiers.py:524-531). */
 int fsc_plane_border_sums(const float* x, int n, int c, int h, int w, float* out, fsc_stream_t stream);
+/* First block of the 1-d model (classifiers.py:147-154: BatchNorm1d -> Conv1d(k = 3) on a spectrogram that needs no gradient): the
+ * Conv1d weight gradient and the BatchNorm's dgamma / dbeta from the weight-gradient pass over the BatchNorm's RAW input, in one
+ * launch: dwx (c_out, c_in, 3) = fsc_conv_wgrad(x, dc), dc (n, c_out, 1, len) the convolution's output gradient, dc_chan_sum
+ * (c_out) its per-channel sum; with T[co][t] = dc_chan_sum minus dc's first (t = 0) / last (t = 2) column summed over the images
+ * and C = invstd (dwx - mean T):  dw = gamma C + beta T, dgamma[ci] = sum w C, dbeta[ci] = sum w T. */
+int fsc_first_block_1d_finish(const float* dwx, const float* dc, const float* dc_chan_sum, const float* mean, const float* invstd,
+                              const float* gamma, const float* beta, const float* weight, int n, int c_in, int c_out, int len,
+                              float* dw, float* dgamma, float* dbeta, fsc_stream_t stream);
 /* out[0] = min |x[i]| over n >= 1 floats (one small launch: the guard of a division by a parameter vector) */
 int fsc_absmin(const float* x, long n, float* out, fsc_stream_t stream);
 /* split = 0: out (rows, sum widths) = the `count` <= 16 column pieces (rows, widths[i]) side by side (torch.cat(feats, -1),
