@@ -37,8 +37,8 @@ for ev in prof.events():
                    "aten::mul", "aten::sum", "aten::contiguous", "aten::_to_copy"):
         if ev.cpu_parent is not None and ev.cpu_parent.name.startswith("aten::"):
             continue
-        stack = [s for s in (ev.stack or []) if "freesound_classification_amd" in s or "bench.py" in s or "autograd" in s]
-        groups[(ev.name, tuple(stack[:3]))] += 1
+        stack = [s for s in (ev.stack or []) if "freesound_classification_amd" in s or "bench.py" in s or "autograd" in s or "prof_fills" in s]
+        groups[(ev.name, tuple(stack[:3]) if stack else tuple((ev.stack or [])[:2]))] += 1
         names[ev.name] += 1
 print(names)
 for (n, st), k in groups.most_common(60):
