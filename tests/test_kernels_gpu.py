@@ -542,6 +542,31 @@ def test_dropout_statistics_and_backward():
     assert F.dropout(x, 0.7, False) is x
 
 
+@pytest.mark.parametrize("n,c", [(128, 80), (5, 256), (3, 300), (7, 64), (4, 65)])
+def test_lsep_over_the_pairs_that_exist(n, c):
+    """c <= 256: the kernels that list the classes with partners (multi-hot labels: the positives) against the oracle's pairwise
+    table (reference networks/losses.py:47-58) -- no positives, everything positive, soft targets, c > 256 (the masked kernels)."""
+    from freesound_classification_amd.networks.losses import lsep_loss
+    from oracle import ref_torch as oref
+    torch.manual_seed(n * c)
+    logits = 2.0 * torch.randn(n, c)
+    labels = (torch.rand(n, c) < 0.03).float()
+    labels[0] = 0.0                                  # no positive: loss 0, gradient 0
+    labels[1] = 1.0                                  # nothing below: the same
+    labels[2] = torch.rand(c)                        # soft targets: every class but the smallest has partners
+    labels[min(3, n - 1), 5] = 1.0
+    ref_x = logits.clone().requires_grad_()
+    ref = oref.lsep(ref_x, labels, average=False)
+    w = torch.rand(n)
+    (ref * w).sum().backward()
+    x = logits.to(DEV).requires_grad_()
+    val = lsep_loss(x, labels.to(DEV), average=False)
+    (val * w.to(DEV)).sum().backward()
+    assert maxdiff(val, ref) < 2e-5 * max(1.0, float(ref.abs().max()))
+    assert maxdiff(x.grad, ref_x.grad) < 2e-5
+    assert float(val[0]) == 0.0 and float(x.grad[0].abs().max()) == 0.0 and float(val[1]) == 0.0
+
+
 def test_losses_golden(golden):
     from freesound_classification_amd.networks.losses import binary_cross_entropy, lsep_loss
     g = golden("g6_losses.npz")
