@@ -2066,11 +2066,16 @@ __global__ __launch_bounds__(kRedX * kRedY) void wgrad_reduce_kernel(const float
     if (co < c_out) {
         const float* p = part + ((long)tap * ci_pad + ci) * co_pad + co;
         int sp = threadIdx.y;
-        for (; sp + kRedY < nsplit; sp += 2 * kRedY) {
+        float s2 = 0.f, s3 = 0.f;                 // (four loads in flight: 64 slices are 16 per thread)
+        for (; sp + 3 * kRedY < nsplit; sp += 4 * kRedY) {
             s0 += p[(long)sp * slice];
             s1 += p[(long)(sp + kRedY) * slice];
+            s2 += p[(long)(sp + 2 * kRedY) * slice];
+            s3 += p[(long)(sp + 3 * kRedY) * slice];
         }
-        if (sp < nsplit) s0 += p[(long)sp * slice];
+        for (; sp < nsplit; sp += kRedY) s0 += p[(long)sp * slice];
+        s0 += s2;
+        s1 += s3;
     }
     red[threadIdx.y][threadIdx.x] = s0 + s1;
     __syncthreads();
@@ -2104,11 +2109,16 @@ __global__ __launch_bounds__(kRedX * kRedY) void wgrad_reduce_multi_kernel(RedJo
     if (co < q.c_out) {
         const float* p = q.part + ((long)tap * q.ci_pad + ci) * q.co_pad + co;
         int sp = threadIdx.y;
-        for (; sp + kRedY < q.nsplit; sp += 2 * kRedY) {
+        float s2 = 0.f, s3 = 0.f;
+        for (; sp + 3 * kRedY < q.nsplit; sp += 4 * kRedY) {
             s0 += p[(long)sp * slice];
             s1 += p[(long)(sp + kRedY) * slice];
+            s2 += p[(long)(sp + 2 * kRedY) * slice];
+            s3 += p[(long)(sp + 3 * kRedY) * slice];
         }
-        if (sp < q.nsplit) s0 += p[(long)sp * slice];
+        for (; sp < q.nsplit; sp += kRedY) s0 += p[(long)sp * slice];
+        s0 += s2;
+        s1 += s3;
     }
     red[threadIdx.y][threadIdx.x] = s0 + s1;
     __syncthreads();
