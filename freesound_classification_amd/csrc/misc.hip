@@ -253,14 +253,23 @@ __global__ __launch_bounds__(256) void first_block_1d_kernel(const float* __rest
     // border columns of dc summed over the images: thread = (channel, quarter of the batch)
     for (int e = tid; e < 4 * c_out; e += 256) {
         const int co = e >> 2, q = e & 3;
-        float f = 0.f, l = 0.f;
-        for (int b = q; b < n; b += 4) {
-            const float* p = dc + ((long)b * c_out + co) * len;
-            f += p[0];
-            l += p[len - 1];
+        float f[4] = {0.f, 0.f, 0.f, 0.f}, l[4] = {0.f, 0.f, 0.f, 0.f};      // (eight loads in flight: a chain of n / 4 round trips otherwise)
+        int b = q;
+        for (; b + 12 < n; b += 16) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float* p = dc + ((long)(b + 4 * u) * c_out + co) * len;
+                f[u] += p[0];
+                l[u] += p[len - 1];
+            }
         }
-        part[(co * 2) * 4 + q] = f;
-        part[(co * 2 + 1) * 4 + q] = l;
+        for (; b < n; b += 4) {
+            const float* p = dc + ((long)b * c_out + co) * len;
+            f[0] += p[0];
+            l[0] += p[len - 1];
+        }
+        part[(co * 2) * 4 + q] = (f[0] + f[1]) + (f[2] + f[3]);
+        part[(co * 2 + 1) * 4 + q] = (l[0] + l[1]) + (l[2] + l[3]);
     }
     __syncthreads();
     for (int co = tid; co < c_out; co += 256) {
