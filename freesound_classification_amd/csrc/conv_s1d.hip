@@ -520,12 +520,14 @@ __global__ __launch_bounds__(kWWaves * 64) void s1d_wgrad_seg_kernel(WArgs a, in
 // (re-measured with 64-channel workgroups, profiles/r06_s1d_layers.txt last table: k = 3 wins up to rows of 215 frames (27.5 k
 // positions: 27 -> 19 us) and loses at 430 (29 against 27 us); k = 1 -- a third of the gathers -- still wins there (27 -> 24 us)
 // and loses at 861; the weight gradient's segment form wins or ties up to 55 k positions (38 -> 28 us on 100 -> 100 k1 @ 430))
-int max_px(int taps) {
+// (the FORWARD of a k = 1 layer at 55 k positions goes back to the ring kernel since that has the statistics epilogue: 27 us with
+// the BatchNorm statistics against 24 + a 16 us statistics pass; the input gradient keeps the gathers)
+int max_px(int taps, int dgrad) {
     static const int v = [] {
         const char* e = getenv("FSC_S1D_MAXPX");
         return e ? atoi(e) : -1;
     }();
-    return v >= 0 ? v : (taps == 1 ? 65536 : 32768);
+    return v >= 0 ? v : ((taps == 1 && dgrad) ? 65536 : 32768);
 }
 int max_px_small() {
     static const int v = [] {
@@ -574,7 +576,7 @@ bool plan_fwd(const fsc_conv_desc& d, int dgrad, Plan* out) {
     p.npix = (long)d.n * d.h * d.w;
     // ranges: the bf16 kernels on 1-d rows as measured (max_px); 2-d planes and the nine-product arithmetic take the layers the
     // persistent kernels cannot fill (cfg 2's last block: 759 channels on 2 x 6 pixels, 1536 positions at batch 128)
-    const long cap = (p.nprod == 1 && d.h == 1) ? max_px(p.taps) : max_px_small();
+    const long cap = (p.nprod == 1 && d.h == 1) ? max_px(p.taps, dgrad) : max_px_small();
     if (p.npix > cap || p.cin < 32 || p.cout < 48) return false;
     const int rem = p.cin % 32;
     p.nfull = p.cin / 32 + (rem > 24 ? 1 : 0);

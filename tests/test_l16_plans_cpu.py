@@ -65,14 +65,16 @@ def test_cfg3_late_blocks_weight_gradients_run_one_unit_per_workgroup():
         txt = _describe(d, 2)
         assert txt.startswith("conv_s1d_wgrad_kernel<1,%d>" % k) and "units=%d split=%d " % (units, split) in txt, txt
         assert _describe(d, 0).startswith("conv_s1d_fwd_kernel<1,%d>" % k) and _describe(d, 1).startswith("conv_s1d_fwd_kernel")
-    # the ranges: k = 3 forward / input gradient up to 32 768 positions, k = 1 and the weight gradient's segment form up to 65 536;
-    # rows above keep the round-1 kernels in every direction
+    # the ranges: forward and k = 3 input gradient up to 32 768 positions, the k = 1 input gradient and the weight gradient's segment
+    # form up to 65 536 (the k = 1 FORWARD at 55 k positions is the ring kernel's again: it has the statistics epilogue); rows above
+    # keep the round-1 kernels in every direction
     d = F._desc(128, 125, 156, 1, 215, 1, 3, 1)
     assert _describe(d, 0).startswith("conv_s1d_fwd_kernel") and _describe(d, 2).startswith("conv_s1d_wgrad_kernel")
     d = F._desc(128, 100, 100, 1, 430, 1, 3, 1)
     assert _describe(d, 0).startswith("conv_fwd_x3_kernel") and _describe(d, 2).startswith("conv_s1d_wgrad_kernel")
     d = F._desc(128, 100, 100, 1, 430, 1, 1, 1)
-    assert _describe(d, 0).startswith("conv_s1d_fwd_kernel") and _describe(d, 2).startswith("conv_s1d_wgrad_kernel")
+    assert _describe(d, 0).startswith("conv_fwd_x3_kernel") and _describe(d, 1).startswith("conv_s1d_fwd_kernel")
+    assert _describe(d, 2).startswith("conv_s1d_wgrad_kernel")
     d = F._desc(128, 80, 80, 1, 861, 1, 1, 1)
     assert _describe(d, 0).startswith("conv_fwd_x3_kernel") and _describe(d, 2).startswith("conv_wgrad_kernel")
 

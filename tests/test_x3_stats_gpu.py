@@ -26,7 +26,7 @@ def _layout(d):
 
 
 # cfg 3's blocks 0 - 2 at batch 128 (k3 and k1), a batch that does not fill the workers, a shape whose last tile overhangs the row
-CASES = [(128, 64, 64, 1723, 3), (128, 64, 64, 1723, 1), (128, 80, 80, 861, 3), (128, 100, 100, 430, 3), (32, 64, 80, 1500, 3),
+CASES = [(128, 64, 64, 1723, 3), (128, 64, 64, 1723, 1), (128, 80, 80, 861, 3), (128, 100, 100, 430, 3), (128, 100, 100, 430, 1), (32, 64, 80, 1500, 3),
          (16, 48, 64, 3001, 3)]
 
 
