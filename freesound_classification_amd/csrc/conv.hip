@@ -1094,8 +1094,11 @@ __global__ __launch_bounds__(kXWaves * 64) void conv_fwd_x3_kernel(Geom g, const
             b += __shfl_xor(b, 1, 64); b += __shfl_xor(b, 2, 64);
             mn = fminf(mn, __shfl_xor(mn, 1, 64)); mn = fminf(mn, __shfl_xor(mn, 2, 64));
             mx = fmaxf(mx, __shfl_xor(mx, 1, 64)); mx = fmaxf(mx, __shfl_xor(mx, 2, 64));
-            if ((lane & 3) == 0)
-                stat_rec[((long)blockIdx.x * kXWaves + wid) * CO_BLK_ + i * 16 + (lane >> 2)] = make_float4(a, b, mn, mx);
+            // (transposed: [channel][slot] -- the fold's workgroup of a channel reads its slots contiguously; layout order 2)
+            if ((lane & 3) == 0) {
+                const int chn = (int)(blockIdx.x % g.x_coblk) * CO_BLK_ + i * 16 + (lane >> 2);
+                stat_rec[(long)chn * ((long)gridDim.x * kXWaves) + (long)blockIdx.x * kXWaves + wid] = make_float4(a, b, mn, mx);
+            }
         }
     }
 }
@@ -3007,13 +3010,13 @@ int fsc_conv_fwd(const fsc_conv_desc* d, const float* in, const float* packed, c
     return launch_fwd<1, 1>(p, in, packed, bias, out, accumulate, in_amax, st);
 }
 
-/* statistics records of fsc_conv_fwd_stats: out4 = {workers, channel blocks, channels per block, order (0)}; workers * 8 * channels-per-
- * block float4 {sum (y - pivot), sum (y - pivot)^2, min, max} -- the record format of fsc_conv_l16_stats_layout.  0: no such kernel
+/* statistics records of fsc_conv_fwd_stats: out4 = {workers, channel blocks, channels per block, order (2: transposed, [channel][slot])};
+ * workers * 8 * channels-per-block float4 {sum (y - pivot), sum (y - pivot)^2, min, max} -- the records of fsc_conv_l16_stats_layout.  0: no such kernel
  * for this layer (anything but plain bf16 arithmetic on 1-d rows with a ring-kernel tiling). */
 int fsc_conv_fwd_stats_layout(const fsc_conv_desc* d, int* out4) {
     FwdPlan p;
     if (!valid_desc(d) || !out4 || !plan_fwd(*d, 0, &p) || !x3_stats_ok(p, *d)) return 0;
-    out4[0] = (int)p.launch_x; out4[1] = p.co_blocks; out4[2] = p.cot * 16; out4[3] = 0;
+    out4[0] = (int)p.launch_x; out4[1] = p.co_blocks; out4[2] = p.cot * 16; out4[3] = 2;      // (order 2: [channel][slot])
     return 1;
 }
 

@@ -368,7 +368,7 @@ def conv_forward(x, weight, bias, x_amax=None, stats_bn=None):
         lay = _X3_STATS_LAYOUT[key]
         if lay is not None:
             bn, training = stats_bn
-            rec = torch.empty(lay[0] * 8 * lay[2] * 4, device=x.device, dtype=torch.float32)
+            rec = torch.empty(lay[0] * 8 * lay[1] * lay[2] * 4, device=x.device, dtype=torch.float32)     # ([channel][slot])
             pivot = bn.running_mean if bn_tracks(bn, training) else None
             with _timed(d, 0):
                 call("fsc_conv_fwd_stats", C.byref(d), ptr(x), ptr(packed), ptr(bias), ptr(out), ptr(pivot), ptr(rec), stream_ptr())
@@ -423,7 +423,7 @@ def conv_pool1d_forward(x, weight, bias, stats_bn):
     packed = conv_pack(d, weight, 0)
     y = _empty((n, c_out, 1, w // 2), x)
     idx = _empty((n, c_out, 1, w // 2), x, torch.uint8)
-    rec = torch.empty(lay[0] * 8 * lay[2] * 4, device=x.device, dtype=torch.float32)
+    rec = torch.empty(lay[0] * 8 * lay[1] * lay[2] * 4, device=x.device, dtype=torch.float32)
     pivot = bn.running_mean if bn_tracks(bn, training) else None
     with _timed(d, 0):
         call("fsc_conv_fwd_pool_stats", C.byref(d), ptr(x), ptr(packed), ptr(bias), ptr(y), ptr(idx), ptr(pivot), ptr(rec), stream_ptr())

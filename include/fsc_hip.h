@@ -358,7 +358,8 @@ int fsc_bn_records_fold(const void* records, const float* y, int n, int c, long 
  * early blocks (classifiers.py:147-163, 78-101: every Conv1d of a ResnetBlock feeds a BatchNorm): fsc_conv_fwd (forward, no
  * accumulation) that also leaves the record format of fsc_conv_l16_stats_layout for fsc_bn_train_stats_conv (sums about `stat_pivot`
  * = that BatchNorm's running mean, or NULL = 0).  `_layout` returns 0 where the layer has no such kernel (other arithmetics, 2-d
- * planes, the small-layer kernels of conv_s1d.hip, split-K plans). */
+ * planes, the small-layer kernels of conv_s1d.hip, split-K plans).  out4[3] = 2: these records are TRANSPOSED -- [channel][slot],
+ * out4[0] * 8 * out4[1] * out4[2] float4 in all -- so that the fold reads a channel's slots contiguously. */
 int fsc_conv_fwd_stats_layout(const fsc_conv_desc* d, int* out4);
 /* ... and of a k3 Conv1d followed by MaxPool1d(2) (the entry convolution of a block of the 1-d model, classifiers.py:149-155) in one
  * launch: `pooled` (n, c_out, 1, w / 2) and `pool_idx` (bytes, same shape) are what fsc_maxpool_fwd gives on the convolution's
